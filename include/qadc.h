@@ -1,0 +1,158 @@
+/*
+ * qadc.h — C-ABI of the MI355X-native Quick-ADC scan engine (libqadc_hip.so).
+ *
+ * Drop-in boundary for ONE path of technicolor-research/quick-adc: the 4-bit PQ scan + top-R
+ * that lives behind the reference's duck-typed ScannerType.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference tree).  Plain
+ * pointers and sizes only; no C++ types, no exceptions cross this boundary.  All functions
+ * return QADC_OK (0) or a negative QADC_E_* code; qadc_last_error() gives the message of the
+ * last failure on the calling thread.
+ *
+ * Threading: one host thread drives one index (as the reference's query loop,
+ * query_common.hpp:351-365).  One index = one GPU (one process per GPU for multi-GPU).
+ */
+#ifndef QADC_H_
+#define QADC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QADC_OK 0
+#define QADC_E_ARG (-1)       /* bad argument (unsupported M, mixed labels, not finalized, ...) */
+#define QADC_E_HIP (-2)       /* HIP runtime failure */
+#define QADC_E_CAPACITY (-3)  /* candidate buffer too small even after regrowth / caller buffer too small */
+#define QADC_E_STATE (-4)     /* call out of order */
+
+typedef struct qadc_index qadc_index;
+
+const char* qadc_last_error(void);
+const char* qadc_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Database side — replaces scanner_4::prepare_database (db_query_4.cpp:210-228) and the layout
+ * step interleave_partition_4 (simd_layout.hpp:55-65).  The device layout is plain row-major
+ * [n][M/2] (one coalesced 16-byte load per lane); the 16-code block transpose is an AVX2 need.
+ * ------------------------------------------------------------------------------------------- */
+
+/* M = 16 or 32 sub-quantizers of 4 bits (get_simd_scan_func_epi8, db_query_4.cpp:22-35). */
+int qadc_index_create(qadc_index** out, int M, int device_id);
+int qadc_index_destroy(qadc_index* idx);
+
+/* Append partitions given as base_db::get_partition() yields them (databases.hpp:50-55):
+ * row-major codes [sizes[p]][M/2], labels[p] = u32[sizes[p]] or labels == NULL for a flat DB
+ * (key = position).  Host buffers are copied to the GPU; the caller may free them afterwards
+ * (the reference does, db_query_4.cpp:190).  All-or-none labels (db_query_4.cpp:118-124). */
+int qadc_index_add_partitions(qadc_index* idx, int part_count, const uint8_t* const* codes,
+                              const uint32_t* const* labels, const uint32_t* sizes);
+
+/* Append one partition already laid out in the reference's block layout [ceil(n/16)][M/2][16]
+ * (what scanner_4::parts holds, db_query_4.cpp:171-177); converted on the GPU. */
+int qadc_index_add_partition_interleaved(qadc_index* idx, const uint8_t* interleaved,
+                                         const uint32_t* labels, uint32_t size);
+
+/* Append one partition whose row-major codes (and labels) already live in device memory of this
+ * GPU (borrowed, not freed; must stay valid; 16-byte aligned, readable up to size*M/2 rounded up
+ * to 16 bytes). */
+int qadc_index_add_partition_device(qadc_index* idx, const void* d_codes, const void* d_labels, uint32_t size);
+
+/* Append one synthetic flat partition generated on the GPU: 8-byte word w of the code stream =
+ * splitmix64(seed ^ splitmix64(first_word + w)) (reproducible on the CPU). */
+int qadc_index_add_partition_synthetic(qadc_index* idx, uint32_t size, uint64_t seed, uint64_t first_word);
+
+/* Keys reported for an unlabeled partition are key_base + position (shard offset for multi-GPU). */
+int qadc_index_set_key_base(qadc_index* idx, int part, uint32_t key_base);
+
+/* Fix the "starts" sizes: max(1, unsigned(size * keep)) with the product in float
+ * (db_query_4.cpp:125-126).  keep is a fraction (the CLI's -k percent * 0.01). */
+int qadc_index_finalize(qadc_index* idx, float keep);
+
+int qadc_index_partition_count(const qadc_index* idx);
+uint32_t qadc_index_partition_size(const qadc_index* idx, int part);
+uint32_t qadc_index_start_size(const qadc_index* idx, int part);
+
+/* Tunables: "quant_mode" (1 = as compiled by the reference's flags, 0 = source level),
+ * "cand_capacity", "level_base", "level_growth", "wgs_per_item", "profile" (0/1). */
+int qadc_set_option(qadc_index* idx, const char* name, double value);
+
+/* Copy codes back (tests / checksums): partition `part`, codes [first, first+count). */
+int qadc_index_read_codes(qadc_index* idx, int part, uint32_t first, uint32_t count, uint8_t* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Query side.
+ * ------------------------------------------------------------------------------------------- */
+
+/* scanner_4::query_scan (db_query_4.cpp:245-309) for nq queries at once.
+ *   assign  [nq][ma]          probed partitions in scan order (index_db::assign_compute_residuals)
+ *   tables  [nq][ma][M*16]    float distance tables; MUTATED like the reference (negatives -> 0)
+ *   R                         heap capacity (-r)
+ * Outputs, per query q (any may be NULL):
+ *   keys[q][R], values[q][R], sizes[q]   the heap ARRAYS the reference's kv_binheap would hold
+ *                                        after the query (incl. the (0,127) sentinel if it survived)
+ *   status[q]   0 ok; 1 = qmax > 1e30: the reference prints "Max quantization bound too high" and
+ *               exit(1)s (db_query_4.cpp:271-274); here the query is skipped (sizes[q] = 0)
+ *   qmin[q], qmax[q], qtables[q][ma][M][16]   the quantizer inputs/outputs (diagnostics, parity) */
+int qadc_query_scan(qadc_index* idx, int nq, int ma, const int32_t* assign, float* tables, int R,
+                    uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
+                    float* qmin, float* qmax, int8_t* qtables);
+
+/* Same work, but returns the ordered candidate stream instead of replaying it: pushing
+ * (cand_keys[i], cand_vals[i]) for i in [offsets[q], offsets[q+1]) in order into the reference's
+ * own kv_binheap<unsigned,int8_t>(R), after bh.push(0,127), leaves it in exactly the state the
+ * reference scan would (a superset of its successful pushes, in scan order, padding-lane
+ * duplicates included).  This is what a ScannerType::query_scan wrapper calls.
+ * cand_capacity = entries available in cand_keys/cand_vals; QADC_E_CAPACITY if too small
+ * (offsets[nq] then holds the required count). */
+int qadc_query_scan_candidates(qadc_index* idx, int nq, int ma, const int32_t* assign, float* tables, int R,
+                               uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals,
+                               uint64_t* offsets, int32_t* status, float* qmin, float* qmax);
+
+/* Integer half only — replaces the scan_avx_4<M> calls (simd_scan.hpp:125-187; call sites
+ * db_query_4.cpp:287-308): the caller supplies int8 tables qtables[nq][ma][M][16] with entries
+ * in [0,127] (what QuantizerMAX<int8_t> produces) and gets the heap arrays. */
+int qadc_scan_i8(qadc_index* idx, int nq, int ma, const int32_t* assign, const int8_t* qtables, int R,
+                 uint32_t* keys, int8_t* values, int32_t* sizes);
+
+int qadc_scan_i8_candidates(qadc_index* idx, int nq, int ma, const int32_t* assign, const int8_t* qtables, int R,
+                            uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals, uint64_t* offsets);
+
+/* Float pre-scan only — replaces scanner_4::query_scan_start + tmp_bh.max()
+ * (db_query_4.cpp:230-242, 259): qmax[q] = R-th smallest float ADC distance over the starts of
+ * the probed partitions (FLT_MAX when fewer than R starts). */
+int qadc_scan_start(qadc_index* idx, int nq, int ma, const int32_t* assign, const float* tables, int R, float* qmax);
+
+/* Two-slot asynchronous form of qadc_query_scan for throughput: submit enqueues all GPU work of a
+ * batch on the index's stream and returns; collect waits for that batch, replays and fills the
+ * outputs.  slot is 0 or 1; a slot must be collected before it is submitted again.  `tables` must
+ * stay valid until collect (it is mutated then). */
+int qadc_query_scan_submit(qadc_index* idx, int slot, int nq, int ma, const int32_t* assign, float* tables, int R);
+int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes,
+                            int32_t* status, float* qmin, float* qmax, int8_t* qtables);
+
+/* Diagnostic: all candidate values min(127, sum) of one partition for one int8 table [M][16]. */
+int qadc_candidates_i8(qadc_index* idx, int part, const int8_t* qtable, int8_t* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement (bench.py): HIP-event timing of the int8 scan kernel on the index's stream.
+ * Enabled with qadc_set_option(idx, "profile", 1).  Totals since the last reset.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct qadc_profile {
+    uint64_t scan_launches;   /* launches of the int8 scan kernel */
+    uint64_t scan_codes;      /* codes those launches scanned (algorithmic bytes = codes * M/2) */
+    double scan_ms;           /* sum of their HIP-event durations */
+    uint64_t start_codes;     /* codes scanned by the float pre-scan */
+    double start_ms;          /* float pre-scan + select + quantize, HIP-event duration */
+    uint64_t candidates;      /* candidates returned by the device (before padding duplicates) */
+    uint64_t regrows;         /* batches re-run because the candidate buffer overflowed */
+    double host_replay_ms;    /* host sort + replay wall time */
+} qadc_profile;
+
+int qadc_profile_read(qadc_index* idx, qadc_profile* out);
+int qadc_profile_reset(qadc_index* idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QADC_H_ */

@@ -1,0 +1,257 @@
+"""TEST INFRASTRUCTURE — ctypes bindings for the CPU oracle (oracle/libqadc_oracle.so, the C
+restatement) and, when present, the reference build (oracle/_ref/libqadc_ref.so, the
+reference's own kernels compiled from /root/reference by oracle/Makefile).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+The product path (quick-adc_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_SO = os.path.join(_HERE, "libqadc_oracle.so")
+_REF_SO = os.path.join(_HERE, "_ref", "libqadc_ref.so")
+
+u8p = C.POINTER(C.c_uint8)
+i8p = C.POINTER(C.c_int8)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+
+
+def build(force=False):
+    """Compile the C restatement (and the reference build when /root/reference exists)."""
+    if force or not os.path.exists(_ORACLE_SO) or \
+            os.path.getmtime(_ORACLE_SO) < os.path.getmtime(os.path.join(_HERE, "qadc_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "libqadc_oracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_SO)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _ptr_array(arrs, t):
+    if arrs is None:
+        return None, None
+    keep = [np.ascontiguousarray(a) for a in arrs]
+    arr = (t * len(keep))(*[_p(a, t) for a in keep])
+    return arr, keep
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_ORACLE_SO)
+        _lib.orc_interleaved_size.restype = C.c_long
+        _lib.orc_interleaved_size.argtypes = [C.c_uint32, C.c_int]
+        _lib.orc_start_size.restype = C.c_uint32
+        _lib.orc_start_size.argtypes = [C.c_uint32, C.c_float]
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(_REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(_REF_SO)
+        _ref.qadc_ref_interleaved_size.restype = C.c_long
+        _ref.qadc_ref_interleaved_size.argtypes = [C.c_uint, C.c_int]
+    return _ref
+
+
+# ----------------------------------------------------------------------------- C restatement
+def heap_replay_i8(keys, vals, R):
+    keys = np.ascontiguousarray(keys, np.uint32)
+    vals = np.ascontiguousarray(vals, np.int8)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.int8), C.c_int(0)
+    lib().orc_heap_replay_i8(C.c_long(len(keys)), _p(keys, u32p), _p(vals, i8p), R,
+                             _p(ok, u32p), _p(ov, i8p), C.byref(osz))
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def heap_replay_f32(keys, vals, R):
+    keys = np.ascontiguousarray(keys, np.uint32)
+    vals = np.ascontiguousarray(vals, np.float32)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.float32), C.c_int(0)
+    lib().orc_heap_replay_f32(C.c_long(len(keys)), _p(keys, u32p), _p(vals, f32p), R,
+                              _p(ok, u32p), _p(ov, f32p), C.byref(osz))
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def pack4(assign, M):
+    assign = np.ascontiguousarray(assign, np.int32)
+    n = assign.shape[0]
+    codes = np.zeros((n, M // 2), np.uint8)
+    lib().orc_pack4(_p(assign, i32p), C.c_long(n), M, _p(codes, u8p))
+    return codes
+
+
+def interleave(codes):
+    codes = np.ascontiguousarray(codes, np.uint8)
+    n, cs = codes.shape
+    out = np.zeros(lib().orc_interleaved_size(n, cs), np.uint8)
+    lib().orc_interleave(_p(out, u8p), _p(codes, u8p), n, cs)
+    return out
+
+
+def deinterleave(inter, n, cs):
+    inter = np.ascontiguousarray(inter, np.uint8)
+    out = np.zeros((n, cs), np.uint8)
+    lib().orc_deinterleave(_p(out, u8p), _p(inter, u8p), n, cs)
+    return out
+
+
+def scan_i8(M, parts, labels, qtables, R, sentinel=True, layout="rowmajor"):
+    """parts: list of arrays (row-major [n][cs] or interleaved bytes); labels: list or None;
+    qtables: int8 [nparts][M][16].  Returns heap (keys, values) arrays of length size."""
+    if layout != "rowmajor":
+        raise ValueError("use scan_i8_interleaved")
+    parts = [np.ascontiguousarray(p, np.uint8) for p in parts]
+    sizes = np.array([p.shape[0] for p in parts], np.uint32)
+    pa, keep1 = _ptr_array(parts, u8p)
+    la, keep2 = _ptr_array(labels, u32p) if labels is not None else (None, None)
+    qt = np.ascontiguousarray(qtables, np.int8)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.int8), C.c_int(0)
+    rc = lib().orc_scan_i8(M, len(parts), pa, la, _p(sizes, u32p), _p(qt, i8p), R, int(sentinel), 1,
+                           _p(ok, u32p), _p(ov, i8p), C.byref(osz))
+    assert rc == 0
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def scan_i8_interleaved(M, inter_parts, sizes, labels, qtables, R, sentinel=True):
+    sizes = np.ascontiguousarray(sizes, np.uint32)
+    pa, keep1 = _ptr_array(inter_parts, u8p)
+    la, keep2 = _ptr_array(labels, u32p) if labels is not None else (None, None)
+    qt = np.ascontiguousarray(qtables, np.int8)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.int8), C.c_int(0)
+    rc = lib().orc_scan_i8(M, len(inter_parts), pa, la, _p(sizes, u32p), _p(qt, i8p), R, int(sentinel), 0,
+                           _p(ok, u32p), _p(ov, i8p), C.byref(osz))
+    assert rc == 0
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def candidates_i8(M, codes, qt):
+    codes = np.ascontiguousarray(codes, np.uint8)
+    qt = np.ascontiguousarray(qt, np.int8)
+    out = np.zeros(codes.shape[0], np.int8)
+    lib().orc_candidates_i8(M, _p(codes, u8p), C.c_long(codes.shape[0]), _p(qt, i8p), _p(out, i8p))
+    return out
+
+
+def candidates_f32(M, codes, dists):
+    codes = np.ascontiguousarray(codes, np.uint8)
+    dists = np.ascontiguousarray(dists, np.float32)
+    out = np.zeros(codes.shape[0], np.float32)
+    lib().orc_candidates_f32(M, _p(codes, u8p), C.c_long(codes.shape[0]), _p(dists, f32p), _p(out, f32p))
+    return out
+
+
+def scan_standard_u8(NSQ, parts, labels, tables, R):
+    sizes = np.array([p.shape[0] for p in parts], np.uint32)
+    pa, keep1 = _ptr_array(parts, u8p)
+    la, keep2 = _ptr_array(labels, u32p) if labels is not None else (None, None)
+    tb = np.ascontiguousarray(tables, np.float32)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.float32), C.c_int(0)
+    lib().orc_scan_standard_u8(NSQ, len(parts), pa, la, _p(sizes, u32p), _p(tb, f32p), R,
+                               _p(ok, u32p), _p(ov, f32p), C.byref(osz))
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def quantize_tables(tables, qmin, qmax, mode=1):
+    tb = np.ascontiguousarray(tables, np.float32)
+    out = np.zeros(tb.shape, np.int8)
+    lib().orc_quantize_tables(_p(tb, f32p), C.c_long(tb.size), C.c_float(qmin), C.c_float(qmax), mode,
+                              _p(out, i8p))
+    return out
+
+
+def start_size(size, keep):
+    return int(lib().orc_start_size(int(size), C.c_float(keep)))
+
+
+def query_scan(M, parts, labels, keep, assign, tables, R, quant_mode=1):
+    """Whole scanner_4::query_scan on row-major database partitions.  `tables` [ma][M*16] float32 is
+    modified in place (negative clamp).  Returns dict(rc, qmin, qmax, qtables, keys, values)."""
+    sizes = np.array([p.shape[0] for p in parts], np.uint32)
+    pa, keep1 = _ptr_array(parts, u8p)
+    la, keep2 = _ptr_array(labels, u32p) if labels is not None else (None, None)
+    assign = np.ascontiguousarray(assign, np.int32)
+    ma = len(assign)
+    assert tables.dtype == np.float32 and tables.flags.c_contiguous
+    qmin, qmax = C.c_float(0), C.c_float(0)
+    qt = np.zeros((ma, M, 16), np.int8)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.int8), C.c_int(0)
+    rc = lib().orc_query_scan(M, pa, la, _p(sizes, u32p), C.c_float(keep), _p(assign, i32p), ma,
+                              _p(tables, f32p), R, quant_mode, C.byref(qmin), C.byref(qmax),
+                              _p(qt, i8p), _p(ok, u32p), _p(ov, i8p), C.byref(osz))
+    return dict(rc=rc, qmin=qmin.value, qmax=qmax.value, qtables=qt,
+                keys=ok[:osz.value].copy(), values=ov[:osz.value].copy())
+
+
+def fill_codes(first_word, nwords, seed):
+    out = np.zeros(nwords * 8, np.uint8)
+    lib().orc_fill_codes(_p(out, u8p), C.c_uint64(first_word), C.c_uint64(nwords), C.c_uint64(seed))
+    return out
+
+
+# ----------------------------------------------------------------------------- reference build
+def ref_interleave(codes):
+    codes = np.ascontiguousarray(codes, np.uint8)
+    n, cs = codes.shape
+    out = np.zeros(ref().qadc_ref_interleaved_size(n, cs), np.uint8)
+    ref().qadc_ref_interleave(_p(out, u8p), _p(codes, u8p), n, cs)
+    return out
+
+
+def ref_scan(M, parts_rowmajor, labels, qtables, R, sentinel=True, want_sorted=False):
+    """Runs the reference's scan_avx_4<M> over partitions given row-major (they are interleaved
+    with the reference's own interleave_partition_4 first)."""
+    inter = [ref_interleave(p) for p in parts_rowmajor]
+    return ref_scan_interleaved(M, inter, [p.shape[0] for p in parts_rowmajor], labels, qtables, R,
+                                sentinel, want_sorted)
+
+
+def ref_scan_interleaved(M, inter_parts, sizes, labels, qtables, R, sentinel=True, want_sorted=False):
+    sizes = np.ascontiguousarray(sizes, np.uint32)
+    pa, keep1 = _ptr_array(inter_parts, u8p)
+    la, keep2 = _ptr_array(labels, u32p) if labels is not None else (None, None)
+    qt = np.ascontiguousarray(qtables, np.int8)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.int8), C.c_int(0)
+    sk = np.zeros(R, np.uint32)
+    rc = ref().qadc_ref_scan(M, len(inter_parts), pa, la, _p(sizes, u32p), _p(qt, i8p), R, int(sentinel),
+                             _p(ok, u32p), _p(ov, i8p), C.byref(osz), _p(sk, u32p) if want_sorted else None)
+    assert rc == 0
+    if want_sorted:
+        return ok[:osz.value].copy(), ov[:osz.value].copy(), sk[:osz.value].copy()
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def ref_heap_replay_i8(keys, vals, R):
+    keys = np.ascontiguousarray(keys, np.uint32)
+    vals = np.ascontiguousarray(vals, np.int8)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.int8), C.c_int(0)
+    ref().qadc_ref_heap_replay_i8(C.c_long(len(keys)), _p(keys, u32p), _p(vals, i8p), R,
+                                  _p(ok, u32p), _p(ov, i8p), C.byref(osz), None)
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def ref_heap_replay_f32(keys, vals, R):
+    keys = np.ascontiguousarray(keys, np.uint32)
+    vals = np.ascontiguousarray(vals, np.float32)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.float32), C.c_int(0)
+    ref().qadc_ref_heap_replay_f32(C.c_long(len(keys)), _p(keys, u32p), _p(vals, f32p), R,
+                                   _p(ok, u32p), _p(ov, f32p), C.byref(osz))
+    return ok[:osz.value].copy(), ov[:osz.value].copy()

@@ -1,0 +1,390 @@
+/*
+ * TEST INFRASTRUCTURE — CPU oracle for the Quick-ADC scan path.  NOT product code.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / reported baseline.  The product path
+ * (quick-adc_amd/, libqadc_hip.so) never links, loads or calls anything in oracle/.
+ *
+ * Plain-C restatement of the reference's algorithm for the path, written from the
+ * reference's behaviour (file:line cited per function, paths relative to
+ * /root/reference).  Parity status:
+ *   - heap, layout, int8 scan (orc_heap_*, orc_interleave, orc_scan_i8_*):
+ *       PINNED — checked entry-by-entry against the reference's own kernels compiled
+ *       from /root/reference into oracle/_ref/libqadc_ref.so (tests/test_oracle_vs_ref.py)
+ *       and against the committed fixtures in tests/golden/ generated from that build.
+ *   - float start scan, QuantizerMAX, query_scan glue (orc_scan4_f32, orc_quantize_tables,
+ *       orc_query_scan): PARITY UNPINNED.  Their translation unit (db_query_4.cpp /
+ *       query_common.hpp) needs Cereal, cblas and OpenCV headers that this image lacks,
+ *       so it cannot be compiled here without stand-ins; they are restated from the
+ *       source text plus the as-compiled behaviour recorded in SURVEY.md §8 row A5.
+ *
+ * Build: strict IEEE (no -ffast-math) so every float expression evaluates exactly as
+ * written here.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+/* ------------------------------------------------------------------------------------------
+ * kv_binheap<unsigned, T>::push  — binheap.hpp:75-116
+ * Array max-heap on value, two parallel arrays.  Not full: append + sift-up with strict '>'.
+ * Full: replace root iff value < root, sift-down taking the right child only if strictly
+ * greater than the left, stop when child <= current.
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_DEFINE_HEAP(SUFFIX, VT)                                                           \
+    typedef struct { uint32_t* keys; VT* vals; int cap; int size; } orc_heap_##SUFFIX;        \
+    static void orc_heap_##SUFFIX##_push(orc_heap_##SUFFIX* h, uint32_t key, VT value) {      \
+        if (h->size != h->cap) {                                                              \
+            int i = h->size++;                                                                \
+            h->vals[i] = value; h->keys[i] = key;                                             \
+            int p = (i - 1) / 2;                                                              \
+            while (i != 0 && h->vals[i] > h->vals[p]) {                                       \
+                VT tv = h->vals[i]; h->vals[i] = h->vals[p]; h->vals[p] = tv;                 \
+                uint32_t tk = h->keys[i]; h->keys[i] = h->keys[p]; h->keys[p] = tk;           \
+                i = p; p = (i - 1) / 2;                                                       \
+            }                                                                                 \
+            return;                                                                           \
+        }                                                                                     \
+        if (value < h->vals[0]) {                                                             \
+            int i = 0;                                                                        \
+            h->vals[0] = value; h->keys[0] = key;                                             \
+            for (;;) {                                                                        \
+                const int l = 2 * i + 1, r = 2 * i + 2;                                       \
+                if (l >= h->size) break;                                                      \
+                int c = l;                                                                    \
+                if (r < h->size && h->vals[r] > h->vals[l]) c = r;                            \
+                if (h->vals[c] <= h->vals[i]) break;                                          \
+                VT tv = h->vals[i]; h->vals[i] = h->vals[c]; h->vals[c] = tv;                 \
+                uint32_t tk = h->keys[i]; h->keys[i] = h->keys[c]; h->keys[c] = tk;           \
+                i = c;                                                                        \
+            }                                                                                 \
+        }                                                                                     \
+    }
+
+ORC_DEFINE_HEAP(i8, int8_t)
+ORC_DEFINE_HEAP(f32, float)
+
+/* Exported replays: push (keys[i], vals[i]) in order into an empty heap of capacity R. */
+void orc_heap_replay_i8(long n, const uint32_t* keys, const int8_t* vals, int R,
+                        uint32_t* out_keys, int8_t* out_vals, int* out_size) {
+    orc_heap_i8 h = { out_keys, out_vals, R, 0 };
+    for (long i = 0; i < n; ++i) orc_heap_i8_push(&h, keys[i], vals[i]);
+    *out_size = h.size;
+}
+
+void orc_heap_replay_f32(long n, const uint32_t* keys, const float* vals, int R,
+                         uint32_t* out_keys, float* out_vals, int* out_size) {
+    orc_heap_f32 h = { out_keys, out_vals, R, 0 };
+    for (long i = 0; i < n; ++i) orc_heap_f32_push(&h, keys[i], vals[i]);
+    *out_size = h.size;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * multiple_set_bits_4 — quantizers.hpp:49-68.  assign is [n][M] centroid ids (0..15);
+ * byte b of a code: low nibble = sub-quantizer 2b, high nibble = 2b+1.
+ * ---------------------------------------------------------------------------------------- */
+void orc_pack4(const int32_t* assign, long n, int M, uint8_t* codes) {
+    const int cs = M / 2;
+    for (long i = 0; i < n; ++i)
+        for (int m = 0; m < M; ++m) {
+            const uint8_t a = (uint8_t)assign[i * M + m];
+            uint8_t* c = codes + i * cs + m / 2;
+            if (m % 2 == 1) *c = (uint8_t)(*c | (uint8_t)(a << 4));
+            else            *c = a;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * simd_layout.hpp:31-65 — row-major [n][cs] -> [B][cs][16]; lanes past n replicate code n-1.
+ * ---------------------------------------------------------------------------------------- */
+long orc_interleaved_size(uint32_t n, int cs) {
+    return (long)((n + 15u) / 16u) * cs * 16;
+}
+
+void orc_interleave(uint8_t* dst, const uint8_t* rowmajor, uint32_t n, int cs) {
+    const long blocks = (n + 15u) / 16u;
+    for (long k = 0; k < blocks; ++k)
+        for (int b = 0; b < cs; ++b)
+            for (int j = 0; j < 16; ++j) {
+                long ci = k * 16 + j;
+                if (ci >= (long)n) ci = (long)n - 1;
+                *dst++ = rowmajor[ci * cs + b];
+            }
+}
+
+/* Inverse view used by tests: block layout -> row-major (first n codes). */
+void orc_deinterleave(uint8_t* rowmajor, const uint8_t* inter, uint32_t n, int cs) {
+    for (long ci = 0; ci < (long)n; ++ci)
+        for (int b = 0; b < cs; ++b)
+            rowmajor[ci * cs + b] = inter[(ci / 16) * cs * 16 + b * 16 + (ci % 16)];
+}
+
+static inline int8_t sat_add8(int8_t a, int8_t b) {    /* _mm256_adds_epi8 */
+    int s = (int)a + (int)b;
+    return (int8_t)(s > 127 ? 127 : (s < -128 ? -128 : s));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * scan_avx_4<M> + compare_extract_matches_sse + bh_push — simd_scan.hpp:63-187.
+ * Works on the interleaved layout, block by block, with the reference's exact
+ * saturating-add order:
+ *   lo-lane chain: T[0][p0.lo] (+) T[1][p0.hi] (+) T[4][p2.lo] (+) T[5][p2.hi] ...   (138-174)
+ *   hi-lane chain: T[2][p1.lo] (+) T[3][p1.hi] (+) T[6][p3.lo] (+) T[7][p3.hi] ...
+ *   cand = hi (+) lo                                                                 (177-179)
+ * Signed compare against the bound sampled at block start; matches pushed in ascending
+ * lane order with index clamped to size-1 (padding quirk, 67); bound refreshed after a
+ * block with at least one match (116).
+ * qt: int8 [M][16].
+ * ---------------------------------------------------------------------------------------- */
+static void scan_i8_blocks(orc_heap_i8* h, int M, const uint8_t* part, const uint32_t* labels,
+                           uint32_t size, const int8_t* qt) {
+    const int cs = M / 2, rows = M / 4;
+    int8_t bound = h->vals[0];
+    const uint32_t max_scan = size - 1u;
+    uint32_t scanned = 0;
+    while (scanned <= max_scan) {
+        int8_t cand[16];
+        for (int j = 0; j < 16; ++j) {
+            int8_t lo = 0, hi = 0;
+            for (int r = 0; r < rows; ++r) {
+                const uint8_t p0 = part[(2 * r) * 16 + j], p1 = part[(2 * r + 1) * 16 + j];
+                const int8_t a = qt[(4 * r) * 16 + (p0 & 15)], b = qt[(4 * r + 1) * 16 + (p0 >> 4)];
+                const int8_t c = qt[(4 * r + 2) * 16 + (p1 & 15)], d = qt[(4 * r + 3) * 16 + (p1 >> 4)];
+                if (r == 0) { lo = sat_add8(b, a); hi = sat_add8(d, c); }
+                else { lo = sat_add8(a, lo); lo = sat_add8(b, lo); hi = sat_add8(c, hi); hi = sat_add8(d, hi); }
+            }
+            cand[j] = sat_add8(hi, lo);
+        }
+        int any = 0;
+        for (int j = 0; j < 16; ++j) {
+            if (cand[j] < bound) {
+                uint32_t ci = scanned + (uint32_t)j;
+                if (ci > max_scan) ci = max_scan;
+                orc_heap_i8_push(h, labels ? labels[ci] : ci, cand[j]);
+                any = 1;
+            }
+        }
+        if (any) bound = h->vals[0];
+        scanned += 16;
+        part += (long)cs * 16;
+    }
+}
+
+/* Row-major statement of the same scan (SURVEY.md §8 A1 facts i-iii): for entries in
+ * [0,127] cand == min(127, sum); per lane in block order push iff cand < current bound;
+ * the last block's padding lanes replay code n-1.  Used for large inputs / CPU "port" timing.
+ * Identical results to scan_i8_blocks whenever all table entries are in [0,127]. */
+static void scan_i8_rowmajor(orc_heap_i8* h, int M, const uint8_t* codes, const uint32_t* labels,
+                             uint32_t size, const int8_t* qt) {
+    const int cs = M / 2;
+    const uint32_t blocks = (size + 15u) / 16u;
+    int8_t bound = h->vals[0];
+    for (uint32_t k = 0; k < blocks; ++k) {
+        int any = 0;
+        const int8_t bound_blk = bound;
+        for (int j = 0; j < 16; ++j) {
+            uint32_t ci = k * 16u + (uint32_t)j;
+            if (ci > size - 1u) ci = size - 1u;
+            const uint8_t* c = codes + (long)ci * cs;
+            int s = 0;
+            for (int b = 0; b < cs; ++b)
+                s += qt[(2 * b) * 16 + (c[b] & 15)] + qt[(2 * b + 1) * 16 + (c[b] >> 4)];
+            const int8_t cand = (int8_t)(s > 127 ? 127 : s);
+            if (cand < bound_blk) { orc_heap_i8_push(h, labels ? labels[ci] : ci, cand); any = 1; }
+        }
+        if (any) bound = h->vals[0];
+    }
+}
+
+/* Integer half of scanner_4::query_scan (db_query_4.cpp:276, 287-308): optional (0,127)
+ * sentinel, then every probed partition in order into one heap.
+ * layout: 0 = parts[] are interleaved (reference layout), 1 = parts[] are row-major. */
+int orc_scan_i8(int M, int nparts, const uint8_t* const* parts, const uint32_t* const* labels,
+                const uint32_t* sizes, const int8_t* qtables, int R, int push_sentinel, int layout,
+                uint32_t* out_keys, int8_t* out_vals, int* out_size) {
+    if (M != 16 && M != 32) return -1;
+    orc_heap_i8 h = { out_keys, out_vals, R, 0 };
+    if (push_sentinel) orc_heap_i8_push(&h, 0, 127);
+    for (int p = 0; p < nparts; ++p) {
+        if (sizes[p] == 0) continue;
+        const int8_t* qt = qtables + (long)p * M * 16;
+        const uint32_t* lab = labels ? labels[p] : NULL;
+        if (layout == 0) scan_i8_blocks(&h, M, parts[p], lab, sizes[p], qt);
+        else             scan_i8_rowmajor(&h, M, parts[p], lab, sizes[p], qt);
+    }
+    *out_size = h.size;
+    return 0;
+}
+
+/* Per-code candidate values min(127, sum) for row-major codes (test helper: what the
+ * device must compute for every code; SURVEY.md §8 A1 fact i). */
+void orc_candidates_i8(int M, const uint8_t* codes, long n, const int8_t* qt, int8_t* out) {
+    const int cs = M / 2;
+    for (long i = 0; i < n; ++i) {
+        int s = 0;
+        for (int b = 0; b < cs; ++b)
+            s += qt[(2 * b) * 16 + (codes[i * cs + b] & 15)] + qt[(2 * b + 1) * 16 + (codes[i * cs + b] >> 4)];
+        out[i] = (int8_t)(s > 127 ? 127 : s);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * scan_4<NSQ> — query_common.hpp:59-90.  Float ADC on row-major 4-bit codes; the sum is
+ * accumulated sequentially from 0: byte by byte, low nibble then high nibble (72-80);
+ * push iff cand < min, min refreshed after every push (81-88).
+ * ---------------------------------------------------------------------------------------- */
+static void scan4_f32(orc_heap_f32* h, int M, const uint8_t* codes, const uint32_t* labels,
+                      uint32_t count, const float* dists) {
+    const int cs = M / 2;
+    float min = h->vals[0];
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint8_t* c = codes + (long)i * cs;
+        float cand = 0;
+        for (int b = 0; b < cs; ++b) {
+            cand += dists[(2 * b) * 16 + (c[b] & 0xf)];
+            cand += dists[(2 * b + 1) * 16 + ((c[b] & 0xf0) >> 4)];
+        }
+        if (cand < min) {
+            orc_heap_f32_push(h, labels ? labels[i] : i, cand);
+            min = h->vals[0];
+        }
+    }
+}
+
+/* Per-code float ADC values with the same summation order (test helper). */
+void orc_candidates_f32(int M, const uint8_t* codes, long n, const float* dists, float* out) {
+    const int cs = M / 2;
+    for (long i = 0; i < n; ++i) {
+        float cand = 0;
+        for (int b = 0; b < cs; ++b) {
+            cand += dists[(2 * b) * 16 + (codes[i * cs + b] & 0xf)];
+            cand += dists[(2 * b + 1) * 16 + (codes[i * cs + b] >> 4)];
+        }
+        out[i] = cand;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * scan_standard<uint8_t,NSQ> — query_common.hpp:92-118 (BASELINE config 1: PQ 8x8 float ADC),
+ * preceded by scanner_simple::query_scan's R sentinel pushes (db_query.cpp:32-34).
+ * codes row-major [n][NSQ] bytes, dists [NSQ][256].
+ * ---------------------------------------------------------------------------------------- */
+int orc_scan_standard_u8(int NSQ, int nparts, const uint8_t* const* parts, const uint32_t* const* labels,
+                         const uint32_t* sizes, const float* tables, int R,
+                         uint32_t* out_keys, float* out_vals, int* out_size) {
+    orc_heap_f32 h = { out_keys, out_vals, R, 0 };
+    for (int t = 0; t < R; ++t) orc_heap_f32_push(&h, 0, FLT_MAX - (float)t);
+    for (int p = 0; p < nparts; ++p) {
+        const float* dists = tables + (long)p * NSQ * 256;
+        const uint32_t* lab = labels ? labels[p] : NULL;
+        float min = h.vals[0];
+        for (uint32_t i = 0; i < sizes[p]; ++i) {
+            const uint8_t* c = parts[p] + (long)i * NSQ;
+            float cand = 0;
+            for (int m = 0; m < NSQ; ++m) cand += dists[m * 256 + c[m]];
+            if (cand < min) {
+                orc_heap_f32_push(&h, lab ? lab[i] : i, cand);
+                min = h.vals[0];
+            }
+        }
+    }
+    *out_size = h.size;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * QuantizerMAX<int8_t> — db_query_4.cpp:37-71.  val >= max -> 127, else trunc toward zero.
+ * mode 0: source-level  int8(((val - min) / delta)),  delta = (max - min) / 127   (44-55)
+ * mode 1: as compiled by g++ 11.4 with the reference's flags (-O3 -ffast-math): one
+ *         scale = 127.0f / (max - min), then int8((val - min) * scale)  (SURVEY.md §8 A5 [probe]).
+ * The two can differ by 1 at bucket edges.  PARITY UNPINNED (see header).
+ * ---------------------------------------------------------------------------------------- */
+void orc_quantize_tables(const float* tables, long count, float qmin, float qmax, int mode, int8_t* out) {
+    const float delta = (qmax - qmin) / 127;
+    const float scale = 127.0f / (qmax - qmin);
+    for (long i = 0; i < count; ++i) {
+        const float v = tables[i];
+        if (v >= qmax) { out[i] = 127; continue; }
+        const float q = mode == 0 ? (v - qmin) / delta : (v - qmin) * scale;
+        out[i] = (int8_t)(int)q;
+    }
+}
+
+/* starts size — db_query_4.cpp:125-126: max(1u, unsigned(size * keep)), product in float. */
+uint32_t orc_start_size(uint32_t size, float keep) {
+    if (size == 0) return 0;
+    const uint32_t s = (uint32_t)((float)size * keep);
+    return s > 1u ? s : 1u;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * scanner_4::query_scan — db_query_4.cpp:230-309, on row-major partitions of the database.
+ *   all_parts / all_labels / all_sizes : the database's partitions (labels NULL = flat)
+ *   assign[ma], tables[ma][M*16] (MUTABLE: negatives are clamped in place, 262-269)
+ * Returns 0, or 1 when qmax > 1e30 (the reference prints a warning and exit(1)s, 271-274).
+ * Outputs: qmin/qmax, the int8 tables [ma][M][16], and the final heap arrays.
+ * ---------------------------------------------------------------------------------------- */
+int orc_query_scan(int M, const uint8_t* const* all_parts, const uint32_t* const* all_labels,
+                   const uint32_t* all_sizes, float keep, const int32_t* assign, int ma,
+                   float* tables, int R, int quant_mode,
+                   float* out_qmin, float* out_qmax, int8_t* out_qtables,
+                   uint32_t* out_keys, int8_t* out_vals, int* out_size) {
+    const int table_dim = M * 16;
+    /* query_scan_start (230-242) */
+    uint32_t* tk = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)R);
+    float* tv = (float*)malloc(sizeof(float) * (size_t)R);
+    orc_heap_f32 th = { tk, tv, R, 0 };
+    orc_heap_f32_push(&th, 0, FLT_MAX);
+    for (int a = 0; a < ma; ++a) {
+        const int p = assign[a];
+        const uint32_t s = orc_start_size(all_sizes[p], keep);
+        scan4_f32(&th, M, all_parts[p], all_labels ? all_labels[p] : NULL, s, tables + (long)a * table_dim);
+    }
+    float qmax = th.vals[0];
+    free(tk); free(tv);
+    /* qmin + clamp (258-269) */
+    const long all = (long)ma * table_dim;
+    float qmin = tables[0];
+    for (long i = 1; i < all; ++i) if (tables[i] < qmin) qmin = tables[i];
+    if (qmin < 0) {
+        qmin = 0;
+        for (long i = 0; i < all; ++i) if (tables[i] < 0) tables[i] = 0;
+    }
+    *out_qmin = qmin; *out_qmax = qmax;
+    if (qmax > 1e30f) return 1;
+    orc_quantize_tables(tables, all, qmin, qmax, quant_mode, out_qtables);
+    /* sentinel + scan of every probed partition IN FULL, in assign order (276, 287-308) */
+    orc_heap_i8 h = { out_keys, out_vals, R, 0 };
+    orc_heap_i8_push(&h, 0, 127);
+    for (int a = 0; a < ma; ++a) {
+        const int p = assign[a];
+        const uint32_t n = all_sizes[p];
+        if (n == 0) continue;
+        uint8_t* inter = (uint8_t*)malloc((size_t)orc_interleaved_size(n, M / 2));
+        orc_interleave(inter, all_parts[p], n, M / 2);
+        scan_i8_blocks(&h, M, inter, all_labels ? all_labels[p] : NULL, n, out_qtables + (long)a * table_dim);
+        free(inter);
+    }
+    *out_size = h.size;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Counter-based synthetic code generator: byte stream of a splitmix64
+ * hash of (seed, 64-bit word index).  Word w of partition stream = 8 consecutive code bytes.
+ * Must match qadc_fill_codes in the HIP library bit for bit (tests compare them).
+ * ---------------------------------------------------------------------------------------- */
+static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+void orc_fill_codes(uint8_t* dst, uint64_t first_word, uint64_t nwords, uint64_t seed) {
+    for (uint64_t w = 0; w < nwords; ++w) {
+        const uint64_t v = splitmix64(seed ^ splitmix64(first_word + w));
+        memcpy(dst + 8 * w, &v, 8);
+    }
+}

@@ -1,0 +1,806 @@
+// Host side of libqadc_hip.so: the C-ABI declared in include/qadc.h.
+//
+// Mirrors scanner_4 (db_query_4.cpp:73-310): prepare (upload partitions, starts sizes) and
+// query_scan (float pre-scan -> qmax, qmin/clamp, int8 quantization, scan of every probed
+// partition in assign order into one heap).  All per-query arithmetic runs on the GPU in one
+// stream-ordered chain (no host round trip between pre-scan, quantizer and scan); the host only
+// plans the work items, sorts the returned candidates into scan order and replays them through
+// a heap with the reference's push semantics (host/qadc_heap.hpp).
+//
+// The product path never touches oracle/: if the HIP runtime or the GPU is missing every entry
+// point fails loudly with QADC_E_HIP.
+#include "../../include/qadc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../host/qadc_heap.hpp"
+#include "qadc_kernels.h"
+
+using namespace qadc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(QADC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Part {
+    uint8_t* d_codes = nullptr;
+    uint32_t* d_labels = nullptr;
+    uint32_t n = 0;
+    uint32_t start_n = 0;
+    uint32_t key_base = 0;
+    bool own = true;
+};
+
+struct LevelLaunch {
+    size_t first;   // first item
+    int nitems;
+    int wgs;
+    uint64_t codes;
+};
+
+struct Slot {
+    bool busy = false;
+    bool float_path = false;
+    int nq = 0, ma = 0, R = 0;
+    float* tables = nullptr;            // caller's float tables (float path)
+    std::vector<int32_t> assign;
+    std::vector<int8_t> qtables_in;     // int8 path input copy
+    uint32_t cand_cap = 0;
+    uint32_t prefetched = 0;
+
+    DevBuf<float> d_ftables;
+    DevBuf<int8_t> d_qtables;
+    DevBuf<QueryState> d_qs;
+    DevBuf<CandHeader> d_hdr;
+    DevBuf<Cand> d_cands;
+    DevBuf<ScanItem> d_items;
+    DevBuf<StartItem> d_sitems;
+    DevBuf<float> d_fc;
+    DevBuf<uint32_t> d_fc_count;
+    DevBuf<uint32_t> d_sel_hist;
+
+    PinBuf<ScanItem> h_items;
+    PinBuf<StartItem> h_sitems;
+    PinBuf<uint32_t> h_fc_count;
+    PinBuf<float> h_ftables;
+    PinBuf<int8_t> h_qtables;
+    PinBuf<QueryState> h_qs;
+    PinBuf<CandHeader> h_hdr;
+    PinBuf<Cand> h_cands;
+
+    std::vector<LevelLaunch> launches;
+    uint64_t start_codes = 0;
+    hipEvent_t ev_done = nullptr;
+    std::vector<hipEvent_t> prof_ev;    // pairs: [2i] before, [2i+1] after; pair 0 = pre-scan chain
+    size_t prof_used = 0;
+
+    // collect() results
+    std::vector<uint32_t> out_keys;
+    std::vector<int8_t> out_vals;
+    std::vector<uint64_t> out_off;
+};
+
+}  // namespace
+
+struct qadc_index {
+    int M = 16, cs = 8, device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Part> parts;
+    int labeled = -1;  // -1 unknown, 0 flat, 1 labels
+    bool finalized = false;
+    float keep = 0.01f;
+    // options
+    int quant_mode = 1;
+    uint32_t cand_capacity = 1u << 16;
+    uint64_t level_base = 1024;
+    uint64_t level_growth = 16;
+    int wgs_per_item = 0;  // 0 = auto
+    bool profile = false;
+    Slot slot[2];
+    qadc_profile prof{};
+};
+
+namespace {
+
+int use_device(const qadc_index* idx) {
+    HIPCHECK(hipSetDevice(idx->device));
+    return QADC_OK;
+}
+
+hipError_t prof_event(Slot& s, hipStream_t st) {
+    if (s.prof_used == s.prof_ev.size()) {
+        hipEvent_t e;
+        hipError_t r = hipEventCreate(&e);
+        if (r != hipSuccess) return r;
+        s.prof_ev.push_back(e);
+    }
+    return hipEventRecord(s.prof_ev[s.prof_used++], st);
+}
+
+// Level boundaries in the concatenated scan position space of one query.
+void level_bounds(const qadc_index* idx, uint64_t* L) {
+    L[0] = 0;
+    uint64_t b = std::max<uint64_t>(idx->level_base, 16);
+    for (int k = 1; k < kMaxLevels; ++k) {
+        L[k] = b;
+        b = (b > (UINT64_MAX >> 8)) ? UINT64_MAX : b * std::max<uint64_t>(idx->level_growth, 2);
+    }
+    L[kMaxLevels] = UINT64_MAX;
+}
+
+int plan_and_launch(qadc_index* idx, Slot& s) {
+    const int M = idx->M, cs = idx->cs, nq = s.nq, ma = s.ma;
+    const uint32_t cpl = 16 / cs;
+    hipStream_t st = idx->stream;
+    const size_t table_dim = (size_t)M * 16;
+
+    // ---- plan -------------------------------------------------------------------------------
+    uint64_t L[kMaxLevels + 1];
+    level_bounds(idx, L);
+    std::vector<std::vector<ScanItem>> per_level(kMaxLevels);
+    std::vector<StartItem> sitems;
+    HIPCHECK(s.h_fc_count.ensure(nq));
+    uint64_t fc_stride = 1;
+    s.start_codes = 0;
+    for (int q = 0; q < nq; ++q) {
+        uint64_t c = 0;
+        uint32_t soff = 0;
+        for (int a = 0; a < ma; ++a) {
+            const int p = s.assign[(size_t)q * ma + a];
+            if (p < 0 || p >= (int)idx->parts.size())
+                return fail(QADC_E_ARG, "assign[] names a partition that does not exist");
+            const Part& pt = idx->parts[p];
+            if (pt.n == 0) continue;  // db_query_4.cpp:291-293
+            if (s.float_path) {
+                StartItem si;
+                si.codes = pt.d_codes;
+                si.n = pt.start_n;
+                si.table = (uint32_t)((size_t)q * ma + a);
+                si.query = (uint32_t)q;
+                si.out_off = soff;
+                sitems.push_back(si);
+                soff += pt.start_n;
+                s.start_codes += pt.start_n;
+            }
+            uint64_t prev = 0;
+            for (int k = 0; k < kMaxLevels && prev < pt.n; ++k) {
+                uint64_t cut = pt.n;
+                if (L[k + 1] < c + pt.n) {
+                    cut = L[k + 1] > c ? L[k + 1] - c : 0;
+                    cut -= cut % cpl;  // keep every run 16-byte aligned
+                }
+                if (cut <= prev) continue;
+                // runs longer than 2^31 codes are cut so that 32-bit vector indices cannot wrap
+                for (uint64_t b0 = prev; b0 < cut;) {
+                    const uint64_t len = std::min<uint64_t>(cut - b0, 1ull << 31);
+                    ScanItem it;
+                    it.codes = pt.d_codes + b0 * cs;
+                    it.labels = pt.d_labels;
+                    it.n = (uint32_t)len;
+                    it.pos0 = (uint32_t)b0;
+                    it.key_base = pt.key_base;
+                    it.table = (uint32_t)((size_t)q * ma + a);
+                    it.query = (uint32_t)q;
+                    it.order = ((uint32_t)k << 16) | (uint32_t)a;
+                    per_level[k].push_back(it);
+                    b0 += len;
+                }
+                prev = cut;
+            }
+            c += pt.n;
+        }
+        s.h_fc_count.p[q] = soff;
+        fc_stride = std::max<uint64_t>(fc_stride, soff);
+    }
+    size_t nitems = 0;
+    for (auto& v : per_level) nitems += v.size();
+    HIPCHECK(s.h_items.ensure(nitems));
+    HIPCHECK(s.d_items.ensure(nitems));
+    s.launches.clear();
+    size_t off = 0;
+    const int wgs_cap = idx->wgs_per_item > 0 ? idx->wgs_per_item : (M == 16 ? 512 : 256);
+    for (int k = 0; k < kMaxLevels; ++k) {
+        if (per_level[k].empty()) continue;
+        uint64_t maxn = 0, codes = 0;
+        for (auto& it : per_level[k]) {
+            maxn = std::max<uint64_t>(maxn, it.n);
+            codes += it.n;
+        }
+        std::memcpy(s.h_items.p + off, per_level[k].data(), per_level[k].size() * sizeof(ScanItem));
+        const uint64_t nvec = (maxn + cpl - 1) / cpl;
+        LevelLaunch ll;
+        ll.first = off;
+        ll.nitems = (int)per_level[k].size();
+        ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + 2047) / 2048, 1), (uint64_t)wgs_cap);
+        ll.codes = codes;
+        s.launches.push_back(ll);
+        off += per_level[k].size();
+    }
+
+    // ---- upload -----------------------------------------------------------------------------
+    HIPCHECK(s.d_qs.ensure(nq));
+    HIPCHECK(s.h_qs.ensure(nq));
+    HIPCHECK(s.d_hdr.ensure(1));
+    HIPCHECK(s.h_hdr.ensure(1));
+    HIPCHECK(s.d_cands.ensure(s.cand_cap));
+    HIPCHECK(s.d_qtables.ensure((size_t)nq * ma * table_dim));
+    HIPCHECK(hipMemsetAsync(s.d_qs.p, 0, sizeof(QueryState) * nq, st));
+    HIPCHECK(hipMemsetAsync(s.d_hdr.p, 0, sizeof(CandHeader), st));
+    if (nitems) HIPCHECK(hipMemcpyAsync(s.d_items.p, s.h_items.p, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, st));
+    s.prof_used = 0;
+
+    if (s.float_path) {
+        const size_t nt = (size_t)nq * ma * table_dim;
+        HIPCHECK(s.h_ftables.ensure(nt));
+        HIPCHECK(s.d_ftables.ensure(nt));
+        std::memcpy(s.h_ftables.p, s.tables, nt * sizeof(float));
+        HIPCHECK(hipMemcpyAsync(s.d_ftables.p, s.h_ftables.p, nt * sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHECK(s.h_sitems.ensure(sitems.size()));
+        HIPCHECK(s.d_sitems.ensure(sitems.size()));
+        HIPCHECK(s.d_fc_count.ensure(nq));
+        HIPCHECK(s.d_sel_hist.ensure((size_t)nq * 256));
+        HIPCHECK(s.d_fc.ensure((size_t)nq * fc_stride));
+        HIPCHECK(hipMemcpyAsync(s.d_fc_count.p, s.h_fc_count.p, nq * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        if (idx->profile) HIPCHECK(prof_event(s, st));
+        if (!sitems.empty()) {
+            std::memcpy(s.h_sitems.p, sitems.data(), sitems.size() * sizeof(StartItem));
+            HIPCHECK(hipMemcpyAsync(s.d_sitems.p, s.h_sitems.p, sitems.size() * sizeof(StartItem), hipMemcpyHostToDevice, st));
+            uint32_t maxs = 0;
+            for (auto& si : sitems) maxs = std::max(maxs, si.n);
+            const int wgs = (int)std::min<uint32_t>(std::max<uint32_t>((maxs + 1023) / 1024, 1), 1024);
+            launch_start_scan_f32(M, s.d_sitems.p, (int)sitems.size(), wgs, s.d_ftables.p, s.d_fc.p, fc_stride, st);
+        }
+        launch_select_kth(s.d_fc.p, fc_stride, s.d_fc_count.p, nq, (uint32_t)s.R, s.d_qs.p, s.d_sel_hist.p, st);
+        launch_quantize(M, ma, nq, s.d_ftables.p, s.d_qtables.p, s.d_qs.p, idx->quant_mode, st);
+        if (idx->profile) HIPCHECK(prof_event(s, st));
+    } else {
+        const size_t nt = (size_t)nq * ma * table_dim;
+        HIPCHECK(s.h_qtables.ensure(nt));
+        std::memcpy(s.h_qtables.p, s.qtables_in.data(), nt);
+        HIPCHECK(hipMemcpyAsync(s.d_qtables.p, s.h_qtables.p, nt, hipMemcpyHostToDevice, st));
+        if (idx->profile) { HIPCHECK(prof_event(s, st)); HIPCHECK(prof_event(s, st)); }
+    }
+
+    // ---- scan levels ------------------------------------------------------------------------
+    for (auto& ll : s.launches) {
+        if (idx->profile) HIPCHECK(prof_event(s, st));
+        launch_scan_i8(M, 0, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p, s.d_cands.p,
+                       s.cand_cap, (uint32_t)s.R, st);
+        if (idx->profile) HIPCHECK(prof_event(s, st));
+    }
+    HIPCHECK(hipGetLastError());
+
+    // ---- results ----------------------------------------------------------------------------
+    HIPCHECK(hipMemcpyAsync(s.h_hdr.p, s.d_hdr.p, sizeof(CandHeader), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(s.h_qs.p, s.d_qs.p, sizeof(QueryState) * nq, hipMemcpyDeviceToHost, st));
+    s.prefetched = std::min<uint32_t>(s.cand_cap, 32768);
+    HIPCHECK(s.h_cands.ensure(s.cand_cap));
+    HIPCHECK(hipMemcpyAsync(s.h_cands.p, s.d_cands.p, sizeof(Cand) * s.prefetched, hipMemcpyDeviceToHost, st));
+    if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(s.ev_done, st));
+    return QADC_OK;
+}
+
+int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* assign, float* tables,
+                  const int8_t* qtables, int R) {
+    if (!idx) return fail(QADC_E_ARG, "null index");
+    if (slot_i < 0 || slot_i > 1) return fail(QADC_E_ARG, "slot must be 0 or 1");
+    if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
+    if (nq <= 0 || ma <= 0 || R <= 0 || !assign) return fail(QADC_E_ARG, "nq, ma, R must be > 0 and assign non-null");
+    if (nq >= (1 << 24)) return fail(QADC_E_ARG, "nq must be < 2^24");
+    if (ma >= (1 << 16)) return fail(QADC_E_ARG, "ma must be < 65536");
+    if (!tables && !qtables) return fail(QADC_E_ARG, "tables is null");
+    Slot& s = idx->slot[slot_i];
+    if (s.busy) return fail(QADC_E_STATE, "slot still holds an uncollected batch");
+    if (int rc = use_device(idx)) return rc;
+    s.nq = nq;
+    s.ma = ma;
+    s.R = R;
+    s.float_path = tables != nullptr;
+    s.tables = tables;
+    s.assign.assign(assign, assign + (size_t)nq * ma);
+    if (qtables) {
+        const size_t nt = (size_t)nq * ma * idx->M * 16;
+        for (size_t i = 0; i < nt; ++i)
+            if (qtables[i] < 0)
+                return fail(QADC_E_ARG, "int8 tables must lie in [0,127] (QuantizerMAX<int8_t> output, db_query_4.cpp:37-71)");
+        s.qtables_in.assign(qtables, qtables + nt);
+    }
+    s.cand_cap = std::max<uint32_t>(s.cand_cap, idx->cand_capacity);
+    if (int rc = plan_and_launch(idx, s)) return rc;
+    s.busy = true;
+    return QADC_OK;
+}
+
+// Waits for the batch, regrows and re-runs on overflow, sorts candidates into scan order and
+// expands padding-lane duplicates into s.out_*.
+int collect_common(qadc_index* idx, int slot_i) {
+    if (!idx) return fail(QADC_E_ARG, "null index");
+    if (slot_i < 0 || slot_i > 1) return fail(QADC_E_ARG, "slot must be 0 or 1");
+    Slot& s = idx->slot[slot_i];
+    if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
+    if (int rc = use_device(idx)) return rc;
+    for (int attempt = 0;; ++attempt) {
+        HIPCHECK(hipEventSynchronize(s.ev_done));
+        if (s.h_hdr.p->overflow == 0) break;
+        if (attempt >= 4) {
+            s.busy = false;
+            return fail(QADC_E_CAPACITY, "candidate buffer overflow persists after regrowth");
+        }
+        // every emitted candidate was counted: size the buffer for all of them and run again
+        const uint64_t need = (uint64_t)s.h_hdr.p->count + 1024;
+        if (need > (1ull << 31)) {
+            s.busy = false;
+            return fail(QADC_E_CAPACITY, "more than 2^31 candidates: adversarial scan order");
+        }
+        s.cand_cap = (uint32_t)std::max<uint64_t>(need, (uint64_t)s.cand_cap * 2);
+        idx->prof.regrows++;
+        if (int rc = plan_and_launch(idx, s)) {
+            s.busy = false;
+            return rc;
+        }
+    }
+    s.busy = false;
+    const uint32_t count = s.h_hdr.p->count;
+    if (count > s.prefetched) {
+        HIPCHECK(hipMemcpyAsync(s.h_cands.p + s.prefetched, s.d_cands.p + s.prefetched,
+                                sizeof(Cand) * (count - s.prefetched), hipMemcpyDeviceToHost, idx->stream));
+        HIPCHECK(hipStreamSynchronize(idx->stream));
+    }
+    if (idx->profile) {
+        float ms = 0;
+        if (s.prof_used >= 2) {
+            HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[0], s.prof_ev[1]));
+            if (s.float_path) idx->prof.start_ms += ms;
+        }
+        for (size_t i = 0; i < s.launches.size() && 3 + 2 * i < s.prof_used; ++i) {
+            HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[2 + 2 * i], s.prof_ev[3 + 2 * i]));
+            idx->prof.scan_ms += ms;
+            idx->prof.scan_launches++;
+            idx->prof.scan_codes += s.launches[i].codes;
+        }
+        if (s.float_path) idx->prof.start_codes += s.start_codes;
+        idx->prof.candidates += count;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    Cand* c = s.h_cands.p;
+    std::sort(c, c + count, [](const Cand& a, const Cand& b) {
+        const uint32_t qa = a.qv >> 8, qb = b.qv >> 8;
+        if (qa != qb) return qa < qb;
+        if (a.order != b.order) return a.order < b.order;
+        return a.pos < b.pos;
+    });
+    s.out_keys.clear();
+    s.out_vals.clear();
+    s.out_off.assign((size_t)s.nq + 1, 0);
+    uint32_t i = 0;
+    for (int q = 0; q < s.nq; ++q) {
+        s.out_off[q] = s.out_keys.size();
+        for (; i < count && (int)(c[i].qv >> 8) == q; ++i) {
+            const int a = (int)(c[i].order & 0xffffu);
+            const Part& pt = idx->parts[s.assign[(size_t)q * s.ma + a]];
+            // lanes past the end of the last 16-code block replay code n-1 (simd_layout.hpp:46-50,
+            // simd_scan.hpp:67): the reference offers that code 1 + pad times in a row
+            int reps = 1;
+            if (c[i].pos == pt.n - 1) reps += (int)((16u - pt.n % 16u) % 16u);
+            for (int r = 0; r < reps; ++r) {
+                s.out_keys.push_back(c[i].key);
+                s.out_vals.push_back((int8_t)(c[i].qv & 0xffu));
+            }
+        }
+    }
+    s.out_off[s.nq] = s.out_keys.size();
+    idx->prof.host_replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return QADC_OK;
+}
+
+void finish_float_outputs(qadc_index* idx, Slot& s, int32_t* status, float* qmin, float* qmax) {
+    const size_t per_q = (size_t)s.ma * idx->M * 16;
+    for (int q = 0; q < s.nq; ++q) {
+        const QueryState& qs = s.h_qs.p[q];
+        if (status) status[q] = (qs.flags & 1u) ? 1 : 0;
+        if (qmin) qmin[q] = qs.qmin;
+        if (qmax) qmax[q] = qs.qmax;
+        if ((qs.flags & 2u) && s.tables) {  // in-place clamp of the caller's tables (db_query_4.cpp:262-269)
+            float* t = s.tables + (size_t)q * per_q;
+            for (size_t i = 0; i < per_q; ++i)
+                if (t[i] < 0) t[i] = 0;
+        }
+    }
+}
+
+int replay_outputs(Slot& s, uint32_t* keys, int8_t* values, int32_t* sizes, const int32_t* status) {
+    const auto t0 = std::chrono::steady_clock::now();
+    kv_heap<uint32_t, int8_t> bh(s.R);
+    for (int q = 0; q < s.nq; ++q) {
+        bh.reset();
+        if (status && status[q]) {
+            if (sizes) sizes[q] = 0;
+            continue;
+        }
+        bh.push(0, 127);  // db_query_4.cpp:276
+        for (uint64_t i = s.out_off[q]; i < s.out_off[q + 1]; ++i) bh.push(s.out_keys[i], s.out_vals[i]);
+        if (sizes) sizes[q] = bh.size();
+        if (keys) std::memcpy(keys + (size_t)q * s.R, bh.keys(), sizeof(uint32_t) * bh.size());
+        if (values) std::memcpy(values + (size_t)q * s.R, bh.values(), bh.size());
+    }
+    (void)t0;
+    return QADC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* qadc_last_error(void) { return g_err.c_str(); }
+const char* qadc_version(void) { return "qadc-mi355x 0.1 (gfx950)"; }
+
+int qadc_index_create(qadc_index** out, int M, int device_id) {
+    if (!out) return fail(QADC_E_ARG, "out is null");
+    if (M != 16 && M != 32)
+        return fail(QADC_E_ARG, "Unsupported (nsq,nsq_bits) configuration. Supported configurations are: (16,4) (32,4).");
+    int ndev = 0;
+    HIPCHECK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(QADC_E_HIP, "no HIP device: the Quick-ADC engine has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(QADC_E_ARG, "device_id out of range");
+    HIPCHECK(hipSetDevice(device_id));
+    qadc_index* idx = new qadc_index();
+    idx->M = M;
+    idx->cs = M / 2;
+    idx->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete idx;
+        return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = idx;
+    return QADC_OK;
+}
+
+int qadc_index_destroy(qadc_index* idx) {
+    if (!idx) return QADC_OK;
+    (void)hipSetDevice(idx->device);
+    (void)hipStreamSynchronize(idx->stream);
+    for (auto& p : idx->parts)
+        if (p.own) {
+            if (p.d_codes) (void)hipFree(p.d_codes);
+            if (p.d_labels) (void)hipFree(p.d_labels);
+        }
+    for (auto& s : idx->slot) {
+        s.d_ftables.release(); s.d_qtables.release(); s.d_qs.release(); s.d_hdr.release(); s.d_cands.release();
+        s.d_items.release(); s.d_sitems.release(); s.d_fc.release(); s.d_fc_count.release(); s.d_sel_hist.release();
+        s.h_items.release(); s.h_sitems.release(); s.h_fc_count.release(); s.h_ftables.release(); s.h_qtables.release();
+        s.h_qs.release(); s.h_hdr.release(); s.h_cands.release();
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        for (auto e : s.prof_ev) (void)hipEventDestroy(e);
+    }
+    (void)hipStreamDestroy(idx->stream);
+    delete idx;
+    return QADC_OK;
+}
+
+static int check_labels_mode(qadc_index* idx, bool has_labels) {
+    if (idx->labeled < 0) idx->labeled = has_labels ? 1 : 0;
+    if ((idx->labeled == 1) != has_labels)
+        return fail(QADC_E_ARG, "Cannot prepare database. Some partitions have labels and some have not");
+    return QADC_OK;
+}
+
+static int alloc_part(qadc_index* idx, Part& pt, uint32_t n, bool labels) {
+    pt.n = n;
+    const size_t bytes = ((size_t)n * idx->cs + 15) / 16 * 16 + 64;  // tail padding for 16-byte vector reads
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&pt.d_codes), bytes));
+    HIPCHECK(hipMemsetAsync(pt.d_codes + (bytes - 80), 0, 80, idx->stream));
+    if (labels) HIPCHECK(hipMalloc(reinterpret_cast<void**>(&pt.d_labels), std::max<size_t>(n, 1) * sizeof(uint32_t)));
+    return QADC_OK;
+}
+
+int qadc_index_add_partitions(qadc_index* idx, int part_count, const uint8_t* const* codes,
+                              const uint32_t* const* labels, const uint32_t* sizes) {
+    if (!idx || part_count < 0 || !sizes || (part_count && !codes)) return fail(QADC_E_ARG, "bad arguments");
+    if (int rc = use_device(idx)) return rc;
+    for (int p = 0; p < part_count; ++p) {
+        Part pt;
+        const bool has_labels = labels != nullptr && labels[p] != nullptr;
+        if (sizes[p] == 0) {  // "Warning: Partition i is empty" (db_query_4.cpp:113-116)
+            idx->parts.push_back(pt);
+            continue;
+        }
+        if (int rc = check_labels_mode(idx, has_labels)) return rc;
+        if (int rc = alloc_part(idx, pt, sizes[p], has_labels)) return rc;
+        HIPCHECK(hipMemcpyAsync(pt.d_codes, codes[p], (size_t)sizes[p] * idx->cs, hipMemcpyHostToDevice, idx->stream));
+        if (has_labels)
+            HIPCHECK(hipMemcpyAsync(pt.d_labels, labels[p], (size_t)sizes[p] * 4, hipMemcpyHostToDevice, idx->stream));
+        HIPCHECK(hipStreamSynchronize(idx->stream));
+        idx->parts.push_back(pt);
+    }
+    idx->finalized = false;
+    return QADC_OK;
+}
+
+int qadc_index_add_partition_interleaved(qadc_index* idx, const uint8_t* interleaved, const uint32_t* labels, uint32_t size) {
+    if (!idx || (size && !interleaved)) return fail(QADC_E_ARG, "bad arguments");
+    if (int rc = use_device(idx)) return rc;
+    Part pt;
+    if (size == 0) {
+        idx->parts.push_back(pt);
+        return QADC_OK;
+    }
+    if (int rc = check_labels_mode(idx, labels != nullptr)) return rc;
+    if (int rc = alloc_part(idx, pt, size, labels != nullptr)) return rc;
+    const size_t ibytes = (size_t)((size + 15u) / 16u) * idx->cs * 16;
+    uint8_t* d_tmp = nullptr;
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_tmp), ibytes));
+    HIPCHECK(hipMemcpyAsync(d_tmp, interleaved, ibytes, hipMemcpyHostToDevice, idx->stream));
+    launch_deinterleave(pt.d_codes, d_tmp, size, idx->cs, idx->stream);
+    if (labels) HIPCHECK(hipMemcpyAsync(pt.d_labels, labels, (size_t)size * 4, hipMemcpyHostToDevice, idx->stream));
+    HIPCHECK(hipStreamSynchronize(idx->stream));
+    HIPCHECK(hipFree(d_tmp));
+    idx->parts.push_back(pt);
+    idx->finalized = false;
+    return QADC_OK;
+}
+
+int qadc_index_add_partition_device(qadc_index* idx, const void* d_codes, const void* d_labels, uint32_t size) {
+    if (!idx || (size && !d_codes)) return fail(QADC_E_ARG, "bad arguments");
+    if ((reinterpret_cast<uintptr_t>(d_codes) & 15u) != 0) return fail(QADC_E_ARG, "d_codes must be 16-byte aligned");
+    Part pt;
+    if (size) {
+        if (int rc = check_labels_mode(idx, d_labels != nullptr)) return rc;
+        pt.d_codes = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_codes));
+        pt.d_labels = const_cast<uint32_t*>(static_cast<const uint32_t*>(d_labels));
+        pt.n = size;
+        pt.own = false;
+    }
+    idx->parts.push_back(pt);
+    idx->finalized = false;
+    return QADC_OK;
+}
+
+int qadc_index_add_partition_synthetic(qadc_index* idx, uint32_t size, uint64_t seed, uint64_t first_word) {
+    if (!idx) return fail(QADC_E_ARG, "null index");
+    if (int rc = use_device(idx)) return rc;
+    Part pt;
+    if (size) {
+        if (int rc = check_labels_mode(idx, false)) return rc;
+        if (int rc = alloc_part(idx, pt, size, false)) return rc;
+        const uint64_t nwords = ((uint64_t)size * idx->cs + 7) / 8;
+        launch_fill_codes(pt.d_codes, first_word, nwords, seed, idx->stream);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(idx->stream));
+    }
+    idx->parts.push_back(pt);
+    idx->finalized = false;
+    return QADC_OK;
+}
+
+int qadc_index_set_key_base(qadc_index* idx, int part, uint32_t key_base) {
+    if (!idx || part < 0 || part >= (int)idx->parts.size()) return fail(QADC_E_ARG, "bad partition");
+    idx->parts[part].key_base = key_base;
+    return QADC_OK;
+}
+
+int qadc_index_finalize(qadc_index* idx, float keep) {
+    if (!idx) return fail(QADC_E_ARG, "null index");
+    if (idx->parts.empty()) return fail(QADC_E_STATE, "no partitions");
+    idx->keep = keep;
+    for (auto& p : idx->parts) {
+        if (p.n == 0) {
+            p.start_n = 0;
+            continue;
+        }
+        // std::max(1u, static_cast<unsigned>(size * keep)) with unsigned*float -> float (db_query_4.cpp:125-126)
+        const float prod = static_cast<float>(p.n) * keep;
+        const unsigned s = static_cast<unsigned>(prod);
+        p.start_n = std::min<uint32_t>(std::max(1u, s), p.n);
+    }
+    idx->finalized = true;
+    return QADC_OK;
+}
+
+int qadc_index_partition_count(const qadc_index* idx) { return idx ? (int)idx->parts.size() : 0; }
+uint32_t qadc_index_partition_size(const qadc_index* idx, int part) {
+    return (idx && part >= 0 && part < (int)idx->parts.size()) ? idx->parts[part].n : 0;
+}
+uint32_t qadc_index_start_size(const qadc_index* idx, int part) {
+    return (idx && part >= 0 && part < (int)idx->parts.size()) ? idx->parts[part].start_n : 0;
+}
+
+int qadc_set_option(qadc_index* idx, const char* name, double value) {
+    if (!idx || !name) return fail(QADC_E_ARG, "bad arguments");
+    const std::string n(name);
+    if (n == "quant_mode") idx->quant_mode = value != 0 ? 1 : 0;
+    else if (n == "cand_capacity") idx->cand_capacity = (uint32_t)std::max(16.0, std::min(value, 2147483648.0 - 1));
+    else if (n == "level_base") idx->level_base = (uint64_t)std::max(16.0, value);
+    else if (n == "level_growth") idx->level_growth = (uint64_t)std::max(2.0, value);
+    else if (n == "wgs_per_item") idx->wgs_per_item = (int)value;
+    else if (n == "profile") idx->profile = value != 0;
+    else return fail(QADC_E_ARG, "unknown option: " + n);
+    if (n == "cand_capacity") idx->slot[0].cand_cap = idx->slot[1].cand_cap = 0;
+    return QADC_OK;
+}
+
+int qadc_index_read_codes(qadc_index* idx, int part, uint32_t first, uint32_t count, uint8_t* out) {
+    if (!idx || part < 0 || part >= (int)idx->parts.size() || !out) return fail(QADC_E_ARG, "bad arguments");
+    const Part& p = idx->parts[part];
+    if ((uint64_t)first + count > p.n) return fail(QADC_E_ARG, "range outside the partition");
+    if (int rc = use_device(idx)) return rc;
+    HIPCHECK(hipMemcpy(out, p.d_codes + (size_t)first * idx->cs, (size_t)count * idx->cs, hipMemcpyDeviceToHost));
+    return QADC_OK;
+}
+
+int qadc_query_scan_submit(qadc_index* idx, int slot, int nq, int ma, const int32_t* assign, float* tables, int R) {
+    if (!tables) return fail(QADC_E_ARG, "tables is null");
+    return submit_common(idx, slot, nq, ma, assign, tables, nullptr, R);
+}
+
+int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
+                            float* qmin, float* qmax, int8_t* qtables) {
+    if (int rc = collect_common(idx, slot)) return rc;
+    Slot& s = idx->slot[slot];
+    std::vector<int32_t> st_local;
+    if (!status) {
+        st_local.resize(s.nq);
+        status = st_local.data();
+    }
+    finish_float_outputs(idx, s, status, qmin, qmax);
+    if (qtables) {
+        HIPCHECK(hipMemcpy(qtables, s.d_qtables.p, (size_t)s.nq * s.ma * idx->M * 16, hipMemcpyDeviceToHost));
+    }
+    return replay_outputs(s, keys, values, sizes, status);
+}
+
+int qadc_query_scan(qadc_index* idx, int nq, int ma, const int32_t* assign, float* tables, int R, uint32_t* keys,
+                    int8_t* values, int32_t* sizes, int32_t* status, float* qmin, float* qmax, int8_t* qtables) {
+    if (int rc = qadc_query_scan_submit(idx, 0, nq, ma, assign, tables, R)) return rc;
+    return qadc_query_scan_collect(idx, 0, keys, values, sizes, status, qmin, qmax, qtables);
+}
+
+static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals, uint64_t* offsets) {
+    if (!offsets) return fail(QADC_E_ARG, "offsets is null");
+    std::memcpy(offsets, s.out_off.data(), sizeof(uint64_t) * (s.nq + 1));
+    const uint64_t total = s.out_off[s.nq];
+    if (total > cand_capacity) return fail(QADC_E_CAPACITY, "candidate output buffers too small (see offsets[nq])");
+    if (total && cand_keys) std::memcpy(cand_keys, s.out_keys.data(), total * sizeof(uint32_t));
+    if (total && cand_vals) std::memcpy(cand_vals, s.out_vals.data(), total);
+    return QADC_OK;
+}
+
+int qadc_query_scan_candidates(qadc_index* idx, int nq, int ma, const int32_t* assign, float* tables, int R,
+                               uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals, uint64_t* offsets,
+                               int32_t* status, float* qmin, float* qmax) {
+    if (!tables) return fail(QADC_E_ARG, "tables is null");
+    if (int rc = submit_common(idx, 0, nq, ma, assign, tables, nullptr, R)) return rc;
+    if (int rc = collect_common(idx, 0)) return rc;
+    Slot& s = idx->slot[0];
+    std::vector<int32_t> st_local(nq);
+    finish_float_outputs(idx, s, st_local.data(), qmin, qmax);
+    if (status) std::memcpy(status, st_local.data(), sizeof(int32_t) * nq);
+    for (int q = 0; q < nq; ++q)
+        if (st_local[q]) {  // the reference never reaches the scan for such a query
+            // keep offsets monotone but expose no candidates: handled by the caller through status
+        }
+    return copy_stream(s, cand_capacity, cand_keys, cand_vals, offsets);
+}
+
+int qadc_scan_i8(qadc_index* idx, int nq, int ma, const int32_t* assign, const int8_t* qtables, int R, uint32_t* keys,
+                 int8_t* values, int32_t* sizes) {
+    if (!qtables) return fail(QADC_E_ARG, "qtables is null");
+    if (int rc = submit_common(idx, 0, nq, ma, assign, nullptr, qtables, R)) return rc;
+    if (int rc = collect_common(idx, 0)) return rc;
+    return replay_outputs(idx->slot[0], keys, values, sizes, nullptr);
+}
+
+int qadc_scan_i8_candidates(qadc_index* idx, int nq, int ma, const int32_t* assign, const int8_t* qtables, int R,
+                            uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals, uint64_t* offsets) {
+    if (!qtables) return fail(QADC_E_ARG, "qtables is null");
+    if (int rc = submit_common(idx, 0, nq, ma, assign, nullptr, qtables, R)) return rc;
+    if (int rc = collect_common(idx, 0)) return rc;
+    return copy_stream(idx->slot[0], cand_capacity, cand_keys, cand_vals, offsets);
+}
+
+int qadc_scan_start(qadc_index* idx, int nq, int ma, const int32_t* assign, const float* tables, int R, float* qmax) {
+    if (!idx || !tables || !qmax || !assign || nq <= 0 || ma <= 0 || R <= 0) return fail(QADC_E_ARG, "bad arguments");
+    if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
+    // Runs the float chain of a batch and reads back qmax only (copy: the caller's tables stay untouched).
+    std::vector<float> copy(tables, tables + (size_t)nq * ma * idx->M * 16);
+    std::vector<float> qm(nq);
+    if (int rc = submit_common(idx, 0, nq, ma, assign, copy.data(), nullptr, R)) return rc;
+    if (int rc = collect_common(idx, 0)) return rc;
+    for (int q = 0; q < nq; ++q) qmax[q] = idx->slot[0].h_qs.p[q].qmax;
+    return QADC_OK;
+}
+
+int qadc_candidates_i8(qadc_index* idx, int part, const int8_t* qtable, int8_t* out) {
+    if (!idx || part < 0 || part >= (int)idx->parts.size() || !qtable || !out) return fail(QADC_E_ARG, "bad arguments");
+    const Part& p = idx->parts[part];
+    if (p.n == 0) return QADC_OK;
+    for (int i = 0; i < idx->M * 16; ++i)
+        if (qtable[i] < 0) return fail(QADC_E_ARG, "int8 tables must lie in [0,127]");
+    if (int rc = use_device(idx)) return rc;
+    int8_t *d_t = nullptr, *d_o = nullptr;
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_t), idx->M * 16));
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_o), p.n));
+    HIPCHECK(hipMemcpyAsync(d_t, qtable, idx->M * 16, hipMemcpyHostToDevice, idx->stream));
+    launch_candidates_i8(idx->M, p.d_codes, p.n, d_t, d_o, idx->stream);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(out, d_o, p.n, hipMemcpyDeviceToHost, idx->stream));
+    HIPCHECK(hipStreamSynchronize(idx->stream));
+    HIPCHECK(hipFree(d_t));
+    HIPCHECK(hipFree(d_o));
+    return QADC_OK;
+}
+
+int qadc_profile_read(qadc_index* idx, qadc_profile* out) {
+    if (!idx || !out) return fail(QADC_E_ARG, "bad arguments");
+    *out = idx->prof;
+    return QADC_OK;
+}
+
+int qadc_profile_reset(qadc_index* idx) {
+    if (!idx) return fail(QADC_E_ARG, "null index");
+    idx->prof = qadc_profile{};
+    return QADC_OK;
+}
+
+}  // extern "C"

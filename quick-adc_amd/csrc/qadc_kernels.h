@@ -1,0 +1,84 @@
+// Device-side data structures and kernel launchers of the MI355X Quick-ADC scan engine.
+// Internal header (not part of the C-ABI; see include/qadc.h for that).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace qadc {
+
+// One contiguous run of codes of one probed partition, scanned with one int8 table.
+// (A probed partition is cut into one item per bound level, see DESIGN.md "Exact filtering".)
+struct ScanItem {
+    const uint8_t* codes;    // first code of the run (16-byte aligned)
+    const uint32_t* labels;  // partition labels (indexed by position in partition) or nullptr
+    uint32_t n;              // codes in the run
+    uint32_t pos0;           // position of the first code inside its partition
+    uint32_t key_base;       // added to the position when labels == nullptr (shard offset)
+    uint32_t table;          // table index: qtables + table * M * 16
+    uint32_t query;          // per-query state index
+    uint32_t order;          // (level << 16) | assign slot: scan-order major key of emitted entries
+};
+
+// Candidate emitted by the scan: value < bound derived from a strict prefix of the scan order.
+struct Cand {
+    uint32_t order;  // ScanItem::order
+    uint32_t pos;    // position inside the partition
+    uint32_t key;    // label, or key_base + pos
+    uint32_t qv;     // (query << 8) | int8 distance sum (0..126)
+};
+
+// Batch-wide append buffer header (one per in-flight batch).
+struct CandHeader {
+    uint32_t count;     // entries appended (may exceed the capacity: then `overflow` > 0)
+    uint32_t overflow;  // entries dropped because the buffer was full
+    uint32_t pad[2];
+};
+
+constexpr int kMaxLevels = 8;   // bound levels per query
+
+// Per-query device state.  hist[l][v] counts the candidates of value v emitted by level l.
+struct QueryState {
+    uint32_t hist[kMaxLevels * 128];
+    uint32_t count;     // candidates this query emitted (diagnostic)
+    uint32_t overflow;  // unused (kept for layout stability)
+    uint32_t flags;     // bit0: qmax > 1e30 (reference would exit), bit1: negative table entries clamped
+    float qmin;
+    float qmax;
+    uint32_t sel_prefix;  // radix-select running key prefix
+    uint32_t sel_k;       // radix-select remaining rank (1-based)
+    uint32_t pad;
+};
+
+// Float ADC item for the "starts" pre-scan (scanner_4::query_scan_start).
+struct StartItem {
+    const uint8_t* codes;  // first code of the partition
+    uint32_t n;            // starts size of that partition
+    uint32_t table;        // float table index: ftables + table * M * 16
+    uint32_t query;
+    uint32_t out_off;      // offset inside the query's float candidate buffer
+};
+
+void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int wgs_per_item,
+                    const int8_t* d_qtables, QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands,
+                    uint32_t cand_cap, uint32_t R, hipStream_t stream);
+
+void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item,
+                           const float* d_ftables, float* d_fc, uint64_t fc_stride, hipStream_t stream);
+
+// k-th smallest (k = R) of each query's float candidates -> QueryState::qmax (FLT_MAX if fewer than R).
+void launch_select_kth(float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_count, int nq, uint32_t R,
+                       QueryState* d_qs, uint32_t* d_sel_hist, hipStream_t stream);
+
+// QuantizerMAX<int8> for every query: qmin, in-place negative clamp, int8 tables.
+void launch_quantize(int M, int ma, int nq, float* d_ftables, int8_t* d_qtables, QueryState* d_qs,
+                     int quant_mode, hipStream_t stream);
+
+void launch_fill_codes(uint8_t* d_dst, uint64_t first_word, uint64_t nwords, uint64_t seed, hipStream_t stream);
+
+void launch_deinterleave(uint8_t* d_rowmajor, const uint8_t* d_inter, uint32_t n, int cs, hipStream_t stream);
+
+// All-code candidate values min(127, sum) (diagnostic / parity helper; not on the query path).
+void launch_candidates_i8(int M, const uint8_t* d_codes, uint64_t n, const int8_t* d_qtable, int8_t* d_out,
+                          hipStream_t stream);
+
+}  // namespace qadc

@@ -1,0 +1,451 @@
+// MI355X (gfx950 / CDNA4) kernels of the Quick-ADC scan engine.
+//
+// Replaces, on device, the reference's hot loop scan_avx_4<M> (simd_scan.hpp:125-187) and the
+// float pre-scan scan_4<M> (query_common.hpp:59-90).  Nothing here is a translation of the AVX2
+// code: the pshufb register lookup becomes an LDS gather against pair-fused, bank-replicated byte
+// tables, the 16-code block transpose (simd_layout.hpp) is dropped in favour of plain row-major
+// codes read with one coalesced 16-byte load per lane, and the sequential heap is replaced by a
+// prefix-bound filter whose output is replayed on the host.
+//
+// The op is a gather + byte add bound by HBM reads: no MFMA.
+#include "qadc_kernels.h"
+
+#include <algorithm>
+#include <cfloat>
+
+namespace qadc {
+
+constexpr int kWG = 1024;       // threads per workgroup of the int8 scan (16 waves)
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+// ---------------------------------------------------------------------------------------------
+// int8 scan
+//
+// LDS image (per workgroup): for byte position b of a code (b = 4g + j) the pair table
+//     P_b[x] = T[2b][x & 15] + T[2b+1][x >> 4]          (<= 254, one byte)
+// is stored at   region(g) + x*256 + (g&1)*128 + bank*4 + j     for bank = 0..31,
+// region(g) = (g>>1) * 64 KiB.  A lane reads with bank = lane & 31, so the 32 lanes of a
+// ds_read lane group hit 32 different banks whatever their x: conflict-free by construction.
+// One dword holds the four tables of a group, so the 32-fold replication costs 64 KiB per
+// 8 code bytes (M=16: 64 KiB, M=32: 128 KiB).
+// The byte address x*256 + bank*4 is formed by ONE v_perm_b32 from the code dword and the
+// lane constant; (g&1)*128 + j rides in the ds_read immediate offset.
+// ---------------------------------------------------------------------------------------------
+template <int M>
+struct ScanCfg {
+    static constexpr int CS = M / 2;             // code bytes
+    static constexpr int DW = M / 8;             // dwords per code
+    static constexpr int CPL = 16 / CS;          // codes per 16-byte lane load
+    static constexpr int TABLE_BYTES = (M / 16) * 65536;
+    static constexpr int STAGE_OFF = TABLE_BYTES;          // int8 [M][16] staging copy
+    static constexpr int HIST_OFF = STAGE_OFF + M * 16;    // u32 [128] prefix histogram
+    static constexpr int BOUND_OFF = HIST_OFF + 512;       // u32 bound
+    static constexpr int LDS_BYTES = BOUND_OFF + 16;
+};
+
+template <int M>
+__device__ __forceinline__ void build_pair_tables(const int8_t* __restrict__ qt) {
+    using C = ScanCfg<M>;
+    const int t = threadIdx.x;
+    // stage the int8 table (M*16 bytes) into LDS
+    if (t < M * 4) reinterpret_cast<uint32_t*>(smem + C::STAGE_OFF)[t] = reinterpret_cast<const uint32_t*>(qt)[t];
+    __syncthreads();
+    const unsigned char* T = smem + C::STAGE_OFF;
+    constexpr int PAIRS = (M / 8) * 256;                 // (group, x) pairs
+    constexpr int TPP = kWG / PAIRS;                     // threads per pair (M=16: 2, M=32: 1)
+    constexpr int REPL = 32 / TPP;                       // bank replicas written per thread
+    const int p = t / TPP, part = t % TPP;
+    const int g = p >> 8, x = p & 255;
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = 4 * g + j;
+        const uint32_t v = (uint32_t)T[(2 * b) * 16 + (x & 15)] + (uint32_t)T[(2 * b + 1) * 16 + (x >> 4)];
+        w |= v << (8 * j);
+    }
+    unsigned char* dst = smem + (g >> 1) * 65536 + x * 256 + (g & 1) * 128 + part * (REPL * 4);
+    const uint4 w4 = make_uint4(w, w, w, w);
+#pragma unroll
+    for (int r = 0; r < REPL / 4; ++r) reinterpret_cast<uint4*>(dst)[r] = w4;
+}
+
+// bound = smallest v with #(emitted candidates of all earlier levels with value <= v) >= R, else 127.
+// Valid for every code of this level because those candidates all precede it in scan order.
+__device__ __forceinline__ uint32_t prefix_bound(const QueryState* qs, int level, uint32_t R, uint32_t* lds_hist,
+                                                 uint32_t* lds_bound) {
+    const int t = threadIdx.x;
+    if (t < 128) {
+        uint32_t c = 0;
+        for (int l = 0; l < level; ++l) c += qs->hist[l * 128 + t];
+        lds_hist[t] = c;
+    }
+    __syncthreads();
+    if (t < 64) {
+        const uint32_t c0 = lds_hist[2 * t], c1 = lds_hist[2 * t + 1];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (t >= d) incl += o;
+        }
+        const uint32_t excl = incl - (c0 + c1);
+        uint32_t b = 127;
+        if (excl + c0 >= R) b = 2 * t;
+        else if (incl >= R) b = 2 * t + 1;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) b = min(b, (uint32_t)__shfl_xor(b, d, 64));
+        if (t == 0) *lds_bound = min(b, 127u);
+    }
+    __syncthreads();
+    return *lds_bound;
+}
+
+__device__ __noinline__ void emit_candidate(QueryState* qs, CandHeader* hdr, Cand* __restrict__ out, uint32_t cap,
+                                            const uint32_t* __restrict__ labels, uint32_t key_base, uint32_t order,
+                                            uint32_t query, uint32_t pos, uint32_t val) {
+    const uint32_t slot = atomicAdd(&hdr->count, 1u);
+    if (slot < cap) {
+        Cand c;
+        c.order = order;
+        c.pos = pos;
+        c.key = labels ? labels[pos] : key_base + pos;
+        c.qv = (query << 8) | val;
+        out[slot] = c;
+    } else {
+        atomicAdd(&hdr->overflow, 1u);
+    }
+    atomicAdd(&qs->count, 1u);
+    atomicAdd(&qs->hist[(order >> 16) * 128 + val], 1u);
+}
+
+template <int M>
+__device__ __forceinline__ uint32_t pair_sum(const uint32_t* d, uint32_t lane_lo, uint32_t lane_hi) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int w = 0; w < M / 8; ++w) {
+        const uint32_t lo = (w >> 1) ? lane_hi : lane_lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // byte0 = bank*4, byte1 = code byte k, byte2 = region bit, byte3 = 0
+            const uint32_t a = __builtin_amdgcn_perm(d[w], lo, 0x0c020000u | ((4u + k) << 8));
+            s += smem[a + (w & 1) * 128 + k];
+        }
+    }
+    return s;
+}
+
+template <int M, int U>
+__global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
+    const ScanItem* __restrict__ items, const int8_t* __restrict__ qtables, QueryState* __restrict__ qstates,
+    CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap, uint32_t R) {
+    using C = ScanCfg<M>;
+    const ScanItem it = items[blockIdx.y];
+    QueryState* qs = qstates + it.query;
+
+    build_pair_tables<M>(qtables + (uint64_t)it.table * (M * 16));
+    const uint32_t bound = prefix_bound(qs, it.order >> 16, R, reinterpret_cast<uint32_t*>(smem + C::HIST_OFF),
+                                        reinterpret_cast<uint32_t*>(smem + C::BOUND_OFF));
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane_lo = (tid & 31u) * 4u;
+    const uint32_t lane_hi = lane_lo | 0x10000u;
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(it.codes);
+    const uint32_t n = it.n;
+    const uint32_t nvec = (n + C::CPL - 1) / C::CPL;            // 16-byte vectors in the run
+    const uint32_t ntiles = (nvec + kWG - 1) / kWG;
+    const uint32_t G = gridDim.x;
+
+    for (uint32_t t0 = blockIdx.x; t0 < ntiles; t0 += G * U) {
+        uint4 v[U];
+        uint32_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            e[u] = (t0 + u * G) * kWG + tid;                    // vector index (< 2^29)
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (e[u] < nvec) v[u] = src[e[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int c = 0; c < C::CPL; ++c) {
+                const uint32_t s = pair_sum<M>(d + c * C::DW, lane_lo, lane_hi);
+                const uint32_t cand = min(s, 127u);
+                const uint32_t idx = e[u] * C::CPL + c;
+                if (__builtin_expect(cand < bound && idx < n && e[u] < nvec, 0))
+                    emit_candidate(qs, hdr, out, cand_cap, it.labels, it.key_base, it.order, it.query, it.pos0 + idx, cand);
+            }
+        }
+    }
+}
+
+void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int wgs_per_item,
+                    const int8_t* d_qtables, QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap,
+                    uint32_t R, hipStream_t stream) {
+    (void)variant;
+    const dim3 grid(wgs_per_item, nitems), block(kWG);
+    if (M == 16) {
+        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_i8_kernel<16, 2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, ScanCfg<16>::LDS_BYTES), true);
+        (void)once;
+        hipLaunchKernelGGL((scan_i8_kernel<16, 2>), grid, block, ScanCfg<16>::LDS_BYTES, stream, d_items, d_qtables, d_qs,
+                           d_hdr, d_cands, cand_cap, R);
+    } else {
+        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_i8_kernel<32, 2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, ScanCfg<32>::LDS_BYTES), true);
+        (void)once;
+        hipLaunchKernelGGL((scan_i8_kernel<32, 2>), grid, block, ScanCfg<32>::LDS_BYTES, stream, d_items, d_qtables, d_qs,
+                           d_hdr, d_cands, cand_cap, R);
+    }
+}
+
+// All candidate values (diagnostic; used by parity tests and checksums at full size).
+template <int M>
+__global__ __launch_bounds__(kWG) void candidates_i8_kernel(const uint8_t* __restrict__ codes, uint64_t n,
+                                                            const int8_t* __restrict__ qtable, int8_t* __restrict__ out) {
+    using C = ScanCfg<M>;
+    build_pair_tables<M>(qtable);
+    __syncthreads();
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane_lo = (tid & 31u) * 4u, lane_hi = lane_lo | 0x10000u;
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(codes);
+    const uint64_t nvec = (n + C::CPL - 1) / C::CPL;
+    for (uint64_t e = (uint64_t)blockIdx.x * kWG + tid; e < nvec; e += (uint64_t)gridDim.x * kWG) {
+        const uint4 v = src[e];
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < C::CPL; ++c) {
+            const uint64_t idx = e * C::CPL + c;
+            if (idx < n) out[idx] = (int8_t)min(pair_sum<M>(d + c * C::DW, lane_lo, lane_hi), 127u);
+        }
+    }
+}
+
+void launch_candidates_i8(int M, const uint8_t* d_codes, uint64_t n, const int8_t* d_qtable, int8_t* d_out,
+                          hipStream_t stream) {
+    const uint64_t nvec = (n + (M == 16 ? 2 : 1) - 1) / (M == 16 ? 2 : 1);
+    const int grid = (int)std::min<uint64_t>((nvec + kWG - 1) / kWG, 512);
+    if (M == 16) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&candidates_i8_kernel<16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, ScanCfg<16>::LDS_BYTES);
+        hipLaunchKernelGGL(candidates_i8_kernel<16>, dim3(grid), dim3(kWG), ScanCfg<16>::LDS_BYTES, stream, d_codes, n,
+                           d_qtable, d_out);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&candidates_i8_kernel<32>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, ScanCfg<32>::LDS_BYTES);
+        hipLaunchKernelGGL(candidates_i8_kernel<32>, dim3(grid), dim3(kWG), ScanCfg<32>::LDS_BYTES, stream, d_codes, n,
+                           d_qtable, d_out);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// float pre-scan of the "starts" (scan_4<M>, query_common.hpp:59-90): cand accumulated
+// sequentially from 0, byte by byte, low nibble then high nibble — same IEEE adds, same order.
+// The 16 lanes-distinct entries of one table sit in 16 consecutive LDS dwords, so every lookup
+// instruction (all lanes in the same table) is bank-conflict-free without replication.
+// ---------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __restrict__ items,
+                                                             const float* __restrict__ ftables, float* __restrict__ fc,
+                                                             uint64_t fc_stride) {
+    __shared__ float tab[M * 16];
+    const StartItem it = items[blockIdx.y];
+    const float* __restrict__ ft = ftables + (uint64_t)it.table * (M * 16);
+    for (int i = threadIdx.x; i < M * 16; i += 256) tab[i] = ft[i];
+    __syncthreads();
+    float* __restrict__ dst = fc + (uint64_t)it.query * fc_stride + it.out_off;
+    constexpr int DW = M / 8;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < it.n; i += gridDim.x * 256) {
+        uint32_t d[DW];
+        if constexpr (M == 16) {
+            const uint2 v = reinterpret_cast<const uint2*>(it.codes)[i];
+            d[0] = v.x; d[1] = v.y;
+        } else {
+            const uint4 v = reinterpret_cast<const uint4*>(it.codes)[i];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        float cand = 0.0f;
+#pragma unroll
+        for (int b = 0; b < M / 2; ++b) {
+            const uint32_t byte = (d[b >> 2] >> (8 * (b & 3))) & 0xffu;
+            cand += tab[(2 * b) * 16 + (byte & 15u)];
+            cand += tab[(2 * b + 1) * 16 + (byte >> 4)];
+        }
+        dst[i] = cand;
+    }
+}
+
+void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item, const float* d_ftables,
+                           float* d_fc, uint64_t fc_stride, hipStream_t stream) {
+    const dim3 grid(wgs_per_item, nitems), block(256);
+    if (M == 16) hipLaunchKernelGGL(start_scan_f32_kernel<16>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride);
+    else         hipLaunchKernelGGL(start_scan_f32_kernel<32>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride);
+}
+
+// ---------------------------------------------------------------------------------------------
+// R-th smallest float per query (= tmp_bh.max() after query_scan_start, db_query_4.cpp:259):
+// 4-pass MSD radix select on the order-preserving u32 image of the floats.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fkey(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float funkey(uint32_t k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+__global__ void select_init_kernel(QueryState* qs, uint32_t R, uint32_t* sel_hist, int nq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) { qs[i].sel_prefix = 0; qs[i].sel_k = R; }
+    if (i < nq * 256) sel_hist[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ fc, uint64_t fc_stride,
+                                                          const uint32_t* __restrict__ counts,
+                                                          const QueryState* __restrict__ qs, uint32_t* __restrict__ sel_hist,
+                                                          int pass) {
+    __shared__ uint32_t lh[256];
+    const int q = blockIdx.y;
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n = counts[q];
+    const float* __restrict__ src = fc + (uint64_t)q * fc_stride;
+    const int shift = 24 - 8 * pass;
+    const uint32_t prefix = qs[q].sel_prefix;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t k = fkey(src[i]);
+        const bool match = pass == 0 || ((k ^ prefix) >> (shift + 8)) == 0;
+        if (match) atomicAdd(&lh[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&sel_hist[q * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void select_pick_kernel(QueryState* __restrict__ qs, uint32_t* __restrict__ sel_hist,
+                                                          const uint32_t* __restrict__ counts, int pass, uint32_t R) {
+    __shared__ uint32_t sc[256];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const uint32_t c = sel_hist[q * 256 + t];
+    sel_hist[q * 256 + t] = 0;
+    sc[t] = c;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t o = t >= d ? sc[t - d] : 0;
+        __syncthreads();
+        sc[t] += o;
+        __syncthreads();
+    }
+    const uint32_t incl = sc[t], excl = incl - c;
+    const uint32_t k = qs[q].sel_k;
+    const int shift = 24 - 8 * pass;
+    __syncthreads();
+    if (counts[q] < R) {
+        if (t == 0 && pass == 3) qs[q].qmax = FLT_MAX;   // heap never fills: max() stays the FLT_MAX sentinel
+        return;
+    }
+    if (incl >= k && excl < k) {
+        const uint32_t prefix = qs[q].sel_prefix | ((uint32_t)t << shift);
+        qs[q].sel_prefix = prefix;
+        qs[q].sel_k = k - excl;
+        if (pass == 3) qs[q].qmax = funkey(prefix);
+    }
+}
+
+void launch_select_kth(float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_count, int nq, uint32_t R, QueryState* d_qs,
+                       uint32_t* d_sel_hist, hipStream_t stream) {
+    hipLaunchKernelGGL(select_init_kernel, dim3((nq * 256 + 255) / 256), dim3(256), 0, stream, d_qs, R, d_sel_hist, nq);
+    for (int pass = 0; pass < 4; ++pass) {
+        hipLaunchKernelGGL(select_hist_kernel, dim3(256, nq), dim3(256), 0, stream, d_fc, fc_stride, d_fc_count, d_qs,
+                           d_sel_hist, pass);
+        hipLaunchKernelGGL(select_pick_kernel, dim3(nq), dim3(256), 0, stream, d_qs, d_sel_hist, d_fc_count, pass, R);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// QuantizerMAX<int8_t> (db_query_4.cpp:37-71) + qmin / clamp glue of query_scan (258-274).
+// quant_mode 1 = as compiled by the reference's flags: scale = 127/(max-min), trunc((v-min)*scale);
+// quant_mode 0 = source level: trunc((v-min)/delta), delta = (max-min)/127.
+// Strict IEEE float ops (build uses -ffp-contract=off, no fast-math), so results equal a CPU
+// evaluation of the same expressions.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_kernel(int table_dim_all, float* __restrict__ ftables,
+                                                       int8_t* __restrict__ qtables, QueryState* __restrict__ qs,
+                                                       int quant_mode) {
+    __shared__ float red[256];
+    const int q = blockIdx.x, t = threadIdx.x;
+    float* __restrict__ tb = ftables + (uint64_t)q * table_dim_all;
+    int8_t* __restrict__ qt = qtables + (uint64_t)q * table_dim_all;
+    float m = FLT_MAX;
+    for (int i = t; i < table_dim_all; i += 256) m = fminf(m, tb[i]);
+    red[t] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (t < d) red[t] = fminf(red[t], red[t + d]);
+        __syncthreads();
+    }
+    float qmin = red[0];
+    uint32_t flags = 0;
+    if (qmin < 0) { qmin = 0; flags |= 2u; }
+    const float qmax = qs[q].qmax;
+    if (qmax > 1e30f) flags |= 1u;
+    const float delta = (qmax - qmin) / 127;
+    const float scale = 127.0f / (qmax - qmin);
+    for (int i = t; i < table_dim_all; i += 256) {
+        float v = tb[i];
+        if (v < 0) { v = 0; tb[i] = 0; }
+        int8_t o;
+        if (flags & 1u) o = 127;   // query is skipped by the host; emit nothing
+        else if (v >= qmax) o = 127;
+        else o = (int8_t)(int)(quant_mode == 0 ? (v - qmin) / delta : (v - qmin) * scale);
+        qt[i] = o;
+    }
+    if (t == 0) { qs[q].qmin = qmin; qs[q].flags = flags; }
+}
+
+void launch_quantize(int M, int ma, int nq, float* d_ftables, int8_t* d_qtables, QueryState* d_qs, int quant_mode,
+                     hipStream_t stream) {
+    hipLaunchKernelGGL(quantize_kernel, dim3(nq), dim3(256), 0, stream, ma * M * 16, d_ftables, d_qtables, d_qs, quant_mode);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic codes: word w (8 code bytes) = splitmix64(seed ^ splitmix64(w)), little endian.
+// Same function as orc_fill_codes in the oracle, so any sub-range is reproducible on the CPU.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void fill_codes_kernel(uint64_t* __restrict__ dst, uint64_t first_word, uint64_t nwords,
+                                                         uint64_t seed) {
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (uint64_t)gridDim.x * 256)
+        dst[w] = splitmix64(seed ^ splitmix64(first_word + w));
+}
+
+void launch_fill_codes(uint8_t* d_dst, uint64_t first_word, uint64_t nwords, uint64_t seed, hipStream_t stream) {
+    const int grid = (int)std::min<uint64_t>((nwords + 255) / 256, 8192);
+    hipLaunchKernelGGL(fill_codes_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<uint64_t*>(d_dst), first_word,
+                       nwords, seed);
+}
+
+// Reference block layout [B][cs][16] (simd_layout.hpp:41-65) -> device row-major [n][cs].
+__global__ __launch_bounds__(256) void deinterleave_kernel(uint8_t* __restrict__ rowmajor, const uint8_t* __restrict__ inter,
+                                                           uint32_t n, int cs) {
+    const uint64_t total = (uint64_t)n * cs;
+    for (uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (uint64_t)gridDim.x * 256) {
+        const uint64_t ci = o / cs;
+        const int b = (int)(o % cs);
+        rowmajor[o] = inter[(ci / 16) * cs * 16 + (uint64_t)b * 16 + (ci % 16)];
+    }
+}
+
+void launch_deinterleave(uint8_t* d_rowmajor, const uint8_t* d_inter, uint32_t n, int cs, hipStream_t stream) {
+    const uint64_t total = (uint64_t)n * cs;
+    const int grid = (int)std::min<uint64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(deinterleave_kernel, dim3(grid), dim3(256), 0, stream, d_rowmajor, d_inter, n, cs);
+}
+
+}  // namespace qadc

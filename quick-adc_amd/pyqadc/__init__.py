@@ -1,0 +1,271 @@
+"""ctypes binding of libqadc_hip.so (the C-ABI in include/qadc.h) for tests and bench.py.
+
+Thin by design: numpy in, numpy out, no computation here.  Loading fails loudly when the HIP
+library has not been built; there is no CPU fallback anywhere on this path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libqadc_hip.so")
+
+u8p = C.POINTER(C.c_uint8)
+i8p = C.POINTER(C.c_int8)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+f32p = C.POINTER(C.c_float)
+
+# every symbol include/qadc.h declares
+SYMBOLS = [
+    "qadc_last_error", "qadc_version", "qadc_index_create", "qadc_index_destroy",
+    "qadc_index_add_partitions", "qadc_index_add_partition_interleaved",
+    "qadc_index_add_partition_device", "qadc_index_add_partition_synthetic",
+    "qadc_index_set_key_base", "qadc_index_finalize", "qadc_index_partition_count",
+    "qadc_index_partition_size", "qadc_index_start_size", "qadc_set_option",
+    "qadc_index_read_codes", "qadc_query_scan", "qadc_query_scan_candidates", "qadc_scan_i8",
+    "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit",
+    "qadc_query_scan_collect", "qadc_candidates_i8", "qadc_profile_read", "qadc_profile_reset",
+]
+
+
+class Profile(C.Structure):
+    _fields_ = [("scan_launches", C.c_uint64), ("scan_codes", C.c_uint64), ("scan_ms", C.c_double),
+                ("start_codes", C.c_uint64), ("start_ms", C.c_double), ("candidates", C.c_uint64),
+                ("regrows", C.c_uint64), ("host_replay_ms", C.c_double)]
+
+
+class QadcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QadcError("libqadc_hip.so is not built (run __graft_entry__.build() or make -C quick-adc_amd); "
+                            "the Quick-ADC engine has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.qadc_last_error.restype = C.c_char_p
+        L.qadc_version.restype = C.c_char_p
+        L.qadc_index_partition_size.restype = C.c_uint32
+        L.qadc_index_start_size.restype = C.c_uint32
+        L.qadc_index_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        L.qadc_index_destroy.argtypes = [C.c_void_p]
+        L.qadc_index_add_partitions.argtypes = [C.c_void_p, C.c_int, C.POINTER(u8p), C.POINTER(u32p), u32p]
+        L.qadc_index_add_partition_interleaved.argtypes = [C.c_void_p, u8p, u32p, C.c_uint32]
+        L.qadc_index_add_partition_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.qadc_index_add_partition_synthetic.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]
+        L.qadc_index_set_key_base.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        L.qadc_index_finalize.argtypes = [C.c_void_p, C.c_float]
+        L.qadc_index_partition_count.argtypes = [C.c_void_p]
+        L.qadc_index_partition_size.argtypes = [C.c_void_p, C.c_int]
+        L.qadc_index_start_size.argtypes = [C.c_void_p, C.c_int]
+        L.qadc_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.qadc_index_read_codes.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, u8p]
+        L.qadc_query_scan.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, f32p, C.c_int, u32p, i8p, i32p, i32p,
+                                      f32p, f32p, i8p]
+        L.qadc_query_scan_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, f32p, C.c_int, C.c_uint64,
+                                                 u32p, i8p, u64p, i32p, f32p, f32p]
+        L.qadc_scan_i8.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, i8p, C.c_int, u32p, i8p, i32p]
+        L.qadc_scan_i8_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, i8p, C.c_int, C.c_uint64,
+                                              u32p, i8p, u64p]
+        L.qadc_scan_start.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, f32p, C.c_int, f32p]
+        L.qadc_query_scan_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_int]
+        L.qadc_query_scan_collect.argtypes = [C.c_void_p, C.c_int, u32p, i8p, i32p, i32p, f32p, f32p, i8p]
+        L.qadc_candidates_i8.argtypes = [C.c_void_p, C.c_int, i8p, i8p]
+        L.qadc_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile)]
+        L.qadc_profile_reset.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _check(rc):
+    if rc != 0:
+        raise QadcError("qadc error %d: %s" % (rc, lib().qadc_last_error().decode()))
+
+
+class Index:
+    """One GPU-resident Quick-ADC database (the role of scanner_4 after prepare_database)."""
+
+    def __init__(self, M, device=0):
+        self.M = M
+        self.cs = M // 2
+        self._h = C.c_void_p()
+        _check(lib().qadc_index_create(C.byref(self._h), M, device))
+        self._keepalive = []
+
+    def close(self):
+        if self._h:
+            lib().qadc_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- database --------------------------------------------------------------------------
+    def add_partitions(self, codes, labels=None):
+        codes = [np.ascontiguousarray(c, np.uint8).reshape(-1, self.cs) for c in codes]
+        sizes = np.array([c.shape[0] for c in codes], np.uint32)
+        ca = (u8p * len(codes))(*[_p(c, u8p) for c in codes])
+        la = None
+        if labels is not None:
+            labels = [np.ascontiguousarray(l, np.uint32) for l in labels]
+            la = (u32p * len(labels))(*[_p(l, u32p) for l in labels])
+        _check(lib().qadc_index_add_partitions(self._h, len(codes), ca, la, _p(sizes, u32p)))
+
+    def add_partition_interleaved(self, inter, size, labels=None):
+        inter = np.ascontiguousarray(inter, np.uint8)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.uint32)
+        _check(lib().qadc_index_add_partition_interleaved(self._h, _p(inter, u8p), _p(lab, u32p), size))
+
+    def add_partition_device(self, d_codes_ptr, size, d_labels_ptr=None, keepalive=None):
+        self._keepalive.append(keepalive)
+        _check(lib().qadc_index_add_partition_device(self._h, C.c_void_p(d_codes_ptr),
+                                                     C.c_void_p(d_labels_ptr) if d_labels_ptr else None, size))
+
+    def add_partition_synthetic(self, size, seed, first_word=0):
+        _check(lib().qadc_index_add_partition_synthetic(self._h, size, seed, first_word))
+
+    def set_key_base(self, part, base):
+        _check(lib().qadc_index_set_key_base(self._h, part, base))
+
+    def finalize(self, keep):
+        _check(lib().qadc_index_finalize(self._h, keep))
+
+    def set_option(self, name, value):
+        _check(lib().qadc_set_option(self._h, name.encode(), float(value)))
+
+    def partition_count(self):
+        return lib().qadc_index_partition_count(self._h)
+
+    def partition_size(self, p):
+        return lib().qadc_index_partition_size(self._h, p)
+
+    def start_size(self, p):
+        return lib().qadc_index_start_size(self._h, p)
+
+    def read_codes(self, part, first, count):
+        out = np.zeros((count, self.cs), np.uint8)
+        _check(lib().qadc_index_read_codes(self._h, part, first, count, _p(out, u8p)))
+        return out
+
+    # ---- queries ---------------------------------------------------------------------------
+    @staticmethod
+    def _prep(assign, nq=None):
+        assign = np.ascontiguousarray(assign, np.int32)
+        if assign.ndim == 1:
+            assign = assign.reshape(1, -1) if nq is None else assign.reshape(nq, -1)
+        return assign
+
+    def _heaps(self, nq, R, keys, vals, sizes):
+        return [(keys[q, :sizes[q]].copy(), vals[q, :sizes[q]].copy()) for q in range(nq)]
+
+    def query_scan(self, assign, tables, R, want_qtables=False):
+        """tables: float32 [nq][ma][M*16], mutated in place.  Returns dict with heaps etc."""
+        assign = self._prep(assign)
+        nq, ma = assign.shape
+        assert tables.dtype == np.float32 and tables.flags.c_contiguous and tables.size == nq * ma * self.M * 16
+        keys = np.zeros((nq, R), np.uint32)
+        vals = np.zeros((nq, R), np.int8)
+        sizes = np.zeros(nq, np.int32)
+        status = np.zeros(nq, np.int32)
+        qmin = np.zeros(nq, np.float32)
+        qmax = np.zeros(nq, np.float32)
+        qt = np.zeros((nq, ma, self.M, 16), np.int8) if want_qtables else None
+        _check(lib().qadc_query_scan(self._h, nq, ma, _p(assign, i32p), _p(tables, f32p), R, _p(keys, u32p),
+                                     _p(vals, i8p), _p(sizes, i32p), _p(status, i32p), _p(qmin, f32p),
+                                     _p(qmax, f32p), _p(qt, i8p)))
+        return dict(heaps=self._heaps(nq, R, keys, vals, sizes), status=status, qmin=qmin, qmax=qmax, qtables=qt,
+                    keys=keys, values=vals, sizes=sizes)
+
+    def submit(self, slot, assign, tables, R):
+        assign = self._prep(assign)
+        nq, ma = assign.shape
+        assert tables.dtype == np.float32 and tables.flags.c_contiguous
+        self._pending = getattr(self, "_pending", {})
+        self._pending[slot] = (nq, R, tables, assign)
+        _check(lib().qadc_query_scan_submit(self._h, slot, nq, ma, _p(assign, i32p), _p(tables, f32p), R))
+
+    def collect(self, slot):
+        nq, R, tables, assign = self._pending.pop(slot)
+        keys = np.zeros((nq, R), np.uint32)
+        vals = np.zeros((nq, R), np.int8)
+        sizes = np.zeros(nq, np.int32)
+        status = np.zeros(nq, np.int32)
+        _check(lib().qadc_query_scan_collect(self._h, slot, _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p),
+                                             _p(status, i32p), None, None, None))
+        return dict(keys=keys, values=vals, sizes=sizes, status=status)
+
+    def scan_i8(self, assign, qtables, R):
+        assign = self._prep(assign)
+        nq, ma = assign.shape
+        qt = np.ascontiguousarray(qtables, np.int8)
+        assert qt.size == nq * ma * self.M * 16
+        keys = np.zeros((nq, R), np.uint32)
+        vals = np.zeros((nq, R), np.int8)
+        sizes = np.zeros(nq, np.int32)
+        _check(lib().qadc_scan_i8(self._h, nq, ma, _p(assign, i32p), _p(qt, i8p), R, _p(keys, u32p), _p(vals, i8p),
+                                  _p(sizes, i32p)))
+        return self._heaps(nq, R, keys, vals, sizes)
+
+    def scan_i8_candidates(self, assign, qtables, R, capacity=1 << 20):
+        assign = self._prep(assign)
+        nq, ma = assign.shape
+        qt = np.ascontiguousarray(qtables, np.int8)
+        ck = np.zeros(capacity, np.uint32)
+        cv = np.zeros(capacity, np.int8)
+        off = np.zeros(nq + 1, np.uint64)
+        _check(lib().qadc_scan_i8_candidates(self._h, nq, ma, _p(assign, i32p), _p(qt, i8p), R, capacity,
+                                             _p(ck, u32p), _p(cv, i8p), _p(off, u64p)))
+        return [(ck[int(off[q]):int(off[q + 1])].copy(), cv[int(off[q]):int(off[q + 1])].copy()) for q in range(nq)]
+
+    def query_scan_candidates(self, assign, tables, R, capacity=1 << 20):
+        assign = self._prep(assign)
+        nq, ma = assign.shape
+        ck = np.zeros(capacity, np.uint32)
+        cv = np.zeros(capacity, np.int8)
+        off = np.zeros(nq + 1, np.uint64)
+        status = np.zeros(nq, np.int32)
+        qmin = np.zeros(nq, np.float32)
+        qmax = np.zeros(nq, np.float32)
+        _check(lib().qadc_query_scan_candidates(self._h, nq, ma, _p(assign, i32p), _p(tables, f32p), R, capacity,
+                                                _p(ck, u32p), _p(cv, i8p), _p(off, u64p), _p(status, i32p),
+                                                _p(qmin, f32p), _p(qmax, f32p)))
+        streams = [(ck[int(off[q]):int(off[q + 1])].copy(), cv[int(off[q]):int(off[q + 1])].copy())
+                   for q in range(nq)]
+        return dict(streams=streams, status=status, qmin=qmin, qmax=qmax)
+
+    def scan_start(self, assign, tables, R):
+        assign = self._prep(assign)
+        nq, ma = assign.shape
+        tb = np.ascontiguousarray(tables, np.float32)
+        qmax = np.zeros(nq, np.float32)
+        _check(lib().qadc_scan_start(self._h, nq, ma, _p(assign, i32p), _p(tb, f32p), R, _p(qmax, f32p)))
+        return qmax
+
+    def candidates_i8(self, part, qtable):
+        qt = np.ascontiguousarray(qtable, np.int8)
+        out = np.zeros(self.partition_size(part), np.int8)
+        _check(lib().qadc_candidates_i8(self._h, part, _p(qt, i8p), _p(out, i8p)))
+        return out
+
+    def profile(self):
+        pr = Profile()
+        _check(lib().qadc_profile_read(self._h, C.byref(pr)))
+        return {f: getattr(pr, f) for f, _ in Profile._fields_}
+
+    def profile_reset(self):
+        _check(lib().qadc_profile_reset(self._h))
