@@ -1,0 +1,200 @@
+"""bench.py — Quick-ADC flat scan on MI355X: PQ codes scanned / second (+ Recall@100).
+
+Workload (BASELINE.json configs[3] shape, which fits one GPU): flat database of 1B synthetic
+16x4 PQ codes (8 B/code, counter-based generator), R = 100, keep = 1 %, one query per pass over
+the list.  A step = one batch of NQ queries through the whole scanner_4::query_scan path
+(float pre-scan of the starts -> qmax, quantizer, int8 scan of every code, candidate replay).
+With --gpus N the SAME 1B-code list is sharded over the N ranks in contiguous ranges ("strong"
+scaling; keys are 32-bit as in the reference, so the list cannot grow past 2^32 anyway) and the
+per-shard push streams are gathered once per batch over RCCL and replayed (pyqadc/sharded.py).
+
+    python bench.py --gpus 1 --steps 20 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Environment overrides for quick runs: QADC_BENCH_CODES, QADC_BENCH_NQ,
+QADC_BENCH_M, QADC_BENCH_CPU_SECONDS (0 disables the CPU leg).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "quick-adc_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def make_tables(rng, codebooks, nq):
+    """Float distance tables ||q_m - c||^2 of N(0,1) queries against N(0,1) codebooks [M][16][d]."""
+    M, _, d = codebooks.shape
+    q = rng.normal(size=(nq, M, 1, d)).astype(np.float32)
+    t = ((q - codebooks[None]) ** 2).sum(-1, dtype=np.float32)
+    return np.ascontiguousarray(t.reshape(nq, 1, M * 16), np.float32)
+
+
+def cpu_baseline(M, n_total, seed, qtables, R, seconds):
+    """Times the reference's own scan_avx_4<M> (oracle/_ref, built from /root/reference) — or, if
+    that build is absent, the oracle's scalar C port — on a bounded prefix of the same synthetic
+    list with the same int8 tables, one thread.  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    cs = M // 2
+    n = int(min(n_total, 32 * 1024 * 1024))
+    codes = po.fill_codes(0, (n * cs + 7) // 8, seed)[:n * cs].reshape(n, cs)
+    kind = "reference" if po.have_ref() else "port"
+    if kind == "reference":
+        inter = po.ref_interleave(codes)
+        run = lambda qt: po.ref_scan_interleaved(M, [inter], [n], None, qt, R)
+    else:
+        run = lambda qt: po.scan_i8(M, [codes], None, qt, R)
+    run(qtables[0])  # warm
+    t0, nqueries = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        run(qtables[nqueries % len(qtables)])
+        nqueries += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * nqueries / dt, "unit": "codes/s", "cores": 1, "kind": kind,
+            "sample": "%d queries x first %d codes of the same synthetic list, same int8 tables, R=%d, "
+                      "1 thread, %s" % (nqueries, n, R, "scan_avx_4<%d> compiled from the reference" % M
+                                        if kind == "reference" else "scalar C port (oracle)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    M = int(os.environ.get("QADC_BENCH_M", 16))
+    N = int(float(os.environ.get("QADC_BENCH_CODES", 1e9)))
+    NQ = int(os.environ.get("QADC_BENCH_NQ", 8))
+    R, KEEP, SEED = 100, 0.01, 0x5EED0001
+    cs = M // 2
+
+    import torch
+    import torch.distributed as dist
+    import pyqadc
+    from pyqadc import sharded
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the Quick-ADC engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- database: this rank's contiguous shard of the synthetic list + replica of the starts ----
+    first, local_n = sharded.shard_ranges(N, world)[rank]
+    starts = max(1, int(np.float32(N) * np.float32(KEEP)))
+    idx = pyqadc.Index(M, local_rank)
+    idx.add_partition_synthetic_shard(N, first, local_n, SEED, starts)
+    idx.finalize(KEEP)
+    idx.set_option("profile", 1)
+
+    rng = np.random.default_rng(1234)
+    codebooks = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
+    pool = [make_tables(rng, codebooks, NQ) for _ in range(4)]   # 4 distinct query batches, reused cyclically
+    assign = np.zeros((NQ, 1), np.int32)
+
+    def finish(step_res):
+        if world == 1:
+            return step_res
+        return sharded.merge_batch(step_res, NQ, R, step_res["status"], dev)
+
+    def run_steps(k):
+        """k pipelined steps: batch s+1 is enqueued before batch s is collected and replayed."""
+        last = None
+        pending = None
+        for s in range(k):
+            tb = pool[s % len(pool)].copy()
+            idx.submit(s % 2, assign, tb, R)
+            if pending is not None:
+                last = finish(idx.collect(pending) if world == 1 else idx.collect_candidates(pending))
+            pending = s % 2
+        if pending is not None:
+            last = finish(idx.collect(pending) if world == 1 else idx.collect_candidates(pending))
+        return last
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup)
+    idx.profile_reset()
+    sync()
+    t0 = time.perf_counter()
+    last = run_steps(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = idx.profile()
+
+    # ---- Recall@100 against the exact float-ADC nearest code, last batch, untimed ----
+    tb = pool[(args.steps - 1) % len(pool)]
+    keys = last["keys"] if world == 1 else last[0]
+    hits = 0
+    for q in range(NQ):
+        key, _, dist_q = idx.float_top1(0, tb[q, 0])
+        if world > 1:
+            cand = torch.tensor([dist_q, float(key)], dtype=torch.float64, device=dev)
+            allc = torch.empty(2 * world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allc, cand)
+            allc = allc.cpu().numpy().reshape(world, 2)
+            key = int(allc[np.lexsort((allc[:, 1], allc[:, 0]))[0], 1])   # min distance, lowest key on ties
+        hits += int(key in set(keys[q].tolist()))
+    recall = hits / NQ
+
+    if rank == 0:
+        total_codes = float(N) * NQ * args.steps
+        scan_ms = prof["scan_ms"]
+        achieved = prof["scan_codes"] * cs / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if world == 1 and os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("bytes_per_launch")
+        out = {
+            "metric": "pq_codes_scanned_per_sec", "value": total_codes / elapsed, "unit": "codes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+            "config": {"workload": "flat DB, %d x %dx4 PQ codes (%d B/code), R=%d, keep=%.2f%%, %d queries/step, "
+                                   "one query per pass, sharded over %d GPU(s)" % (N, M, cs, R, KEEP * 100, NQ, world),
+                       "codes": N, "M": M, "R": R, "keep": KEEP, "queries_per_step": NQ,
+                       "parallelism": "shard%d" % world},
+            "recall_at_100": recall,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "scan_i8_kernel<%d,2>" % M, "launches": prof["scan_launches"],
+                         "avg_launch_ms": scan_ms / max(prof["scan_launches"], 1),
+                         "algorithmic_bytes_per_launch": prof["scan_codes"] * cs / max(prof["scan_launches"], 1)},
+            "phases": {"prescan_quantize_ms_per_step": prof["start_ms"] / args.steps,
+                       "scan_kernel_ms_per_step": scan_ms / args.steps,
+                       "host_sort_replay_ms_per_step": prof["host_replay_ms"] / args.steps,
+                       "candidates_per_query": prof["candidates"] / (NQ * args.steps), "regrows": prof["regrows"]},
+        }
+        cpu_s = float(os.environ.get("QADC_BENCH_CPU_SECONDS", 15))
+        if world == 1 and cpu_s > 0:
+            res = idx.query_scan(assign, pool[0].copy(), R, want_qtables=True)
+            out["cpu_baseline"] = cpu_baseline(M, N, SEED, res["qtables"][:, 0], R, cpu_s)
+        print(json.dumps(out), flush=True)
+    idx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

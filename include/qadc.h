@@ -62,6 +62,19 @@ int qadc_index_add_partition_device(qadc_index* idx, const void* d_codes, const 
  * splitmix64(seed ^ splitmix64(first_word + w)) (reproducible on the CPU). */
 int qadc_index_add_partition_synthetic(qadc_index* idx, uint32_t size, uint64_t seed, uint64_t first_word);
 
+/* Multi-GPU: append the local range [first_pos, first_pos + local_n) of a partition of global_n
+ * codes (one process per GPU, contiguous ranges in rank order; every range but the last a multiple
+ * of 16 codes).  Keys of an unlabeled shard are first_pos + local position.  `starts` = the first
+ * starts_count codes of the WHOLE partition (>= max(1, unsigned(global_n * keep))), needed by every
+ * rank whose range does not begin the partition: the pre-scan and therefore qmax / the int8 tables
+ * are then identical on all ranks without any exchange (the reference keeps the starts in a
+ * separate buffer too, db_query_4.cpp:137-145).  The padding-lane replay of the partition's last
+ * code happens only on the rank that holds it. */
+int qadc_index_add_partition_shard(qadc_index* idx, const uint8_t* codes, const uint32_t* labels, uint32_t local_n,
+                                   uint32_t global_n, uint32_t first_pos, const uint8_t* starts, uint32_t starts_count);
+int qadc_index_add_partition_synthetic_shard(qadc_index* idx, uint32_t global_n, uint32_t first_pos, uint32_t local_n,
+                                             uint64_t seed, uint32_t starts_count);
+
 /* Keys reported for an unlabeled partition are key_base + position (shard offset for multi-GPU). */
 int qadc_index_set_key_base(qadc_index* idx, int part, uint32_t key_base);
 
@@ -131,8 +144,25 @@ int qadc_query_scan_submit(qadc_index* idx, int slot, int nq, int ma, const int3
 int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes,
                             int32_t* status, float* qmin, float* qmax, int8_t* qtables);
 
+/* collect variant returning the ordered candidate stream (see qadc_query_scan_candidates): what a
+ * rank hands to the cross-GPU gather. */
+int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_capacity, uint32_t* cand_keys,
+                                       int8_t* cand_vals, uint64_t* offsets, int32_t* status, float* qmin, float* qmax);
+
+/* Host-only helper (no GPU involved): push (keys[i], vals[i]), i = 0..n-1, in order into an empty
+ * heap of capacity R with kv_binheap<unsigned,int8_t>::push semantics (binheap.hpp:75-116), after
+ * an optional (0,127) sentinel (db_query_4.cpp:276), and return the heap arrays.  This is the
+ * replay the other entry points apply to the device's candidate stream. */
+int qadc_replay_i8(uint64_t n, const uint32_t* keys, const int8_t* vals, int R, int push_sentinel,
+                   uint32_t* out_keys, int8_t* out_vals, int32_t* out_size);
+
 /* Diagnostic: all candidate values min(127, sum) of one partition for one int8 table [M][16]. */
 int qadc_candidates_i8(qadc_index* idx, int part, const int8_t* qtable, int8_t* out);
+
+/* Diagnostic / recall ground truth: the exact float-ADC nearest code of one
+ * partition for one float table [M*16]: smallest distance (scan_4<M> summation order), lowest
+ * position on ties.  key = label, or key_base + position. */
+int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out_key, uint32_t* out_pos, float* out_dist);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement (bench.py): HIP-event timing of the int8 scan kernel on the index's stream.

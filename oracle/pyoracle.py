@@ -143,6 +143,19 @@ def scan_i8_interleaved(M, inter_parts, sizes, labels, qtables, R, sentinel=True
     return ok[:osz.value].copy(), ov[:osz.value].copy()
 
 
+def shard_stream(M, codes, labels, global_n, first_pos, qt, R, cap=1 << 20):
+    """Ordered push stream of one shard (see orc_scan_i8_shard_stream)."""
+    codes = np.ascontiguousarray(codes, np.uint8)
+    lab = None if labels is None else np.ascontiguousarray(labels, np.uint32)
+    qt = np.ascontiguousarray(qt, np.int8)
+    ok, ov = np.zeros(cap, np.uint32), np.zeros(cap, np.int8)
+    lib().orc_scan_i8_shard_stream.restype = C.c_long
+    cnt = lib().orc_scan_i8_shard_stream(M, _p(codes, u8p), None if lab is None else _p(lab, u32p), codes.shape[0],
+                                         global_n, first_pos, _p(qt, i8p), R, _p(ok, u32p), _p(ov, i8p), C.c_long(cap))
+    assert cnt <= cap
+    return ok[:cnt].copy(), ov[:cnt].copy()
+
+
 def candidates_i8(M, codes, qt):
     codes = np.ascontiguousarray(codes, np.uint8)
     qt = np.ascontiguousarray(qt, np.int8)

@@ -388,3 +388,50 @@ void orc_fill_codes(uint8_t* dst, uint64_t first_word, uint64_t nwords, uint64_t
         memcpy(dst + 8 * w, &v, 8);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Push stream of ONE SHARD of a partition (multi-GPU tests; SURVEY.md §8 A3 "S2"): the local range
+ * [first_pos, first_pos + n) of a partition of global_n codes is scanned into a LOCAL heap seeded
+ * with the (0,127) sentinel, and every push the block-stale local bound lets through is recorded
+ * (key, value) in scan order — padding-lane replicas of the partition's last code included when
+ * this shard holds it.  Concatenating the shard streams in shard order and replaying them through
+ * one heap must reproduce the sequential scan of the whole partition.
+ * Keys: labels[local pos] or first_pos + local pos.  Returns the stream length (may exceed cap).
+ * ---------------------------------------------------------------------------------------- */
+long orc_scan_i8_shard_stream(int M, const uint8_t* codes, const uint32_t* labels, uint32_t n, uint32_t global_n,
+                              uint32_t first_pos, const int8_t* qt, int R, uint32_t* out_keys, int8_t* out_vals, long cap) {
+    const int cs = M / 2;
+    uint32_t* hk = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)R);
+    int8_t* hv = (int8_t*)malloc((size_t)R);
+    orc_heap_i8 h = { hk, hv, R, 0 };
+    orc_heap_i8_push(&h, 0, 127);
+    long count = 0;
+    int8_t bound = h.vals[0];
+    const uint32_t last_global = global_n - 1u;
+    const uint32_t end = first_pos + n;                       /* exclusive, global */
+    const uint32_t blk_end = (end == global_n) ? (global_n + 15u) / 16u * 16u : end;
+    for (uint32_t g0 = first_pos; g0 < blk_end; g0 += 16) {  /* first_pos is a multiple of 16 */
+        int any = 0;
+        const int8_t bound_blk = bound;
+        for (int j = 0; j < 16; ++j) {
+            uint32_t gi = g0 + (uint32_t)j;
+            if (gi > last_global) gi = last_global;
+            const uint32_t li = gi - first_pos;
+            const uint8_t* c = codes + (long)li * cs;
+            int s = 0;
+            for (int b = 0; b < cs; ++b)
+                s += qt[(2 * b) * 16 + (c[b] & 15)] + qt[(2 * b + 1) * 16 + (c[b] >> 4)];
+            const int8_t cand = (int8_t)(s > 127 ? 127 : s);
+            if (cand < bound_blk) {
+                const uint32_t key = labels ? labels[li] : gi;
+                orc_heap_i8_push(&h, key, cand);
+                if (count < cap) { out_keys[count] = key; out_vals[count] = cand; }
+                ++count;
+                any = 1;
+            }
+        }
+        if (any) bound = h.vals[0];
+    }
+    free(hk); free(hv);
+    return count;
+}

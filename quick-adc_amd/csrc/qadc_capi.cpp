@@ -83,9 +83,13 @@ struct PinBuf {
 };
 
 struct Part {
-    uint8_t* d_codes = nullptr;
-    uint32_t* d_labels = nullptr;
-    uint32_t n = 0;
+    uint8_t* d_codes = nullptr;    // row-major codes of the local range
+    uint32_t* d_labels = nullptr;  // labels of the local range (or null)
+    uint8_t* d_starts = nullptr;   // replica of the global partition's first codes (null: d_codes, first_pos == 0)
+    uint32_t n = 0;                // codes held here
+    uint32_t global_n = 0;         // codes of the whole partition (== n unless sharded)
+    uint32_t first_pos = 0;        // global position of local code 0
+    uint32_t starts_cap = 0;       // codes available for the pre-scan
     uint32_t start_n = 0;
     uint32_t key_base = 0;
     bool own = true;
@@ -213,7 +217,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             if (pt.n == 0) continue;  // db_query_4.cpp:291-293
             if (s.float_path) {
                 StartItem si;
-                si.codes = pt.d_codes;
+                si.codes = pt.d_starts ? pt.d_starts : pt.d_codes;
                 si.n = pt.start_n;
                 si.table = (uint32_t)((size_t)q * ma + a);
                 si.query = (uint32_t)q;
@@ -238,7 +242,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                     it.labels = pt.d_labels;
                     it.n = (uint32_t)len;
                     it.pos0 = (uint32_t)b0;
-                    it.key_base = pt.key_base;
+                    it.key_base = pt.key_base + pt.first_pos;
                     it.table = (uint32_t)((size_t)q * ma + a);
                     it.query = (uint32_t)q;
                     it.order = ((uint32_t)k << 16) | (uint32_t)a;
@@ -442,7 +446,7 @@ int collect_common(qadc_index* idx, int slot_i) {
             // lanes past the end of the last 16-code block replay code n-1 (simd_layout.hpp:46-50,
             // simd_scan.hpp:67): the reference offers that code 1 + pad times in a row
             int reps = 1;
-            if (c[i].pos == pt.n - 1) reps += (int)((16u - pt.n % 16u) % 16u);
+            if (c[i].pos == pt.n - 1 && pt.first_pos + pt.n == pt.global_n) reps += (int)((16u - pt.global_n % 16u) % 16u);
             for (int r = 0; r < reps; ++r) {
                 s.out_keys.push_back(c[i].key);
                 s.out_vals.push_back((int8_t)(c[i].qv & 0xffu));
@@ -521,11 +525,13 @@ int qadc_index_destroy(qadc_index* idx) {
     if (!idx) return QADC_OK;
     (void)hipSetDevice(idx->device);
     (void)hipStreamSynchronize(idx->stream);
-    for (auto& p : idx->parts)
+    for (auto& p : idx->parts) {
         if (p.own) {
             if (p.d_codes) (void)hipFree(p.d_codes);
             if (p.d_labels) (void)hipFree(p.d_labels);
         }
+        if (p.d_starts) (void)hipFree(p.d_starts);
+    }
     for (auto& s : idx->slot) {
         s.d_ftables.release(); s.d_qtables.release(); s.d_qs.release(); s.d_hdr.release(); s.d_cands.release();
         s.d_items.release(); s.d_sitems.release(); s.d_fc.release(); s.d_fc_count.release(); s.d_sel_hist.release();
@@ -548,6 +554,8 @@ static int check_labels_mode(qadc_index* idx, bool has_labels) {
 
 static int alloc_part(qadc_index* idx, Part& pt, uint32_t n, bool labels) {
     pt.n = n;
+    pt.global_n = n;
+    pt.starts_cap = n;
     const size_t bytes = ((size_t)n * idx->cs + 15) / 16 * 16 + 64;  // tail padding for 16-byte vector reads
     HIPCHECK(hipMalloc(reinterpret_cast<void**>(&pt.d_codes), bytes));
     HIPCHECK(hipMemsetAsync(pt.d_codes + (bytes - 80), 0, 80, idx->stream));
@@ -610,6 +618,8 @@ int qadc_index_add_partition_device(qadc_index* idx, const void* d_codes, const 
         pt.d_codes = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_codes));
         pt.d_labels = const_cast<uint32_t*>(static_cast<const uint32_t*>(d_labels));
         pt.n = size;
+        pt.global_n = size;
+        pt.starts_cap = size;
         pt.own = false;
     }
     idx->parts.push_back(pt);
@@ -634,6 +644,65 @@ int qadc_index_add_partition_synthetic(qadc_index* idx, uint32_t size, uint64_t 
     return QADC_OK;
 }
 
+static int attach_starts(qadc_index* idx, Part& pt, const uint8_t* starts_host, uint32_t starts_count, uint64_t seed,
+                         bool synthetic) {
+    if (pt.first_pos == 0 && starts_count <= pt.n) {  // the local range begins with the starts
+        pt.starts_cap = pt.n;
+        return QADC_OK;
+    }
+    if (starts_count == 0) return fail(QADC_E_ARG, "a shard that does not begin the partition needs a starts replica");
+    const size_t bytes = ((size_t)starts_count * idx->cs + 15) / 16 * 16 + 64;
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&pt.d_starts), bytes));
+    if (synthetic) {
+        launch_fill_codes(pt.d_starts, 0, ((uint64_t)starts_count * idx->cs + 7) / 8, seed, idx->stream);
+        HIPCHECK(hipGetLastError());
+    } else {
+        HIPCHECK(hipMemcpyAsync(pt.d_starts, starts_host, (size_t)starts_count * idx->cs, hipMemcpyHostToDevice, idx->stream));
+    }
+    HIPCHECK(hipStreamSynchronize(idx->stream));
+    pt.starts_cap = starts_count;
+    return QADC_OK;
+}
+
+int qadc_index_add_partition_shard(qadc_index* idx, const uint8_t* codes, const uint32_t* labels, uint32_t local_n,
+                                   uint32_t global_n, uint32_t first_pos, const uint8_t* starts, uint32_t starts_count) {
+    if (!idx || !codes || local_n == 0 || (uint64_t)first_pos + local_n > global_n)
+        return fail(QADC_E_ARG, "bad shard range");
+    if ((uint64_t)first_pos * idx->cs % 16 != 0) return fail(QADC_E_ARG, "first_pos must keep the shard 16-byte aligned");
+    if (int rc = use_device(idx)) return rc;
+    if (int rc = check_labels_mode(idx, labels != nullptr)) return rc;
+    Part pt;
+    if (int rc = alloc_part(idx, pt, local_n, labels != nullptr)) return rc;
+    pt.global_n = global_n;
+    pt.first_pos = first_pos;
+    HIPCHECK(hipMemcpyAsync(pt.d_codes, codes, (size_t)local_n * idx->cs, hipMemcpyHostToDevice, idx->stream));
+    if (labels) HIPCHECK(hipMemcpyAsync(pt.d_labels, labels, (size_t)local_n * 4, hipMemcpyHostToDevice, idx->stream));
+    HIPCHECK(hipStreamSynchronize(idx->stream));
+    if (int rc = attach_starts(idx, pt, starts, starts_count, 0, false)) return rc;
+    idx->parts.push_back(pt);
+    idx->finalized = false;
+    return QADC_OK;
+}
+
+int qadc_index_add_partition_synthetic_shard(qadc_index* idx, uint32_t global_n, uint32_t first_pos, uint32_t local_n,
+                                             uint64_t seed, uint32_t starts_count) {
+    if (!idx || local_n == 0 || (uint64_t)first_pos + local_n > global_n) return fail(QADC_E_ARG, "bad shard range");
+    if ((uint64_t)first_pos * idx->cs % 16 != 0) return fail(QADC_E_ARG, "first_pos must keep the shard 16-byte aligned");
+    if (int rc = use_device(idx)) return rc;
+    if (int rc = check_labels_mode(idx, false)) return rc;
+    Part pt;
+    if (int rc = alloc_part(idx, pt, local_n, false)) return rc;
+    pt.global_n = global_n;
+    pt.first_pos = first_pos;
+    launch_fill_codes(pt.d_codes, (uint64_t)first_pos * idx->cs / 8, ((uint64_t)local_n * idx->cs + 7) / 8, seed, idx->stream);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(idx->stream));
+    if (int rc = attach_starts(idx, pt, nullptr, starts_count, seed, true)) return rc;
+    idx->parts.push_back(pt);
+    idx->finalized = false;
+    return QADC_OK;
+}
+
 int qadc_index_set_key_base(qadc_index* idx, int part, uint32_t key_base) {
     if (!idx || part < 0 || part >= (int)idx->parts.size()) return fail(QADC_E_ARG, "bad partition");
     idx->parts[part].key_base = key_base;
@@ -650,9 +719,11 @@ int qadc_index_finalize(qadc_index* idx, float keep) {
             continue;
         }
         // std::max(1u, static_cast<unsigned>(size * keep)) with unsigned*float -> float (db_query_4.cpp:125-126)
-        const float prod = static_cast<float>(p.n) * keep;
+        const float prod = static_cast<float>(p.global_n) * keep;
         const unsigned s = static_cast<unsigned>(prod);
-        p.start_n = std::min<uint32_t>(std::max(1u, s), p.n);
+        p.start_n = std::min<uint32_t>(std::max(1u, s), p.global_n);
+        if (p.start_n > p.starts_cap)
+            return fail(QADC_E_ARG, "shard holds fewer start codes than max(1, unsigned(global_size * keep))");
     }
     idx->finalized = true;
     return QADC_OK;
@@ -708,6 +779,16 @@ int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* v
         HIPCHECK(hipMemcpy(qtables, s.d_qtables.p, (size_t)s.nq * s.ma * idx->M * 16, hipMemcpyDeviceToHost));
     }
     return replay_outputs(s, keys, values, sizes, status);
+}
+
+static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals, uint64_t* offsets);
+
+int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_capacity, uint32_t* cand_keys,
+                                       int8_t* cand_vals, uint64_t* offsets, int32_t* status, float* qmin, float* qmax) {
+    if (int rc = collect_common(idx, slot)) return rc;
+    Slot& s = idx->slot[slot];
+    finish_float_outputs(idx, s, status, qmin, qmax);
+    return copy_stream(s, cand_capacity, cand_keys, cand_vals, offsets);
 }
 
 int qadc_query_scan(qadc_index* idx, int nq, int ma, const int32_t* assign, float* tables, int R, uint32_t* keys,
@@ -771,6 +852,18 @@ int qadc_scan_start(qadc_index* idx, int nq, int ma, const int32_t* assign, cons
     return QADC_OK;
 }
 
+int qadc_replay_i8(uint64_t n, const uint32_t* keys, const int8_t* vals, int R, int push_sentinel, uint32_t* out_keys,
+                   int8_t* out_vals, int32_t* out_size) {
+    if (R <= 0 || (n && (!keys || !vals)) || !out_size) return fail(QADC_E_ARG, "bad arguments");
+    kv_heap<uint32_t, int8_t> bh(R);
+    if (push_sentinel) bh.push(0, 127);
+    for (uint64_t i = 0; i < n; ++i) bh.push(keys[i], vals[i]);
+    *out_size = bh.size();
+    if (out_keys) std::memcpy(out_keys, bh.keys(), sizeof(uint32_t) * bh.size());
+    if (out_vals) std::memcpy(out_vals, bh.values(), bh.size());
+    return QADC_OK;
+}
+
 int qadc_candidates_i8(qadc_index* idx, int part, const int8_t* qtable, int8_t* out) {
     if (!idx || part < 0 || part >= (int)idx->parts.size() || !qtable || !out) return fail(QADC_E_ARG, "bad arguments");
     const Part& p = idx->parts[part];
@@ -788,6 +881,39 @@ int qadc_candidates_i8(qadc_index* idx, int part, const int8_t* qtable, int8_t* 
     HIPCHECK(hipStreamSynchronize(idx->stream));
     HIPCHECK(hipFree(d_t));
     HIPCHECK(hipFree(d_o));
+    return QADC_OK;
+}
+
+int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out_key, uint32_t* out_pos, float* out_dist) {
+    if (!idx || part < 0 || part >= (int)idx->parts.size() || !table) return fail(QADC_E_ARG, "bad arguments");
+    const Part& p = idx->parts[part];
+    if (p.n == 0) return fail(QADC_E_ARG, "empty partition");
+    if (int rc = use_device(idx)) return rc;
+    const int blocks = (int)std::min<uint32_t>((p.n + 255) / 256, 2048);
+    float *d_t = nullptr, *d_v = nullptr;
+    uint32_t* d_p = nullptr;
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_t), idx->M * 16 * sizeof(float)));
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_v), blocks * sizeof(float)));
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_p), blocks * sizeof(uint32_t)));
+    HIPCHECK(hipMemcpyAsync(d_t, table, idx->M * 16 * sizeof(float), hipMemcpyHostToDevice, idx->stream));
+    launch_float_top1(idx->M, p.d_codes, p.n, d_t, d_v, d_p, blocks, idx->stream);
+    HIPCHECK(hipGetLastError());
+    std::vector<float> hv(blocks);
+    std::vector<uint32_t> hp(blocks);
+    HIPCHECK(hipMemcpyAsync(hv.data(), d_v, blocks * sizeof(float), hipMemcpyDeviceToHost, idx->stream));
+    HIPCHECK(hipMemcpyAsync(hp.data(), d_p, blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
+    HIPCHECK(hipStreamSynchronize(idx->stream));
+    int b = 0;
+    for (int i = 1; i < blocks; ++i)
+        if (hv[i] < hv[b] || (hv[i] == hv[b] && hp[i] < hp[b])) b = i;
+    uint32_t key = p.key_base + hp[b];
+    if (p.d_labels) HIPCHECK(hipMemcpy(&key, p.d_labels + hp[b], sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (out_key) *out_key = key;
+    if (out_pos) *out_pos = hp[b];
+    if (out_dist) *out_dist = hv[b];
+    HIPCHECK(hipFree(d_t));
+    HIPCHECK(hipFree(d_v));
+    HIPCHECK(hipFree(d_p));
     return QADC_OK;
 }
 

@@ -65,6 +65,10 @@ void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int
 void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item,
                            const float* d_ftables, float* d_fc, uint64_t fc_stride, hipStream_t stream);
 
+// Per-block (min float ADC distance, lowest position) over a whole partition; host reduces the blocks.
+void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,
+                       int blocks, hipStream_t stream);
+
 // k-th smallest (k = R) of each query's float candidates -> QueryState::qmax (FLT_MAX if fewer than R).
 void launch_select_kth(float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_count, int nq, uint32_t R,
                        QueryState* d_qs, uint32_t* d_sel_hist, hipStream_t stream);

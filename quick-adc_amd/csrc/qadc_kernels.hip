@@ -276,6 +276,62 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
     }
 }
 
+// Exact float-ADC nearest code of a partition (smallest distance, lowest position on ties):
+// the ground truth Recall@R is measured against when float ground truth over the raw vectors is
+// not available.  Same summation order as scan_4<M>.
+template <int M>
+__global__ __launch_bounds__(256) void float_top1_kernel(const uint8_t* __restrict__ codes, uint32_t n,
+                                                         const float* __restrict__ ftable, float* __restrict__ out_val,
+                                                         uint32_t* __restrict__ out_pos) {
+    __shared__ float tab[M * 16];
+    __shared__ float rv[256];
+    __shared__ uint32_t rp[256];
+    for (int i = threadIdx.x; i < M * 16; i += 256) tab[i] = ftable[i];
+    __syncthreads();
+    constexpr int DW = M / 8;
+    float best = FLT_MAX;
+    uint32_t bpos = 0xffffffffu;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint32_t d[DW];
+        if constexpr (M == 16) {
+            const uint2 v = reinterpret_cast<const uint2*>(codes)[i];
+            d[0] = v.x; d[1] = v.y;
+        } else {
+            const uint4 v = reinterpret_cast<const uint4*>(codes)[i];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        float cand = 0.0f;
+#pragma unroll
+        for (int b = 0; b < M / 2; ++b) {
+            const uint32_t byte = (d[b >> 2] >> (8 * (b & 3))) & 0xffu;
+            cand += tab[(2 * b) * 16 + (byte & 15u)];
+            cand += tab[(2 * b + 1) * 16 + (byte >> 4)];
+        }
+        if (cand < best) { best = cand; bpos = i; }   // i ascends per thread: first minimum kept
+    }
+    rv[threadIdx.x] = best;
+    rp[threadIdx.x] = bpos;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float ov = rv[threadIdx.x + s];
+            const uint32_t op = rp[threadIdx.x + s];
+            if (ov < rv[threadIdx.x] || (ov == rv[threadIdx.x] && op < rp[threadIdx.x])) {
+                rv[threadIdx.x] = ov;
+                rp[threadIdx.x] = op;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out_val[blockIdx.x] = rv[0]; out_pos[blockIdx.x] = rp[0]; }
+}
+
+void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,
+                       int blocks, hipStream_t stream) {
+    if (M == 16) hipLaunchKernelGGL(float_top1_kernel<16>, dim3(blocks), dim3(256), 0, stream, d_codes, n, d_ftable, d_val, d_pos);
+    else         hipLaunchKernelGGL(float_top1_kernel<32>, dim3(blocks), dim3(256), 0, stream, d_codes, n, d_ftable, d_val, d_pos);
+}
+
 void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item, const float* d_ftables,
                            float* d_fc, uint64_t fc_stride, hipStream_t stream) {
     const dim3 grid(wgs_per_item, nitems), block(256);

@@ -23,11 +23,12 @@ SYMBOLS = [
     "qadc_last_error", "qadc_version", "qadc_index_create", "qadc_index_destroy",
     "qadc_index_add_partitions", "qadc_index_add_partition_interleaved",
     "qadc_index_add_partition_device", "qadc_index_add_partition_synthetic",
+    "qadc_index_add_partition_shard", "qadc_index_add_partition_synthetic_shard", "qadc_query_scan_collect_candidates",
     "qadc_index_set_key_base", "qadc_index_finalize", "qadc_index_partition_count",
     "qadc_index_partition_size", "qadc_index_start_size", "qadc_set_option",
     "qadc_index_read_codes", "qadc_query_scan", "qadc_query_scan_candidates", "qadc_scan_i8",
     "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit",
-    "qadc_query_scan_collect", "qadc_candidates_i8", "qadc_profile_read", "qadc_profile_reset",
+    "qadc_query_scan_collect", "qadc_replay_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
 ]
 
 
@@ -61,6 +62,12 @@ def lib():
         L.qadc_index_add_partition_interleaved.argtypes = [C.c_void_p, u8p, u32p, C.c_uint32]
         L.qadc_index_add_partition_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.qadc_index_add_partition_synthetic.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]
+        L.qadc_index_add_partition_shard.argtypes = [C.c_void_p, u8p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u8p,
+                                                     C.c_uint32]
+        L.qadc_index_add_partition_synthetic_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                               C.c_uint64, C.c_uint32]
+        L.qadc_query_scan_collect_candidates.argtypes = [C.c_void_p, C.c_int, C.c_uint64, u32p, i8p, u64p, i32p, f32p,
+                                                         f32p]
         L.qadc_index_set_key_base.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
         L.qadc_index_finalize.argtypes = [C.c_void_p, C.c_float]
         L.qadc_index_partition_count.argtypes = [C.c_void_p]
@@ -78,7 +85,9 @@ def lib():
         L.qadc_scan_start.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, f32p, C.c_int, f32p]
         L.qadc_query_scan_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_int]
         L.qadc_query_scan_collect.argtypes = [C.c_void_p, C.c_int, u32p, i8p, i32p, i32p, f32p, f32p, i8p]
+        L.qadc_replay_i8.argtypes = [C.c_uint64, u32p, i8p, C.c_int, C.c_int, u32p, i8p, i32p]
         L.qadc_candidates_i8.argtypes = [C.c_void_p, C.c_int, i8p, i8p]
+        L.qadc_float_top1.argtypes = [C.c_void_p, C.c_int, f32p, u32p, u32p, f32p]
         L.qadc_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.qadc_profile_reset.argtypes = [C.c_void_p]
         _lib = L
@@ -92,6 +101,16 @@ def _p(a, t):
 def _check(rc):
     if rc != 0:
         raise QadcError("qadc error %d: %s" % (rc, lib().qadc_last_error().decode()))
+
+
+def replay_i8(keys, vals, R, sentinel=False):
+    """Host-only heap replay (no GPU needed)."""
+    keys = np.ascontiguousarray(keys, np.uint32)
+    vals = np.ascontiguousarray(vals, np.int8)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.int8), C.c_int32(0)
+    _check(lib().qadc_replay_i8(len(keys), _p(keys, u32p), _p(vals, i8p), R, int(sentinel), _p(ok, u32p),
+                                _p(ov, i8p), C.byref(osz)))
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
 
 
 class Index:
@@ -138,6 +157,17 @@ class Index:
 
     def add_partition_synthetic(self, size, seed, first_word=0):
         _check(lib().qadc_index_add_partition_synthetic(self._h, size, seed, first_word))
+
+    def add_partition_shard(self, codes, local_first, global_n, labels=None, starts=None):
+        codes = np.ascontiguousarray(codes, np.uint8).reshape(-1, self.cs)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.uint32)
+        st = None if starts is None else np.ascontiguousarray(starts, np.uint8).reshape(-1, self.cs)
+        _check(lib().qadc_index_add_partition_shard(self._h, _p(codes, u8p), _p(lab, u32p), codes.shape[0], global_n,
+                                                    local_first, _p(st, u8p), 0 if st is None else st.shape[0]))
+
+    def add_partition_synthetic_shard(self, global_n, first_pos, local_n, seed, starts_count):
+        _check(lib().qadc_index_add_partition_synthetic_shard(self._h, global_n, first_pos, local_n, seed,
+                                                              starts_count))
 
     def set_key_base(self, part, base):
         _check(lib().qadc_index_set_key_base(self._h, part, base))
@@ -209,6 +239,19 @@ class Index:
                                              _p(status, i32p), None, None, None))
         return dict(keys=keys, values=vals, sizes=sizes, status=status)
 
+    def collect_candidates(self, slot, capacity=1 << 20):
+        nq, R, tables, assign = self._pending.pop(slot)
+        ck = np.zeros(capacity, np.uint32)
+        cv = np.zeros(capacity, np.int8)
+        off = np.zeros(nq + 1, np.uint64)
+        status = np.zeros(nq, np.int32)
+        qmin = np.zeros(nq, np.float32)
+        qmax = np.zeros(nq, np.float32)
+        _check(lib().qadc_query_scan_collect_candidates(self._h, slot, capacity, _p(ck, u32p), _p(cv, i8p),
+                                                        _p(off, u64p), _p(status, i32p), _p(qmin, f32p),
+                                                        _p(qmax, f32p)))
+        return dict(keys=ck, vals=cv, offsets=off.astype(np.int64), status=status, qmin=qmin, qmax=qmax)
+
     def scan_i8(self, assign, qtables, R):
         assign = self._prep(assign)
         nq, ma = assign.shape
@@ -261,6 +304,12 @@ class Index:
         out = np.zeros(self.partition_size(part), np.int8)
         _check(lib().qadc_candidates_i8(self._h, part, _p(qt, i8p), _p(out, i8p)))
         return out
+
+    def float_top1(self, part, table):
+        tb = np.ascontiguousarray(table, np.float32).reshape(-1)
+        key, pos, dist = C.c_uint32(0), C.c_uint32(0), C.c_float(0)
+        _check(lib().qadc_float_top1(self._h, part, _p(tb, f32p), C.byref(key), C.byref(pos), C.byref(dist)))
+        return key.value, pos.value, dist.value
 
     def profile(self):
         pr = Profile()

@@ -98,3 +98,113 @@ def test_query_scan_full_pipeline(pyqadc, po, M, levels):
         assert np.array_equal(t_cpu, t_gpu[q])          # in-place clamp of negatives
         assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
     idx.close()
+
+
+def test_gpu_matches_reference_golden(pyqadc, po):
+    """HIP path vs the vectors the reference's own scan_avx_4 produced (tests/golden)."""
+    import golden_cases
+    g = golden_cases.load()
+    n = 0
+    for c in golden_cases.scan_cases(g, po):
+        idx = pyqadc.Index(c["M"])
+        idx.add_partitions(c["parts"], c["labels"])
+        idx.finalize(0.01)
+        nparts = len(c["parts"])
+        got = idx.scan_i8(np.arange(nparts, dtype=np.int32).reshape(1, nparts), c["qt"], c["R"])[0]
+        assert np.array_equal(got[0], c["keys"]) and np.array_equal(got[1], c["vals"]), c["cid"]
+        idx.close()
+        n += 1
+    assert n >= 50
+
+
+@pytest.mark.parametrize("M", [16, 32])
+def test_import_of_reference_block_layout(pyqadc, po, M):
+    rng = np.random.default_rng(31 + M)
+    for n in (1, 16, 37, 5000):
+        codes = rand_codes(rng, n, M)
+        idx = pyqadc.Index(M)
+        idx.add_partition_interleaved(po.interleave(codes), n)
+        idx.finalize(0.01)
+        assert np.array_equal(idx.read_codes(0, 0, n), codes)
+        qt = rand_qtables(rng, (1, 1), M, 9)
+        assert heaps_equal(idx.scan_i8(np.zeros((1, 1), np.int32), qt, 100)[0], po.scan_i8(M, [codes], None, qt[0], 100))
+        idx.close()
+
+
+def test_synthetic_generator_matches_cpu(pyqadc, po):
+    idx = pyqadc.Index(16)
+    idx.add_partition_synthetic(100001, 0xABCDEF)
+    idx.add_partition_synthetic_shard(100000, 4096, 5000, 77, 1000)
+    idx.finalize(0.01)
+    assert np.array_equal(idx.read_codes(0, 0, 100001).reshape(-1), po.fill_codes(0, 100001, 0xABCDEF))
+    assert np.array_equal(idx.read_codes(1, 0, 5000).reshape(-1), po.fill_codes(4096, 5000, 77))
+    idx.close()
+
+
+@pytest.mark.parametrize("M,n,tmax", [(16, 100003, 3), (16, 300000, 25), (32, 50001, 8)])
+def test_sharded_streams_replay_to_sequential_heap(pyqadc, po, M, n, tmax):
+    """Two shards of one list on one GPU (the per-rank work of the multi-GPU path): concatenating the
+    shard streams in shard order and replaying equals the single sequential scan; and the full
+    float pipeline gives every shard the same qmax / int8 tables."""
+    from pyqadc import sharded
+    rng = np.random.default_rng(n)
+    codes = rand_codes(rng, n, M)
+    keep, R, nq = 0.01, 100, 4
+    starts_n = po.start_size(n, keep)
+    shards = []
+    for first, ln in sharded.shard_ranges(n, 3):
+        idx = pyqadc.Index(M)
+        idx.add_partition_shard(codes[first:first + ln], first, n, starts=codes[:starts_n])
+        idx.finalize(keep)
+        shards.append(idx)
+    tables = float_tables(rng, nq, 1, M)
+    assign = np.zeros((nq, 1), np.int32)
+    res = [s.query_scan_candidates(assign, tables.copy(), R) for s in shards]
+    for q in range(nq):
+        want = po.query_scan(M, [codes], None, keep, [0], tables[q].copy(), R)
+        for r in res:
+            assert r["qmax"][q] == np.float32(want["qmax"]) and r["qmin"][q] == np.float32(want["qmin"])
+        ks = np.concatenate([r["streams"][q][0] for r in res])
+        vs = np.concatenate([r["streams"][q][1] for r in res])
+        assert heaps_equal(pyqadc.replay_i8(ks, vs, R, sentinel=True), (want["keys"], want["values"])), q
+    for s in shards:
+        s.close()
+
+
+def test_qmax_too_high_is_reported_not_fatal(pyqadc, po):
+    rng = np.random.default_rng(4)
+    codes = rand_codes(rng, 5000, 16)
+    idx = pyqadc.Index(16)
+    idx.add_partitions([codes])
+    idx.finalize(0.001)                      # 5 starts < R-1: the reference would exit(1)
+    tables = float_tables(rng, 2, 1, 16)
+    res = idx.query_scan(np.zeros((2, 1), np.int32), tables, 100)
+    assert list(res["status"]) == [1, 1] and list(res["sizes"]) == [0, 0] and res["qmax"][0] > 1e30
+    idx.close()
+
+
+def test_candidate_buffer_regrow_is_exact(pyqadc, po):
+    rng = np.random.default_rng(8)
+    codes = rand_codes(rng, 200000, 16)
+    idx = pyqadc.Index(16)
+    idx.add_partitions([codes])
+    idx.finalize(0.01)
+    idx.set_option("cand_capacity", 16)      # far too small: forces the overflow -> regrow -> rerun path
+    idx.set_option("profile", 1)
+    qt = rand_qtables(rng, (2, 1), 16, 20)
+    got = idx.scan_i8(np.zeros((2, 1), np.int32), qt, 100)
+    assert idx.profile()["regrows"] >= 1
+    for q in range(2):
+        assert heaps_equal(got[q], po.scan_i8(16, [codes], None, qt[q], 100))
+    idx.close()
+
+
+def test_negative_int8_tables_rejected(pyqadc):
+    idx = pyqadc.Index(16)
+    idx.add_partitions([np.zeros((10, 8), np.uint8)])
+    idx.finalize(0.01)
+    qt = np.zeros((1, 1, 16, 16), np.int8)
+    qt[0, 0, 3, 3] = -1
+    with pytest.raises(pyqadc.QadcError):
+        idx.scan_i8(np.zeros((1, 1), np.int32), qt, 10)
+    idx.close()
