@@ -149,6 +149,7 @@ struct Slot {
 struct qadc_index {
     int M = 16, cs = 8, device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // late D2H of a finished batch must not queue behind the next batch
     std::vector<Part> parts;
     int labeled = -1;  // -1 unknown, 0 flat, 1 labels
     bool finalized = false;
@@ -337,7 +338,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     // ---- results ----------------------------------------------------------------------------
     HIPCHECK(hipMemcpyAsync(s.h_hdr.p, s.d_hdr.p, sizeof(CandHeader), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipMemcpyAsync(s.h_qs.p, s.d_qs.p, sizeof(QueryState) * nq, hipMemcpyDeviceToHost, st));
-    s.prefetched = std::min<uint32_t>(s.cand_cap, 32768);
+    s.prefetched = std::min<uint32_t>(s.cand_cap, 1u << 16);
     HIPCHECK(s.h_cands.ensure(s.cand_cap));
     HIPCHECK(hipMemcpyAsync(s.h_cands.p, s.d_cands.p, sizeof(Cand) * s.prefetched, hipMemcpyDeviceToHost, st));
     if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
@@ -408,8 +409,8 @@ int collect_common(qadc_index* idx, int slot_i) {
     const uint32_t count = s.h_hdr.p->count;
     if (count > s.prefetched) {
         HIPCHECK(hipMemcpyAsync(s.h_cands.p + s.prefetched, s.d_cands.p + s.prefetched,
-                                sizeof(Cand) * (count - s.prefetched), hipMemcpyDeviceToHost, idx->stream));
-        HIPCHECK(hipStreamSynchronize(idx->stream));
+                                sizeof(Cand) * (count - s.prefetched), hipMemcpyDeviceToHost, idx->copy_stream));
+        HIPCHECK(hipStreamSynchronize(idx->copy_stream));
     }
     if (idx->profile) {
         float ms = 0;
@@ -513,6 +514,7 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     idx->cs = M / 2;
     idx->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete idx;
         return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -541,6 +543,7 @@ int qadc_index_destroy(qadc_index* idx) {
         for (auto e : s.prof_ev) (void)hipEventDestroy(e);
     }
     (void)hipStreamDestroy(idx->stream);
+    if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
     delete idx;
     return QADC_OK;
 }
@@ -776,7 +779,9 @@ int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* v
     }
     finish_float_outputs(idx, s, status, qmin, qmax);
     if (qtables) {
-        HIPCHECK(hipMemcpy(qtables, s.d_qtables.p, (size_t)s.nq * s.ma * idx->M * 16, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpyAsync(qtables, s.d_qtables.p, (size_t)s.nq * s.ma * idx->M * 16, hipMemcpyDeviceToHost,
+                                idx->copy_stream));
+        HIPCHECK(hipStreamSynchronize(idx->copy_stream));
     }
     return replay_outputs(s, keys, values, sizes, status);
 }

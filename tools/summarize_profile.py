@@ -1,0 +1,81 @@
+"""Turns the rocprofv3 CSVs written by tools/profile_r01.sh (gpurun_out/prof_<tag>_*) into the
+committed summaries under profiles/: <tag>_kernel_stats.csv (verbatim --stats output),
+<tag>_pmc_summary.md and <tag>_hbm_traffic.json (read by bench.py for roofline.traffic).
+
+HBM bytes follow MI355X_MICROARCH.md §HBM: separate --pmc passes; FETCH_SIZE (KB) is doubled
+on gfx950 for 16-B/lane coalesced streaming reads; WRITE_SIZE (KB) read as is."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(G, pattern))
+    assert f, pattern
+    return f[0]
+
+
+shutil.copy(one("prof_%s_kt/*/*_kernel_stats.csv" % tag), os.path.join(P, "%s_kernel_stats.csv" % tag))
+bench_line = [l for l in open(os.path.join(G, "prof_%s_kt.log" % tag)) if l.startswith("{")][-1]
+bench = json.loads(bench_line)
+open(os.path.join(P, "%s_bench_under_rocprof.json" % tag), "w").write(bench_line)
+
+
+def counters(sub):
+    rows = list(csv.DictReader(open(one("prof_%s_%s/*/*_counter_collection.csv" % (tag, sub)))))
+    per = collections.defaultdict(dict)
+    for r in rows:
+        if "scan_i8_kernel" in r["Kernel_Name"]:
+            per[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+            per[int(r["Dispatch_Id"])]["_dur_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return per
+
+
+def biggest(per, key):
+    d = max(per.values(), key=lambda c: c["_dur_ns"])
+    return d
+
+
+f = biggest(counters("fetch"), "FETCH_SIZE")
+w = biggest(counters("write"), "WRITE_SIZE")
+l = biggest(counters("lds"), "SQ_LDS_IDX_ACTIVE")
+cfg = bench["config"]
+cs = cfg["M"] // 2
+# the longest launch is the last bound level: all codes past the previous level boundary, every query of the batch
+level_start = 1024 * 16 ** 4
+codes = (cfg["codes"] - level_start) * cfg["queries_per_step"]
+algo = codes * cs
+fetch_bytes = f["FETCH_SIZE"] * 1024 * 2
+write_bytes = w["WRITE_SIZE"] * 1024
+clk = l["GRBM_GUI_ACTIVE"] / 8 / (l["_dur_ns"] * 1e-9) / 1e9
+summary = {
+    "kernel": "scan_i8_kernel<%d,2>, longest launch (last bound level, %d queries)" % (cfg["M"], cfg["queries_per_step"]),
+    "codes_in_launch": codes, "algorithmic_bytes": algo,
+    "FETCH_SIZE_KB": f["FETCH_SIZE"], "hbm_read_bytes(FETCH_SIZE*1024*2)": fetch_bytes,
+    "WRITE_SIZE_KB": w["WRITE_SIZE"], "hbm_write_bytes": write_bytes,
+    "bytes_per_launch": fetch_bytes + write_bytes, "traffic_over_algorithmic": (fetch_bytes + write_bytes) / algo,
+    "duration_ms_under_pmc": f["_dur_ns"] / 1e6,
+    "SQ_LDS_BANK_CONFLICT": l["SQ_LDS_BANK_CONFLICT"], "SQ_LDS_IDX_ACTIVE": l["SQ_LDS_IDX_ACTIVE"],
+    "lds_conflict_fraction": l["SQ_LDS_BANK_CONFLICT"] / l["SQ_LDS_IDX_ACTIVE"],
+    "effective_clock_GHz(GRBM_GUI_ACTIVE/8/duration)": clk,
+}
+json.dump(summary, open(os.path.join(P, "%s_hbm_traffic.json" % tag), "w"), indent=1)
+with open(os.path.join(P, "%s_pmc_summary.md" % tag), "w") as o:
+    o.write("# %s — PMC summary of the dominant kernel (rocprofv3, MI355X)\n\n" % tag)
+    o.write("Command per pass: `rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --steps 2 --warmup 1` "
+            "(FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set in three separate runs; tools/profile_r01.sh).\n\n")
+    for k, v in summary.items():
+        o.write("- %s: %s\n" % (k, v))
+    o.write("\nKernel-trace stats (`--kernel-trace --stats`) are in %s_kernel_stats.csv; the bench line printed under the "
+            "profiler is %s_bench_under_rocprof.json.\n" % (tag, tag))
+print(json.dumps(summary, indent=1))
