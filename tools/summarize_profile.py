@@ -46,8 +46,11 @@ def biggest(per, key):
     return d
 
 
-f = biggest(counters("fetch"), "FETCH_SIZE")
-w = biggest(counters("write"), "WRITE_SIZE")
+fall, wall = counters("fetch"), counters("write")
+avg_read = sum(c["FETCH_SIZE"] for c in fall.values()) * 1024 * 2 / len(fall)
+avg_write = sum(c["WRITE_SIZE"] for c in wall.values()) * 1024 / len(wall)
+f = biggest(fall, "FETCH_SIZE")
+w = biggest(wall, "WRITE_SIZE")
 l = biggest(counters("lds"), "SQ_LDS_IDX_ACTIVE")
 cfg = bench["config"]
 cs = cfg["M"] // 2
@@ -63,7 +66,10 @@ summary = {
     "codes_in_launch": codes, "algorithmic_bytes": algo,
     "FETCH_SIZE_KB": f["FETCH_SIZE"], "hbm_read_bytes(FETCH_SIZE*1024*2)": fetch_bytes,
     "WRITE_SIZE_KB": w["WRITE_SIZE"], "hbm_write_bytes": write_bytes,
-    "bytes_per_launch": fetch_bytes + write_bytes, "traffic_over_algorithmic": (fetch_bytes + write_bytes) / algo,
+    "longest_launch_bytes": fetch_bytes + write_bytes, "traffic_over_algorithmic": (fetch_bytes + write_bytes) / algo,
+    "launches_in_pmc_run": len(fall),
+    "bytes_per_launch": avg_read + avg_write,   # average over ALL launches of the kernel, like roofline.achieved
+    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
     "duration_ms_under_pmc": f["_dur_ns"] / 1e6,
     "SQ_LDS_BANK_CONFLICT": l["SQ_LDS_BANK_CONFLICT"], "SQ_LDS_IDX_ACTIVE": l["SQ_LDS_IDX_ACTIVE"],
     "lds_conflict_fraction": l["SQ_LDS_BANK_CONFLICT"] / l["SQ_LDS_IDX_ACTIVE"],
