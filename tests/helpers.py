@@ -23,3 +23,13 @@ def float_tables(rng, nq, ma, M, scale=1.0, negatives=False):
 
 def heaps_equal(a, b):
     return np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def splitmix64(x):
+    """Vectorised splitmix64 finaliser on uint64 arrays (wraps mod 2^64)."""
+    x = np.asarray(x, np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))

@@ -1,0 +1,57 @@
+"""The C++14 host mirror (quick-adc_amd/host/scanner_hip.hpp) of the reference's ScannerType:
+builds with plain g++ -std=c++14 against the C-ABI (CPU), and on the GPU its query_scan fills the
+caller's heap exactly as the oracle's restatement of scanner_4::query_scan does."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import splitmix64
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "scanner_hip_demo")
+
+
+def build_demo():
+    libdir = os.path.join(ROOT, "quick-adc_amd")
+    if not os.path.exists(os.path.join(libdir, "libqadc_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror",
+                           os.path.join(ROOT, "tests", "cpp", "scanner_hip_demo.cpp"), "-o", EXE,
+                           "-L" + libdir, "-lqadc_hip", "-Wl,-rpath," + libdir])
+
+
+def test_scanner_hip_builds_as_cxx14():
+    build_demo()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,sizes,labeled,ma", [(16, [60000], 0, 1), (16, [20000, 37, 9000, 15001], 1, 3),
+                                                 (32, [30000, 12345], 1, 2)])
+def test_scanner_hip_fills_heap_like_oracle(po, M, sizes, labeled, ma):
+    build_demo()
+    keep, R, nq, seed = 0.02, 100, 3, 4242
+    out = subprocess.check_output([EXE, str(M), str(len(sizes))] + [str(s) for s in sizes] +
+                                  [str(labeled), str(keep), str(R), str(nq), str(ma), str(seed)]).decode().split("\n")
+    cs = M // 2
+    parts = [po.fill_codes(0, (s * cs + 7) // 8, seed + p)[:s * cs].reshape(s, cs).copy() for p, s in enumerate(sizes)]
+    labels = [(1000000 * (p + 1) + 7 * np.arange(s)).astype(np.uint32) for p, s in enumerate(sizes)] if labeled else None
+    line = 0
+    for q in range(nq):
+        assign = [(q + i * 3) % len(sizes) for i in range(ma)]
+        i = np.arange(ma * M * 16, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            h = splitmix64(np.uint64(seed * 31 + q * 1000003) + i)
+        tables = ((h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0) * np.float32(4.0))
+        want = po.query_scan(M, parts, labels, keep, assign, np.ascontiguousarray(tables.reshape(ma, M * 16)), R)
+        assert want["rc"] == 0
+        hdr = out[line].split()
+        assert hdr[0] == "q" and int(hdr[1]) == q
+        size = int(hdr[3])
+        rows = np.array([[int(x) for x in l.split()] for l in out[line + 1:line + 1 + size]], np.int64).reshape(size, 2)
+        line += 1 + size
+        assert size == len(want["keys"])
+        assert np.array_equal(rows[:, 0].astype(np.uint32), want["keys"]) and np.array_equal(rows[:, 1].astype(np.int8), want["values"])
