@@ -160,6 +160,7 @@ struct qadc_index {
     uint64_t level_base = 1024;
     uint64_t level_growth = 16;
     int wgs_per_item = 0;  // 0 = auto
+    int variant = 0x0e;    // kernel tuning variant (see launch_scan_i8): U=4, non-temporal loads, chunked tiles
     bool profile = false;
     Slot slot[2];
     qadc_profile prof{};
@@ -329,7 +330,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     // ---- scan levels ------------------------------------------------------------------------
     for (auto& ll : s.launches) {
         if (idx->profile) HIPCHECK(prof_event(s, st));
-        launch_scan_i8(M, 0, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p, s.d_cands.p,
+        launch_scan_i8(M, idx->variant, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p, s.d_cands.p,
                        s.cand_cap, (uint32_t)s.R, st);
         if (idx->profile) HIPCHECK(prof_event(s, st));
     }
@@ -748,6 +749,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "level_base") idx->level_base = (uint64_t)std::max(16.0, value);
     else if (n == "level_growth") idx->level_growth = (uint64_t)std::max(2.0, value);
     else if (n == "wgs_per_item") idx->wgs_per_item = (int)value;
+    else if (n == "variant") idx->variant = (int)value;
     else if (n == "profile") idx->profile = value != 0;
     else return fail(QADC_E_ARG, "unknown option: " + n);
     if (n == "cand_capacity") idx->slot[0].cand_cap = idx->slot[1].cand_cap = 0;

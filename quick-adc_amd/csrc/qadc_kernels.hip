@@ -135,7 +135,10 @@ __device__ __forceinline__ uint32_t pair_sum(const uint32_t* d, uint32_t lane_lo
     return s;
 }
 
-template <int M, int U>
+// Tuning knobs (compile-time): U = 16-KiB tiles in flight per lane, NT = non-temporal loads,
+// CHUNK = each workgroup owns a contiguous run of tiles instead of a grid-stride, PROBE = replace the
+// LDS lookups by a trivial reduction (streaming-ceiling diagnostic; results meaningless).
+template <int M, int U, bool NT, bool CHUNK, bool PROBE, bool PF>
 __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
     const ScanItem* __restrict__ items, const int8_t* __restrict__ qtables, QueryState* __restrict__ qstates,
     CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap, uint32_t R) {
@@ -150,54 +153,127 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
     const uint32_t tid = threadIdx.x;
     const uint32_t lane_lo = (tid & 31u) * 4u;
     const uint32_t lane_hi = lane_lo | 0x10000u;
-    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(it.codes);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(it.codes);
     const uint32_t n = it.n;
     const uint32_t nvec = (n + C::CPL - 1) / C::CPL;            // 16-byte vectors in the run
     const uint32_t ntiles = (nvec + kWG - 1) / kWG;
     const uint32_t G = gridDim.x;
+    // tile sequence of this workgroup: first, first+step, ... < last
+    uint32_t first = blockIdx.x, last = ntiles, step = G;
+    if (CHUNK) {
+        const uint32_t per = (ntiles + G - 1) / G;
+        first = blockIdx.x * per;
+        last = min(ntiles, first + per);
+        step = 1;
+    }
 
-    for (uint32_t t0 = blockIdx.x; t0 < ntiles; t0 += G * U) {
-        uint4 v[U];
-        uint32_t e[U];
+    auto load_tiles = [&](uint32_t t0, u32x4 (&v)[U], uint32_t (&e)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            e[u] = (t0 + u * G) * kWG + tid;                    // vector index (< 2^29)
-            v[u] = make_uint4(0, 0, 0, 0);
-            if (e[u] < nvec) v[u] = src[e[u]];
+            const uint32_t t = t0 + u * step;
+            e[u] = t * kWG + tid;                               // vector index
+            v[u] = u32x4{0, 0, 0, 0};
+            if (t < last && e[u] < nvec) v[u] = NT ? __builtin_nontemporal_load(src + e[u]) : src[e[u]];
+            else e[u] = 0xffffffffu;
         }
+    };
+    auto process = [&](const u32x4 (&v)[U], const uint32_t (&e)[U]) {
+        uint32_t cand[U * C::CPL];
+        uint32_t best = 127u;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
             for (int c = 0; c < C::CPL; ++c) {
-                const uint32_t s = pair_sum<M>(d + c * C::DW, lane_lo, lane_hi);
-                const uint32_t cand = min(s, 127u);
-                const uint32_t idx = e[u] * C::CPL + c;
-                if (__builtin_expect(cand < bound && idx < n && e[u] < nvec, 0))
-                    emit_candidate(qs, hdr, out, cand_cap, it.labels, it.key_base, it.order, it.query, it.pos0 + idx, cand);
+                uint32_t s;
+                if (PROBE) {
+                    s = 0;
+#pragma unroll
+                    for (int w = 0; w < C::DW; ++w) s ^= d[c * C::DW + w];
+                    s = (s == 0x12345678u) ? 0u : 200u;
+                } else {
+                    s = pair_sum<M>(d + c * C::DW, lane_lo, lane_hi);
+                }
+                // lanes past the end of the run never qualify: 127 is not < bound (bound <= 127)
+                const bool live = e[u] != 0xffffffffu && e[u] * C::CPL + c < n;
+                cand[u * C::CPL + c] = live ? min(s, 127u) : 127u;
+                best = min(best, cand[u * C::CPL + c]);
             }
+        }
+        if (__builtin_expect(best < bound, 0)) {                // rare: one branch per U tiles
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < C::CPL; ++c)
+                    if (cand[u * C::CPL + c] < bound)
+                        emit_candidate(qs, hdr, out, cand_cap, it.labels, it.key_base, it.order, it.query,
+                                       it.pos0 + e[u] * C::CPL + c, cand[u * C::CPL + c]);
+        }
+    };
+
+    if (PF) {
+        // software prefetch: the next U tiles are requested before the current ones are consumed, so every
+        // wave keeps loads in flight during its LDS/VALU phase
+        u32x4 cur[U], nxt[U];
+        uint32_t ecur[U], enxt[U];
+        load_tiles(first, cur, ecur);
+        for (uint32_t t0 = first; t0 < last; t0 += step * U) {
+            load_tiles(t0 + step * U, nxt, enxt);
+            process(cur, ecur);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { cur[u] = nxt[u]; ecur[u] = enxt[u]; }
+        }
+    } else {
+        for (uint32_t t0 = first; t0 < last; t0 += step * U) {
+            u32x4 v[U];
+            uint32_t e[U];
+            load_tiles(t0, v, e);
+            process(v, e);
         }
     }
 }
 
+template <int M, int U, bool NT, bool CHUNK, bool PROBE, bool PF>
+static void launch_scan_variant(dim3 grid, hipStream_t stream, const ScanItem* d_items, const int8_t* d_qtables,
+                                QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R) {
+    auto k = &scan_i8_kernel<M, U, NT, CHUNK, PROBE, PF>;
+    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            ScanCfg<M>::LDS_BYTES), true);
+    (void)once;
+    hipLaunchKernelGGL(k, grid, dim3(kWG), ScanCfg<M>::LDS_BYTES, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R);
+}
+
+// variant bits: [1:0] U = 1,2,4 (index 0,1,2)  [2] NT  [3] CHUNK  [4] PROBE  [5] PF (software prefetch).
 void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int wgs_per_item,
                     const int8_t* d_qtables, QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap,
                     uint32_t R, hipStream_t stream) {
-    (void)variant;
-    const dim3 grid(wgs_per_item, nitems), block(kWG);
-    if (M == 16) {
-        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_i8_kernel<16, 2>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, ScanCfg<16>::LDS_BYTES), true);
-        (void)once;
-        hipLaunchKernelGGL((scan_i8_kernel<16, 2>), grid, block, ScanCfg<16>::LDS_BYTES, stream, d_items, d_qtables, d_qs,
-                           d_hdr, d_cands, cand_cap, R);
-    } else {
-        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_i8_kernel<32, 2>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, ScanCfg<32>::LDS_BYTES), true);
-        (void)once;
-        hipLaunchKernelGGL((scan_i8_kernel<32, 2>), grid, block, ScanCfg<32>::LDS_BYTES, stream, d_items, d_qtables, d_qs,
-                           d_hdr, d_cands, cand_cap, R);
+    const dim3 grid(wgs_per_item, nitems);
+#define QADC_ARGS grid, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R
+#define QADC_V(MM, UU, NTT, CH, PR) \
+    do { if (variant & 32) launch_scan_variant<MM, UU, NTT, CH, PR, true>(QADC_ARGS); \
+         else launch_scan_variant<MM, UU, NTT, CH, PR, false>(QADC_ARGS); } while (0)
+#define QADC_DISPATCH_U(MM, NTT, CH, PR)                                    \
+    switch (variant & 3) {                                                  \
+        case 0: QADC_V(MM, 1, NTT, CH, PR); break;                          \
+        case 2: QADC_V(MM, 4, NTT, CH, PR); break;                          \
+        default: QADC_V(MM, 2, NTT, CH, PR); break;                         \
     }
+#define QADC_DISPATCH_P(MM, PR)                                             \
+    switch ((variant >> 2) & 3) {                                           \
+        case 0: QADC_DISPATCH_U(MM, false, false, PR) break;                \
+        case 1: QADC_DISPATCH_U(MM, true, false, PR) break;                 \
+        case 2: QADC_DISPATCH_U(MM, false, true, PR) break;                 \
+        default: QADC_DISPATCH_U(MM, true, true, PR) break;                 \
+    }
+#define QADC_DISPATCH(MM)                                                   \
+    if (variant & 16) { QADC_DISPATCH_P(MM, true) } else { QADC_DISPATCH_P(MM, false) }
+    if (M == 16) { QADC_DISPATCH(16) } else { QADC_DISPATCH(32) }
+#undef QADC_DISPATCH
+#undef QADC_DISPATCH_P
+#undef QADC_DISPATCH_U
+#undef QADC_V
+#undef QADC_ARGS
 }
 
 // All candidate values (diagnostic; used by parity tests and checksums at full size).

@@ -208,3 +208,27 @@ def test_negative_int8_tables_rejected(pyqadc):
     with pytest.raises(pyqadc.QadcError):
         idx.scan_i8(np.zeros((1, 1), np.int32), qt, 10)
     idx.close()
+
+
+@pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x05, 0x09, 0x0d, 0x0e, 0x21, 0x2c, 0x2d, 0x2e, 0x26])
+@pytest.mark.parametrize("M", [16, 32])
+def test_kernel_tuning_variants_are_exact(pyqadc, po, M, variant):
+    """Every tuning variant of the scan kernel (tiles in flight, non-temporal loads, chunked tile order,
+    software prefetch) must give the same heap arrays."""
+    rng = np.random.default_rng(variant * 7 + M)
+    sizes = [70001, 4097, 1]
+    parts = [rand_codes(rng, s, M) for s in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts)
+    idx.finalize(0.01)
+    idx.set_option("variant", variant)
+    idx.set_option("level_base", 64)
+    idx.set_option("level_growth", 4)
+    for wgs in (0, 3):
+        idx.set_option("wgs_per_item", wgs)
+        qt = rand_qtables(rng, (2, 3), M, 11)
+        got = idx.scan_i8(np.array([[0, 1, 2], [2, 0, 1]], np.int32), qt, 100)
+        for q, order in enumerate(([0, 1, 2], [2, 0, 1])):
+            want = po.scan_i8(M, [parts[p] for p in order], None, qt[q], 100)
+            assert heaps_equal(got[q], want), (M, variant, wgs, q)
+    idx.close()
