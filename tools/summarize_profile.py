@@ -20,9 +20,9 @@ os.makedirs(P, exist_ok=True)
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(G, pattern))
+    f = sorted(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)   # newest run wins
     assert f, pattern
-    return f[0]
+    return f[-1]
 
 
 shutil.copy(one("prof_%s_kt/*/*_kernel_stats.csv" % tag), os.path.join(P, "%s_kernel_stats.csv" % tag))
