@@ -87,10 +87,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Quick-ADC engine has no CPU path")
+    # test hooks (not used by the driver): run the multi-rank path on a 1-GPU box over gloo
+    backend = os.environ.get("QADC_BENCH_BACKEND", "nccl")
+    if os.environ.get("QADC_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")   # device of the collective buffers
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- database: this rank's contiguous shard of the synthetic list + replica of the starts ----
     first, local_n = sharded.shard_ranges(N, world)[rank]
@@ -108,7 +116,7 @@ def main():
     def finish(step_res):
         if world == 1:
             return step_res
-        return sharded.merge_batch(step_res, NQ, R, step_res["status"], dev)
+        return sharded.merge_batch(step_res, NQ, R, step_res["status"], cdev)
 
     def run_steps(k):
         """k pipelined steps: batch s+1 is enqueued before batch s is collected and replayed."""
@@ -137,7 +145,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = idx.profile()
@@ -149,8 +157,8 @@ def main():
     for q in range(NQ):
         key, _, dist_q = idx.float_top1(0, tb[q, 0])
         if world > 1:
-            cand = torch.tensor([dist_q, float(key)], dtype=torch.float64, device=dev)
-            allc = torch.empty(2 * world, dtype=torch.float64, device=dev)
+            cand = torch.tensor([dist_q, float(key)], dtype=torch.float64, device=cdev)
+            allc = torch.empty(2 * world, dtype=torch.float64, device=cdev)
             dist.all_gather_into_tensor(allc, cand)
             allc = allc.cpu().numpy().reshape(world, 2)
             key = int(allc[np.lexsort((allc[:, 1], allc[:, 0]))[0], 1])   # min distance, lowest key on ties

@@ -313,8 +313,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             HIPCHECK(hipMemcpyAsync(s.d_sitems.p, s.h_sitems.p, sitems.size() * sizeof(StartItem), hipMemcpyHostToDevice, st));
             uint32_t maxs = 0;
             for (auto& si : sitems) maxs = std::max(maxs, si.n);
-            const int wgs = (int)std::min<uint32_t>(std::max<uint32_t>((maxs + 1023) / 1024, 1), 1024);
-            launch_start_scan_f32(M, s.d_sitems.p, (int)sitems.size(), wgs, s.d_ftables.p, s.d_fc.p, fc_stride, st);
+            const int wgs = (int)std::min<uint32_t>(std::max<uint32_t>((maxs + 4095) / 4096, 1), 512);
+            launch_start_scan_f32(M, s.d_sitems.p, (int)sitems.size(), wgs, s.d_ftables.p, s.d_fc.p, fc_stride, s.d_qs.p, st);
         }
         launch_select_kth(s.d_fc.p, fc_stride, s.d_fc_count.p, nq, (uint32_t)s.R, s.d_qs.p, s.d_sel_hist.p, st);
         launch_quantize(M, ma, nq, s.d_ftables.p, s.d_qtables.p, s.d_qs.p, idx->quant_mode, st);
@@ -913,7 +913,7 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
     int b = 0;
     for (int i = 1; i < blocks; ++i)
         if (hv[i] < hv[b] || (hv[i] == hv[b] && hp[i] < hp[b])) b = i;
-    uint32_t key = p.key_base + hp[b];
+    uint32_t key = p.key_base + p.first_pos + hp[b];
     if (p.d_labels) HIPCHECK(hipMemcpy(&key, p.d_labels + hp[b], sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (out_key) *out_key = key;
     if (out_pos) *out_pos = hp[b];

@@ -44,9 +44,12 @@ struct QueryState {
     uint32_t flags;     // bit0: qmax > 1e30 (reference would exit), bit1: negative table entries clamped
     float qmin;
     float qmax;
-    uint32_t sel_prefix;  // radix-select running key prefix
+    uint32_t sel_prefix;  // radix-select running prefix (in key - sel_min space)
     uint32_t sel_k;       // radix-select remaining rank (1-based)
-    uint32_t pad;
+    uint32_t sel_hi;      // bits [sel_hi, 32) of (key - sel_min) are already fixed to sel_prefix
+    uint32_t sel_nmin;    // ~min(key) over the query's pre-scan values (atomicMax of ~key; 0 = none)
+    uint32_t sel_max;     // max(key)
+    uint32_t pad[3];
 };
 
 // Float ADC item for the "starts" pre-scan (scanner_4::query_scan_start).
@@ -63,7 +66,8 @@ void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int
                     uint32_t cand_cap, uint32_t R, hipStream_t stream);
 
 void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item,
-                           const float* d_ftables, float* d_fc, uint64_t fc_stride, hipStream_t stream);
+                           const float* d_ftables, float* d_fc, uint64_t fc_stride, QueryState* d_qs,
+                           hipStream_t stream);
 
 // Per-block (min float ADC distance, lowest position) over a whole partition; host reduces the blocks.
 void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,

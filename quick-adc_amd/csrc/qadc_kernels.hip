@@ -321,10 +321,18 @@ void launch_candidates_i8(int M, const uint8_t* d_codes, uint64_t n, const int8_
 // The 16 lanes-distinct entries of one table sit in 16 consecutive LDS dwords, so every lookup
 // instruction (all lanes in the same table) is bank-conflict-free without replication.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fkey(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float funkey(uint32_t k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
 template <int M>
 __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __restrict__ items,
                                                              const float* __restrict__ ftables, float* __restrict__ fc,
-                                                             uint64_t fc_stride) {
+                                                             uint64_t fc_stride, QueryState* __restrict__ qstates) {
     __shared__ float tab[M * 16];
     const StartItem it = items[blockIdx.y];
     const float* __restrict__ ft = ftables + (uint64_t)it.table * (M * 16);
@@ -332,6 +340,7 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
     __syncthreads();
     float* __restrict__ dst = fc + (uint64_t)it.query * fc_stride + it.out_off;
     constexpr int DW = M / 8;
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < it.n; i += gridDim.x * 256) {
         uint32_t d[DW];
         if constexpr (M == 16) {
@@ -349,6 +358,26 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
             cand += tab[(2 * b + 1) * 16 + (byte >> 4)];
         }
         dst[i] = cand;
+        const uint32_t k = fkey(cand);
+        kmin = min(kmin, k);
+        kmax = max(kmax, k);
+    }
+    // key range of the query's pre-scan values: lets the radix select skip the constant leading bits
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor(kmin, d, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor(kmax, d, 64));
+    }
+    __shared__ uint32_t red[8];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = kmin; red[4 + (threadIdx.x >> 6)] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                  // one atomic pair per workgroup
+        kmin = min(min(red[0], red[1]), min(red[2], red[3]));
+        kmax = max(max(red[4], red[5]), max(red[6], red[7]));
+        if (kmin <= kmax) {
+            atomicMax(&qstates[it.query].sel_nmin, ~kmin);
+            atomicMax(&qstates[it.query].sel_max, kmax);
+        }
     }
 }
 
@@ -409,55 +438,58 @@ void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d
 }
 
 void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item, const float* d_ftables,
-                           float* d_fc, uint64_t fc_stride, hipStream_t stream) {
+                           float* d_fc, uint64_t fc_stride, QueryState* d_qs, hipStream_t stream) {
     const dim3 grid(wgs_per_item, nitems), block(256);
-    if (M == 16) hipLaunchKernelGGL(start_scan_f32_kernel<16>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride);
-    else         hipLaunchKernelGGL(start_scan_f32_kernel<32>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride);
+    if (M == 16) hipLaunchKernelGGL(start_scan_f32_kernel<16>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride, d_qs);
+    else         hipLaunchKernelGGL(start_scan_f32_kernel<32>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride, d_qs);
 }
 
 // ---------------------------------------------------------------------------------------------
 // R-th smallest float per query (= tmp_bh.max() after query_scan_start, db_query_4.cpp:259):
 // 4-pass MSD radix select on the order-preserving u32 image of the floats.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t fkey(float f) {
-    const uint32_t b = __float_as_uint(f);
-    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
-}
-__device__ __forceinline__ float funkey(uint32_t k) {
-    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
-}
-
+// Select on k' = key - min(key): only the bits below the range's top bit vary, so the first 8-bit digit
+// already spreads the values over the histogram (no single hot LDS bin).
 __global__ void select_init_kernel(QueryState* qs, uint32_t R, uint32_t* sel_hist, int nq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq) { qs[i].sel_prefix = 0; qs[i].sel_k = R; }
+    if (i < nq) {
+        const uint32_t kmin = ~qs[i].sel_nmin, kmax = qs[i].sel_max;
+        const uint32_t range = kmax >= kmin ? kmax - kmin : 0u;
+        qs[i].sel_prefix = 0;
+        qs[i].sel_k = R;
+        qs[i].sel_hi = range ? 32u - (uint32_t)__clz(range) : 0u;
+    }
     if (i < nq * 256) sel_hist[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ fc, uint64_t fc_stride,
                                                           const uint32_t* __restrict__ counts,
-                                                          const QueryState* __restrict__ qs, uint32_t* __restrict__ sel_hist,
-                                                          int pass) {
+                                                          const QueryState* __restrict__ qs, uint32_t* __restrict__ sel_hist) {
     __shared__ uint32_t lh[256];
     const int q = blockIdx.y;
+    const uint32_t hi = qs[q].sel_hi;
+    if (hi == 0) return;                                   // every remaining bit is decided
     lh[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t n = counts[q];
     const float* __restrict__ src = fc + (uint64_t)q * fc_stride;
-    const int shift = 24 - 8 * pass;
-    const uint32_t prefix = qs[q].sel_prefix;
+    const uint32_t lo = hi > 8 ? hi - 8 : 0;
+    const uint32_t prefix = qs[q].sel_prefix, kmin = ~qs[q].sel_nmin;
+    const uint32_t dmask = (1u << (hi - lo)) - 1u;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t k = fkey(src[i]);
-        const bool match = pass == 0 || ((k ^ prefix) >> (shift + 8)) == 0;
-        if (match) atomicAdd(&lh[(k >> shift) & 255u], 1u);
+        const uint32_t k = fkey(src[i]) - kmin;
+        const bool match = hi >= 32 || ((k ^ prefix) >> hi) == 0;
+        if (match) atomicAdd(&lh[(k >> lo) & dmask], 1u);
     }
     __syncthreads();
     if (lh[threadIdx.x]) atomicAdd(&sel_hist[q * 256 + threadIdx.x], lh[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void select_pick_kernel(QueryState* __restrict__ qs, uint32_t* __restrict__ sel_hist,
-                                                          const uint32_t* __restrict__ counts, int pass, uint32_t R) {
+                                                          const uint32_t* __restrict__ counts, int last_pass, uint32_t R) {
     __shared__ uint32_t sc[256];
     const int q = blockIdx.x, t = threadIdx.x;
+    const uint32_t hi = qs[q].sel_hi;
     const uint32_t c = sel_hist[q * 256 + t];
     sel_hist[q * 256 + t] = 0;
     sc[t] = c;
@@ -470,17 +502,23 @@ __global__ __launch_bounds__(256) void select_pick_kernel(QueryState* __restrict
     }
     const uint32_t incl = sc[t], excl = incl - c;
     const uint32_t k = qs[q].sel_k;
-    const int shift = 24 - 8 * pass;
+    const uint32_t kmin = ~qs[q].sel_nmin;
     __syncthreads();
     if (counts[q] < R) {
-        if (t == 0 && pass == 3) qs[q].qmax = FLT_MAX;   // heap never fills: max() stays the FLT_MAX sentinel
+        if (t == 0 && last_pass) qs[q].qmax = FLT_MAX;     // heap never fills: max() stays the FLT_MAX sentinel
         return;
     }
+    if (hi == 0) {                                          // already decided (or all values equal)
+        if (t == 0 && last_pass) qs[q].qmax = funkey(qs[q].sel_prefix + kmin);
+        return;
+    }
+    const uint32_t lo = hi > 8 ? hi - 8 : 0;
     if (incl >= k && excl < k) {
-        const uint32_t prefix = qs[q].sel_prefix | ((uint32_t)t << shift);
+        const uint32_t prefix = qs[q].sel_prefix | ((uint32_t)t << lo);
         qs[q].sel_prefix = prefix;
         qs[q].sel_k = k - excl;
-        if (pass == 3) qs[q].qmax = funkey(prefix);
+        qs[q].sel_hi = lo;
+        if (last_pass) qs[q].qmax = funkey(prefix + kmin);
     }
 }
 
@@ -489,8 +527,8 @@ void launch_select_kth(float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_cou
     hipLaunchKernelGGL(select_init_kernel, dim3((nq * 256 + 255) / 256), dim3(256), 0, stream, d_qs, R, d_sel_hist, nq);
     for (int pass = 0; pass < 4; ++pass) {
         hipLaunchKernelGGL(select_hist_kernel, dim3(256, nq), dim3(256), 0, stream, d_fc, fc_stride, d_fc_count, d_qs,
-                           d_sel_hist, pass);
-        hipLaunchKernelGGL(select_pick_kernel, dim3(nq), dim3(256), 0, stream, d_qs, d_sel_hist, d_fc_count, pass, R);
+                           d_sel_hist);
+        hipLaunchKernelGGL(select_pick_kernel, dim3(nq), dim3(256), 0, stream, d_qs, d_sel_hist, d_fc_count, pass == 3, R);
     }
 }
 
