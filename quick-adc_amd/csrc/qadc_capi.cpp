@@ -109,7 +109,8 @@ struct Slot {
     float* tables = nullptr;            // caller's float tables (float path)
     std::vector<int32_t> assign;
     std::vector<int8_t> qtables_in;     // int8 path input copy
-    uint32_t cand_cap = 0;
+    uint32_t cap_q = 0;                 // candidate region entries per query
+    uint32_t out_cap = 0;               // entries of the device-sorted output
     uint32_t prefetched = 0;
 
     DevBuf<float> d_ftables;
@@ -117,6 +118,8 @@ struct Slot {
     DevBuf<QueryState> d_qs;
     DevBuf<CandHeader> d_hdr;
     DevBuf<Cand> d_cands;
+    DevBuf<uint32_t> d_out_keys;
+    DevBuf<int8_t> d_out_vals;
     DevBuf<ScanItem> d_items;
     DevBuf<StartItem> d_sitems;
     DevBuf<float> d_fc;
@@ -130,7 +133,9 @@ struct Slot {
     PinBuf<int8_t> h_qtables;
     PinBuf<QueryState> h_qs;
     PinBuf<CandHeader> h_hdr;
-    PinBuf<Cand> h_cands;
+    PinBuf<Cand> h_cands;               // host-sort fallback only
+    PinBuf<uint32_t> h_out_keys;
+    PinBuf<int8_t> h_out_vals;
 
     std::vector<LevelLaunch> launches;
     uint64_t start_codes = 0;
@@ -156,7 +161,7 @@ struct qadc_index {
     float keep = 0.01f;
     // options
     int quant_mode = 1;
-    uint32_t cand_capacity = 1u << 16;
+    uint32_t cand_capacity = kSortCap;  // candidate region entries per query
     uint64_t level_base = 1024;
     uint64_t level_growth = 16;
     int wgs_per_item = 0;  // 0 = auto
@@ -248,6 +253,9 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                     it.table = (uint32_t)((size_t)q * ma + a);
                     it.query = (uint32_t)q;
                     it.order = ((uint32_t)k << 16) | (uint32_t)a;
+                    // padding-lane replay of the partition's last code (simd_layout.hpp:46-50, simd_scan.hpp:67)
+                    it.dup_pos = (pt.first_pos + pt.n == pt.global_n) ? pt.n - 1u : 0xffffffffu;
+                    it.dup_reps = (16u - pt.global_n % 16u) % 16u;
                     per_level[k].push_back(it);
                     b0 += len;
                 }
@@ -288,7 +296,9 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     HIPCHECK(s.h_qs.ensure(nq));
     HIPCHECK(s.d_hdr.ensure(1));
     HIPCHECK(s.h_hdr.ensure(1));
-    HIPCHECK(s.d_cands.ensure(s.cand_cap));
+    HIPCHECK(s.d_cands.ensure((size_t)nq * s.cap_q));
+    HIPCHECK(s.d_out_keys.ensure(s.out_cap));
+    HIPCHECK(s.d_out_vals.ensure(s.out_cap));
     HIPCHECK(s.d_qtables.ensure((size_t)nq * ma * table_dim));
     HIPCHECK(hipMemsetAsync(s.d_qs.p, 0, sizeof(QueryState) * nq, st));
     HIPCHECK(hipMemsetAsync(s.d_hdr.p, 0, sizeof(CandHeader), st));
@@ -331,17 +341,20 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     for (auto& ll : s.launches) {
         if (idx->profile) HIPCHECK(prof_event(s, st));
         launch_scan_i8(M, idx->variant, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p, s.d_cands.p,
-                       s.cand_cap, (uint32_t)s.R, st);
+                       s.cap_q, (uint32_t)s.R, st);
         if (idx->profile) HIPCHECK(prof_event(s, st));
     }
+    launch_sort_cands(s.d_qs.p, s.d_cands.p, s.cap_q, nq, s.d_out_keys.p, s.d_out_vals.p, s.out_cap, s.d_hdr.p, st);
     HIPCHECK(hipGetLastError());
 
     // ---- results ----------------------------------------------------------------------------
     HIPCHECK(hipMemcpyAsync(s.h_hdr.p, s.d_hdr.p, sizeof(CandHeader), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipMemcpyAsync(s.h_qs.p, s.d_qs.p, sizeof(QueryState) * nq, hipMemcpyDeviceToHost, st));
-    s.prefetched = std::min<uint32_t>(s.cand_cap, 1u << 16);
-    HIPCHECK(s.h_cands.ensure(s.cand_cap));
-    HIPCHECK(hipMemcpyAsync(s.h_cands.p, s.d_cands.p, sizeof(Cand) * s.prefetched, hipMemcpyDeviceToHost, st));
+    s.prefetched = std::min<uint32_t>(s.out_cap, 1u << 16);
+    HIPCHECK(s.h_out_keys.ensure(s.out_cap));
+    HIPCHECK(s.h_out_vals.ensure(s.out_cap));
+    HIPCHECK(hipMemcpyAsync(s.h_out_keys.p, s.d_out_keys.p, sizeof(uint32_t) * s.prefetched, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(s.h_out_vals.p, s.d_out_vals.p, s.prefetched, hipMemcpyDeviceToHost, st));
     if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(s.ev_done, st));
     return QADC_OK;
@@ -354,7 +367,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
     if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
     if (nq <= 0 || ma <= 0 || R <= 0 || !assign) return fail(QADC_E_ARG, "nq, ma, R must be > 0 and assign non-null");
     if (nq >= (1 << 24)) return fail(QADC_E_ARG, "nq must be < 2^24");
-    if (ma >= (1 << 16)) return fail(QADC_E_ARG, "ma must be < 65536");
+    if (ma >= (1 << 15)) return fail(QADC_E_ARG, "ma must be < 32768");
     if (!tables && !qtables) return fail(QADC_E_ARG, "tables is null");
     Slot& s = idx->slot[slot_i];
     if (s.busy) return fail(QADC_E_STATE, "slot still holds an uncollected batch");
@@ -372,34 +385,44 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
                 return fail(QADC_E_ARG, "int8 tables must lie in [0,127] (QuantizerMAX<int8_t> output, db_query_4.cpp:37-71)");
         s.qtables_in.assign(qtables, qtables + nt);
     }
-    s.cand_cap = std::max<uint32_t>(s.cand_cap, idx->cand_capacity);
+    s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
+    s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)nq * 8192u, 1ull << 30));
     if (int rc = plan_and_launch(idx, s)) return rc;
     s.busy = true;
     return QADC_OK;
 }
 
-// Waits for the batch, regrows and re-runs on overflow, sorts candidates into scan order and
-// expands padding-lane duplicates into s.out_*.
+// Waits for the batch, regrows and re-runs on overflow, and lays the ordered candidate streams
+// (padding-lane replays expanded) out in s.out_*.  Queries the device could not sort (more than
+// kSortCap candidates) are sorted here.
 int collect_common(qadc_index* idx, int slot_i) {
     if (!idx) return fail(QADC_E_ARG, "null index");
     if (slot_i < 0 || slot_i > 1) return fail(QADC_E_ARG, "slot must be 0 or 1");
     Slot& s = idx->slot[slot_i];
     if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
     if (int rc = use_device(idx)) return rc;
+    const uint32_t sort_limit_max = kSortCap;
+    uint64_t total_sorted = 0;
     for (int attempt = 0;; ++attempt) {
         HIPCHECK(hipEventSynchronize(s.ev_done));
-        if (s.h_hdr.p->overflow == 0) break;
-        if (attempt >= 4) {
-            s.busy = false;
-            return fail(QADC_E_CAPACITY, "candidate buffer overflow persists after regrowth");
+        const uint32_t limit = std::min<uint32_t>(s.cap_q, sort_limit_max);
+        uint64_t max_count = 0;
+        total_sorted = 0;
+        for (int q = 0; q < s.nq; ++q) {
+            const QueryState& qs = s.h_qs.p[q];
+            max_count = std::max<uint64_t>(max_count, qs.count);
+            if (qs.count <= limit) total_sorted += (uint64_t)qs.count + qs.reps;
         }
-        // every emitted candidate was counted: size the buffer for all of them and run again
-        const uint64_t need = (uint64_t)s.h_hdr.p->count + 1024;
-        if (need > (1ull << 31)) {
+        const bool region_overflow = s.h_hdr.p->overflow != 0;
+        const bool out_overflow = total_sorted > s.out_cap;
+        if (!region_overflow && !out_overflow) break;
+        if (attempt >= 4 || max_count + 64 > (1ull << 31) || total_sorted > (1ull << 31)) {
             s.busy = false;
-            return fail(QADC_E_CAPACITY, "more than 2^31 candidates: adversarial scan order");
+            return fail(QADC_E_CAPACITY, "candidate buffers overflow persists (adversarial scan order?)");
         }
-        s.cand_cap = (uint32_t)std::max<uint64_t>(need, (uint64_t)s.cand_cap * 2);
+        // every emitted candidate was counted: size the buffers for all of them and run the batch again
+        if (region_overflow) s.cap_q = (uint32_t)std::max<uint64_t>(max_count + 64, (uint64_t)s.cap_q * 2);
+        if (out_overflow) s.out_cap = (uint32_t)(total_sorted + total_sorted / 4 + 1024);
         idx->prof.regrows++;
         if (int rc = plan_and_launch(idx, s)) {
             s.busy = false;
@@ -407,10 +430,12 @@ int collect_common(qadc_index* idx, int slot_i) {
         }
     }
     s.busy = false;
-    const uint32_t count = s.h_hdr.p->count;
-    if (count > s.prefetched) {
-        HIPCHECK(hipMemcpyAsync(s.h_cands.p + s.prefetched, s.d_cands.p + s.prefetched,
-                                sizeof(Cand) * (count - s.prefetched), hipMemcpyDeviceToHost, idx->copy_stream));
+    if (total_sorted > s.prefetched) {
+        const size_t rest = (size_t)total_sorted - s.prefetched;
+        HIPCHECK(hipMemcpyAsync(s.h_out_keys.p + s.prefetched, s.d_out_keys.p + s.prefetched, rest * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, idx->copy_stream));
+        HIPCHECK(hipMemcpyAsync(s.h_out_vals.p + s.prefetched, s.d_out_vals.p + s.prefetched, rest, hipMemcpyDeviceToHost,
+                                idx->copy_stream));
         HIPCHECK(hipStreamSynchronize(idx->copy_stream));
     }
     if (idx->profile) {
@@ -426,32 +451,37 @@ int collect_common(qadc_index* idx, int slot_i) {
             idx->prof.scan_codes += s.launches[i].codes;
         }
         if (s.float_path) idx->prof.start_codes += s.start_codes;
-        idx->prof.candidates += count;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    Cand* c = s.h_cands.p;
-    std::sort(c, c + count, [](const Cand& a, const Cand& b) {
-        const uint32_t qa = a.qv >> 8, qb = b.qv >> 8;
-        if (qa != qb) return qa < qb;
-        if (a.order != b.order) return a.order < b.order;
-        return a.pos < b.pos;
-    });
     s.out_keys.clear();
     s.out_vals.clear();
     s.out_off.assign((size_t)s.nq + 1, 0);
-    uint32_t i = 0;
     for (int q = 0; q < s.nq; ++q) {
+        const QueryState& qs = s.h_qs.p[q];
         s.out_off[q] = s.out_keys.size();
-        for (; i < count && (int)(c[i].qv >> 8) == q; ++i) {
-            const int a = (int)(c[i].order & 0xffffu);
-            const Part& pt = idx->parts[s.assign[(size_t)q * s.ma + a]];
-            // lanes past the end of the last 16-code block replay code n-1 (simd_layout.hpp:46-50,
-            // simd_scan.hpp:67): the reference offers that code 1 + pad times in a row
-            int reps = 1;
-            if (c[i].pos == pt.n - 1 && pt.first_pos + pt.n == pt.global_n) reps += (int)((16u - pt.global_n % 16u) % 16u);
-            for (int r = 0; r < reps; ++r) {
+        idx->prof.candidates += qs.count;
+        if (qs.flags & 4u) {                                  // ordered and expanded on the device
+            const size_t n = (size_t)qs.count + qs.reps;
+            s.out_keys.insert(s.out_keys.end(), s.h_out_keys.p + qs.out_off, s.h_out_keys.p + qs.out_off + n);
+            s.out_vals.insert(s.out_vals.end(), s.h_out_vals.p + qs.out_off, s.h_out_vals.p + qs.out_off + n);
+            continue;
+        }
+        // host fallback: fetch the raw region, sort by (level, assign slot, position), expand replays
+        HIPCHECK(s.h_cands.ensure(qs.count));
+        HIPCHECK(hipMemcpyAsync(s.h_cands.p, s.d_cands.p + (size_t)q * s.cap_q, sizeof(Cand) * qs.count,
+                                hipMemcpyDeviceToHost, idx->copy_stream));
+        HIPCHECK(hipStreamSynchronize(idx->copy_stream));
+        Cand* c = s.h_cands.p;
+        std::sort(c, c + qs.count, [](const Cand& a, const Cand& b) {
+            const uint32_t oa = a.order & 0xfffffu, ob = b.order & 0xfffffu;
+            if (oa != ob) return oa < ob;
+            return a.pos < b.pos;
+        });
+        for (uint32_t i = 0; i < qs.count; ++i) {
+            const uint32_t reps = 1u + ((c[i].order >> 20) & 15u);
+            for (uint32_t r = 0; r < reps; ++r) {
                 s.out_keys.push_back(c[i].key);
-                s.out_vals.push_back((int8_t)(c[i].qv & 0xffu));
+                s.out_vals.push_back((int8_t)c[i].val);
             }
         }
     }
@@ -536,10 +566,10 @@ int qadc_index_destroy(qadc_index* idx) {
         if (p.d_starts) (void)hipFree(p.d_starts);
     }
     for (auto& s : idx->slot) {
-        s.d_ftables.release(); s.d_qtables.release(); s.d_qs.release(); s.d_hdr.release(); s.d_cands.release();
+        s.d_ftables.release(); s.d_qtables.release(); s.d_qs.release(); s.d_hdr.release(); s.d_cands.release(); s.d_out_keys.release(); s.d_out_vals.release();
         s.d_items.release(); s.d_sitems.release(); s.d_fc.release(); s.d_fc_count.release(); s.d_sel_hist.release();
         s.h_items.release(); s.h_sitems.release(); s.h_fc_count.release(); s.h_ftables.release(); s.h_qtables.release();
-        s.h_qs.release(); s.h_hdr.release(); s.h_cands.release();
+        s.h_qs.release(); s.h_hdr.release(); s.h_cands.release(); s.h_out_keys.release(); s.h_out_vals.release();
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         for (auto e : s.prof_ev) (void)hipEventDestroy(e);
     }
@@ -752,7 +782,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "variant") idx->variant = (int)value;
     else if (n == "profile") idx->profile = value != 0;
     else return fail(QADC_E_ARG, "unknown option: " + n);
-    if (n == "cand_capacity") idx->slot[0].cand_cap = idx->slot[1].cand_cap = 0;
+    if (n == "cand_capacity") idx->slot[0].cap_q = idx->slot[1].cap_q = 0;
     return QADC_OK;
 }
 

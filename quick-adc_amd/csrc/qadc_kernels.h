@@ -17,20 +17,25 @@ struct ScanItem {
     uint32_t table;          // table index: qtables + table * M * 16
     uint32_t query;          // per-query state index
     uint32_t order;          // (level << 16) | assign slot: scan-order major key of emitted entries
+    uint32_t dup_pos;        // position (in the partition) of the code the reference replays in its padding
+                             // lanes, if this run's partition end is held here; else 0xffffffff
+    uint32_t dup_reps;       // number of extra replays of that code: (16 - n % 16) % 16
 };
 
 // Candidate emitted by the scan: value < bound derived from a strict prefix of the scan order.
 struct Cand {
-    uint32_t order;  // ScanItem::order
+    uint32_t order;  // ScanItem::order | (extra replays << 20)
     uint32_t pos;    // position inside the partition
     uint32_t key;    // label, or key_base + pos
-    uint32_t qv;     // (query << 8) | int8 distance sum (0..126)
+    uint32_t val;    // int8 distance sum (0..126)
 };
 
-// Batch-wide append buffer header (one per in-flight batch).
+constexpr uint32_t kSortCap = 16384;   // candidates per query the device sort handles (LDS: 16384 x 8 B)
+
+// Batch-wide flags (one per in-flight batch).
 struct CandHeader {
-    uint32_t count;     // entries appended (may exceed the capacity: then `overflow` > 0)
-    uint32_t overflow;  // entries dropped because the buffer was full
+    uint32_t overflow;      // candidates dropped because some query's region was full
+    uint32_t out_overflow;  // sorted entries that did not fit the sorted output buffer
     uint32_t pad[2];
 };
 
@@ -39,9 +44,10 @@ constexpr int kMaxLevels = 8;   // bound levels per query
 // Per-query device state.  hist[l][v] counts the candidates of value v emitted by level l.
 struct QueryState {
     uint32_t hist[kMaxLevels * 128];
-    uint32_t count;     // candidates this query emitted (diagnostic)
-    uint32_t overflow;  // unused (kept for layout stability)
-    uint32_t flags;     // bit0: qmax > 1e30 (reference would exit), bit1: negative table entries clamped
+    uint32_t count;     // candidates this query emitted (slots requested in its region)
+    uint32_t reps;      // extra padding-lane replays among them
+    uint32_t flags;     // bit0: qmax > 1e30 (reference would exit), bit1: negative table entries clamped,
+                        // bit2: candidates sorted into scan order on the device
     float qmin;
     float qmax;
     uint32_t sel_prefix;  // radix-select running prefix (in key - sel_min space)
@@ -49,7 +55,8 @@ struct QueryState {
     uint32_t sel_hi;      // bits [sel_hi, 32) of (key - sel_min) are already fixed to sel_prefix
     uint32_t sel_nmin;    // ~min(key) over the query's pre-scan values (atomicMax of ~key; 0 = none)
     uint32_t sel_max;     // max(key)
-    uint32_t pad[3];
+    uint32_t out_off;     // first entry of this query in the sorted output (valid with flags bit2)
+    uint32_t pad[2];
 };
 
 // Float ADC item for the "starts" pre-scan (scanner_4::query_scan_start).
@@ -63,7 +70,14 @@ struct StartItem {
 
 void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int wgs_per_item,
                     const int8_t* d_qtables, QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands,
-                    uint32_t cand_cap, uint32_t R, hipStream_t stream);
+                    uint32_t cap_per_query, uint32_t R, hipStream_t stream);
+
+// One workgroup per query: bitonic sort of the query's candidates into scan order (level, assign slot,
+// position), padding-lane replays expanded, written compactly to d_out_keys / d_out_vals at the prefix
+// offset of the query.  Queries with more than kSortCap candidates (or an overflowed region) are left
+// to the host (flags bit2 stays clear).
+void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, uint32_t* d_out_keys,
+                       int8_t* d_out_vals, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream);
 
 void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item,
                            const float* d_ftables, float* d_fc, uint64_t fc_stride, QueryState* d_qs,

@@ -101,21 +101,22 @@ __device__ __forceinline__ uint32_t prefix_bound(const QueryState* qs, int level
     return *lds_bound;
 }
 
-__device__ __noinline__ void emit_candidate(QueryState* qs, CandHeader* hdr, Cand* __restrict__ out, uint32_t cap,
+__device__ __noinline__ void emit_candidate(QueryState* qs, CandHeader* hdr, Cand* __restrict__ region, uint32_t cap,
                                             const uint32_t* __restrict__ labels, uint32_t key_base, uint32_t order,
-                                            uint32_t query, uint32_t pos, uint32_t val) {
-    const uint32_t slot = atomicAdd(&hdr->count, 1u);
+                                            uint32_t dup_pos, uint32_t dup_reps, uint32_t pos, uint32_t val) {
+    const uint32_t reps = pos == dup_pos ? dup_reps : 0u;
+    const uint32_t slot = atomicAdd(&qs->count, 1u);
     if (slot < cap) {
         Cand c;
-        c.order = order;
+        c.order = order | (reps << 20);
         c.pos = pos;
         c.key = labels ? labels[pos] : key_base + pos;
-        c.qv = (query << 8) | val;
-        out[slot] = c;
+        c.val = val;
+        region[slot] = c;
     } else {
         atomicAdd(&hdr->overflow, 1u);
     }
-    atomicAdd(&qs->count, 1u);
+    if (reps) atomicAdd(&qs->reps, reps);
     atomicAdd(&qs->hist[(order >> 16) * 128 + val], 1u);
 }
 
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
     using C = ScanCfg<M>;
     const ScanItem it = items[blockIdx.y];
     QueryState* qs = qstates + it.query;
+    out += (uint64_t)it.query * cand_cap;                       // this query's candidate region
 
     build_pair_tables<M>(qtables + (uint64_t)it.table * (M * 16));
     const uint32_t bound = prefix_bound(qs, it.order >> 16, R, reinterpret_cast<uint32_t*>(smem + C::HIST_OFF),
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
 #pragma unroll
                 for (int c = 0; c < C::CPL; ++c)
                     if (cand[u * C::CPL + c] < bound)
-                        emit_candidate(qs, hdr, out, cand_cap, it.labels, it.key_base, it.order, it.query,
+                        emit_candidate(qs, hdr, out, cand_cap, it.labels, it.key_base, it.order, it.dup_pos, it.dup_reps,
                                        it.pos0 + e[u] * C::CPL + c, cand[u * C::CPL + c]);
         }
     };
@@ -274,6 +276,97 @@ void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int
 #undef QADC_DISPATCH_U
 #undef QADC_V
 #undef QADC_ARGS
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-side ordering of the candidates: the host replay needs them in scan order.
+// key = (level:3 | assign slot:15) << 46 | position << 14 | index in the query's region.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict__ qstates, const Cand* __restrict__ cands,
+                                                          uint32_t cap, int nq, uint32_t* __restrict__ out_keys,
+                                                          int8_t* __restrict__ out_vals, uint32_t out_cap,
+                                                          CandHeader* __restrict__ hdr) {
+    // all LDS in the dynamic region (keeps the 8-byte key array naturally aligned)
+    uint64_t* lkey = reinterpret_cast<uint64_t*>(smem);
+    uint32_t* scan = reinterpret_cast<uint32_t*>(smem + kSortCap * 8);
+    uint32_t& s_off = scan[1024];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    QueryState* qs = qstates + q;
+    const uint32_t n = qs->count;
+    const uint32_t limit = min(cap, kSortCap);
+    if (n > limit) return;                                       // host sorts this query's region
+    // offset of this query in the compact output = candidates (+ replays) of the device-sorted queries before it
+    uint32_t part = 0;
+    for (int p = tid; p < q; p += 1024) {
+        const uint32_t c = qstates[p].count;
+        if (c <= limit) part += c + qstates[p].reps;
+    }
+    scan[tid] = part;
+    __syncthreads();
+    for (int d = 512; d >= 1; d >>= 1) {
+        if (tid < d) scan[tid] += scan[tid + d];
+        __syncthreads();
+    }
+    if (tid == 0) s_off = scan[0];
+    __syncthreads();
+    const uint32_t off = s_off;
+    __syncthreads();
+    uint32_t n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    const Cand* __restrict__ region = cands + (uint64_t)q * cap;
+    for (uint32_t i = tid; i < n2; i += 1024) {
+        uint64_t k = ~0ull;
+        if (i < n) {
+            const Cand c = region[i];
+            const uint64_t ord = ((uint64_t)((c.order >> 16) & 7u) << 15) | (c.order & 0x7fffu);
+            k = (ord << 46) | ((uint64_t)c.pos << 14) | i;
+        }
+        lkey[i] = k;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < n2; i += 1024) {
+                const uint32_t p = i ^ j;
+                if (p > i) {
+                    const uint64_t a = lkey[i], b = lkey[p];
+                    if ((a > b) == ((i & k) == 0)) { lkey[i] = b; lkey[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // expand padding-lane replays while writing: thread t owns sorted entries [t*chunk, (t+1)*chunk)
+    const uint32_t chunk = (n2 + 1023) / 1024;
+    const uint32_t b0 = min(n, tid * chunk), b1 = min(n, (tid + 1) * chunk);
+    uint32_t myreps = 0;
+    for (uint32_t i = b0; i < b1; ++i) myreps += (region[lkey[i] & 0x3fffu].order >> 20) & 15u;
+    scan[tid] = myreps;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t o = tid >= d ? scan[tid - d] : 0;
+        __syncthreads();
+        scan[tid] += o;
+        __syncthreads();
+    }
+    uint32_t w = off + b0 + (scan[tid] - myreps);
+    for (uint32_t i = b0; i < b1; ++i) {
+        const Cand c = region[lkey[i] & 0x3fffu];
+        const uint32_t reps = 1u + ((c.order >> 20) & 15u);
+        for (uint32_t r = 0; r < reps; ++r, ++w) {
+            if (w < out_cap) { out_keys[w] = c.key; out_vals[w] = (int8_t)c.val; }
+            else atomicAdd(&hdr->out_overflow, 1u);
+        }
+    }
+    if (tid == 0) { qs->out_off = off; qs->flags |= 4u; }
+}
+
+void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, uint32_t* d_out_keys,
+                       int8_t* d_out_vals, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream) {
+    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_cands_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 8 + 4112), true);
+    (void)once;
+    hipLaunchKernelGGL(sort_cands_kernel, dim3(nq), dim3(1024), kSortCap * 8 + 4112, stream, d_qs, d_cands, cap_per_query, nq,
+                       d_out_keys, d_out_vals, out_cap, d_hdr);
 }
 
 // All candidate values (diagnostic; used by parity tests and checksums at full size).

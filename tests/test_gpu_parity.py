@@ -232,3 +232,22 @@ def test_kernel_tuning_variants_are_exact(pyqadc, po, M, variant):
             want = po.scan_i8(M, [parts[p] for p in order], None, qt[q], 100)
             assert heaps_equal(got[q], want), (M, variant, wgs, q)
     idx.close()
+
+
+def test_host_sort_fallback_when_a_query_has_too_many_candidates(pyqadc, po):
+    """One query emits far more than the device sort handles (all-zero tables + a huge first level):
+    its region is regrown and sorted on the host; the other query stays on the device-sorted path."""
+    rng = np.random.default_rng(12)
+    codes = rand_codes(rng, 150001, 16)
+    idx = pyqadc.Index(16)
+    idx.add_partitions([codes])
+    idx.finalize(0.01)
+    idx.set_option("level_base", 1 << 20)
+    idx.set_option("profile", 1)
+    qt = rand_qtables(rng, (2, 1), 16, 30)
+    qt[0] = 0                                             # every code ties at 0 and is emitted by level 0
+    got = idx.scan_i8(np.zeros((2, 1), np.int32), qt, 100)
+    assert idx.profile()["regrows"] >= 1
+    for q in range(2):
+        assert heaps_equal(got[q], po.scan_i8(16, [codes], None, qt[q], 100)), q
+    idx.close()
