@@ -169,14 +169,20 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
  * Enabled with qadc_set_option(idx, "profile", 1).  Totals since the last reset.
  * ------------------------------------------------------------------------------------------- */
 typedef struct qadc_profile {
-    uint64_t scan_launches;   /* launches of the int8 scan kernel */
+    uint64_t scan_launches;   /* launches of the streaming int8 scan kernel (scan_i8_kernel) */
     uint64_t scan_codes;      /* codes those launches scanned (algorithmic bytes = codes * M/2) */
     double scan_ms;           /* sum of their HIP-event durations */
+    uint64_t small_launches;  /* launches of the small-run int8 scan kernel (scan_i8_small_kernel) */
+    uint64_t small_codes;
+    double small_ms;
     uint64_t start_codes;     /* codes scanned by the float pre-scan */
     double start_ms;          /* float pre-scan + select + quantize, HIP-event duration */
     uint64_t candidates;      /* candidates returned by the device (before padding duplicates) */
     uint64_t regrows;         /* batches re-run because the candidate buffer overflowed */
-    double host_replay_ms;    /* host sort + replay wall time */
+    double host_replay_ms;    /* host wall time assembling the ordered candidate streams */
+    double host_plan_ms;      /* host wall time planning + enqueueing batches */
+    double host_heap_ms;      /* host wall time replaying streams through the heap */
+    uint64_t host_sorted_queries; /* queries whose candidates the host had to sort (> 16384 candidates) */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

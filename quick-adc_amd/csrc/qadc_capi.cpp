@@ -100,6 +100,7 @@ struct LevelLaunch {
     int nitems;
     int wgs;
     uint64_t codes;
+    bool small;     // small-run kernel (runs below idx->small_run codes)
 };
 
 struct Slot {
@@ -165,6 +166,7 @@ struct qadc_index {
     uint64_t level_base = 1024;
     uint64_t level_growth = 16;
     int wgs_per_item = 0;  // 0 = auto
+    uint32_t small_run = 1u << 17;  // runs shorter than this use the small-run kernel
     int variant = 0x0e;    // kernel tuning variant (see launch_scan_i8): U=4, non-temporal loads, chunked tiles
     bool profile = false;
     Slot slot[2];
@@ -199,7 +201,15 @@ void level_bounds(const qadc_index* idx, uint64_t* L) {
     L[kMaxLevels] = UINT64_MAX;
 }
 
+struct ScopedMs {
+    double& acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit ScopedMs(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~ScopedMs() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 int plan_and_launch(qadc_index* idx, Slot& s) {
+    ScopedMs timer(idx->prof.host_plan_ms);
     const int M = idx->M, cs = idx->cs, nq = s.nq, ma = s.ma;
     const uint32_t cpl = 16 / cs;
     hipStream_t st = idx->stream;
@@ -275,20 +285,28 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     const int wgs_cap = idx->wgs_per_item > 0 ? idx->wgs_per_item : (M == 16 ? 512 : 256);
     for (int k = 0; k < kMaxLevels; ++k) {
         if (per_level[k].empty()) continue;
-        uint64_t maxn = 0, codes = 0;
-        for (auto& it : per_level[k]) {
-            maxn = std::max<uint64_t>(maxn, it.n);
-            codes += it.n;
+        // one launch for the short runs of the level, one for the long ones
+        for (int small = 1; small >= 0; --small) {
+            uint64_t maxn = 0, codes = 0;
+            size_t cnt = 0;
+            for (auto& it : per_level[k]) {
+                if ((it.n < idx->small_run) != (small == 1)) continue;
+                s.h_items.p[off + cnt++] = it;
+                maxn = std::max<uint64_t>(maxn, it.n);
+                codes += it.n;
+            }
+            if (!cnt) continue;
+            const uint64_t nvec = (maxn + cpl - 1) / cpl;
+            LevelLaunch ll;
+            ll.first = off;
+            ll.nitems = (int)cnt;
+            ll.small = small == 1;
+            if (ll.small) ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + 8191) / 8192, 1), 64);
+            else ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + 16383) / 16384, 1), (uint64_t)wgs_cap);
+            ll.codes = codes;
+            s.launches.push_back(ll);
+            off += cnt;
         }
-        std::memcpy(s.h_items.p + off, per_level[k].data(), per_level[k].size() * sizeof(ScanItem));
-        const uint64_t nvec = (maxn + cpl - 1) / cpl;
-        LevelLaunch ll;
-        ll.first = off;
-        ll.nitems = (int)per_level[k].size();
-        ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + 2047) / 2048, 1), (uint64_t)wgs_cap);
-        ll.codes = codes;
-        s.launches.push_back(ll);
-        off += per_level[k].size();
     }
 
     // ---- upload -----------------------------------------------------------------------------
@@ -340,8 +358,12 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     // ---- scan levels ------------------------------------------------------------------------
     for (auto& ll : s.launches) {
         if (idx->profile) HIPCHECK(prof_event(s, st));
-        launch_scan_i8(M, idx->variant, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p, s.d_cands.p,
-                       s.cap_q, (uint32_t)s.R, st);
+        if (ll.small)
+            launch_scan_i8_small(M, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p, s.d_cands.p,
+                                 s.cap_q, (uint32_t)s.R, st);
+        else
+            launch_scan_i8(M, idx->variant, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p,
+                           s.d_cands.p, s.cap_q, (uint32_t)s.R, st);
         if (idx->profile) HIPCHECK(prof_event(s, st));
     }
     launch_sort_cands(s.d_qs.p, s.d_cands.p, s.cap_q, nq, s.d_out_keys.p, s.d_out_vals.p, s.out_cap, s.d_hdr.p, st);
@@ -446,9 +468,15 @@ int collect_common(qadc_index* idx, int slot_i) {
         }
         for (size_t i = 0; i < s.launches.size() && 3 + 2 * i < s.prof_used; ++i) {
             HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[2 + 2 * i], s.prof_ev[3 + 2 * i]));
-            idx->prof.scan_ms += ms;
-            idx->prof.scan_launches++;
-            idx->prof.scan_codes += s.launches[i].codes;
+            if (s.launches[i].small) {
+                idx->prof.small_ms += ms;
+                idx->prof.small_launches++;
+                idx->prof.small_codes += s.launches[i].codes;
+            } else {
+                idx->prof.scan_ms += ms;
+                idx->prof.scan_launches++;
+                idx->prof.scan_codes += s.launches[i].codes;
+            }
         }
         if (s.float_path) idx->prof.start_codes += s.start_codes;
     }
@@ -467,6 +495,7 @@ int collect_common(qadc_index* idx, int slot_i) {
             continue;
         }
         // host fallback: fetch the raw region, sort by (level, assign slot, position), expand replays
+        idx->prof.host_sorted_queries++;
         HIPCHECK(s.h_cands.ensure(qs.count));
         HIPCHECK(hipMemcpyAsync(s.h_cands.p, s.d_cands.p + (size_t)q * s.cap_q, sizeof(Cand) * qs.count,
                                 hipMemcpyDeviceToHost, idx->copy_stream));
@@ -505,8 +534,8 @@ void finish_float_outputs(qadc_index* idx, Slot& s, int32_t* status, float* qmin
     }
 }
 
-int replay_outputs(Slot& s, uint32_t* keys, int8_t* values, int32_t* sizes, const int32_t* status) {
-    const auto t0 = std::chrono::steady_clock::now();
+int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int32_t* sizes, const int32_t* status) {
+    ScopedMs timer(idx->prof.host_heap_ms);
     kv_heap<uint32_t, int8_t> bh(s.R);
     for (int q = 0; q < s.nq; ++q) {
         bh.reset();
@@ -520,7 +549,6 @@ int replay_outputs(Slot& s, uint32_t* keys, int8_t* values, int32_t* sizes, cons
         if (keys) std::memcpy(keys + (size_t)q * s.R, bh.keys(), sizeof(uint32_t) * bh.size());
         if (values) std::memcpy(values + (size_t)q * s.R, bh.values(), bh.size());
     }
-    (void)t0;
     return QADC_OK;
 }
 
@@ -780,6 +808,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "level_growth") idx->level_growth = (uint64_t)std::max(2.0, value);
     else if (n == "wgs_per_item") idx->wgs_per_item = (int)value;
     else if (n == "variant") idx->variant = (int)value;
+    else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
     else if (n == "profile") idx->profile = value != 0;
     else return fail(QADC_E_ARG, "unknown option: " + n);
     if (n == "cand_capacity") idx->slot[0].cap_q = idx->slot[1].cap_q = 0;
@@ -815,7 +844,7 @@ int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* v
                                 idx->copy_stream));
         HIPCHECK(hipStreamSynchronize(idx->copy_stream));
     }
-    return replay_outputs(s, keys, values, sizes, status);
+    return replay_outputs(idx, s, keys, values, sizes, status);
 }
 
 static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals, uint64_t* offsets);
@@ -866,7 +895,7 @@ int qadc_scan_i8(qadc_index* idx, int nq, int ma, const int32_t* assign, const i
     if (!qtables) return fail(QADC_E_ARG, "qtables is null");
     if (int rc = submit_common(idx, 0, nq, ma, assign, nullptr, qtables, R)) return rc;
     if (int rc = collect_common(idx, 0)) return rc;
-    return replay_outputs(idx->slot[0], keys, values, sizes, nullptr);
+    return replay_outputs(idx, idx->slot[0], keys, values, sizes, nullptr);
 }
 
 int qadc_scan_i8_candidates(qadc_index* idx, int nq, int ma, const int32_t* assign, const int8_t* qtables, int R,

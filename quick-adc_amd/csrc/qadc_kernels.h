@@ -72,6 +72,11 @@ void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int
                     const int8_t* d_qtables, QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands,
                     uint32_t cap_per_query, uint32_t R, hipStream_t stream);
 
+// Small-run variant of the scan (256-thread workgroups, unreplicated tables): IVF partitions, early levels.
+void launch_scan_i8_small(int M, const ScanItem* d_items, int nitems, int wgs_per_item, const int8_t* d_qtables,
+                          QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cap_per_query, uint32_t R,
+                          hipStream_t stream);
+
 // One workgroup per query: bitonic sort of the query's candidates into scan order (level, assign slot,
 // position), padding-lane replays expanded, written compactly to d_out_keys / d_out_vals at the prefix
 // offset of the query.  Queries with more than kSortCap candidates (or an overflowed region) are left

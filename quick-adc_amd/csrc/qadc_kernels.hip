@@ -236,6 +236,89 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-run variant (IVF partitions, early bound levels): same pair-fused lookup, but the byte tables
+// are NOT bank-replicated — 2 KiB (16x4) / 4 KiB (32x4) of LDS and a trivial build, 256-thread
+// workgroups, so many workgroups per CU overlap their item/table/histogram fetch latencies.  A table
+// spans 64 dwords = 2 per bank, so a lookup is at worst a 2-way bank conflict; that costs LDS cycles
+// the streaming kernel cannot afford at 6 TB/s but a run of a few 10^4 codes is latency-bound anyway.
+// ---------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void scan_i8_small_kernel(const ScanItem* __restrict__ items,
+                                                            const int8_t* __restrict__ qtables,
+                                                            QueryState* __restrict__ qstates, CandHeader* __restrict__ hdr,
+                                                            Cand* __restrict__ out, uint32_t cand_cap, uint32_t R) {
+    constexpr int CS = M / 2, DW = M / 8, CPL = 16 / CS;
+    __shared__ __attribute__((aligned(16))) unsigned char ptab[CS * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char tq[M * 16];
+    __shared__ uint32_t lhist[128];
+    __shared__ uint32_t lbound;
+    const ScanItem it = items[blockIdx.y];
+    QueryState* qs = qstates + it.query;
+    out += (uint64_t)it.query * cand_cap;
+    const uint32_t tid = threadIdx.x;
+    if (tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] =
+        reinterpret_cast<const uint32_t*>(qtables + (uint64_t)it.table * (M * 16))[tid];
+    __syncthreads();
+    for (int e = tid; e < CS * 256; e += 256) {
+        const int b = e >> 8, x = e & 255;
+        ptab[e] = (unsigned char)(tq[(2 * b) * 16 + (x & 15)] + tq[(2 * b + 1) * 16 + (x >> 4)]);
+    }
+    const uint32_t bound = prefix_bound(qs, it.order >> 16, R, lhist, &lbound);   // syncs inside
+
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(it.codes);
+    const uint32_t n = it.n;
+    const uint32_t nvec = (n + CPL - 1) / CPL;
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t e0 = blockIdx.x * 256 + tid; e0 < nvec; e0 += 2 * stride) {
+        u32x4 v[2];
+        uint32_t e[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            e[u] = e0 + u * stride;
+            v[u] = u32x4{0, 0, 0, 0};
+            if (e[u] < nvec) v[u] = __builtin_nontemporal_load(src + e[u]);
+            else e[u] = 0xffffffffu;
+        }
+        uint32_t cand[2 * CPL];
+        uint32_t best = 127u;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                uint32_t sum = 0;
+#pragma unroll
+                for (int b = 0; b < CS; ++b) {
+                    const uint32_t w = d[c * DW + (b >> 2)];
+                    sum += ptab[b * 256 + ((w >> (8 * (b & 3))) & 0xffu)];
+                }
+                const bool live = e[u] != 0xffffffffu && e[u] * CPL + c < n;
+                cand[u * CPL + c] = live ? min(sum, 127u) : 127u;
+                best = min(best, cand[u * CPL + c]);
+            }
+        }
+        if (__builtin_expect(best < bound, 0)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c)
+                    if (cand[u * CPL + c] < bound)
+                        emit_candidate(qs, hdr, out, cand_cap, it.labels, it.key_base, it.order, it.dup_pos, it.dup_reps,
+                                       it.pos0 + e[u] * CPL + c, cand[u * CPL + c]);
+        }
+    }
+}
+
+void launch_scan_i8_small(int M, const ScanItem* d_items, int nitems, int wgs_per_item, const int8_t* d_qtables,
+                          QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cap_per_query, uint32_t R,
+                          hipStream_t stream) {
+    const dim3 grid(wgs_per_item, nitems), block(256);
+    if (M == 16) hipLaunchKernelGGL(scan_i8_small_kernel<16>, grid, block, 0, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cap_per_query, R);
+    else         hipLaunchKernelGGL(scan_i8_small_kernel<32>, grid, block, 0, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cap_per_query, R);
+}
+
 template <int M, int U, bool NT, bool CHUNK, bool PROBE, bool PF>
 static void launch_scan_variant(dim3 grid, hipStream_t stream, const ScanItem* d_items, const int8_t* d_qtables,
                                 QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R) {

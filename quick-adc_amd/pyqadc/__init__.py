@@ -34,8 +34,10 @@ SYMBOLS = [
 
 class Profile(C.Structure):
     _fields_ = [("scan_launches", C.c_uint64), ("scan_codes", C.c_uint64), ("scan_ms", C.c_double),
+                ("small_launches", C.c_uint64), ("small_codes", C.c_uint64), ("small_ms", C.c_double),
                 ("start_codes", C.c_uint64), ("start_ms", C.c_double), ("candidates", C.c_uint64),
-                ("regrows", C.c_uint64), ("host_replay_ms", C.c_double)]
+                ("regrows", C.c_uint64), ("host_replay_ms", C.c_double), ("host_plan_ms", C.c_double),
+                ("host_heap_ms", C.c_double), ("host_sorted_queries", C.c_uint64)]
 
 
 class QadcError(RuntimeError):
