@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../host/qadc_heap.hpp"
@@ -124,12 +125,12 @@ struct Slot {
     DevBuf<ScanItem> d_items;
     DevBuf<StartItem> d_sitems;
     DevBuf<float> d_fc;
-    DevBuf<uint32_t> d_fc_count;
-    DevBuf<uint32_t> d_sel_hist;
+    DevBuf<uint32_t> d_fc_init;
 
     PinBuf<ScanItem> h_items;
     PinBuf<StartItem> h_sitems;
-    PinBuf<uint32_t> h_fc_count;
+    PinBuf<uint32_t> h_fc_init;
+    bool full_prescan = false;          // survivor buffer overflowed: pre-scan everything unfiltered
     PinBuf<float> h_ftables;
     PinBuf<int8_t> h_qtables;
     PinBuf<QueryState> h_qs;
@@ -141,6 +142,7 @@ struct Slot {
     std::vector<LevelLaunch> launches;
     uint64_t start_codes = 0;
     hipEvent_t ev_done = nullptr;
+    hipEvent_t ev_scanned = nullptr;    // last scan level finished (main stream)
     std::vector<hipEvent_t> prof_ev;    // pairs: [2i] before, [2i+1] after; pair 0 = pre-scan chain
     size_t prof_used = 0;
 
@@ -156,6 +158,7 @@ struct qadc_index {
     int M = 16, cs = 8, device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // late D2H of a finished batch must not queue behind the next batch
+    hipStream_t sort_stream = nullptr;  // candidate ordering + result D2H of batch s overlap the kernels of batch s+1
     std::vector<Part> parts;
     int labeled = -1;  // -1 unknown, 0 flat, 1 labels
     bool finalized = false;
@@ -163,9 +166,12 @@ struct qadc_index {
     // options
     int quant_mode = 1;
     uint32_t cand_capacity = kSortCap;  // candidate region entries per query
-    uint64_t level_base = 1024;
-    uint64_t level_growth = 16;
+    uint64_t level_base = 512;
+    uint64_t level_growth = 4;
     int wgs_per_item = 0;  // 0 = auto
+    uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
+    int replay_threads = 0;            // 0 = auto
+    uint32_t small_vec_per_wg = 512;  // 16-byte vectors one small-run workgroup covers
     uint32_t small_run = 1u << 17;  // runs shorter than this use the small-run kernel
     int variant = 0x0e;    // kernel tuning variant (see launch_scan_i8): U=4, non-temporal loads, chunked tiles
     bool profile = false;
@@ -219,13 +225,21 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     uint64_t L[kMaxLevels + 1];
     level_bounds(idx, L);
     std::vector<std::vector<ScanItem>> per_level(kMaxLevels);
-    std::vector<StartItem> sitems;
-    HIPCHECK(s.h_fc_count.ensure(nq));
+    std::vector<StartItem> sitems_a, sitems_b;   // phase A: unfiltered sample, phase B: filtered remainder
+    HIPCHECK(s.h_fc_init.ensure(2 * (size_t)nq));
     uint64_t fc_stride = 1;
     s.start_codes = 0;
     for (int q = 0; q < nq; ++q) {
         uint64_t c = 0;
-        uint32_t soff = 0;
+        uint64_t stotal = 0;
+        if (s.float_path)
+            for (int a = 0; a < ma; ++a) {
+                const int p = s.assign[(size_t)q * ma + a];
+                if (p >= 0 && p < (int)idx->parts.size()) stotal += idx->parts[p].start_n;
+            }
+        // two-phase pre-scan only pays (and is only needed) when the starts are many
+        const uint64_t sample = (s.full_prescan || stotal <= 2ull * idx->prescan_sample) ? stotal : idx->prescan_sample;
+        uint64_t soff = 0;
         for (int a = 0; a < ma; ++a) {
             const int p = s.assign[(size_t)q * ma + a];
             if (p < 0 || p >= (int)idx->parts.size())
@@ -233,13 +247,25 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             const Part& pt = idx->parts[p];
             if (pt.n == 0) continue;  // db_query_4.cpp:291-293
             if (s.float_path) {
+                const uint8_t* sc = pt.d_starts ? pt.d_starts : pt.d_codes;
+                const uint64_t in_a = soff < sample ? std::min<uint64_t>(pt.start_n, sample - soff) : 0;
                 StartItem si;
-                si.codes = pt.d_starts ? pt.d_starts : pt.d_codes;
-                si.n = pt.start_n;
                 si.table = (uint32_t)((size_t)q * ma + a);
                 si.query = (uint32_t)q;
-                si.out_off = soff;
-                sitems.push_back(si);
+                if (in_a) {
+                    si.codes = sc;
+                    si.n = (uint32_t)in_a;
+                    si.out_off = (uint32_t)soff;
+                    si.filter = 0;
+                    sitems_a.push_back(si);
+                }
+                if (in_a < pt.start_n) {
+                    si.codes = sc + in_a * cs;
+                    si.n = (uint32_t)(pt.start_n - in_a);
+                    si.out_off = 0;
+                    si.filter = 1;
+                    sitems_b.push_back(si);
+                }
                 soff += pt.start_n;
                 s.start_codes += pt.start_n;
             }
@@ -273,8 +299,13 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             }
             c += pt.n;
         }
-        s.h_fc_count.p[q] = soff;
-        fc_stride = std::max<uint64_t>(fc_stride, soff);
+        // survivors of the filter: expected R * stotal / sample; 16x head-room, the overflow flag catches the rest
+        uint64_t cap = sample;
+        if (sample < stotal)
+            cap += std::min<uint64_t>(stotal - sample, std::max<uint64_t>(16ull * s.R * ((stotal + sample - 1) / sample), 4096));
+        s.h_fc_init.p[2 * q] = (uint32_t)sample;
+        s.h_fc_init.p[2 * q + 1] = (uint32_t)cap;
+        fc_stride = std::max<uint64_t>(fc_stride, cap);
     }
     size_t nitems = 0;
     for (auto& v : per_level) nitems += v.size();
@@ -301,8 +332,12 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             ll.first = off;
             ll.nitems = (int)cnt;
             ll.small = small == 1;
-            if (ll.small) ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + 8191) / 8192, 1), 64);
-            else ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + 16383) / 16384, 1), (uint64_t)wgs_cap);
+            if (ll.small) {
+                // enough workgroups to fill the chip, but no more: each one pays a table build + bound fetch
+                const uint64_t want = std::max<uint64_t>(1, 4096 / cnt);
+                ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + idx->small_vec_per_wg - 1) / idx->small_vec_per_wg, 1), want);
+            }
+            else ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + 4095) / 4096, 1), (uint64_t)wgs_cap);
             ll.codes = codes;
             s.launches.push_back(ll);
             off += cnt;
@@ -329,22 +364,32 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         HIPCHECK(s.d_ftables.ensure(nt));
         std::memcpy(s.h_ftables.p, s.tables, nt * sizeof(float));
         HIPCHECK(hipMemcpyAsync(s.d_ftables.p, s.h_ftables.p, nt * sizeof(float), hipMemcpyHostToDevice, st));
-        HIPCHECK(s.h_sitems.ensure(sitems.size()));
-        HIPCHECK(s.d_sitems.ensure(sitems.size()));
-        HIPCHECK(s.d_fc_count.ensure(nq));
-        HIPCHECK(s.d_sel_hist.ensure((size_t)nq * 256));
+        const size_t na = sitems_a.size(), nb = sitems_b.size();
+        HIPCHECK(s.h_sitems.ensure(na + nb));
+        HIPCHECK(s.d_sitems.ensure(na + nb));
+        HIPCHECK(s.d_fc_init.ensure(2 * (size_t)nq));
         HIPCHECK(s.d_fc.ensure((size_t)nq * fc_stride));
-        HIPCHECK(hipMemcpyAsync(s.d_fc_count.p, s.h_fc_count.p, nq * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(s.d_fc_init.p, s.h_fc_init.p, 2 * (size_t)nq * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
-        if (!sitems.empty()) {
-            std::memcpy(s.h_sitems.p, sitems.data(), sitems.size() * sizeof(StartItem));
-            HIPCHECK(hipMemcpyAsync(s.d_sitems.p, s.h_sitems.p, sitems.size() * sizeof(StartItem), hipMemcpyHostToDevice, st));
-            uint32_t maxs = 0;
-            for (auto& si : sitems) maxs = std::max(maxs, si.n);
-            const int wgs = (int)std::min<uint32_t>(std::max<uint32_t>((maxs + 4095) / 4096, 1), 512);
-            launch_start_scan_f32(M, s.d_sitems.p, (int)sitems.size(), wgs, s.d_ftables.p, s.d_fc.p, fc_stride, s.d_qs.p, st);
+        launch_prescan_init(s.d_qs.p, s.d_fc_init.p, nq, st);
+        if (na + nb) {
+            if (na) std::memcpy(s.h_sitems.p, sitems_a.data(), na * sizeof(StartItem));
+            if (nb) std::memcpy(s.h_sitems.p + na, sitems_b.data(), nb * sizeof(StartItem));
+            HIPCHECK(hipMemcpyAsync(s.d_sitems.p, s.h_sitems.p, (na + nb) * sizeof(StartItem), hipMemcpyHostToDevice, st));
         }
-        launch_select_kth(s.d_fc.p, fc_stride, s.d_fc_count.p, nq, (uint32_t)s.R, s.d_qs.p, s.d_sel_hist.p, st);
+        auto wgs_for = [](const std::vector<StartItem>& v) {
+            uint32_t maxs = 0;
+            for (auto& si : v) maxs = std::max(maxs, si.n);
+            return (int)std::min<uint32_t>(std::max<uint32_t>((maxs + 4095) / 4096, 1), 512);
+        };
+        // phase A: the sample, unfiltered -> its R-th smallest; phase B: the rest, keeping only values <= that
+        if (na) launch_start_scan_f32(M, s.d_sitems.p, (int)na, wgs_for(sitems_a), s.d_ftables.p, s.d_fc.p, fc_stride, s.d_qs.p, st);
+        // (with a phase B the first select only has to bound the R-th smallest from above: 2 digit passes)
+        launch_select_kth(s.d_fc.p, fc_stride, nq, (uint32_t)s.R, s.d_qs.p, nb ? 2 : 4, st);
+        if (nb) {
+            launch_start_scan_f32(M, s.d_sitems.p + na, (int)nb, wgs_for(sitems_b), s.d_ftables.p, s.d_fc.p, fc_stride, s.d_qs.p, st);
+            launch_select_kth(s.d_fc.p, fc_stride, nq, (uint32_t)s.R, s.d_qs.p, 4, st);
+        }
         launch_quantize(M, ma, nq, s.d_ftables.p, s.d_qtables.p, s.d_qs.p, idx->quant_mode, st);
         if (idx->profile) HIPCHECK(prof_event(s, st));
     } else {
@@ -366,6 +411,13 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                            s.d_cands.p, s.cap_q, (uint32_t)s.R, st);
         if (idx->profile) HIPCHECK(prof_event(s, st));
     }
+    // the ordering pass and the result copies run on a side stream: they only occupy nq CUs, and the main
+    // stream is free to start the next batch's kernels meanwhile (it uses the other slot's buffers)
+    hipStream_t main_st = st;
+    if (!s.ev_scanned) HIPCHECK(hipEventCreateWithFlags(&s.ev_scanned, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(s.ev_scanned, main_st));
+    st = idx->sort_stream;
+    HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
     launch_sort_cands(s.d_qs.p, s.d_cands.p, s.cap_q, nq, s.d_out_keys.p, s.d_out_vals.p, s.out_cap, s.d_hdr.p, st);
     HIPCHECK(hipGetLastError());
 
@@ -389,7 +441,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
     if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
     if (nq <= 0 || ma <= 0 || R <= 0 || !assign) return fail(QADC_E_ARG, "nq, ma, R must be > 0 and assign non-null");
     if (nq >= (1 << 24)) return fail(QADC_E_ARG, "nq must be < 2^24");
-    if (ma >= (1 << 15)) return fail(QADC_E_ARG, "ma must be < 32768");
+    if (ma >= (1 << 14)) return fail(QADC_E_ARG, "ma must be < 16384");
     if (!tables && !qtables) return fail(QADC_E_ARG, "tables is null");
     Slot& s = idx->slot[slot_i];
     if (s.busy) return fail(QADC_E_STATE, "slot still holds an uncollected batch");
@@ -407,6 +459,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
                 return fail(QADC_E_ARG, "int8 tables must lie in [0,127] (QuantizerMAX<int8_t> output, db_query_4.cpp:37-71)");
         s.qtables_in.assign(qtables, qtables + nt);
     }
+    s.full_prescan = false;
     s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
     s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)nq * 8192u, 1ull << 30));
     if (int rc = plan_and_launch(idx, s)) return rc;
@@ -437,7 +490,9 @@ int collect_common(qadc_index* idx, int slot_i) {
         }
         const bool region_overflow = s.h_hdr.p->overflow != 0;
         const bool out_overflow = total_sorted > s.out_cap;
-        if (!region_overflow && !out_overflow) break;
+        bool prescan_overflow = false;
+        for (int q = 0; q < s.nq; ++q) prescan_overflow |= (s.h_qs.p[q].flags & 8u) != 0;
+        if (!region_overflow && !out_overflow && !prescan_overflow) break;
         if (attempt >= 4 || max_count + 64 > (1ull << 31) || total_sorted > (1ull << 31)) {
             s.busy = false;
             return fail(QADC_E_CAPACITY, "candidate buffers overflow persists (adversarial scan order?)");
@@ -445,6 +500,7 @@ int collect_common(qadc_index* idx, int slot_i) {
         // every emitted candidate was counted: size the buffers for all of them and run the batch again
         if (region_overflow) s.cap_q = (uint32_t)std::max<uint64_t>(max_count + 64, (uint64_t)s.cap_q * 2);
         if (out_overflow) s.out_cap = (uint32_t)(total_sorted + total_sorted / 4 + 1024);
+        if (prescan_overflow) s.full_prescan = true;   // adversarially ordered starts: pre-scan all of them unfiltered
         idx->prof.regrows++;
         if (int rc = plan_and_launch(idx, s)) {
             s.busy = false;
@@ -536,18 +592,34 @@ void finish_float_outputs(qadc_index* idx, Slot& s, int32_t* status, float* qmin
 
 int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int32_t* sizes, const int32_t* status) {
     ScopedMs timer(idx->prof.host_heap_ms);
-    kv_heap<uint32_t, int8_t> bh(s.R);
-    for (int q = 0; q < s.nq; ++q) {
-        bh.reset();
-        if (status && status[q]) {
-            if (sizes) sizes[q] = 0;
-            continue;
+    auto work = [&](int q0, int q1) {
+        kv_heap<uint32_t, int8_t> bh(s.R);
+        for (int q = q0; q < q1; ++q) {
+            bh.reset();
+            if (status && status[q]) {
+                if (sizes) sizes[q] = 0;
+                continue;
+            }
+            bh.push(0, 127);  // db_query_4.cpp:276
+            for (uint64_t i = s.out_off[q]; i < s.out_off[q + 1]; ++i) bh.push(s.out_keys[i], s.out_vals[i]);
+            if (sizes) sizes[q] = bh.size();
+            if (keys) std::memcpy(keys + (size_t)q * s.R, bh.keys(), sizeof(uint32_t) * bh.size());
+            if (values) std::memcpy(values + (size_t)q * s.R, bh.values(), bh.size());
         }
-        bh.push(0, 127);  // db_query_4.cpp:276
-        for (uint64_t i = s.out_off[q]; i < s.out_off[q + 1]; ++i) bh.push(s.out_keys[i], s.out_vals[i]);
-        if (sizes) sizes[q] = bh.size();
-        if (keys) std::memcpy(keys + (size_t)q * s.R, bh.keys(), sizeof(uint32_t) * bh.size());
-        if (values) std::memcpy(values + (size_t)q * s.R, bh.values(), bh.size());
+    };
+    // queries are independent: large batches (IVF) are replayed by a few host threads, the caller still
+    // drives the library from one thread
+    const uint64_t pushes = s.out_off[s.nq];
+    int nt = idx->replay_threads > 0 ? idx->replay_threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 8);
+    nt = std::max(1, std::min(nt, s.nq / 16));
+    if (pushes < 200000) nt = 1;
+    if (nt == 1) {
+        work(0, s.nq);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back(work, (int)((int64_t)s.nq * t / nt), (int)((int64_t)s.nq * (t + 1) / nt));
+        for (auto& x : th) x.join();
     }
     return QADC_OK;
 }
@@ -574,6 +646,7 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     idx->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->sort_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete idx;
         return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -586,6 +659,7 @@ int qadc_index_destroy(qadc_index* idx) {
     if (!idx) return QADC_OK;
     (void)hipSetDevice(idx->device);
     (void)hipStreamSynchronize(idx->stream);
+    if (idx->sort_stream) (void)hipStreamSynchronize(idx->sort_stream);
     for (auto& p : idx->parts) {
         if (p.own) {
             if (p.d_codes) (void)hipFree(p.d_codes);
@@ -595,14 +669,16 @@ int qadc_index_destroy(qadc_index* idx) {
     }
     for (auto& s : idx->slot) {
         s.d_ftables.release(); s.d_qtables.release(); s.d_qs.release(); s.d_hdr.release(); s.d_cands.release(); s.d_out_keys.release(); s.d_out_vals.release();
-        s.d_items.release(); s.d_sitems.release(); s.d_fc.release(); s.d_fc_count.release(); s.d_sel_hist.release();
-        s.h_items.release(); s.h_sitems.release(); s.h_fc_count.release(); s.h_ftables.release(); s.h_qtables.release();
+        s.d_items.release(); s.d_sitems.release(); s.d_fc.release(); s.d_fc_init.release();
+        s.h_items.release(); s.h_sitems.release(); s.h_fc_init.release(); s.h_ftables.release(); s.h_qtables.release();
         s.h_qs.release(); s.h_hdr.release(); s.h_cands.release(); s.h_out_keys.release(); s.h_out_vals.release();
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.ev_scanned) (void)hipEventDestroy(s.ev_scanned);
         for (auto e : s.prof_ev) (void)hipEventDestroy(e);
     }
     (void)hipStreamDestroy(idx->stream);
     if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
+    if (idx->sort_stream) (void)hipStreamDestroy(idx->sort_stream);
     delete idx;
     return QADC_OK;
 }
@@ -808,6 +884,9 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "level_growth") idx->level_growth = (uint64_t)std::max(2.0, value);
     else if (n == "wgs_per_item") idx->wgs_per_item = (int)value;
     else if (n == "variant") idx->variant = (int)value;
+    else if (n == "prescan_sample") idx->prescan_sample = (uint32_t)std::max(256.0, value);
+    else if (n == "replay_threads") idx->replay_threads = (int)value;
+    else if (n == "small_vec_per_wg") idx->small_vec_per_wg = (uint32_t)std::max(256.0, value);
     else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
     else if (n == "profile") idx->profile = value != 0;
     else return fail(QADC_E_ARG, "unknown option: " + n);

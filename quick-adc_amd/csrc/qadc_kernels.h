@@ -16,7 +16,7 @@ struct ScanItem {
     uint32_t key_base;       // added to the position when labels == nullptr (shard offset)
     uint32_t table;          // table index: qtables + table * M * 16
     uint32_t query;          // per-query state index
-    uint32_t order;          // (level << 16) | assign slot: scan-order major key of emitted entries
+    uint32_t order;          // (level << 16) | assign slot (< 2^14): scan-order major key of emitted entries
     uint32_t dup_pos;        // position (in the partition) of the code the reference replays in its padding
                              // lanes, if this run's partition end is held here; else 0xffffffff
     uint32_t dup_reps;       // number of extra replays of that code: (16 - n % 16) % 16
@@ -39,7 +39,7 @@ struct CandHeader {
     uint32_t pad[2];
 };
 
-constexpr int kMaxLevels = 8;   // bound levels per query
+constexpr int kMaxLevels = 16;  // bound levels per query
 
 // Per-query device state.  hist[l][v] counts the candidates of value v emitted by level l.
 struct QueryState {
@@ -47,7 +47,8 @@ struct QueryState {
     uint32_t count;     // candidates this query emitted (slots requested in its region)
     uint32_t reps;      // extra padding-lane replays among them
     uint32_t flags;     // bit0: qmax > 1e30 (reference would exit), bit1: negative table entries clamped,
-                        // bit2: candidates sorted into scan order on the device
+                        // bit2: candidates sorted into scan order on the device,
+                        // bit3: pre-scan survivor buffer overflowed (host re-runs the batch unfiltered)
     float qmin;
     float qmax;
     uint32_t sel_prefix;  // radix-select running prefix (in key - sel_min space)
@@ -56,7 +57,8 @@ struct QueryState {
     uint32_t sel_nmin;    // ~min(key) over the query's pre-scan values (atomicMax of ~key; 0 = none)
     uint32_t sel_max;     // max(key)
     uint32_t out_off;     // first entry of this query in the sorted output (valid with flags bit2)
-    uint32_t pad[2];
+    uint32_t fc_n;        // float pre-scan values stored for this query (sample + appended survivors)
+    uint32_t fc_cap;      // capacity of the query's float value buffer
 };
 
 // Float ADC item for the "starts" pre-scan (scanner_4::query_scan_start).
@@ -65,7 +67,8 @@ struct StartItem {
     uint32_t n;            // starts size of that partition
     uint32_t table;        // float table index: ftables + table * M * 16
     uint32_t query;
-    uint32_t out_off;      // offset inside the query's float candidate buffer
+    uint32_t out_off;      // filter == 0: offset inside the query's float value buffer
+    uint32_t filter;       // 1: append only values <= QueryState::qmax (the sample's R-th smallest)
 };
 
 void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int wgs_per_item,
@@ -92,9 +95,13 @@ void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_
 void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,
                        int blocks, hipStream_t stream);
 
-// k-th smallest (k = R) of each query's float candidates -> QueryState::qmax (FLT_MAX if fewer than R).
-void launch_select_kth(float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_count, int nq, uint32_t R,
-                       QueryState* d_qs, uint32_t* d_sel_hist, hipStream_t stream);
+// Sets QueryState::fc_n / fc_cap from init[2*q], init[2*q+1].
+void launch_prescan_init(QueryState* d_qs, const uint32_t* d_init, int nq, hipStream_t stream);
+
+// R-th smallest of each query's stored float values (one workgroup per query) -> QueryState::qmax
+// (FLT_MAX if fewer than R values).
+void launch_select_kth(const float* d_fc, uint64_t fc_stride, int nq, uint32_t R, QueryState* d_qs, int max_passes,
+                       hipStream_t stream);
 
 // QuantizerMAX<int8> for every query: qmin, in-place negative clamp, int8 tables.
 void launch_quantize(int M, int ma, int nq, float* d_ftables, int8_t* d_qtables, QueryState* d_qs,

@@ -363,7 +363,7 @@ void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int
 
 // ---------------------------------------------------------------------------------------------
 // Device-side ordering of the candidates: the host replay needs them in scan order.
-// key = (level:3 | assign slot:15) << 46 | position << 14 | index in the query's region.
+// key = (level:4 | assign slot:14) << 46 | position << 14 | index in the query's region.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict__ qstates, const Cand* __restrict__ cands,
                                                           uint32_t cap, int nq, uint32_t* __restrict__ out_keys,
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
         uint64_t k = ~0ull;
         if (i < n) {
             const Cand c = region[i];
-            const uint64_t ord = ((uint64_t)((c.order >> 16) & 7u) << 15) | (c.order & 0x7fffu);
+            const uint64_t ord = ((uint64_t)((c.order >> 16) & 15u) << 14) | (c.order & 0x3fffu);
             k = (ord << 46) | ((uint64_t)c.pos << 14) | i;
         }
         lkey[i] = k;
@@ -509,34 +509,75 @@ template <int M>
 __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __restrict__ items,
                                                              const float* __restrict__ ftables, float* __restrict__ fc,
                                                              uint64_t fc_stride, QueryState* __restrict__ qstates) {
+    constexpr int kStage = 1024;                             // survivors staged in LDS per workgroup
     __shared__ float tab[M * 16];
+    __shared__ float stage[kStage];
+    __shared__ uint32_t stage_n, stage_base;
+    __shared__ uint32_t red[8];
     const StartItem it = items[blockIdx.y];
     const float* __restrict__ ft = ftables + (uint64_t)it.table * (M * 16);
+    if (threadIdx.x == 0) stage_n = 0;
     for (int i = threadIdx.x; i < M * 16; i += 256) tab[i] = ft[i];
     __syncthreads();
-    float* __restrict__ dst = fc + (uint64_t)it.query * fc_stride + it.out_off;
+    float* __restrict__ dst = fc + (uint64_t)it.query * fc_stride;
+    QueryState* qs = qstates + it.query;
+    const float thr = it.filter ? qs->qmax : 0.0f;           // R-th smallest of the sample (phase A)
+    const uint32_t cap = qs->fc_cap;
     constexpr int DW = M / 8;
     uint32_t kmin = 0xffffffffu, kmax = 0u;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < it.n; i += gridDim.x * 256) {
-        uint32_t d[DW];
-        if constexpr (M == 16) {
-            const uint2 v = reinterpret_cast<const uint2*>(it.codes)[i];
-            d[0] = v.x; d[1] = v.y;
-        } else {
-            const uint4 v = reinterpret_cast<const uint4*>(it.codes)[i];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    const uint32_t stride = gridDim.x * 256;
+    // two codes per lane and iteration: two independent (sequential-order) float sums in flight
+    for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < it.n; i0 += 2 * stride) {
+        uint32_t d[2][DW];
+        bool live[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t i = i0 + u * stride;
+            live[u] = i < it.n;
+#pragma unroll
+            for (int w = 0; w < DW; ++w) d[u][w] = 0;
+            if (live[u]) {
+                if constexpr (M == 16) {
+                    const uint2 v = reinterpret_cast<const uint2*>(it.codes)[i];
+                    d[u][0] = v.x; d[u][1] = v.y;
+                } else {
+                    const uint4 v = reinterpret_cast<const uint4*>(it.codes)[i];
+                    d[u][0] = v.x; d[u][1] = v.y; d[u][2] = v.z; d[u][3] = v.w;
+                }
+            }
         }
-        float cand = 0.0f;
+        // scan_4<M> order: byte by byte, low nibble then high nibble, accumulated from 0 (query_common.hpp:72-80)
+        float cand[2] = {0.0f, 0.0f};
 #pragma unroll
         for (int b = 0; b < M / 2; ++b) {
-            const uint32_t byte = (d[b >> 2] >> (8 * (b & 3))) & 0xffu;
-            cand += tab[(2 * b) * 16 + (byte & 15u)];
-            cand += tab[(2 * b + 1) * 16 + (byte >> 4)];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t byte = (d[u][b >> 2] >> (8 * (b & 3))) & 0xffu;
+                cand[u] += tab[(2 * b) * 16 + (byte & 15u)];
+                cand[u] += tab[(2 * b + 1) * 16 + (byte >> 4)];
+            }
         }
-        dst[i] = cand;
-        const uint32_t k = fkey(cand);
-        kmin = min(kmin, k);
-        kmax = max(kmax, k);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!live[u]) continue;
+            if (it.filter) {
+                // a value above the sample's R-th smallest cannot be the R-th smallest of the whole set
+                if (!(cand[u] <= thr)) continue;
+                const uint32_t ls = atomicAdd(&stage_n, 1u);
+                if (ls < kStage) {
+                    stage[ls] = cand[u];
+                } else {                                     // staging full (rare): straight to the query's buffer
+                    const uint32_t slot = atomicAdd(&qs->fc_n, 1u);
+                    if (slot >= cap) { atomicOr(&qs->flags, 8u); continue; }
+                    dst[slot] = cand[u];
+                }
+            } else {
+                dst[it.out_off + i0 + u * stride] = cand[u];
+            }
+            const uint32_t k = fkey(cand[u]);
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+        }
     }
     // key range of the query's pre-scan values: lets the radix select skip the constant leading bits
 #pragma unroll
@@ -544,15 +585,24 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
         kmin = min(kmin, (uint32_t)__shfl_xor(kmin, d, 64));
         kmax = max(kmax, (uint32_t)__shfl_xor(kmax, d, 64));
     }
-    __shared__ uint32_t red[8];
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = kmin; red[4 + (threadIdx.x >> 6)] = kmax; }
     __syncthreads();
-    if (threadIdx.x == 0) {                                  // one atomic pair per workgroup
+    const uint32_t ns = min(stage_n, (uint32_t)kStage);
+    if (threadIdx.x == 0) {                                  // one atomic set per workgroup
         kmin = min(min(red[0], red[1]), min(red[2], red[3]));
         kmax = max(max(red[4], red[5]), max(red[6], red[7]));
         if (kmin <= kmax) {
-            atomicMax(&qstates[it.query].sel_nmin, ~kmin);
-            atomicMax(&qstates[it.query].sel_max, kmax);
+            atomicMax(&qs->sel_nmin, ~kmin);
+            atomicMax(&qs->sel_max, kmax);
+        }
+        if (ns) stage_base = atomicAdd(&qs->fc_n, ns);
+    }
+    __syncthreads();
+    if (ns) {
+        const uint32_t base = stage_base;
+        for (uint32_t j = threadIdx.x; j < ns; j += 256) {
+            if (base + j < cap) dst[base + j] = stage[j];
+            else atomicOr(&qs->flags, 8u);
         }
     }
 }
@@ -624,88 +674,82 @@ void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_
 // R-th smallest float per query (= tmp_bh.max() after query_scan_start, db_query_4.cpp:259):
 // 4-pass MSD radix select on the order-preserving u32 image of the floats.
 // ---------------------------------------------------------------------------------------------
-// Select on k' = key - min(key): only the bits below the range's top bit vary, so the first 8-bit digit
-// already spreads the values over the histogram (no single hot LDS bin).
-__global__ void select_init_kernel(QueryState* qs, uint32_t R, uint32_t* sel_hist, int nq) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq) {
-        const uint32_t kmin = ~qs[i].sel_nmin, kmax = qs[i].sel_max;
-        const uint32_t range = kmax >= kmin ? kmax - kmin : 0u;
-        qs[i].sel_prefix = 0;
-        qs[i].sel_k = R;
-        qs[i].sel_hi = range ? 32u - (uint32_t)__clz(range) : 0u;
-    }
-    if (i < nq * 256) sel_hist[i] = 0;
+__global__ void prescan_init_kernel(QueryState* qs, const uint32_t* __restrict__ init, int nq) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) { qs[q].fc_n = init[2 * q]; qs[q].fc_cap = init[2 * q + 1]; }
 }
 
-__global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ fc, uint64_t fc_stride,
-                                                          const uint32_t* __restrict__ counts,
-                                                          const QueryState* __restrict__ qs, uint32_t* __restrict__ sel_hist) {
-    __shared__ uint32_t lh[256];
-    const int q = blockIdx.y;
-    const uint32_t hi = qs[q].sel_hi;
-    if (hi == 0) return;                                   // every remaining bit is decided
-    lh[threadIdx.x] = 0;
+void launch_prescan_init(QueryState* d_qs, const uint32_t* d_init, int nq, hipStream_t stream) {
+    hipLaunchKernelGGL(prescan_init_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, d_qs, d_init, nq);
+}
+
+// MSD radix select, one workgroup per query, on k' = key - min(key): only the bits below the range's
+// top bit vary, so the first 8-bit digit already spreads the values over the LDS histogram.
+// max_passes < 4 stops early and returns the UPPER edge of the digit bin reached: an upper bound of the
+// R-th smallest, good enough (and valid) as the survivor filter of the pre-scan's second phase.
+__global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restrict__ fc, uint64_t fc_stride, uint32_t R,
+                                                          QueryState* __restrict__ qstates, int max_passes) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_k, s_hi;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    QueryState* qs = qstates + q;
+    const uint32_t n = min(qs->fc_n, qs->fc_cap);
+    if (n < R) {                                           // heap never fills: max() stays the FLT_MAX sentinel
+        if (tid == 0) qs->qmax = FLT_MAX;
+        return;
+    }
+    const uint32_t kmin = ~qs->sel_nmin, kmax = qs->sel_max;
+    const uint32_t range = kmax >= kmin ? kmax - kmin : 0u;
+    if (tid == 0) { s_prefix = 0; s_k = R; s_hi = range ? 32u - (uint32_t)__clz(range) : 0u; }
     __syncthreads();
-    const uint32_t n = counts[q];
     const float* __restrict__ src = fc + (uint64_t)q * fc_stride;
-    const uint32_t lo = hi > 8 ? hi - 8 : 0;
-    const uint32_t prefix = qs[q].sel_prefix, kmin = ~qs[q].sel_nmin;
-    const uint32_t dmask = (1u << (hi - lo)) - 1u;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t k = fkey(src[i]) - kmin;
-        const bool match = hi >= 32 || ((k ^ prefix) >> hi) == 0;
-        if (match) atomicAdd(&lh[(k >> lo) & dmask], 1u);
-    }
-    __syncthreads();
-    if (lh[threadIdx.x]) atomicAdd(&sel_hist[q * 256 + threadIdx.x], lh[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void select_pick_kernel(QueryState* __restrict__ qs, uint32_t* __restrict__ sel_hist,
-                                                          const uint32_t* __restrict__ counts, int last_pass, uint32_t R) {
-    __shared__ uint32_t sc[256];
-    const int q = blockIdx.x, t = threadIdx.x;
-    const uint32_t hi = qs[q].sel_hi;
-    const uint32_t c = sel_hist[q * 256 + t];
-    sel_hist[q * 256 + t] = 0;
-    sc[t] = c;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t o = t >= d ? sc[t - d] : 0;
+    for (int pass = 0; pass < max_passes; ++pass) {
+        const uint32_t hi = s_hi, prefix = s_prefix, k = s_k;
+        if (hi == 0) break;
+        const uint32_t lo = hi > 8 ? hi - 8 : 0;
+        const uint32_t dmask = (1u << (hi - lo)) - 1u;
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        sc[t] += o;
+        for (uint32_t i = tid; i < n; i += 1024) {
+            const uint32_t key = fkey(src[i]) - kmin;
+            if (hi >= 32 || ((key ^ prefix) >> hi) == 0) atomicAdd(&hist[(key >> lo) & dmask], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {                                    // wave 0: 4 bins per lane, inclusive scan, pick the digit
+            const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const uint32_t mine = c0 + c1 + c2 + c3;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (tid >= d) incl += o;
+            }
+            const uint32_t excl = incl - mine;
+            if (incl >= k && excl < k) {                   // exactly one lane
+                uint32_t run = excl, digit = 4 * tid;
+                const uint32_t cs[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (run + cs[j] >= k) { digit = 4 * tid + j; break; }
+                    run += cs[j];
+                }
+                s_prefix = prefix | (digit << lo);
+                s_k = k - run;
+                s_hi = lo;
+            }
+        }
         __syncthreads();
     }
-    const uint32_t incl = sc[t], excl = incl - c;
-    const uint32_t k = qs[q].sel_k;
-    const uint32_t kmin = ~qs[q].sel_nmin;
-    __syncthreads();
-    if (counts[q] < R) {
-        if (t == 0 && last_pass) qs[q].qmax = FLT_MAX;     // heap never fills: max() stays the FLT_MAX sentinel
-        return;
-    }
-    if (hi == 0) {                                          // already decided (or all values equal)
-        if (t == 0 && last_pass) qs[q].qmax = funkey(qs[q].sel_prefix + kmin);
-        return;
-    }
-    const uint32_t lo = hi > 8 ? hi - 8 : 0;
-    if (incl >= k && excl < k) {
-        const uint32_t prefix = qs[q].sel_prefix | ((uint32_t)t << lo);
-        qs[q].sel_prefix = prefix;
-        qs[q].sel_k = k - excl;
-        qs[q].sel_hi = lo;
-        if (last_pass) qs[q].qmax = funkey(prefix + kmin);
+    if (tid == 0) {
+        const uint32_t low = s_hi ? ((s_hi >= 32 ? 0u : (1u << s_hi)) - 1u) : 0u;   // undecided bits -> all ones
+        const uint64_t key = (uint64_t)(s_prefix | low) + kmin;
+        qs->qmax = funkey(key > kmax ? kmax : (uint32_t)key);   // never above the largest stored value
     }
 }
 
-void launch_select_kth(float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_count, int nq, uint32_t R, QueryState* d_qs,
-                       uint32_t* d_sel_hist, hipStream_t stream) {
-    hipLaunchKernelGGL(select_init_kernel, dim3((nq * 256 + 255) / 256), dim3(256), 0, stream, d_qs, R, d_sel_hist, nq);
-    for (int pass = 0; pass < 4; ++pass) {
-        hipLaunchKernelGGL(select_hist_kernel, dim3(256, nq), dim3(256), 0, stream, d_fc, fc_stride, d_fc_count, d_qs,
-                           d_sel_hist);
-        hipLaunchKernelGGL(select_pick_kernel, dim3(nq), dim3(256), 0, stream, d_qs, d_sel_hist, d_fc_count, pass == 3, R);
-    }
+void launch_select_kth(const float* d_fc, uint64_t fc_stride, int nq, uint32_t R, QueryState* d_qs, int max_passes,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(select_kth_kernel, dim3(nq), dim3(1024), 0, stream, d_fc, fc_stride, R, d_qs, max_passes);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -746,7 +790,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(int table_dim_all, float*
         else o = (int8_t)(int)(quant_mode == 0 ? (v - qmin) / delta : (v - qmin) * scale);
         qt[i] = o;
     }
-    if (t == 0) { qs[q].qmin = qmin; qs[q].flags = flags; }
+    if (t == 0) { qs[q].qmin = qmin; qs[q].flags |= flags; }   // keeps bit3 set by the pre-scan
 }
 
 void launch_quantize(int M, int ma, int nq, float* d_ftables, int8_t* d_qtables, QueryState* d_qs, int quant_mode,

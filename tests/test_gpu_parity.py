@@ -251,3 +251,49 @@ def test_host_sort_fallback_when_a_query_has_too_many_candidates(pyqadc, po):
     for q in range(2):
         assert heaps_equal(got[q], po.scan_i8(16, [codes], None, qt[q], 100)), q
     idx.close()
+
+
+@pytest.mark.parametrize("M", [16, 32])
+def test_two_phase_prescan_is_exact(pyqadc, po, M):
+    """Starts beyond the sample are filtered by the sample's R-th smallest distance before the select:
+    qmax (and everything downstream) must not change."""
+    rng = np.random.default_rng(21 + M)
+    sizes = [300000, 150000, 90001]
+    parts = [rand_codes(rng, s, M) for s in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts)
+    keep = 0.05                                            # 15000 + 7500 + 4500 starts
+    idx.finalize(keep)
+    idx.set_option("prescan_sample", 1000)
+    nq, ma, R = 4, 3, 100
+    assign = np.stack([rng.permutation(3) for _ in range(nq)]).astype(np.int32)
+    tables = float_tables(rng, nq, ma, M)
+    res = idx.query_scan(assign, tables.copy(), R, want_qtables=True)
+    for q in range(nq):
+        want = po.query_scan(M, parts, None, keep, assign[q], tables[q].copy(), R)
+        assert res["qmax"][q] == np.float32(want["qmax"]) and np.array_equal(res["qtables"][q], want["qtables"])
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"]))
+    idx.close()
+
+
+def test_prescan_survivor_overflow_falls_back_to_full_prescan(pyqadc, po):
+    """Adversarial starts: everything after the sample beats the sample's R-th smallest, so the survivor
+    buffer overflows; the batch is re-run with an unfiltered pre-scan and stays exact."""
+    rng = np.random.default_rng(5)
+    n, M, keep = 2000000, 16, 0.05
+    codes = rand_codes(rng, n, M)
+    codes[4096:100000] = 0                                # starts 4096.. all hit centroid 0 of every sub-quantizer
+    tables = float_tables(rng, 2, 1, M) + np.float32(1.0)
+    tables.reshape(2, M, 16)[:, :, 0] = np.float32(0.001)  # ... which is by far the closest
+    idx = pyqadc.Index(M)
+    idx.add_partitions([codes])
+    idx.finalize(keep)
+    idx.set_option("prescan_sample", 4096)
+    idx.set_option("profile", 1)
+    res = idx.query_scan(np.zeros((2, 1), np.int32), tables.copy(), 100, want_qtables=True)
+    assert idx.profile()["regrows"] >= 1
+    for q in range(2):
+        want = po.query_scan(M, [codes], None, keep, [0], tables[q].copy(), 100)
+        assert res["qmax"][q] == np.float32(want["qmax"])
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"]))
+    idx.close()

@@ -55,8 +55,13 @@ l = biggest(counters("lds"), "SQ_LDS_IDX_ACTIVE")
 cfg = bench["config"]
 cs = cfg["M"] // 2
 # the longest launch is the last bound level: all codes past the previous level boundary, every query of the batch
-level_start = 1024 * 16 ** 4
-codes = (cfg["codes"] - level_start) * cfg["queries_per_step"]
+# bound-level boundaries of the planner (level_base = 512, level_growth = 4, at most 16 levels)
+bounds, b = [0], 512
+while b < cfg["codes"] and len(bounds) < 16:
+    bounds.append(b)
+    b *= 4
+bounds.append(cfg["codes"])
+codes = max(hi - lo for lo, hi in zip(bounds, bounds[1:])) * cfg["queries_per_step"]
 algo = codes * cs
 fetch_bytes = f["FETCH_SIZE"] * 1024 * 2
 write_bytes = w["WRITE_SIZE"] * 1024
