@@ -1,0 +1,232 @@
+// Host-side query driver around a ScannerType — C++14, header only, no GPU code.
+//
+// The pieces of the reference that stay on the host next to the accelerated scan (SURVEY.md §8 rows
+// A9/A10), restated for this repo's stand-alone driver and examples:
+//   pq4            base_pq for 4-bit sub-quantizers: encode + per-query float distance tables
+//                  (quantizers.hpp:96-246, distances.hpp:294-311 "single" form ||x_m - c||^2)
+//   flat_database  flat_db  (databases.hpp:77-167): one partition, key = position
+//   ivf_database   index_db (databases.hpp:176-331): coarse centroids, per-partition codes + labels,
+//                  assign = the ma nearest centroids in ascending distance, residual = x - centroid
+//   nns_engine     per-query sequence assign -> (rotate: none for plain PQ) -> tables -> scanner.query_scan
+//                  with the four phase timers (query_common.hpp:245-309)
+//   process_queries  fresh heap per query, recall = true nearest neighbour among the R returned keys,
+//                  averaged metrics (query_common.hpp:330-368) and the CSV line of db_query_4.cpp:387-390
+// Float results of these feeders are NOT pinned against the reference (its versions go through
+// OpenBLAS / AVX kernels); the scan below them is, and it receives whatever tables they produce.
+#pragma once
+#include <sys/time.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <vector>
+
+namespace qadc {
+
+static inline std::uint64_t ustime() {  // common.hpp:17-21
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);
+    return (std::uint64_t)tv.tv_sec * 1000000 + tv.tv_usec;
+}
+
+struct pq4 {
+    int sq_count;                  // M
+    int sq_bits;                   // 4
+    int dim;
+    std::vector<float> centroids;  // [M][16][sq_dim]
+
+    pq4(int m, int d) : sq_count(m), sq_bits(4), dim(d), centroids((size_t)m * 16 * (d / m)) {}
+    int sq_dim() const { return dim / sq_count; }
+    int code_size() const { return sq_count / 2; }
+    const float* centroid(int m, int c) const { return centroids.data() + ((size_t)m * 16 + c) * sq_dim(); }
+
+    // tables[m][c] = ||x_m - centroid(m,c)||^2
+    void tables(const float* x, float* out) const {
+        const int ds = sq_dim();
+        for (int m = 0; m < sq_count; ++m)
+            for (int c = 0; c < 16; ++c) {
+                const float* ce = centroid(m, c);
+                float s = 0;
+                for (int d = 0; d < ds; ++d) {
+                    const float t = x[m * ds + d] - ce[d];
+                    s += t * t;
+                }
+                out[m * 16 + c] = s;
+            }
+    }
+
+    // nearest centroid per sub-quantizer (first minimum), packed two per byte: even sub-quantizer in the low
+    // nibble, odd one in the high nibble of byte m/2 (multiple_set_bits_4, quantizers.hpp:49-68)
+    void encode(const float* vecs, size_t n, std::uint8_t* codes) const {
+        const int ds = sq_dim(), cs = code_size();
+        std::vector<float> t((size_t)sq_count * 16);
+        for (size_t i = 0; i < n; ++i) {
+            tables(vecs + i * dim, t.data());
+            std::uint8_t* code = codes + i * cs;
+            for (int m = 0; m < sq_count; ++m) {
+                int best = 0;
+                for (int c = 1; c < 16; ++c)
+                    if (t[m * 16 + c] < t[m * 16 + best]) best = c;
+                if (m % 2 == 0) code[m / 2] = (std::uint8_t)best;
+                else code[m / 2] = (std::uint8_t)(code[m / 2] | (best << 4));
+            }
+        }
+        (void)ds;
+    }
+};
+
+struct flat_database {
+    std::unique_ptr<pq4> pq;
+    std::vector<std::uint8_t> codes;
+    unsigned count = 0;
+
+    void add_vectors(const float* vecs, unsigned n) {
+        codes.resize((size_t)(count + n) * pq->code_size());
+        pq->encode(vecs, n, codes.data() + (size_t)count * pq->code_size());
+        count += n;
+    }
+    int partition_count() const { return 1; }
+    void get_partition(int, const std::uint8_t*& c, unsigned*& labels, unsigned& size) {
+        c = codes.data();
+        labels = nullptr;
+        size = count;
+    }
+    void free_partition(int) { std::vector<std::uint8_t>().swap(codes); }
+    void assign_compute_residuals(const float* x, int ma, int* assign, float* residuals) const {
+        for (int a = 0; a < ma; ++a) {  // databases.hpp:93-101
+            assign[a] = 0;
+            std::memcpy(residuals + (size_t)a * pq->dim, x, sizeof(float) * pq->dim);
+        }
+    }
+};
+
+struct ivf_database {
+    std::unique_ptr<pq4> pq;
+    int part_count;
+    std::vector<float> coarse;  // [K][dim]
+    std::vector<std::vector<std::uint8_t>> partitions;
+    std::vector<std::vector<unsigned>> labels;
+
+    ivf_database(std::unique_ptr<pq4> p, int k, std::vector<float> c)
+        : pq(std::move(p)), part_count(k), coarse(std::move(c)), partitions(k), labels(k) {}
+
+    float dist2(const float* x, int k) const {
+        const float* c = coarse.data() + (size_t)k * pq->dim;
+        float s = 0;
+        for (int d = 0; d < pq->dim; ++d) {
+            const float t = x[d] - c[d];
+            s += t * t;
+        }
+        return s;
+    }
+    // the ma nearest coarse centroids, ascending by distance (find_k_neighbors + heap sort, neighbors.cpp:30-76)
+    void nearest(const float* x, int ma, int* out) const {
+        std::vector<std::pair<float, int>> d(part_count);
+        for (int k = 0; k < part_count; ++k) d[k] = std::make_pair(dist2(x, k), k);
+        std::partial_sort(d.begin(), d.begin() + ma, d.end());
+        for (int a = 0; a < ma; ++a) out[a] = d[a].second;
+    }
+    void add_vectors(const float* vecs, unsigned n, unsigned labels_offset) {  // databases.hpp:270-298
+        std::vector<float> res(pq->dim);
+        std::vector<std::uint8_t> code(pq->code_size());
+        for (unsigned i = 0; i < n; ++i) {
+            const float* x = vecs + (size_t)i * pq->dim;
+            int p;
+            nearest(x, 1, &p);
+            for (int d = 0; d < pq->dim; ++d) res[d] = x[d] - coarse[(size_t)p * pq->dim + d];
+            pq->encode(res.data(), 1, code.data());
+            partitions[p].insert(partitions[p].end(), code.begin(), code.end());
+            labels[p].push_back(i + labels_offset);
+        }
+    }
+    int partition_count() const { return part_count; }
+    void get_partition(int i, const std::uint8_t*& c, unsigned*& l, unsigned& size) {
+        c = partitions[i].data();
+        l = labels[i].data();
+        size = (unsigned)labels[i].size();
+    }
+    void free_partition(int i) {
+        std::vector<std::uint8_t>().swap(partitions[i]);
+        std::vector<unsigned>().swap(labels[i]);
+    }
+    void assign_compute_residuals(const float* x, int ma, int* assign, float* residuals) const {  // databases.hpp:201-211
+        nearest(x, ma, assign);
+        for (int a = 0; a < ma; ++a)
+            for (int d = 0; d < pq->dim; ++d)
+                residuals[(size_t)a * pq->dim + d] = x[d] - coarse[(size_t)assign[a] * pq->dim + d];
+    }
+};
+
+struct query_metrics {  // query_common.hpp:21-56
+    std::uint64_t index_us = 0, rotate_us = 0, table_us = 0, scan_us = 0;
+    query_metrics& operator+=(const query_metrics& o) {
+        index_us += o.index_us; rotate_us += o.rotate_us; table_us += o.table_us; scan_us += o.scan_us;
+        return *this;
+    }
+    query_metrics& operator/=(int f) {
+        index_us /= f; rotate_us /= f; table_us /= f; scan_us /= f;
+        return *this;
+    }
+};
+inline std::ostream& operator<<(std::ostream& os, const query_metrics& m) {
+    return os << m.index_us << "," << m.rotate_us << "," << m.table_us << "," << m.scan_us;
+}
+
+template <typename Db, typename Scanner>
+struct nns_engine {  // query_common.hpp:245-309
+    Db& db;
+    Scanner& scanner;
+    int ma, table_dim;
+    std::vector<float> residuals, dists;
+    std::vector<int> assign;
+    nns_engine(Scanner& s, Db& d, int ma_)
+        : db(d), scanner(s), ma(ma_), table_dim(d.pq->sq_count * 16), residuals((size_t)ma_ * d.pq->dim),
+          dists((size_t)ma_ * d.pq->sq_count * 16), assign(ma_) {}
+    void prepare_database() { scanner.prepare_database(db); }
+    template <typename Heap>
+    void process_query(const float* query, Heap& bh, query_metrics& metrics) {
+        const int dim = db.pq->dim;  // read before free_partition could matter; pq outlives the partitions
+        const std::uint64_t t0 = ustime();
+        db.assign_compute_residuals(query, ma, assign.data(), residuals.data());
+        const std::uint64_t t1 = ustime();  // plain PQ: rotate_multiple_vectors is a no-op
+        const std::uint64_t t2 = ustime();
+        for (int a = 0; a < ma; ++a) db.pq->tables(residuals.data() + (size_t)a * dim, dists.data() + (size_t)a * table_dim);
+        const std::uint64_t t3 = ustime();
+        scanner.query_scan(residuals.data(), assign.data(), ma, dists.data(), table_dim, bh, metrics);
+        metrics.scan_us = ustime() - t3;
+        metrics.table_us = t3 - t2;
+        metrics.rotate_us = t2 - t1;
+        metrics.index_us = t1 - t0;
+    }
+};
+
+// query_common.hpp:330-368.  groundtruth[q] = id of the true nearest neighbour; recall@R counts the queries
+// whose true neighbour is among keys()[0..R) — read unsorted and up to R even if the heap is not full.
+template <typename Engine, typename Heap>
+void process_queries(Engine& engine, const float* queries, int count, int dim, int r, const unsigned* groundtruth,
+                     query_metrics& total_metrics, double& total_recall) {
+    engine.prepare_database();
+    total_metrics = query_metrics();
+    total_recall = 0;
+    for (int q = 0; q < count; ++q) {
+        Heap bh(r);
+        query_metrics metrics;
+        engine.process_query(queries + (size_t)q * dim, bh, metrics);
+        if (bh.size() != r) std::cerr << " WARNING: Binheap not full" << std::endl;
+        const unsigned* k = bh.keys();
+        total_recall += std::find(k, k + bh.size(), groundtruth[q]) != k + bh.size() ? 1 : 0;
+        total_metrics += metrics;
+    }
+    total_metrics /= count;
+    total_recall /= count;
+}
+
+inline void print_csv(std::ostream& os, int r, double recall, int ma, float keep, const query_metrics& m) {
+    os << "r,recall,ma,adc_type,keep,index_us,rotate_us,table_us,scan_us" << std::endl;  // db_query_4.cpp:387-390
+    os << r << "," << recall << "," << ma << ",qadc," << keep << "," << m << std::endl;
+}
+
+}  // namespace qadc

@@ -297,3 +297,34 @@ def test_prescan_survivor_overflow_falls_back_to_full_prescan(pyqadc, po):
         assert res["qmax"][q] == np.float32(want["qmax"])
         assert heaps_equal(res["heaps"][q], (want["keys"], want["values"]))
     idx.close()
+
+
+@pytest.mark.parametrize("M", [16, 32])
+def test_edge_cases_small_r_large_r_repeated_and_empty_partitions(pyqadc, po, M):
+    """R larger than the list (heap never fills, sentinel survives), R = 1, the same partition probed
+    twice, and empty partitions inside assign[] (skipped like db_query_4.cpp:291-293)."""
+    rng = np.random.default_rng(77 + M)
+    sizes = [50, 0, 333, 0, 17]
+    parts = [rand_codes(rng, s, M) for s in sizes]
+    labels = [np.arange(s, dtype=np.uint32) + 1000 * i for i, s in enumerate(sizes)]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(0.5)
+    assign = np.array([[0, 1, 2, 3], [2, 2, 4, 0], [4, 3, 1, 0]], np.int32)
+    for R in (1, 7, 100, 1000):
+        qt = rand_qtables(rng, (3, 4), M, 9)
+        got = idx.scan_i8(assign, qt, R)
+        for q in range(3):
+            ps = [parts[p] for p in assign[q]]
+            ls = [labels[p] for p in assign[q]]
+            want = po.scan_i8(M, ps, ls, qt[q], R)
+            assert heaps_equal(got[q], want), (M, R, q)
+    # full float pipeline with starts taken from every probed partition (keep = 50 %)
+    tables = float_tables(rng, 3, 4, M)
+    res = idx.query_scan(assign, tables.copy(), 100)
+    for q in range(3):
+        want = po.query_scan(M, parts, labels, 0.5, assign[q], tables[q].copy(), 100)
+        assert want["rc"] == res["status"][q]
+        if want["rc"] == 0:
+            assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
+    idx.close()

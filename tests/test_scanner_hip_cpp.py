@@ -55,3 +55,74 @@ def test_scanner_hip_fills_heap_like_oracle(po, M, sizes, labeled, ma):
         line += 1 + size
         assert size == len(want["keys"])
         assert np.array_equal(rows[:, 0].astype(np.uint32), want["keys"]) and np.array_equal(rows[:, 1].astype(np.int8), want["values"])
+
+
+DRIVER = os.path.join(ROOT, "tests", "cpp", "db_query_4_hip")
+
+
+def build_driver():
+    libdir = os.path.join(ROOT, "quick-adc_amd")
+    if not os.path.exists(os.path.join(libdir, "libqadc_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror",
+                           os.path.join(ROOT, "tests", "cpp", "db_query_4_hip.cpp"), "-o", DRIVER,
+                           "-L" + libdir, "-lqadc_hip", "-Wl,-rpath," + libdir])
+
+
+def test_db_query_4_driver_builds_as_cxx14():
+    build_driver()
+    assert os.path.exists(DRIVER)
+
+
+def _parse_dump(path, M, ma, nq):
+    raw = np.fromfile(path, np.uint8)
+    o = 0
+
+    def take(n, dt):
+        nonlocal o
+        a = raw[o:o + n * np.dtype(dt).itemsize].view(dt)
+        o += n * np.dtype(dt).itemsize
+        return a
+
+    nparts = int(take(1, np.int32)[0])
+    parts, labels = [], []
+    for _ in range(nparts):
+        n = int(take(1, np.uint32)[0])
+        labeled = int(take(1, np.int32)[0])
+        parts.append(take(n * (M // 2), np.uint8).reshape(n, M // 2).copy())
+        labels.append(take(n, np.uint32).copy() if labeled else None)
+    queries = []
+    for _ in range(nq):
+        assign = take(ma, np.int32).copy()
+        tables = take(ma * M * 16, np.float32).copy()
+        size = int(take(1, np.int32)[0])
+        keys = take(size, np.uint32).copy()
+        vals = take(size, np.int8).copy()
+        queries.append((assign, tables, keys, vals))
+    assert o == len(raw)
+    return parts, (labels if labels[0] is not None else None), queries
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,M,N,ma,K,keep_pct", [("flat", 16, 60000, 1, 0, 2.0), ("ivf", 16, 60000, 6, 48, 2.0),
+                                                      ("ivf", 32, 30000, 4, 24, 8.0)])
+def test_db_query_4_driver_end_to_end(po, tmp_path, mode, M, N, ma, K, keep_pct):
+    """Real PQ encodings of clustered vectors (tie-heavy int8 sums, labelled IVF partitions of ragged size):
+    the heap every query leaves behind equals the oracle's scanner_4::query_scan on the same inputs; the
+    CSV line has the reference's columns and a sane recall."""
+    build_driver()
+    nq, R = 12, 100
+    dump = str(tmp_path / "dump.bin")
+    out = subprocess.check_output([DRIVER, mode, str(M), str(N), str(nq), str(R), str(keep_pct), str(ma), str(K), "7",
+                                   dump]).decode().strip().split("\n")
+    assert out[-2] == "r,recall,ma,adc_type,keep,index_us,rotate_us,table_us,scan_us"
+    cols = out[-1].split(",")
+    assert int(cols[0]) == R and cols[3] == "qadc" and int(cols[2]) == ma
+    assert 0.5 <= float(cols[1]) <= 1.0          # true nearest neighbour found for most queries
+    parts, labels, queries = _parse_dump(dump, M, ma, nq)
+    keep = float(np.float32(keep_pct) * np.float32(0.01))
+    for q, (assign, tables, keys, vals) in enumerate(queries):
+        want = po.query_scan(M, parts, labels, keep, assign, np.ascontiguousarray(tables.reshape(ma, M * 16)), R)
+        assert want["rc"] == 0
+        assert np.array_equal(keys, want["keys"]) and np.array_equal(vals, want["values"]), (mode, M, q)
