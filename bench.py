@@ -185,7 +185,7 @@ def main():
             "recall_at_100": recall,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "scan_i8_kernel<%d,4,nt,chunk>" % M, "launches": prof["scan_launches"],
+                         "kernel": "scan_i8_kernel<%d,2,nt,chunk>" % M, "launches": prof["scan_launches"],
                          "avg_launch_ms": scan_ms / max(prof["scan_launches"], 1),
                          "algorithmic_bytes_per_launch": prof["scan_codes"] * cs / max(prof["scan_launches"], 1)},
             "phases": {"prescan_quantize_ms_per_step": prof["start_ms"] / args.steps,

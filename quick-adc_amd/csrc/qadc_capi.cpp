@@ -173,7 +173,7 @@ struct qadc_index {
     int replay_threads = 0;            // 0 = auto
     uint32_t small_vec_per_wg = 512;  // 16-byte vectors one small-run workgroup covers
     uint32_t small_run = 1u << 17;  // runs shorter than this use the small-run kernel
-    int variant = 0x0e;    // kernel tuning variant (see launch_scan_i8): U=4, non-temporal loads, chunked tiles
+    int variant = 0x0d;    // kernel tuning variant (see launch_scan_i8): U=2, non-temporal loads, chunked tiles
     bool profile = false;
     Slot slot[2];
     qadc_profile prof{};

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <type_traits>
 
 namespace qadc {
 
@@ -120,6 +121,15 @@ __device__ __noinline__ void emit_candidate(QueryState* qs, CandHeader* hdr, Can
     atomicAdd(&qs->hist[(order >> 16) * 128 + val], 1u);
 }
 
+// The pair tables start at LDS address 0 (these kernels have no static __shared__, so the dynamic
+// region begins there — checked once per workgroup by lds_base_is_zero()); the lookups therefore use
+// ABSOLUTE LDS addresses, which spares one "add the array base" VALU instruction per lookup.
+typedef const __attribute__((address_space(3))) unsigned char* lds_bytes_t;
+
+__device__ __forceinline__ void lds_base_is_zero() {
+    if (reinterpret_cast<uintptr_t>((lds_bytes_t)smem) != 0) __builtin_trap();
+}
+
 template <int M>
 __device__ __forceinline__ uint32_t pair_sum(const uint32_t* d, uint32_t lane_lo, uint32_t lane_hi) {
     uint32_t s = 0;
@@ -130,7 +140,7 @@ __device__ __forceinline__ uint32_t pair_sum(const uint32_t* d, uint32_t lane_lo
         for (int k = 0; k < 4; ++k) {
             // byte0 = bank*4, byte1 = code byte k, byte2 = region bit, byte3 = 0
             const uint32_t a = __builtin_amdgcn_perm(d[w], lo, 0x0c020000u | ((4u + k) << 8));
-            s += smem[a + (w & 1) * 128 + k];
+            s += *reinterpret_cast<lds_bytes_t>(static_cast<uintptr_t>(a + (w & 1) * 128 + k));
         }
     }
     return s;
@@ -156,7 +166,10 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
     const uint32_t lane_lo = (tid & 31u) * 4u;
     const uint32_t lane_hi = lane_lo | 0x10000u;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(it.codes);
+    // codes live in global memory: say so, or the non-temporal builtin falls back to FLAT loads
+    typedef const __attribute__((address_space(1))) u32x4* gvec_t;
+    const gvec_t src = (gvec_t)(uintptr_t)it.codes;
+    lds_base_is_zero();
     const uint32_t n = it.n;
     const uint32_t nvec = (n + C::CPL - 1) / C::CPL;            // 16-byte vectors in the run
     const uint32_t ntiles = (nvec + kWG - 1) / kWG;
@@ -170,17 +183,23 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
         step = 1;
     }
 
-    auto load_tiles = [&](uint32_t t0, u32x4 (&v)[U], uint32_t (&e)[U]) {
+    // FULL = every lane of every tile of the iteration holds CPL valid codes: no predicates, no branches
+    // around the lookups, so the compiler can keep all U*CPL*CS ds_reads of an iteration in flight.
+    auto load_tiles = [&](uint32_t t0, u32x4 (&v)[U], uint32_t (&e)[U], auto full) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t t = t0 + u * step;
             e[u] = t * kWG + tid;                               // vector index
-            v[u] = u32x4{0, 0, 0, 0};
-            if (t < last && e[u] < nvec) v[u] = NT ? __builtin_nontemporal_load(src + e[u]) : src[e[u]];
-            else e[u] = 0xffffffffu;
+            if (decltype(full)::value) {
+                v[u] = NT ? __builtin_nontemporal_load(src + e[u]) : src[e[u]];
+            } else {
+                v[u] = u32x4{0, 0, 0, 0};
+                if (t < last && e[u] < nvec) v[u] = NT ? __builtin_nontemporal_load(src + e[u]) : src[e[u]];
+                else e[u] = 0xffffffffu;
+            }
         }
     };
-    auto process = [&](const u32x4 (&v)[U], const uint32_t (&e)[U]) {
+    auto process = [&](const u32x4 (&v)[U], const uint32_t (&e)[U], auto full) {
         uint32_t cand[U * C::CPL];
         uint32_t best = 127u;
 #pragma unroll
@@ -197,10 +216,14 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
                 } else {
                     s = pair_sum<M>(d + c * C::DW, lane_lo, lane_hi);
                 }
-                // lanes past the end of the run never qualify: 127 is not < bound (bound <= 127)
-                const bool live = e[u] != 0xffffffffu && e[u] * C::CPL + c < n;
-                cand[u * C::CPL + c] = live ? min(s, 127u) : 127u;
-                best = min(best, cand[u * C::CPL + c]);
+                uint32_t cv = min(s, 127u);
+                if (!decltype(full)::value) {
+                    // lanes past the end of the run never qualify: 127 is not < bound (bound <= 127)
+                    const bool live = e[u] != 0xffffffffu && e[u] * C::CPL + c < n;
+                    cv = live ? cv : 127u;
+                }
+                cand[u * C::CPL + c] = cv;
+                best = min(best, cv);
             }
         }
         if (__builtin_expect(best < bound, 0)) {                // rare: one branch per U tiles
@@ -213,25 +236,36 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
                                        it.pos0 + e[u] * C::CPL + c, cand[u * C::CPL + c]);
         }
     };
+    using full_t = std::integral_constant<bool, true>;
+    using part_t = std::integral_constant<bool, false>;
+    // tiles [0, tiles_full) contain only complete vectors of complete codes
+    const uint32_t tiles_full = (n / C::CPL) / kWG;
+    const uint32_t full_last = min(last, tiles_full);
 
+    uint32_t t0 = first;
     if (PF) {
-        // software prefetch: the next U tiles are requested before the current ones are consumed, so every
-        // wave keeps loads in flight during its LDS/VALU phase
+        // software prefetch: the next U tiles are requested before the current ones are consumed
         u32x4 cur[U], nxt[U];
         uint32_t ecur[U], enxt[U];
-        load_tiles(first, cur, ecur);
-        for (uint32_t t0 = first; t0 < last; t0 += step * U) {
-            load_tiles(t0 + step * U, nxt, enxt);
-            process(cur, ecur);
+        load_tiles(t0, cur, ecur, part_t());
+        for (; t0 < last; t0 += step * U) {
+            load_tiles(t0 + step * U, nxt, enxt, part_t());
+            process(cur, ecur, part_t());
 #pragma unroll
             for (int u = 0; u < U; ++u) { cur[u] = nxt[u]; ecur[u] = enxt[u]; }
         }
     } else {
-        for (uint32_t t0 = first; t0 < last; t0 += step * U) {
+        for (; t0 + (U - 1) * step < full_last; t0 += step * U) {   // steady state: unpredicated
             u32x4 v[U];
             uint32_t e[U];
-            load_tiles(t0, v, e);
-            process(v, e);
+            load_tiles(t0, v, e, full_t());
+            process(v, e, full_t());
+        }
+        for (; t0 < last; t0 += step * U) {                          // ragged end of the run
+            u32x4 v[U];
+            uint32_t e[U];
+            load_tiles(t0, v, e, part_t());
+            process(v, e, part_t());
         }
     }
 }
@@ -267,7 +301,8 @@ __global__ __launch_bounds__(256) void scan_i8_small_kernel(const ScanItem* __re
     const uint32_t bound = prefix_bound(qs, it.order >> 16, R, lhist, &lbound);   // syncs inside
 
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(it.codes);
+    typedef const __attribute__((address_space(1))) u32x4* gvec_t;
+    const gvec_t src = (gvec_t)(uintptr_t)it.codes;
     const uint32_t n = it.n;
     const uint32_t nvec = (n + CPL - 1) / CPL;
     const uint32_t stride = gridDim.x * 256;
@@ -457,6 +492,7 @@ template <int M>
 __global__ __launch_bounds__(kWG) void candidates_i8_kernel(const uint8_t* __restrict__ codes, uint64_t n,
                                                             const int8_t* __restrict__ qtable, int8_t* __restrict__ out) {
     using C = ScanCfg<M>;
+    lds_base_is_zero();
     build_pair_tables<M>(qtable);
     __syncthreads();
     const uint32_t tid = threadIdx.x;
