@@ -172,9 +172,9 @@ typedef struct qadc_profile {
     uint64_t scan_launches;   /* launches of the streaming int8 scan kernel (scan_i8_kernel) */
     uint64_t scan_codes;      /* codes those launches scanned (algorithmic bytes = codes * M/2) */
     double scan_ms;           /* sum of their HIP-event durations */
-    uint64_t small_launches;  /* launches of the small-run int8 scan kernel (scan_i8_small_kernel) */
-    uint64_t small_codes;
-    double small_ms;
+    uint64_t small_launches;  /* launches of the small-run int8 scan kernel (scan_i8_small_kernel): counted, */
+    uint64_t small_codes;     /* not event-timed (an event pair costs as much stream time as such a launch) */
+    double small_ms;          /* always 0; per-kernel times of these launches come from rocprofv3 */
     uint64_t start_codes;     /* codes scanned by the float pre-scan */
     double start_ms;          /* float pre-scan + select + quantize, HIP-event duration */
     uint64_t candidates;      /* candidates returned by the device (before padding duplicates) */

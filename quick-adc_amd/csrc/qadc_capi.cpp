@@ -102,6 +102,7 @@ struct LevelLaunch {
     int wgs;
     uint64_t codes;
     bool small;     // small-run kernel (runs below idx->small_run codes)
+    int ev = -1;    // index of the HIP event recorded before the launch (the next one follows it), -1 = not timed
 };
 
 struct Slot {
@@ -401,15 +402,18 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     }
 
     // ---- scan levels ------------------------------------------------------------------------
+    // HIP events cost a few microseconds of stream time each: with profiling on, only the streaming-kernel
+    // launches (the roofline figure) are bracketed individually; the small-run launches share one pair
     for (auto& ll : s.launches) {
-        if (idx->profile) HIPCHECK(prof_event(s, st));
+        const bool timed = idx->profile && !ll.small;
+        if (timed) { ll.ev = (int)s.prof_used; HIPCHECK(prof_event(s, st)); }
         if (ll.small)
             launch_scan_i8_small(M, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p, s.d_cands.p,
                                  s.cap_q, (uint32_t)s.R, st);
         else
             launch_scan_i8(M, idx->variant, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p,
                            s.d_cands.p, s.cap_q, (uint32_t)s.R, st);
-        if (idx->profile) HIPCHECK(prof_event(s, st));
+        if (timed) HIPCHECK(prof_event(s, st));
     }
     // the ordering pass and the result copies run on a side stream: they only occupy nq CUs, and the main
     // stream is free to start the next batch's kernels meanwhile (it uses the other slot's buffers)
@@ -522,17 +526,17 @@ int collect_common(qadc_index* idx, int slot_i) {
             HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[0], s.prof_ev[1]));
             if (s.float_path) idx->prof.start_ms += ms;
         }
-        for (size_t i = 0; i < s.launches.size() && 3 + 2 * i < s.prof_used; ++i) {
-            HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[2 + 2 * i], s.prof_ev[3 + 2 * i]));
-            if (s.launches[i].small) {
-                idx->prof.small_ms += ms;
+        for (auto& ll : s.launches) {
+            if (ll.small) {                                  // counted, not timed (see plan_and_launch)
                 idx->prof.small_launches++;
-                idx->prof.small_codes += s.launches[i].codes;
-            } else {
-                idx->prof.scan_ms += ms;
-                idx->prof.scan_launches++;
-                idx->prof.scan_codes += s.launches[i].codes;
+                idx->prof.small_codes += ll.codes;
+                continue;
             }
+            if (ll.ev < 0 || (size_t)ll.ev + 1 >= s.prof_used) continue;
+            HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[ll.ev], s.prof_ev[ll.ev + 1]));
+            idx->prof.scan_ms += ms;
+            idx->prof.scan_launches++;
+            idx->prof.scan_codes += ll.codes;
         }
         if (s.float_path) idx->prof.start_codes += s.start_codes;
     }

@@ -573,11 +573,14 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
 #pragma unroll
             for (int w = 0; w < DW; ++w) d[u][w] = 0;
             if (live[u]) {
+                // explicit global address space: a pointer read from the item struct is generic otherwise
                 if constexpr (M == 16) {
-                    const uint2 v = reinterpret_cast<const uint2*>(it.codes)[i];
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 v = ((const __attribute__((address_space(1))) u32x2*)(uintptr_t)it.codes)[i];
                     d[u][0] = v.x; d[u][1] = v.y;
                 } else {
-                    const uint4 v = reinterpret_cast<const uint4*>(it.codes)[i];
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v = ((const __attribute__((address_space(1))) u32x4*)(uintptr_t)it.codes)[i];
                     d[u][0] = v.x; d[u][1] = v.y; d[u][2] = v.z; d[u][3] = v.w;
                 }
             }
