@@ -149,6 +149,27 @@ int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* v
 int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_capacity, uint32_t* cand_keys,
                                        int8_t* cand_vals, uint64_t* offsets, int32_t* status, float* qmin, float* qmax);
 
+/* ---------------------------------------------------------------------------------------------
+ * "Next" row N1 of SURVEY.md §8(f): the host feeders of the path, on the device.  Queries in, heaps out;
+ * assignment, residuals and float tables never cross PCIe.  Replaces, for plain PQ (no OPQ rotation):
+ *   index_db::assign_compute_residuals  (databases.hpp:201-211; find_k_neighbors, neighbors.cpp:30-76)
+ *   flat_db::assign_compute_residuals   (databases.hpp:93-101)
+ *   compute_dists_single_simd_cg        (distances.hpp:294-311)
+ * followed by the same chain as qadc_query_scan.  Float parity of these feeders against the reference
+ * is unpinned (its versions go through OpenBLAS / AVX kernels); they are bit-exact against
+ * quick-adc_amd/host/query_driver.hpp, which evaluates the same loops on the host.
+ * ------------------------------------------------------------------------------------------- */
+/* codebooks [M][16][dim/M] (base_pq::centroids_flat order). */
+int qadc_index_set_pq(qadc_index* idx, int dim, const float* codebooks);
+/* coarse centroids [K][dim], K == partition count (partition p belongs to centroid p).  Not called = flat. */
+int qadc_index_set_coarse(qadc_index* idx, int K, const float* centroids);
+/* queries [nq][dim]; outputs as qadc_query_scan; assign_out [nq][ma] (nullable) = probed partitions. */
+int qadc_search(qadc_index* idx, int nq, const float* queries, int ma, int R, uint32_t* keys, int8_t* values,
+                int32_t* sizes, int32_t* status, int32_t* assign_out);
+int qadc_search_submit(qadc_index* idx, int slot, int nq, const float* queries, int ma, int R);
+int qadc_search_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
+                        int32_t* assign_out);
+
 /* Host-only helper (no GPU involved): push (keys[i], vals[i]), i = 0..n-1, in order into an empty
  * heap of capacity R with kv_binheap<unsigned,int8_t>::push semantics (binheap.hpp:75-116), after
  * an optional (0,127) sentinel (db_query_4.cpp:276), and return the heap arrays.  This is the

@@ -139,6 +139,14 @@ struct Slot {
     PinBuf<Cand> h_cands;               // host-sort fallback only
     PinBuf<uint32_t> h_out_keys;
     PinBuf<int8_t> h_out_vals;
+    // device-side feeders (qadc_search): queries in, tables never leave the GPU
+    bool device_tables = false;
+    DevBuf<float> d_queries;
+    DevBuf<int32_t> d_assign;
+    DevBuf<float> d_cdist;
+    PinBuf<float> h_queries;
+    PinBuf<int32_t> h_assign;
+    hipEvent_t ev_feed = nullptr;
 
     std::vector<LevelLaunch> launches;
     uint64_t start_codes = 0;
@@ -176,6 +184,11 @@ struct qadc_index {
     uint32_t small_run = 1u << 17;  // runs shorter than this use the small-run kernel
     int variant = 0x0d;    // kernel tuning variant (see launch_scan_i8): U=2, non-temporal loads, chunked tiles
     bool profile = false;
+    // N1: host feeders on the device
+    int dim = 0;                 // vector dimension (0 = qadc_index_set_pq not called)
+    DevBuf<float> d_codebooks;   // [M][16][dim/M]
+    int K = 0;                   // coarse centroids (0 = flat)
+    DevBuf<float> d_coarse;      // [K][dim]
     Slot slot[2];
     qadc_profile prof{};
 };
@@ -361,10 +374,17 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
 
     if (s.float_path) {
         const size_t nt = (size_t)nq * ma * table_dim;
-        HIPCHECK(s.h_ftables.ensure(nt));
         HIPCHECK(s.d_ftables.ensure(nt));
-        std::memcpy(s.h_ftables.p, s.tables, nt * sizeof(float));
-        HIPCHECK(hipMemcpyAsync(s.d_ftables.p, s.h_ftables.p, nt * sizeof(float), hipMemcpyHostToDevice, st));
+        if (s.device_tables) {
+            // residuals + float tables built on the GPU from the queries uploaded by search_submit
+            HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
+            launch_build_tables(s.d_queries.p, idx->K ? idx->d_coarse.p : nullptr, s.d_assign.p, idx->d_codebooks.p, nq, ma, M,
+                                idx->dim, s.d_ftables.p, st);
+        } else {
+            HIPCHECK(s.h_ftables.ensure(nt));
+            std::memcpy(s.h_ftables.p, s.tables, nt * sizeof(float));
+            HIPCHECK(hipMemcpyAsync(s.d_ftables.p, s.h_ftables.p, nt * sizeof(float), hipMemcpyHostToDevice, st));
+        }
         const size_t na = sitems_a.size(), nb = sitems_b.size();
         HIPCHECK(s.h_sitems.ensure(na + nb));
         HIPCHECK(s.d_sitems.ensure(na + nb));
@@ -455,6 +475,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
     s.R = R;
     s.float_path = tables != nullptr;
     s.tables = tables;
+    s.device_tables = false;
     s.assign.assign(assign, assign + (size_t)nq * ma);
     if (qtables) {
         const size_t nt = (size_t)nq * ma * idx->M * 16;
@@ -463,6 +484,57 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
                 return fail(QADC_E_ARG, "int8 tables must lie in [0,127] (QuantizerMAX<int8_t> output, db_query_4.cpp:37-71)");
         s.qtables_in.assign(qtables, qtables + nt);
     }
+    s.full_prescan = false;
+    s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
+    s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)nq * 8192u, 1ull << 30));
+    if (int rc = plan_and_launch(idx, s)) return rc;
+    s.busy = true;
+    return QADC_OK;
+}
+
+// N1: queries in.  Coarse assignment runs on the copy stream (so it does not queue behind the previous
+// batch's scan), the host reads assign[] back to plan the work items, residuals and float tables are built
+// on the GPU by the main stream.
+int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int ma, int R) {
+    if (!idx || !queries) return fail(QADC_E_ARG, "null argument");
+    if (slot_i < 0 || slot_i > 1) return fail(QADC_E_ARG, "slot must be 0 or 1");
+    if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
+    if (idx->dim == 0) return fail(QADC_E_STATE, "qadc_index_set_pq has not been called");
+    if (nq <= 0 || ma <= 0 || R <= 0) return fail(QADC_E_ARG, "nq, ma, R must be > 0");
+    if (nq >= (1 << 24) || ma >= (1 << 14)) return fail(QADC_E_ARG, "nq must be < 2^24 and ma < 16384");
+    if (idx->K && (idx->K != (int)idx->parts.size() || ma > idx->K))
+        return fail(QADC_E_ARG, "coarse centroids must match the partitions one to one and ma <= K");
+    if (!idx->K && idx->parts.size() != 1) return fail(QADC_E_ARG, "a database without coarse centroids must be flat (1 partition)");
+    Slot& s = idx->slot[slot_i];
+    if (s.busy) return fail(QADC_E_STATE, "slot still holds an uncollected batch");
+    if (int rc = use_device(idx)) return rc;
+    const int dim = idx->dim;
+    s.nq = nq;
+    s.ma = ma;
+    s.R = R;
+    s.float_path = true;
+    s.device_tables = true;
+    s.tables = nullptr;
+    HIPCHECK(s.h_queries.ensure((size_t)nq * dim));
+    HIPCHECK(s.d_queries.ensure((size_t)nq * dim));
+    HIPCHECK(s.h_assign.ensure((size_t)nq * ma));
+    HIPCHECK(s.d_assign.ensure((size_t)nq * ma));
+    std::memcpy(s.h_queries.p, queries, sizeof(float) * (size_t)nq * dim);
+    hipStream_t cs = idx->copy_stream;
+    HIPCHECK(hipMemcpyAsync(s.d_queries.p, s.h_queries.p, sizeof(float) * (size_t)nq * dim, hipMemcpyHostToDevice, cs));
+    if (idx->K) {
+        HIPCHECK(s.d_cdist.ensure((size_t)nq * idx->K));
+        launch_coarse_assign(s.d_queries.p, idx->d_coarse.p, nq, idx->K, dim, ma, s.d_cdist.p, s.d_assign.p, cs);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(s.h_assign.p, s.d_assign.p, sizeof(int32_t) * (size_t)nq * ma, hipMemcpyDeviceToHost, cs));
+    } else {
+        HIPCHECK(hipMemsetAsync(s.d_assign.p, 0, sizeof(int32_t) * (size_t)nq * ma, cs));
+        std::memset(s.h_assign.p, 0, sizeof(int32_t) * (size_t)nq * ma);
+    }
+    if (!s.ev_feed) HIPCHECK(hipEventCreateWithFlags(&s.ev_feed, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(s.ev_feed, cs));
+    HIPCHECK(hipStreamSynchronize(cs));                      // the planner needs assign[] on the host
+    s.assign.assign(s.h_assign.p, s.h_assign.p + (size_t)nq * ma);
     s.full_prescan = false;
     s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
     s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)nq * 8192u, 1ull << 30));
@@ -671,11 +743,15 @@ int qadc_index_destroy(qadc_index* idx) {
         }
         if (p.d_starts) (void)hipFree(p.d_starts);
     }
+    idx->d_codebooks.release();
+    idx->d_coarse.release();
     for (auto& s : idx->slot) {
         s.d_ftables.release(); s.d_qtables.release(); s.d_qs.release(); s.d_hdr.release(); s.d_cands.release(); s.d_out_keys.release(); s.d_out_vals.release();
         s.d_items.release(); s.d_sitems.release(); s.d_fc.release(); s.d_fc_init.release();
         s.h_items.release(); s.h_sitems.release(); s.h_fc_init.release(); s.h_ftables.release(); s.h_qtables.release();
         s.h_qs.release(); s.h_hdr.release(); s.h_cands.release(); s.h_out_keys.release(); s.h_out_vals.release();
+        s.d_queries.release(); s.d_assign.release(); s.d_cdist.release(); s.h_queries.release(); s.h_assign.release();
+        if (s.ev_feed) (void)hipEventDestroy(s.ev_feed);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         if (s.ev_scanned) (void)hipEventDestroy(s.ev_scanned);
         for (auto e : s.prof_ev) (void)hipEventDestroy(e);
@@ -1064,6 +1140,50 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
     HIPCHECK(hipFree(d_v));
     HIPCHECK(hipFree(d_p));
     return QADC_OK;
+}
+
+int qadc_index_set_pq(qadc_index* idx, int dim, const float* codebooks) {
+    if (!idx || !codebooks || dim <= 0 || dim % idx->M != 0) return fail(QADC_E_ARG, "dim must be a positive multiple of M");
+    if (int rc = use_device(idx)) return rc;
+    const size_t n = (size_t)idx->M * 16 * (dim / idx->M);
+    HIPCHECK(idx->d_codebooks.ensure(n));
+    HIPCHECK(hipMemcpy(idx->d_codebooks.p, codebooks, n * sizeof(float), hipMemcpyHostToDevice));
+    idx->dim = dim;
+    return QADC_OK;
+}
+
+int qadc_index_set_coarse(qadc_index* idx, int K, const float* centroids) {
+    if (!idx || K <= 0 || !centroids) return fail(QADC_E_ARG, "bad arguments");
+    if (idx->dim == 0) return fail(QADC_E_STATE, "call qadc_index_set_pq first");
+    if (int rc = use_device(idx)) return rc;
+    HIPCHECK(idx->d_coarse.ensure((size_t)K * idx->dim));
+    HIPCHECK(hipMemcpy(idx->d_coarse.p, centroids, (size_t)K * idx->dim * sizeof(float), hipMemcpyHostToDevice));
+    idx->K = K;
+    return QADC_OK;
+}
+
+int qadc_search_submit(qadc_index* idx, int slot, int nq, const float* queries, int ma, int R) {
+    return search_submit(idx, slot, nq, queries, ma, R);
+}
+
+int qadc_search_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
+                        int32_t* assign_out) {
+    if (int rc = collect_common(idx, slot)) return rc;
+    Slot& s = idx->slot[slot];
+    std::vector<int32_t> st_local;
+    if (!status) {
+        st_local.resize(s.nq);
+        status = st_local.data();
+    }
+    finish_float_outputs(idx, s, status, nullptr, nullptr);
+    if (assign_out) std::memcpy(assign_out, s.assign.data(), sizeof(int32_t) * s.assign.size());
+    return replay_outputs(idx, s, keys, values, sizes, status);
+}
+
+int qadc_search(qadc_index* idx, int nq, const float* queries, int ma, int R, uint32_t* keys, int8_t* values, int32_t* sizes,
+                int32_t* status, int32_t* assign_out) {
+    if (int rc = search_submit(idx, 0, nq, queries, ma, R)) return rc;
+    return qadc_search_collect(idx, 0, keys, values, sizes, status, assign_out);
 }
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out) {

@@ -95,6 +95,17 @@ void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_
 void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,
                        int blocks, hipStream_t stream);
 
+// ---- host feeders on the device --------------------------------------------------
+// Coarse assignment of index_db::assign_compute_residuals (databases.hpp:201-211): the `ma` nearest of K
+// centroids per query, ascending by squared L2 distance (lower index first on ties).  d_dist = scratch [nq][K].
+void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
+                          int32_t* d_assign, hipStream_t stream);
+// Residual + per-query distance tables (compute_dists_single_simd_cg's result, distances.hpp:294-311):
+// tables[q][a][m][c] = sum_d ((x - centroid[assign])[m*ds+d] - codebook[m][c][d])^2, d ascending.
+// d_coarse == nullptr (flat DB): residual = query.
+void launch_build_tables(const float* d_queries, const float* d_coarse, const int32_t* d_assign, const float* d_codebooks,
+                         int nq, int ma, int M, int dim, float* d_ftables, hipStream_t stream);
+
 // Sets QueryState::fc_n / fc_cap from init[2*q], init[2*q+1].
 void launch_prescan_init(QueryState* d_qs, const uint32_t* d_init, int nq, hipStream_t stream);
 

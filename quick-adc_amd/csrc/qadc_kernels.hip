@@ -838,6 +838,100 @@ void launch_quantize(int M, int ma, int nq, float* d_ftables, int8_t* d_qtables,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Host feeders on the device: coarse assignment, residuals, float distance tables.
+// Plain sequential float arithmetic (no FMA contraction), so a host evaluation of the same loops
+// (host/query_driver.hpp) gives identical bits.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restrict__ queries,
+                                                            const float* __restrict__ coarse, int K, int dim, int ma,
+                                                            float* __restrict__ dist, int32_t* __restrict__ assign) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    float* q = reinterpret_cast<float*>(dyn);                 // [dim]
+    __shared__ float rv[256];
+    __shared__ int rk[256];
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    for (int d = tid; d < dim; d += 256) q[d] = queries[(size_t)qi * dim + d];
+    __syncthreads();
+    float* __restrict__ dq = dist + (size_t)qi * K;
+    for (int k = tid; k < K; k += 256) {
+        const float* __restrict__ c = coarse + (size_t)k * dim;
+        float s = 0.0f;
+        for (int d = 0; d < dim; ++d) {
+            const float t = q[d] - c[d];
+            s += t * t;
+        }
+        dq[k] = s;
+    }
+    __syncthreads();
+    // ma rounds of "smallest (distance, index) strictly after the previous pick"
+    float last_v = -1.0f;
+    int last_k = -1;
+    for (int a = 0; a < ma; ++a) {
+        float bv = FLT_MAX;
+        int bk = 0x7fffffff;
+        for (int k = tid; k < K; k += 256) {
+            const float v = dq[k];
+            const bool after = v > last_v || (v == last_v && k > last_k);
+            if (after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
+        }
+        rv[tid] = bv;
+        rk[tid] = bk;
+        __syncthreads();
+        for (int st = 128; st >= 1; st >>= 1) {
+            if (tid < st) {
+                const float ov = rv[tid + st];
+                const int ok = rk[tid + st];
+                if (ov < rv[tid] || (ov == rv[tid] && ok < rk[tid])) { rv[tid] = ov; rk[tid] = ok; }
+            }
+            __syncthreads();
+        }
+        last_v = rv[0];
+        last_k = rk[0];
+        if (tid == 0) assign[(size_t)qi * ma + a] = last_k;
+        __syncthreads();
+    }
+}
+
+void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
+                          int32_t* d_assign, hipStream_t stream) {
+    hipLaunchKernelGGL(coarse_assign_kernel, dim3(nq), dim3(256), dim * sizeof(float), stream, d_queries, d_coarse, K, dim, ma,
+                       d_dist, d_assign);
+}
+
+__global__ __launch_bounds__(256) void build_tables_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
+                                                           const int32_t* __restrict__ assign,
+                                                           const float* __restrict__ codebooks, int ma, int M, int dim,
+                                                           float* __restrict__ ftables) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    float* res = reinterpret_cast<float*>(dyn);               // [dim] residual of this (query, probe)
+    const int a = blockIdx.x, qi = blockIdx.y, tid = threadIdx.x;
+    const int ds = dim / M;
+    const float* __restrict__ c = coarse ? coarse + (size_t)assign[(size_t)qi * ma + a] * dim : nullptr;
+    for (int d = tid; d < dim; d += 256) {
+        const float x = queries[(size_t)qi * dim + d];
+        res[d] = c ? x - c[d] : x;
+    }
+    __syncthreads();
+    float* __restrict__ out = ftables + ((size_t)qi * ma + a) * (M * 16);
+    for (int e = tid; e < M * 16; e += 256) {
+        const int m = e >> 4;
+        const float* __restrict__ ce = codebooks + (size_t)e * ds;   // [m][c][ds] is contiguous in e
+        float s = 0.0f;
+        for (int d = 0; d < ds; ++d) {
+            const float t = res[m * ds + d] - ce[d];
+            s += t * t;
+        }
+        out[e] = s;
+    }
+}
+
+void launch_build_tables(const float* d_queries, const float* d_coarse, const int32_t* d_assign, const float* d_codebooks,
+                         int nq, int ma, int M, int dim, float* d_ftables, hipStream_t stream) {
+    hipLaunchKernelGGL(build_tables_kernel, dim3(ma, nq), dim3(256), dim * sizeof(float), stream, d_queries, d_coarse, d_assign,
+                       d_codebooks, ma, M, dim, d_ftables);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic codes: word w (8 code bytes) = splitmix64(seed ^ splitmix64(w)), little endian.
 // Same function as orc_fill_codes in the oracle, so any sub-range is reproducible on the CPU.
 // ---------------------------------------------------------------------------------------------

@@ -28,7 +28,8 @@ SYMBOLS = [
     "qadc_index_partition_size", "qadc_index_start_size", "qadc_set_option",
     "qadc_index_read_codes", "qadc_query_scan", "qadc_query_scan_candidates", "qadc_scan_i8",
     "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit",
-    "qadc_query_scan_collect", "qadc_replay_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
+    "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
+    "qadc_search_collect", "qadc_replay_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
 ]
 
 
@@ -87,6 +88,11 @@ def lib():
         L.qadc_scan_start.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, f32p, C.c_int, f32p]
         L.qadc_query_scan_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_int]
         L.qadc_query_scan_collect.argtypes = [C.c_void_p, C.c_int, u32p, i8p, i32p, i32p, f32p, f32p, i8p]
+        L.qadc_index_set_pq.argtypes = [C.c_void_p, C.c_int, f32p]
+        L.qadc_index_set_coarse.argtypes = [C.c_void_p, C.c_int, f32p]
+        L.qadc_search.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, u32p, i8p, i32p, i32p, i32p]
+        L.qadc_search_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, C.c_int, C.c_int]
+        L.qadc_search_collect.argtypes = [C.c_void_p, C.c_int, u32p, i8p, i32p, i32p, i32p]
         L.qadc_replay_i8.argtypes = [C.c_uint64, u32p, i8p, C.c_int, C.c_int, u32p, i8p, i32p]
         L.qadc_candidates_i8.argtypes = [C.c_void_p, C.c_int, i8p, i8p]
         L.qadc_float_top1.argtypes = [C.c_void_p, C.c_int, f32p, u32p, u32p, f32p]
@@ -253,6 +259,29 @@ class Index:
                                                         _p(off, u64p), _p(status, i32p), _p(qmin, f32p),
                                                         _p(qmax, f32p)))
         return dict(keys=ck, vals=cv, offsets=off.astype(np.int64), status=status, qmin=qmin, qmax=qmax)
+
+    def set_pq(self, codebooks):
+        cb = np.ascontiguousarray(codebooks, np.float32)
+        assert cb.shape[0] == self.M and cb.shape[1] == 16
+        self.dim = self.M * cb.shape[2]
+        _check(lib().qadc_index_set_pq(self._h, self.dim, _p(cb, f32p)))
+
+    def set_coarse(self, centroids):
+        c = np.ascontiguousarray(centroids, np.float32)
+        _check(lib().qadc_index_set_coarse(self._h, c.shape[0], _p(c, f32p)))
+
+    def search(self, queries, ma, R):
+        q = np.ascontiguousarray(queries, np.float32)
+        nq = q.shape[0]
+        keys = np.zeros((nq, R), np.uint32)
+        vals = np.zeros((nq, R), np.int8)
+        sizes = np.zeros(nq, np.int32)
+        status = np.zeros(nq, np.int32)
+        assign = np.zeros((nq, ma), np.int32)
+        _check(lib().qadc_search(self._h, nq, _p(q, f32p), ma, R, _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p),
+                                 _p(status, i32p), _p(assign, i32p)))
+        return dict(heaps=self._heaps(nq, R, keys, vals, sizes), status=status, assign=assign, keys=keys,
+                    values=vals, sizes=sizes)
 
     def scan_i8(self, assign, qtables, R):
         assign = self._prep(assign)

@@ -328,3 +328,56 @@ def test_edge_cases_small_r_large_r_repeated_and_empty_partitions(pyqadc, po, M)
         if want["rc"] == 0:
             assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
     idx.close()
+
+
+def _seq_sqdist(x, c):
+    """sum_d (x[d] - c[..., d])^2 accumulated in float32 in ascending d, as the device loops do."""
+    s = np.zeros(c.shape[:-1], np.float32)
+    for d in range(c.shape[-1]):
+        t = (x[..., d] - c[..., d]).astype(np.float32)
+        s = (s + (t * t).astype(np.float32)).astype(np.float32)
+    return s
+
+
+@pytest.mark.parametrize("M,K,ma", [(16, 37, 5), (32, 16, 3), (16, 0, 1)])
+def test_search_with_device_side_feeders(pyqadc, po, M, K, ma):
+    """N1: queries in -> coarse assignment, residuals and float tables on the GPU -> same heaps as feeding
+    the oracle with tables/assignments evaluated by the same float loops on the host."""
+    rng = np.random.default_rng(M * 100 + K)
+    dim, nq, R, keep = 128, 7, 100, 0.05
+    ds = dim // M
+    cb = rng.normal(size=(M, 16, ds)).astype(np.float32)
+    nparts = max(K, 1)
+    sizes = [int(s) for s in rng.integers(3000, 9000, nparts)]
+    parts = [rand_codes(rng, s, M) for s in sizes]
+    labels = None
+    if K:
+        perm = rng.permutation(sum(sizes)).astype(np.uint32)
+        labels = list(np.split(perm, np.cumsum(sizes)[:-1]))
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(keep)
+    idx.set_pq(cb)
+    coarse = None
+    if K:
+        coarse = rng.normal(size=(K, dim)).astype(np.float32)
+        coarse[5] = coarse[3]                                   # exact distance tie between two centroids
+        idx.set_coarse(coarse)
+    queries = rng.normal(size=(nq, dim)).astype(np.float32)
+    res = idx.search(queries, ma, R)
+    for q in range(nq):
+        if K:
+            dist = _seq_sqdist(queries[q][None, :], coarse)
+            assign = np.lexsort((np.arange(K), dist))[:ma].astype(np.int32)
+            resid = (queries[q][None, :] - coarse[assign]).astype(np.float32)
+        else:
+            assign = np.zeros(ma, np.int32)
+            resid = np.repeat(queries[q][None, :], ma, 0)
+        assert np.array_equal(res["assign"][q], assign), q
+        tables = np.zeros((ma, M, 16), np.float32)
+        for a in range(ma):
+            tables[a] = _seq_sqdist(resid[a].reshape(M, 1, ds), cb)
+        want = po.query_scan(M, parts, labels, keep, assign, np.ascontiguousarray(tables.reshape(ma, M * 16)), R)
+        assert want["rc"] == res["status"][q] == 0
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
+    idx.close()

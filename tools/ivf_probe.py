@@ -33,3 +33,18 @@ for r in range(3):
           p["scan_codes"] * (M // 2) / (max(p["scan_ms"], 1e-9) * 1e-3) / 1e9, p["small_ms"], p["small_launches"],
           p["small_codes"] * (M // 2) / (max(p["small_ms"], 1e-9) * 1e-3) / 1e9, p["start_ms"], p["host_replay_ms"], p["host_plan_ms"], p["host_heap_ms"], p["candidates"] / NQ, 0, p["host_sorted_queries"], p["regrows"],
           int(res["status"].sum())), flush=True)
+
+# ---- N1 path: queries in (coarse assignment + tables on the GPU) ----
+dim = 128
+coarse = rng.normal(size=(K, dim)).astype(np.float32)
+idx.set_pq(cb); idx.set_coarse(coarse)
+queries = rng.normal(size=(NQ, dim)).astype(np.float32)
+idx.search(queries, MA, R)
+for r in range(3):
+    idx.profile_reset(); t = time.time()
+    res = idx.search(queries, MA, R)
+    dt = time.time() - t; p = idx.profile()
+    codes = sizes[res["assign"]].sum()
+    print("search rep %d: %.2f ms/batch (%.1f us/query) -> %.3e codes/s | prescan+tables %.2f ms host asm %.2f plan %.2f heap %.2f ms "
+          "cands/query %.0f" % (r, dt * 1e3, dt * 1e6 / NQ, codes / dt, p["start_ms"], p["host_replay_ms"], p["host_plan_ms"],
+                                p["host_heap_ms"], p["candidates"] / NQ), flush=True)
