@@ -154,6 +154,7 @@ int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_
  * assignment, residuals and float tables never cross PCIe.  Replaces, for plain PQ (no OPQ rotation):
  *   index_db::assign_compute_residuals  (databases.hpp:201-211; find_k_neighbors, neighbors.cpp:30-76)
  *   flat_db::assign_compute_residuals   (databases.hpp:93-101)
+ *   opq::rotate_multiple_vectors        (quantizers.hpp:289-301)
  *   compute_dists_single_simd_cg        (distances.hpp:294-311)
  * followed by the same chain as qadc_query_scan.  Float parity of these feeders against the reference
  * is unpinned (its versions go through OpenBLAS / AVX kernels); they are bit-exact against
@@ -161,6 +162,9 @@ int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_
  * ------------------------------------------------------------------------------------------- */
 /* codebooks [M][16][dim/M] (base_pq::centroids_flat order). */
 int qadc_index_set_pq(qadc_index* idx, int dim, const float* codebooks);
+/* OPQ rotation [dim][dim] (opq::rotation): residuals are rotated before the tables are built,
+ * rotated[r] = sum_c x[c] * rotation[r][c] (opq::rotate_multiple_vectors, quantizers.hpp:289-301).  NULL = plain PQ. */
+int qadc_index_set_rotation(qadc_index* idx, const float* rotation);
 /* coarse centroids [K][dim], K == partition count (partition p belongs to centroid p).  Not called = flat. */
 int qadc_index_set_coarse(qadc_index* idx, int K, const float* centroids);
 /* queries [nq][dim]; outputs as qadc_query_scan; assign_out [nq][ma] (nullable) = probed partitions. */

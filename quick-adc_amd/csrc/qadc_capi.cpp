@@ -187,6 +187,8 @@ struct qadc_index {
     // N1: host feeders on the device
     int dim = 0;                 // vector dimension (0 = qadc_index_set_pq not called)
     DevBuf<float> d_codebooks;   // [M][16][dim/M]
+    DevBuf<float> d_rotation;    // [dim][dim] OPQ rotation (empty = plain PQ)
+    bool has_rotation = false;
     int K = 0;                   // coarse centroids (0 = flat)
     DevBuf<float> d_coarse;      // [K][dim]
     Slot slot[2];
@@ -378,7 +380,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         if (s.device_tables) {
             // residuals + float tables built on the GPU from the queries uploaded by search_submit
             HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
-            launch_build_tables(s.d_queries.p, idx->K ? idx->d_coarse.p : nullptr, s.d_assign.p, idx->d_codebooks.p, nq, ma, M,
+            launch_build_tables(s.d_queries.p, idx->K ? idx->d_coarse.p : nullptr, s.d_assign.p, idx->d_codebooks.p,
+                                idx->has_rotation ? idx->d_rotation.p : nullptr, nq, ma, M,
                                 idx->dim, s.d_ftables.p, st);
         } else {
             HIPCHECK(s.h_ftables.ensure(nt));
@@ -744,6 +747,7 @@ int qadc_index_destroy(qadc_index* idx) {
         if (p.d_starts) (void)hipFree(p.d_starts);
     }
     idx->d_codebooks.release();
+    idx->d_rotation.release();
     idx->d_coarse.release();
     for (auto& s : idx->slot) {
         s.d_ftables.release(); s.d_qtables.release(); s.d_qs.release(); s.d_hdr.release(); s.d_cands.release(); s.d_out_keys.release(); s.d_out_vals.release();
@@ -1149,6 +1153,21 @@ int qadc_index_set_pq(qadc_index* idx, int dim, const float* codebooks) {
     HIPCHECK(idx->d_codebooks.ensure(n));
     HIPCHECK(hipMemcpy(idx->d_codebooks.p, codebooks, n * sizeof(float), hipMemcpyHostToDevice));
     idx->dim = dim;
+    return QADC_OK;
+}
+
+int qadc_index_set_rotation(qadc_index* idx, const float* rotation) {
+    if (!idx) return fail(QADC_E_ARG, "null index");
+    if (idx->dim == 0) return fail(QADC_E_STATE, "call qadc_index_set_pq first");
+    if (!rotation) {
+        idx->has_rotation = false;
+        return QADC_OK;
+    }
+    if (int rc = use_device(idx)) return rc;
+    const size_t n = (size_t)idx->dim * idx->dim;
+    HIPCHECK(idx->d_rotation.ensure(n));
+    HIPCHECK(hipMemcpy(idx->d_rotation.p, rotation, n * sizeof(float), hipMemcpyHostToDevice));
+    idx->has_rotation = true;
     return QADC_OK;
 }
 

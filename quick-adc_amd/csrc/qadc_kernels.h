@@ -102,9 +102,10 @@ void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq,
                           int32_t* d_assign, hipStream_t stream);
 // Residual + per-query distance tables (compute_dists_single_simd_cg's result, distances.hpp:294-311):
 // tables[q][a][m][c] = sum_d ((x - centroid[assign])[m*ds+d] - codebook[m][c][d])^2, d ascending.
-// d_coarse == nullptr (flat DB): residual = query.
+// d_coarse == nullptr (flat DB): residual = query.  d_rotation != nullptr (OPQ): the residual is rotated first,
+// rotated[r] = sum_c x[c] * rotation[r][c]  (opq::rotate_multiple_vectors, quantizers.hpp:289-301).
 void launch_build_tables(const float* d_queries, const float* d_coarse, const int32_t* d_assign, const float* d_codebooks,
-                         int nq, int ma, int M, int dim, float* d_ftables, hipStream_t stream);
+                         const float* d_rotation, int nq, int ma, int M, int dim, float* d_ftables, hipStream_t stream);
 
 // Sets QueryState::fc_n / fc_cap from init[2*q], init[2*q+1].
 void launch_prescan_init(QueryState* d_qs, const uint32_t* d_init, int nq, hipStream_t stream);

@@ -900,18 +900,31 @@ void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq,
 
 __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
                                                            const int32_t* __restrict__ assign,
-                                                           const float* __restrict__ codebooks, int ma, int M, int dim,
+                                                           const float* __restrict__ codebooks,
+                                                           const float* __restrict__ rotation, int ma, int M, int dim,
                                                            float* __restrict__ ftables) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     float* res = reinterpret_cast<float*>(dyn);               // [dim] residual of this (query, probe)
+    float* tmp = res + dim;                                   // [dim] un-rotated residual (OPQ only)
     const int a = blockIdx.x, qi = blockIdx.y, tid = threadIdx.x;
     const int ds = dim / M;
     const float* __restrict__ c = coarse ? coarse + (size_t)assign[(size_t)qi * ma + a] * dim : nullptr;
+    float* first = rotation ? tmp : res;
     for (int d = tid; d < dim; d += 256) {
         const float x = queries[(size_t)qi * dim + d];
-        res[d] = c ? x - c[d] : x;
+        first[d] = c ? x - c[d] : x;
     }
     __syncthreads();
+    if (rotation) {
+        // opq::rotate_multiple_vectors (quantizers.hpp:289-301): rotated[r] = sum_c x[c] * rotation[r][c]
+        for (int r = tid; r < dim; r += 256) {
+            const float* __restrict__ row = rotation + (size_t)r * dim;
+            float acc = 0.0f;
+            for (int cc = 0; cc < dim; ++cc) acc += tmp[cc] * row[cc];
+            res[r] = acc;
+        }
+        __syncthreads();
+    }
     float* __restrict__ out = ftables + ((size_t)qi * ma + a) * (M * 16);
     for (int e = tid; e < M * 16; e += 256) {
         const int m = e >> 4;
@@ -926,9 +939,9 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restri
 }
 
 void launch_build_tables(const float* d_queries, const float* d_coarse, const int32_t* d_assign, const float* d_codebooks,
-                         int nq, int ma, int M, int dim, float* d_ftables, hipStream_t stream) {
-    hipLaunchKernelGGL(build_tables_kernel, dim3(ma, nq), dim3(256), dim * sizeof(float), stream, d_queries, d_coarse, d_assign,
-                       d_codebooks, ma, M, dim, d_ftables);
+                         const float* d_rotation, int nq, int ma, int M, int dim, float* d_ftables, hipStream_t stream) {
+    hipLaunchKernelGGL(build_tables_kernel, dim3(ma, nq), dim3(256), 2 * dim * sizeof(float), stream, d_queries, d_coarse,
+                       d_assign, d_codebooks, d_rotation, ma, M, dim, d_ftables);
 }
 
 // ---------------------------------------------------------------------------------------------

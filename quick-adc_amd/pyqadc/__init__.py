@@ -28,7 +28,7 @@ SYMBOLS = [
     "qadc_index_partition_size", "qadc_index_start_size", "qadc_set_option",
     "qadc_index_read_codes", "qadc_query_scan", "qadc_query_scan_candidates", "qadc_scan_i8",
     "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit",
-    "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
+    "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
     "qadc_search_collect", "qadc_replay_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
 ]
 
@@ -89,6 +89,7 @@ def lib():
         L.qadc_query_scan_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_int]
         L.qadc_query_scan_collect.argtypes = [C.c_void_p, C.c_int, u32p, i8p, i32p, i32p, f32p, f32p, i8p]
         L.qadc_index_set_pq.argtypes = [C.c_void_p, C.c_int, f32p]
+        L.qadc_index_set_rotation.argtypes = [C.c_void_p, f32p]
         L.qadc_index_set_coarse.argtypes = [C.c_void_p, C.c_int, f32p]
         L.qadc_search.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, u32p, i8p, i32p, i32p, i32p]
         L.qadc_search_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, C.c_int, C.c_int]
@@ -265,6 +266,10 @@ class Index:
         assert cb.shape[0] == self.M and cb.shape[1] == 16
         self.dim = self.M * cb.shape[2]
         _check(lib().qadc_index_set_pq(self._h, self.dim, _p(cb, f32p)))
+
+    def set_rotation(self, rotation):
+        r = None if rotation is None else np.ascontiguousarray(rotation, np.float32)
+        _check(lib().qadc_index_set_rotation(self._h, _p(r, f32p)))
 
     def set_coarse(self, centroids):
         c = np.ascontiguousarray(centroids, np.float32)

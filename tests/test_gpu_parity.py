@@ -339,8 +339,9 @@ def _seq_sqdist(x, c):
     return s
 
 
-@pytest.mark.parametrize("M,K,ma", [(16, 37, 5), (32, 16, 3), (16, 0, 1)])
-def test_search_with_device_side_feeders(pyqadc, po, M, K, ma):
+@pytest.mark.parametrize("M,K,ma,opq", [(16, 37, 5, False), (32, 16, 3, False), (16, 0, 1, False), (16, 21, 4, True),
+                                         (32, 0, 1, True)])
+def test_search_with_device_side_feeders(pyqadc, po, M, K, ma, opq):
     """N1: queries in -> coarse assignment, residuals and float tables on the GPU -> same heaps as feeding
     the oracle with tables/assignments evaluated by the same float loops on the host."""
     rng = np.random.default_rng(M * 100 + K)
@@ -363,6 +364,10 @@ def test_search_with_device_side_feeders(pyqadc, po, M, K, ma):
         coarse = rng.normal(size=(K, dim)).astype(np.float32)
         coarse[5] = coarse[3]                                   # exact distance tie between two centroids
         idx.set_coarse(coarse)
+    rot = None
+    if opq:
+        rot = np.linalg.qr(rng.normal(size=(dim, dim)))[0].astype(np.float32)
+        idx.set_rotation(rot)
     queries = rng.normal(size=(nq, dim)).astype(np.float32)
     res = idx.search(queries, ma, R)
     for q in range(nq):
@@ -374,6 +379,11 @@ def test_search_with_device_side_feeders(pyqadc, po, M, K, ma):
             assign = np.zeros(ma, np.int32)
             resid = np.repeat(queries[q][None, :], ma, 0)
         assert np.array_equal(res["assign"][q], assign), q
+        if opq:   # rotated[r] = sum_c x[c] * rot[r][c], float32, ascending c
+            acc = np.zeros((ma, dim), np.float32)
+            for cc in range(dim):
+                acc = (acc + (resid[:, cc:cc + 1] * rot[None, :, cc]).astype(np.float32)).astype(np.float32)
+            resid = acc
         tables = np.zeros((ma, M, 16), np.float32)
         for a in range(ma):
             tables[a] = _seq_sqdist(resid[a].reshape(M, 1, ds), cb)
