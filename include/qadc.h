@@ -145,7 +145,8 @@ int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* v
                             int32_t* status, float* qmin, float* qmax, int8_t* qtables);
 
 /* collect variant returning the ordered candidate stream (see qadc_query_scan_candidates): what a
- * rank hands to the cross-GPU gather. */
+ * rank hands to the cross-GPU gather.  On QADC_E_CAPACITY the result is kept: call again with buffers of
+ * offsets[nq] entries. */
 int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_capacity, uint32_t* cand_keys,
                                        int8_t* cand_vals, uint64_t* offsets, int32_t* status, float* qmin, float* qmax);
 

@@ -107,6 +107,7 @@ struct LevelLaunch {
 
 struct Slot {
     bool busy = false;
+    bool has_result = false;            // collected streams not yet handed to the caller (capacity retry)
     bool float_path = false;
     int nq = 0, ma = 0, R = 0;
     float* tables = nullptr;            // caller's float tables (float path)
@@ -1014,10 +1015,19 @@ static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int
 
 int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_capacity, uint32_t* cand_keys,
                                        int8_t* cand_vals, uint64_t* offsets, int32_t* status, float* qmin, float* qmax) {
-    if (int rc = collect_common(idx, slot)) return rc;
+    if (!idx || slot < 0 || slot > 1) return fail(QADC_E_ARG, "bad arguments");
     Slot& s = idx->slot[slot];
+    if (s.busy) {
+        if (int rc = collect_common(idx, slot)) return rc;
+        s.has_result = true;
+    } else if (!s.has_result) {
+        return fail(QADC_E_STATE, "slot holds no batch");
+    }
     finish_float_outputs(idx, s, status, qmin, qmax);
-    return copy_stream(s, cand_capacity, cand_keys, cand_vals, offsets);
+    // QADC_E_CAPACITY keeps the result: call again with buffers of offsets[nq] entries
+    const int rc = copy_stream(s, cand_capacity, cand_keys, cand_vals, offsets);
+    if (rc == QADC_OK) s.has_result = false;
+    return rc;
 }
 
 int qadc_query_scan(qadc_index* idx, int nq, int ma, const int32_t* assign, float* tables, int R, uint32_t* keys,

@@ -248,17 +248,24 @@ class Index:
                                              _p(status, i32p), None, None, None))
         return dict(keys=keys, values=vals, sizes=sizes, status=status)
 
-    def collect_candidates(self, slot, capacity=1 << 20):
+    def collect_candidates(self, slot, capacity=1 << 18):
         nq, R, tables, assign = self._pending.pop(slot)
-        ck = np.zeros(capacity, np.uint32)
-        cv = np.zeros(capacity, np.int8)
+        bufs = getattr(self, "_cand_bufs", None)
+        if bufs is None or len(bufs[0]) < capacity:        # reused across calls: no per-step page faults
+            bufs = self._cand_bufs = (np.zeros(capacity, np.uint32), np.zeros(capacity, np.int8))
+        ck, cv = bufs
         off = np.zeros(nq + 1, np.uint64)
         status = np.zeros(nq, np.int32)
         qmin = np.zeros(nq, np.float32)
         qmax = np.zeros(nq, np.float32)
-        _check(lib().qadc_query_scan_collect_candidates(self._h, slot, capacity, _p(ck, u32p), _p(cv, i8p),
-                                                        _p(off, u64p), _p(status, i32p), _p(qmin, f32p),
-                                                        _p(qmax, f32p)))
+        rc = lib().qadc_query_scan_collect_candidates(self._h, slot, len(ck), _p(ck, u32p), _p(cv, i8p), _p(off, u64p),
+                                                      _p(status, i32p), _p(qmin, f32p), _p(qmax, f32p))
+        if rc == -3:                                        # QADC_E_CAPACITY: the result is kept, retry larger
+            need = int(off[nq]) + 1024
+            ck, cv = self._cand_bufs = (np.zeros(need, np.uint32), np.zeros(need, np.int8))
+            rc = lib().qadc_query_scan_collect_candidates(self._h, slot, need, _p(ck, u32p), _p(cv, i8p), _p(off, u64p),
+                                                          _p(status, i32p), _p(qmin, f32p), _p(qmax, f32p))
+        _check(rc)
         return dict(keys=ck, vals=cv, offsets=off.astype(np.int64), status=status, qmin=qmin, qmax=qmax)
 
     def set_pq(self, codebooks):

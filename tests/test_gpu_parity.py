@@ -391,3 +391,20 @@ def test_search_with_device_side_feeders(pyqadc, po, M, K, ma, opq):
         assert want["rc"] == res["status"][q] == 0
         assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
     idx.close()
+
+
+def test_collect_candidates_capacity_retry(pyqadc, po):
+    rng = np.random.default_rng(3)
+    codes = rand_codes(rng, 120000, 16)
+    idx = pyqadc.Index(16)
+    idx.add_partitions([codes])
+    idx.finalize(0.01)
+    tables = float_tables(rng, 3, 1, 16)
+    idx.submit(0, np.zeros((3, 1), np.int32), tables.copy(), 100)
+    res = idx.collect_candidates(0, capacity=8)            # far too small: E_CAPACITY, then the retry path
+    for q in range(3):
+        a, b = int(res["offsets"][q]), int(res["offsets"][q + 1])
+        want = po.query_scan(16, [codes], None, 0.01, [0], tables[q].copy(), 100)
+        assert heaps_equal(pyqadc.replay_i8(res["keys"][a:b], res["vals"][a:b], 100, sentinel=True),
+                           (want["keys"], want["values"]))
+    idx.close()
