@@ -197,7 +197,8 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
 typedef struct qadc_profile {
     uint64_t scan_launches;   /* launches of the streaming int8 scan kernel (scan_i8_kernel) */
     uint64_t scan_codes;      /* codes those launches scanned (algorithmic bytes = codes * M/2) */
-    double scan_ms;           /* sum of their HIP-event durations */
+    double scan_ms;           /* HIP-event time of those launches (one event pair per run of consecutive launches,
+                                 i.e. including the ~2 us hand-over between them) */
     uint64_t small_launches;  /* launches of the small-run int8 scan kernel (scan_i8_small_kernel): counted, */
     uint64_t small_codes;     /* not event-timed (an event pair costs as much stream time as such a launch) */
     double small_ms;          /* always 0; per-kernel times of these launches come from rocprofv3 */

@@ -426,18 +426,22 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     }
 
     // ---- scan levels ------------------------------------------------------------------------
-    // HIP events cost a few microseconds of stream time each: with profiling on, only the streaming-kernel
-    // launches (the roofline figure) are bracketed individually; the small-run launches share one pair
-    for (auto& ll : s.launches) {
+    // HIP events cost ~10 us of stream time each: with profiling on, every run of consecutive streaming-kernel
+    // launches (the roofline figure) shares ONE event pair; small-run launches are counted, not timed
+    for (size_t li = 0; li < s.launches.size(); ++li) {
+        LevelLaunch& ll = s.launches[li];
         const bool timed = idx->profile && !ll.small;
-        if (timed) { ll.ev = (int)s.prof_used; HIPCHECK(prof_event(s, st)); }
+        const bool group_start = timed && (li == 0 || s.launches[li - 1].small);
+        const bool group_end = timed && (li + 1 == s.launches.size() || s.launches[li + 1].small);
+        ll.ev = -1;
+        if (group_start) { ll.ev = (int)s.prof_used; HIPCHECK(prof_event(s, st)); }
         if (ll.small)
             launch_scan_i8_small(M, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p, s.d_cands.p,
                                  s.cap_q, (uint32_t)s.R, st);
         else
             launch_scan_i8(M, idx->variant, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p,
                            s.d_cands.p, s.cap_q, (uint32_t)s.R, st);
-        if (timed) HIPCHECK(prof_event(s, st));
+        if (group_end) HIPCHECK(prof_event(s, st));
     }
     // the ordering pass and the result copies run on a side stream: they only occupy nq CUs, and the main
     // stream is free to start the next batch's kernels meanwhile (it uses the other slot's buffers)
@@ -608,11 +612,11 @@ int collect_common(qadc_index* idx, int slot_i) {
                 idx->prof.small_codes += ll.codes;
                 continue;
             }
-            if (ll.ev < 0 || (size_t)ll.ev + 1 >= s.prof_used) continue;
-            HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[ll.ev], s.prof_ev[ll.ev + 1]));
-            idx->prof.scan_ms += ms;
             idx->prof.scan_launches++;
             idx->prof.scan_codes += ll.codes;
+            if (ll.ev < 0 || (size_t)ll.ev + 1 >= s.prof_used) continue;   // not the first launch of its timed group
+            HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[ll.ev], s.prof_ev[ll.ev + 1]));
+            idx->prof.scan_ms += ms;
         }
         if (s.float_path) idx->prof.start_codes += s.start_codes;
     }

@@ -749,9 +749,20 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
         const uint32_t dmask = (1u << (hi - lo)) - 1u;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += 1024) {
-            const uint32_t key = fkey(src[i]) - kmin;
-            if (hi >= 32 || ((key ^ prefix) >> hi) == 0) atomicAdd(&hist[(key >> lo) & dmask], 1u);
+        // 8 independent loads per thread and iteration: the loop is latency-bound otherwise (one workgroup)
+        for (uint32_t i0 = tid; i0 < n; i0 += 8 * 1024) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + u * 1024;
+                v[u] = i < n ? src[i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u * 1024 >= n) continue;
+                const uint32_t key = fkey(v[u]) - kmin;
+                if (hi >= 32 || ((key ^ prefix) >> hi) == 0) atomicAdd(&hist[(key >> lo) & dmask], 1u);
+            }
         }
         __syncthreads();
         if (tid < 64) {                                    // wave 0: 4 bins per lane, inclusive scan, pick the digit
