@@ -94,7 +94,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev if backend == "nccl" else torch.device("cpu")   # device of the collective buffers
-    if world > 1:
+    # QADC_BENCH_FORCE_DIST=1 takes the multi-rank code path (collectives included) even with one rank
+    use_dist = world > 1 or bool(os.environ.get("QADC_BENCH_FORCE_DIST"))
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -114,7 +116,7 @@ def main():
     assign = np.zeros((NQ, 1), np.int32)
 
     def finish(step_res):
-        if world == 1:
+        if not use_dist:
             return step_res
         return sharded.merge_batch(step_res, NQ, R, step_res["status"], cdev)
 
@@ -126,14 +128,14 @@ def main():
             tb = pool[s % len(pool)].copy()
             idx.submit(s % 2, assign, tb, R)
             if pending is not None:
-                last = finish(idx.collect(pending) if world == 1 else idx.collect_candidates(pending))
+                last = finish(idx.collect_candidates(pending) if use_dist else idx.collect(pending))
             pending = s % 2
         if pending is not None:
-            last = finish(idx.collect(pending) if world == 1 else idx.collect_candidates(pending))
+            last = finish(idx.collect_candidates(pending) if use_dist else idx.collect(pending))
         return last
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +146,7 @@ def main():
     last = run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -152,11 +154,11 @@ def main():
 
     # ---- Recall@100 against the exact float-ADC nearest code, last batch, untimed ----
     tb = pool[(args.steps - 1) % len(pool)]
-    keys = last["keys"] if world == 1 else last[0]
+    keys = last[0] if use_dist else last["keys"]
     hits = 0
     for q in range(NQ):
         key, _, dist_q = idx.float_top1(0, tb[q, 0])
-        if world > 1:
+        if use_dist:
             cand = torch.tensor([dist_q, float(key)], dtype=torch.float64, device=cdev)
             allc = torch.empty(2 * world, dtype=torch.float64, device=cdev)
             dist.all_gather_into_tensor(allc, cand)
@@ -199,7 +201,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(M, N, SEED, res["qtables"][:, 0], R, cpu_s)
         print(json.dumps(out), flush=True)
     idx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
