@@ -426,6 +426,11 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     }
 
     // ---- scan levels ------------------------------------------------------------------------
+    // a database that fits the 256 MiB Infinity Cache is re-read from it by every query: keep the default
+    // cache policy there; non-temporal loads only pay for lists that stream from HBM anyway
+    uint64_t db_bytes = 0;
+    for (auto& p : idx->parts) db_bytes += (uint64_t)p.n * cs;
+    const int variant = db_bytes <= (200ull << 20) ? (idx->variant & ~4) : idx->variant;
     // HIP events cost ~10 us of stream time each: with profiling on, every run of consecutive streaming-kernel
     // launches (the roofline figure) shares ONE event pair; small-run launches are counted, not timed
     for (size_t li = 0; li < s.launches.size(); ++li) {
@@ -439,7 +444,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             launch_scan_i8_small(M, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p, s.d_cands.p,
                                  s.cap_q, (uint32_t)s.R, st);
         else
-            launch_scan_i8(M, idx->variant, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p,
+            launch_scan_i8(M, variant, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p,
                            s.d_cands.p, s.cap_q, (uint32_t)s.R, st);
         if (group_end) HIPCHECK(prof_event(s, st));
     }
