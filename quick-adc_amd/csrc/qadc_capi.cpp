@@ -354,7 +354,12 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                 const uint64_t want = std::max<uint64_t>(1, 4096 / cnt);
                 ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + idx->small_vec_per_wg - 1) / idx->small_vec_per_wg, 1), want);
             }
-            else ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + 4095) / 4096, 1), (uint64_t)wgs_cap);
+            else {
+                // each streaming workgroup builds a 64-128 KiB table: with many runs in the launch, give every
+                // workgroup more tiles instead of more workgroups per run
+                const uint64_t want = std::max<uint64_t>(1, 8192 / cnt);
+                ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + 4095) / 4096, 1), std::min<uint64_t>(wgs_cap, want));
+            }
             ll.codes = codes;
             s.launches.push_back(ll);
             off += cnt;
@@ -701,7 +706,7 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
     const uint64_t pushes = s.out_off[s.nq];
     int nt = idx->replay_threads > 0 ? idx->replay_threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 8);
     nt = std::max(1, std::min(nt, s.nq / 16));
-    if (pushes < 200000) nt = 1;
+    if (pushes < 50000) nt = 1;
     if (nt == 1) {
         work(0, s.nq);
     } else {
