@@ -203,8 +203,59 @@ struct nns_engine {  // query_common.hpp:245-309
     }
 };
 
+// nns_engine_batch (query_common.hpp:149-243): tables of `batch` queries are prepared together when the first
+// query of a batch is asked for; here the scanner also scans the whole batch in one GPU call at that point
+// (scanner.batch_scan) and the per-query calls only replay the cached candidate stream, so the reference's
+// per-query process_queries<> loop drives a batched GPU scan unchanged.
+template <typename Db, typename Scanner>
+struct nns_engine_batch {
+    Db& db;
+    Scanner& scanner;
+    int ma, batch, table_dim, r;
+    std::vector<float> residuals, dists;
+    std::vector<int> assign;
+    nns_engine_batch(Scanner& s, Db& d, int ma_, int batch_, int r_)
+        : db(d), scanner(s), ma(ma_), batch(batch_), table_dim(d.pq->sq_count * 16), r(r_),
+          residuals((size_t)batch_ * ma_ * d.pq->dim), dists((size_t)batch_ * ma_ * d.pq->sq_count * 16),
+          assign((size_t)batch_ * ma_) {}
+    void prepare_database() { scanner.prepare_database(db); }
+    template <typename Heap>
+    void process_query(int query_i, const float* queries, int count, Heap& bh, query_metrics& metrics) {
+        const int dim = db.pq->dim;
+        const int b = query_i % batch;
+        metrics = query_metrics();
+        if (b == 0) {
+            const int nb = std::min(batch, count - query_i);
+            const std::uint64_t t0 = ustime();
+            for (int i = 0; i < nb; ++i)
+                db.assign_compute_residuals(queries + (size_t)(query_i + i) * dim, ma, assign.data() + (size_t)i * ma,
+                                            residuals.data() + (size_t)i * ma * dim);
+            const std::uint64_t t1 = ustime();
+            for (int i = 0; i < nb * ma; ++i) db.pq->tables(residuals.data() + (size_t)i * dim, dists.data() + (size_t)i * table_dim);
+            const std::uint64_t t2 = ustime();
+            scanner.batch_scan(nb, assign.data(), ma, dists.data(), table_dim, r);
+            metrics.scan_us = ustime() - t2;
+            metrics.table_us = t2 - t1;
+            metrics.index_us = t1 - t0;
+        }
+        const std::uint64_t t3 = ustime();
+        scanner.batch_replay(b, bh);
+        metrics.scan_us += ustime() - t3;
+    }
+};
+
 // query_common.hpp:330-368.  groundtruth[q] = id of the true nearest neighbour; recall@R counts the queries
 // whose true neighbour is among keys()[0..R) — read unsorted and up to R even if the heap is not full.
+template <typename Db, typename Scanner, typename Heap>
+inline void call_engine(nns_engine<Db, Scanner>& e, int q, const float* queries, int, int dim, Heap& bh, query_metrics& m) {
+    e.process_query(queries + (size_t)q * dim, bh, m);
+}
+template <typename Db, typename Scanner, typename Heap>
+inline void call_engine(nns_engine_batch<Db, Scanner>& e, int q, const float* queries, int count, int, Heap& bh,
+                        query_metrics& m) {
+    e.process_query(q, queries, count, bh, m);
+}
+
 template <typename Engine, typename Heap>
 void process_queries(Engine& engine, const float* queries, int count, int dim, int r, const unsigned* groundtruth,
                      query_metrics& total_metrics, double& total_recall) {
@@ -214,7 +265,7 @@ void process_queries(Engine& engine, const float* queries, int count, int dim, i
     for (int q = 0; q < count; ++q) {
         Heap bh(r);
         query_metrics metrics;
-        engine.process_query(queries + (size_t)q * dim, bh, metrics);
+        call_engine(engine, q, queries, count, dim, bh, metrics);
         if (bh.size() != r) std::cerr << " WARNING: Binheap not full" << std::endl;
         const unsigned* k = bh.keys();
         total_recall += std::find(k, k + bh.size(), groundtruth[q]) != k + bh.size() ? 1 : 0;

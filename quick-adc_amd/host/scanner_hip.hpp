@@ -95,6 +95,41 @@ struct scanner_hip {
         bh.push(0, 127);  // db_query_4.cpp:276
         for (std::uint64_t i = offsets[0]; i < offsets[1]; ++i) bh.push(cand_keys[i], cand_vals[i]);
     }
+
+    // Batched form for nns_engine_batch-style callers (query_common.hpp:149-243): the whole batch is scanned by
+    // ONE call (tables [nq][ma][table_dim], assign [nq][ma]); batch_replay(q, bh) then fills query q's heap
+    // exactly as query_scan would have.  R = heap capacity the caller will use.
+    std::vector<std::uint64_t> batch_offsets;
+    std::vector<std::int32_t> batch_status;
+
+    void batch_scan(int nq, int* assign, int ma, float* tables, int /*table_dim*/, int R) {
+        batch_offsets.assign((std::size_t)nq + 1, 0);
+        batch_status.assign(nq, 0);
+        if (cand_keys.empty()) {
+            cand_keys.resize(1 << 16);
+            cand_vals.resize(1 << 16);
+        }
+        int rc = qadc_query_scan_submit(index, 0, nq, ma, assign, tables, R);
+        if (rc == QADC_OK)
+            rc = qadc_query_scan_collect_candidates(index, 0, cand_keys.size(), cand_keys.data(), cand_vals.data(),
+                                                    batch_offsets.data(), batch_status.data(), nullptr, nullptr);
+        if (rc == QADC_E_CAPACITY) {  // the result is kept: fetch it again with buffers of the required size
+            cand_keys.resize(batch_offsets[nq]);
+            cand_vals.resize(batch_offsets[nq]);
+            rc = qadc_query_scan_collect_candidates(index, 0, cand_keys.size(), cand_keys.data(), cand_vals.data(),
+                                                    batch_offsets.data(), batch_status.data(), nullptr, nullptr);
+        }
+        if (rc != QADC_OK) die("batch_scan");
+    }
+
+    void batch_replay(int q, BhType& bh) {
+        if (batch_status[q] != 0) {  // db_query_4.cpp:271-274
+            std::cerr << "Warning: Max quantization bound too high. Try larger keep value." << std::endl;
+            std::exit(1);
+        }
+        bh.push(0, 127);  // db_query_4.cpp:276
+        for (std::uint64_t i = batch_offsets[q]; i < batch_offsets[q + 1]; ++i) bh.push(cand_keys[i], cand_vals[i]);
+    }
 };
 
 }  // namespace qadc

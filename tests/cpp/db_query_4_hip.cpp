@@ -3,7 +3,7 @@
 // -> per query: assign, tables (host) -> scanner_hip::query_scan (MI355X) -> recall@R against the exact
 // float nearest neighbour -> the reference's CSV line.  With --dump every query_scan call's inputs and
 // the resulting heap are written to a file so the Python test can replay them through the CPU oracle.
-//   usage: db_query_4_hip flat|ivf M N nq R keep_percent ma K seed [dumpfile]
+//   usage: db_query_4_hip flat|ivf M N nq R keep_percent ma K seed [dumpfile|-] [batch]
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -22,6 +22,27 @@ struct recording_scanner {
     std::ofstream* dump;
     recording_scanner(float keep, std::ofstream* d) : inner(keep, 0, /*free_host_partitions=*/false), dump(d) {}
     void prepare_database(Db& db) { inner.prepare_database(db); }
+    // batched form: remember the inputs of the batch, dump them query by query at replay time
+    std::vector<int> b_assign;
+    std::vector<float> b_tables;
+    int b_ma = 0, b_dim = 0;
+    void batch_scan(int nq, int* assign, int ma, float* tables, int table_dim, int R) {
+        b_assign.assign(assign, assign + (size_t)nq * ma);
+        b_tables.assign(tables, tables + (size_t)nq * ma * table_dim);
+        b_ma = ma;
+        b_dim = table_dim;
+        inner.batch_scan(nq, assign, ma, tables, table_dim, R);
+    }
+    void batch_replay(int q, BhType& bh) {
+        inner.batch_replay(q, bh);
+        if (!dump) return;
+        const int sz = bh.size();
+        dump->write(reinterpret_cast<const char*>(b_assign.data() + (size_t)q * b_ma), sizeof(int) * b_ma);
+        dump->write(reinterpret_cast<const char*>(b_tables.data() + (size_t)q * b_ma * b_dim), sizeof(float) * b_ma * b_dim);
+        dump->write(reinterpret_cast<const char*>(&sz), sizeof(int));
+        dump->write(reinterpret_cast<const char*>(bh.keys()), sizeof(unsigned) * sz);
+        dump->write(reinterpret_cast<const char*>(bh.values()), sz);
+    }
     void query_scan(const float* q, int* assign, int ma, float* tables, int table_dim, BhType& bh, query_metrics& m) {
         std::vector<float> before(tables, tables + (size_t)ma * table_dim);
         inner.query_scan(q, assign, ma, tables, table_dim, bh, m);
@@ -52,16 +73,24 @@ static void dump_db(std::ofstream& f, Db& db, int M) {
     }
 }
 
+static int g_batch = 1;  // the CLI's -b (db_query_4.cpp:343)
+
 template <typename Db>
 static void run(Db& db, const std::vector<float>& queries, int nq, int dim, int R, float keep, int ma,
                 const std::vector<unsigned>& gt, std::ofstream* dump, int M) {
     if (dump) dump_db(*dump, db, M);
     recording_scanner<Db> scanner(keep, dump);
-    nns_engine<Db, recording_scanner<Db>> engine(scanner, db, ma);
     query_metrics metrics;
     double recall = 0;
-    process_queries<nns_engine<Db, recording_scanner<Db>>, typename recording_scanner<Db>::BhType>(
-        engine, queries.data(), nq, dim, R, gt.data(), metrics, recall);
+    if (g_batch != 1) {  // db_query_4.cpp:368-376
+        nns_engine_batch<Db, recording_scanner<Db>> engine(scanner, db, ma, g_batch, R);
+        process_queries<nns_engine_batch<Db, recording_scanner<Db>>, typename recording_scanner<Db>::BhType>(
+            engine, queries.data(), nq, dim, R, gt.data(), metrics, recall);
+    } else {
+        nns_engine<Db, recording_scanner<Db>> engine(scanner, db, ma);
+        process_queries<nns_engine<Db, recording_scanner<Db>>, typename recording_scanner<Db>::BhType>(
+            engine, queries.data(), nq, dim, R, gt.data(), metrics, recall);
+    }
     print_csv(std::cout, R, recall, ma, keep, metrics);
 }
 
@@ -79,7 +108,8 @@ int main(int argc, char** argv) {
     const unsigned seed = (unsigned)std::atol(argv[9]);
     const int dim = 128;
     std::ofstream dumpf;
-    if (argc > 10) dumpf.open(argv[10], std::ios::binary);
+    if (argc > 10 && std::string(argv[10]) != "-") dumpf.open(argv[10], std::ios::binary);
+    if (argc > 11) g_batch = std::atoi(argv[11]);
 
     // clustered synthetic vectors: 2000 centres ~ 3*N(0,1), points = centre + N(0,1)
     std::mt19937 rng(seed);

@@ -126,3 +126,26 @@ def test_db_query_4_driver_end_to_end(po, tmp_path, mode, M, N, ma, K, keep_pct)
         want = po.query_scan(M, parts, labels, keep, assign, np.ascontiguousarray(tables.reshape(ma, M * 16)), R)
         assert want["rc"] == 0
         assert np.array_equal(keys, want["keys"]) and np.array_equal(vals, want["values"]), (mode, M, q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,M,N,ma,K", [("flat", 16, 50000, 1, 0), ("ivf", 16, 50000, 5, 40)])
+def test_batched_engine_equals_per_query_engine(po, tmp_path, mode, M, N, ma, K):
+    """nns_engine_batch-style driving (-b 5: one GPU call per 5 queries, per-query replay of the cached
+    streams, last batch ragged) leaves exactly the heaps of the per-query engine and of the oracle."""
+    build_driver()
+    nq, R, keep_pct = 13, 100, 3.0
+    dumps = []
+    for batch in (1, 5):
+        dump = str(tmp_path / ("dump%d.bin" % batch))
+        out = subprocess.check_output([DRIVER, mode, str(M), str(N), str(nq), str(R), str(keep_pct), str(ma), str(K), "11",
+                                       dump, str(batch)]).decode().strip().split("\n")
+        assert out[-2].startswith("r,recall,ma,adc_type,keep")
+        dumps.append(_parse_dump(dump, M, ma, nq))
+    (parts, labels, q1), (_, _, q5) = dumps
+    keep = float(np.float32(keep_pct) * np.float32(0.01))
+    for q in range(nq):
+        assert np.array_equal(q1[q][0], q5[q][0]) and np.array_equal(q1[q][1], q5[q][1])        # same inputs
+        assert np.array_equal(q1[q][2], q5[q][2]) and np.array_equal(q1[q][3], q5[q][3]), q     # same heaps
+        want = po.query_scan(M, parts, labels, keep, q5[q][0], np.ascontiguousarray(q5[q][1].reshape(ma, M * 16)), R)
+        assert np.array_equal(q5[q][2], want["keys"]) and np.array_equal(q5[q][3], want["values"]), q
