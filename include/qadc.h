@@ -86,8 +86,10 @@ int qadc_index_partition_count(const qadc_index* idx);
 uint32_t qadc_index_partition_size(const qadc_index* idx, int part);
 uint32_t qadc_index_start_size(const qadc_index* idx, int part);
 
-/* Tunables: "quant_mode" (1 = as compiled by the reference's flags, 0 = source level),
- * "cand_capacity", "level_base", "level_growth", "wgs_per_item", "profile" (0/1). */
+/* Tunables: "quant_mode" (1 = as compiled by the reference's flags, 0 = source level), "profile" (0/1),
+ * "cand_capacity" (candidate region entries per query), "level_base", "level_growth" (bound levels),
+ * "prescan_sample", "small_run", "small_vec_per_wg", "wgs_per_item", "variant" (kernel tuning),
+ * "replay_threads". */
 int qadc_set_option(qadc_index* idx, const char* name, double value);
 
 /* Copy codes back (tests / checksums): partition `part`, codes [first, first+count). */

@@ -3,9 +3,9 @@
 // Mirrors scanner_4 (db_query_4.cpp:73-310): prepare (upload partitions, starts sizes) and
 // query_scan (float pre-scan -> qmax, qmin/clamp, int8 quantization, scan of every probed
 // partition in assign order into one heap).  All per-query arithmetic runs on the GPU in one
-// stream-ordered chain (no host round trip between pre-scan, quantizer and scan); the host only
-// plans the work items, sorts the returned candidates into scan order and replays them through
-// a heap with the reference's push semantics (host/qadc_heap.hpp).
+// stream-ordered chain (no host round trip between pre-scan, quantizer, scan and the ordering of the
+// candidates); the host only plans the work items and replays the returned, already ordered candidate
+// streams through a heap with the reference's push semantics (host/qadc_heap.hpp).
 //
 // The product path never touches oracle/: if the HIP runtime or the GPU is missing every entry
 // point fails loudly with QADC_E_HIP.
