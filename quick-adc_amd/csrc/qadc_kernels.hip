@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
 // spans 64 dwords = 2 per bank, so a lookup is at worst a 2-way bank conflict; that costs LDS cycles
 // the streaming kernel cannot afford at 6 TB/s but a run of a few 10^4 codes is latency-bound anyway.
 // ---------------------------------------------------------------------------------------------
-template <int M>
+template <int M, int SU>
 __global__ __launch_bounds__(256) void scan_i8_small_kernel(const ScanItem* __restrict__ items,
                                                             const int8_t* __restrict__ qtables,
                                                             QueryState* __restrict__ qstates, CandHeader* __restrict__ hdr,
@@ -306,20 +306,20 @@ __global__ __launch_bounds__(256) void scan_i8_small_kernel(const ScanItem* __re
     const uint32_t n = it.n;
     const uint32_t nvec = (n + CPL - 1) / CPL;
     const uint32_t stride = gridDim.x * 256;
-    for (uint32_t e0 = blockIdx.x * 256 + tid; e0 < nvec; e0 += 2 * stride) {
-        u32x4 v[2];
-        uint32_t e[2];
+    for (uint32_t e0 = blockIdx.x * 256 + tid; e0 < nvec; e0 += SU * stride) {
+        u32x4 v[SU];
+        uint32_t e[SU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < SU; ++u) {
             e[u] = e0 + u * stride;
             v[u] = u32x4{0, 0, 0, 0};
             if (e[u] < nvec) v[u] = __builtin_nontemporal_load(src + e[u]);
             else e[u] = 0xffffffffu;
         }
-        uint32_t cand[2 * CPL];
+        uint32_t cand[SU * CPL];
         uint32_t best = 127u;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < SU; ++u) {
             const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void scan_i8_small_kernel(const ScanItem* __re
         }
         if (__builtin_expect(best < bound, 0)) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < SU; ++u)
 #pragma unroll
                 for (int c = 0; c < CPL; ++c)
                     if (cand[u * CPL + c] < bound)
@@ -350,8 +350,9 @@ void launch_scan_i8_small(int M, const ScanItem* d_items, int nitems, int wgs_pe
                           QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cap_per_query, uint32_t R,
                           hipStream_t stream) {
     const dim3 grid(wgs_per_item, nitems), block(256);
-    if (M == 16) hipLaunchKernelGGL(scan_i8_small_kernel<16>, grid, block, 0, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cap_per_query, R);
-    else         hipLaunchKernelGGL(scan_i8_small_kernel<32>, grid, block, 0, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cap_per_query, R);
+    // 4 vectors (64 B) in flight per lane: these runs are latency-bound
+    if (M == 16) hipLaunchKernelGGL((scan_i8_small_kernel<16, 4>), grid, block, 0, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cap_per_query, R);
+    else         hipLaunchKernelGGL((scan_i8_small_kernel<32, 4>), grid, block, 0, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cap_per_query, R);
 }
 
 template <int M, int U, bool NT, bool CHUNK, bool PROBE, bool PF>
@@ -853,25 +854,44 @@ void launch_quantize(int M, int ma, int nq, float* d_ftables, int8_t* d_qtables,
 // Plain sequential float arithmetic (no FMA contraction), so a host evaluation of the same loops
 // (host/query_driver.hpp) gives identical bits.
 // ---------------------------------------------------------------------------------------------
+// KPT = centroids per thread kept in registers (K <= 256 * KPT); KPT == 0: distances live in the global scratch.
+// Every thread accumulates ITS centroid's dimensions in ascending order (bit-exact with the host loop); a
+// thread walks one row sequentially, so each cache line it touches is reused 16 times from L1 and the K x dim
+// matrix (shared by every query's workgroup) stays in L2.
+template <int KPT>
 __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restrict__ queries,
                                                             const float* __restrict__ coarse, int K, int dim, int ma,
                                                             float* __restrict__ dist, int32_t* __restrict__ assign) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     float* q = reinterpret_cast<float*>(dyn);                 // [dim]
-    __shared__ float rv[256];
-    __shared__ int rk[256];
+    __shared__ float rv[4];
+    __shared__ int rk[4];
     const int qi = blockIdx.x, tid = threadIdx.x;
     for (int d = tid; d < dim; d += 256) q[d] = queries[(size_t)qi * dim + d];
     __syncthreads();
     float* __restrict__ dq = dist + (size_t)qi * K;
-    for (int k = tid; k < K; k += 256) {
+    constexpr int NR = KPT > 0 ? KPT : 1;
+    float mine[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) mine[j] = FLT_MAX;
+    const int nblk = (K + 255) / 256;
+    auto row_dist = [&](int k) {
         const float* __restrict__ c = coarse + (size_t)k * dim;
         float s = 0.0f;
         for (int d = 0; d < dim; ++d) {
             const float t = q[d] - c[d];
             s += t * t;
         }
-        dq[k] = s;
+        return s;
+    };
+    if (KPT > 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int k = j * 256 + tid;
+            if (j < nblk && k < K) mine[j] = row_dist(k);
+        }
+    } else {
+        for (int k = tid; k < K; k += 256) dq[k] = row_dist(k);
     }
     __syncthreads();
     // ma rounds of "smallest (distance, index) strictly after the previous pick"
@@ -880,24 +900,37 @@ __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restr
     for (int a = 0; a < ma; ++a) {
         float bv = FLT_MAX;
         int bk = 0x7fffffff;
-        for (int k = tid; k < K; k += 256) {
-            const float v = dq[k];
-            const bool after = v > last_v || (v == last_v && k > last_k);
-            if (after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
-        }
-        rv[tid] = bv;
-        rk[tid] = bk;
-        __syncthreads();
-        for (int st = 128; st >= 1; st >>= 1) {
-            if (tid < st) {
-                const float ov = rv[tid + st];
-                const int ok = rk[tid + st];
-                if (ov < rv[tid] || (ov == rv[tid] && ok < rk[tid])) { rv[tid] = ov; rk[tid] = ok; }
+        if (KPT > 0) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int k = j * 256 + tid;
+                const float v = mine[j];
+                const bool after = v > last_v || (v == last_v && k > last_k);
+                if (k < K && after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
             }
-            __syncthreads();
+        } else {
+            for (int k = tid; k < K; k += 256) {
+                const float v = dq[k];
+                const bool after = v > last_v || (v == last_v && k > last_k);
+                if (after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
+            }
         }
-        last_v = rv[0];
-        last_k = rk[0];
+        // wave-level reduction first (no barrier), then across the 4 waves through LDS
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(bv, d, 64);
+            const int ok = __shfl_xor(bk, d, 64);
+            if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+        }
+        if ((tid & 63) == 0) { rv[tid >> 6] = bv; rk[tid >> 6] = bk; }
+        __syncthreads();
+        bv = rv[0];
+        bk = rk[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (rv[w] < bv || (rv[w] == bv && rk[w] < bk)) { bv = rv[w]; bk = rk[w]; }
+        last_v = bv;
+        last_k = bk;
         if (tid == 0) assign[(size_t)qi * ma + a] = last_k;
         __syncthreads();
     }
@@ -905,8 +938,14 @@ __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restr
 
 void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
                           int32_t* d_assign, hipStream_t stream) {
-    hipLaunchKernelGGL(coarse_assign_kernel, dim3(nq), dim3(256), dim * sizeof(float), stream, d_queries, d_coarse, K, dim, ma,
-                       d_dist, d_assign);
+    const size_t lds = (size_t)dim * sizeof(float);
+    const int kpt = (K + 255) / 256;
+#define QADC_CA(N) hipLaunchKernelGGL(coarse_assign_kernel<N>, dim3(nq), dim3(256), lds, stream, d_queries, d_coarse, K, dim, ma, d_dist, d_assign)
+    if (kpt <= 4) QADC_CA(4);
+    else if (kpt <= 16) QADC_CA(16);
+    else if (kpt <= 32) QADC_CA(32);
+    else QADC_CA(0);
+#undef QADC_CA
 }
 
 __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
