@@ -398,18 +398,73 @@ void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// Device-side ordering of the candidates: the host replay needs them in scan order.
-// key = (level:4 | assign slot:14) << 46 | position << 14 | index in the query's region.
+// Device-side ordering of the candidates: the host replay needs them in scan order
+// (level, assign slot, position).  A query's region is already grouped by level — slots are handed
+// out by an atomic counter and the levels are separate, stream-ordered launches — so each level's
+// segment (<= R * growth entries, typically a few hundred) is sorted by ONE WAVE with a barrier-free
+// bitonic network in its own LDS slice, all levels concurrently.  Segments above 512 entries fall
+// back to a workgroup-wide bitonic sort of the whole region.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSegCap = 512;                        // entries one wave sorts: 4 KiB keys + 4 KiB payload per wave
+
+__device__ __forceinline__ uint64_t cand_sort_key(const Cand& c, uint32_t idx) {
+    const uint64_t ord = ((uint64_t)((c.order >> 16) & 15u) << 14) | (c.order & 0x3fffu);
+    return (ord << 46) | ((uint64_t)c.pos << 14) | idx;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in order; this only stops the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Bitonic sort of 512 u64 keys held by one wave, 8 per lane, element e = r*64 + lane.  Exchanges at distance
+// >= 64 are register swaps inside a lane, shorter ones are wave shuffles: no LDS round trips, no barriers.
+__device__ __forceinline__ void wave_sort512(uint64_t (&v)[8], uint32_t lane) {
+#pragma unroll
+    for (uint32_t k = 2; k <= 512; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const uint32_t jr = j >> 6;
+#pragma unroll
+                for (uint32_t r = 0; r < 8; ++r) {
+                    if ((r & jr) == 0) {
+                        const bool asc = (((r << 6) | lane) & k) == 0;
+                        const uint64_t a = v[r], b = v[r | jr];
+                        const bool sw = (a > b) == asc;
+                        v[r] = sw ? b : a;
+                        v[r | jr] = sw ? a : b;
+                    }
+                }
+            } else {
+                const bool lower = (lane & j) == 0;
+#pragma unroll
+                for (uint32_t r = 0; r < 8; ++r) {
+                    const bool asc = (((r << 6) | lane) & k) == 0;
+                    const uint64_t a = v[r];
+                    const uint64_t b = ((uint64_t)__shfl_xor((uint32_t)(a >> 32), j, 64) << 32) | __shfl_xor((uint32_t)a, j, 64);
+                    const bool keep_min = lower == asc;
+                    v[r] = keep_min ? (a < b ? a : b) : (a > b ? a : b);
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict__ qstates, const Cand* __restrict__ cands,
                                                           uint32_t cap, int nq, uint32_t* __restrict__ out_keys,
                                                           int8_t* __restrict__ out_vals, uint32_t out_cap,
                                                           CandHeader* __restrict__ hdr) {
     // all LDS in the dynamic region (keeps the 8-byte key array naturally aligned)
     uint64_t* lkey = reinterpret_cast<uint64_t*>(smem);
-    uint32_t* scan = reinterpret_cast<uint32_t*>(smem + kSortCap * 8);
+    uint32_t* scan = reinterpret_cast<uint32_t*>(smem + kSortCap * 8);   // [1024] + misc
     uint32_t& s_off = scan[1024];
-    const int q = blockIdx.x, tid = threadIdx.x;
+    uint32_t* seg_cnt = scan + 1025;                         // [16]
+    uint32_t* seg_off = scan + 1041;                         // [17]
+    uint32_t* seg_reps = scan + 1058;                        // [16] then exclusive prefix
+    uint32_t& s_fast = scan[1074];
+    const int q = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     QueryState* qs = qstates + q;
     const uint32_t n = qs->count;
     const uint32_t limit = min(cap, kSortCap);
@@ -421,27 +476,95 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
         if (c <= limit) part += c + qstates[p].reps;
     }
     scan[tid] = part;
+    // entries per level = sum of the level's value histogram (wave w <-> level w)
+    {
+        uint32_t c = qs->hist[wave * 128 + lane] + qs->hist[wave * 128 + 64 + lane];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+        if (lane == 0) seg_cnt[wave] = c;
+    }
     __syncthreads();
     for (int d = 512; d >= 1; d >>= 1) {
         if (tid < d) scan[tid] += scan[tid + d];
         __syncthreads();
     }
-    if (tid == 0) s_off = scan[0];
+    if (tid == 0) {
+        s_off = scan[0];
+        uint32_t run = 0, fast = 1;
+        for (int l = 0; l < kMaxLevels; ++l) {
+            seg_off[l] = run;
+            run += seg_cnt[l];
+            if (seg_cnt[l] > kSegCap) fast = 0;
+        }
+        seg_off[kMaxLevels] = run;
+        s_fast = (fast && run == n) ? 1u : 0u;
+    }
     __syncthreads();
     const uint32_t off = s_off;
-    __syncthreads();
+    const Cand* __restrict__ region = cands + (uint64_t)q * cap;
+
+    if (s_fast) {
+        // ---- one wave per level segment, no workgroup barriers in the sort ----
+        uint64_t* wkey = lkey + (size_t)wave * (2 * kSegCap);   // [kSegCap] sort keys
+        uint64_t* wpay = wkey + kSegCap;                          // [kSegCap] payload: key | (val | replays << 8) << 32
+        const uint32_t s0 = seg_off[wave], ns = seg_cnt[wave];
+        // keys in registers (element e = r*64 + lane), payload in LDS indexed by the entry's position in the segment
+        uint64_t v[8];
+#pragma unroll
+        for (uint32_t r = 0; r < 8; ++r) {
+            const uint32_t i = r * 64 + lane;
+            uint64_t k = ~0ull;
+            if (i < ns) {
+                const Cand c = region[s0 + i];
+                k = cand_sort_key(c, i);
+                wpay[i] = (uint64_t)c.key | ((uint64_t)(c.val | (((c.order >> 20) & 15u) << 8)) << 32);
+            }
+            v[r] = k;
+        }
+        if (ns > 1) wave_sort512(v, lane);
+#pragma unroll
+        for (uint32_t r = 0; r < 8; ++r) wkey[r * 64 + lane] = v[r];
+        wave_lds_sync();
+        const uint32_t n2 = 512;
+        // padding-lane replays: lane owns sorted entries [lane*chunk, (lane+1)*chunk) of the segment
+        const uint32_t chunk = n2 / 64;
+        const uint32_t b0 = min(ns, lane * chunk), b1 = min(ns, (lane + 1) * chunk);
+        uint32_t myreps = 0;
+        for (uint32_t i = b0; i < b1; ++i) myreps += (uint32_t)(wpay[wkey[i] & 0x3fffu] >> 40) & 15u;
+        uint32_t incl = myreps;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) seg_reps[wave] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int l = 0; l < kMaxLevels; ++l) {
+                const uint32_t r = seg_reps[l];
+                seg_reps[l] = run;
+                run += r;
+            }
+        }
+        __syncthreads();
+        uint32_t w = off + s0 + seg_reps[wave] + b0 + (incl - myreps);
+        for (uint32_t i = b0; i < b1; ++i) {
+            const uint64_t pay = wpay[wkey[i] & 0x3fffu];
+            const uint32_t reps = 1u + ((uint32_t)(pay >> 40) & 15u);
+            for (uint32_t r = 0; r < reps; ++r, ++w) {
+                if (w < out_cap) { out_keys[w] = (uint32_t)pay; out_vals[w] = (int8_t)((pay >> 32) & 0xffu); }
+                else atomicAdd(&hdr->out_overflow, 1u);
+            }
+        }
+        if (tid == 0) { qs->out_off = off; qs->flags |= 4u; }
+        return;
+    }
+
+    // ---- fallback: workgroup-wide bitonic sort of the whole region ----
     uint32_t n2 = 1;
     while (n2 < n) n2 <<= 1;
-    const Cand* __restrict__ region = cands + (uint64_t)q * cap;
-    for (uint32_t i = tid; i < n2; i += 1024) {
-        uint64_t k = ~0ull;
-        if (i < n) {
-            const Cand c = region[i];
-            const uint64_t ord = ((uint64_t)((c.order >> 16) & 15u) << 14) | (c.order & 0x3fffu);
-            k = (ord << 46) | ((uint64_t)c.pos << 14) | i;
-        }
-        lkey[i] = k;
-    }
+    for (uint32_t i = tid; i < n2; i += 1024) lkey[i] = i < n ? cand_sort_key(region[i], i) : ~0ull;
     __syncthreads();
     for (uint32_t k = 2; k <= n2; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -482,9 +605,9 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
 void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, uint32_t* d_out_keys,
                        int8_t* d_out_vals, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream) {
     static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_cands_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 8 + 4112), true);
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 8 + 4352), true);
     (void)once;
-    hipLaunchKernelGGL(sort_cands_kernel, dim3(nq), dim3(1024), kSortCap * 8 + 4112, stream, d_qs, d_cands, cap_per_query, nq,
+    hipLaunchKernelGGL(sort_cands_kernel, dim3(nq), dim3(1024), kSortCap * 8 + 4352, stream, d_qs, d_cands, cap_per_query, nq,
                        d_out_keys, d_out_vals, out_cap, d_hdr);
 }
 

@@ -408,3 +408,24 @@ def test_collect_candidates_capacity_retry(pyqadc, po):
         assert heaps_equal(pyqadc.replay_i8(res["keys"][a:b], res["vals"][a:b], 100, sentinel=True),
                            (want["keys"], want["values"]))
     idx.close()
+
+
+def test_sort_paths_wave_segments_and_workgroup_fallback(pyqadc, po):
+    """Level segments up to 1024 candidates are ordered by one wave each; a bigger segment (here a 4096-code
+    first level that emits everything) takes the workgroup-wide sort.  Both must give the oracle's heap."""
+    rng = np.random.default_rng(19)
+    parts = [rand_codes(rng, 30011, 16), rand_codes(rng, 9000, 16)]
+    labels = [np.arange(30011, dtype=np.uint32)[::-1].copy(), np.arange(9000, dtype=np.uint32) + 50000]
+    idx = pyqadc.Index(16)
+    idx.add_partitions(parts, labels)
+    idx.finalize(0.01)
+    idx.set_option("profile", 1)
+    for base in (512, 4096):
+        idx.set_option("level_base", base)
+        qt = rand_qtables(rng, (3, 2), 16, 5)              # tie-heavy; nearly every code of level 0 is emitted
+        got = idx.scan_i8(np.array([[0, 1], [1, 0], [0, 1]], np.int32), qt, 100)
+        for q, order in enumerate(([0, 1], [1, 0], [0, 1])):
+            want = po.scan_i8(16, [parts[p] for p in order], [labels[p] for p in order], qt[q], 100)
+            assert heaps_equal(got[q], want), (base, q)
+    assert idx.profile()["host_sorted_queries"] == 0
+    idx.close()
