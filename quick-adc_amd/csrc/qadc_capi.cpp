@@ -117,29 +117,32 @@ struct Slot {
     uint32_t out_cap = 0;               // entries of the device-sorted output
     uint32_t prefetched = 0;
 
-    DevBuf<float> d_ftables;
+    // one upload block per batch: [ScanItem items][StartItem starts][u32 fc_init[2 nq]][float or int8 tables]
+    DevBuf<unsigned char> d_in;
+    PinBuf<unsigned char> h_in;
+    ScanItem* d_items = nullptr;
+    StartItem* d_sitems = nullptr;
+    uint32_t* d_fc_init = nullptr;
+    float* d_ftables_in = nullptr;      // float tables inside d_in (host-table path)
+    // one state block, cleared by ONE memset: [CandHeader (64 B)][QueryState[nq]]
+    DevBuf<unsigned char> d_state;
+    CandHeader* d_hdr = nullptr;
+    QueryState* d_qs = nullptr;
+    // one result block, fetched by ONE copy: [QueryOut[nq]][u64 entries[out_cap]]
+    DevBuf<unsigned char> d_result;
+    PinBuf<unsigned char> h_result;
+    QueryOut* d_qout = nullptr;
+    uint64_t* d_entries = nullptr;
+    QueryOut* h_qout = nullptr;
+    uint64_t* h_entries = nullptr;
+    DevBuf<float> d_ftables;            // float tables built on the device (qadc_search)
     DevBuf<int8_t> d_qtables;
-    DevBuf<QueryState> d_qs;
-    DevBuf<CandHeader> d_hdr;
     DevBuf<Cand> d_cands;
-    DevBuf<uint32_t> d_out_keys;
-    DevBuf<int8_t> d_out_vals;
-    DevBuf<ScanItem> d_items;
-    DevBuf<StartItem> d_sitems;
     DevBuf<float> d_fc;
-    DevBuf<uint32_t> d_fc_init;
 
-    PinBuf<ScanItem> h_items;
-    PinBuf<StartItem> h_sitems;
-    PinBuf<uint32_t> h_fc_init;
     bool full_prescan = false;          // survivor buffer overflowed: pre-scan everything unfiltered
-    PinBuf<float> h_ftables;
-    PinBuf<int8_t> h_qtables;
-    PinBuf<QueryState> h_qs;
     PinBuf<CandHeader> h_hdr;
     PinBuf<Cand> h_cands;               // host-sort fallback only
-    PinBuf<uint32_t> h_out_keys;
-    PinBuf<int8_t> h_out_vals;
     // device-side feeders (qadc_search): queries in, tables never leave the GPU
     bool device_tables = false;
     DevBuf<float> d_queries;
@@ -156,9 +159,8 @@ struct Slot {
     std::vector<hipEvent_t> prof_ev;    // pairs: [2i] before, [2i+1] after; pair 0 = pre-scan chain
     size_t prof_used = 0;
 
-    // collect() results
-    std::vector<uint32_t> out_keys;
-    std::vector<int8_t> out_vals;
+    // collect() results: ordered candidate streams, entry = key | (value << 32)
+    std::vector<uint64_t> out_entries;
     std::vector<uint64_t> out_off;
 };
 
@@ -243,7 +245,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     level_bounds(idx, L);
     std::vector<std::vector<ScanItem>> per_level(kMaxLevels);
     std::vector<StartItem> sitems_a, sitems_b;   // phase A: unfiltered sample, phase B: filtered remainder
-    HIPCHECK(s.h_fc_init.ensure(2 * (size_t)nq));
+    std::vector<uint32_t> fc_init(2 * (size_t)nq, 0);
     uint64_t fc_stride = 1;
     s.start_codes = 0;
     for (int q = 0; q < nq; ++q) {
@@ -320,14 +322,13 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         uint64_t cap = sample;
         if (sample < stotal)
             cap += std::min<uint64_t>(stotal - sample, std::max<uint64_t>(16ull * s.R * ((stotal + sample - 1) / sample), 4096));
-        s.h_fc_init.p[2 * q] = (uint32_t)sample;
-        s.h_fc_init.p[2 * q + 1] = (uint32_t)cap;
+        fc_init[2 * q] = (uint32_t)sample;
+        fc_init[2 * q + 1] = (uint32_t)cap;
         fc_stride = std::max<uint64_t>(fc_stride, cap);
     }
     size_t nitems = 0;
     for (auto& v : per_level) nitems += v.size();
-    HIPCHECK(s.h_items.ensure(nitems));
-    HIPCHECK(s.d_items.ensure(nitems));
+    std::vector<ScanItem> all_items(nitems);
     s.launches.clear();
     size_t off = 0;
     const int wgs_cap = idx->wgs_per_item > 0 ? idx->wgs_per_item : (M == 16 ? 512 : 256);
@@ -339,7 +340,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             size_t cnt = 0;
             for (auto& it : per_level[k]) {
                 if ((it.n < idx->small_run) != (small == 1)) continue;
-                s.h_items.p[off + cnt++] = it;
+                all_items[off + cnt++] = it;
                 maxn = std::max<uint64_t>(maxn, it.n);
                 codes += it.n;
             }
@@ -366,67 +367,79 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         }
     }
 
-    // ---- upload -----------------------------------------------------------------------------
-    HIPCHECK(s.d_qs.ensure(nq));
-    HIPCHECK(s.h_qs.ensure(nq));
-    HIPCHECK(s.d_hdr.ensure(1));
+    // ---- upload: ONE block, ONE copy ----------------------------------------------------------
+    const size_t nt = (size_t)nq * ma * table_dim;
+    const size_t na = sitems_a.size(), nb = sitems_b.size();
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t off_items = 0;
+    const size_t off_sitems = align16(off_items + nitems * sizeof(ScanItem));
+    const size_t off_init = align16(off_sitems + (na + nb) * sizeof(StartItem));
+    const size_t off_tables = align16(off_init + fc_init.size() * sizeof(uint32_t));
+    const size_t tables_bytes = s.float_path ? (s.device_tables ? 0 : nt * sizeof(float)) : nt;
+    const size_t in_bytes = align16(off_tables + tables_bytes);
+    HIPCHECK(s.h_in.ensure(in_bytes));
+    HIPCHECK(s.d_in.ensure(in_bytes));
+    if (nitems) std::memcpy(s.h_in.p + off_items, all_items.data(), nitems * sizeof(ScanItem));
+    if (na) std::memcpy(s.h_in.p + off_sitems, sitems_a.data(), na * sizeof(StartItem));
+    if (nb) std::memcpy(s.h_in.p + off_sitems + na * sizeof(StartItem), sitems_b.data(), nb * sizeof(StartItem));
+    std::memcpy(s.h_in.p + off_init, fc_init.data(), fc_init.size() * sizeof(uint32_t));
+    if (s.float_path && !s.device_tables) std::memcpy(s.h_in.p + off_tables, s.tables, nt * sizeof(float));
+    if (!s.float_path) std::memcpy(s.h_in.p + off_tables, s.qtables_in.data(), nt);
+    s.d_items = reinterpret_cast<ScanItem*>(s.d_in.p + off_items);
+    s.d_sitems = reinterpret_cast<StartItem*>(s.d_in.p + off_sitems);
+    s.d_fc_init = reinterpret_cast<uint32_t*>(s.d_in.p + off_init);
+    s.d_ftables_in = reinterpret_cast<float*>(s.d_in.p + off_tables);
+
+    // state block: [CandHeader, 64 B][QueryState[nq]]; result block: [QueryOut[nq]][u64 entries[out_cap]]
+    const size_t state_bytes = 64 + sizeof(QueryState) * (size_t)nq;
+    const size_t result_bytes = sizeof(QueryOut) * (size_t)nq + sizeof(uint64_t) * (size_t)s.out_cap;
+    HIPCHECK(s.d_state.ensure(state_bytes));
+    HIPCHECK(s.d_result.ensure(result_bytes));
+    HIPCHECK(s.h_result.ensure(result_bytes));
     HIPCHECK(s.h_hdr.ensure(1));
+    s.d_hdr = reinterpret_cast<CandHeader*>(s.d_state.p);
+    s.d_qs = reinterpret_cast<QueryState*>(s.d_state.p + 64);
+    s.d_qout = reinterpret_cast<QueryOut*>(s.d_result.p);
+    s.d_entries = reinterpret_cast<uint64_t*>(s.d_result.p + sizeof(QueryOut) * (size_t)nq);
+    s.h_qout = reinterpret_cast<QueryOut*>(s.h_result.p);
+    s.h_entries = reinterpret_cast<uint64_t*>(s.h_result.p + sizeof(QueryOut) * (size_t)nq);
     HIPCHECK(s.d_cands.ensure((size_t)nq * s.cap_q));
-    HIPCHECK(s.d_out_keys.ensure(s.out_cap));
-    HIPCHECK(s.d_out_vals.ensure(s.out_cap));
-    HIPCHECK(s.d_qtables.ensure((size_t)nq * ma * table_dim));
-    HIPCHECK(hipMemsetAsync(s.d_qs.p, 0, sizeof(QueryState) * nq, st));
-    HIPCHECK(hipMemsetAsync(s.d_hdr.p, 0, sizeof(CandHeader), st));
-    if (nitems) HIPCHECK(hipMemcpyAsync(s.d_items.p, s.h_items.p, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, st));
+    HIPCHECK(s.d_qtables.ensure(nt));
+    HIPCHECK(hipMemsetAsync(s.d_state.p, 0, state_bytes, st));
+    HIPCHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, st));
     s.prof_used = 0;
 
     if (s.float_path) {
-        const size_t nt = (size_t)nq * ma * table_dim;
-        HIPCHECK(s.d_ftables.ensure(nt));
+        float* d_ft = s.d_ftables_in;
         if (s.device_tables) {
             // residuals + float tables built on the GPU from the queries uploaded by search_submit
+            HIPCHECK(s.d_ftables.ensure(nt));
+            d_ft = s.d_ftables.p;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
             launch_build_tables(s.d_queries.p, idx->K ? idx->d_coarse.p : nullptr, s.d_assign.p, idx->d_codebooks.p,
-                                idx->has_rotation ? idx->d_rotation.p : nullptr, nq, ma, M,
-                                idx->dim, s.d_ftables.p, st);
-        } else {
-            HIPCHECK(s.h_ftables.ensure(nt));
-            std::memcpy(s.h_ftables.p, s.tables, nt * sizeof(float));
-            HIPCHECK(hipMemcpyAsync(s.d_ftables.p, s.h_ftables.p, nt * sizeof(float), hipMemcpyHostToDevice, st));
+                                idx->has_rotation ? idx->d_rotation.p : nullptr, nq, ma, M, idx->dim, d_ft, st);
         }
-        const size_t na = sitems_a.size(), nb = sitems_b.size();
-        HIPCHECK(s.h_sitems.ensure(na + nb));
-        HIPCHECK(s.d_sitems.ensure(na + nb));
-        HIPCHECK(s.d_fc_init.ensure(2 * (size_t)nq));
         HIPCHECK(s.d_fc.ensure((size_t)nq * fc_stride));
-        HIPCHECK(hipMemcpyAsync(s.d_fc_init.p, s.h_fc_init.p, 2 * (size_t)nq * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
-        launch_prescan_init(s.d_qs.p, s.d_fc_init.p, nq, st);
-        if (na + nb) {
-            if (na) std::memcpy(s.h_sitems.p, sitems_a.data(), na * sizeof(StartItem));
-            if (nb) std::memcpy(s.h_sitems.p + na, sitems_b.data(), nb * sizeof(StartItem));
-            HIPCHECK(hipMemcpyAsync(s.d_sitems.p, s.h_sitems.p, (na + nb) * sizeof(StartItem), hipMemcpyHostToDevice, st));
-        }
         auto wgs_for = [](const std::vector<StartItem>& v) {
             uint32_t maxs = 0;
             for (auto& si : v) maxs = std::max(maxs, si.n);
             return (int)std::min<uint32_t>(std::max<uint32_t>((maxs + 4095) / 4096, 1), 512);
         };
-        // phase A: the sample, unfiltered -> its R-th smallest; phase B: the rest, keeping only values <= that
-        if (na) launch_start_scan_f32(M, s.d_sitems.p, (int)na, wgs_for(sitems_a), s.d_ftables.p, s.d_fc.p, fc_stride, s.d_qs.p, st);
-        // (with a phase B the first select only has to bound the R-th smallest from above: 2 digit passes)
-        launch_select_kth(s.d_fc.p, fc_stride, nq, (uint32_t)s.R, s.d_qs.p, nb ? 2 : 4, st);
+        const int tda = (int)(ma * table_dim);
+        // phase A: the sample, unfiltered -> its R-th smallest; phase B: the rest, keeping only values <= that.
+        // The LAST select of the chain also quantizes the query's tables (QuantizerMAX) in the same workgroup.
+        if (na) launch_start_scan_f32(M, s.d_sitems, (int)na, wgs_for(sitems_a), d_ft, s.d_fc.p, fc_stride, s.d_fc_init, s.d_qs, st);
         if (nb) {
-            launch_start_scan_f32(M, s.d_sitems.p + na, (int)nb, wgs_for(sitems_b), s.d_ftables.p, s.d_fc.p, fc_stride, s.d_qs.p, st);
-            launch_select_kth(s.d_fc.p, fc_stride, nq, (uint32_t)s.R, s.d_qs.p, 4, st);
+            // (with a phase B the first select only has to bound the R-th smallest from above: 2 digit passes)
+            launch_select_kth(s.d_fc.p, fc_stride, s.d_fc_init, nq, (uint32_t)s.R, s.d_qs, 2, nullptr, nullptr, tda, 0, st);
+            launch_start_scan_f32(M, s.d_sitems + na, (int)nb, wgs_for(sitems_b), d_ft, s.d_fc.p, fc_stride, s.d_fc_init, s.d_qs, st);
         }
-        launch_quantize(M, ma, nq, s.d_ftables.p, s.d_qtables.p, s.d_qs.p, idx->quant_mode, st);
+        launch_select_kth(s.d_fc.p, fc_stride, s.d_fc_init, nq, (uint32_t)s.R, s.d_qs, 4, d_ft, s.d_qtables.p, tda,
+                          idx->quant_mode, st);
         if (idx->profile) HIPCHECK(prof_event(s, st));
     } else {
-        const size_t nt = (size_t)nq * ma * table_dim;
-        HIPCHECK(s.h_qtables.ensure(nt));
-        std::memcpy(s.h_qtables.p, s.qtables_in.data(), nt);
-        HIPCHECK(hipMemcpyAsync(s.d_qtables.p, s.h_qtables.p, nt, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(s.d_qtables.p, s.d_in.p + off_tables, nt, hipMemcpyDeviceToDevice, st));
         if (idx->profile) { HIPCHECK(prof_event(s, st)); HIPCHECK(prof_event(s, st)); }
     }
 
@@ -446,10 +459,10 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         ll.ev = -1;
         if (group_start) { ll.ev = (int)s.prof_used; HIPCHECK(prof_event(s, st)); }
         if (ll.small)
-            launch_scan_i8_small(M, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p, s.d_cands.p,
+            launch_scan_i8_small(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs, s.d_hdr, s.d_cands.p,
                                  s.cap_q, (uint32_t)s.R, st);
         else
-            launch_scan_i8(M, variant, s.d_items.p + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs.p, s.d_hdr.p,
+            launch_scan_i8(M, variant, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs, s.d_hdr,
                            s.d_cands.p, s.cap_q, (uint32_t)s.R, st);
         if (group_end) HIPCHECK(prof_event(s, st));
     }
@@ -460,17 +473,14 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     HIPCHECK(hipEventRecord(s.ev_scanned, main_st));
     st = idx->sort_stream;
     HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
-    launch_sort_cands(s.d_qs.p, s.d_cands.p, s.cap_q, nq, s.d_out_keys.p, s.d_out_vals.p, s.out_cap, s.d_hdr.p, st);
+    launch_sort_cands(s.d_qs, s.d_cands.p, s.cap_q, nq, s.d_qout, s.d_entries, s.out_cap, s.d_hdr, st);
     HIPCHECK(hipGetLastError());
 
-    // ---- results ----------------------------------------------------------------------------
-    HIPCHECK(hipMemcpyAsync(s.h_hdr.p, s.d_hdr.p, sizeof(CandHeader), hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipMemcpyAsync(s.h_qs.p, s.d_qs.p, sizeof(QueryState) * nq, hipMemcpyDeviceToHost, st));
+    // ---- results: the 16-byte header and ONE copy of [QueryOut[nq]][first entries] ----------------
+    HIPCHECK(hipMemcpyAsync(s.h_hdr.p, s.d_hdr, sizeof(CandHeader), hipMemcpyDeviceToHost, st));
     s.prefetched = std::min<uint32_t>(s.out_cap, 1u << 16);
-    HIPCHECK(s.h_out_keys.ensure(s.out_cap));
-    HIPCHECK(s.h_out_vals.ensure(s.out_cap));
-    HIPCHECK(hipMemcpyAsync(s.h_out_keys.p, s.d_out_keys.p, sizeof(uint32_t) * s.prefetched, hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipMemcpyAsync(s.h_out_vals.p, s.d_out_vals.p, s.prefetched, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(QueryOut) * (size_t)nq + sizeof(uint64_t) * s.prefetched,
+                            hipMemcpyDeviceToHost, st));
     if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(s.ev_done, st));
     return QADC_OK;
@@ -578,14 +588,14 @@ int collect_common(qadc_index* idx, int slot_i) {
         uint64_t max_count = 0;
         total_sorted = 0;
         for (int q = 0; q < s.nq; ++q) {
-            const QueryState& qs = s.h_qs.p[q];
+            const QueryOut& qs = s.h_qout[q];
             max_count = std::max<uint64_t>(max_count, qs.count);
             if (qs.count <= limit) total_sorted += (uint64_t)qs.count + qs.reps;
         }
         const bool region_overflow = s.h_hdr.p->overflow != 0;
         const bool out_overflow = total_sorted > s.out_cap;
         bool prescan_overflow = false;
-        for (int q = 0; q < s.nq; ++q) prescan_overflow |= (s.h_qs.p[q].flags & 8u) != 0;
+        for (int q = 0; q < s.nq; ++q) prescan_overflow |= (s.h_qout[q].flags & 8u) != 0;
         if (!region_overflow && !out_overflow && !prescan_overflow) break;
         if (attempt >= 4 || max_count + 64 > (1ull << 31) || total_sorted > (1ull << 31)) {
             s.busy = false;
@@ -604,10 +614,8 @@ int collect_common(qadc_index* idx, int slot_i) {
     s.busy = false;
     if (total_sorted > s.prefetched) {
         const size_t rest = (size_t)total_sorted - s.prefetched;
-        HIPCHECK(hipMemcpyAsync(s.h_out_keys.p + s.prefetched, s.d_out_keys.p + s.prefetched, rest * sizeof(uint32_t),
+        HIPCHECK(hipMemcpyAsync(s.h_entries + s.prefetched, s.d_entries + s.prefetched, rest * sizeof(uint64_t),
                                 hipMemcpyDeviceToHost, idx->copy_stream));
-        HIPCHECK(hipMemcpyAsync(s.h_out_vals.p + s.prefetched, s.d_out_vals.p + s.prefetched, rest, hipMemcpyDeviceToHost,
-                                idx->copy_stream));
         HIPCHECK(hipStreamSynchronize(idx->copy_stream));
     }
     if (idx->profile) {
@@ -631,17 +639,15 @@ int collect_common(qadc_index* idx, int slot_i) {
         if (s.float_path) idx->prof.start_codes += s.start_codes;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    s.out_keys.clear();
-    s.out_vals.clear();
+    s.out_entries.clear();
     s.out_off.assign((size_t)s.nq + 1, 0);
     for (int q = 0; q < s.nq; ++q) {
-        const QueryState& qs = s.h_qs.p[q];
-        s.out_off[q] = s.out_keys.size();
+        const QueryOut& qs = s.h_qout[q];
+        s.out_off[q] = s.out_entries.size();
         idx->prof.candidates += qs.count;
         if (qs.flags & 4u) {                                  // ordered and expanded on the device
             const size_t n = (size_t)qs.count + qs.reps;
-            s.out_keys.insert(s.out_keys.end(), s.h_out_keys.p + qs.out_off, s.h_out_keys.p + qs.out_off + n);
-            s.out_vals.insert(s.out_vals.end(), s.h_out_vals.p + qs.out_off, s.h_out_vals.p + qs.out_off + n);
+            s.out_entries.insert(s.out_entries.end(), s.h_entries + qs.out_off, s.h_entries + qs.out_off + n);
             continue;
         }
         // host fallback: fetch the raw region, sort by (level, assign slot, position), expand replays
@@ -658,13 +664,11 @@ int collect_common(qadc_index* idx, int slot_i) {
         });
         for (uint32_t i = 0; i < qs.count; ++i) {
             const uint32_t reps = 1u + ((c[i].order >> 20) & 15u);
-            for (uint32_t r = 0; r < reps; ++r) {
-                s.out_keys.push_back(c[i].key);
-                s.out_vals.push_back((int8_t)c[i].val);
-            }
+            for (uint32_t r = 0; r < reps; ++r)
+                s.out_entries.push_back((uint64_t)c[i].key | ((uint64_t)(c[i].val & 0xffu) << 32));
         }
     }
-    s.out_off[s.nq] = s.out_keys.size();
+    s.out_off[s.nq] = s.out_entries.size();
     idx->prof.host_replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return QADC_OK;
 }
@@ -672,7 +676,7 @@ int collect_common(qadc_index* idx, int slot_i) {
 void finish_float_outputs(qadc_index* idx, Slot& s, int32_t* status, float* qmin, float* qmax) {
     const size_t per_q = (size_t)s.ma * idx->M * 16;
     for (int q = 0; q < s.nq; ++q) {
-        const QueryState& qs = s.h_qs.p[q];
+        const QueryOut& qs = s.h_qout[q];
         if (status) status[q] = (qs.flags & 1u) ? 1 : 0;
         if (qmin) qmin[q] = qs.qmin;
         if (qmax) qmax[q] = qs.qmax;
@@ -695,7 +699,8 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
                 continue;
             }
             bh.push(0, 127);  // db_query_4.cpp:276
-            for (uint64_t i = s.out_off[q]; i < s.out_off[q + 1]; ++i) bh.push(s.out_keys[i], s.out_vals[i]);
+            for (uint64_t i = s.out_off[q]; i < s.out_off[q + 1]; ++i)
+                bh.push((uint32_t)s.out_entries[i], (int8_t)(s.out_entries[i] >> 32));
             if (sizes) sizes[q] = bh.size();
             if (keys) std::memcpy(keys + (size_t)q * s.R, bh.keys(), sizeof(uint32_t) * bh.size());
             if (values) std::memcpy(values + (size_t)q * s.R, bh.values(), bh.size());
@@ -765,10 +770,9 @@ int qadc_index_destroy(qadc_index* idx) {
     idx->d_rotation.release();
     idx->d_coarse.release();
     for (auto& s : idx->slot) {
-        s.d_ftables.release(); s.d_qtables.release(); s.d_qs.release(); s.d_hdr.release(); s.d_cands.release(); s.d_out_keys.release(); s.d_out_vals.release();
-        s.d_items.release(); s.d_sitems.release(); s.d_fc.release(); s.d_fc_init.release();
-        s.h_items.release(); s.h_sitems.release(); s.h_fc_init.release(); s.h_ftables.release(); s.h_qtables.release();
-        s.h_qs.release(); s.h_hdr.release(); s.h_cands.release(); s.h_out_keys.release(); s.h_out_vals.release();
+        s.d_in.release(); s.h_in.release(); s.d_state.release(); s.d_result.release(); s.h_result.release();
+        s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
+        s.h_hdr.release(); s.h_cands.release();
         s.d_queries.release(); s.d_assign.release(); s.d_cdist.release(); s.h_queries.release(); s.h_assign.release();
         if (s.ev_feed) (void)hipEventDestroy(s.ev_feed);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
@@ -1055,8 +1059,10 @@ static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int
     std::memcpy(offsets, s.out_off.data(), sizeof(uint64_t) * (s.nq + 1));
     const uint64_t total = s.out_off[s.nq];
     if (total > cand_capacity) return fail(QADC_E_CAPACITY, "candidate output buffers too small (see offsets[nq])");
-    if (total && cand_keys) std::memcpy(cand_keys, s.out_keys.data(), total * sizeof(uint32_t));
-    if (total && cand_vals) std::memcpy(cand_vals, s.out_vals.data(), total);
+    for (uint64_t i = 0; i < total; ++i) {
+        if (cand_keys) cand_keys[i] = (uint32_t)s.out_entries[i];
+        if (cand_vals) cand_vals[i] = (int8_t)(s.out_entries[i] >> 32);
+    }
     return QADC_OK;
 }
 
@@ -1101,7 +1107,7 @@ int qadc_scan_start(qadc_index* idx, int nq, int ma, const int32_t* assign, cons
     std::vector<float> qm(nq);
     if (int rc = submit_common(idx, 0, nq, ma, assign, copy.data(), nullptr, R)) return rc;
     if (int rc = collect_common(idx, 0)) return rc;
-    for (int q = 0; q < nq; ++q) qmax[q] = idx->slot[0].h_qs.p[q].qmax;
+    for (int q = 0; q < nq; ++q) qmax[q] = idx->slot[0].h_qout[q].qmax;
     return QADC_OK;
 }
 

@@ -57,8 +57,18 @@ struct QueryState {
     uint32_t sel_nmin;    // ~min(key) over the query's pre-scan values (atomicMax of ~key; 0 = none)
     uint32_t sel_max;     // max(key)
     uint32_t out_off;     // first entry of this query in the sorted output (valid with flags bit2)
-    uint32_t fc_n;        // float pre-scan values stored for this query (sample + appended survivors)
-    uint32_t fc_cap;      // capacity of the query's float value buffer
+    uint32_t fc_n;        // pre-scan survivors appended behind the query's sample values
+    uint32_t pad;
+};
+
+// What the host reads back per query (32 bytes instead of the 8 KiB QueryState).
+struct QueryOut {
+    uint32_t count;    // candidates emitted (region slots requested)
+    uint32_t reps;     // extra padding-lane replays among them
+    uint32_t flags;    // QueryState::flags (bit2 = ordered on the device, entries valid)
+    uint32_t out_off;  // first entry in the sorted output
+    float qmin, qmax;
+    uint32_t pad[2];
 };
 
 // Float ADC item for the "starts" pre-scan (scanner_4::query_scan_start).
@@ -84,12 +94,14 @@ void launch_scan_i8_small(int M, const ScanItem* d_items, int nitems, int wgs_pe
 // position), padding-lane replays expanded, written compactly to d_out_keys / d_out_vals at the prefix
 // offset of the query.  Queries with more than kSortCap candidates (or an overflowed region) are left
 // to the host (flags bit2 stays clear).
-void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, uint32_t* d_out_keys,
-                       int8_t* d_out_vals, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream);
+// Sorted entries are written as u64 = key | (value << 32); every query gets its QueryOut record.
+void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, QueryOut* d_qout,
+                       uint64_t* d_entries, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream);
 
+// d_fc_init[2q] = values of query q written unfiltered (phase A), d_fc_init[2q+1] = capacity of its buffer.
 void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item,
-                           const float* d_ftables, float* d_fc, uint64_t fc_stride, QueryState* d_qs,
-                           hipStream_t stream);
+                           const float* d_ftables, float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init,
+                           QueryState* d_qs, hipStream_t stream);
 
 // Per-block (min float ADC distance, lowest position) over a whole partition; host reduces the blocks.
 void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,
@@ -107,17 +119,13 @@ void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq,
 void launch_build_tables(const float* d_queries, const float* d_coarse, const int32_t* d_assign, const float* d_codebooks,
                          const float* d_rotation, int nq, int ma, int M, int dim, float* d_ftables, hipStream_t stream);
 
-// Sets QueryState::fc_n / fc_cap from init[2*q], init[2*q+1].
-void launch_prescan_init(QueryState* d_qs, const uint32_t* d_init, int nq, hipStream_t stream);
-
 // R-th smallest of each query's stored float values (one workgroup per query) -> QueryState::qmax
-// (FLT_MAX if fewer than R values).
-void launch_select_kth(const float* d_fc, uint64_t fc_stride, int nq, uint32_t R, QueryState* d_qs, int max_passes,
-                       hipStream_t stream);
-
-// QuantizerMAX<int8> for every query: qmin, in-place negative clamp, int8 tables.
-void launch_quantize(int M, int ma, int nq, float* d_ftables, int8_t* d_qtables, QueryState* d_qs,
-                     int quant_mode, hipStream_t stream);
+// (FLT_MAX if fewer than R values).  max_passes < 4: upper bound only (survivor filter of the pre-scan).
+// d_qtables != nullptr: the same workgroup then runs QuantizerMAX<int8> for the query (qmin, in-place negative
+// clamp of d_ftables, int8 tables) — the last step of the float chain, saving a launch.
+void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init, int nq, uint32_t R,
+                       QueryState* d_qs, int max_passes, float* d_ftables, int8_t* d_qtables, int table_dim_all,
+                       int quant_mode, hipStream_t stream);
 
 void launch_fill_codes(uint8_t* d_dst, uint64_t first_word, uint64_t nwords, uint64_t seed, hipStream_t stream);
 

@@ -452,9 +452,18 @@ __device__ __forceinline__ void wave_sort512(uint64_t (&v)[8], uint32_t lane) {
     }
 }
 
+__device__ __forceinline__ void write_query_out(QueryOut* __restrict__ o, const QueryState* qs, uint32_t off, uint32_t flags) {
+    o->count = qs->count;
+    o->reps = qs->reps;
+    o->flags = flags;
+    o->out_off = off;
+    o->qmin = qs->qmin;
+    o->qmax = qs->qmax;
+}
+
 __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict__ qstates, const Cand* __restrict__ cands,
-                                                          uint32_t cap, int nq, uint32_t* __restrict__ out_keys,
-                                                          int8_t* __restrict__ out_vals, uint32_t out_cap,
+                                                          uint32_t cap, int nq, QueryOut* __restrict__ qout,
+                                                          uint64_t* __restrict__ out_entries, uint32_t out_cap,
                                                           CandHeader* __restrict__ hdr) {
     // all LDS in the dynamic region (keeps the 8-byte key array naturally aligned)
     uint64_t* lkey = reinterpret_cast<uint64_t*>(smem);
@@ -468,7 +477,10 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
     QueryState* qs = qstates + q;
     const uint32_t n = qs->count;
     const uint32_t limit = min(cap, kSortCap);
-    if (n > limit) return;                                       // host sorts this query's region
+    if (n > limit) {                                             // host sorts this query's region
+        if (tid == 0) write_query_out(qout + q, qs, 0, qs->flags);
+        return;
+    }
     // offset of this query in the compact output = candidates (+ replays) of the device-sorted queries before it
     uint32_t part = 0;
     for (int p = tid; p < q; p += 1024) {
@@ -553,11 +565,11 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
             const uint64_t pay = wpay[wkey[i] & 0x3fffu];
             const uint32_t reps = 1u + ((uint32_t)(pay >> 40) & 15u);
             for (uint32_t r = 0; r < reps; ++r, ++w) {
-                if (w < out_cap) { out_keys[w] = (uint32_t)pay; out_vals[w] = (int8_t)((pay >> 32) & 0xffu); }
+                if (w < out_cap) out_entries[w] = pay & 0xffffffffffull;        // key | value << 32
                 else atomicAdd(&hdr->out_overflow, 1u);
             }
         }
-        if (tid == 0) { qs->out_off = off; qs->flags |= 4u; }
+        if (tid == 0) write_query_out(qout + q, qs, off, qs->flags | 4u);
         return;
     }
 
@@ -595,20 +607,20 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
         const Cand c = region[lkey[i] & 0x3fffu];
         const uint32_t reps = 1u + ((c.order >> 20) & 15u);
         for (uint32_t r = 0; r < reps; ++r, ++w) {
-            if (w < out_cap) { out_keys[w] = c.key; out_vals[w] = (int8_t)c.val; }
+            if (w < out_cap) out_entries[w] = (uint64_t)c.key | ((uint64_t)(c.val & 0xffu) << 32);
             else atomicAdd(&hdr->out_overflow, 1u);
         }
     }
-    if (tid == 0) { qs->out_off = off; qs->flags |= 4u; }
+    if (tid == 0) write_query_out(qout + q, qs, off, qs->flags | 4u);
 }
 
-void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, uint32_t* d_out_keys,
-                       int8_t* d_out_vals, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream) {
+void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, QueryOut* d_qout,
+                       uint64_t* d_entries, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream) {
     static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_cands_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 8 + 4352), true);
     (void)once;
     hipLaunchKernelGGL(sort_cands_kernel, dim3(nq), dim3(1024), kSortCap * 8 + 4352, stream, d_qs, d_cands, cap_per_query, nq,
-                       d_out_keys, d_out_vals, out_cap, d_hdr);
+                       d_qout, d_entries, out_cap, d_hdr);
 }
 
 // All candidate values (diagnostic; used by parity tests and checksums at full size).
@@ -668,7 +680,8 @@ __device__ __forceinline__ float funkey(uint32_t k) {
 template <int M>
 __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __restrict__ items,
                                                              const float* __restrict__ ftables, float* __restrict__ fc,
-                                                             uint64_t fc_stride, QueryState* __restrict__ qstates) {
+                                                             uint64_t fc_stride, const uint32_t* __restrict__ fc_init,
+                                                             QueryState* __restrict__ qstates) {
     constexpr int kStage = 1024;                             // survivors staged in LDS per workgroup
     __shared__ float tab[M * 16];
     __shared__ float stage[kStage];
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
     float* __restrict__ dst = fc + (uint64_t)it.query * fc_stride;
     QueryState* qs = qstates + it.query;
     const float thr = it.filter ? qs->qmax : 0.0f;           // R-th smallest of the sample (phase A)
-    const uint32_t cap = qs->fc_cap;
+    const uint32_t base_n = fc_init[2 * it.query], cap = fc_init[2 * it.query + 1];   // survivors go behind the sample
     constexpr int DW = M / 8;
     uint32_t kmin = 0xffffffffu, kmax = 0u;
     const uint32_t stride = gridDim.x * 256;
@@ -730,7 +743,7 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
                 if (ls < kStage) {
                     stage[ls] = cand[u];
                 } else {                                     // staging full (rare): straight to the query's buffer
-                    const uint32_t slot = atomicAdd(&qs->fc_n, 1u);
+                    const uint32_t slot = base_n + atomicAdd(&qs->fc_n, 1u);
                     if (slot >= cap) { atomicOr(&qs->flags, 8u); continue; }
                     dst[slot] = cand[u];
                 }
@@ -758,7 +771,7 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
             atomicMax(&qs->sel_nmin, ~kmin);
             atomicMax(&qs->sel_max, kmax);
         }
-        if (ns) stage_base = atomicAdd(&qs->fc_n, ns);
+        if (ns) stage_base = base_n + atomicAdd(&qs->fc_n, ns);
     }
     __syncthreads();
     if (ns) {
@@ -827,38 +840,70 @@ void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d
 }
 
 void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item, const float* d_ftables,
-                           float* d_fc, uint64_t fc_stride, QueryState* d_qs, hipStream_t stream) {
+                           float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init, QueryState* d_qs, hipStream_t stream) {
     const dim3 grid(wgs_per_item, nitems), block(256);
-    if (M == 16) hipLaunchKernelGGL(start_scan_f32_kernel<16>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride, d_qs);
-    else         hipLaunchKernelGGL(start_scan_f32_kernel<32>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride, d_qs);
+    if (M == 16) hipLaunchKernelGGL(start_scan_f32_kernel<16>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride, d_fc_init, d_qs);
+    else         hipLaunchKernelGGL(start_scan_f32_kernel<32>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride, d_fc_init, d_qs);
 }
 
 // ---------------------------------------------------------------------------------------------
 // R-th smallest float per query (= tmp_bh.max() after query_scan_start, db_query_4.cpp:259):
 // 4-pass MSD radix select on the order-preserving u32 image of the floats.
 // ---------------------------------------------------------------------------------------------
-__global__ void prescan_init_kernel(QueryState* qs, const uint32_t* __restrict__ init, int nq) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nq) { qs[q].fc_n = init[2 * q]; qs[q].fc_cap = init[2 * q + 1]; }
-}
-
-void launch_prescan_init(QueryState* d_qs, const uint32_t* d_init, int nq, hipStream_t stream) {
-    hipLaunchKernelGGL(prescan_init_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, d_qs, d_init, nq);
-}
-
 // MSD radix select, one workgroup per query, on k' = key - min(key): only the bits below the range's
 // top bit vary, so the first 8-bit digit already spreads the values over the LDS histogram.
 // max_passes < 4 stops early and returns the UPPER edge of the digit bin reached: an upper bound of the
 // R-th smallest, good enough (and valid) as the survivor filter of the pre-scan's second phase.
-__global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restrict__ fc, uint64_t fc_stride, uint32_t R,
-                                                          QueryState* __restrict__ qstates, int max_passes) {
+// QuantizerMAX<int8_t> (db_query_4.cpp:37-71) + qmin / clamp glue of query_scan (258-274), run by the query's
+// select workgroup once qmax is known.
+// quant_mode 1 = as compiled by the reference's flags: scale = 127/(max-min), trunc((v-min)*scale);
+// quant_mode 0 = source level: trunc((v-min)/delta), delta = (max-min)/127.
+// Strict IEEE float ops (build uses -ffp-contract=off, no fast-math), so results equal a CPU
+// evaluation of the same expressions.
+__device__ void quantize_query(int table_dim_all, float* __restrict__ tb, int8_t* __restrict__ qt, QueryState* qs,
+                               float qmax, int quant_mode, float* red /* [1024] LDS */) {
+    const int t = threadIdx.x;
+    float m = FLT_MAX;
+    for (int i = t; i < table_dim_all; i += 1024) m = fminf(m, tb[i]);
+    red[t] = m;
+    __syncthreads();
+    for (int d = 512; d >= 1; d >>= 1) {
+        if (t < d) red[t] = fminf(red[t], red[t + d]);
+        __syncthreads();
+    }
+    float qmin = red[0];
+    uint32_t flags = 0;
+    if (qmin < 0) { qmin = 0; flags |= 2u; }
+    if (qmax > 1e30f) flags |= 1u;
+    const float delta = (qmax - qmin) / 127;
+    const float scale = 127.0f / (qmax - qmin);
+    for (int i = t; i < table_dim_all; i += 1024) {
+        float v = tb[i];
+        if (v < 0) { v = 0; tb[i] = 0; }
+        int8_t o;
+        if (flags & 1u) o = 127;   // query is skipped by the host; emit nothing
+        else if (v >= qmax) o = 127;
+        else o = (int8_t)(int)(quant_mode == 0 ? (v - qmin) / delta : (v - qmin) * scale);
+        qt[i] = o;
+    }
+    if (t == 0) { qs->qmin = qmin; qs->flags |= flags; }   // keeps bit3 set by the pre-scan
+}
+
+__global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restrict__ fc, uint64_t fc_stride,
+                                                          const uint32_t* __restrict__ fc_init, uint32_t R,
+                                                          QueryState* __restrict__ qstates, int max_passes,
+                                                          float* __restrict__ ftables, int8_t* __restrict__ qtables,
+                                                          int table_dim_all, int quant_mode) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_k, s_hi;
+    __shared__ float red[1024];
     const int q = blockIdx.x, tid = threadIdx.x;
     QueryState* qs = qstates + q;
-    const uint32_t n = min(qs->fc_n, qs->fc_cap);
+    const uint32_t n = min(fc_init[2 * q] + qs->fc_n, fc_init[2 * q + 1]);
     if (n < R) {                                           // heap never fills: max() stays the FLT_MAX sentinel
         if (tid == 0) qs->qmax = FLT_MAX;
+        if (qtables) quantize_query(table_dim_all, ftables + (uint64_t)q * table_dim_all, qtables + (uint64_t)q * table_dim_all,
+                                    qs, FLT_MAX, quant_mode, red);
         return;
     }
     const uint32_t kmin = ~qs->sel_nmin, kmax = qs->sel_max;
@@ -914,62 +959,19 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        const uint32_t low = s_hi ? ((s_hi >= 32 ? 0u : (1u << s_hi)) - 1u) : 0u;   // undecided bits -> all ones
-        const uint64_t key = (uint64_t)(s_prefix | low) + kmin;
-        qs->qmax = funkey(key > kmax ? kmax : (uint32_t)key);   // never above the largest stored value
-    }
+    const uint32_t low = s_hi ? ((s_hi >= 32 ? 0u : (1u << s_hi)) - 1u) : 0u;       // undecided bits -> all ones
+    const uint64_t key = (uint64_t)(s_prefix | low) + kmin;
+    const float qmax = funkey(key > kmax ? kmax : (uint32_t)key);                  // never above the largest stored value
+    if (tid == 0) qs->qmax = qmax;
+    if (qtables) quantize_query(table_dim_all, ftables + (uint64_t)q * table_dim_all, qtables + (uint64_t)q * table_dim_all,
+                                qs, qmax, quant_mode, red);
 }
 
-void launch_select_kth(const float* d_fc, uint64_t fc_stride, int nq, uint32_t R, QueryState* d_qs, int max_passes,
+void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init, int nq, uint32_t R, QueryState* d_qs,
+                       int max_passes, float* d_ftables, int8_t* d_qtables, int table_dim_all, int quant_mode,
                        hipStream_t stream) {
-    hipLaunchKernelGGL(select_kth_kernel, dim3(nq), dim3(1024), 0, stream, d_fc, fc_stride, R, d_qs, max_passes);
-}
-
-// ---------------------------------------------------------------------------------------------
-// QuantizerMAX<int8_t> (db_query_4.cpp:37-71) + qmin / clamp glue of query_scan (258-274).
-// quant_mode 1 = as compiled by the reference's flags: scale = 127/(max-min), trunc((v-min)*scale);
-// quant_mode 0 = source level: trunc((v-min)/delta), delta = (max-min)/127.
-// Strict IEEE float ops (build uses -ffp-contract=off, no fast-math), so results equal a CPU
-// evaluation of the same expressions.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void quantize_kernel(int table_dim_all, float* __restrict__ ftables,
-                                                       int8_t* __restrict__ qtables, QueryState* __restrict__ qs,
-                                                       int quant_mode) {
-    __shared__ float red[256];
-    const int q = blockIdx.x, t = threadIdx.x;
-    float* __restrict__ tb = ftables + (uint64_t)q * table_dim_all;
-    int8_t* __restrict__ qt = qtables + (uint64_t)q * table_dim_all;
-    float m = FLT_MAX;
-    for (int i = t; i < table_dim_all; i += 256) m = fminf(m, tb[i]);
-    red[t] = m;
-    __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
-        if (t < d) red[t] = fminf(red[t], red[t + d]);
-        __syncthreads();
-    }
-    float qmin = red[0];
-    uint32_t flags = 0;
-    if (qmin < 0) { qmin = 0; flags |= 2u; }
-    const float qmax = qs[q].qmax;
-    if (qmax > 1e30f) flags |= 1u;
-    const float delta = (qmax - qmin) / 127;
-    const float scale = 127.0f / (qmax - qmin);
-    for (int i = t; i < table_dim_all; i += 256) {
-        float v = tb[i];
-        if (v < 0) { v = 0; tb[i] = 0; }
-        int8_t o;
-        if (flags & 1u) o = 127;   // query is skipped by the host; emit nothing
-        else if (v >= qmax) o = 127;
-        else o = (int8_t)(int)(quant_mode == 0 ? (v - qmin) / delta : (v - qmin) * scale);
-        qt[i] = o;
-    }
-    if (t == 0) { qs[q].qmin = qmin; qs[q].flags |= flags; }   // keeps bit3 set by the pre-scan
-}
-
-void launch_quantize(int M, int ma, int nq, float* d_ftables, int8_t* d_qtables, QueryState* d_qs, int quant_mode,
-                     hipStream_t stream) {
-    hipLaunchKernelGGL(quantize_kernel, dim3(nq), dim3(256), 0, stream, ma * M * 16, d_ftables, d_qtables, d_qs, quant_mode);
+    hipLaunchKernelGGL(select_kth_kernel, dim3(nq), dim3(1024), 0, stream, d_fc, fc_stride, d_fc_init, R, d_qs, max_passes,
+                       d_ftables, d_qtables, table_dim_all, quant_mode);
 }
 
 // ---------------------------------------------------------------------------------------------
