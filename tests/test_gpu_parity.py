@@ -429,3 +429,39 @@ def test_sort_paths_wave_segments_and_workgroup_fallback(pyqadc, po):
             assert heaps_equal(got[q], want), (base, q)
     assert idx.profile()["host_sorted_queries"] == 0
     idx.close()
+
+
+def test_large_heap_capacity(pyqadc, po):
+    """R = 1000: level segments exceed what one wave orders and the total exceeds the device sort capacity for
+    some queries (regrow + workgroup-wide / host ordering); results stay exact."""
+    rng = np.random.default_rng(41)
+    codes = rand_codes(rng, 400000, 16)
+    idx = pyqadc.Index(16)
+    idx.add_partitions([codes])
+    idx.finalize(0.02)
+    tables = float_tables(rng, 3, 1, 16)
+    res = idx.query_scan(np.zeros((3, 1), np.int32), tables.copy(), 1000)
+    for q in range(3):
+        want = po.query_scan(16, [codes], None, 0.02, [0], tables[q].copy(), 1000)
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
+    idx.close()
+
+
+def test_many_indexes_create_destroy(pyqadc, po):
+    rng = np.random.default_rng(42)
+    codes = rand_codes(rng, 5000, 16)
+    qt = rand_qtables(rng, (1, 1), 16, 9)
+    want = po.scan_i8(16, [codes], None, qt[0], 50)
+    live = []
+    for i in range(12):
+        idx = pyqadc.Index(16)
+        idx.add_partitions([codes])
+        idx.finalize(0.01)
+        assert heaps_equal(idx.scan_i8(np.zeros((1, 1), np.int32), qt, 50)[0], want)
+        if i % 3 == 0:
+            live.append(idx)            # several indexes alive at once on the same GPU
+        else:
+            idx.close()
+    for idx in live:
+        assert heaps_equal(idx.scan_i8(np.zeros((1, 1), np.int32), qt, 50)[0], want)
+        idx.close()
