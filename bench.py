@@ -64,6 +64,47 @@ def cpu_baseline(M, n_total, seed, qtables, R, seconds):
                                         if kind == "reference" else "scalar C port (oracle)")}
 
 
+def real_encode_recall(M, R, keep, n, nq, local_rank):
+    """Recall@R on REAL encodings (SURVEY.md §8d "real-encode variant"): clustered synthetic 128-d vectors,
+    codebooks = sampled sub-vectors, PQ-encoded on the GPU (qadc_pq_encode), queried through the device-side
+    feeders (qadc_search); ground truth = exact float L2 nearest neighbour (torch, chunked).  Untimed."""
+    import torch
+    import pyqadc
+    dev = torch.device("cuda", local_rank)
+    g = torch.Generator(device=dev).manual_seed(7)
+    dim, ds, cs = 128, 128 // M, M // 2
+    C = max(2000, n // 300)     # ~300 points per cluster: neither trivial nor hopeless for a 100-entry shortlist
+    centres = torch.randn(C, dim, device=dev, generator=g) * 3
+    base = centres[torch.randint(0, C, (n,), device=dev, generator=g)] + torch.randn(n, dim, device=dev, generator=g)
+    queries = centres[torch.randint(0, C, (nq,), device=dev, generator=g)] + torch.randn(nq, dim, device=dev, generator=g)
+    ids = torch.randint(0, n, (M, 16), device=dev, generator=g)
+    cb = torch.stack([base[ids[m], m * ds:(m + 1) * ds] for m in range(M)]).contiguous()      # [M][16][ds]
+    raw = torch.zeros(n * cs + 64, dtype=torch.uint8, device=dev)                             # padded tail
+    torch.cuda.synchronize()
+    cb_host = cb.cpu().numpy()
+    pyqadc.pq_encode_device(cb_host, base.data_ptr(), n, dim, raw.data_ptr(), local_rank)
+    best_d = torch.full((nq,), float("inf"), device=dev)
+    best_i = torch.zeros(nq, dtype=torch.long, device=dev)
+    for lo in range(0, n, 1 << 20):
+        d = torch.cdist(queries, base[lo:lo + (1 << 20)])
+        dmin, imin = d.min(dim=1)
+        upd = dmin < best_d
+        best_d = torch.where(upd, dmin, best_d)
+        best_i = torch.where(upd, imin + lo, best_i)
+    gt = best_i.cpu().numpy()
+    torch.cuda.synchronize()
+    idx = pyqadc.Index(M, local_rank)
+    idx.add_partition_device(raw.data_ptr(), n, keepalive=raw)
+    idx.finalize(keep)
+    idx.set_pq(cb_host)
+    res = idx.search(queries.cpu().numpy(), 1, R)
+    hits = sum(int(gt[q] in set(res["keys"][q][:res["sizes"][q]].tolist())) for q in range(nq))
+    idx.close()
+    return {"value": hits / nq, "codes": n, "queries": nq,
+            "data": "synthetic 128-d vectors, %d clusters (3*N(0,1) centres + N(0,1)), codebooks = sampled sub-vectors, PQ %dx4 "
+                    "encoded on the GPU; ground truth = exact float L2 NN" % (C, M)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +236,9 @@ def main():
                        "host_sort_replay_ms_per_step": prof["host_replay_ms"] / args.steps,
                        "candidates_per_query": prof["candidates"] / (NQ * args.steps), "regrows": prof["regrows"]},
         }
+        n_real = int(float(os.environ.get("QADC_BENCH_REAL_CODES", 1e7)))
+        if world == 1 and n_real > 0:
+            out["recall_at_100_real_encode"] = real_encode_recall(M, R, KEEP, n_real, 64, local_rank)
         cpu_s = float(os.environ.get("QADC_BENCH_CPU_SECONDS", 15))
         if world == 1 and cpu_s > 0:
             res = idx.query_scan(assign, pool[0].copy(), R, want_qtables=True)

@@ -177,6 +177,14 @@ int qadc_search_submit(qadc_index* idx, int slot, int nq, const float* queries, 
 int qadc_search_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
                         int32_t* assign_out);
 
+/* "Next" row N4 (database build): PQ encode on the device — base_pq::encode_multiple_vectors for plain PQ
+ * (quantizers.hpp:222-245): nearest centroid per sub-quantizer, packed by multiple_set_bits_4
+ * (quantizers.hpp:49-68).  d_vectors [n][dim] float and d_codes [n][M/2] are device pointers of `device_id`
+ * (the _host form stages host buffers).  Used by bench.py to build a real-encoded list for its recall figure. */
+int qadc_pq_encode(int M, int dim, const float* codebooks, const void* d_vectors, uint64_t n, void* d_codes, int device_id);
+int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vectors, uint64_t n, uint8_t* codes,
+                        int device_id);
+
 /* Host-only helper (no GPU involved): push (keys[i], vals[i]), i = 0..n-1, in order into an empty
  * heap of capacity R with kv_binheap<unsigned,int8_t>::push semantics (binheap.hpp:75-116), after
  * an optional (0,127) sentinel (db_query_4.cpp:276), and return the heap arrays.  This is the

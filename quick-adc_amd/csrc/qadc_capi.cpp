@@ -1235,6 +1235,36 @@ int qadc_search(qadc_index* idx, int nq, const float* queries, int ma, int R, ui
     return qadc_search_collect(idx, 0, keys, values, sizes, status, assign_out);
 }
 
+int qadc_pq_encode(int M, int dim, const float* codebooks, const void* d_vectors, uint64_t n, void* d_codes, int device_id) {
+    if ((M != 16 && M != 32) || dim <= 0 || dim % M != 0 || !codebooks || (n && (!d_vectors || !d_codes)))
+        return fail(QADC_E_ARG, "bad arguments");
+    HIPCHECK(hipSetDevice(device_id));
+    const size_t ncb = (size_t)M * 16 * (dim / M);
+    float* d_cb = nullptr;
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_cb), ncb * sizeof(float)));
+    HIPCHECK(hipMemcpy(d_cb, codebooks, ncb * sizeof(float), hipMemcpyHostToDevice));
+    if (n) launch_pq_encode(static_cast<const float*>(d_vectors), n, M, dim, d_cb, static_cast<uint8_t*>(d_codes), nullptr);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipFree(d_cb));
+    return QADC_OK;
+}
+
+int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vectors, uint64_t n, uint8_t* codes, int device_id) {
+    if (!vectors || !codes) return fail(QADC_E_ARG, "bad arguments");
+    HIPCHECK(hipSetDevice(device_id));
+    float* d_v = nullptr;
+    uint8_t* d_c = nullptr;
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_v), std::max<size_t>(1, n * dim * sizeof(float))));
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_c), std::max<size_t>(1, n * (M / 2))));
+    HIPCHECK(hipMemcpy(d_v, vectors, n * dim * sizeof(float), hipMemcpyHostToDevice));
+    const int rc = qadc_pq_encode(M, dim, codebooks, d_v, n, d_c, device_id);
+    if (rc == QADC_OK) HIPCHECK(hipMemcpy(codes, d_c, n * (M / 2), hipMemcpyDeviceToHost));
+    HIPCHECK(hipFree(d_v));
+    HIPCHECK(hipFree(d_c));
+    return rc;
+}
+
 int qadc_profile_read(qadc_index* idx, qadc_profile* out) {
     if (!idx || !out) return fail(QADC_E_ARG, "bad arguments");
     *out = idx->prof;

@@ -127,6 +127,10 @@ void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_
                        QueryState* d_qs, int max_passes, float* d_ftables, int8_t* d_qtables, int table_dim_all,
                        int quant_mode, hipStream_t stream);
 
+// PQ encode of device-resident vectors [n][dim] with codebooks [M][16][dim/M] -> codes [n][M/2].
+void launch_pq_encode(const float* d_vectors, uint64_t n, int M, int dim, const float* d_codebooks, uint8_t* d_codes,
+                      hipStream_t stream);
+
 void launch_fill_codes(uint8_t* d_dst, uint64_t first_word, uint64_t nwords, uint64_t seed, hipStream_t stream);
 
 void launch_deinterleave(uint8_t* d_rowmajor, const uint8_t* d_inter, uint32_t n, int cs, hipStream_t stream);

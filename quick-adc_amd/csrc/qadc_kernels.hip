@@ -1120,6 +1120,52 @@ void launch_build_tables(const float* d_queries, const float* d_coarse, const in
 }
 
 // ---------------------------------------------------------------------------------------------
+// PQ encoder (base_pq::encode_multiple_vectors, quantizers.hpp:222-245, for plain PQ):
+// nearest centroid per sub-quantizer (first minimum of the sequentially accumulated squared distance, as
+// host/query_driver.hpp pq4::encode), two sub-quantizers per byte: even one in the low nibble
+// (multiple_set_bits_4, quantizers.hpp:49-68).  One thread per code byte.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pq_encode_kernel(const float* __restrict__ vectors, uint64_t n, int M, int dim,
+                                                        const float* __restrict__ codebooks, uint8_t* __restrict__ codes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    float* cb = reinterpret_cast<float*>(dyn);                // [M][16][ds]
+    const int ds = dim / M, cs = M / 2;
+    for (int i = threadIdx.x; i < M * 16 * ds; i += 256) cb[i] = codebooks[i];
+    __syncthreads();
+    const uint64_t total = n * (uint64_t)cs;
+    for (uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (uint64_t)gridDim.x * 256) {
+        const uint64_t vi = o / cs;
+        const int b = (int)(o % cs);
+        uint32_t packed = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int m = 2 * b + h;
+            const float* __restrict__ x = vectors + vi * dim + (uint64_t)m * ds;
+            int best = 0;
+            float bestd = FLT_MAX;
+            for (int c = 0; c < 16; ++c) {
+                const float* ce = cb + ((size_t)m * 16 + c) * ds;
+                float s = 0.0f;
+                for (int d = 0; d < ds; ++d) {
+                    const float t = x[d] - ce[d];
+                    s += t * t;
+                }
+                if (s < bestd) { bestd = s; best = c; }
+            }
+            packed |= (uint32_t)best << (4 * h);
+        }
+        codes[o] = (uint8_t)packed;
+    }
+}
+
+void launch_pq_encode(const float* d_vectors, uint64_t n, int M, int dim, const float* d_codebooks, uint8_t* d_codes,
+                      hipStream_t stream) {
+    const uint64_t total = n * (uint64_t)(M / 2);
+    const int grid = (int)std::min<uint64_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(pq_encode_kernel, dim3(grid), dim3(256), (size_t)M * 16 * (dim / M) * sizeof(float), stream, d_vectors, n,
+                       M, dim, d_codebooks, d_codes);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic codes: word w (8 code bytes) = splitmix64(seed ^ splitmix64(w)), little endian.
 // Same function as orc_fill_codes in the oracle, so any sub-range is reproducible on the CPU.
 // ---------------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@ SYMBOLS = [
     "qadc_index_read_codes", "qadc_query_scan", "qadc_query_scan_candidates", "qadc_scan_i8",
     "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit",
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
-    "qadc_search_collect", "qadc_replay_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
+    "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_replay_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
 ]
 
 
@@ -94,6 +94,8 @@ def lib():
         L.qadc_search.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, u32p, i8p, i32p, i32p, i32p]
         L.qadc_search_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, C.c_int, C.c_int]
         L.qadc_search_collect.argtypes = [C.c_void_p, C.c_int, u32p, i8p, i32p, i32p, i32p]
+        L.qadc_pq_encode.argtypes = [C.c_int, C.c_int, f32p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.qadc_pq_encode_host.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_uint64, u8p, C.c_int]
         L.qadc_replay_i8.argtypes = [C.c_uint64, u32p, i8p, C.c_int, C.c_int, u32p, i8p, i32p]
         L.qadc_candidates_i8.argtypes = [C.c_void_p, C.c_int, i8p, i8p]
         L.qadc_float_top1.argtypes = [C.c_void_p, C.c_int, f32p, u32p, u32p, f32p]
@@ -120,6 +122,21 @@ def replay_i8(keys, vals, R, sentinel=False):
     _check(lib().qadc_replay_i8(len(keys), _p(keys, u32p), _p(vals, i8p), R, int(sentinel), _p(ok, u32p),
                                 _p(ov, i8p), C.byref(osz)))
     return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def pq_encode(codebooks, vectors, device=0):
+    """PQ-encode host vectors [n][dim] on the GPU -> uint8 codes [n][M/2]."""
+    cb = np.ascontiguousarray(codebooks, np.float32)
+    v = np.ascontiguousarray(vectors, np.float32)
+    M, dim = cb.shape[0], v.shape[1]
+    codes = np.zeros((v.shape[0], M // 2), np.uint8)
+    _check(lib().qadc_pq_encode_host(M, dim, _p(cb, f32p), _p(v, f32p), v.shape[0], _p(codes, u8p), device))
+    return codes
+
+
+def pq_encode_device(codebooks, d_vectors_ptr, n, dim, d_codes_ptr, device=0):
+    cb = np.ascontiguousarray(codebooks, np.float32)
+    _check(lib().qadc_pq_encode(cb.shape[0], dim, _p(cb, f32p), C.c_void_p(d_vectors_ptr), n, C.c_void_p(d_codes_ptr), device))
 
 
 class Index:

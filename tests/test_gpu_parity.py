@@ -465,3 +465,22 @@ def test_many_indexes_create_destroy(pyqadc, po):
     for idx in live:
         assert heaps_equal(idx.scan_i8(np.zeros((1, 1), np.int32), qt, 50)[0], want)
         idx.close()
+
+
+@pytest.mark.parametrize("M", [16, 32])
+def test_pq_encode_matches_host_loops(pyqadc, M):
+    """N4: device PQ encoder == first-minimum of the sequentially accumulated squared distances, packed
+    low nibble = even sub-quantizer (numpy restatement of the host loop)."""
+    rng = np.random.default_rng(M)
+    dim, n = 128, 20000
+    ds = dim // M
+    cb = rng.normal(size=(M, 16, ds)).astype(np.float32)
+    cb[3, 7] = cb[3, 2]                                       # duplicate centroid: ties must resolve to the first
+    v = rng.normal(size=(n, dim)).astype(np.float32)
+    got = pyqadc.pq_encode(cb, v)
+    best = np.zeros((n, M), np.int64)
+    for m in range(M):
+        d = _seq_sqdist(v[:, None, m * ds:(m + 1) * ds], cb[m][None, :, :])      # [n][16]
+        best[:, m] = np.argmin(d, axis=1)                     # first minimum
+    want = (best[:, 0::2] | (best[:, 1::2] << 4)).astype(np.uint8)
+    assert np.array_equal(got, want)
