@@ -147,10 +147,13 @@ int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* v
                             int32_t* status, float* qmin, float* qmax, int8_t* qtables);
 
 /* collect variant returning the ordered candidate stream (see qadc_query_scan_candidates): what a
- * rank hands to the cross-GPU gather.  On QADC_E_CAPACITY the result is kept: call again with buffers of
- * offsets[nq] entries. */
+ * rank hands to the cross-GPU gather.  cand_slots[i] (nullable) = position in assign[] of the probed
+ * partition entry i comes from: with every partition range-sharded over the ranks, the global scan order is
+ * (assign slot, rank, position), so the merge needs the slot boundaries of each rank's stream.
+ * On QADC_E_CAPACITY the result is kept: call again with buffers of offsets[nq] entries. */
 int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_capacity, uint32_t* cand_keys,
-                                       int8_t* cand_vals, uint64_t* offsets, int32_t* status, float* qmin, float* qmax);
+                                       int8_t* cand_vals, uint16_t* cand_slots, uint64_t* offsets, int32_t* status,
+                                       float* qmin, float* qmax);
 
 /* ---------------------------------------------------------------------------------------------
  * "Next" row N1 of SURVEY.md §8(f): the host feeders of the path, on the device.  Queries in, heaps out;

@@ -156,6 +156,27 @@ def shard_stream(M, codes, labels, global_n, first_pos, qt, R, cap=1 << 20):
     return ok[:cnt].copy(), ov[:cnt].copy()
 
 
+def shards_stream(M, pieces, labels, global_n, first_pos, qt, R, cap=1 << 20):
+    """Ordered push stream of one rank that holds one range of every probed partition (see
+    orc_scan_i8_shards_stream).  pieces[a] = row-major codes of the local range; labels[a] or None."""
+    ma = len(pieces)
+    pieces = [np.ascontiguousarray(p, np.uint8) for p in pieces]
+    pa, keep1 = _ptr_array(pieces, u8p)
+    la = None
+    if labels is not None:
+        la, keep2 = _ptr_array([np.ascontiguousarray(l, np.uint32) for l in labels], u32p)
+    n = np.array([p.shape[0] for p in pieces], np.uint32)
+    gn = np.ascontiguousarray(global_n, np.uint32)
+    fp = np.ascontiguousarray(first_pos, np.uint32)
+    qt = np.ascontiguousarray(qt, np.int8)
+    ok, ov, os_ = np.zeros(cap, np.uint32), np.zeros(cap, np.int8), np.zeros(cap, np.uint16)
+    lib().orc_scan_i8_shards_stream.restype = C.c_long
+    cnt = lib().orc_scan_i8_shards_stream(M, ma, pa, la, _p(n, u32p), _p(gn, u32p), _p(fp, u32p), _p(qt, i8p), R,
+                                          _p(ok, u32p), _p(ov, i8p), os_.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_long(cap))
+    assert cnt <= cap
+    return ok[:cnt].copy(), ov[:cnt].copy(), os_[:cnt].copy()
+
+
 def candidates_i8(M, codes, qt):
     codes = np.ascontiguousarray(codes, np.uint8)
     qt = np.ascontiguousarray(qt, np.int8)

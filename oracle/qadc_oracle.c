@@ -435,3 +435,50 @@ long orc_scan_i8_shard_stream(int M, const uint8_t* codes, const uint32_t* label
     free(hk); free(hv);
     return count;
 }
+
+/* Multi-partition form of orc_scan_i8_shard_stream (IVF on several GPUs): one rank holds the range
+ * [first_pos[a], first_pos[a] + n[a]) of every probed partition a (assign order); its LOCAL heap (sentinel
+ * first) is shared across its partition pieces exactly like scanner_4's heap across partitions.  Records every
+ * attempted push with its assign slot.  qt: int8 [ma][M][16].  Returns the stream length. */
+long orc_scan_i8_shards_stream(int M, int ma, const uint8_t* const* codes, const uint32_t* const* labels,
+                               const uint32_t* n, const uint32_t* global_n, const uint32_t* first_pos, const int8_t* qt,
+                               int R, uint32_t* out_keys, int8_t* out_vals, uint16_t* out_slots, long cap) {
+    const int cs = M / 2;
+    uint32_t* hk = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)R);
+    int8_t* hv = (int8_t*)malloc((size_t)R);
+    orc_heap_i8 h = { hk, hv, R, 0 };
+    orc_heap_i8_push(&h, 0, 127);
+    long count = 0;
+    for (int a = 0; a < ma; ++a) {
+        if (n[a] == 0) continue;
+        const int8_t* t = qt + (long)a * M * 16;
+        int8_t bound = h.vals[0];                             /* scan_avx_4 samples bh.max() on entry */
+        const uint32_t last_global = global_n[a] - 1u;
+        const uint32_t end = first_pos[a] + n[a];
+        const uint32_t blk_end = (end == global_n[a]) ? (global_n[a] + 15u) / 16u * 16u : end;
+        for (uint32_t g0 = first_pos[a]; g0 < blk_end; g0 += 16) {
+            int any = 0;
+            const int8_t bound_blk = bound;
+            for (int j = 0; j < 16; ++j) {
+                uint32_t gi = g0 + (uint32_t)j;
+                if (gi > last_global) gi = last_global;
+                const uint32_t li = gi - first_pos[a];
+                const uint8_t* c = codes[a] + (long)li * cs;
+                int s = 0;
+                for (int b = 0; b < cs; ++b)
+                    s += t[(2 * b) * 16 + (c[b] & 15)] + t[(2 * b + 1) * 16 + (c[b] >> 4)];
+                const int8_t cand = (int8_t)(s > 127 ? 127 : s);
+                if (cand < bound_blk) {
+                    const uint32_t key = (labels && labels[a]) ? labels[a][li] : gi;
+                    orc_heap_i8_push(&h, key, cand);
+                    if (count < cap) { out_keys[count] = key; out_vals[count] = cand; out_slots[count] = (uint16_t)a; }
+                    ++count;
+                    any = 1;
+                }
+            }
+            if (any) bound = h.vals[0];
+        }
+    }
+    free(hk); free(hv);
+    return count;
+}

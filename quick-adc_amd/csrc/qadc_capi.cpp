@@ -159,7 +159,7 @@ struct Slot {
     std::vector<hipEvent_t> prof_ev;    // pairs: [2i] before, [2i+1] after; pair 0 = pre-scan chain
     size_t prof_used = 0;
 
-    // collect() results: ordered candidate streams, entry = key | (value << 32)
+    // collect() results: ordered candidate streams, entry = key | value << 32 | assign slot << 40
     std::vector<uint64_t> out_entries;
     std::vector<uint64_t> out_off;
 };
@@ -264,8 +264,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             if (p < 0 || p >= (int)idx->parts.size())
                 return fail(QADC_E_ARG, "assign[] names a partition that does not exist");
             const Part& pt = idx->parts[p];
-            if (pt.n == 0) continue;  // db_query_4.cpp:291-293
-            if (s.float_path) {
+            if (pt.global_n == 0) continue;  // empty partition: db_query_4.cpp:291-293
+            if (s.float_path && pt.start_n) {
                 const uint8_t* sc = pt.d_starts ? pt.d_starts : pt.d_codes;
                 const uint64_t in_a = soff < sample ? std::min<uint64_t>(pt.start_n, sample - soff) : 0;
                 StartItem si;
@@ -288,6 +288,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                 soff += pt.start_n;
                 s.start_codes += pt.start_n;
             }
+            if (pt.n == 0) continue;         // this rank holds no codes of the partition (only its starts replica)
             uint64_t prev = 0;
             for (int k = 0; k < kMaxLevels && prev < pt.n; ++k) {
                 uint64_t cut = pt.n;
@@ -665,7 +666,8 @@ int collect_common(qadc_index* idx, int slot_i) {
         for (uint32_t i = 0; i < qs.count; ++i) {
             const uint32_t reps = 1u + ((c[i].order >> 20) & 15u);
             for (uint32_t r = 0; r < reps; ++r)
-                s.out_entries.push_back((uint64_t)c[i].key | ((uint64_t)(c[i].val & 0xffu) << 32));
+                s.out_entries.push_back((uint64_t)c[i].key | ((uint64_t)(c[i].val & 0xffu) << 32) |
+                                        ((uint64_t)(c[i].order & 0x3fffu) << 40));
         }
     }
     s.out_off[s.nq] = s.out_entries.size();
@@ -887,7 +889,7 @@ int qadc_index_add_partition_synthetic(qadc_index* idx, uint32_t size, uint64_t 
 
 static int attach_starts(qadc_index* idx, Part& pt, const uint8_t* starts_host, uint32_t starts_count, uint64_t seed,
                          bool synthetic) {
-    if (pt.first_pos == 0 && starts_count <= pt.n) {  // the local range begins with the starts
+    if (pt.n && pt.first_pos == 0 && starts_count <= pt.n) {  // the local range begins with the starts
         pt.starts_cap = pt.n;
         return QADC_OK;
     }
@@ -907,18 +909,21 @@ static int attach_starts(qadc_index* idx, Part& pt, const uint8_t* starts_host, 
 
 int qadc_index_add_partition_shard(qadc_index* idx, const uint8_t* codes, const uint32_t* labels, uint32_t local_n,
                                    uint32_t global_n, uint32_t first_pos, const uint8_t* starts, uint32_t starts_count) {
-    if (!idx || !codes || local_n == 0 || (uint64_t)first_pos + local_n > global_n)
+    if (!idx || (local_n && !codes) || global_n == 0 || (uint64_t)first_pos + local_n > global_n)
         return fail(QADC_E_ARG, "bad shard range");
     if ((uint64_t)first_pos * idx->cs % 16 != 0) return fail(QADC_E_ARG, "first_pos must keep the shard 16-byte aligned");
     if (int rc = use_device(idx)) return rc;
-    if (int rc = check_labels_mode(idx, labels != nullptr)) return rc;
+    if (local_n)
+        if (int rc = check_labels_mode(idx, labels != nullptr)) return rc;
     Part pt;
-    if (int rc = alloc_part(idx, pt, local_n, labels != nullptr)) return rc;
-    pt.global_n = global_n;
+    if (local_n) {
+        if (int rc = alloc_part(idx, pt, local_n, labels != nullptr)) return rc;
+        HIPCHECK(hipMemcpyAsync(pt.d_codes, codes, (size_t)local_n * idx->cs, hipMemcpyHostToDevice, idx->stream));
+        if (labels) HIPCHECK(hipMemcpyAsync(pt.d_labels, labels, (size_t)local_n * 4, hipMemcpyHostToDevice, idx->stream));
+        HIPCHECK(hipStreamSynchronize(idx->stream));
+    }
+    pt.global_n = global_n;      // local_n == 0: the rank holds only the partition's starts replica
     pt.first_pos = first_pos;
-    HIPCHECK(hipMemcpyAsync(pt.d_codes, codes, (size_t)local_n * idx->cs, hipMemcpyHostToDevice, idx->stream));
-    if (labels) HIPCHECK(hipMemcpyAsync(pt.d_labels, labels, (size_t)local_n * 4, hipMemcpyHostToDevice, idx->stream));
-    HIPCHECK(hipStreamSynchronize(idx->stream));
     if (int rc = attach_starts(idx, pt, starts, starts_count, 0, false)) return rc;
     idx->parts.push_back(pt);
     idx->finalized = false;
@@ -955,7 +960,7 @@ int qadc_index_finalize(qadc_index* idx, float keep) {
     if (idx->parts.empty()) return fail(QADC_E_STATE, "no partitions");
     idx->keep = keep;
     for (auto& p : idx->parts) {
-        if (p.n == 0) {
+        if (p.global_n == 0) {
             p.start_n = 0;
             continue;
         }
@@ -1029,10 +1034,12 @@ int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* v
     return replay_outputs(idx, s, keys, values, sizes, status);
 }
 
-static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals, uint64_t* offsets);
+static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals, uint64_t* offsets,
+                       uint16_t* cand_slots = nullptr);
 
 int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_capacity, uint32_t* cand_keys,
-                                       int8_t* cand_vals, uint64_t* offsets, int32_t* status, float* qmin, float* qmax) {
+                                       int8_t* cand_vals, uint16_t* cand_slots, uint64_t* offsets, int32_t* status,
+                                       float* qmin, float* qmax) {
     if (!idx || slot < 0 || slot > 1) return fail(QADC_E_ARG, "bad arguments");
     Slot& s = idx->slot[slot];
     if (s.busy) {
@@ -1043,7 +1050,7 @@ int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_
     }
     finish_float_outputs(idx, s, status, qmin, qmax);
     // QADC_E_CAPACITY keeps the result: call again with buffers of offsets[nq] entries
-    const int rc = copy_stream(s, cand_capacity, cand_keys, cand_vals, offsets);
+    const int rc = copy_stream(s, cand_capacity, cand_keys, cand_vals, offsets, cand_slots);
     if (rc == QADC_OK) s.has_result = false;
     return rc;
 }
@@ -1054,7 +1061,8 @@ int qadc_query_scan(qadc_index* idx, int nq, int ma, const int32_t* assign, floa
     return qadc_query_scan_collect(idx, 0, keys, values, sizes, status, qmin, qmax, qtables);
 }
 
-static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals, uint64_t* offsets) {
+static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int8_t* cand_vals, uint64_t* offsets,
+                       uint16_t* cand_slots) {
     if (!offsets) return fail(QADC_E_ARG, "offsets is null");
     std::memcpy(offsets, s.out_off.data(), sizeof(uint64_t) * (s.nq + 1));
     const uint64_t total = s.out_off[s.nq];
@@ -1062,6 +1070,7 @@ static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int
     for (uint64_t i = 0; i < total; ++i) {
         if (cand_keys) cand_keys[i] = (uint32_t)s.out_entries[i];
         if (cand_vals) cand_vals[i] = (int8_t)(s.out_entries[i] >> 32);
+        if (cand_slots) cand_slots[i] = (uint16_t)((s.out_entries[i] >> 40) & 0x3fffu);
     }
     return QADC_OK;
 }

@@ -94,7 +94,7 @@ void launch_scan_i8_small(int M, const ScanItem* d_items, int nitems, int wgs_pe
 // position), padding-lane replays expanded, written compactly to d_out_keys / d_out_vals at the prefix
 // offset of the query.  Queries with more than kSortCap candidates (or an overflowed region) are left
 // to the host (flags bit2 stays clear).
-// Sorted entries are written as u64 = key | (value << 32); every query gets its QueryOut record.
+// Sorted entries are written as u64 = key | value << 32 | assign slot << 40; every query gets its QueryOut record.
 void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, QueryOut* d_qout,
                        uint64_t* d_entries, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream);
 

@@ -529,7 +529,8 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
             if (i < ns) {
                 const Cand c = region[s0 + i];
                 k = cand_sort_key(c, i);
-                wpay[i] = (uint64_t)c.key | ((uint64_t)(c.val | (((c.order >> 20) & 15u) << 8)) << 32);
+                wpay[i] = (uint64_t)c.key | ((uint64_t)(c.val | (((c.order >> 20) & 15u) << 8)) << 32) |
+                          ((uint64_t)(c.order & 0x3fffu) << 48);   // key | value | replays << 40 | assign slot << 48
             }
             v[r] = k;
         }
@@ -565,7 +566,8 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
             const uint64_t pay = wpay[wkey[i] & 0x3fffu];
             const uint32_t reps = 1u + ((uint32_t)(pay >> 40) & 15u);
             for (uint32_t r = 0; r < reps; ++r, ++w) {
-                if (w < out_cap) out_entries[w] = pay & 0xffffffffffull;        // key | value << 32
+                // entry = key | value << 32 | assign slot << 40
+                if (w < out_cap) out_entries[w] = (pay & 0xffffffffffull) | ((pay >> 48) << 40);
                 else atomicAdd(&hdr->out_overflow, 1u);
             }
         }
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
         const Cand c = region[lkey[i] & 0x3fffu];
         const uint32_t reps = 1u + ((c.order >> 20) & 15u);
         for (uint32_t r = 0; r < reps; ++r, ++w) {
-            if (w < out_cap) out_entries[w] = (uint64_t)c.key | ((uint64_t)(c.val & 0xffu) << 32);
+            if (w < out_cap) out_entries[w] = (uint64_t)c.key | ((uint64_t)(c.val & 0xffu) << 32) | ((uint64_t)(c.order & 0x3fffu) << 40);
             else atomicAdd(&hdr->out_overflow, 1u);
         }
     }

@@ -111,12 +111,12 @@ struct scanner_hip {
         }
         int rc = qadc_query_scan_submit(index, 0, nq, ma, assign, tables, R);
         if (rc == QADC_OK)
-            rc = qadc_query_scan_collect_candidates(index, 0, cand_keys.size(), cand_keys.data(), cand_vals.data(),
+            rc = qadc_query_scan_collect_candidates(index, 0, cand_keys.size(), cand_keys.data(), cand_vals.data(), nullptr,
                                                     batch_offsets.data(), batch_status.data(), nullptr, nullptr);
         if (rc == QADC_E_CAPACITY) {  // the result is kept: fetch it again with buffers of the required size
             cand_keys.resize(batch_offsets[nq]);
             cand_vals.resize(batch_offsets[nq]);
-            rc = qadc_query_scan_collect_candidates(index, 0, cand_keys.size(), cand_keys.data(), cand_vals.data(),
+            rc = qadc_query_scan_collect_candidates(index, 0, cand_keys.size(), cand_keys.data(), cand_vals.data(), nullptr,
                                                     batch_offsets.data(), batch_status.data(), nullptr, nullptr);
         }
         if (rc != QADC_OK) die("batch_scan");

@@ -69,8 +69,8 @@ def lib():
                                                      C.c_uint32]
         L.qadc_index_add_partition_synthetic_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                                                C.c_uint64, C.c_uint32]
-        L.qadc_query_scan_collect_candidates.argtypes = [C.c_void_p, C.c_int, C.c_uint64, u32p, i8p, u64p, i32p, f32p,
-                                                         f32p]
+        L.qadc_query_scan_collect_candidates.argtypes = [C.c_void_p, C.c_int, C.c_uint64, u32p, i8p, C.POINTER(C.c_uint16),
+                                                         u64p, i32p, f32p, f32p]
         L.qadc_index_set_key_base.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
         L.qadc_index_finalize.argtypes = [C.c_void_p, C.c_float]
         L.qadc_index_partition_count.argtypes = [C.c_void_p]
@@ -268,22 +268,24 @@ class Index:
     def collect_candidates(self, slot, capacity=1 << 18):
         nq, R, tables, assign = self._pending.pop(slot)
         bufs = getattr(self, "_cand_bufs", None)
+        u16p = C.POINTER(C.c_uint16)
         if bufs is None or len(bufs[0]) < capacity:        # reused across calls: no per-step page faults
-            bufs = self._cand_bufs = (np.zeros(capacity, np.uint32), np.zeros(capacity, np.int8))
-        ck, cv = bufs
+            bufs = self._cand_bufs = (np.zeros(capacity, np.uint32), np.zeros(capacity, np.int8),
+                                      np.zeros(capacity, np.uint16))
+        ck, cv, cs_ = bufs
         off = np.zeros(nq + 1, np.uint64)
         status = np.zeros(nq, np.int32)
         qmin = np.zeros(nq, np.float32)
         qmax = np.zeros(nq, np.float32)
-        rc = lib().qadc_query_scan_collect_candidates(self._h, slot, len(ck), _p(ck, u32p), _p(cv, i8p), _p(off, u64p),
-                                                      _p(status, i32p), _p(qmin, f32p), _p(qmax, f32p))
+        rc = lib().qadc_query_scan_collect_candidates(self._h, slot, len(ck), _p(ck, u32p), _p(cv, i8p), _p(cs_, u16p),
+                                                      _p(off, u64p), _p(status, i32p), _p(qmin, f32p), _p(qmax, f32p))
         if rc == -3:                                        # QADC_E_CAPACITY: the result is kept, retry larger
             need = int(off[nq]) + 1024
-            ck, cv = self._cand_bufs = (np.zeros(need, np.uint32), np.zeros(need, np.int8))
-            rc = lib().qadc_query_scan_collect_candidates(self._h, slot, need, _p(ck, u32p), _p(cv, i8p), _p(off, u64p),
-                                                          _p(status, i32p), _p(qmin, f32p), _p(qmax, f32p))
+            ck, cv, cs_ = self._cand_bufs = (np.zeros(need, np.uint32), np.zeros(need, np.int8), np.zeros(need, np.uint16))
+            rc = lib().qadc_query_scan_collect_candidates(self._h, slot, need, _p(ck, u32p), _p(cv, i8p), _p(cs_, u16p),
+                                                          _p(off, u64p), _p(status, i32p), _p(qmin, f32p), _p(qmax, f32p))
         _check(rc)
-        return dict(keys=ck, vals=cv, offsets=off.astype(np.int64), status=status, qmin=qmin, qmax=qmax)
+        return dict(keys=ck, vals=cv, slots=cs_, offsets=off.astype(np.int64), status=status, qmin=qmin, qmax=qmax)
 
     def set_pq(self, codebooks):
         cb = np.ascontiguousarray(codebooks, np.float32)
@@ -334,6 +336,14 @@ class Index:
         _check(lib().qadc_scan_i8_candidates(self._h, nq, ma, _p(assign, i32p), _p(qt, i8p), R, capacity,
                                              _p(ck, u32p), _p(cv, i8p), _p(off, u64p)))
         return [(ck[int(off[q]):int(off[q + 1])].copy(), cv[int(off[q]):int(off[q + 1])].copy()) for q in range(nq)]
+
+    def query_scan_shard_streams(self, assign, tables, R, capacity=1 << 18):
+        """submit + collect_candidates: this rank's ordered streams with assign slots (multi-GPU callers)."""
+        self.submit(0, assign, tables, R)
+        res = self.collect_candidates(0, capacity)
+        total = int(res["offsets"][-1])
+        return dict(keys=res["keys"][:total].copy(), vals=res["vals"][:total].copy(), slots=res["slots"][:total].copy(),
+                    offsets=res["offsets"].copy(), status=res["status"], qmin=res["qmin"], qmax=res["qmax"])
 
     def query_scan_candidates(self, assign, tables, R, capacity=1 << 20):
         assign = self._prep(assign)

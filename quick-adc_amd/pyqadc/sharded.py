@@ -30,21 +30,25 @@ def shard_ranges(n, world, align=16):
 
 
 def _pack(local, nq, cap):
-    """int32 buffer: [nq counts][cap keys][cap/4 packed int8 vals]."""
+    """int32 buffer: [nq counts][cap keys][cap/4 packed int8 vals][cap/2 packed u16 assign slots]."""
     counts = np.diff(local["offsets"]).astype(np.int64)
     total = int(counts.sum())
-    buf = np.zeros(nq + cap + (cap + 3) // 4, np.int32)
+    nv = (cap + 3) // 4
+    buf = np.zeros(nq + cap + nv + (cap + 1) // 2, np.int32)
     buf[:nq] = counts
     if total <= cap:
         buf[nq:nq + total] = local["keys"][:total].view(np.int32)
-        vb = buf[nq + cap:].view(np.int8)
-        vb[:total] = local["vals"][:total]
+        buf[nq + cap:nq + cap + nv].view(np.int8)[:total] = local["vals"][:total]
+        if local.get("slots") is not None:
+            buf[nq + cap + nv:].view(np.uint16)[:total] = local["slots"][:total]
     return buf, total
 
 
-def merge_batch(local, nq, R, status, device, cap=1 << 15):
+def merge_batch(local, nq, R, status, device, cap=1 << 15, ma=1):
     """All ranks call with their local ordered candidate stream
-    local = dict(keys=u32[...], vals=i8[...], offsets=i64[nq+1]).
+    local = dict(keys=u32[...], vals=i8[...], offsets=i64[nq+1][, slots=u16[...]]).
+    ma > 1 (IVF, every probed partition range-sharded over the ranks): the global scan order is
+    (assign slot, rank, position), so the per-rank streams are interleaved by their slot boundaries.
     Returns (keys u32[nq][R], vals i8[nq][R], sizes i32[nq]) identical on every rank: the heap arrays
     the reference's single sequential scan over the whole list would leave."""
     world = dist.get_world_size()
@@ -67,10 +71,25 @@ def merge_batch(local, nq, R, status, device, cap=1 << 15):
         if status is not None and status[q]:
             continue
         ks, vs = [], []
+        nv = (cap + 3) // 4
+        segs = []
         for g in range(world):
             a, b = int(offs[g, q]), int(offs[g, q + 1])
-            ks.append(allb[g, nq + a:nq + b].view(np.uint32))
-            vs.append(allb[g, nq + cap:].view(np.int8)[a:b])
+            k = allb[g, nq + a:nq + b].view(np.uint32)
+            v = allb[g, nq + cap:nq + cap + nv].view(np.int8)[a:b]
+            if ma == 1:
+                segs.append((k, v, None))
+            else:
+                sl = allb[g, nq + cap + nv:].view(np.uint16)[a:b]          # ascending: a rank scans in assign order
+                segs.append((k, v, np.searchsorted(sl, np.arange(ma + 1))))
+        for slot in range(ma):
+            for k, v, bnd in segs:
+                if bnd is None:
+                    ks.append(k)
+                    vs.append(v)
+                else:
+                    ks.append(k[bnd[slot]:bnd[slot + 1]])
+                    vs.append(v[bnd[slot]:bnd[slot + 1]])
         k, v = replay_i8(np.concatenate(ks), np.concatenate(vs), R, sentinel=True)   # db_query_4.cpp:276
         keys[q, :len(k)] = k
         vals[q, :len(v)] = v

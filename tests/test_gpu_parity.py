@@ -484,3 +484,44 @@ def test_pq_encode_matches_host_loops(pyqadc, M):
         best[:, m] = np.argmin(d, axis=1)                     # first minimum
     want = (best[:, 0::2] | (best[:, 1::2] << 4)).astype(np.uint8)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("M", [16, 32])
+def test_ivf_range_shards_merge_by_assign_slot(pyqadc, po, M):
+    """Multi-GPU IVF as 3 virtual ranks on one GPU: every partition (labelled, ragged, some so small that a rank
+    holds none of it) is range-sharded; each rank carries the partitions' starts; the streams, interleaved by
+    (assign slot, rank), replay to the heaps of the unsharded database."""
+    from pyqadc import sharded
+    rng = np.random.default_rng(7 + M)
+    sizes = [20011, 37, 6000, 16, 9003]
+    keep, R, nq, ma, world = 0.05, 100, 4, 3, 3
+    parts = [rand_codes(rng, s, M) for s in sizes]
+    perm = rng.permutation(sum(sizes)).astype(np.uint32)
+    labels = list(np.split(perm, np.cumsum(sizes)[:-1]))
+    ranks = []
+    for r in range(world):
+        idx = pyqadc.Index(M)
+        for p, s in enumerate(sizes):
+            first, ln = sharded.shard_ranges(s, world)[r]
+            st = po.start_size(s, keep)
+            idx.add_partition_shard(parts[p][first:first + ln], first, s, labels=labels[p][first:first + ln] if ln else None,
+                                    starts=parts[p][:st])
+        idx.finalize(keep)
+        ranks.append(idx)
+    assign = np.stack([rng.choice(len(sizes), ma, replace=False) for _ in range(nq)]).astype(np.int32)
+    tables = float_tables(rng, nq, ma, M)
+    outs = [idx.query_scan_shard_streams(assign, tables.copy(), R) for idx in ranks]
+    for q in range(nq):
+        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
+        ks, vs = [], []
+        for slot in range(ma):
+            for o in outs:
+                assert o["qmax"][q] == np.float32(want["qmax"])
+                a, b = int(o["offsets"][q]), int(o["offsets"][q + 1])
+                sel = o["slots"][a:b] == slot
+                ks.append(o["keys"][a:b][sel])
+                vs.append(o["vals"][a:b][sel])
+        got = pyqadc.replay_i8(np.concatenate(ks), np.concatenate(vs), R, sentinel=True)
+        assert heaps_equal(got, (want["keys"], want["values"])), q
+    for idx in ranks:
+        idx.close()
