@@ -157,7 +157,7 @@ int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_
 
 /* ---------------------------------------------------------------------------------------------
  * "Next" row N1 of SURVEY.md §8(f): the host feeders of the path, on the device.  Queries in, heaps out;
- * assignment, residuals and float tables never cross PCIe.  Replaces, for plain PQ (no OPQ rotation):
+ * assignment, residuals and float tables never cross PCIe.  Replaces:
  *   index_db::assign_compute_residuals  (databases.hpp:201-211; find_k_neighbors, neighbors.cpp:30-76)
  *   flat_db::assign_compute_residuals   (databases.hpp:93-101)
  *   opq::rotate_multiple_vectors        (quantizers.hpp:289-301)
