@@ -64,6 +64,45 @@ def cpu_baseline(M, n_total, seed, qtables, R, seconds):
                                         if kind == "reference" else "scalar C port (oracle)")}
 
 
+def cpu_extra_legs(M, n_total, seed, qtables, R, seconds):
+    """Two more CPU figures asked for by BASELINE.md §3 (reported, never the target):
+    - the reference's AVX2 scan on ALL host cores (one query per thread: ctypes releases the GIL);
+    - BASELINE config 1, PQ 8x8 float ADC over 1M codes (scanner_simple / scan_standard<uint8_t,8>), 1 thread,
+      timed with the oracle's C port."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    out = {}
+    if po.have_ref():
+        cs = M // 2
+        n = int(min(n_total, 32 * 1024 * 1024))
+        codes = po.fill_codes(0, (n * cs + 7) // 8, seed)[:n * cs].reshape(n, cs)
+        inter = po.ref_interleave(codes)
+        cores = os.cpu_count() or 1
+        run = lambda i: po.ref_scan_interleaved(M, [inter], [n], None, qtables[i % len(qtables)], R)
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(run, range(cores)))                       # warm
+            t0, done = time.perf_counter(), 0
+            while time.perf_counter() - t0 < seconds:
+                list(ex.map(run, range(4 * cores)))
+                done += 4 * cores
+            dt = time.perf_counter() - t0
+        out["cpu_baseline_all_cores"] = {"value": n * done / dt, "unit": "codes/s", "cores": cores, "kind": "reference",
+                                         "sample": "%d queries x first %d codes, one query per thread" % (done, n)}
+    rng = np.random.default_rng(5)
+    codes8 = rng.integers(0, 256, (1000000, 8), dtype=np.uint8)
+    tables8 = rng.random((1, 8, 256)).astype(np.float32)
+    po.scan_standard_u8(8, [codes8], None, tables8, R)
+    t0, done = time.perf_counter(), 0
+    while time.perf_counter() - t0 < min(seconds, 3.0):
+        po.scan_standard_u8(8, [codes8], None, tables8, R)
+        done += 1
+    dt = time.perf_counter() - t0
+    out["cpu_config1_pq8x8_float_adc"] = {"value": 1000000 * done / dt, "unit": "codes/s", "cores": 1, "kind": "port",
+                                          "sample": "%d queries x 1M codes, scan_standard<uint8_t,8> C port" % done}
+    return out
+
+
 def real_encode_recall(M, R, keep, n, nq, local_rank):
     """Recall@R on REAL encodings (SURVEY.md §8d "real-encode variant"): clustered synthetic 128-d vectors,
     codebooks = sampled sub-vectors, PQ-encoded on the GPU (qadc_pq_encode), queried through the device-side
@@ -243,6 +282,7 @@ def main():
         if world == 1 and cpu_s > 0:
             res = idx.query_scan(assign, pool[0].copy(), R, want_qtables=True)
             out["cpu_baseline"] = cpu_baseline(M, N, SEED, res["qtables"][:, 0], R, cpu_s)
+            out.update(cpu_extra_legs(M, N, SEED, res["qtables"][:, 0], R, min(cpu_s, 6.0)))
         print(json.dumps(out), flush=True)
     idx.close()
     if use_dist:
