@@ -525,3 +525,76 @@ def test_ivf_range_shards_merge_by_assign_slot(pyqadc, po, M):
         assert heaps_equal(got, (want["keys"], want["values"])), q
     for idx in ranks:
         idx.close()
+
+
+def test_borrowed_device_partitions_key_base_and_scan_start(pyqadc, po):
+    """Partitions whose codes/labels already live in device memory (torch tensors here), a key offset for an
+    unlabelled partition, and the stand-alone pre-scan entry point."""
+    import torch
+    rng = np.random.default_rng(51)
+    M, R, keep = 16, 100, 0.03
+    sizes = [30000, 12001]
+    parts = [rand_codes(rng, s, M) for s in sizes]
+    labels = [rng.permutation(s).astype(np.uint32) + 10 * s for s in sizes]
+    tables = float_tables(rng, 2, 2, M)
+    assign = np.array([[0, 1], [1, 0]], np.int32)
+    # labelled, borrowed
+    idx = pyqadc.Index(M)
+    keep_alive = []
+    for c, l in zip(parts, labels):
+        dc = torch.zeros(c.size + 64, dtype=torch.uint8, device="cuda")
+        dc[:c.size] = torch.from_numpy(c.reshape(-1)).cuda()
+        dl = torch.from_numpy(l.astype(np.int64)).cuda().to(torch.int32)        # same 32 bits as the uint32 labels
+        torch.cuda.synchronize()
+        keep_alive += [dc, dl]
+        idx.add_partition_device(dc.data_ptr(), c.shape[0], dl.data_ptr(), keepalive=(dc, dl))
+    idx.finalize(keep)
+    res = idx.query_scan(assign, tables.copy(), R)
+    qmax = idx.scan_start(assign, tables, R)
+    for q in range(2):
+        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"]))
+        assert qmax[q] == np.float32(want["qmax"])
+    idx.close()
+    # unlabelled with a key offset: keys = key_base + position
+    idx = pyqadc.Index(M)
+    idx.add_partitions([parts[0]])
+    idx.set_key_base(0, 1000000)
+    idx.finalize(keep)
+    t1 = float_tables(rng, 1, 1, M)
+    got = idx.query_scan(np.zeros((1, 1), np.int32), t1.copy(), R)["heaps"][0]
+    want = po.query_scan(M, [parts[0]], None, keep, [0], t1[0].copy(), R)
+    wk = want["keys"].copy()
+    real = np.ones(len(wk), bool)
+    if want["values"][0] == 127 or (len(wk) < R):              # a surviving (0,127) sentinel keeps key 0
+        real = ~((want["keys"] == 0) & (want["values"] == 127))
+    wk[real] += 1000000
+    assert np.array_equal(got[0], wk) and np.array_equal(got[1], want["values"])
+    idx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_quantizer_modes_match_oracle(pyqadc, po, mode):
+    rng = np.random.default_rng(60 + mode)
+    codes = rand_codes(rng, 50000, 16)
+    idx = pyqadc.Index(16)
+    idx.add_partitions([codes])
+    idx.finalize(0.02)
+    idx.set_option("quant_mode", mode)
+    tables = float_tables(rng, 4, 1, 16, scale=0.37)
+    res = idx.query_scan(np.zeros((4, 1), np.int32), tables.copy(), 100, want_qtables=True)
+    for q in range(4):
+        want = po.query_scan(16, [codes], None, 0.02, [0], tables[q].copy(), 100, quant_mode=mode)
+        assert np.array_equal(res["qtables"][q], want["qtables"])
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"]))
+    idx.close()
+
+
+def test_candidate_output_capacity_error(pyqadc):
+    rng = np.random.default_rng(61)
+    idx = pyqadc.Index(16)
+    idx.add_partitions([rand_codes(rng, 20000, 16)])
+    idx.finalize(0.05)
+    with pytest.raises(pyqadc.QadcError, match="too small"):
+        idx.query_scan_candidates(np.zeros((1, 1), np.int32), float_tables(rng, 1, 1, 16), 100, capacity=4)
+    idx.close()
