@@ -1,9 +1,11 @@
 """bench.py — Quick-ADC flat scan on MI355X: PQ codes scanned / second (+ Recall@100).
 
 Workload (BASELINE.json configs[3] shape, which fits one GPU): flat database of 1B synthetic
-16x4 PQ codes (8 B/code, counter-based generator), R = 100, keep = 1 %, one query per pass over
-the list.  A step = one batch of NQ queries through the whole scanner_4::query_scan path
-(float pre-scan of the starts -> qmax, quantizer, int8 scan of every code, candidate replay).
+16x4 PQ codes (8 B/code, counter-based generator), R = 100, keep = 1 %, every query scans the
+whole list.  A step = one batch of NQ = 32 queries (the reference's documented `-b32`,
+README.md:275-330) through the whole scanner_4::query_scan path (float pre-scan of the starts ->
+qmax, quantizer, int8 scan of every code, candidate replay).  The queries of a batch are launched
+as L2-sharing siblings: the codes cross the HBM interface about once per launch, not once per query.
 With --gpus N the SAME 1B-code list is sharded over the N ranks in contiguous ranges ("strong"
 scaling; keys are 32-bit as in the reference, so the list cannot grow past 2^32 anyway) and the
 per-shard push streams are gathered once per batch over RCCL and replayed (pyqadc/sharded.py).
@@ -156,7 +158,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     M = int(os.environ.get("QADC_BENCH_M", 16))
     N = int(float(os.environ.get("QADC_BENCH_CODES", 1e9)))
-    NQ = int(os.environ.get("QADC_BENCH_NQ", 8))
+    NQ = int(os.environ.get("QADC_BENCH_NQ", 32))
     R, KEEP, SEED = 100, 0.01, 0x5EED0001
     cs = M // 2
 
@@ -189,6 +191,8 @@ def main():
     idx.add_partition_synthetic_shard(N, first, local_n, SEED, starts)
     idx.finalize(KEEP)
     idx.set_option("profile", 1)
+    for kv in filter(None, os.environ.get("QADC_BENCH_OPTS", "").split(",")):     # tuning experiments only
+        idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 
     rng = np.random.default_rng(1234)
     codebooks = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
@@ -254,7 +258,13 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if world == 1 and os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("bytes_per_launch")
+            pj = json.load(open(pmc))
+            if pj.get("queries_per_step") == NQ and pj.get("codes") == N and pj.get("M") == M:
+                traffic = pj.get("bytes_per_launch")
+        launches = max(prof["scan_launches"], 1)
+        avg_ms = scan_ms / launches
+        alg_bytes = prof["scan_codes"] * cs / launches
+        lookups = prof["scan_codes"] * (M // 2) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0   # ds_read_u8 lanes, G/s
         out = {
             "metric": "pq_codes_scanned_per_sec", "value": total_codes / elapsed, "unit": "codes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -267,9 +277,20 @@ def main():
             "recall_at_100": recall,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "scan_i8_kernel<%d,2,nt,chunk>" % M, "launches": prof["scan_launches"],
-                         "avg_launch_ms": scan_ms / max(prof["scan_launches"], 1),
-                         "algorithmic_bytes_per_launch": prof["scan_codes"] * cs / max(prof["scan_launches"], 1)},
+                         "kernel": "scan_i8_kernel<%d,2> (sibling-major launch, %d queries share each tile)" % (M, NQ)
+                                   if NQ > 1 else "scan_i8_kernel<%d,2,nt,chunk>" % M,
+                         "launches": prof["scan_launches"], "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         # what actually crossed the HBM interface (PMC pass, profiles/): below the algorithmic
+                         # bytes because the queries of a launch share tiles in L2 -- which is why frac can exceed 1
+                         "hbm_actual": None if traffic is None else
+                         {"achieved": traffic / (avg_ms * 1e-3) / 1e9, "unit": "GB/s",
+                          "frac": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "traffic_over_algorithmic": traffic / alg_bytes},
+                         # the limiter once the codes come from L2: one ds_read_u8 per pair of sub-quantizers,
+                         # 2 LDS cycles per wave-instruction (MI355X_MICROARCH.md, LDS) = 32 lanes/clk/CU
+                         "lds": {"achieved": lookups, "peak": 256 * 32 * 2.4, "unit": "G lookups/s",
+                                 "frac": lookups / (256 * 32 * 2.4)}},
             "phases": {"prescan_quantize_ms_per_step": prof["start_ms"] / args.steps,
                        "scan_kernel_ms_per_step": scan_ms / args.steps,
                        "host_sort_replay_ms_per_step": prof["host_replay_ms"] / args.steps,

@@ -88,8 +88,9 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
 
 /* Tunables: "quant_mode" (1 = as compiled by the reference's flags, 0 = source level), "profile" (0/1),
  * "cand_capacity" (candidate region entries per query), "level_base", "level_growth" (bound levels),
- * "prescan_sample", "small_run", "small_vec_per_wg", "wgs_per_item", "variant" (kernel tuning),
- * "replay_threads". */
+ * "prescan_sample", "small_run", "small_vec_per_wg", "wgs_per_item", "variant", "share_variant" (0 = never
+ * launch the queries of a batch as L2-sharing siblings), "share_codes_per_wg", "overlap_front" (kernel and
+ * launch tuning), "replay_threads". */
 int qadc_set_option(qadc_index* idx, const char* name, double value);
 
 /* Copy codes back (tests / checksums): partition `part`, codes [first, first+count). */

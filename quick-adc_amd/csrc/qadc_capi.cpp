@@ -67,12 +67,12 @@ template <typename T>
 struct PinBuf {
     T* p = nullptr;
     size_t cap = 0;
-    hipError_t ensure(size_t n) {
+    hipError_t ensure(size_t n, unsigned flags = hipHostMallocDefault) {
         if (n <= cap) return hipSuccess;
         if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
-        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T), flags);
         if (e == hipSuccess) cap = n;
         return e;
     }
@@ -102,6 +102,7 @@ struct LevelLaunch {
     int wgs;
     uint64_t codes;
     bool small;     // small-run kernel (runs below idx->small_run codes)
+    bool shared;    // every run of the launch covers the same codes (one run per query): sibling-major launch
     int ev = -1;    // index of the HIP event recorded before the launch (the next one follows it), -1 = not timed
 };
 
@@ -115,7 +116,6 @@ struct Slot {
     std::vector<int8_t> qtables_in;     // int8 path input copy
     uint32_t cap_q = 0;                 // candidate region entries per query
     uint32_t out_cap = 0;               // entries of the device-sorted output
-    uint32_t prefetched = 0;
 
     // one upload block per batch: [ScanItem items][StartItem starts][u32 fc_init[2 nq]][float or int8 tables]
     DevBuf<unsigned char> d_in;
@@ -128,11 +128,12 @@ struct Slot {
     DevBuf<unsigned char> d_state;
     CandHeader* d_hdr = nullptr;
     QueryState* d_qs = nullptr;
-    // one result block, fetched by ONE copy: [QueryOut[nq]][u64 entries[out_cap]]
-    DevBuf<unsigned char> d_result;
+    // one result block in pinned, device-mapped HOST memory: [QueryOut[nq]][u64 entries[out_cap]].  The ordering
+    // kernel stores into it directly; there is no result copy (see plan_and_launch)
     PinBuf<unsigned char> h_result;
-    QueryOut* d_qout = nullptr;
+    QueryOut* d_qout = nullptr;         // device-side addresses of h_qout / h_entries
     uint64_t* d_entries = nullptr;
+    const int8_t* d_qt = nullptr;       // int8 tables the scan reads (d_qtables, or the uploaded ones)
     QueryOut* h_qout = nullptr;
     uint64_t* h_entries = nullptr;
     DevBuf<float> d_ftables;            // float tables built on the device (qadc_search)
@@ -141,7 +142,6 @@ struct Slot {
     DevBuf<float> d_fc;
 
     bool full_prescan = false;          // survivor buffer overflowed: pre-scan everything unfiltered
-    PinBuf<CandHeader> h_hdr;
     PinBuf<Cand> h_cands;               // host-sort fallback only
     // device-side feeders (qadc_search): queries in, tables never leave the GPU
     bool device_tables = false;
@@ -155,6 +155,8 @@ struct Slot {
     std::vector<LevelLaunch> launches;
     uint64_t start_codes = 0;
     hipEvent_t ev_done = nullptr;
+    hipEvent_t ev_front = nullptr;      // pre-scan + quantizer finished (front stream)
+    hipEvent_t ev_up = nullptr;         // this batch's upload finished (copy stream)
     hipEvent_t ev_scanned = nullptr;    // last scan level finished (main stream)
     std::vector<hipEvent_t> prof_ev;    // pairs: [2i] before, [2i+1] after; pair 0 = pre-scan chain
     size_t prof_used = 0;
@@ -169,6 +171,7 @@ struct Slot {
 struct qadc_index {
     int M = 16, cs = 8, device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t front_stream = nullptr; // a batch's pre-scan/quantize chain, under the previous batch's streaming launches
     hipStream_t copy_stream = nullptr;  // late D2H of a finished batch must not queue behind the next batch
     hipStream_t sort_stream = nullptr;  // candidate ordering + result D2H of batch s overlap the kernels of batch s+1
     std::vector<Part> parts;
@@ -181,6 +184,9 @@ struct qadc_index {
     uint64_t level_base = 512;
     uint64_t level_growth = 4;
     int wgs_per_item = 0;  // 0 = auto
+    int share_variant = 0x41;            // streaming-kernel variant for shared launches: sibling-major, U=2, cached loads
+    uint32_t share_codes_per_wg = 1u << 20;
+    int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
     int replay_threads = 0;            // 0 = auto
     uint32_t small_vec_per_wg = 512;  // 16-byte vectors one small-run workgroup covers
@@ -339,8 +345,10 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         for (int small = 1; small >= 0; --small) {
             uint64_t maxn = 0, codes = 0;
             size_t cnt = 0;
+            bool same = true;
             for (auto& it : per_level[k]) {
                 if ((it.n < idx->small_run) != (small == 1)) continue;
+                if (cnt) same = same && it.codes == all_items[off].codes && it.n == all_items[off].n;
                 all_items[off + cnt++] = it;
                 maxn = std::max<uint64_t>(maxn, it.n);
                 codes += it.n;
@@ -351,7 +359,20 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             ll.first = off;
             ll.nitems = (int)cnt;
             ll.small = small == 1;
-            if (ll.small) {
+            ll.shared = !ll.small && same && cnt >= 2 && idx->share_variant != 0;
+            if (ll.shared) {
+                // Queries of a batch over the same codes (flat database; IVF queries probing the same cell): the
+                // sibling-major launch makes them share every tile through one XCD's L2, so the codes cross the
+                // HBM interface about once per LAUNCH, not once per query, and the launch is bound by the LDS
+                // lookup rate instead.  Workgroups per run: ~2M codes each (amortises the table build, leaves the
+                // dispatcher room to balance), a multiple of 8 so that the XCD decode applies.
+                uint64_t w = idx->wgs_per_item > 0 ? (uint64_t)idx->wgs_per_item
+                                                   : (maxn + idx->share_codes_per_wg - 1) / idx->share_codes_per_wg;
+                w = std::min<uint64_t>(std::max<uint64_t>(w, 64), 512);
+                w = std::min<uint64_t>(w, std::max<uint64_t>((nvec + 4095) / 4096, 1));
+                if (w >= 8) w &= ~7ull;
+                ll.wgs = (int)w;
+            } else if (ll.small) {
                 // enough workgroups to fill the chip, but no more: each one pays a table build + bound fetch
                 const uint64_t want = std::max<uint64_t>(1, 4096 / cnt);
                 ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + idx->small_vec_per_wg - 1) / idx->small_vec_per_wg, 1), want);
@@ -395,21 +416,35 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     const size_t state_bytes = 64 + sizeof(QueryState) * (size_t)nq;
     const size_t result_bytes = sizeof(QueryOut) * (size_t)nq + sizeof(uint64_t) * (size_t)s.out_cap;
     HIPCHECK(s.d_state.ensure(state_bytes));
-    HIPCHECK(s.d_result.ensure(result_bytes));
-    HIPCHECK(s.h_result.ensure(result_bytes));
-    HIPCHECK(s.h_hdr.ensure(1));
+    HIPCHECK(s.h_result.ensure(result_bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    unsigned char* d_result = nullptr;
+    HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_result), s.h_result.p, 0));
     s.d_hdr = reinterpret_cast<CandHeader*>(s.d_state.p);
     s.d_qs = reinterpret_cast<QueryState*>(s.d_state.p + 64);
-    s.d_qout = reinterpret_cast<QueryOut*>(s.d_result.p);
-    s.d_entries = reinterpret_cast<uint64_t*>(s.d_result.p + sizeof(QueryOut) * (size_t)nq);
+    s.d_qout = reinterpret_cast<QueryOut*>(d_result);
+    s.d_entries = reinterpret_cast<uint64_t*>(d_result + sizeof(QueryOut) * (size_t)nq);
     s.h_qout = reinterpret_cast<QueryOut*>(s.h_result.p);
     s.h_entries = reinterpret_cast<uint64_t*>(s.h_result.p + sizeof(QueryOut) * (size_t)nq);
     HIPCHECK(s.d_cands.ensure((size_t)nq * s.cap_q));
     HIPCHECK(s.d_qtables.ensure(nt));
+    // The front of the batch (state clear, table build, float pre-scan, selects, quantizer) depends on nothing the
+    // previous batch produces: it runs on its own high-priority stream, under that batch's streaming launches, and
+    // the first scan level waits for it.  Its short single-workgroup selects are pure latency; hidden this way they
+    // stop being a fixed cost per batch (which is what limits strong scaling when the per-GPU shard gets small).
+    hipStream_t main_stream = st;
+    if (idx->overlap_front) st = idx->front_stream;
     HIPCHECK(hipMemsetAsync(s.d_state.p, 0, state_bytes, st));
-    HIPCHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, st));
+    // The upload goes on the copy stream, where it depends on nothing (the slot's previous batch was collected),
+    // and the main stream waits for it.  Issued on the main stream it would sit in the DMA engine's queue until the
+    // PREVIOUS batch's kernels finish, and every other copy of the process (the caller's streams, the RCCL gather of
+    // the multi-GPU merge) would queue behind it: copies wait in engine order, not stream order.
+    HIPCHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, idx->copy_stream));
+    if (!s.ev_up) HIPCHECK(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(s.ev_up, idx->copy_stream));
+    HIPCHECK(hipStreamWaitEvent(st, s.ev_up, 0));
     s.prof_used = 0;
 
+    s.d_qt = s.d_qtables.p;
     if (s.float_path) {
         float* d_ft = s.d_ftables_in;
         if (s.device_tables) {
@@ -440,10 +475,16 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                           idx->quant_mode, st);
         if (idx->profile) HIPCHECK(prof_event(s, st));
     } else {
-        HIPCHECK(hipMemcpyAsync(s.d_qtables.p, s.d_in.p + off_tables, nt, hipMemcpyDeviceToDevice, st));
+        s.d_qt = reinterpret_cast<const int8_t*>(s.d_in.p + off_tables);     // caller's int8 tables, as uploaded
         if (idx->profile) { HIPCHECK(prof_event(s, st)); HIPCHECK(prof_event(s, st)); }
     }
 
+    if (st != main_stream) {
+        if (!s.ev_front) HIPCHECK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(s.ev_front, st));
+        st = main_stream;
+        HIPCHECK(hipStreamWaitEvent(st, s.ev_front, 0));
+    }
     // ---- scan levels ------------------------------------------------------------------------
     // a database that fits the 256 MiB Infinity Cache is re-read from it by every query: keep the default
     // cache policy there; non-temporal loads only pay for lists that stream from HBM anyway
@@ -460,15 +501,17 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         ll.ev = -1;
         if (group_start) { ll.ev = (int)s.prof_used; HIPCHECK(prof_event(s, st)); }
         if (ll.small)
-            launch_scan_i8_small(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs, s.d_hdr, s.d_cands.p,
+            launch_scan_i8_small(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p,
                                  s.cap_q, (uint32_t)s.R, st);
         else
-            launch_scan_i8(M, variant, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qtables.p, s.d_qs, s.d_hdr,
-                           s.d_cands.p, s.cap_q, (uint32_t)s.R, st);
+            launch_scan_i8(M, ll.shared ? idx->share_variant : (variant & ~64), s.d_items + ll.first, ll.nitems, ll.wgs,
+                           s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q, (uint32_t)s.R, st);
         if (group_end) HIPCHECK(prof_event(s, st));
     }
-    // the ordering pass and the result copies run on a side stream: they only occupy nq CUs, and the main
-    // stream is free to start the next batch's kernels meanwhile (it uses the other slot's buffers)
+    // the ordering pass runs on a side stream: it only occupies nq CUs, and the main stream is free to start the
+    // next batch's kernels meanwhile (it uses the other slot's buffers).  It stores [QueryOut[nq]][entries] straight
+    // into the slot's pinned host block, so no device-to-host copy waits in the DMA queue behind this batch (a
+    // queued copy with an unmet dependency stalls every later copy of the process, see the upload above).
     hipStream_t main_st = st;
     if (!s.ev_scanned) HIPCHECK(hipEventCreateWithFlags(&s.ev_scanned, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(s.ev_scanned, main_st));
@@ -477,11 +520,6 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     launch_sort_cands(s.d_qs, s.d_cands.p, s.cap_q, nq, s.d_qout, s.d_entries, s.out_cap, s.d_hdr, st);
     HIPCHECK(hipGetLastError());
 
-    // ---- results: the 16-byte header and ONE copy of [QueryOut[nq]][first entries] ----------------
-    HIPCHECK(hipMemcpyAsync(s.h_hdr.p, s.d_hdr, sizeof(CandHeader), hipMemcpyDeviceToHost, st));
-    s.prefetched = std::min<uint32_t>(s.out_cap, 1u << 16);
-    HIPCHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(QueryOut) * (size_t)nq + sizeof(uint64_t) * s.prefetched,
-                            hipMemcpyDeviceToHost, st));
     if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(s.ev_done, st));
     return QADC_OK;
@@ -593,7 +631,7 @@ int collect_common(qadc_index* idx, int slot_i) {
             max_count = std::max<uint64_t>(max_count, qs.count);
             if (qs.count <= limit) total_sorted += (uint64_t)qs.count + qs.reps;
         }
-        const bool region_overflow = s.h_hdr.p->overflow != 0;
+        const bool region_overflow = max_count > s.cap_q;     // emit_candidate counts every request
         const bool out_overflow = total_sorted > s.out_cap;
         bool prescan_overflow = false;
         for (int q = 0; q < s.nq; ++q) prescan_overflow |= (s.h_qout[q].flags & 8u) != 0;
@@ -613,12 +651,6 @@ int collect_common(qadc_index* idx, int slot_i) {
         }
     }
     s.busy = false;
-    if (total_sorted > s.prefetched) {
-        const size_t rest = (size_t)total_sorted - s.prefetched;
-        HIPCHECK(hipMemcpyAsync(s.h_entries + s.prefetched, s.d_entries + s.prefetched, rest * sizeof(uint64_t),
-                                hipMemcpyDeviceToHost, idx->copy_stream));
-        HIPCHECK(hipStreamSynchronize(idx->copy_stream));
-    }
     if (idx->profile) {
         float ms = 0;
         if (s.prof_used >= 2) {
@@ -745,9 +777,16 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     idx->M = M;
     idx->cs = M / 2;
     idx->device = device_id;
-    hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->sort_stream, hipStreamNonBlocking);
+    // The streaming launches fill every CU for milliseconds.  They go on the LOWEST-priority queue so that the
+    // short work that must overlap them is dispatched as soon as a workgroup slot frees up instead of waiting for
+    // the whole batch: the previous batch's candidate sort and result copies (own streams, highest priority) and
+    // the caller's own streams (the RCCL gather of the multi-GPU merge).
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    hipError_t e = hipStreamCreateWithPriority(&idx->stream, hipStreamNonBlocking, prio_least);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&idx->copy_stream, hipStreamNonBlocking, prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&idx->sort_stream, hipStreamNonBlocking, prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&idx->front_stream, hipStreamNonBlocking, prio_greatest);
     if (e != hipSuccess) {
         delete idx;
         return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -772,17 +811,20 @@ int qadc_index_destroy(qadc_index* idx) {
     idx->d_rotation.release();
     idx->d_coarse.release();
     for (auto& s : idx->slot) {
-        s.d_in.release(); s.h_in.release(); s.d_state.release(); s.d_result.release(); s.h_result.release();
+        s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
         s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
-        s.h_hdr.release(); s.h_cands.release();
+        s.h_cands.release();
         s.d_queries.release(); s.d_assign.release(); s.d_cdist.release(); s.h_queries.release(); s.h_assign.release();
         if (s.ev_feed) (void)hipEventDestroy(s.ev_feed);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.ev_up) (void)hipEventDestroy(s.ev_up);
+        if (s.ev_front) (void)hipEventDestroy(s.ev_front);
         if (s.ev_scanned) (void)hipEventDestroy(s.ev_scanned);
         for (auto e : s.prof_ev) (void)hipEventDestroy(e);
     }
     (void)hipStreamDestroy(idx->stream);
     if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
+    if (idx->front_stream) (void)hipStreamDestroy(idx->front_stream);
     if (idx->sort_stream) (void)hipStreamDestroy(idx->sort_stream);
     delete idx;
     return QADC_OK;
@@ -991,6 +1033,9 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "level_base") idx->level_base = (uint64_t)std::max(16.0, value);
     else if (n == "level_growth") idx->level_growth = (uint64_t)std::max(2.0, value);
     else if (n == "wgs_per_item") idx->wgs_per_item = (int)value;
+    else if (n == "overlap_front") idx->overlap_front = value != 0;
+    else if (n == "share_variant") idx->share_variant = (int)value;
+    else if (n == "share_codes_per_wg") idx->share_codes_per_wg = (uint32_t)std::max(value, 4096.0);
     else if (n == "variant") idx->variant = (int)value;
     else if (n == "prescan_sample") idx->prescan_sample = (uint32_t)std::max(256.0, value);
     else if (n == "replay_threads") idx->replay_threads = (int)value;
@@ -1027,7 +1072,7 @@ int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* v
     }
     finish_float_outputs(idx, s, status, qmin, qmax);
     if (qtables) {
-        HIPCHECK(hipMemcpyAsync(qtables, s.d_qtables.p, (size_t)s.nq * s.ma * idx->M * 16, hipMemcpyDeviceToHost,
+        HIPCHECK(hipMemcpyAsync(qtables, s.d_qt, (size_t)s.nq * s.ma * idx->M * 16, hipMemcpyDeviceToHost,
                                 idx->copy_stream));
         HIPCHECK(hipStreamSynchronize(idx->copy_stream));
     }

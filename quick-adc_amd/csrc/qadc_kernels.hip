@@ -152,9 +152,26 @@ __device__ __forceinline__ uint32_t pair_sum(const uint32_t* d, uint32_t lane_lo
 template <int M, int U, bool NT, bool CHUNK, bool PROBE, bool PF>
 __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
     const ScanItem* __restrict__ items, const int8_t* __restrict__ qtables, QueryState* __restrict__ qstates,
-    CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap, uint32_t R) {
+    CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap, uint32_t R, uint32_t sib_items) {
     using C = ScanCfg<M>;
-    const ScanItem it = items[blockIdx.y];
+    // Workgroup -> (run, position in the run).  2-D launch: blockIdx.y = run.  Sibling-major 1-D launch
+    // (sib_items = runs in the launch, all over the SAME code range, one per query): the hardware deals consecutive
+    // workgroup ids round-robin to the 8 XCDs, so ids that are equal mod 8 share an L2; the decode below puts the
+    // sib_items workgroups that read the same tiles (one per query) on one XCD, dispatched back to back: the first
+    // of them pulls a tile from HBM, the others find it in that XCD's L2.
+    uint32_t bx = blockIdx.x, by = blockIdx.y, G = gridDim.x;
+    if (sib_items) {
+        G = gridDim.x / sib_items;
+        if ((G & 7u) == 0) {
+            const uint32_t r = blockIdx.x >> 3;
+            by = r % sib_items;
+            bx = (r / sib_items) * 8u + (blockIdx.x & 7u);
+        } else {
+            by = blockIdx.x % sib_items;
+            bx = blockIdx.x / sib_items;
+        }
+    }
+    const ScanItem it = items[by];
     QueryState* qs = qstates + it.query;
     out += (uint64_t)it.query * cand_cap;                       // this query's candidate region
 
@@ -173,12 +190,11 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
     const uint32_t n = it.n;
     const uint32_t nvec = (n + C::CPL - 1) / C::CPL;            // 16-byte vectors in the run
     const uint32_t ntiles = (nvec + kWG - 1) / kWG;
-    const uint32_t G = gridDim.x;
     // tile sequence of this workgroup: first, first+step, ... < last
-    uint32_t first = blockIdx.x, last = ntiles, step = G;
+    uint32_t first = bx, last = ntiles, step = G;
     if (CHUNK) {
         const uint32_t per = (ntiles + G - 1) / G;
-        first = blockIdx.x * per;
+        first = bx * per;
         last = min(ntiles, first + per);
         step = 1;
     }
@@ -357,20 +373,24 @@ void launch_scan_i8_small(int M, const ScanItem* d_items, int nitems, int wgs_pe
 
 template <int M, int U, bool NT, bool CHUNK, bool PROBE, bool PF>
 static void launch_scan_variant(dim3 grid, hipStream_t stream, const ScanItem* d_items, const int8_t* d_qtables,
-                                QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R) {
+                                QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R,
+                                uint32_t sib_items) {
     auto k = &scan_i8_kernel<M, U, NT, CHUNK, PROBE, PF>;
     static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             ScanCfg<M>::LDS_BYTES), true);
     (void)once;
-    hipLaunchKernelGGL(k, grid, dim3(kWG), ScanCfg<M>::LDS_BYTES, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R);
+    hipLaunchKernelGGL(k, grid, dim3(kWG), ScanCfg<M>::LDS_BYTES, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, sib_items);
 }
 
-// variant bits: [1:0] U = 1,2,4 (index 0,1,2)  [2] NT  [3] CHUNK  [4] PROBE  [5] PF (software prefetch).
+// variant bits: [1:0] U = 1,2,4 (index 0,1,2)  [2] NT  [3] CHUNK  [4] PROBE  [5] PF (software prefetch)
+// [6] sibling-major 1-D launch (every run of the launch covers the same codes; see the kernel's decode).
 void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int wgs_per_item,
                     const int8_t* d_qtables, QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap,
                     uint32_t R, hipStream_t stream) {
-    const dim3 grid(wgs_per_item, nitems);
-#define QADC_ARGS grid, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R
+    const bool sib = (variant & 64) != 0;
+    const dim3 grid = sib ? dim3((unsigned)wgs_per_item * (unsigned)nitems) : dim3(wgs_per_item, nitems);
+    const uint32_t sib_items = sib ? (uint32_t)nitems : 0u;
+#define QADC_ARGS grid, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, sib_items
 #define QADC_V(MM, UU, NTT, CH, PR) \
     do { if (variant & 32) launch_scan_variant<MM, UU, NTT, CH, PR, true>(QADC_ARGS); \
          else launch_scan_variant<MM, UU, NTT, CH, PR, false>(QADC_ARGS); } while (0)

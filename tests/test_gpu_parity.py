@@ -598,3 +598,24 @@ def test_candidate_output_capacity_error(pyqadc):
     with pytest.raises(pyqadc.QadcError, match="too small"):
         idx.query_scan_candidates(np.zeros((1, 1), np.int32), float_tables(rng, 1, 1, 16), 100, capacity=4)
     idx.close()
+
+
+@pytest.mark.parametrize("M,wgs,share", [(16, 0, 0x41), (16, 12, 0x41), (16, 16, 0x49), (32, 0, 0x41), (16, 0, 0)])
+def test_shared_launch_of_a_batch_matches_oracle(pyqadc, po, M, wgs, share):
+    """The queries of a batch over the same codes run as L2-sharing siblings (1-D sibling-major launch, XCD decode
+    when the workgroups per run are a multiple of 8, plain decode otherwise): same heaps as one query at a time."""
+    rng = np.random.default_rng(70 + M + wgs)
+    n, nq, R, keep = 700001, 5, 100, 0.01
+    codes = rand_codes(rng, n, M)
+    idx = pyqadc.Index(M)
+    idx.add_partitions([codes])
+    idx.finalize(keep)
+    idx.set_option("small_run", 32768)          # streaming kernel from the 32768-code level on
+    idx.set_option("wgs_per_item", wgs)
+    idx.set_option("share_variant", share)
+    tables = float_tables(rng, nq, 1, M)
+    res = idx.query_scan(np.zeros((nq, 1), np.int32), tables.copy(), R)
+    for q in range(nq):
+        want = po.query_scan(M, [codes], None, keep, [0], tables[q].copy(), R)
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
+    idx.close()

@@ -13,7 +13,7 @@ tables = np.ascontiguousarray(((q - cb[None]) ** 2).sum(-1).reshape(NQ, 1, 256),
 assign = np.zeros((NQ, 1), np.int32)
 idx.submit(0, assign, tables.copy(), 100); idx.collect(0)
 t0 = time.perf_counter(); pend = None
-for s in range(6):
+for s in range(int(os.environ.get("STEPS", 6))):
     a = time.perf_counter(); idx.submit(s % 2, assign, tables.copy(), 100); b = time.perf_counter()
     if pend is not None:
         idx.collect(pend)

@@ -68,6 +68,7 @@ write_bytes = w["WRITE_SIZE"] * 1024
 clk = l["GRBM_GUI_ACTIVE"] / 8 / (l["_dur_ns"] * 1e-9) / 1e9
 summary = {
     "kernel": "scan_i8_kernel<%d,2>, longest launch (last bound level, %d queries)" % (cfg["M"], cfg["queries_per_step"]),
+    "codes": cfg["codes"], "M": cfg["M"], "queries_per_step": cfg["queries_per_step"],
     "codes_in_launch": codes, "algorithmic_bytes": algo,
     "FETCH_SIZE_KB": f["FETCH_SIZE"], "hbm_read_bytes(FETCH_SIZE*1024*2)": fetch_bytes,
     "WRITE_SIZE_KB": w["WRITE_SIZE"], "hbm_write_bytes": write_bytes,
@@ -79,6 +80,9 @@ summary = {
     "SQ_LDS_BANK_CONFLICT": l["SQ_LDS_BANK_CONFLICT"], "SQ_LDS_IDX_ACTIVE": l["SQ_LDS_IDX_ACTIVE"],
     "lds_conflict_fraction": l["SQ_LDS_BANK_CONFLICT"] / l["SQ_LDS_IDX_ACTIVE"],
     "effective_clock_GHz(GRBM_GUI_ACTIVE/8/duration)": clk,
+    # all LDS-array cycles of the launch over (256 CUs x launch cycles): how busy the lookup pipe was
+    "lds_busy_fraction(SQ_LDS_IDX_ACTIVE/(256*GRBM_GUI_ACTIVE/8))": l["SQ_LDS_IDX_ACTIVE"] / (256 * l["GRBM_GUI_ACTIVE"] / 8),
+    "sq_counters_longest_launch": {k: v for k, v in l.items() if not k.startswith("_")},
 }
 json.dump(summary, open(os.path.join(P, "%s_hbm_traffic.json" % tag), "w"), indent=1)
 with open(os.path.join(P, "%s_pmc_summary.md" % tag), "w") as o:
