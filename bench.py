@@ -264,7 +264,11 @@ def main():
         launches = max(prof["scan_launches"], 1)
         avg_ms = scan_ms / launches
         alg_bytes = prof["scan_codes"] * cs / launches
-        lookups = prof["scan_codes"] * (M // 2) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0   # ds_read_u8 lanes, G/s
+        mq = prof["mq_launches"] > 0
+        # LDS-array cycles the launches need (MI355X_MICROARCH.md, LDS): multi-query kernel = one ds_read_b128 (4 cycles
+        # per 64 lanes) per code nibble and pass; single-query kernel = one ds_read_u8 (2 cycles) per code byte and query
+        lds_cycles = prof["pass_codes"] * (M * 4 if mq else (M // 2) * 2) / 64.0
+        lds_frac = lds_cycles / (256 * 2.4e9 * scan_ms * 1e-3) if scan_ms > 0 else 0.0
         out = {
             "metric": "pq_codes_scanned_per_sec", "value": total_codes / elapsed, "unit": "codes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -277,8 +281,10 @@ def main():
             "recall_at_100": recall,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "scan_i8_kernel<%d,2> (sibling-major launch, %d queries share each tile)" % (M, NQ)
-                                   if NQ > 1 else "scan_i8_kernel<%d,2,nt,chunk>" % M,
+                         "kernel": ("scan_i8_mq_kernel<%d,2> (8 queries per pass, %d passes per launch as L2-sharing siblings)"
+                                    % (M, (NQ + 7) // 8)) if mq else
+                                   ("scan_i8_kernel<%d,2> (sibling-major launch, %d queries share each tile)" % (M, NQ)
+                                    if NQ > 1 else "scan_i8_kernel<%d,2,nt,chunk>" % M),
                          "launches": prof["scan_launches"], "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          # what actually crossed the HBM interface (PMC pass, profiles/): below the algorithmic
@@ -287,10 +293,11 @@ def main():
                          {"achieved": traffic / (avg_ms * 1e-3) / 1e9, "unit": "GB/s",
                           "frac": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "traffic_over_algorithmic": traffic / alg_bytes},
-                         # the limiter once the codes come from L2: one ds_read_u8 per pair of sub-quantizers,
-                         # 2 LDS cycles per wave-instruction (MI355X_MICROARCH.md, LDS) = 32 lanes/clk/CU
-                         "lds": {"achieved": lookups, "peak": 256 * 32 * 2.4, "unit": "G lookups/s",
-                                 "frac": lookups / (256 * 32 * 2.4)}},
+                         # the limiter once a pass serves several queries: LDS-array cycles the lookups need over the
+                         # LDS cycles available (256 CUs x 2.4 GHz x duration); the VALU pipe is equally loaded
+                         "lds": {"achieved": lds_cycles / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0,
+                                 "peak": 256 * 2.4, "unit": "G LDS cycles/s", "frac": lds_frac,
+                                 "code_reads_per_launch": prof["pass_codes"] / launches}},
             "phases": {"prescan_quantize_ms_per_step": prof["start_ms"] / args.steps,
                        "scan_kernel_ms_per_step": scan_ms / args.steps,
                        "host_sort_replay_ms_per_step": prof["host_replay_ms"] / args.steps,

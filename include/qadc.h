@@ -209,7 +209,7 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
  * Enabled with qadc_set_option(idx, "profile", 1).  Totals since the last reset.
  * ------------------------------------------------------------------------------------------- */
 typedef struct qadc_profile {
-    uint64_t scan_launches;   /* launches of the streaming int8 scan kernel (scan_i8_kernel) */
+    uint64_t scan_launches;   /* launches of the streaming int8 scan kernels (scan_i8_kernel, scan_i8_mq_kernel) */
     uint64_t scan_codes;      /* codes those launches scanned (algorithmic bytes = codes * M/2) */
     double scan_ms;           /* HIP-event time of those launches (one event pair per run of consecutive launches,
                                  i.e. including the ~2 us hand-over between them) */
@@ -224,6 +224,9 @@ typedef struct qadc_profile {
     double host_plan_ms;      /* host wall time planning + enqueueing batches */
     double host_heap_ms;      /* host wall time replaying streams through the heap */
     uint64_t host_sorted_queries; /* queries whose candidates the host had to sort (> 16384 candidates) */
+    uint64_t mq_launches;     /* of scan_launches: multi-query launches (scan_i8_mq_kernel, 8 queries per pass) */
+    uint64_t pass_codes;      /* codes the streaming launches READ: a run's codes once per query, or once per group
+                                 of 8 queries in a multi-query launch (LDS row reads = pass_codes * M there) */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

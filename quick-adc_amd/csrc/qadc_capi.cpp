@@ -103,6 +103,7 @@ struct LevelLaunch {
     uint64_t codes;
     bool small;     // small-run kernel (runs below idx->small_run codes)
     bool shared;    // every run of the launch covers the same codes (one run per query): sibling-major launch
+    bool mq;        // ... and groups of 8 of them share one pass (scan_i8_mq_kernel)
     int ev = -1;    // index of the HIP event recorded before the launch (the next one follows it), -1 = not timed
 };
 
@@ -186,6 +187,8 @@ struct qadc_index {
     int wgs_per_item = 0;  // 0 = auto
     int share_variant = 0x41;            // streaming-kernel variant for shared launches: sibling-major, U=2, cached loads
     uint32_t share_codes_per_wg = 1u << 20;
+    int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
+    uint32_t mq_codes_per_wg = 1u << 18;
     int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
     int replay_threads = 0;            // 0 = auto
@@ -348,7 +351,11 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             bool same = true;
             for (auto& it : per_level[k]) {
                 if ((it.n < idx->small_run) != (small == 1)) continue;
-                if (cnt) same = same && it.codes == all_items[off].codes && it.n == all_items[off].n;
+                if (cnt) {
+                    const ScanItem& f = all_items[off];
+                    same = same && it.codes == f.codes && it.n == f.n && it.pos0 == f.pos0 && it.labels == f.labels &&
+                           it.key_base == f.key_base && it.dup_pos == f.dup_pos && it.dup_reps == f.dup_reps;
+                }
                 all_items[off + cnt++] = it;
                 maxn = std::max<uint64_t>(maxn, it.n);
                 codes += it.n;
@@ -360,7 +367,19 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             ll.nitems = (int)cnt;
             ll.small = small == 1;
             ll.shared = !ll.small && same && cnt >= 2 && idx->share_variant != 0;
-            if (ll.shared) {
+            ll.mq = ll.shared && idx->mq;
+            if (ll.mq) {
+                // 8 queries per pass (scan_i8_mq_kernel): 256-thread workgroups, ~256 Ki codes each, groups of 8
+                // queries as L2-sharing siblings
+                const uint64_t tiles = std::max<uint64_t>((nvec + 255) / 256, 1);
+                uint64_t w = idx->wgs_per_item > 0 ? (uint64_t)idx->wgs_per_item
+                                                   : (maxn + idx->mq_codes_per_wg - 1) / idx->mq_codes_per_wg;
+                const uint64_t ngroups = (cnt + 7) / 8;
+                w = std::max<uint64_t>(w, (4096 + ngroups - 1) / ngroups);     // >= 2 rounds of the 2048 resident workgroups
+                w = std::min<uint64_t>(std::min<uint64_t>(w, 8192), tiles);
+                if (w >= 8) w &= ~7ull;
+                ll.wgs = (int)w;
+            } else if (ll.shared) {
                 // Queries of a batch over the same codes (flat database; IVF queries probing the same cell): the
                 // sibling-major launch makes them share every tile through one XCD's L2, so the codes cross the
                 // HBM interface about once per LAUNCH, not once per query, and the launch is bound by the LDS
@@ -503,6 +522,9 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         if (ll.small)
             launch_scan_i8_small(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p,
                                  s.cap_q, (uint32_t)s.R, st);
+        else if (ll.mq)
+            launch_scan_i8_mq(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q,
+                              (uint32_t)s.R, st);
         else
             launch_scan_i8(M, ll.shared ? idx->share_variant : (variant & ~64), s.d_items + ll.first, ll.nitems, ll.wgs,
                            s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q, (uint32_t)s.R, st);
@@ -665,6 +687,8 @@ int collect_common(qadc_index* idx, int slot_i) {
             }
             idx->prof.scan_launches++;
             idx->prof.scan_codes += ll.codes;
+            idx->prof.mq_launches += ll.mq ? 1 : 0;
+            idx->prof.pass_codes += ll.mq ? ll.codes / (uint64_t)ll.nitems * (uint64_t)((ll.nitems + 7) / 8) : ll.codes;
             if (ll.ev < 0 || (size_t)ll.ev + 1 >= s.prof_used) continue;   // not the first launch of its timed group
             HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[ll.ev], s.prof_ev[ll.ev + 1]));
             idx->prof.scan_ms += ms;
@@ -1035,6 +1059,8 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "wgs_per_item") idx->wgs_per_item = (int)value;
     else if (n == "overlap_front") idx->overlap_front = value != 0;
     else if (n == "share_variant") idx->share_variant = (int)value;
+    else if (n == "mq") idx->mq = value != 0;
+    else if (n == "mq_codes_per_wg") idx->mq_codes_per_wg = (uint32_t)std::max(value, 4096.0);
     else if (n == "share_codes_per_wg") idx->share_codes_per_wg = (uint32_t)std::max(value, 4096.0);
     else if (n == "variant") idx->variant = (int)value;
     else if (n == "prescan_sample") idx->prescan_sample = (uint32_t)std::max(256.0, value);

@@ -287,6 +287,215 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Multi-query streaming scan: ONE pass over the codes serves up to 8 queries.
+//
+// Once the queries of a batch share the codes through L2 (sibling-major launch above), scan_i8_kernel is bound
+// by the LDS lookup pipe: one ds_read_u8 per (code byte, query) = 2 LDS cycles per 64 lookups, and 3/4 of every
+// bank access is thrown away.  Here a lookup returns the entries of EIGHT queries at once:
+//
+//   LDS image: for sub-quantizer t and centroid x, row (t, x) = { T_q[t][x] as u16 : q = 0..7 } = 16 bytes at
+//              t*256 + x*16.  One ds_read_b128 per code nibble = 4 LDS cycles per 64 lanes x 8 queries,
+//              i.e. 8 LDS cycles per (64 codes, query) against 16.
+//   No replication: a 16-lane ds_read_b128 group conflicts only when two lanes want DIFFERENT rows in the same
+//   banks; the 16 rows of a table tile the 64 banks exactly once, and lanes that want the same row are one
+//   broadcast.  Conflict-free for any code data, in 4 KiB (16x4) / 8 KiB (32x4) of LDS instead of 64 / 128 KiB.
+//   Sums: the 16-bit fields never overflow (<= 32 x 127), so a row is added as TWO 64-bit integers
+//   (v_lshl_add_u64: 4 queries per instruction, half the instructions of v_pk_add_u16), no widening, no
+//   per-query loop.
+//   Test: adding (0x8000 - bound) to every field sets the field's top bit iff sum >= bound (no carry between
+//   fields: <= 4064 + 32768); the results are AND-ed over the U x CPL codes of an iteration and tested with ONE
+//   branch; the rare path emits per query exactly as scan_i8_kernel does.
+//
+// Exactness is untouched: the same integer sums, the same prefix bound per query, the same candidates.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMQ = 8;          // queries per pass
+constexpr int kMQWG = 256;      // threads per workgroup
+
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u64x2* lds_row_t;
+
+// wave-level prefix bound (no LDS, no barrier): lane l owns value bins 2l and 2l+1
+__device__ __forceinline__ uint32_t prefix_bound_wave(const QueryState* qs, int level, uint32_t R, uint32_t lane) {
+    uint32_t c0 = 0, c1 = 0;
+    for (int l = 0; l < level; ++l) {
+        const uint2 h = *reinterpret_cast<const uint2*>(&qs->hist[l * 128 + 2 * lane]);
+        c0 += h.x;
+        c1 += h.y;
+    }
+    uint32_t incl = c0 + c1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    const uint32_t excl = incl - (c0 + c1);
+    uint32_t b = 127;
+    if (excl + c0 >= R) b = 2 * lane;
+    else if (incl >= R) b = 2 * lane + 1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) b = min(b, (uint32_t)__shfl_xor(b, d, 64));
+    return min(b, 127u);
+}
+
+template <int M, int U>
+__global__ __launch_bounds__(kMQWG, 4) void scan_i8_mq_kernel(
+    const ScanItem* __restrict__ items, int nitems, const int8_t* __restrict__ qtables,
+    QueryState* __restrict__ qstates, CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap,
+    uint32_t R, uint32_t ngroups) {
+    constexpr int CS = M / 2, DW = M / 8, CPL = 16 / CS;
+    constexpr int TAB = M * 256;                 // bytes of the u16 row image; then u32 bound[8]
+    uint32_t* lbound = reinterpret_cast<uint32_t*>(smem + TAB);
+    // sibling-major decode over the query GROUPS (see scan_i8_kernel): groups that read the same tiles share an XCD
+    const uint32_t G = gridDim.x / ngroups;
+    uint32_t bx, grp;
+    if ((G & 7u) == 0) {
+        const uint32_t r = blockIdx.x >> 3;
+        grp = r % ngroups;
+        bx = (r / ngroups) * 8u + (blockIdx.x & 7u);
+    } else {
+        grp = blockIdx.x % ngroups;
+        bx = blockIdx.x / ngroups;
+    }
+    const int first_item = (int)grp * kMQ;
+    const int nq = min(kMQ, nitems - first_item);            // queries of this group (>= 1)
+    const ScanItem* __restrict__ its = items + first_item;
+    const ScanItem it = its[0];                              // codes / n / pos0 / labels / key_base / dup_*: shared
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    lds_base_is_zero();
+
+    // ---- row image: thread -> (t, x); the 8 queries' entries widened to u16; absent queries read as 0 ----
+    for (int e = tid; e < M * 16; e += kMQWG) {
+        u16x8 row;
+#pragma unroll
+        for (int j = 0; j < kMQ; ++j) {
+            uint16_t v = 0;
+            if (j < nq) v = (uint16_t)(uint8_t)qtables[(uint64_t)its[j].table * (M * 16) + e];
+            row[j] = v;
+        }
+        *reinterpret_cast<u16x8*>(smem + e * 16) = row;     // little-endian: query j = field j&3 of u64 j>>2
+    }
+    // ---- bounds: wave w computes queries w, w+4 (absent queries: 0 = nothing qualifies) ----
+    for (int j = (int)wave; j < kMQ; j += kMQWG / 64) {
+        uint32_t b = 0;
+        if (j < nq) b = prefix_bound_wave(qstates + its[j].query, its[j].order >> 16, R, lane);
+        if (lane == 0) lbound[j] = b;
+    }
+    __syncthreads();
+    uint32_t bq[kMQ];
+    uint64_t bias[2] = {0, 0};                               // (0x8000 - bound) in every 16-bit field
+#pragma unroll
+    for (int j = 0; j < kMQ; ++j) {
+        bq[j] = __builtin_amdgcn_readfirstlane(lbound[j]);
+        bias[j >> 2] |= (uint64_t)(0x8000u - bq[j]) << (16 * (j & 3));
+    }
+    constexpr uint64_t kTop = 0x8000800080008000ull;
+
+    typedef const __attribute__((address_space(1))) u32x4_t* gvec_t;
+    const gvec_t src = (gvec_t)(uintptr_t)it.codes;
+    const uint32_t n = it.n;
+    const uint32_t nvec = (n + CPL - 1) / CPL;
+    const uint32_t ntiles = (nvec + kMQWG - 1) / kMQWG;
+
+    // sums of the 8 queries for one code (DW dwords at d)
+    auto code_sums = [&](const uint32_t* d) -> u64x2 {
+        u64x2 a = {0, 0};
+#pragma unroll
+        for (int w = 0; w < DW; ++w) {
+            // every nibble pre-shifted to bits [4,8) of its byte: byte k of hi4 / lo4 is the row offset x*16
+            const uint32_t hi4 = d[w] & 0xf0f0f0f0u, lo4 = (d[w] << 4) & 0xf0f0f0f0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // code byte b = 4w + k: sub-quantizer 2b takes the low nibble, 2b+1 the high one
+                const int t0 = 2 * (4 * w + k);
+                const uint32_t xl = __builtin_amdgcn_ubfe(lo4, 8 * k, 8), xh = __builtin_amdgcn_ubfe(hi4, 8 * k, 8);
+                a += *reinterpret_cast<lds_row_t>(static_cast<uintptr_t>(xl + t0 * 256));
+                a += *reinterpret_cast<lds_row_t>(static_cast<uintptr_t>(xh + (t0 + 1) * 256));
+            }
+        }
+        return a;
+    };
+
+    auto run = [&](uint32_t t0, auto full) {
+        u32x4_t v[U];
+        uint32_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t t = t0 + u * G;
+            e[u] = t * kMQWG + tid;
+            if (decltype(full)::value) {
+                v[u] = src[e[u]];
+            } else {
+                v[u] = u32x4_t{0, 0, 0, 0};
+                if (t < ntiles && e[u] < nvec) v[u] = src[e[u]];
+                else e[u] = 0xffffffffu;
+            }
+        }
+        u64x2 sums[U * CPL];
+        uint64_t all0 = kTop, all1 = kTop;                       // stays kTop while no field is below its bound
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const u64x2 a = code_sums(d + c * DW);
+                sums[u * CPL + c] = a;
+                uint64_t t0 = a.x + bias[0], t1 = a.y + bias[1];     // field top bit: sum >= bound
+                if (!decltype(full)::value) {
+                    const bool live = e[u] != 0xffffffffu && e[u] * CPL + c < n;
+                    if (!live) { t0 = kTop; t1 = kTop; }
+                }
+                all0 &= t0;
+                all1 &= t1;
+            }
+        }
+        if (__builtin_expect(((all0 & all1) & kTop) != kTop, 0)) {   // rare
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    if (!decltype(full)::value && !(e[u] != 0xffffffffu && e[u] * CPL + c < n)) continue;
+#pragma unroll
+                    for (int j = 0; j < kMQ; ++j) {
+                        const uint32_t sj = (uint32_t)(sums[u * CPL + c][j >> 2] >> (16 * (j & 3))) & 0xffffu;
+                        if (sj < bq[j]) {
+                            const ScanItem* ij = its + j;
+                            emit_candidate(qstates + ij->query, hdr, out + (uint64_t)ij->query * cand_cap, cand_cap,
+                                           it.labels, it.key_base, ij->order, it.dup_pos, it.dup_reps,
+                                           it.pos0 + e[u] * CPL + c, sj);
+                        }
+                    }
+                }
+        }
+    };
+    using full_t = std::integral_constant<bool, true>;
+    using part_t = std::integral_constant<bool, false>;
+    const uint32_t tiles_full = (n / CPL) / kMQWG;           // tiles whose every lane holds CPL complete codes
+    uint32_t t0 = bx;
+    for (; t0 + (U - 1) * G < tiles_full; t0 += G * U) run(t0, full_t());
+    for (; t0 < ntiles; t0 += G * U) run(t0, part_t());
+}
+
+template <int M>
+static void launch_scan_mq_m(const ScanItem* d_items, int nitems, int wgs_per_group, const int8_t* d_qtables,
+                             QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R,
+                             hipStream_t stream) {
+    const uint32_t ngroups = (uint32_t)(nitems + kMQ - 1) / kMQ;
+    hipLaunchKernelGGL((scan_i8_mq_kernel<M, 2>), dim3(ngroups * (uint32_t)wgs_per_group), dim3(kMQWG), M * 256 + 64,
+                       stream, d_items, nitems, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, ngroups);
+}
+
+// Runs of the launch must all cover the same codes (same codes / n / pos0 / labels / key_base / dup_*): the
+// planner guarantees it.  Groups of up to 8 consecutive runs share one pass.
+void launch_scan_i8_mq(int M, const ScanItem* d_items, int nitems, int wgs_per_group, const int8_t* d_qtables,
+                       QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R,
+                       hipStream_t stream) {
+    if (M == 16) launch_scan_mq_m<16>(d_items, nitems, wgs_per_group, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, stream);
+    else         launch_scan_mq_m<32>(d_items, nitems, wgs_per_group, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Small-run variant (IVF partitions, early bound levels): same pair-fused lookup, but the byte tables
 // are NOT bank-replicated — 2 KiB (16x4) / 4 KiB (32x4) of LDS and a trivial build, 256-thread
 // workgroups, so many workgroups per CU overlap their item/table/histogram fetch latencies.  A table

@@ -38,7 +38,8 @@ class Profile(C.Structure):
                 ("small_launches", C.c_uint64), ("small_codes", C.c_uint64), ("small_ms", C.c_double),
                 ("start_codes", C.c_uint64), ("start_ms", C.c_double), ("candidates", C.c_uint64),
                 ("regrows", C.c_uint64), ("host_replay_ms", C.c_double), ("host_plan_ms", C.c_double),
-                ("host_heap_ms", C.c_double), ("host_sorted_queries", C.c_uint64)]
+                ("host_heap_ms", C.c_double), ("host_sorted_queries", C.c_uint64), ("mq_launches", C.c_uint64),
+                ("pass_codes", C.c_uint64)]
 
 
 class QadcError(RuntimeError):

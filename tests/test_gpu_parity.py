@@ -600,8 +600,9 @@ def test_candidate_output_capacity_error(pyqadc):
     idx.close()
 
 
-@pytest.mark.parametrize("M,wgs,share", [(16, 0, 0x41), (16, 12, 0x41), (16, 16, 0x49), (32, 0, 0x41), (16, 0, 0)])
-def test_shared_launch_of_a_batch_matches_oracle(pyqadc, po, M, wgs, share):
+@pytest.mark.parametrize("M,wgs,share,mq", [(16, 0, 0x41, 0), (16, 12, 0x41, 0), (16, 16, 0x49, 0), (32, 0, 0x41, 0),
+                                            (16, 0, 0, 0), (16, 0, 0x41, 1), (32, 0, 0x41, 1), (16, 12, 0x41, 1)])
+def test_shared_launch_of_a_batch_matches_oracle(pyqadc, po, M, wgs, share, mq):
     """The queries of a batch over the same codes run as L2-sharing siblings (1-D sibling-major launch, XCD decode
     when the workgroups per run are a multiple of 8, plain decode otherwise): same heaps as one query at a time."""
     rng = np.random.default_rng(70 + M + wgs)
@@ -613,9 +614,38 @@ def test_shared_launch_of_a_batch_matches_oracle(pyqadc, po, M, wgs, share):
     idx.set_option("small_run", 32768)          # streaming kernel from the 32768-code level on
     idx.set_option("wgs_per_item", wgs)
     idx.set_option("share_variant", share)
+    idx.set_option("mq", mq)
     tables = float_tables(rng, nq, 1, M)
     res = idx.query_scan(np.zeros((nq, 1), np.int32), tables.copy(), R)
     for q in range(nq):
         want = po.query_scan(M, [codes], None, keep, [0], tables[q].copy(), R)
         assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
+    idx.close()
+
+
+@pytest.mark.parametrize("M", [16, 32])
+def test_multi_query_pass_groups_labels_and_padding_replays(pyqadc, po, M):
+    """19 queries = groups of 8, 8 and 3 sharing one pass each; labelled ragged partition (padding-lane replays of the
+    last code), tie-heavy tables, tiny candidate regions (regrow path) — heaps equal the one-query-at-a-time oracle."""
+    rng = np.random.default_rng(80 + M)
+    n, nq, R, keep = 300003, 19, 37, 0.02
+    codes = rand_codes(rng, n, M)
+    labels = (rng.permutation(n).astype(np.uint32) * 7 + 3).astype(np.uint32)
+    idx = pyqadc.Index(M)
+    idx.add_partitions([codes], labels=[labels])
+    idx.finalize(keep)
+    idx.set_option("small_run", 8192)
+    idx.set_option("cand_capacity", 256)
+    tables = float_tables(rng, nq, 1, M, scale=0.2)
+    tables = np.round(tables * 3) / 3                          # few distinct values: massive ties
+    res = idx.query_scan(np.zeros((nq, 1), np.int32), tables.copy(), R)
+    for q in range(nq):
+        want = po.query_scan(M, [codes], [labels], keep, [0], tables[q].copy(), R)
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
+    # same through the direct int8 entry point, one query per table, R > candidates of the early levels
+    qt = rng.integers(0, 9, (nq, 1, M, 16)).astype(np.int8)
+    heaps = idx.scan_i8(np.zeros((nq, 1), np.int32), qt, R)
+    for q in range(nq):
+        want = po.scan_i8(M, [codes], [labels], qt[q, 0], R)
+        assert heaps_equal(heaps[q], want), q
     idx.close()

@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "quick-adc_amd"))
 import pyqadc
-N = int(float(os.environ.get("N", 1e9))); NQ = 8; M = 16
+N = int(float(os.environ.get("N", 1e9))); NQ = int(os.environ.get("NQ", 8)); M = 16
 idx = pyqadc.Index(M); idx.add_partition_synthetic(N, 1); idx.finalize(0.01)
 rng = np.random.default_rng(0)
 cb = rng.normal(size=(M, 16, 8)).astype(np.float32)

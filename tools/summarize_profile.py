@@ -35,7 +35,8 @@ def counters(sub):
     rows = list(csv.DictReader(open(one("prof_%s_%s/*/*_counter_collection.csv" % (tag, sub)))))
     per = collections.defaultdict(dict)
     for r in rows:
-        if "scan_i8_kernel" in r["Kernel_Name"]:
+        if "scan_i8_kernel" in r["Kernel_Name"] or "scan_i8_mq_kernel" in r["Kernel_Name"]:
+            per[int(r["Dispatch_Id"])]["_name"] = r["Kernel_Name"].split("(")[0]
             per[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
             per[int(r["Dispatch_Id"])]["_dur_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return per
@@ -66,8 +67,12 @@ algo = codes * cs
 fetch_bytes = f["FETCH_SIZE"] * 1024 * 2
 write_bytes = w["WRITE_SIZE"] * 1024
 clk = l["GRBM_GUI_ACTIVE"] / 8 / (l["_dur_ns"] * 1e-9) / 1e9
+mq = "mq" in l["_name"]
+groups = (cfg["queries_per_step"] + 7) // 8
+# LDS-array cycles the lookups of the launch need (MI355X_MICROARCH.md, LDS table)
+lds_model = codes / cfg["queries_per_step"] * groups * cfg["M"] * 4 / 64 if mq else codes * cs * 2 / 64
 summary = {
-    "kernel": "scan_i8_kernel<%d,2>, longest launch (last bound level, %d queries)" % (cfg["M"], cfg["queries_per_step"]),
+    "kernel": "%s, longest launch (last bound level, %d queries)" % (l["_name"], cfg["queries_per_step"]),
     "codes": cfg["codes"], "M": cfg["M"], "queries_per_step": cfg["queries_per_step"],
     "codes_in_launch": codes, "algorithmic_bytes": algo,
     "FETCH_SIZE_KB": f["FETCH_SIZE"], "hbm_read_bytes(FETCH_SIZE*1024*2)": fetch_bytes,
@@ -79,9 +84,12 @@ summary = {
     "duration_ms_under_pmc": f["_dur_ns"] / 1e6,
     "SQ_LDS_BANK_CONFLICT": l["SQ_LDS_BANK_CONFLICT"], "SQ_LDS_IDX_ACTIVE": l["SQ_LDS_IDX_ACTIVE"],
     "lds_conflict_fraction": l["SQ_LDS_BANK_CONFLICT"] / l["SQ_LDS_IDX_ACTIVE"],
+    "lds_cycles_model(code reads x lookups x cycles / 64 lanes)": lds_model,
     "effective_clock_GHz(GRBM_GUI_ACTIVE/8/duration)": clk,
     # all LDS-array cycles of the launch over (256 CUs x launch cycles): how busy the lookup pipe was
     "lds_busy_fraction(SQ_LDS_IDX_ACTIVE/(256*GRBM_GUI_ACTIVE/8))": l["SQ_LDS_IDX_ACTIVE"] / (256 * l["GRBM_GUI_ACTIVE"] / 8),
+    "valu_issue_fraction(SQ_INSTS_VALU/(256*GRBM_GUI_ACTIVE/8), 1 wave-instruction per CU clock = 1.0)":
+        (l["SQ_INSTS_VALU"] / (256 * l["GRBM_GUI_ACTIVE"] / 8)) if "SQ_INSTS_VALU" in l else None,
     "sq_counters_longest_launch": {k: v for k, v in l.items() if not k.startswith("_")},
 }
 json.dump(summary, open(os.path.join(P, "%s_hbm_traffic.json" % tag), "w"), indent=1)
