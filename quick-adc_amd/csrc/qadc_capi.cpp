@@ -188,7 +188,7 @@ struct qadc_index {
     int share_variant = 0x41;            // streaming-kernel variant for shared launches: sibling-major, U=2, cached loads
     uint32_t share_codes_per_wg = 1u << 20;
     int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
-    uint32_t mq_codes_per_wg = 1u << 18;
+    uint32_t mq_codes_per_wg = 1u << 16;
     int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
     int replay_threads = 0;            // 0 = auto
@@ -369,14 +369,14 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             ll.shared = !ll.small && same && cnt >= 2 && idx->share_variant != 0;
             ll.mq = ll.shared && idx->mq;
             if (ll.mq) {
-                // 8 queries per pass (scan_i8_mq_kernel): 256-thread workgroups, ~256 Ki codes each, groups of 8
+                // 8 queries per pass (scan_i8_mq_kernel): 256-thread workgroups, ~64 Ki codes each, groups of 8
                 // queries as L2-sharing siblings
                 const uint64_t tiles = std::max<uint64_t>((nvec + 255) / 256, 1);
                 uint64_t w = idx->wgs_per_item > 0 ? (uint64_t)idx->wgs_per_item
                                                    : (maxn + idx->mq_codes_per_wg - 1) / idx->mq_codes_per_wg;
                 const uint64_t ngroups = (cnt + 7) / 8;
                 w = std::max<uint64_t>(w, (4096 + ngroups - 1) / ngroups);     // >= 2 rounds of the 2048 resident workgroups
-                w = std::min<uint64_t>(std::min<uint64_t>(w, 8192), tiles);
+                w = std::min<uint64_t>(std::min<uint64_t>(w, 65536), tiles);
                 if (w >= 8) w &= ~7ull;
                 ll.wgs = (int)w;
             } else if (ll.shared) {

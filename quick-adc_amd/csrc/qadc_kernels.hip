@@ -339,6 +339,18 @@ __device__ __forceinline__ uint32_t prefix_bound_wave(const QueryState* qs, int 
     return min(b, 127u);
 }
 
+// (byte K of d) & mask in ONE VALU instruction (sub-dword operand select); the compiler finds this form for only a
+// quarter of the lookups by itself and spends a shift + and on the others
+template <int K>
+__device__ __forceinline__ uint32_t byte_and(uint32_t d, uint32_t mask) {
+    uint32_t r;
+    if (K == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(mask), "v"(d));
+    if (K == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(mask), "v"(d));
+    if (K == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(mask), "v"(d));
+    if (K == 3) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(mask), "v"(d));
+    return r;
+}
+
 template <int M, int U>
 __global__ __launch_bounds__(kMQWG, 4) void scan_i8_mq_kernel(
     const ScanItem* __restrict__ items, int nitems, const int8_t* __restrict__ qtables,
@@ -398,21 +410,24 @@ __global__ __launch_bounds__(kMQWG, 4) void scan_i8_mq_kernel(
     const uint32_t nvec = (n + CPL - 1) / CPL;
     const uint32_t ntiles = (nvec + kMQWG - 1) / kMQWG;
 
+    const uint32_t nib_mask = 0xf0u;
     // sums of the 8 queries for one code (DW dwords at d)
     auto code_sums = [&](const uint32_t* d) -> u64x2 {
         u64x2 a = {0, 0};
 #pragma unroll
         for (int w = 0; w < DW; ++w) {
-            // every nibble pre-shifted to bits [4,8) of its byte: byte k of hi4 / lo4 is the row offset x*16
-            const uint32_t hi4 = d[w] & 0xf0f0f0f0u, lo4 = (d[w] << 4) & 0xf0f0f0f0u;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // code byte b = 4w + k: sub-quantizer 2b takes the low nibble, 2b+1 the high one
-                const int t0 = 2 * (4 * w + k);
-                const uint32_t xl = __builtin_amdgcn_ubfe(lo4, 8 * k, 8), xh = __builtin_amdgcn_ubfe(hi4, 8 * k, 8);
-                a += *reinterpret_cast<lds_row_t>(static_cast<uintptr_t>(xl + t0 * 256));
-                a += *reinterpret_cast<lds_row_t>(static_cast<uintptr_t>(xh + (t0 + 1) * 256));
+            // row offset = x*16: the high nibble of byte k is (byte k) & 0xf0, the low one the same of d << 4
+            const uint32_t dl = d[w] << 4;
+#define QADC_MQ_BYTE(k)                                                                                        \
+            {                                                                                                  \
+                /* code byte b = 4w + k: sub-quantizer 2b takes the low nibble, 2b+1 the high one */           \
+                const int t0 = 2 * (4 * w + (k));                                                              \
+                const uint32_t xl = byte_and<(k)>(dl, nib_mask), xh = byte_and<(k)>(d[w], nib_mask);           \
+                a += *reinterpret_cast<lds_row_t>(static_cast<uintptr_t>(xl + t0 * 256));                      \
+                a += *reinterpret_cast<lds_row_t>(static_cast<uintptr_t>(xh + (t0 + 1) * 256));                \
             }
+            QADC_MQ_BYTE(0) QADC_MQ_BYTE(1) QADC_MQ_BYTE(2) QADC_MQ_BYTE(3)
+#undef QADC_MQ_BYTE
         }
         return a;
     };
