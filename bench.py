@@ -199,24 +199,48 @@ def main():
     pool = [make_tables(rng, codebooks, NQ) for _ in range(4)]   # 4 distinct query batches, reused cyclically
     assign = np.zeros((NQ, 1), np.int32)
 
-    def finish(step_res):
-        if not use_dist:
-            return step_res
-        return sharded.merge_batch(step_res, NQ, R, step_res["status"], cdev)
-
     def run_steps(k):
         """k pipelined steps: batch s+1 is enqueued before batch s is collected and replayed."""
+        if use_dist:
+            return run_steps_dist(k)
         last = None
         pending = None
         for s in range(k):
             tb = pool[s % len(pool)].copy()
             idx.submit(s % 2, assign, tb, R)
             if pending is not None:
-                last = finish(idx.collect_candidates(pending) if use_dist else idx.collect(pending))
+                last = idx.collect(pending)
             pending = s % 2
         if pending is not None:
-            last = finish(idx.collect_candidates(pending) if use_dist else idx.collect(pending))
+            last = idx.collect(pending)
         return last
+
+    def run_steps_dist(k):
+        """Multi-rank steps.  Every rank pre-scans 1/world of the starts (the rest of the path is sharded by codes, the
+        pre-scan by starts); ONE all-gather per step carries the finished batch's candidate streams and the next
+        batch's pre-scan values; batch s runs on the GPU while batch s-1 is merged and batch s+1 is pre-scanned."""
+        last = None
+        if k <= 0:
+            return last
+        tbs = {0: pool[0].copy()}
+        idx.prescan_submit(0, assign, tbs[0], R, rank, world)
+        idx.submit(0, assign, tbs[0], R, prescan=sharded.gather_prescan(idx.prescan_collect(0), cdev))
+        for s in range(k):                                     # batch s is in flight in slot s % 2
+            nxt = s + 1 < k
+            if nxt:
+                tbs[(s + 1) % 2] = pool[(s + 1) % len(pool)].copy()
+                idx.prescan_submit((s + 1) % 2, assign, tbs[(s + 1) % 2], R, rank, world)
+            if s > 0:
+                res = idx.collect_candidates((s - 1) % 2)
+                pv = idx.prescan_collect((s + 1) % 2) if nxt else None
+                out = sharded.merge_batch(res, NQ, R, res["status"], cdev, extra=pv)
+                last, gathered = (out[:3], out[3]) if nxt else (out, None)
+            elif nxt:
+                gathered = sharded.gather_prescan(idx.prescan_collect((s + 1) % 2), cdev)
+            if nxt:
+                idx.submit((s + 1) % 2, assign, tbs[(s + 1) % 2], R, prescan=gathered)
+        res = idx.collect_candidates((k - 1) % 2)
+        return sharded.merge_batch(res, NQ, R, res["status"], cdev)
 
     def sync():
         if use_dist:

@@ -147,6 +147,21 @@ int qadc_query_scan_submit(qadc_index* idx, int slot, int nq, int ma, const int3
 int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes,
                             int32_t* status, float* qmin, float* qmax, int8_t* qtables);
 
+/* Sharded pre-scan for multi-GPU (no counterpart in the reference, whose scan is one process).  With every rank
+ * holding a replica of the starts, the float pre-scan (query_scan_start, db_query_4.cpp:230-242) would be repeated
+ * on every rank; instead rank r of w pre-scans slice r of w of every probed partition's starts:
+ *   qadc_prescan_submit   enqueues that pass (own buffers and stream: it may overlap an uncollected batch);
+ *   qadc_prescan_collect  returns vals[nq][R] = the R smallest distances of the slice per query, FLT_MAX-padded;
+ *   the caller gathers vals over the ranks (one small all-gather) into gathered[nq][w*R] and submits the batch with
+ *   qadc_query_scan_submit_prescanned, which selects qmax from the gathered values instead of pre-scanning.
+ * The R-th smallest of the union of the slices' R smallest values is the R-th smallest of all starts, so qmax, the
+ * int8 tables and the heaps are bit-identical to qadc_query_scan_submit.  Collect with the usual collect calls. */
+int qadc_prescan_submit(qadc_index* idx, int slot, int nq, int ma, const int32_t* assign, float* tables, int R,
+                        int slice, int nslices);
+int qadc_prescan_collect(qadc_index* idx, int slot, float* vals);
+int qadc_query_scan_submit_prescanned(qadc_index* idx, int slot, int nq, int ma, const int32_t* assign, float* tables,
+                                      int R, const float* prescan_vals, int nvals);
+
 /* collect variant returning the ordered candidate stream (see qadc_query_scan_candidates): what a
  * rank hands to the cross-GPU gather.  cand_slots[i] (nullable) = position in assign[] of the probed
  * partition entry i comes from: with every partition range-sharded over the ranks, the global scan order is
@@ -195,6 +210,14 @@ int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vec
  * replay the other entry points apply to the device's candidate stream. */
 int qadc_replay_i8(uint64_t n, const uint32_t* keys, const int8_t* vals, int R, int push_sentinel,
                    uint32_t* out_keys, int8_t* out_vals, int32_t* out_size);
+
+/* Host half of the multi-GPU merge: `gathered` = the world int32 buffers of buflen words each that the ranks
+ * contributed to ONE all-gather, each laid out as [nq counts][cap keys][ceil(cap/4) words of int8 values]
+ * [only when ma > 1: ceil(cap/2) words of u16 assign slots][anything else].  Replays queries q_first, q_first + q_step, ... in
+ * global scan order (assign slot, rank, position) after the (0,127) sentinel; keys/vals are [nq][R], rows of other
+ * queries are left untouched.  No GPU needed. */
+int qadc_merge_streams_i8(int world, int nq, int R, uint64_t cap, int ma, const int32_t* gathered, uint64_t buflen,
+                          int q_first, int q_step, const int32_t* status, uint32_t* keys, int8_t* vals, int32_t* sizes);
 
 /* Diagnostic: all candidate values min(127, sum) of one partition for one int8 table [M][16]. */
 int qadc_candidates_i8(qadc_index* idx, int part, const int8_t* qtable, int8_t* out);

@@ -143,6 +143,15 @@ struct Slot {
     DevBuf<float> d_fc;
 
     bool full_prescan = false;          // survivor buffer overflowed: pre-scan everything unfiltered
+    // sharded pre-scan (multi-GPU): mode 1 = pre-scan ONLY, of slice pre_slice of pre_nslices of every probed
+    // partition's starts, exporting the R smallest values per query; mode 2 = a full batch whose pre-scan is
+    // replaced by the gathered values inj_vals[nq][inj_n] of all ranks
+    int mode = 0;
+    int pre_slice = 0, pre_nslices = 1;
+    std::vector<float> inj_vals;
+    uint32_t inj_n = 0;
+    float* h_export = nullptr;          // mode 1 results in the pinned result block: [nq][R] floats, then [nq] flags
+    uint32_t* h_export_flags = nullptr;
     PinBuf<Cand> h_cands;               // host-sort fallback only
     // device-side feeders (qadc_search): queries in, tables never leave the GPU
     bool device_tables = false;
@@ -204,6 +213,8 @@ struct qadc_index {
     int K = 0;                   // coarse centroids (0 = flat)
     DevBuf<float> d_coarse;      // [K][dim]
     Slot slot[2];
+    Slot pre_slot[2];                   // sharded pre-scan passes (mode 1): own buffers, so that one can run
+                                        // while slot[i] still holds an uncollected batch
     qadc_profile prof{};
 };
 
@@ -260,13 +271,29 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     for (int q = 0; q < nq; ++q) {
         uint64_t c = 0;
         uint64_t stotal = 0;
+        // the starts of a partition this call pre-scans: all of them, or (mode 1) this rank's slice, cut at
+        // multiples of 16 codes so that every slice starts on a 16-byte boundary; (mode 2) none
+        auto starts_range = [&](const Part& pt, uint64_t& lo, uint64_t& len) {
+            lo = 0;
+            len = s.mode == 2 ? 0 : pt.start_n;
+            if (s.mode == 1 && s.pre_nslices > 1) {
+                lo = ((uint64_t)pt.start_n * s.pre_slice / s.pre_nslices) & ~15ull;
+                const uint64_t hi = s.pre_slice + 1 == s.pre_nslices
+                                        ? pt.start_n : (((uint64_t)pt.start_n * (s.pre_slice + 1) / s.pre_nslices) & ~15ull);
+                len = hi > lo ? hi - lo : 0;
+            }
+        };
         if (s.float_path)
             for (int a = 0; a < ma; ++a) {
                 const int p = s.assign[(size_t)q * ma + a];
-                if (p >= 0 && p < (int)idx->parts.size()) stotal += idx->parts[p].start_n;
+                if (p >= 0 && p < (int)idx->parts.size()) {
+                    uint64_t lo, len;
+                    starts_range(idx->parts[p], lo, len);
+                    stotal += len;
+                }
             }
         // two-phase pre-scan only pays (and is only needed) when the starts are many
-        const uint64_t sample = (s.full_prescan || stotal <= 2ull * idx->prescan_sample) ? stotal : idx->prescan_sample;
+        uint64_t sample = (s.full_prescan || stotal <= 2ull * idx->prescan_sample) ? stotal : idx->prescan_sample;
         uint64_t soff = 0;
         for (int a = 0; a < ma; ++a) {
             const int p = s.assign[(size_t)q * ma + a];
@@ -274,9 +301,11 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                 return fail(QADC_E_ARG, "assign[] names a partition that does not exist");
             const Part& pt = idx->parts[p];
             if (pt.global_n == 0) continue;  // empty partition: db_query_4.cpp:291-293
-            if (s.float_path && pt.start_n) {
-                const uint8_t* sc = pt.d_starts ? pt.d_starts : pt.d_codes;
-                const uint64_t in_a = soff < sample ? std::min<uint64_t>(pt.start_n, sample - soff) : 0;
+            uint64_t slo = 0, slen = 0;
+            if (s.float_path) starts_range(pt, slo, slen);
+            if (slen) {
+                const uint8_t* sc = (pt.d_starts ? pt.d_starts : pt.d_codes) + slo * cs;
+                const uint64_t in_a = soff < sample ? std::min<uint64_t>(slen, sample - soff) : 0;
                 StartItem si;
                 si.table = (uint32_t)((size_t)q * ma + a);
                 si.query = (uint32_t)q;
@@ -287,17 +316,17 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                     si.filter = 0;
                     sitems_a.push_back(si);
                 }
-                if (in_a < pt.start_n) {
+                if (in_a < slen) {
                     si.codes = sc + in_a * cs;
-                    si.n = (uint32_t)(pt.start_n - in_a);
+                    si.n = (uint32_t)(slen - in_a);
                     si.out_off = 0;
                     si.filter = 1;
                     sitems_b.push_back(si);
                 }
-                soff += pt.start_n;
-                s.start_codes += pt.start_n;
+                soff += slen;
+                s.start_codes += slen;
             }
-            if (pt.n == 0) continue;         // this rank holds no codes of the partition (only its starts replica)
+            if (pt.n == 0 || s.mode == 1) continue;   // no codes of the partition here (only its starts replica) / pre-scan only
             uint64_t prev = 0;
             for (int k = 0; k < kMaxLevels && prev < pt.n; ++k) {
                 uint64_t cut = pt.n;
@@ -332,6 +361,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         uint64_t cap = sample;
         if (sample < stotal)
             cap += std::min<uint64_t>(stotal - sample, std::max<uint64_t>(16ull * s.R * ((stotal + sample - 1) / sample), 4096));
+        if (s.mode == 2) sample = cap = s.inj_n;              // the gathered values are the whole "pre-scan output"
         fc_init[2 * q] = (uint32_t)sample;
         fc_init[2 * q + 1] = (uint32_t)cap;
         fc_stride = std::max<uint64_t>(fc_stride, cap);
@@ -417,7 +447,9 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     const size_t off_init = align16(off_sitems + (na + nb) * sizeof(StartItem));
     const size_t off_tables = align16(off_init + fc_init.size() * sizeof(uint32_t));
     const size_t tables_bytes = s.float_path ? (s.device_tables ? 0 : nt * sizeof(float)) : nt;
-    const size_t in_bytes = align16(off_tables + tables_bytes);
+    const size_t off_inj = align16(off_tables + tables_bytes);
+    const size_t inj_bytes = s.mode == 2 ? sizeof(float) * (size_t)nq * s.inj_n : 0;
+    const size_t in_bytes = align16(off_inj + inj_bytes);
     HIPCHECK(s.h_in.ensure(in_bytes));
     HIPCHECK(s.d_in.ensure(in_bytes));
     if (nitems) std::memcpy(s.h_in.p + off_items, all_items.data(), nitems * sizeof(ScanItem));
@@ -426,6 +458,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     std::memcpy(s.h_in.p + off_init, fc_init.data(), fc_init.size() * sizeof(uint32_t));
     if (s.float_path && !s.device_tables) std::memcpy(s.h_in.p + off_tables, s.tables, nt * sizeof(float));
     if (!s.float_path) std::memcpy(s.h_in.p + off_tables, s.qtables_in.data(), nt);
+    if (inj_bytes) std::memcpy(s.h_in.p + off_inj, s.inj_vals.data(), inj_bytes);
     s.d_items = reinterpret_cast<ScanItem*>(s.d_in.p + off_items);
     s.d_sitems = reinterpret_cast<StartItem*>(s.d_in.p + off_sitems);
     s.d_fc_init = reinterpret_cast<uint32_t*>(s.d_in.p + off_init);
@@ -433,7 +466,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
 
     // state block: [CandHeader, 64 B][QueryState[nq]]; result block: [QueryOut[nq]][u64 entries[out_cap]]
     const size_t state_bytes = 64 + sizeof(QueryState) * (size_t)nq;
-    const size_t result_bytes = sizeof(QueryOut) * (size_t)nq + sizeof(uint64_t) * (size_t)s.out_cap;
+    const size_t result_bytes = std::max(sizeof(QueryOut) * (size_t)nq + sizeof(uint64_t) * (size_t)s.out_cap,
+                                         (sizeof(float) * (size_t)s.R + sizeof(uint32_t)) * (size_t)nq);
     HIPCHECK(s.d_state.ensure(state_bytes));
     HIPCHECK(s.h_result.ensure(result_bytes, hipHostMallocMapped | hipHostMallocCoherent));
     unsigned char* d_result = nullptr;
@@ -444,6 +478,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     s.d_entries = reinterpret_cast<uint64_t*>(d_result + sizeof(QueryOut) * (size_t)nq);
     s.h_qout = reinterpret_cast<QueryOut*>(s.h_result.p);
     s.h_entries = reinterpret_cast<uint64_t*>(s.h_result.p + sizeof(QueryOut) * (size_t)nq);
+    s.h_export = reinterpret_cast<float*>(s.h_result.p);
+    s.h_export_flags = reinterpret_cast<uint32_t*>(s.h_result.p + sizeof(float) * (size_t)s.R * nq);
     HIPCHECK(s.d_cands.ensure((size_t)nq * s.cap_q));
     HIPCHECK(s.d_qtables.ensure(nt));
     // The front of the batch (state clear, table build, float pre-scan, selects, quantizer) depends on nothing the
@@ -451,7 +487,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     // the first scan level waits for it.  Its short single-workgroup selects are pure latency; hidden this way they
     // stop being a fixed cost per batch (which is what limits strong scaling when the per-GPU shard gets small).
     hipStream_t main_stream = st;
-    if (idx->overlap_front) st = idx->front_stream;
+    if (idx->overlap_front || s.mode == 1) st = idx->front_stream;
     HIPCHECK(hipMemsetAsync(s.d_state.p, 0, state_bytes, st));
     // The upload goes on the copy stream, where it depends on nothing (the slot's previous batch was collected),
     // and the main stream waits for it.  Issued on the main stream it would sit in the DMA engine's queue until the
@@ -490,7 +526,27 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             launch_select_kth(s.d_fc.p, fc_stride, s.d_fc_init, nq, (uint32_t)s.R, s.d_qs, 2, nullptr, nullptr, tda, 0, st);
             launch_start_scan_f32(M, s.d_sitems + na, (int)nb, wgs_for(sitems_b), d_ft, s.d_fc.p, fc_stride, s.d_fc_init, s.d_qs, st);
         }
-        launch_select_kth(s.d_fc.p, fc_stride, s.d_fc_init, nq, (uint32_t)s.R, s.d_qs, 4, d_ft, s.d_qtables.p, tda,
+        if (s.mode == 1) {
+            // pre-scan only: the exact R-th smallest of this rank's slice, and the R smallest values themselves,
+            // stored straight into the pinned result block; nothing else runs
+            float* d_exp = reinterpret_cast<float*>(d_result);
+            uint32_t* d_expf = reinterpret_cast<uint32_t*>(d_result + sizeof(float) * (size_t)s.R * nq);
+            launch_select_kth(s.d_fc.p, fc_stride, s.d_fc_init, nq, (uint32_t)s.R, s.d_qs, 4, nullptr, nullptr, tda, 0, st,
+                              d_exp, d_expf);
+            HIPCHECK(hipGetLastError());
+            if (idx->profile) HIPCHECK(prof_event(s, st));
+            if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(s.ev_done, st));
+            return QADC_OK;
+        }
+        const float* d_sel = s.d_fc.p;
+        if (s.mode == 2) {
+            // the ranks' gathered smallest values stand in for the pre-scan output
+            d_sel = reinterpret_cast<const float*>(s.d_in.p + off_inj);
+            fc_stride = s.inj_n;
+            launch_prescan_minmax(d_sel, s.inj_n, nq, s.d_qs, st);
+        }
+        launch_select_kth(d_sel, fc_stride, s.d_fc_init, nq, (uint32_t)s.R, s.d_qs, 4, d_ft, s.d_qtables.p, tda,
                           idx->quant_mode, st);
         if (idx->profile) HIPCHECK(prof_event(s, st));
     } else {
@@ -548,7 +604,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
 }
 
 int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* assign, float* tables,
-                  const int8_t* qtables, int R) {
+                  const int8_t* qtables, int R, int mode = 0, int slice = 0, int nslices = 1,
+                  const float* inj_vals = nullptr, int inj_n = 0) {
     if (!idx) return fail(QADC_E_ARG, "null index");
     if (slot_i < 0 || slot_i > 1) return fail(QADC_E_ARG, "slot must be 0 or 1");
     if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
@@ -556,9 +613,16 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
     if (nq >= (1 << 24)) return fail(QADC_E_ARG, "nq must be < 2^24");
     if (ma >= (1 << 14)) return fail(QADC_E_ARG, "ma must be < 16384");
     if (!tables && !qtables) return fail(QADC_E_ARG, "tables is null");
-    Slot& s = idx->slot[slot_i];
+    if (mode == 1 && (nslices < 1 || slice < 0 || slice >= nslices)) return fail(QADC_E_ARG, "need 0 <= slice < nslices");
+    if (mode == 2 && (!inj_vals || inj_n < 1)) return fail(QADC_E_ARG, "prescan values missing");
+    Slot& s = mode == 1 ? idx->pre_slot[slot_i] : idx->slot[slot_i];
     if (s.busy) return fail(QADC_E_STATE, "slot still holds an uncollected batch");
     if (int rc = use_device(idx)) return rc;
+    s.mode = mode;
+    s.pre_slice = slice;
+    s.pre_nslices = nslices;
+    s.inj_n = (uint32_t)inj_n;
+    if (mode == 2) s.inj_vals.assign(inj_vals, inj_vals + (size_t)nq * inj_n);
     s.nq = nq;
     s.ma = ma;
     s.R = R;
@@ -597,6 +661,7 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
     Slot& s = idx->slot[slot_i];
     if (s.busy) return fail(QADC_E_STATE, "slot still holds an uncollected batch");
     if (int rc = use_device(idx)) return rc;
+    s.mode = 0;
     const int dim = idx->dim;
     s.nq = nq;
     s.ma = ma;
@@ -834,7 +899,9 @@ int qadc_index_destroy(qadc_index* idx) {
     idx->d_codebooks.release();
     idx->d_rotation.release();
     idx->d_coarse.release();
-    for (auto& s : idx->slot) {
+    Slot* all_slots[4] = {&idx->slot[0], &idx->slot[1], &idx->pre_slot[0], &idx->pre_slot[1]};
+    for (Slot* sp : all_slots) {
+        Slot& s = *sp;
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
         s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
         s.h_cands.release();
@@ -1087,6 +1154,54 @@ int qadc_query_scan_submit(qadc_index* idx, int slot, int nq, int ma, const int3
     return submit_common(idx, slot, nq, ma, assign, tables, nullptr, R);
 }
 
+/* ---- sharded pre-scan (multi-GPU): every rank pre-scans one slice of the starts, the R smallest values per query
+ * are gathered by the caller (RCCL), and the batch is submitted with the gathered values in place of its own
+ * pre-scan.  The R-th smallest of the union of the per-slice R smallest IS the R-th smallest of all starts, so
+ * qmax — and everything after it — is bit-identical to the unsharded path. ---- */
+int qadc_prescan_submit(qadc_index* idx, int slot, int nq, int ma, const int32_t* assign, float* tables, int R,
+                        int slice, int nslices) {
+    if (!tables) return fail(QADC_E_ARG, "tables is null");
+    return submit_common(idx, slot, nq, ma, assign, tables, nullptr, R, 1, slice, nslices);
+}
+
+int qadc_prescan_collect(qadc_index* idx, int slot, float* vals) {
+    if (!idx || slot < 0 || slot > 1 || !vals) return fail(QADC_E_ARG, "bad arguments");
+    Slot& s = idx->pre_slot[slot];
+    if (!s.busy) return fail(QADC_E_STATE, "slot holds no pre-scan");
+    if (int rc = use_device(idx)) return rc;
+    for (int attempt = 0;; ++attempt) {
+        HIPCHECK(hipEventSynchronize(s.ev_done));
+        bool overflow = false;
+        for (int q = 0; q < s.nq; ++q) overflow |= (s.h_export_flags[q] & 8u) != 0;
+        if (!overflow) break;
+        if (attempt >= 1) {
+            s.busy = false;
+            return fail(QADC_E_CAPACITY, "pre-scan survivor buffer overflow persists");
+        }
+        s.full_prescan = true;               // adversarially ordered starts: evaluate the slice unfiltered
+        idx->prof.regrows++;
+        if (int rc = plan_and_launch(idx, s)) {
+            s.busy = false;
+            return rc;
+        }
+    }
+    s.busy = false;
+    if (idx->profile && s.prof_used >= 2) {
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[0], s.prof_ev[1]));
+        idx->prof.start_ms += ms;
+        idx->prof.start_codes += s.start_codes;
+    }
+    std::memcpy(vals, s.h_export, sizeof(float) * (size_t)s.nq * s.R);
+    return QADC_OK;
+}
+
+int qadc_query_scan_submit_prescanned(qadc_index* idx, int slot, int nq, int ma, const int32_t* assign, float* tables,
+                                      int R, const float* prescan_vals, int nvals) {
+    if (!tables) return fail(QADC_E_ARG, "tables is null");
+    return submit_common(idx, slot, nq, ma, assign, tables, nullptr, R, 2, 0, 1, prescan_vals, nvals);
+}
+
 int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
                             float* qmin, float* qmax, int8_t* qtables) {
     if (int rc = collect_common(idx, slot)) return rc;
@@ -1200,6 +1315,66 @@ int qadc_replay_i8(uint64_t n, const uint32_t* keys, const int8_t* vals, int R, 
     *out_size = bh.size();
     if (out_keys) std::memcpy(out_keys, bh.keys(), sizeof(uint32_t) * bh.size());
     if (out_vals) std::memcpy(out_vals, bh.values(), bh.size());
+    return QADC_OK;
+}
+
+// Host half of the multi-GPU merge (pyqadc/sharded.py): `gathered` holds, rank after rank, the int32 buffers the
+// ranks contributed to the all-gather: [nq counts][cap keys][ceil(cap/4) words of int8 values]
+// [only when ma > 1: ceil(cap/2) words of u16 assign slots][...].  Queries q_first, q_first + q_step, ... are replayed here in
+// global scan order (assign slot, rank, position) through the reference heap after the (0,127) sentinel.
+int qadc_merge_streams_i8(int world, int nq, int R, uint64_t cap, int ma, const int32_t* gathered, uint64_t buflen,
+                          int q_first, int q_step, const int32_t* status, uint32_t* keys, int8_t* vals, int32_t* sizes) {
+    if (world <= 0 || nq <= 0 || R <= 0 || ma <= 0 || !gathered || !keys || !vals || !sizes || q_step <= 0 || q_first < 0)
+        return fail(QADC_E_ARG, "bad arguments");
+    const uint64_t nv = (cap + 3) / 4, ns = ma > 1 ? (cap + 1) / 2 : 0;
+    if (buflen < (uint64_t)nq + cap + nv + ns) return fail(QADC_E_ARG, "gathered buffers shorter than their layout");
+    // entry offsets of every (rank, query)
+    std::vector<uint64_t> offs((size_t)world * (nq + 1), 0);
+    for (int g = 0; g < world; ++g) {
+        const int32_t* cnt = gathered + (uint64_t)g * buflen;
+        uint64_t* o = offs.data() + (size_t)g * (nq + 1);
+        for (int q = 0; q < nq; ++q) o[q + 1] = o[q] + (uint32_t)cnt[q];
+        if (o[nq] > cap) return fail(QADC_E_CAPACITY, "a rank's stream exceeds the gathered capacity");
+    }
+    std::vector<int> mine;
+    for (int q = q_first; q < nq; q += q_step) mine.push_back(q);
+    auto work = [&](size_t i0, size_t i1) {
+        kv_heap<uint32_t, int8_t> bh(R);
+        std::vector<uint64_t> cur(world);
+        for (size_t i = i0; i < i1; ++i) {
+            const int q = mine[i];
+            sizes[q] = 0;
+            if (status && status[q]) continue;
+            bh.reset();
+            bh.push(0, 127);                                     // db_query_4.cpp:276
+            for (int g = 0; g < world; ++g) cur[g] = offs[(size_t)g * (nq + 1) + q];
+            for (int slot = 0; slot < ma; ++slot)
+                for (int g = 0; g < world; ++g) {
+                    const int32_t* base = gathered + (uint64_t)g * buflen;
+                    const uint32_t* k = reinterpret_cast<const uint32_t*>(base + nq);
+                    const int8_t* v = reinterpret_cast<const int8_t*>(base + nq + cap);
+                    const uint16_t* sl = reinterpret_cast<const uint16_t*>(base + nq + cap + nv);
+                    const uint64_t end = offs[(size_t)g * (nq + 1) + q + 1];
+                    uint64_t& c = cur[g];
+                    // a rank scans its partitions in assign order: its slots are ascending
+                    while (c < end && (ma == 1 || sl[c] == (uint16_t)slot)) {
+                        bh.push(k[c], v[c]);
+                        ++c;
+                    }
+                }
+            sizes[q] = bh.size();
+            std::memcpy(keys + (size_t)q * R, bh.keys(), sizeof(uint32_t) * bh.size());
+            std::memcpy(vals + (size_t)q * R, bh.values(), bh.size());
+        }
+    };
+    const size_t nt = std::min<size_t>(std::min<size_t>(mine.size(), 4), std::max<unsigned>(std::thread::hardware_concurrency(), 1));
+    if (nt <= 1) {
+        work(0, mine.size());
+    } else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; ++t) th.emplace_back(work, mine.size() * t / nt, mine.size() * (t + 1) / nt);
+        for (auto& x : th) x.join();
+    }
     return QADC_OK;
 }
 

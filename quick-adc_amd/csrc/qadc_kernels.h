@@ -129,9 +129,15 @@ void launch_build_tables(const float* d_queries, const float* d_coarse, const in
 // (FLT_MAX if fewer than R values).  max_passes < 4: upper bound only (survivor filter of the pre-scan).
 // d_qtables != nullptr: the same workgroup then runs QuantizerMAX<int8> for the query (qmin, in-place negative
 // clamp of d_ftables, int8 tables) — the last step of the float chain, saving a launch.
+// export_vals != nullptr (needs max_passes = 4): also writes the query's R smallest values to export_vals[q][R]
+// (padded with FLT_MAX when there are fewer) and QueryState::flags to export_flags[q] — the sharded pre-scan.
 void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init, int nq, uint32_t R,
                        QueryState* d_qs, int max_passes, float* d_ftables, int8_t* d_qtables, int table_dim_all,
-                       int quant_mode, hipStream_t stream);
+                       int quant_mode, hipStream_t stream, float* export_vals = nullptr,
+                       uint32_t* export_flags = nullptr);
+
+// Key range of d_vals[q][nvals] into QueryState::sel_nmin / sel_max (injected pre-scan values).
+void launch_prescan_minmax(const float* d_vals, uint32_t nvals, int nq, QueryState* d_qs, hipStream_t stream);
 
 // PQ encode of device-resident vectors [n][dim] with codebooks [M][16][dim/M] -> codes [n][M/2].
 void launch_pq_encode(const float* d_vectors, uint64_t n, int M, int dim, const float* d_codebooks, uint8_t* d_codes,

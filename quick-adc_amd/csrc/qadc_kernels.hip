@@ -1139,14 +1139,21 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
                                                           const uint32_t* __restrict__ fc_init, uint32_t R,
                                                           QueryState* __restrict__ qstates, int max_passes,
                                                           float* __restrict__ ftables, int8_t* __restrict__ qtables,
-                                                          int table_dim_all, int quant_mode) {
+                                                          int table_dim_all, int quant_mode,
+                                                          float* __restrict__ export_vals,
+                                                          uint32_t* __restrict__ export_flags) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_k, s_hi;
+    __shared__ uint32_t s_prefix, s_k, s_hi, s_cnt;
     __shared__ float red[1024];
     const int q = blockIdx.x, tid = threadIdx.x;
     QueryState* qs = qstates + q;
     const uint32_t n = min(fc_init[2 * q] + qs->fc_n, fc_init[2 * q + 1]);
+    if (export_flags && tid == 0) export_flags[q] = qs->flags;
     if (n < R) {                                           // heap never fills: max() stays the FLT_MAX sentinel
+        if (export_vals) {                                 // sharded pre-scan: all n values, padded with the sentinel
+            for (uint32_t i = tid; i < R; i += 1024)
+                export_vals[(uint64_t)q * R + i] = i < n ? fc[(uint64_t)q * fc_stride + i] : FLT_MAX;
+        }
         if (tid == 0) qs->qmax = FLT_MAX;
         if (qtables) quantize_query(table_dim_all, ftables + (uint64_t)q * table_dim_all, qtables + (uint64_t)q * table_dim_all,
                                     qs, FLT_MAX, quant_mode, red);
@@ -1209,15 +1216,57 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
     const uint64_t key = (uint64_t)(s_prefix | low) + kmin;
     const float qmax = funkey(key > kmax ? kmax : (uint32_t)key);                  // never above the largest stored value
     if (tid == 0) qs->qmax = qmax;
+    if (export_vals) {
+        // the R smallest values as a multiset (needs the exact R-th smallest: max_passes = 4): every value below
+        // qmax, then qmax itself as often as it takes — which of several equal values is dropped does not matter
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += 1024) {
+            const float v = src[i];
+            if (v < qmax) export_vals[(uint64_t)q * R + atomicAdd(&s_cnt, 1u)] = v;    // fewer than R such values
+        }
+        __syncthreads();
+        for (uint32_t i = s_cnt + tid; i < R; i += 1024) export_vals[(uint64_t)q * R + i] = qmax;
+    }
     if (qtables) quantize_query(table_dim_all, ftables + (uint64_t)q * table_dim_all, qtables + (uint64_t)q * table_dim_all,
                                 qs, qmax, quant_mode, red);
 }
 
+// Sharded pre-scan, second half: the gathered smallest values of all ranks stand in for the pre-scan output of
+// a query.  One workgroup per query records their key range (what start_scan_f32_kernel does for its own values).
+__global__ __launch_bounds__(256) void prescan_minmax_kernel(const float* __restrict__ vals, uint32_t nvals,
+                                                             QueryState* __restrict__ qstates) {
+    __shared__ uint32_t rmin[4], rmax[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    uint32_t kmin = 0xffffffffu, kmax = 0;
+    for (uint32_t i = tid; i < nvals; i += 256) {
+        const uint32_t k = fkey(vals[(uint64_t)q * nvals + i]);
+        kmin = min(kmin, k);
+        kmax = max(kmax, k);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor(kmin, d, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor(kmax, d, 64));
+    }
+    if ((tid & 63) == 0) { rmin[tid >> 6] = kmin; rmax[tid >> 6] = kmax; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) { kmin = min(kmin, rmin[w]); kmax = max(kmax, rmax[w]); }
+        qstates[q].sel_nmin = ~kmin;
+        qstates[q].sel_max = kmax;
+    }
+}
+
+void launch_prescan_minmax(const float* d_vals, uint32_t nvals, int nq, QueryState* d_qs, hipStream_t stream) {
+    hipLaunchKernelGGL(prescan_minmax_kernel, dim3(nq), dim3(256), 0, stream, d_vals, nvals, d_qs);
+}
+
 void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init, int nq, uint32_t R, QueryState* d_qs,
                        int max_passes, float* d_ftables, int8_t* d_qtables, int table_dim_all, int quant_mode,
-                       hipStream_t stream) {
+                       hipStream_t stream, float* export_vals, uint32_t* export_flags) {
     hipLaunchKernelGGL(select_kth_kernel, dim3(nq), dim3(1024), 0, stream, d_fc, fc_stride, d_fc_init, R, d_qs, max_passes,
-                       d_ftables, d_qtables, table_dim_all, quant_mode);
+                       d_ftables, d_qtables, table_dim_all, quant_mode, export_vals, export_flags);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -27,9 +27,10 @@ SYMBOLS = [
     "qadc_index_set_key_base", "qadc_index_finalize", "qadc_index_partition_count",
     "qadc_index_partition_size", "qadc_index_start_size", "qadc_set_option",
     "qadc_index_read_codes", "qadc_query_scan", "qadc_query_scan_candidates", "qadc_scan_i8",
-    "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit",
+    "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit", "qadc_prescan_submit",
+    "qadc_prescan_collect", "qadc_query_scan_submit_prescanned",
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
-    "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_replay_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
+    "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_replay_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
 ]
 
 
@@ -88,6 +89,10 @@ def lib():
                                               u32p, i8p, u64p]
         L.qadc_scan_start.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, f32p, C.c_int, f32p]
         L.qadc_query_scan_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_int]
+        L.qadc_prescan_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_int, C.c_int, C.c_int]
+        L.qadc_prescan_collect.argtypes = [C.c_void_p, C.c_int, f32p]
+        L.qadc_query_scan_submit_prescanned.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_int,
+                                                        f32p, C.c_int]
         L.qadc_query_scan_collect.argtypes = [C.c_void_p, C.c_int, u32p, i8p, i32p, i32p, f32p, f32p, i8p]
         L.qadc_index_set_pq.argtypes = [C.c_void_p, C.c_int, f32p]
         L.qadc_index_set_rotation.argtypes = [C.c_void_p, f32p]
@@ -98,6 +103,8 @@ def lib():
         L.qadc_pq_encode.argtypes = [C.c_int, C.c_int, f32p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.qadc_pq_encode_host.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_uint64, u8p, C.c_int]
         L.qadc_replay_i8.argtypes = [C.c_uint64, u32p, i8p, C.c_int, C.c_int, u32p, i8p, i32p]
+        L.qadc_merge_streams_i8.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, i32p, C.c_uint64, C.c_int,
+                                            C.c_int, i32p, u32p, i8p, i32p]
         L.qadc_candidates_i8.argtypes = [C.c_void_p, C.c_int, i8p, i8p]
         L.qadc_float_top1.argtypes = [C.c_void_p, C.c_int, f32p, u32p, u32p, f32p]
         L.qadc_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile)]
@@ -123,6 +130,14 @@ def replay_i8(keys, vals, R, sentinel=False):
     _check(lib().qadc_replay_i8(len(keys), _p(keys, u32p), _p(vals, i8p), R, int(sentinel), _p(ok, u32p),
                                 _p(ov, i8p), C.byref(osz)))
     return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def merge_streams_i8(gathered, world, nq, R, cap, ma, q_first, q_step, status, keys, vals, sizes):
+    """Host-only: replay the queries q_first, q_first+q_step, ... of the gathered per-rank streams (sharded.py)."""
+    g = np.ascontiguousarray(gathered, np.int32).reshape(world, -1)
+    st = None if status is None else np.ascontiguousarray(status, np.int32)
+    _check(lib().qadc_merge_streams_i8(world, nq, R, cap, ma, _p(g, i32p), g.shape[1], q_first, q_step, _p(st, i32p),
+                                       _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p)))
 
 
 def pq_encode(codebooks, vectors, device=0):
@@ -248,13 +263,35 @@ class Index:
         return dict(heaps=self._heaps(nq, R, keys, vals, sizes), status=status, qmin=qmin, qmax=qmax, qtables=qt,
                     keys=keys, values=vals, sizes=sizes)
 
-    def submit(self, slot, assign, tables, R):
+    def submit(self, slot, assign, tables, R, prescan=None):
+        """prescan: float32 [nq][w*R], the gathered output of prescan_collect on all w ranks (sharded pre-scan)."""
         assign = self._prep(assign)
         nq, ma = assign.shape
         assert tables.dtype == np.float32 and tables.flags.c_contiguous
         self._pending = getattr(self, "_pending", {})
         self._pending[slot] = (nq, R, tables, assign)
-        _check(lib().qadc_query_scan_submit(self._h, slot, nq, ma, _p(assign, i32p), _p(tables, f32p), R))
+        if prescan is None:
+            _check(lib().qadc_query_scan_submit(self._h, slot, nq, ma, _p(assign, i32p), _p(tables, f32p), R))
+        else:
+            pv = np.ascontiguousarray(prescan, np.float32).reshape(nq, -1)
+            _check(lib().qadc_query_scan_submit_prescanned(self._h, slot, nq, ma, _p(assign, i32p), _p(tables, f32p), R,
+                                                           _p(pv, f32p), pv.shape[1]))
+
+    def prescan_submit(self, slot, assign, tables, R, slice_index, nslices):
+        """Sharded pre-scan, first half: this rank's slice of the starts (own buffers: may overlap a pending batch)."""
+        assign = self._prep(assign)
+        nq, ma = assign.shape
+        assert tables.dtype == np.float32 and tables.flags.c_contiguous
+        self._pre_pending = getattr(self, "_pre_pending", {})
+        self._pre_pending[slot] = (nq, R, tables, assign)
+        _check(lib().qadc_prescan_submit(self._h, slot, nq, ma, _p(assign, i32p), _p(tables, f32p), R, slice_index, nslices))
+
+    def prescan_collect(self, slot):
+        """-> float32 [nq][R]: the R smallest pre-scan distances of the slice per query (FLT_MAX-padded)."""
+        nq, R, tables, assign = self._pre_pending.pop(slot)
+        vals = np.zeros((nq, R), np.float32)
+        _check(lib().qadc_prescan_collect(self._h, slot, _p(vals, f32p)))
+        return vals
 
     def collect(self, slot):
         nq, R, tables, assign = self._pending.pop(slot)

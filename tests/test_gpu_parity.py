@@ -649,3 +649,92 @@ def test_multi_query_pass_groups_labels_and_padding_replays(pyqadc, po, M):
         want = po.scan_i8(M, [codes], [labels], qt[q, 0], R)
         assert heaps_equal(heaps[q], want), q
     idx.close()
+
+
+@pytest.mark.parametrize("M,W,sample", [(16, 3, 65536), (16, 8, 512), (32, 2, 512), (16, 5, 64)])
+def test_sharded_prescan_equals_unsharded(pyqadc, po, M, W, sample):
+    """Multi-GPU pre-scan protocol on one GPU: W slices of the starts are pre-scanned separately, the R smallest values
+    of each are concatenated (what the all-gather does) and injected; qmax, tables and heaps equal the plain path and
+    the oracle.  IVF-shaped (3 probes, ragged partitions, one with fewer starts than slices)."""
+    rng = np.random.default_rng(90 + M + W)
+    R, keep, nq, ma = 50, 0.04, 6, 3
+    sizes = [90000, 1234, 40000, 17, 25000]
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts)
+    idx.finalize(keep)
+    idx.set_option("prescan_sample", sample)
+    idx.set_option("small_run", 4096)
+    assign = np.stack([rng.permutation(len(sizes))[:ma] for _ in range(nq)]).astype(np.int32)
+    tables = float_tables(rng, nq, ma, M)
+    plain = idx.query_scan(assign, tables.copy(), R, want_qtables=True)
+    gathered = []
+    for r in range(W):
+        idx.prescan_submit(r % 2, assign, tables.copy(), R, r, W)
+        gathered.append(idx.prescan_collect(r % 2))
+    gathered = np.concatenate(gathered, axis=1)                       # [nq][W*R]
+    tb = tables.copy()
+    idx.submit(0, assign, tb, R, prescan=gathered)
+    got = idx.collect(0)
+    for q in range(nq):
+        want = po.query_scan(M, parts, None, keep, assign[q], tables[q].copy(), R)
+        assert heaps_equal((got["keys"][q, :got["sizes"][q]], got["values"][q, :got["sizes"][q]]),
+                           (want["keys"], want["values"])), q
+        assert heaps_equal((got["keys"][q, :got["sizes"][q]], got["values"][q, :got["sizes"][q]]), plain["heaps"][q]), q
+    # fewer than R starts in total: the sentinel survives and every rank reports it
+    idx2 = pyqadc.Index(M)
+    idx2.add_partitions([parts[1]])
+    idx2.finalize(0.01)                                               # 12 starts < R
+    a1 = np.zeros((2, 1), np.int32)
+    t1 = float_tables(rng, 2, 1, M)
+    pv = []
+    for r in range(W):
+        idx2.prescan_submit(0, a1, t1.copy(), R, r, W)
+        pv.append(idx2.prescan_collect(0))
+    pv = np.concatenate(pv, axis=1)
+    assert np.sum(pv < 3e38) == 2 * 12
+    idx2.submit(1, a1, t1.copy(), R, prescan=pv)
+    assert list(idx2.collect(1)["status"]) == [1, 1]
+    idx.close()
+    idx2.close()
+
+
+@pytest.mark.parametrize("M,W", [(16, 4), (32, 3)])
+def test_multi_gpu_protocol_on_virtual_ranks(pyqadc, po, M, W):
+    """The whole multi-GPU step on one GPU: W shard indexes (contiguous code ranges + a replica of the starts),
+    sliced pre-scan -> gather -> injected submit -> candidate streams -> native merge in (rank, position) order.
+    Heaps equal the oracle's single sequential scan of the whole list."""
+    from pyqadc import sharded
+    rng = np.random.default_rng(95 + M + W)
+    n, nq, R, keep = 260003, 9, 100, 0.03
+    codes = rand_codes(rng, n, M)
+    starts = max(1, int(np.float32(n) * np.float32(keep)))
+    ranges = sharded.shard_ranges(n, W)
+    ranks = []
+    for first, ln in ranges:
+        ix = pyqadc.Index(M)
+        ix.add_partition_shard(codes[first:first + ln], first, n, starts=codes[:starts])
+        ix.finalize(keep)
+        ix.set_option("small_run", 4096)
+        ranks.append(ix)
+    assign = np.zeros((nq, 1), np.int32)
+    tables = float_tables(rng, nq, 1, M)
+    pv = []
+    for r, ix in enumerate(ranks):
+        ix.prescan_submit(0, assign, tables.copy(), R, r, W)
+        pv.append(ix.prescan_collect(0))
+    gathered = np.concatenate(pv, axis=1)
+    cap = 1 << 14
+    bufs = []
+    for ix in ranks:
+        ix.submit(0, assign, tables.copy(), R, prescan=gathered)
+        res = ix.collect_candidates(0)
+        words = sharded._layout(nq, cap, 0, 1)[2]
+        bufs.append(sharded.pack_stream(np.zeros(words, np.int32), res, nq, cap))
+    K, V, S = np.zeros((nq, R), np.uint32), np.zeros((nq, R), np.int8), np.zeros(nq, np.int32)
+    pyqadc.merge_streams_i8(np.stack(bufs), W, nq, R, cap, 1, 0, 1, None, K, V, S)
+    for q in range(nq):
+        want = po.query_scan(M, [codes], None, keep, [0], tables[q].copy(), R)
+        assert heaps_equal((K[q, :S[q]], V[q, :S[q]]), (want["keys"], want["values"])), q
+    for ix in ranks:
+        ix.close()

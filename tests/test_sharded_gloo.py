@@ -32,7 +32,12 @@ def _worker(rank, world, port, M, n, R, tmax, seed, out_dir):
         vals.append(v)
         offs.append(offs[-1] + len(k))
     local = dict(keys=np.concatenate(keys), vals=np.concatenate(vals), offsets=np.array(offs, np.int64))
-    K, V, S = sharded.merge_batch(local, nq, R, None, "cpu", cap=64)   # tiny cap: exercises the regrow round
+    # the gather also carries the next batch's sharded pre-scan values: rank r contributes extra[r]
+    extra = (np.arange(3 * 7, dtype=np.float32).reshape(3, 7) + 100 * rank)
+    K, V, S, G = sharded.merge_batch(local, nq, R, None, "cpu", cap=64, extra=extra)   # tiny cap: exercises the regrow round
+    want_g = np.concatenate([np.arange(3 * 7, dtype=np.float32).reshape(3, 7) + 100 * r for r in range(world)], axis=1)
+    assert np.array_equal(G, want_g)
+    assert np.array_equal(sharded.gather_prescan(extra, "cpu"), want_g)
     for q in range(nq):
         wk, wv = po.scan_i8(M, [codes], None, qt[q:q + 1], R)
         assert S[q] == len(wk), (q, S[q], len(wk))

@@ -1,5 +1,5 @@
-"""Host-side timeline of one rank's multi-GPU step (submit / collect_candidates / merge) on a 1-GPU box:
-world 1 over RCCL, shard size = what one of 8 ranks holds.  Shows where a rank's step time goes."""
+"""Host-side timeline of one rank's multi-GPU step on a 1-GPU box (world 1 over RCCL, shard size = what one of 8
+ranks holds): where the host time of the pipelined loop of bench.py (run_steps_dist) goes."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,28 +8,40 @@ import torch, torch.distributed as dist
 import pyqadc
 from pyqadc import sharded
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-N = int(float(os.environ.get("N", 125e6))); NQ = 8; M = 16; R = 100
+N = int(float(os.environ.get("N", 125e6))); NQ = int(os.environ.get("NQ", 32)); M = 16; R = 100
+STEPS = int(os.environ.get("STEPS", 300)); WORLD_EMU = int(os.environ.get("WORLD_EMU", 8))
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-idx = pyqadc.Index(M); idx.add_partition_synthetic(N, 1); idx.finalize(0.01)
+idx = pyqadc.Index(M); idx.add_partition_synthetic(N, 1); idx.finalize(0.01 * 1e9 / N if N < 1e9 else 0.01)
 rng = np.random.default_rng(0)
 cb = rng.normal(size=(M, 16, 8)).astype(np.float32)
 q = rng.normal(size=(NQ, M, 1, 8)).astype(np.float32)
 tables = np.ascontiguousarray(((q - cb[None]) ** 2).sum(-1).reshape(NQ, 1, 256), np.float32)
 assign = np.zeros((NQ, 1), np.int32)
-for _ in range(3):
-    idx.submit(0, assign, tables.copy(), R); r = idx.collect_candidates(0); sharded.merge_batch(r, NQ, R, r["status"], dev)
-pend = None; rows = []
-t0 = time.perf_counter()
-STEPS = int(os.environ.get('STEPS', 300))
+# this rank pre-scans 1/WORLD_EMU of the (10M) starts and replays NQ/WORLD_EMU queries, as one of WORLD_EMU ranks would
+T = {k: 0.0 for k in ("prescan_submit", "collect_cand", "prescan_collect", "merge", "submit")}
+def tick(k, t0):
+    T[k] += time.perf_counter() - t0
+tb = {0: tables.copy()}
+idx.prescan_submit(0, assign, tb[0], R, 0, WORLD_EMU)
+g = np.tile(idx.prescan_collect(0), (1, WORLD_EMU))
+idx.submit(0, assign, tb[0], R, prescan=g)
+t_start = None
 for s in range(STEPS):
-    a = time.perf_counter(); idx.submit(s % 2, assign, tables.copy(), R); b = time.perf_counter()
-    if pend is not None:
-        r = idx.collect_candidates(pend); c = time.perf_counter()
-        sharded.merge_batch(r, NQ, R, r["status"], dev); d = time.perf_counter()
-        rows.append(((b - a) * 1e3, (c - b) * 1e3, (d - c) * 1e3))
-    pend = s % 2
-tot = (time.perf_counter() - t0) * 1e3
-rows = np.array(rows[STEPS // 3:])
-print("per step: submit %.3f ms, collect %.3f ms, merge %.3f ms; loop %.3f ms/step" % (*rows.mean(0), tot / STEPS))
+    if s == STEPS // 3:
+        for k in T: T[k] = 0.0
+        t_start = time.perf_counter(); s0 = s
+    tb[(s + 1) % 2] = tables.copy()
+    t0 = time.perf_counter(); idx.prescan_submit((s + 1) % 2, assign, tb[(s + 1) % 2], R, 0, WORLD_EMU); tick("prescan_submit", t0)
+    if s > 0:
+        t0 = time.perf_counter(); res = idx.collect_candidates((s - 1) % 2); tick("collect_cand", t0)
+        t0 = time.perf_counter(); pv = idx.prescan_collect((s + 1) % 2); tick("prescan_collect", t0)
+        t0 = time.perf_counter(); out = sharded.merge_batch(res, NQ, R, res["status"], dev, extra=pv); tick("merge", t0)
+        g = np.tile(out[3], (1, WORLD_EMU))
+    else:
+        g = np.tile(idx.prescan_collect((s + 1) % 2), (1, WORLD_EMU))
+    t0 = time.perf_counter(); idx.submit((s + 1) % 2, assign, tb[(s + 1) % 2], R, prescan=g); tick("submit", t0)
+tot = (time.perf_counter() - t_start) * 1e3 / (STEPS - s0)
+print("per step (ms): " + ", ".join("%s %.3f" % (k, v * 1e3 / (STEPS - s0)) for k, v in T.items()) + "; loop %.3f" % tot)
+idx.collect_candidates((STEPS - 1) % 2); idx.collect_candidates(STEPS % 2)
 dist.destroy_process_group()
