@@ -37,8 +37,25 @@ struct pq4 {
     int sq_bits;                   // 4
     int dim;
     std::vector<float> centroids;  // [M][16][sq_dim]
+    std::vector<float> rotation;   // OPQ: [dim][dim], empty for plain PQ (quantizers.hpp:248-324)
 
     pq4(int m, int d) : sq_count(m), sq_bits(4), dim(d), centroids((size_t)m * 16 * (d / m)) {}
+    // opq::rotate_multiple_vectors (quantizers.hpp:289-301): sgemm(NoTrans, Trans) = every vector times the
+    // TRANSPOSED rotation, rotated[r] = sum_c x[c] * rotation[r][c]; plain PQ: no-op (189-195).  Sequential float
+    // sums in ascending c (what the device feeder does too; a BLAS may associate differently).
+    void rotate_multiple_vectors(float* vecs, int count) const {
+        if (rotation.empty()) return;
+        std::vector<float> out((size_t)dim);
+        for (int v = 0; v < count; ++v) {
+            float* x = vecs + (size_t)v * dim;
+            for (int r = 0; r < dim; ++r) {
+                float acc = 0;
+                for (int c = 0; c < dim; ++c) acc += x[c] * rotation[(size_t)r * dim + c];
+                out[r] = acc;
+            }
+            std::copy(out.begin(), out.end(), x);
+        }
+    }
     int sq_dim() const { return dim / sq_count; }
     int code_size() const { return sq_count / 2; }
     const float* centroid(int m, int c) const { return centroids.data() + ((size_t)m * 16 + c) * sq_dim(); }
@@ -62,9 +79,15 @@ struct pq4 {
     // nibble, odd one in the high nibble of byte m/2 (multiple_set_bits_4, quantizers.hpp:49-68)
     void encode(const float* vecs, size_t n, std::uint8_t* codes) const {
         const int ds = sq_dim(), cs = code_size();
-        std::vector<float> t((size_t)sq_count * 16);
+        std::vector<float> t((size_t)sq_count * 16), rot;
         for (size_t i = 0; i < n; ++i) {
-            tables(vecs + i * dim, t.data());
+            const float* x = vecs + i * dim;
+            if (!rotation.empty()) {                       // encode_multiple_vectors rotates first (quantizers.hpp:224)
+                rot.assign(x, x + dim);
+                rotate_multiple_vectors(rot.data(), 1);
+                x = rot.data();
+            }
+            tables(x, t.data());
             std::uint8_t* code = codes + i * cs;
             for (int m = 0; m < sq_count; ++m) {
                 int best = 0;
@@ -191,7 +214,8 @@ struct nns_engine {  // query_common.hpp:245-309
         const int dim = db.pq->dim;  // read before free_partition could matter; pq outlives the partitions
         const std::uint64_t t0 = ustime();
         db.assign_compute_residuals(query, ma, assign.data(), residuals.data());
-        const std::uint64_t t1 = ustime();  // plain PQ: rotate_multiple_vectors is a no-op
+        const std::uint64_t t1 = ustime();
+        db.pq->rotate_multiple_vectors(residuals.data(), ma);   // query_common.hpp:206-207 (no-op for plain PQ)
         const std::uint64_t t2 = ustime();
         for (int a = 0; a < ma; ++a) db.pq->tables(residuals.data() + (size_t)a * dim, dists.data() + (size_t)a * table_dim);
         const std::uint64_t t3 = ustime();
@@ -231,11 +255,14 @@ struct nns_engine_batch {
                 db.assign_compute_residuals(queries + (size_t)(query_i + i) * dim, ma, assign.data() + (size_t)i * ma,
                                             residuals.data() + (size_t)i * ma * dim);
             const std::uint64_t t1 = ustime();
+            db.pq->rotate_multiple_vectors(residuals.data(), nb * ma);
+            const std::uint64_t tr = ustime();
+            metrics.rotate_us = tr - t1;
             for (int i = 0; i < nb * ma; ++i) db.pq->tables(residuals.data() + (size_t)i * dim, dists.data() + (size_t)i * table_dim);
             const std::uint64_t t2 = ustime();
             scanner.batch_scan(nb, assign.data(), ma, dists.data(), table_dim, r);
             metrics.scan_us = ustime() - t2;
-            metrics.table_us = t2 - t1;
+            metrics.table_us = t2 - tr;
             metrics.index_us = t1 - t0;
         }
         const std::uint64_t t3 = ustime();

@@ -4,12 +4,16 @@
 // float nearest neighbour -> the reference's CSV line.  With --dump every query_scan call's inputs and
 // the resulting heap are written to a file so the Python test can replay them through the CPU oracle.
 //   usage: db_query_4_hip flat|ivf M N nq R keep_percent ma K seed [dumpfile|-] [batch]
+// File mode = the reference's own command line (db_query_4.cpp:316-356, README.md:327-330) on the reference's own
+// file formats (host/qadc_io.hpp): database archive, .fvecs/.bvecs/.ivecs queries, .ivecs ground truth:
+//   usage: db_query_4_hip [-r R] [-m ma] [-b batch] [-k keep_percent] DB QUERIES GROUNDTRUTH [dumpfile]
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <random>
 #include <string>
 
+#include "../../quick-adc_amd/host/qadc_io.hpp"
 #include "../../quick-adc_amd/host/query_driver.hpp"
 #include "../../quick-adc_amd/host/scanner_hip.hpp"
 
@@ -94,7 +98,74 @@ static void run(Db& db, const std::vector<float>& queries, int nq, int dim, int 
     print_csv(std::cout, R, recall, ma, keep, metrics);
 }
 
+static std::unique_ptr<pq4> pq_from_archive(const io::pq_data& d) {
+    if (d.sq_bits != 4 || (d.sq_count != 16 && d.sq_count != 32)) {  // get_simd_scan_func_epi8, db_query_4.cpp:22-35
+        std::cerr << "Unsupported (nsq,nsq_bits) configuration. Supported configurations are: (16,4) (32,4)." << std::endl;
+        std::exit(1);
+    }
+    std::unique_ptr<pq4> pq(new pq4(d.sq_count, d.dim));
+    pq->centroids = d.centroids;
+    pq->rotation = d.rotation;
+    return pq;
+}
+
+// the reference's db_query_4 main (db_query_4.cpp:316-414) on files
+static int main_files(int argc, char** argv) {
+    int R = 100, ma = 1;
+    float keep = 0.005f;  // db_query_4.cpp:324
+    std::vector<const char*> pos;
+    for (int i = 1; i < argc; ++i) {
+        const char* a = argv[i];
+        if (a[0] == '-' && a[1] && std::strchr("rmbk", a[1])) {
+            const char* v = a[2] ? a + 2 : (i + 1 < argc ? argv[++i] : "");
+            if (a[1] == 'r') R = std::atoi(v);
+            if (a[1] == 'm') ma = std::atoi(v);
+            if (a[1] == 'b') g_batch = std::atoi(v);
+            if (a[1] == 'k') keep = (float)std::atof(v) * 0.01f;  // a percentage (db_query_4.cpp:345)
+        } else {
+            pos.push_back(a);
+        }
+    }
+    if (pos.size() < 3) {
+        std::cerr << "Usage: " << argv[0] << " [-r R] [-m ma] [-b batch] [-k keep%] [db_file] [query_file] [groundtruth_file]" << std::endl;
+        return 1;
+    }
+    try {
+        std::cerr << "Database file: " << pos[0] << std::endl;
+        io::db_archive ar = io::load_database(pos[0]);
+        io::vectors_owner<float> queries = io::load_vectors_by_extension(pos[1]);
+        io::vectors_owner<int> gtv = io::load_ivecs(pos[2]);
+        if (queries.dimension != ar.pq.dim) {
+            std::cerr << "Query vectors have " << queries.dimension << " dimensions, the database " << ar.pq.dim << std::endl;
+            return 1;
+        }
+        const int nq = (int)std::min<long>(queries.count, gtv.count);
+        std::vector<unsigned> gt(nq);
+        for (int q = 0; q < nq; ++q) gt[q] = (unsigned)gtv.get(q)[0];
+        std::ofstream dumpf;
+        if (pos.size() > 3) dumpf.open(pos[3], std::ios::binary);
+        const int M = ar.pq.sq_count;
+        if (!ar.indexed) {
+            flat_database db;
+            db.pq = pq_from_archive(ar.pq);
+            db.codes.swap(ar.codes);
+            db.count = ar.codes_count;
+            run(db, queries.data, nq, queries.dimension, R, keep, 1, gt, dumpf.is_open() ? &dumpf : nullptr, M);
+        } else {
+            ivf_database db(pq_from_archive(ar.pq), ar.part_count, ar.centroids);
+            db.partitions.swap(ar.partitions);
+            db.labels.swap(ar.labels);
+            run(db, queries.data, nq, queries.dimension, R, keep, ma, gt, dumpf.is_open() ? &dumpf : nullptr, M);
+        }
+    } catch (const std::exception& e) {
+        std::cerr << e.what() << std::endl;   // the reference prints and exits 1
+        return 1;
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) != "flat" && std::string(argv[1]) != "ivf") return main_files(argc, argv);
     if (argc < 10) {
         std::fprintf(stderr, "usage: %s flat|ivf M N nq R keep_percent ma K seed [dumpfile]\n", argv[0]);
         return 2;
