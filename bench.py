@@ -299,7 +299,7 @@ def main():
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": "flat DB, %d x %dx4 PQ codes (%d B/code), R=%d, keep=%.2f%%, %d queries/step, "
-                                   "one query per pass, sharded over %d GPU(s)" % (N, M, cs, R, KEEP * 100, NQ, world),
+                                   "every query scans the whole list, sharded over %d GPU(s)" % (N, M, cs, R, KEEP * 100, NQ, world),
                        "codes": N, "M": M, "R": R, "keep": KEEP, "queries_per_step": NQ,
                        "parallelism": "shard%d" % world},
             "recall_at_100": recall,
