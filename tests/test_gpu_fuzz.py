@@ -1,0 +1,57 @@
+"""Randomised parity sweep: random database shapes, batch shapes and tuning options (every kernel and fallback gets
+hit by some seed), heaps compared bit for bit with the oracle's restatement of scanner_4::query_scan."""
+import numpy as np
+import pytest
+
+from helpers import float_tables, heaps_equal, rand_codes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pyqadc():
+    import pyqadc
+    return pyqadc
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_configuration_matches_oracle(pyqadc, po, seed):
+    rng = np.random.default_rng(1000 + seed)
+    M = int(rng.choice([16, 32]))
+    nparts = int(rng.integers(1, 5))
+    sizes = [int(rng.choice([0, 1, 15, 16, 17, 100, 1000, 5000, 40000, 150001])) for _ in range(nparts)]
+    if sum(sizes) == 0:
+        sizes[0] = 33
+    labelled = bool(rng.integers(0, 2))
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    labels = [rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes] if labelled else None
+    R = int(rng.choice([1, 2, 10, 100, 257]))
+    keep = float(rng.choice([0.001, 0.01, 0.05, 0.3]))
+    same_assign = bool(rng.integers(0, 2))                 # identical probes for all queries: shared / multi-query launches
+    nq = int(rng.integers(1, 21))
+    ma = int(rng.integers(1, nparts + 1))
+    if same_assign:
+        assign = np.tile(rng.permutation(nparts)[:ma], (nq, 1)).astype(np.int32)
+    else:
+        assign = np.stack([rng.permutation(nparts)[:ma] for _ in range(nq)]).astype(np.int32)
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels=labels)
+    idx.finalize(keep)
+    opts = dict(small_run=int(rng.choice([1024, 8192, 131072])), mq=int(rng.integers(0, 2)),
+                share_variant=int(rng.choice([0, 0x41, 0x49])), cand_capacity=int(rng.choice([64, 1024, 16384])),
+                prescan_sample=int(rng.choice([64, 4096, 65536])), level_base=int(rng.choice([64, 512, 4096])),
+                level_growth=int(rng.choice([2, 4, 8])), overlap_front=int(rng.integers(0, 2)))
+    for k, v in opts.items():
+        idx.set_option(k, v)
+    tables = float_tables(rng, nq, ma, M, scale=float(rng.choice([0.2, 1.0])))
+    if rng.integers(0, 2):
+        tables = np.round(tables * 2) / 2                  # tie-heavy
+    res = idx.query_scan(assign, tables.copy(), R)
+    for q in range(nq):
+        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
+        if want["rc"] != 0:                                # the reference would exit: reported as status
+            assert res["status"][q] == 1, (seed, q, opts)
+            continue
+        assert res["status"][q] == 0
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), (seed, q, sizes, R, keep, ma, opts)
+    idx.close()
