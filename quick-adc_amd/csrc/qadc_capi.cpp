@@ -197,7 +197,10 @@ struct qadc_index {
     int share_variant = 0x41;            // streaming-kernel variant for shared launches: sibling-major, U=2, cached loads
     uint32_t share_codes_per_wg = 1u << 20;
     int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
+    int prescan_mq = 1;                  // ... and so does the float pre-scan when every query pre-scans the same starts
     uint32_t mq_codes_per_wg = 1u << 16;
+    uint32_t mq_min_wgs = 4096;          // workgroups a multi-query launch should have at least (2 rounds of the chip)
+    uint32_t mq_min_tiles = 4;           // ... but never fewer than this many 4 KiB tiles per workgroup
     int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
     int replay_threads = 0;            // 0 = auto
@@ -405,8 +408,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                 uint64_t w = idx->wgs_per_item > 0 ? (uint64_t)idx->wgs_per_item
                                                    : (maxn + idx->mq_codes_per_wg - 1) / idx->mq_codes_per_wg;
                 const uint64_t ngroups = (cnt + 7) / 8;
-                w = std::max<uint64_t>(w, (4096 + ngroups - 1) / ngroups);     // >= 2 rounds of the 2048 resident workgroups
-                w = std::min<uint64_t>(std::min<uint64_t>(w, 65536), tiles);
+                w = std::max<uint64_t>(w, (idx->mq_min_wgs + ngroups - 1) / ngroups);   // >= 2 rounds of the 2048 resident workgroups
+                w = std::min<uint64_t>(std::min<uint64_t>(w, 65536), std::max<uint64_t>(tiles / idx->mq_min_tiles, 1));
                 if (w >= 8) w &= ~7ull;
                 ll.wgs = (int)w;
             } else if (ll.shared) {
@@ -520,11 +523,25 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         const int tda = (int)(ma * table_dim);
         // phase A: the sample, unfiltered -> its R-th smallest; phase B: the rest, keeping only values <= that.
         // The LAST select of the chain also quantizes the query's tables (QuantizerMAX) in the same workgroup.
-        if (na) launch_start_scan_f32(M, s.d_sitems, (int)na, wgs_for(sitems_a), d_ft, s.d_fc.p, fc_stride, s.d_fc_init, s.d_qs, st);
+        // every query pre-scans the same starts (flat database, or one shared probe): 8 queries per pass
+        auto shared_items = [&](const std::vector<StartItem>& v) {
+            if (!idx->prescan_mq || v.size() < 2) return false;
+            for (auto& si : v)
+                if (si.codes != v[0].codes || si.n != v[0].n || si.out_off != v[0].out_off || si.filter != v[0].filter) return false;
+            return true;
+        };
+        auto start_scan = [&](const std::vector<StartItem>& v, const StartItem* d_v) {
+            if (shared_items(v))
+                launch_start_scan_mq(M, d_v, (int)v.size(), std::min(2 * wgs_for(v), 1024), d_ft, s.d_fc.p, fc_stride, s.d_fc_init,
+                                     s.d_qs, st);
+            else
+                launch_start_scan_f32(M, d_v, (int)v.size(), wgs_for(v), d_ft, s.d_fc.p, fc_stride, s.d_fc_init, s.d_qs, st);
+        };
+        if (na) start_scan(sitems_a, s.d_sitems);
         if (nb) {
             // (with a phase B the first select only has to bound the R-th smallest from above: 2 digit passes)
             launch_select_kth(s.d_fc.p, fc_stride, s.d_fc_init, nq, (uint32_t)s.R, s.d_qs, 2, nullptr, nullptr, tda, 0, st);
-            launch_start_scan_f32(M, s.d_sitems + na, (int)nb, wgs_for(sitems_b), d_ft, s.d_fc.p, fc_stride, s.d_fc_init, s.d_qs, st);
+            start_scan(sitems_b, s.d_sitems + na);
         }
         if (s.mode == 1) {
             // pre-scan only: the exact R-th smallest of this rank's slice, and the R smallest values themselves,
@@ -1127,7 +1144,10 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "overlap_front") idx->overlap_front = value != 0;
     else if (n == "share_variant") idx->share_variant = (int)value;
     else if (n == "mq") idx->mq = value != 0;
+    else if (n == "prescan_mq") idx->prescan_mq = value != 0;
     else if (n == "mq_codes_per_wg") idx->mq_codes_per_wg = (uint32_t)std::max(value, 4096.0);
+    else if (n == "mq_min_wgs") idx->mq_min_wgs = (uint32_t)std::max(value, 1.0);
+    else if (n == "mq_min_tiles") idx->mq_min_tiles = (uint32_t)std::max(value, 1.0);
     else if (n == "share_codes_per_wg") idx->share_codes_per_wg = (uint32_t)std::max(value, 4096.0);
     else if (n == "variant") idx->variant = (int)value;
     else if (n == "prescan_sample") idx->prescan_sample = (uint32_t)std::max(256.0, value);

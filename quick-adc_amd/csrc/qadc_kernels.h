@@ -109,6 +109,11 @@ void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_
                            const float* d_ftables, float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init,
                            QueryState* d_qs, hipStream_t stream);
 
+// Multi-query form: groups of up to 8 consecutive items that share codes / n / out_off / filter (one per query)
+// are evaluated in one pass; values bit-identical to launch_start_scan_f32.
+void launch_start_scan_mq(int M, const StartItem* d_items, int nitems, int wgs_per_group, const float* d_ftables, float* d_fc,
+                          uint64_t fc_stride, const uint32_t* d_fc_init, QueryState* d_qs, hipStream_t stream);
+
 // Per-block (min float ADC distance, lowest position) over a whole partition; host reduces the blocks.
 void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,
                        int blocks, hipStream_t stream);

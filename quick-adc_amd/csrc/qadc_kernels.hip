@@ -1029,6 +1029,167 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
     }
 }
 
+// Multi-query float pre-scan: the same sums for up to 8 queries in ONE pass over the starts (the float twin of
+// scan_i8_mq_kernel).  LDS row (t, half, x) = { T_q[t][x] : q = 4*half .. 4*half+3 } = 16 bytes at
+// t*512 + half*256 + x*16: two ds_read_b128 per code nibble, each conflict-free without replication (the 16 rows
+// of a (t, half) block tile the 64 banks once; equal rows broadcast).  Every query's sum is still accumulated
+// sequentially from 0 in scan_4's order (low nibble, then high nibble, byte by byte) — v_pk_add_f32 adds two
+// queries per instruction with the rounding of v_add_f32 — so the values are bit-identical to the one-query
+// kernel's.  Items of a group share codes / n / out_off / filter and differ in table / query.
+template <int M>
+__global__ __launch_bounds__(256) void start_scan_mq_kernel(const StartItem* __restrict__ items, int nitems,
+                                                            const float* __restrict__ ftables, float* __restrict__ fc,
+                                                            uint64_t fc_stride, const uint32_t* __restrict__ fc_init,
+                                                            QueryState* __restrict__ qstates) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(3))) f32x4* lds_frow_t;
+    constexpr int kStageQ = 512;                             // survivors staged in LDS per query and workgroup
+    constexpr int TAB = M * 512;
+    float* stage = reinterpret_cast<float*>(smem + TAB);                 // [8][kStageQ]
+    uint32_t* stage_n = reinterpret_cast<uint32_t*>(smem + TAB + kMQ * kStageQ * 4);   // [8]
+    uint32_t* stage_base = stage_n + kMQ;                                              // [8]
+    float* red = reinterpret_cast<float*>(stage_base + kMQ);                            // [2][8][4 waves]
+    const int first_item = (int)blockIdx.y * kMQ;
+    const int nq = min(kMQ, nitems - first_item);
+    const StartItem* __restrict__ its = items + first_item;
+    const StartItem it = its[0];
+    const uint32_t tid = threadIdx.x;
+    lds_base_is_zero();
+    if (tid < kMQ) stage_n[tid] = 0;
+    for (int e = tid; e < M * 16; e += 256) {                // e = t*16 + x
+        float row[kMQ];
+#pragma unroll
+        for (int j = 0; j < kMQ; ++j) row[j] = j < nq ? ftables[(uint64_t)its[j].table * (M * 16) + e] : 0.0f;
+        const int t = e >> 4, x = e & 15;
+        *reinterpret_cast<f32x4*>(smem + t * 512 + x * 16) = f32x4{row[0], row[1], row[2], row[3]};
+        *reinterpret_cast<f32x4*>(smem + t * 512 + 256 + x * 16) = f32x4{row[4], row[5], row[6], row[7]};
+    }
+    __syncthreads();
+    // per query: destination, threshold (phase B), sample size and capacity; absent queries never store
+    float thr[kMQ];
+#pragma unroll
+    for (int j = 0; j < kMQ; ++j) thr[j] = (j < nq && it.filter) ? qstates[its[j].query].qmax : 0.0f;
+    constexpr int DW = M / 8;
+    const uint32_t nib_mask = 0xf0u;
+    float vmin[kMQ], vmax[kMQ];
+#pragma unroll
+    for (int j = 0; j < kMQ; ++j) { vmin[j] = FLT_MAX; vmax[j] = -FLT_MAX; }
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i = blockIdx.x * 256 + tid; i < it.n; i += stride) {
+        uint32_t d[DW];
+        if constexpr (M == 16) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = ((const __attribute__((address_space(1))) u32x2*)(uintptr_t)it.codes)[i];
+            d[0] = v.x; d[1] = v.y;
+        } else {
+            const u32x4_t v = ((const __attribute__((address_space(1))) u32x4_t*)(uintptr_t)it.codes)[i];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        // scan_4<M> order: byte by byte, low nibble then high nibble, accumulated from 0 (query_common.hpp:72-80)
+        f32x2 c01 = {0.0f, 0.0f}, c23 = {0.0f, 0.0f}, c45 = {0.0f, 0.0f}, c67 = {0.0f, 0.0f};
+#pragma unroll
+        for (int w = 0; w < DW; ++w) {
+            const uint32_t dl = d[w] << 4;
+#define QADC_FMQ_ADD(off)                                                                    \
+            {                                                                                 \
+                const f32x4 lo = *reinterpret_cast<lds_frow_t>(static_cast<uintptr_t>(off));         \
+                const f32x4 hi = *reinterpret_cast<lds_frow_t>(static_cast<uintptr_t>((off) + 256)); \
+                c01 += f32x2{lo.x, lo.y};                                                     \
+                c23 += f32x2{lo.z, lo.w};                                                     \
+                c45 += f32x2{hi.x, hi.y};                                                     \
+                c67 += f32x2{hi.z, hi.w};                                                     \
+            }
+#define QADC_FMQ_BYTE(k)                                                                      \
+            {                                                                                 \
+                const int t0 = 2 * (4 * w + (k));                                             \
+                const uint32_t xl = byte_and<(k)>(dl, nib_mask), xh = byte_and<(k)>(d[w], nib_mask); \
+                QADC_FMQ_ADD(xl + t0 * 512)                                                   \
+                QADC_FMQ_ADD(xh + (t0 + 1) * 512)                                             \
+            }
+            QADC_FMQ_BYTE(0) QADC_FMQ_BYTE(1) QADC_FMQ_BYTE(2) QADC_FMQ_BYTE(3)
+#undef QADC_FMQ_BYTE
+#undef QADC_FMQ_ADD
+        }
+        const float cand[kMQ] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y};
+        if (!it.filter) {
+#pragma unroll
+            for (int j = 0; j < kMQ; ++j) {
+                if (j >= nq) continue;
+                fc[(uint64_t)its[j].query * fc_stride + it.out_off + i] = cand[j];
+                vmin[j] = fminf(vmin[j], cand[j]);
+                vmax[j] = fmaxf(vmax[j], cand[j]);
+            }
+        } else {
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < kMQ; ++j) any |= (j < nq) && (cand[j] <= thr[j]);
+            if (__builtin_expect(any, 0)) {
+                // a value above the sample's R-th smallest cannot be the R-th smallest of the whole set
+#pragma unroll
+                for (int j = 0; j < kMQ; ++j) {
+                    if (j >= nq || !(cand[j] <= thr[j])) continue;
+                    vmin[j] = fminf(vmin[j], cand[j]);
+                    vmax[j] = fmaxf(vmax[j], cand[j]);
+                    const uint32_t ls = atomicAdd(&stage_n[j], 1u);
+                    if (ls < (uint32_t)kStageQ) {
+                        stage[j * kStageQ + ls] = cand[j];
+                    } else {                                 // staging full (rare): straight to the query's buffer
+                        QueryState* qs = qstates + its[j].query;
+                        const uint32_t base_n = fc_init[2 * its[j].query], cap = fc_init[2 * its[j].query + 1];
+                        const uint32_t slot = base_n + atomicAdd(&qs->fc_n, 1u);
+                        if (slot >= cap) { atomicOr(&qs->flags, 8u); continue; }
+                        fc[(uint64_t)its[j].query * fc_stride + slot] = cand[j];
+                    }
+                }
+            }
+        }
+    }
+    // key range of each query's values (float order == key order; a sum accumulated from +0 is never -0)
+#pragma unroll
+    for (int j = 0; j < kMQ; ++j) {
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            vmin[j] = fminf(vmin[j], __shfl_xor(vmin[j], dd, 64));
+            vmax[j] = fmaxf(vmax[j], __shfl_xor(vmax[j], dd, 64));
+        }
+        if ((tid & 63) == 0) { red[j * 4 + (tid >> 6)] = vmin[j]; red[32 + j * 4 + (tid >> 6)] = vmax[j]; }
+    }
+    __syncthreads();
+    if (tid < (uint32_t)nq) {                                // one atomic set per workgroup and query
+        const int j = (int)tid;
+        const float mn = fminf(fminf(red[j * 4], red[j * 4 + 1]), fminf(red[j * 4 + 2], red[j * 4 + 3]));
+        const float mx = fmaxf(fmaxf(red[32 + j * 4], red[32 + j * 4 + 1]), fmaxf(red[32 + j * 4 + 2], red[32 + j * 4 + 3]));
+        QueryState* qs = qstates + its[j].query;
+        if (mn <= mx) {
+            atomicMax(&qs->sel_nmin, ~fkey(mn));
+            atomicMax(&qs->sel_max, fkey(mx));
+        }
+        const uint32_t ns = min(stage_n[j], (uint32_t)kStageQ);
+        if (ns) stage_base[j] = fc_init[2 * its[j].query] + atomicAdd(&qs->fc_n, ns);
+    }
+    __syncthreads();
+    for (int j = 0; j < nq; ++j) {
+        const uint32_t ns = min(stage_n[j], (uint32_t)kStageQ);
+        if (!ns) continue;
+        QueryState* qs = qstates + its[j].query;
+        const uint32_t base = stage_base[j], cap = fc_init[2 * its[j].query + 1];
+        for (uint32_t k = tid; k < ns; k += 256) {
+            if (base + k < cap) fc[(uint64_t)its[j].query * fc_stride + base + k] = stage[j * kStageQ + k];
+            else atomicOr(&qs->flags, 8u);
+        }
+    }
+}
+
+// groups of up to 8 consecutive items share codes / n / out_off / filter (the planner guarantees it)
+void launch_start_scan_mq(int M, const StartItem* d_items, int nitems, int wgs_per_group, const float* d_ftables, float* d_fc,
+                          uint64_t fc_stride, const uint32_t* d_fc_init, QueryState* d_qs, hipStream_t stream) {
+    const dim3 grid(wgs_per_group, (nitems + kMQ - 1) / kMQ), block(256);
+    const size_t lds = (size_t)M * 512 + kMQ * 512 * 4 + 2 * kMQ * 4 + 64 * 4;
+    if (M == 16) hipLaunchKernelGGL(start_scan_mq_kernel<16>, grid, block, lds, stream, d_items, nitems, d_ftables, d_fc, fc_stride, d_fc_init, d_qs);
+    else         hipLaunchKernelGGL(start_scan_mq_kernel<32>, grid, block, lds, stream, d_items, nitems, d_ftables, d_fc, fc_stride, d_fc_init, d_qs);
+}
+
 // Exact float-ADC nearest code of a partition (smallest distance, lowest position on ties):
 // the ground truth Recall@R is measured against when float ground truth over the raw vectors is
 // not available.  Same summation order as scan_4<M>.
