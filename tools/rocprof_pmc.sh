@@ -1,3 +1,4 @@
+# SQ/GRBM counters of the multi-query scan under rocprofv3 (run on the GPU box); then python tools/pmc_longest.py gpurun_out/pmc_mq scan_i8_mq
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp

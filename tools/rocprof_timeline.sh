@@ -1,3 +1,4 @@
+# Kernel timeline of pipelined batches under rocprofv3 (run on the GPU box): bash tools/rocprof_timeline.sh [codes] [queries]; then python tools/timeline.py gpurun_out/tl
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
