@@ -352,6 +352,26 @@ class Index:
         return dict(heaps=self._heaps(nq, R, keys, vals, sizes), status=status, assign=assign, keys=keys,
                     values=vals, sizes=sizes)
 
+    def search_submit(self, slot, queries, ma, R):
+        """Two-slot asynchronous form of search(): enqueue a batch, collect it later (overlaps the host replay of
+        one batch with the GPU work of the next)."""
+        q = np.ascontiguousarray(queries, np.float32)
+        self._spending = getattr(self, "_spending", {})
+        self._spending[slot] = (q, ma, R)
+        _check(lib().qadc_search_submit(self._h, slot, q.shape[0], _p(q, f32p), ma, R))
+
+    def search_collect(self, slot):
+        q, ma, R = self._spending.pop(slot)
+        nq = q.shape[0]
+        keys = np.zeros((nq, R), np.uint32)
+        vals = np.zeros((nq, R), np.int8)
+        sizes = np.zeros(nq, np.int32)
+        status = np.zeros(nq, np.int32)
+        assign = np.zeros((nq, ma), np.int32)
+        _check(lib().qadc_search_collect(self._h, slot, _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p), _p(status, i32p),
+                                         _p(assign, i32p)))
+        return dict(keys=keys, values=vals, sizes=sizes, status=status, assign=assign)
+
     def scan_i8(self, assign, qtables, R):
         assign = self._prep(assign)
         nq, ma = assign.shape

@@ -48,3 +48,20 @@ for r in range(3):
     print("search rep %d: %.2f ms/batch (%.1f us/query) -> %.3e codes/s | prescan+tables %.2f ms host asm %.2f plan %.2f heap %.2f ms "
           "cands/query %.0f" % (r, dt * 1e3, dt * 1e6 / NQ, codes / dt, p["start_ms"], p["host_replay_ms"], p["host_plan_ms"],
                                 p["host_heap_ms"], p["candidates"] / NQ), flush=True)
+
+# ---- the same, pipelined through the two slots (batch s+1 is enqueued before batch s is collected) ----
+for nqb in (256, 1024):
+    qs = [rng.normal(size=(nqb, dim)).astype(np.float32) for _ in range(4)]
+    idx.search_submit(0, qs[0], MA, R); idx.search_collect(0)
+    steps = 12
+    idx.profile_reset(); t = time.time(); pend = None; ncodes = 0
+    for s_ in range(steps):
+        idx.search_submit(s_ % 2, qs[s_ % 4], MA, R)
+        if pend is not None:
+            ncodes += sizes[idx.search_collect(pend)["assign"]].sum()
+        pend = s_ % 2
+    ncodes += sizes[idx.search_collect(pend)["assign"]].sum()
+    dt = time.time() - t; p = idx.profile()
+    print("search pipelined, %d queries per batch: %.2f ms/batch (%.2f us/query) -> %.3e codes/s | per batch: plan %.2f asm %.2f heap %.2f ms"
+          % (nqb, dt * 1e3 / steps, dt * 1e6 / steps / nqb, ncodes / dt, p["host_plan_ms"] / steps, p["host_replay_ms"] / steps,
+             p["host_heap_ms"] / steps), flush=True)
