@@ -200,47 +200,52 @@ def main():
     assign = np.zeros((NQ, 1), np.int32)
 
     def run_steps(k):
-        """k pipelined steps: batch s+1 is enqueued before batch s is collected and replayed."""
+        """k pipelined steps, three batches in flight: while batch s scans, batch s-1 is collected and replayed on the
+        host and the front of batch s+1 (upload, pre-scan, quantizer) already runs on its own stream."""
         if use_dist:
             return run_steps_dist(k)
         last = None
-        pending = None
+        pending = []
         for s in range(k):
-            tb = pool[s % len(pool)].copy()
-            idx.submit(s % 2, assign, tb, R)
-            if pending is not None:
-                last = idx.collect(pending)
-            pending = s % 2
-        if pending is not None:
-            last = idx.collect(pending)
+            idx.submit(s % 3, assign, pool[s % len(pool)].copy(), R)
+            pending.append(s % 3)
+            if len(pending) == 3:
+                last = idx.collect(pending.pop(0))
+        while pending:
+            last = idx.collect(pending.pop(0))
         return last
 
     def run_steps_dist(k):
         """Multi-rank steps.  Every rank pre-scans 1/world of the starts (the rest of the path is sharded by codes, the
-        pre-scan by starts); ONE all-gather per step carries the finished batch's candidate streams and the next
-        batch's pre-scan values; batch s runs on the GPU while batch s-1 is merged and batch s+1 is pre-scanned."""
+        pre-scan by starts); ONE all-gather per step carries the finished batch's candidate streams and the pre-scan
+        values of the batch two steps ahead: while the oldest batch in flight is merged on the host, the next one
+        scans and the one after that is pre-scanned."""
         last = None
         if k <= 0:
             return last
-        tbs = {0: pool[0].copy()}
-        idx.prescan_submit(0, assign, tbs[0], R, rank, world)
-        idx.submit(0, assign, tbs[0], R, prescan=sharded.gather_prescan(idx.prescan_collect(0), cdev))
-        for s in range(k):                                     # batch s is in flight in slot s % 2
-            nxt = s + 1 < k
+        tbs = {}
+
+        def start(b, gathered=None):                           # batch b -> slot b % 3 (its pre-scan: pre-slot b % 2)
+            if gathered is None:
+                tbs[b % 3] = pool[b % len(pool)].copy()
+                idx.prescan_submit(b % 2, assign, tbs[b % 3], R, rank, world)
+                gathered = sharded.gather_prescan(idx.prescan_collect(b % 2), cdev)
+            idx.submit(b % 3, assign, tbs[b % 3], R, prescan=gathered)
+
+        for b in range(min(2, k)):
+            start(b)
+        for i in range(k):                                     # batches i and i+1 are in flight; i is collected now
+            nxt = i + 2 < k
             if nxt:
-                tbs[(s + 1) % 2] = pool[(s + 1) % len(pool)].copy()
-                idx.prescan_submit((s + 1) % 2, assign, tbs[(s + 1) % 2], R, rank, world)
-            if s > 0:
-                res = idx.collect_candidates((s - 1) % 2)
-                pv = idx.prescan_collect((s + 1) % 2) if nxt else None
-                out = sharded.merge_batch(res, NQ, R, res["status"], cdev, extra=pv)
-                last, gathered = (out[:3], out[3]) if nxt else (out, None)
-            elif nxt:
-                gathered = sharded.gather_prescan(idx.prescan_collect((s + 1) % 2), cdev)
+                tbs[(i + 2) % 3] = pool[(i + 2) % len(pool)].copy()
+                idx.prescan_submit(i % 2, assign, tbs[(i + 2) % 3], R, rank, world)
+            res = idx.collect_candidates(i % 3)
+            pv = idx.prescan_collect(i % 2) if nxt else None
+            out = sharded.merge_batch(res, NQ, R, res["status"], cdev, extra=pv)
+            last = out[:3]
             if nxt:
-                idx.submit((s + 1) % 2, assign, tbs[(s + 1) % 2], R, prescan=gathered)
-        res = idx.collect_candidates((k - 1) % 2)
-        return sharded.merge_batch(res, NQ, R, res["status"], cdev)
+                start(i + 2, out[3])
+        return last
 
     def sync():
         if use_dist:

@@ -139,10 +139,11 @@ int qadc_scan_i8_candidates(qadc_index* idx, int nq, int ma, const int32_t* assi
  * the probed partitions (FLT_MAX when fewer than R starts). */
 int qadc_scan_start(qadc_index* idx, int nq, int ma, const int32_t* assign, const float* tables, int R, float* qmax);
 
-/* Two-slot asynchronous form of qadc_query_scan for throughput: submit enqueues all GPU work of a
- * batch on the index's stream and returns; collect waits for that batch, replays and fills the
- * outputs.  slot is 0 or 1; a slot must be collected before it is submitted again.  `tables` must
- * stay valid until collect (it is mutated then). */
+/* Asynchronous form of qadc_query_scan for throughput: submit enqueues all GPU work of a batch on the
+ * index's streams and returns; collect waits for that batch, replays and fills the outputs.  slot is
+ * 0, 1 or 2 (three batches in flight: one scanning, one being collected, one whose pre-scan front runs
+ * ahead); a slot must be collected before it is submitted again.  `tables` must stay valid until
+ * collect (it is mutated then). */
 int qadc_query_scan_submit(qadc_index* idx, int slot, int nq, int ma, const int32_t* assign, float* tables, int R);
 int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes,
                             int32_t* status, float* qmin, float* qmax, int8_t* qtables);

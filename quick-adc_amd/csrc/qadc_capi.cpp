@@ -96,6 +96,8 @@ struct Part {
     bool own = true;
 };
 
+constexpr int kSlots = 3;   // batches in flight: one scanning, one being collected, one whose front runs ahead
+
 struct LevelLaunch {
     size_t first;   // first item
     int nitems;
@@ -104,6 +106,8 @@ struct LevelLaunch {
     bool small;     // small-run kernel (runs below idx->small_run codes)
     bool shared;    // every run of the launch covers the same codes (one run per query): sibling-major launch
     bool mq;        // ... and groups of 8 of them share one pass (scan_i8_mq_kernel)
+    uint64_t maxn;  // longest run of the launch
+    bool early;     // launched on the front stream, under the previous batch's long levels: counted, not event-timed
     int ev = -1;    // index of the HIP event recorded before the launch (the next one follows it), -1 = not timed
 };
 
@@ -197,6 +201,8 @@ struct qadc_index {
     int share_variant = 0x41;            // streaming-kernel variant for shared launches: sibling-major, U=2, cached loads
     uint32_t share_codes_per_wg = 1u << 20;
     int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
+    uint64_t front_run_max = 8ull << 20; // leading levels whose runs are at most this long join the front (0 = none)
+    uint64_t front_min_batch = 10000000000ull;   // ... in batches of at least this many (code, query) pairs
     int prescan_mq = 1;                  // ... and so does the float pre-scan when every query pre-scans the same starts
     uint32_t mq_codes_per_wg = 1u << 16;
     uint32_t mq_min_wgs = 4096;          // workgroups a multi-query launch should have at least (2 rounds of the chip)
@@ -215,7 +221,7 @@ struct qadc_index {
     bool has_rotation = false;
     int K = 0;                   // coarse centroids (0 = flat)
     DevBuf<float> d_coarse;      // [K][dim]
-    Slot slot[2];
+    Slot slot[kSlots];
     Slot pre_slot[2];                   // sharded pre-scan passes (mode 1): own buffers, so that one can run
                                         // while slot[i] still holds an uncollected batch
     qadc_profile prof{};
@@ -399,6 +405,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             ll.first = off;
             ll.nitems = (int)cnt;
             ll.small = small == 1;
+            ll.maxn = maxn;
+            ll.early = false;
             ll.shared = !ll.small && same && cnt >= 2 && idx->share_variant != 0;
             ll.mq = ll.shared && idx->mq;
             if (ll.mq) {
@@ -571,36 +579,57 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         if (idx->profile) { HIPCHECK(prof_event(s, st)); HIPCHECK(prof_event(s, st)); }
     }
 
-    if (st != main_stream) {
-        if (!s.ev_front) HIPCHECK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
-        HIPCHECK(hipEventRecord(s.ev_front, st));
-        st = main_stream;
-        HIPCHECK(hipStreamWaitEvent(st, s.ev_front, 0));
-    }
     // ---- scan levels ------------------------------------------------------------------------
     // a database that fits the 256 MiB Infinity Cache is re-read from it by every query: keep the default
     // cache policy there; non-temporal loads only pay for lists that stream from HBM anyway
     uint64_t db_bytes = 0;
     for (auto& p : idx->parts) db_bytes += (uint64_t)p.n * cs;
     const int variant = db_bytes <= (200ull << 20) ? (idx->variant & ~4) : idx->variant;
+    auto launch_level = [&](LevelLaunch& ll, hipStream_t str) {
+        if (ll.small)
+            launch_scan_i8_small(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p,
+                                 s.cap_q, (uint32_t)s.R, str);
+        else if (ll.mq)
+            launch_scan_i8_mq(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q,
+                              (uint32_t)s.R, str);
+        else
+            launch_scan_i8(M, ll.shared ? idx->share_variant : (variant & ~64), s.d_items + ll.first, ll.nitems, ll.wgs,
+                           s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q, (uint32_t)s.R, str);
+    };
+    // The first levels of a batch are short launches in a dependent chain (each level's bound needs the previous
+    // levels' candidates): latency, not work.  They join the front — same stream, after the quantizer — and so run
+    // under the previous batch's long levels instead of in front of this batch's; only the long levels stay on the
+    // main stream.  (Strong scaling: on a 125M-code shard that chain is a sixth of the step.)
+    // Only for long single-GPU batches: front kernels only find room at the boundaries of the long launches, so under
+    // a short batch (a small shard), or with the multi-GPU loop's extra pre-scan pass on the same stream, the front is
+    // the critical path already and the extra launches cost more than they save (125M x 32: +2 %; 1B x 32: -1 %).
+    size_t n_early = 0;
+    uint64_t batch_codes = 0;
+    for (auto& ll : s.launches) batch_codes += ll.codes;
+    if (st != main_stream && s.mode == 0 && batch_codes >= idx->front_min_batch)
+        while (n_early < s.launches.size() && s.launches[n_early].maxn <= idx->front_run_max) ++n_early;
+    if (n_early == s.launches.size() && n_early) --n_early;        // the last level closes the batch on the main stream
+    for (size_t li = 0; li < n_early; ++li) {
+        s.launches[li].early = true;
+        s.launches[li].ev = -1;
+        launch_level(s.launches[li], st);
+    }
+    if (st != main_stream) {
+        if (!s.ev_front) HIPCHECK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(s.ev_front, st));
+        st = main_stream;
+        HIPCHECK(hipStreamWaitEvent(st, s.ev_front, 0));
+    }
     // HIP events cost ~10 us of stream time each: with profiling on, every run of consecutive streaming-kernel
     // launches (the roofline figure) shares ONE event pair; small-run launches are counted, not timed
-    for (size_t li = 0; li < s.launches.size(); ++li) {
+    for (size_t li = n_early; li < s.launches.size(); ++li) {
         LevelLaunch& ll = s.launches[li];
         const bool timed = idx->profile && !ll.small;
-        const bool group_start = timed && (li == 0 || s.launches[li - 1].small);
+        const bool group_start = timed && (li == n_early || s.launches[li - 1].small);
         const bool group_end = timed && (li + 1 == s.launches.size() || s.launches[li + 1].small);
         ll.ev = -1;
         if (group_start) { ll.ev = (int)s.prof_used; HIPCHECK(prof_event(s, st)); }
-        if (ll.small)
-            launch_scan_i8_small(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p,
-                                 s.cap_q, (uint32_t)s.R, st);
-        else if (ll.mq)
-            launch_scan_i8_mq(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q,
-                              (uint32_t)s.R, st);
-        else
-            launch_scan_i8(M, ll.shared ? idx->share_variant : (variant & ~64), s.d_items + ll.first, ll.nitems, ll.wgs,
-                           s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q, (uint32_t)s.R, st);
+        launch_level(ll, st);
         if (group_end) HIPCHECK(prof_event(s, st));
     }
     // the ordering pass runs on a side stream: it only occupies nq CUs, and the main stream is free to start the
@@ -624,13 +653,14 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
                   const int8_t* qtables, int R, int mode = 0, int slice = 0, int nslices = 1,
                   const float* inj_vals = nullptr, int inj_n = 0) {
     if (!idx) return fail(QADC_E_ARG, "null index");
-    if (slot_i < 0 || slot_i > 1) return fail(QADC_E_ARG, "slot must be 0 or 1");
+    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1 or 2");
     if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
     if (nq <= 0 || ma <= 0 || R <= 0 || !assign) return fail(QADC_E_ARG, "nq, ma, R must be > 0 and assign non-null");
     if (nq >= (1 << 24)) return fail(QADC_E_ARG, "nq must be < 2^24");
     if (ma >= (1 << 14)) return fail(QADC_E_ARG, "ma must be < 16384");
     if (!tables && !qtables) return fail(QADC_E_ARG, "tables is null");
     if (mode == 1 && (nslices < 1 || slice < 0 || slice >= nslices)) return fail(QADC_E_ARG, "need 0 <= slice < nslices");
+    if (mode == 1 && slot_i > 1) return fail(QADC_E_ARG, "pre-scan slot must be 0 or 1");
     if (mode == 2 && (!inj_vals || inj_n < 1)) return fail(QADC_E_ARG, "prescan values missing");
     Slot& s = mode == 1 ? idx->pre_slot[slot_i] : idx->slot[slot_i];
     if (s.busy) return fail(QADC_E_STATE, "slot still holds an uncollected batch");
@@ -667,7 +697,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
 // on the GPU by the main stream.
 int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int ma, int R) {
     if (!idx || !queries) return fail(QADC_E_ARG, "null argument");
-    if (slot_i < 0 || slot_i > 1) return fail(QADC_E_ARG, "slot must be 0 or 1");
+    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1 or 2");
     if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
     if (idx->dim == 0) return fail(QADC_E_STATE, "qadc_index_set_pq has not been called");
     if (nq <= 0 || ma <= 0 || R <= 0) return fail(QADC_E_ARG, "nq, ma, R must be > 0");
@@ -719,7 +749,7 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
 // kSortCap candidates) are sorted here.
 int collect_common(qadc_index* idx, int slot_i) {
     if (!idx) return fail(QADC_E_ARG, "null index");
-    if (slot_i < 0 || slot_i > 1) return fail(QADC_E_ARG, "slot must be 0 or 1");
+    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1 or 2");
     Slot& s = idx->slot[slot_i];
     if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
     if (int rc = use_device(idx)) return rc;
@@ -762,7 +792,7 @@ int collect_common(qadc_index* idx, int slot_i) {
             if (s.float_path) idx->prof.start_ms += ms;
         }
         for (auto& ll : s.launches) {
-            if (ll.small) {                                  // counted, not timed (see plan_and_launch)
+            if (ll.small || ll.early) {                      // counted, not timed (see plan_and_launch)
                 idx->prof.small_launches++;
                 idx->prof.small_codes += ll.codes;
                 continue;
@@ -916,7 +946,7 @@ int qadc_index_destroy(qadc_index* idx) {
     idx->d_codebooks.release();
     idx->d_rotation.release();
     idx->d_coarse.release();
-    Slot* all_slots[4] = {&idx->slot[0], &idx->slot[1], &idx->pre_slot[0], &idx->pre_slot[1]};
+    Slot* all_slots[kSlots + 2] = {&idx->slot[0], &idx->slot[1], &idx->slot[2], &idx->pre_slot[0], &idx->pre_slot[1]};
     for (Slot* sp : all_slots) {
         Slot& s = *sp;
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
@@ -1145,6 +1175,8 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "share_variant") idx->share_variant = (int)value;
     else if (n == "mq") idx->mq = value != 0;
     else if (n == "prescan_mq") idx->prescan_mq = value != 0;
+    else if (n == "front_run_max") idx->front_run_max = (uint64_t)std::max(value, 0.0);
+    else if (n == "front_min_batch") idx->front_min_batch = (uint64_t)std::max(value, 0.0);
     else if (n == "mq_codes_per_wg") idx->mq_codes_per_wg = (uint32_t)std::max(value, 4096.0);
     else if (n == "mq_min_wgs") idx->mq_min_wgs = (uint32_t)std::max(value, 1.0);
     else if (n == "mq_min_tiles") idx->mq_min_tiles = (uint32_t)std::max(value, 1.0);
@@ -1156,7 +1188,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
     else if (n == "profile") idx->profile = value != 0;
     else return fail(QADC_E_ARG, "unknown option: " + n);
-    if (n == "cand_capacity") idx->slot[0].cap_q = idx->slot[1].cap_q = 0;
+    if (n == "cand_capacity") idx->slot[0].cap_q = idx->slot[1].cap_q = idx->slot[2].cap_q = 0;
     return QADC_OK;
 }
 
@@ -1246,7 +1278,7 @@ static int copy_stream(Slot& s, uint64_t cand_capacity, uint32_t* cand_keys, int
 int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_capacity, uint32_t* cand_keys,
                                        int8_t* cand_vals, uint16_t* cand_slots, uint64_t* offsets, int32_t* status,
                                        float* qmin, float* qmax) {
-    if (!idx || slot < 0 || slot > 1) return fail(QADC_E_ARG, "bad arguments");
+    if (!idx || slot < 0 || slot >= kSlots) return fail(QADC_E_ARG, "bad arguments");
     Slot& s = idx->slot[slot];
     if (s.busy) {
         if (int rc = collect_common(idx, slot)) return rc;

@@ -41,7 +41,8 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
                 share_variant=int(rng.choice([0, 0x41, 0x49])), cand_capacity=int(rng.choice([64, 1024, 16384])),
                 prescan_sample=int(rng.choice([64, 4096, 65536])), level_base=int(rng.choice([64, 512, 4096])),
                 level_growth=int(rng.choice([2, 4, 8])), overlap_front=int(rng.integers(0, 2)),
-                prescan_mq=int(rng.integers(0, 2)))
+                prescan_mq=int(rng.integers(0, 2)),
+                front_run_max=int(rng.choice([0, 4096, 8 << 20])))
     for k, v in opts.items():
         idx.set_option(k, v)
     tables = float_tables(rng, nq, ma, M, scale=float(rng.choice([0.2, 1.0])))

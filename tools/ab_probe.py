@@ -16,14 +16,15 @@ cb = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
 q = rng.normal(size=(NQ, M, 1, 128 // M)).astype(np.float32)
 tables = np.ascontiguousarray(((q - cb[None]) ** 2).sum(-1).reshape(NQ, 1, M * 16), np.float32)
 assign = np.zeros((NQ, 1), np.int32)
+DEPTH = int(os.environ.get("DEPTH", 2))      # batches in flight (slots used)
 def block(k):
-    pend = None
+    pend = []
     t0 = time.perf_counter()
     for s in range(k):
-        idx.submit(s % 2, assign, tables.copy(), 100)
-        if pend is not None: idx.collect(pend)
-        pend = s % 2
-    idx.collect(pend)
+        idx.submit(s % DEPTH, assign, tables.copy(), 100)
+        pend.append(s % DEPTH)
+        if len(pend) == DEPTH: idx.collect(pend.pop(0))
+    while pend: idx.collect(pend.pop(0))
     return (time.perf_counter() - t0) * 1e3 / k
 block(50)
 res = {va: [], vb: []}

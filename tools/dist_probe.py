@@ -13,6 +13,8 @@ STEPS = int(os.environ.get("STEPS", 300)); WORLD_EMU = int(os.environ.get("WORLD
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 idx = pyqadc.Index(M); idx.add_partition_synthetic(N, 1); idx.finalize(0.01 * 1e9 / N if N < 1e9 else 0.01)
+for kv in sys.argv[1:]:
+    idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 rng = np.random.default_rng(0)
 cb = rng.normal(size=(M, 16, 8)).astype(np.float32)
 q = rng.normal(size=(NQ, M, 1, 8)).astype(np.float32)
@@ -22,26 +24,26 @@ assign = np.zeros((NQ, 1), np.int32)
 T = {k: 0.0 for k in ("prescan_submit", "collect_cand", "prescan_collect", "merge", "submit")}
 def tick(k, t0):
     T[k] += time.perf_counter() - t0
-tb = {0: tables.copy()}
-idx.prescan_submit(0, assign, tb[0], R, 0, WORLD_EMU)
-g = np.tile(idx.prescan_collect(0), (1, WORLD_EMU))
-idx.submit(0, assign, tb[0], R, prescan=g)
-t_start = None
-for s in range(STEPS):
-    if s == STEPS // 3:
+tbs = {}
+def start(b, gathered=None):
+    if gathered is None:
+        tbs[b % 3] = tables.copy()
+        idx.prescan_submit(b % 2, assign, tbs[b % 3], R, 0, WORLD_EMU)
+        gathered = np.tile(idx.prescan_collect(b % 2), (1, WORLD_EMU))
+    idx.submit(b % 3, assign, tbs[b % 3], R, prescan=gathered)
+start(0); start(1)
+t_start = None; s0 = 0
+for i in range(STEPS):
+    if i == STEPS // 3:
         for k in T: T[k] = 0.0
-        t_start = time.perf_counter(); s0 = s
-    tb[(s + 1) % 2] = tables.copy()
-    t0 = time.perf_counter(); idx.prescan_submit((s + 1) % 2, assign, tb[(s + 1) % 2], R, 0, WORLD_EMU); tick("prescan_submit", t0)
-    if s > 0:
-        t0 = time.perf_counter(); res = idx.collect_candidates((s - 1) % 2); tick("collect_cand", t0)
-        t0 = time.perf_counter(); pv = idx.prescan_collect((s + 1) % 2); tick("prescan_collect", t0)
-        t0 = time.perf_counter(); out = sharded.merge_batch(res, NQ, R, res["status"], dev, extra=pv); tick("merge", t0)
-        g = np.tile(out[3], (1, WORLD_EMU))
-    else:
-        g = np.tile(idx.prescan_collect((s + 1) % 2), (1, WORLD_EMU))
-    t0 = time.perf_counter(); idx.submit((s + 1) % 2, assign, tb[(s + 1) % 2], R, prescan=g); tick("submit", t0)
+        t_start = time.perf_counter(); s0 = i
+    tbs[(i + 2) % 3] = tables.copy()
+    t0 = time.perf_counter(); idx.prescan_submit(i % 2, assign, tbs[(i + 2) % 3], R, 0, WORLD_EMU); tick("prescan_submit", t0)
+    t0 = time.perf_counter(); res = idx.collect_candidates(i % 3); tick("collect_cand", t0)
+    t0 = time.perf_counter(); pv = idx.prescan_collect(i % 2); tick("prescan_collect", t0)
+    t0 = time.perf_counter(); out = sharded.merge_batch(res, NQ, R, res["status"], dev, extra=pv); tick("merge", t0)
+    t0 = time.perf_counter(); start(i + 2, np.tile(out[3], (1, WORLD_EMU))); tick("submit", t0)
 tot = (time.perf_counter() - t_start) * 1e3 / (STEPS - s0)
 print("per step (ms): " + ", ".join("%s %.3f" % (k, v * 1e3 / (STEPS - s0)) for k, v in T.items()) + "; loop %.3f" % tot)
-idx.collect_candidates((STEPS - 1) % 2); idx.collect_candidates(STEPS % 2)
+idx.collect_candidates(STEPS % 3); idx.collect_candidates((STEPS + 1) % 3)
 dist.destroy_process_group()
