@@ -24,11 +24,12 @@ def test_1e8_codes_against_reference_build(pyqadc, po):
     idx.add_partition_synthetic(n, SEED)
     idx.finalize(keep)
     rng = np.random.default_rng(1)
-    tables = float_tables(rng, 3, 1, M)
-    res = idx.query_scan(np.zeros((3, 1), np.int32), tables.copy(), R, want_qtables=True)
+    nq = 11                                              # two multi-query groups (8 + 3) launched as L2-sharing siblings
+    tables = float_tables(rng, nq, 1, M)
+    res = idx.query_scan(np.zeros((nq, 1), np.int32), tables.copy(), R, want_qtables=True)
     codes = po.fill_codes(0, n, SEED).reshape(n, 8)
     inter = po.ref_interleave(codes)
-    for q in range(3):
+    for q in range(nq):
         # the reference's own AVX2 kernel on the same 8-byte codes and the int8 tables the device produced
         want = po.ref_scan_interleaved(M, [inter], [n], None, res["qtables"][q], R)
         assert heaps_equal(res["heaps"][q], want), q
