@@ -186,8 +186,8 @@ struct qadc_index {
     int M = 16, cs = 8, device = 0;
     hipStream_t stream = nullptr;
     hipStream_t front_stream = nullptr; // a batch's pre-scan/quantize chain, under the previous batch's streaming launches
-    hipStream_t copy_stream = nullptr;  // late D2H of a finished batch must not queue behind the next batch
-    hipStream_t sort_stream = nullptr;  // candidate ordering + result D2H of batch s overlap the kernels of batch s+1
+    hipStream_t copy_stream = nullptr;  // uploads and on-demand copies: issued where they depend on nothing (see plan_and_launch)
+    hipStream_t sort_stream = nullptr;  // candidate ordering of batch s (stores into pinned host memory) overlaps batch s+1
     std::vector<Part> parts;
     int labeled = -1;  // -1 unknown, 0 flat, 1 labels
     bool finalized = false;
@@ -915,7 +915,7 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     idx->device = device_id;
     // The streaming launches fill every CU for milliseconds.  They go on the LOWEST-priority queue so that the
     // short work that must overlap them is dispatched as soon as a workgroup slot frees up instead of waiting for
-    // the whole batch: the previous batch's candidate sort and result copies (own streams, highest priority) and
+    // the whole batch: the previous batch's candidate sort, the next batch's front (own streams, highest priority) and
     // the caller's own streams (the RCCL gather of the multi-GPU merge).
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
