@@ -139,6 +139,13 @@ struct Slot {
     QueryOut* d_qout = nullptr;         // device-side addresses of h_qout / h_entries
     uint64_t* d_entries = nullptr;
     const int8_t* d_qt = nullptr;       // int8 tables the scan reads (d_qtables, or the uploaded ones)
+    // device-side heap replay (large batches): the ordered stream also stays in device memory, one wave per query
+    // pushes it through the reference's heap, and the host block receives [heaps u64[nq][R]][sizes u32[nq]] as well
+    bool dev_replay = false;
+    DevBuf<uint64_t> d_stream;
+    uint64_t* h_heaps = nullptr;
+    uint32_t* h_heap_sizes = nullptr;
+    bool skipped_streams = false;       // collect_common left device-replayed queries' streams unassembled
     QueryOut* h_qout = nullptr;
     uint64_t* h_entries = nullptr;
     DevBuf<float> d_ftables;            // float tables built on the device (qadc_search)
@@ -201,6 +208,7 @@ struct qadc_index {
     int share_variant = 0x41;            // streaming-kernel variant for shared launches: sibling-major, U=2, cached loads
     uint32_t share_codes_per_wg = 1u << 20;
     int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
+    int device_replay_nq = 64;           // batches of at least this many queries replay their streams on the device (0 = never)
     uint64_t front_run_max = 8ull << 20; // leading levels whose runs are at most this long join the front (0 = none)
     uint64_t front_min_batch = 10000000000ull;   // ... in batches of at least this many (code, query) pairs
     int prescan_mq = 1;                  // ... and so does the float pre-scan when every query pre-scans the same starts
@@ -477,8 +485,10 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
 
     // state block: [CandHeader, 64 B][QueryState[nq]]; result block: [QueryOut[nq]][u64 entries[out_cap]]
     const size_t state_bytes = 64 + sizeof(QueryState) * (size_t)nq;
-    const size_t result_bytes = std::max(sizeof(QueryOut) * (size_t)nq + sizeof(uint64_t) * (size_t)s.out_cap,
-                                         (sizeof(float) * (size_t)s.R + sizeof(uint32_t)) * (size_t)nq);
+    s.dev_replay = s.mode != 1 && idx->device_replay_nq > 0 && nq >= idx->device_replay_nq && s.R <= 4096;
+    const size_t off_heaps = sizeof(QueryOut) * (size_t)nq + sizeof(uint64_t) * (size_t)s.out_cap;
+    const size_t heaps_bytes = s.dev_replay ? (sizeof(uint64_t) * (size_t)s.R + sizeof(uint32_t)) * (size_t)nq : 0;
+    const size_t result_bytes = std::max(off_heaps + heaps_bytes, (sizeof(float) * (size_t)s.R + sizeof(uint32_t)) * (size_t)nq);
     HIPCHECK(s.d_state.ensure(state_bytes));
     HIPCHECK(s.h_result.ensure(result_bytes, hipHostMallocMapped | hipHostMallocCoherent));
     unsigned char* d_result = nullptr;
@@ -489,6 +499,9 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     s.d_entries = reinterpret_cast<uint64_t*>(d_result + sizeof(QueryOut) * (size_t)nq);
     s.h_qout = reinterpret_cast<QueryOut*>(s.h_result.p);
     s.h_entries = reinterpret_cast<uint64_t*>(s.h_result.p + sizeof(QueryOut) * (size_t)nq);
+    s.h_heaps = reinterpret_cast<uint64_t*>(s.h_result.p + off_heaps);
+    s.h_heap_sizes = reinterpret_cast<uint32_t*>(s.h_result.p + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
+    if (s.dev_replay) HIPCHECK(s.d_stream.ensure(s.out_cap));
     s.h_export = reinterpret_cast<float*>(s.h_result.p);
     s.h_export_flags = reinterpret_cast<uint32_t*>(s.h_result.p + sizeof(float) * (size_t)s.R * nq);
     HIPCHECK(s.d_cands.ensure((size_t)nq * s.cap_q));
@@ -641,7 +654,12 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     HIPCHECK(hipEventRecord(s.ev_scanned, main_st));
     st = idx->sort_stream;
     HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
-    launch_sort_cands(s.d_qs, s.d_cands.p, s.cap_q, nq, s.d_qout, s.d_entries, s.out_cap, s.d_hdr, st);
+    launch_sort_cands(s.d_qs, s.d_cands.p, s.cap_q, nq, s.d_qout, s.d_entries, s.out_cap, s.d_hdr, st,
+                      s.dev_replay ? s.d_stream.p : nullptr);
+    if (s.dev_replay)
+        launch_replay_heap(s.d_qs, s.d_stream.p, s.out_cap, nq, (uint32_t)s.R,
+                           reinterpret_cast<uint64_t*>(d_result + off_heaps),
+                           reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq), st);
     HIPCHECK(hipGetLastError());
 
     if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
@@ -747,7 +765,7 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
 // Waits for the batch, regrows and re-runs on overflow, and lays the ordered candidate streams
 // (padding-lane replays expanded) out in s.out_*.  Queries the device could not sort (more than
 // kSortCap candidates) are sorted here.
-int collect_common(qadc_index* idx, int slot_i) {
+int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
     if (!idx) return fail(QADC_E_ARG, "null index");
     if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1 or 2");
     Slot& s = idx->slot[slot_i];
@@ -810,10 +828,15 @@ int collect_common(qadc_index* idx, int slot_i) {
     const auto t0 = std::chrono::steady_clock::now();
     s.out_entries.clear();
     s.out_off.assign((size_t)s.nq + 1, 0);
+    s.skipped_streams = false;
     for (int q = 0; q < s.nq; ++q) {
         const QueryOut& qs = s.h_qout[q];
         s.out_off[q] = s.out_entries.size();
         idx->prof.candidates += qs.count;
+        if (!need_stream && s.dev_replay && s.h_heap_sizes[q] != 0xffffffffu) {   // heap already built on the device
+            s.skipped_streams = true;
+            continue;
+        }
         if (qs.flags & 4u) {                                  // ordered and expanded on the device
             const size_t n = (size_t)qs.count + qs.reps;
             s.out_entries.insert(s.out_entries.end(), s.h_entries + qs.out_off, s.h_entries + qs.out_off + n);
@@ -866,6 +889,16 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
             bh.reset();
             if (status && status[q]) {
                 if (sizes) sizes[q] = 0;
+                continue;
+            }
+            if (s.dev_replay && s.skipped_streams && s.h_heap_sizes[q] != 0xffffffffu) {   // replayed by replay_heap_kernel
+                const uint32_t sz = s.h_heap_sizes[q];
+                const uint64_t* hv = s.h_heaps + (size_t)q * s.R;
+                if (sizes) sizes[q] = (int32_t)sz;
+                for (uint32_t i = 0; i < sz; ++i) {
+                    if (keys) keys[(size_t)q * s.R + i] = (uint32_t)hv[i];
+                    if (values) values[(size_t)q * s.R + i] = (int8_t)(hv[i] >> 32);
+                }
                 continue;
             }
             bh.push(0, 127);  // db_query_4.cpp:276
@@ -1176,6 +1209,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "mq") idx->mq = value != 0;
     else if (n == "prescan_mq") idx->prescan_mq = value != 0;
     else if (n == "front_run_max") idx->front_run_max = (uint64_t)std::max(value, 0.0);
+    else if (n == "device_replay_nq") idx->device_replay_nq = (int)std::max(value, 0.0);
     else if (n == "front_min_batch") idx->front_min_batch = (uint64_t)std::max(value, 0.0);
     else if (n == "mq_codes_per_wg") idx->mq_codes_per_wg = (uint32_t)std::max(value, 4096.0);
     else if (n == "mq_min_wgs") idx->mq_min_wgs = (uint32_t)std::max(value, 1.0);
@@ -1256,7 +1290,7 @@ int qadc_query_scan_submit_prescanned(qadc_index* idx, int slot, int nq, int ma,
 
 int qadc_query_scan_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
                             float* qmin, float* qmax, int8_t* qtables) {
-    if (int rc = collect_common(idx, slot)) return rc;
+    if (int rc = collect_common(idx, slot, /*need_stream=*/false)) return rc;
     Slot& s = idx->slot[slot];
     std::vector<int32_t> st_local;
     if (!status) {
@@ -1524,7 +1558,7 @@ int qadc_search_submit(qadc_index* idx, int slot, int nq, const float* queries, 
 
 int qadc_search_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
                         int32_t* assign_out) {
-    if (int rc = collect_common(idx, slot)) return rc;
+    if (int rc = collect_common(idx, slot, /*need_stream=*/false)) return rc;
     Slot& s = idx->slot[slot];
     std::vector<int32_t> st_local;
     if (!status) {

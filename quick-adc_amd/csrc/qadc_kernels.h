@@ -102,7 +102,15 @@ void launch_scan_i8_small(int M, const ScanItem* d_items, int nitems, int wgs_pe
 // to the host (flags bit2 stays clear).
 // Sorted entries are written as u64 = key | value << 32 | assign slot << 40; every query gets its QueryOut record.
 void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, QueryOut* d_qout,
-                       uint64_t* d_entries, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream);
+                       uint64_t* d_entries, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream,
+                       uint64_t* d_dev_entries = nullptr);
+
+// kv_binheap<unsigned,int8_t> on the device: one wave per query replays the query's ordered stream (the copy
+// launch_sort_cands left in d_dev_entries) through a max-heap of capacity R in LDS, sentinel (0,127) first.
+// d_heaps[q][R] = key | value << 32 in heap-array order; d_heap_sizes[q] = heap size, or 0xffffffff when the
+// query was not ordered on the device (the host replays it).
+void launch_replay_heap(const QueryState* d_qs, const uint64_t* d_entries, uint32_t out_cap, int nq, uint32_t R,
+                        uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
 
 // d_fc_init[2q] = values of query q written unfiltered (phase A), d_fc_init[2q+1] = capacity of its buffer.
 void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item,

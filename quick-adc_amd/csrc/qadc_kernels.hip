@@ -708,7 +708,8 @@ __device__ __forceinline__ void write_query_out(QueryOut* __restrict__ o, const 
 __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict__ qstates, const Cand* __restrict__ cands,
                                                           uint32_t cap, int nq, QueryOut* __restrict__ qout,
                                                           uint64_t* __restrict__ out_entries, uint32_t out_cap,
-                                                          CandHeader* __restrict__ hdr) {
+                                                          CandHeader* __restrict__ hdr,
+                                                          uint64_t* __restrict__ dev_entries) {
     // all LDS in the dynamic region (keeps the 8-byte key array naturally aligned)
     uint64_t* lkey = reinterpret_cast<uint64_t*>(smem);
     uint32_t* scan = reinterpret_cast<uint32_t*>(smem + kSortCap * 8);   // [1024] + misc
@@ -811,11 +812,20 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
             const uint32_t reps = 1u + ((uint32_t)(pay >> 40) & 15u);
             for (uint32_t r = 0; r < reps; ++r, ++w) {
                 // entry = key | value << 32 | assign slot << 40
-                if (w < out_cap) out_entries[w] = (pay & 0xffffffffffull) | ((pay >> 48) << 40);
-                else atomicAdd(&hdr->out_overflow, 1u);
+                if (w < out_cap) {
+                    const uint64_t en = (pay & 0xffffffffffull) | ((pay >> 48) << 40);
+                    out_entries[w] = en;
+                    if (dev_entries) dev_entries[w] = en;        // copy in device memory for replay_heap_kernel
+                } else {
+                    atomicAdd(&hdr->out_overflow, 1u);
+                }
             }
         }
-        if (tid == 0) write_query_out(qout + q, qs, off, qs->flags | 4u);
+        if (tid == 0) {
+            write_query_out(qout + q, qs, off, qs->flags | 4u);
+            qs->out_off = off;
+            qs->flags |= 4u;
+        }
         return;
     }
 
@@ -853,20 +863,114 @@ __global__ __launch_bounds__(1024) void sort_cands_kernel(QueryState* __restrict
         const Cand c = region[lkey[i] & 0x3fffu];
         const uint32_t reps = 1u + ((c.order >> 20) & 15u);
         for (uint32_t r = 0; r < reps; ++r, ++w) {
-            if (w < out_cap) out_entries[w] = (uint64_t)c.key | ((uint64_t)(c.val & 0xffu) << 32) | ((uint64_t)(c.order & 0x3fffu) << 40);
-            else atomicAdd(&hdr->out_overflow, 1u);
+            if (w < out_cap) {
+                const uint64_t en = (uint64_t)c.key | ((uint64_t)(c.val & 0xffu) << 32) | ((uint64_t)(c.order & 0x3fffu) << 40);
+                out_entries[w] = en;
+                if (dev_entries) dev_entries[w] = en;
+            } else {
+                atomicAdd(&hdr->out_overflow, 1u);
+            }
         }
     }
-    if (tid == 0) write_query_out(qout + q, qs, off, qs->flags | 4u);
+    if (tid == 0) {
+        write_query_out(qout + q, qs, off, qs->flags | 4u);
+        qs->out_off = off;
+        qs->flags |= 4u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The reference's heap on the device (kv_binheap<unsigned,int8_t>::push, binheap.hpp:75-116): one wave per
+// query replays the query's ordered candidate stream through a binary max-heap of capacity R kept in LDS —
+// sentinel (0,127) first (db_query_4.cpp:276), then every entry in scan order.  The pushes of one query are
+// inherently sequential (lane 0 executes them; the other lanes stage the stream through LDS 64 entries at a
+// time and write the result out), but thousands of queries replay side by side, which is what an IVF batch
+// needs: the host then only copies R entries per query instead of assembling and replaying the streams.
+// Same arrays as the host replay (qadc_heap.hpp): appended and bubbled up past strictly smaller parents while
+// there is room; afterwards accepted only if strictly below the root, sinking with the left child preferred on
+// ties and stopping at a child <= the value.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void replay_heap_kernel(const QueryState* __restrict__ qstates,
+                                                         const uint64_t* __restrict__ dev_entries, uint32_t out_cap,
+                                                         uint32_t R, uint64_t* __restrict__ heaps,
+                                                         uint32_t* __restrict__ heap_sizes) {
+    uint64_t* hv = reinterpret_cast<uint64_t*>(smem);            // [R]  key | value << 32
+    uint64_t* buf = hv + R;                                      // [64] staged stream entries
+    const int q = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const QueryState* qs = qstates + q;
+    const uint32_t flags = qs->flags;
+    if (!(flags & 4u) || (uint64_t)qs->out_off + qs->count + qs->reps > out_cap) {   // not ordered on the device: host replays
+        if (lane == 0) heap_sizes[q] = 0xffffffffu;
+        return;
+    }
+    if (flags & 1u) {                                            // qmax too high: the reference exits, no result
+        if (lane == 0) heap_sizes[q] = 0;
+        return;
+    }
+    const uint32_t n = qs->count + qs->reps;
+    const uint64_t* __restrict__ src = dev_entries + qs->out_off;
+    uint32_t size = 0;                                           // meaningful on lane 0
+    auto val_of = [](uint64_t e) { return (int32_t)((e >> 32) & 0xffu); };
+    auto push = [&](uint64_t e) {
+        const int32_t value = val_of(e);
+        if (size != R) {
+            uint32_t i = size++;
+            while (i != 0) {
+                const uint32_t parent = (i - 1) / 2;
+                const uint64_t pe = hv[parent];
+                if (!(value > val_of(pe))) break;
+                hv[i] = pe;
+                i = parent;
+            }
+            hv[i] = e;
+            return;
+        }
+        if (!(value < val_of(hv[0]))) return;
+        uint32_t i = 0;
+        for (;;) {
+            const uint32_t l = 2 * i + 1;
+            if (l >= size) break;
+            uint64_t ce = hv[l];
+            uint32_t c = l;
+            if (l + 1 < size) {
+                const uint64_t re = hv[l + 1];
+                if (val_of(re) > val_of(ce)) { ce = re; c = l + 1; }
+            }
+            if (val_of(ce) <= value) break;
+            hv[i] = ce;
+            i = c;
+        }
+        hv[i] = e;
+    };
+    if (lane == 0) push((uint64_t)127 << 32);                    // the sentinel: key 0, value 127
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t m = min(64u, n - base);
+        if (lane < m) buf[lane] = src[base + lane] & 0xffffffffffull;   // key | value (assign slot dropped)
+        wave_lds_sync();
+        if (lane == 0)
+            for (uint32_t j = 0; j < m; ++j) push(buf[j]);
+        wave_lds_sync();
+    }
+    size = __shfl(size, 0, 64);
+    for (uint32_t i = lane; i < size; i += 64) heaps[(uint64_t)q * R + i] = hv[i];
+    if (lane == 0) heap_sizes[q] = size;
+}
+
+void launch_replay_heap(const QueryState* d_qs, const uint64_t* d_entries, uint32_t out_cap, int nq, uint32_t R,
+                        uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
+    hipLaunchKernelGGL(replay_heap_kernel, dim3(nq), dim3(64), (size_t)(R + 64) * 8, stream, d_qs, d_entries, out_cap, R, d_heaps,
+                       d_heap_sizes);
 }
 
 void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, QueryOut* d_qout,
-                       uint64_t* d_entries, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream) {
+                       uint64_t* d_entries, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream,
+                       uint64_t* d_dev_entries) {
     static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_cands_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 8 + 4352), true);
     (void)once;
     hipLaunchKernelGGL(sort_cands_kernel, dim3(nq), dim3(1024), kSortCap * 8 + 4352, stream, d_qs, d_cands, cap_per_query, nq,
-                       d_qout, d_entries, out_cap, d_hdr);
+                       d_qout, d_entries, out_cap, d_hdr, d_dev_entries);
 }
 
 // All candidate values (diagnostic; used by parity tests and checksums at full size).

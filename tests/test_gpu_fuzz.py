@@ -42,7 +42,7 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
                 prescan_sample=int(rng.choice([64, 4096, 65536])), level_base=int(rng.choice([64, 512, 4096])),
                 level_growth=int(rng.choice([2, 4, 8])), overlap_front=int(rng.integers(0, 2)),
                 prescan_mq=int(rng.integers(0, 2)),
-                front_run_max=int(rng.choice([0, 4096, 8 << 20])))
+                front_run_max=int(rng.choice([0, 4096, 8 << 20])), device_replay_nq=int(rng.choice([0, 1, 1])))
     for k, v in opts.items():
         idx.set_option(k, v)
     tables = float_tables(rng, nq, ma, M, scale=float(rng.choice([0.2, 1.0])))
