@@ -288,11 +288,14 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if world == 1 and os.path.exists(pmc):
             pj = json.load(open(pmc))
-            if pj.get("queries_per_step") == NQ and pj.get("codes") == N and pj.get("M") == M:
-                traffic = pj.get("bytes_per_launch")
         launches = max(prof["scan_launches"], 1)
         avg_ms = scan_ms / launches
         alg_bytes = prof["scan_codes"] * cs / launches
+        if world == 1 and os.path.exists(pmc):
+            # HBM bytes per launch = the PMC ratio (FETCH_SIZE*2 + WRITE_SIZE over algorithmic bytes, longest launch of
+            # the profiled run of this same workload) x the algorithmic bytes of this run's average timed launch
+            if pj.get("queries_per_step") == NQ and pj.get("codes") == N and pj.get("M") == M:
+                traffic = pj.get("traffic_over_algorithmic") * alg_bytes
         mq = prof["mq_launches"] > 0
         # LDS-array cycles the launches need (MI355X_MICROARCH.md, LDS): multi-query kernel = one ds_read_b128 (4 cycles
         # per 64 lanes) per code nibble and pass; single-query kernel = one ds_read_u8 (2 cycles) per code byte and query
