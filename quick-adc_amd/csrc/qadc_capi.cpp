@@ -209,7 +209,8 @@ struct qadc_index {
     uint32_t share_codes_per_wg = 1u << 20;
     int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
     int device_replay_nq = 64;           // batches of at least this many queries replay their streams on the device (0 = never)
-    uint64_t front_run_max = 8ull << 20; // leading levels whose runs are at most this long join the front (0 = none)
+    uint64_t front_run_max = 0;          // leading levels whose runs are at most this long join the front (0 = none, the default:
+                                         // -1 % at 1B x 32 with 8 Mi, but those launches then escape the event-timed roofline figure)
     uint64_t front_min_batch = 10000000000ull;   // ... in batches of at least this many (code, query) pairs
     int prescan_mq = 1;                  // ... and so does the float pre-scan when every query pre-scans the same starts
     uint32_t mq_codes_per_wg = 1u << 16;
