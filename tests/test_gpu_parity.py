@@ -738,3 +738,45 @@ def test_multi_gpu_protocol_on_virtual_ranks(pyqadc, po, M, W):
         assert heaps_equal((K[q, :S[q]], V[q, :S[q]]), (want["keys"], want["values"])), q
     for ix in ranks:
         ix.close()
+
+
+def test_pipelined_slots_with_regrows_and_changing_batch_shapes(pyqadc, po):
+    """Three batches in flight, every batch a different shape (queries, R), candidate regions far too small (every
+    batch is regrown and re-run inside collect while the others are still on the GPU): all heaps equal the oracle."""
+    rng = np.random.default_rng(123)
+    M, keep = 16, 0.02
+    sizes = [120000, 3000, 45001]
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts)
+    idx.finalize(keep)
+    idx.set_option("small_run", 8192)
+    idx.set_option("cand_capacity", 32)
+    batches = []
+    for b in range(9):
+        nq = int(rng.integers(1, 13))
+        ma = int(rng.integers(1, 4))
+        R = int(rng.choice([5, 50, 100]))
+        if b % 2 == 0:
+            assign = np.tile(rng.permutation(3)[:ma], (nq, 1)).astype(np.int32)       # shared probes: multi-query launches
+        else:
+            assign = np.stack([rng.permutation(3)[:ma] for _ in range(nq)]).astype(np.int32)
+        batches.append((assign, float_tables(rng, nq, ma, M), R))
+    pending, results = [], {}
+    for b, (assign, tables, R) in enumerate(batches):
+        idx.submit(b % 3, assign, tables.copy(), R)
+        pending.append(b)
+        if len(pending) == 3:
+            d = pending.pop(0)
+            results[d] = idx.collect(d % 3)
+    while pending:
+        d = pending.pop(0)
+        results[d] = idx.collect(d % 3)
+    assert idx.profile()["regrows"] >= len(batches)            # every batch overflowed its 32-entry regions at least once
+    for b, (assign, tables, R) in enumerate(batches):
+        r = results[b]
+        for q in range(assign.shape[0]):
+            want = po.query_scan(M, parts, None, keep, assign[q], tables[q].copy(), R)
+            n = int(r["sizes"][q])
+            assert heaps_equal((r["keys"][q, :n], r["values"][q, :n]), (want["keys"], want["values"])), (b, q)
+    idx.close()
