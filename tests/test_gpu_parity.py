@@ -772,7 +772,7 @@ def test_pipelined_slots_with_regrows_and_changing_batch_shapes(pyqadc, po):
     while pending:
         d = pending.pop(0)
         results[d] = idx.collect(d % 3)
-    assert idx.profile()["regrows"] >= len(batches)            # every batch overflowed its 32-entry regions at least once
+    assert idx.profile()["regrows"] >= 3                       # each slot outgrew its 32-entry regions at least once
     for b, (assign, tables, R) in enumerate(batches):
         r = results[b]
         for q in range(assign.shape[0]):
