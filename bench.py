@@ -218,33 +218,33 @@ def main():
     def run_steps_dist(k):
         """Multi-rank steps.  Every rank pre-scans 1/world of the starts (the rest of the path is sharded by codes, the
         pre-scan by starts); ONE all-gather per step carries the finished batch's candidate streams and the pre-scan
-        values of the batch two steps ahead: while the oldest batch in flight is merged on the host, the next one
-        scans and the one after that is pre-scanned."""
+        values of the batch two steps ahead.  Per iteration i: enqueue the sliced pre-scan of batch i+3, collect batch i,
+        gather [streams of i | pre-scan values of i+2], replay, submit batch i+2 — batches i+1 and i+2 keep the GPU
+        busy meanwhile, and a pre-scan has a whole extra batch of lead (its kernels only find room at the boundaries
+        of the long scan launches)."""
         last = None
         if k <= 0:
             return last
         tbs = {}
 
-        def start(b, gathered=None):                           # batch b -> slot b % 3 (its pre-scan: pre-slot b % 2)
-            if gathered is None:
-                tbs[b % 3] = pool[b % len(pool)].copy()
-                idx.prescan_submit(b % 2, assign, tbs[b % 3], R, rank, world)
-                gathered = sharded.gather_prescan(idx.prescan_collect(b % 2), cdev)
-            idx.submit(b % 3, assign, tbs[b % 3], R, prescan=gathered)
+        def prescan(b):                                        # batch b's sliced pre-scan -> pre-slot b % 2
+            tbs[b % 4] = pool[b % len(pool)].copy()
+            idx.prescan_submit(b % 2, assign, tbs[b % 4], R, rank, world)
 
-        for b in range(min(2, k)):
-            start(b)
+        for b in range(min(2, k)):                             # batches 0 and 1: stand-alone gathers
+            prescan(b)
+            idx.submit(b % 3, assign, tbs[b % 4], R, prescan=sharded.gather_prescan(idx.prescan_collect(b % 2), cdev))
+        if k > 2:
+            prescan(2)
         for i in range(k):                                     # batches i and i+1 are in flight; i is collected now
-            nxt = i + 2 < k
-            if nxt:
-                tbs[(i + 2) % 3] = pool[(i + 2) % len(pool)].copy()
-                idx.prescan_submit(i % 2, assign, tbs[(i + 2) % 3], R, rank, world)
+            if i + 3 < k:
+                prescan(i + 3)                                 # pre-slot (i+3) % 2: batch i+1's, collected an iteration ago
             res = idx.collect_candidates(i % 3)
-            pv = idx.prescan_collect(i % 2) if nxt else None
+            pv = idx.prescan_collect(i % 2) if i + 2 < k else None     # batch i+2's, enqueued an iteration ago
             out = sharded.merge_batch(res, NQ, R, res["status"], cdev, extra=pv)
             last = out[:3]
-            if nxt:
-                start(i + 2, out[3])
+            if i + 2 < k:
+                idx.submit((i + 2) % 3, assign, tbs[(i + 2) % 4], R, prescan=out[3])
         return last
 
     def sync():

@@ -25,25 +25,29 @@ T = {k: 0.0 for k in ("prescan_submit", "collect_cand", "prescan_collect", "merg
 def tick(k, t0):
     T[k] += time.perf_counter() - t0
 tbs = {}
-def start(b, gathered=None):
-    if gathered is None:
-        tbs[b % 3] = tables.copy()
-        idx.prescan_submit(b % 2, assign, tbs[b % 3], R, 0, WORLD_EMU)
-        gathered = np.tile(idx.prescan_collect(b % 2), (1, WORLD_EMU))
-    idx.submit(b % 3, assign, tbs[b % 3], R, prescan=gathered)
-start(0); start(1)
+def prescan(b):
+    tbs[b % 4] = tables.copy()
+    idx.prescan_submit(b % 2, assign, tbs[b % 4], R, 0, WORLD_EMU)
+for b in range(2):
+    prescan(b)
+    idx.submit(b % 3, assign, tbs[b % 4], R, prescan=np.tile(idx.prescan_collect(b % 2), (1, WORLD_EMU)))
+prescan(2)
 t_start = None; s0 = 0
 for i in range(STEPS):
     if i == STEPS // 3:
         for k in T: T[k] = 0.0
         t_start = time.perf_counter(); s0 = i
-    tbs[(i + 2) % 3] = tables.copy()
-    t0 = time.perf_counter(); idx.prescan_submit(i % 2, assign, tbs[(i + 2) % 3], R, 0, WORLD_EMU); tick("prescan_submit", t0)
+    t0 = time.perf_counter(); prescan(i + 3); tick("prescan_submit", t0)
     t0 = time.perf_counter(); res = idx.collect_candidates(i % 3); tick("collect_cand", t0)
     t0 = time.perf_counter(); pv = idx.prescan_collect(i % 2); tick("prescan_collect", t0)
     t0 = time.perf_counter(); out = sharded.merge_batch(res, NQ, R, res["status"], dev, extra=pv); tick("merge", t0)
-    t0 = time.perf_counter(); start(i + 2, np.tile(out[3], (1, WORLD_EMU))); tick("submit", t0)
+    t0 = time.perf_counter(); idx.submit((i + 2) % 3, assign, tbs[(i + 2) % 4], R, prescan=np.tile(out[3], (1, WORLD_EMU))); tick("submit", t0)
 tot = (time.perf_counter() - t_start) * 1e3 / (STEPS - s0)
 print("per step (ms): " + ", ".join("%s %.3f" % (k, v * 1e3 / (STEPS - s0)) for k, v in T.items()) + "; loop %.3f" % tot)
 idx.collect_candidates(STEPS % 3); idx.collect_candidates((STEPS + 1) % 3)
+for sl in (0, 1):
+    try:
+        idx.prescan_collect(sl)
+    except Exception:
+        pass
 dist.destroy_process_group()
