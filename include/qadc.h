@@ -89,8 +89,10 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
 /* Tunables: "quant_mode" (1 = as compiled by the reference's flags, 0 = source level), "profile" (0/1),
  * "cand_capacity" (candidate region entries per query), "level_base", "level_growth" (bound levels),
  * "prescan_sample", "small_run", "small_vec_per_wg", "wgs_per_item", "variant", "share_variant" (0 = never
- * launch the queries of a batch as L2-sharing siblings), "share_codes_per_wg", "overlap_front" (kernel and
- * launch tuning), "replay_threads". */
+ * launch the queries of a batch as L2-sharing siblings), "share_codes_per_wg", "mq" (8 queries per pass),
+ * "mq_codes_per_wg", "mq_min_wgs", "mq_min_tiles", "prescan_mq", "overlap_front", "front_run_max",
+ * "front_min_batch" (kernel and launch tuning), "device_replay_nq" (batches of at least this many queries replay
+ * their candidate streams through the heap on the device; 0 = always on the host), "replay_threads". */
 int qadc_set_option(qadc_index* idx, const char* name, double value);
 
 /* Copy codes back (tests / checksums): partition `part`, codes [first, first+count). */
