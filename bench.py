@@ -231,9 +231,12 @@ def main():
             tbs[b % 4] = pool[b % len(pool)].copy()
             idx.prescan_submit(b % 2, assign, tbs[b % 4], R, rank, world)
 
-        for b in range(min(2, k)):                             # batches 0 and 1: stand-alone gathers
+        nb = min(2, k)                                         # batches 0 and 1: one stand-alone gather for both
+        for b in range(nb):
             prescan(b)
-            idx.submit(b % 3, assign, tbs[b % 4], R, prescan=sharded.gather_prescan(idx.prescan_collect(b % 2), cdev))
+        g = sharded.gather_prescan(np.concatenate([idx.prescan_collect(b) for b in range(nb)]), cdev)
+        for b in range(nb):
+            idx.submit(b % 3, assign, tbs[b % 4], R, prescan=g[b * NQ:(b + 1) * NQ])
         if k > 2:
             prescan(2)
         for i in range(k):                                     # batches i and i+1 are in flight; i is collected now
