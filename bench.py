@@ -330,6 +330,9 @@ def main():
                           "traffic_over_algorithmic": traffic / alg_bytes},
                          # the limiter once a pass serves several queries: LDS-array cycles the lookups need over the
                          # LDS cycles available (256 CUs x 2.4 GHz x duration); the VALU pipe is equally loaded
+                         "note": "achieved = algorithmic bytes (M/2 B per code and query) / launch time; the queries of a "
+                                 "launch share the codes through L2 (8 per pass, passes as siblings), so the HBM interface "
+                                 "moves far fewer bytes (hbm_actual) and frac exceeds 1; the launch is bound by LDS bandwidth (lds)",
                          "lds": {"achieved": lds_cycles / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0,
                                  "peak": 256 * 2.4, "unit": "G LDS cycles/s", "frac": lds_frac,
                                  "code_reads_per_launch": prof["pass_codes"] / launches}},
