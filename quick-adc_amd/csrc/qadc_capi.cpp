@@ -136,6 +136,8 @@ struct Slot {
     // one result block in pinned, device-mapped HOST memory: [QueryOut[nq]][u64 entries[out_cap]].  The ordering
     // kernel stores into it directly; there is no result copy (see plan_and_launch)
     PinBuf<unsigned char> h_result;
+    unsigned char* h_result_mapped = nullptr;   // the allocation d_result_mapped was looked up for
+    unsigned char* d_result_mapped = nullptr;
     QueryOut* d_qout = nullptr;         // device-side addresses of h_qout / h_entries
     uint64_t* d_entries = nullptr;
     const int8_t* d_qt = nullptr;       // int8 tables the scan reads (d_qtables, or the uploaded ones)
@@ -492,8 +494,11 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     const size_t result_bytes = std::max(off_heaps + heaps_bytes, (sizeof(float) * (size_t)s.R + sizeof(uint32_t)) * (size_t)nq);
     HIPCHECK(s.d_state.ensure(state_bytes));
     HIPCHECK(s.h_result.ensure(result_bytes, hipHostMallocMapped | hipHostMallocCoherent));
-    unsigned char* d_result = nullptr;
-    HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_result), s.h_result.p, 0));
+    if (s.h_result.p != s.h_result_mapped) {               // (looked up once per allocation: the call costs ~0.1 ms)
+        HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.d_result_mapped), s.h_result.p, 0));
+        s.h_result_mapped = s.h_result.p;
+    }
+    unsigned char* d_result = s.d_result_mapped;
     s.d_hdr = reinterpret_cast<CandHeader*>(s.d_state.p);
     s.d_qs = reinterpret_cast<QueryState*>(s.d_state.p + 64);
     s.d_qout = reinterpret_cast<QueryOut*>(d_result);
