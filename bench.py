@@ -218,36 +218,39 @@ def main():
     def run_steps_dist(k):
         """Multi-rank steps.  Every rank pre-scans 1/world of the starts (the rest of the path is sharded by codes, the
         pre-scan by starts); ONE all-gather per step carries the finished batch's candidate streams and the pre-scan
-        values of the batch two steps ahead.  Per iteration i: enqueue the sliced pre-scan of batch i+3, collect batch i,
-        gather [streams of i | pre-scan values of i+2], replay, submit batch i+2 — batches i+1 and i+2 keep the GPU
-        busy meanwhile, and a pre-scan has a whole extra batch of lead (its kernels only find room at the boundaries
+        values of the batch three steps ahead.  Per iteration i: enqueue the sliced pre-scan of batch i+4, collect batch i,
+        gather [streams of i | pre-scan values of i+3], replay, submit batch i+3 — batches i+1 and i+2 keep the GPU
+        busy meanwhile (host jitter of a whole step is absorbed), and a pre-scan has a whole extra batch of lead (its kernels only find room at the boundaries
         of the long scan launches)."""
         last = None
         if k <= 0:
             return last
         tbs = {}
+        LEAD = 3                                               # batches in flight besides the one being collected
 
         def prescan(b):                                        # batch b's sliced pre-scan -> pre-slot b % 2
-            tbs[b % 4] = pool[b % len(pool)].copy()
-            idx.prescan_submit(b % 2, assign, tbs[b % 4], R, rank, world)
+            tbs[b % 6] = pool[b % len(pool)].copy()
+            idx.prescan_submit(b % 2, assign, tbs[b % 6], R, rank, world)
 
-        nb = min(2, k)                                         # batches 0 and 1: one stand-alone gather for both
+        nb = min(LEAD, k)                                      # the first batches: one stand-alone gather for all
+        pvs = []
         for b in range(nb):
             prescan(b)
-        g = sharded.gather_prescan(np.concatenate([idx.prescan_collect(b) for b in range(nb)]), cdev)
+            pvs.append(idx.prescan_collect(b % 2))
+        g = sharded.gather_prescan(np.concatenate(pvs), cdev)
         for b in range(nb):
-            idx.submit(b % 3, assign, tbs[b % 4], R, prescan=g[b * NQ:(b + 1) * NQ])
-        if k > 2:
-            prescan(2)
-        for i in range(k):                                     # batches i and i+1 are in flight; i is collected now
-            if i + 3 < k:
-                prescan(i + 3)                                 # pre-slot (i+3) % 2: batch i+1's, collected an iteration ago
-            res = idx.collect_candidates(i % 3)
-            pv = idx.prescan_collect(i % 2) if i + 2 < k else None     # batch i+2's, enqueued an iteration ago
+            idx.submit(b % 4, assign, tbs[b % 6], R, prescan=g[b * NQ:(b + 1) * NQ])
+        if k > LEAD:
+            prescan(LEAD)
+        for i in range(k):                                     # batches i .. i+LEAD-1 are in flight; i is collected now
+            if i + LEAD + 1 < k:
+                prescan(i + LEAD + 1)                          # pre-slot of batch i+LEAD-1, collected an iteration ago
+            res = idx.collect_candidates(i % 4)
+            pv = idx.prescan_collect((i + LEAD) % 2) if i + LEAD < k else None   # batch i+LEAD's, enqueued an iteration ago
             out = sharded.merge_batch(res, NQ, R, res["status"], cdev, extra=pv)
             last = out[:3]
-            if i + 2 < k:
-                idx.submit((i + 2) % 3, assign, tbs[(i + 2) % 4], R, prescan=out[3])
+            if i + LEAD < k:
+                idx.submit((i + LEAD) % 4, assign, tbs[(i + LEAD) % 6], R, prescan=out[3])
         return last
 
     def sync():

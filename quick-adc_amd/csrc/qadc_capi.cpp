@@ -96,7 +96,7 @@ struct Part {
     bool own = true;
 };
 
-constexpr int kSlots = 3;   // batches in flight: one scanning, one being collected, one whose front runs ahead
+constexpr int kSlots = 4;   // batches in flight: one being collected, one scanning, one or two queued behind it with their fronts running ahead
 
 struct LevelLaunch {
     size_t first;   // first item
@@ -689,7 +689,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
                   const int8_t* qtables, int R, int mode = 0, int slice = 0, int nslices = 1,
                   const float* inj_vals = nullptr, int inj_n = 0) {
     if (!idx) return fail(QADC_E_ARG, "null index");
-    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1 or 2");
+    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1, 2 or 3");
     if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
     if (nq <= 0 || ma <= 0 || R <= 0 || !assign) return fail(QADC_E_ARG, "nq, ma, R must be > 0 and assign non-null");
     if (nq >= (1 << 24)) return fail(QADC_E_ARG, "nq must be < 2^24");
@@ -733,7 +733,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
 // on the GPU by the main stream.
 int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int ma, int R) {
     if (!idx || !queries) return fail(QADC_E_ARG, "null argument");
-    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1 or 2");
+    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1, 2 or 3");
     if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
     if (idx->dim == 0) return fail(QADC_E_STATE, "qadc_index_set_pq has not been called");
     if (nq <= 0 || ma <= 0 || R <= 0) return fail(QADC_E_ARG, "nq, ma, R must be > 0");
@@ -785,7 +785,7 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
 // kSortCap candidates) are sorted here.
 int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
     if (!idx) return fail(QADC_E_ARG, "null index");
-    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1 or 2");
+    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1, 2 or 3");
     Slot& s = idx->slot[slot_i];
     if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
     if (int rc = use_device(idx)) return rc;
@@ -997,7 +997,7 @@ int qadc_index_destroy(qadc_index* idx) {
     idx->d_codebooks.release();
     idx->d_rotation.release();
     idx->d_coarse.release();
-    Slot* all_slots[kSlots + 2] = {&idx->slot[0], &idx->slot[1], &idx->slot[2], &idx->pre_slot[0], &idx->pre_slot[1]};
+    Slot* all_slots[kSlots + 2] = {&idx->slot[0], &idx->slot[1], &idx->slot[2], &idx->slot[3], &idx->pre_slot[0], &idx->pre_slot[1]};
     for (Slot* sp : all_slots) {
         Slot& s = *sp;
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
@@ -1240,7 +1240,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
     else if (n == "profile") idx->profile = value != 0;
     else return fail(QADC_E_ARG, "unknown option: " + n);
-    if (n == "cand_capacity") idx->slot[0].cap_q = idx->slot[1].cap_q = idx->slot[2].cap_q = 0;
+    if (n == "cand_capacity") for (auto& sl : idx->slot) sl.cap_q = 0;
     return QADC_OK;
 }
 

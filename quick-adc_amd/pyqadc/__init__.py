@@ -353,7 +353,7 @@ class Index:
                     values=vals, sizes=sizes)
 
     def search_submit(self, slot, queries, ma, R):
-        """Asynchronous (slot 0..2) form of search(): enqueue a batch, collect it later (overlaps the host replay of
+        """Asynchronous (slot 0..3) form of search(): enqueue a batch, collect it later (overlaps the host replay of
         one batch with the GPU work of the next)."""
         q = np.ascontiguousarray(queries, np.float32)
         self._spending = getattr(self, "_spending", {})

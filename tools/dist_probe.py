@@ -24,27 +24,32 @@ assign = np.zeros((NQ, 1), np.int32)
 T = {k: 0.0 for k in ("prescan_submit", "collect_cand", "prescan_collect", "merge", "submit")}
 def tick(k, t0):
     T[k] += time.perf_counter() - t0
+# as one of WORLD_EMU ranks: this rank replays only every WORLD_EMU-th query of the gathered streams
+_orig_merge = sharded.merge_streams_i8
+sharded.merge_streams_i8 = lambda g, world, nq, R_, cap, ma, qf, qs, *rest: _orig_merge(g, world, nq, R_, cap, ma, 0, WORLD_EMU, *rest)
+LEAD = int(os.environ.get("LEAD", 3))
 tbs = {}
 def prescan(b):
-    tbs[b % 4] = tables.copy()
-    idx.prescan_submit(b % 2, assign, tbs[b % 4], R, 0, WORLD_EMU)
-for b in range(2):
+    tbs[b % 6] = tables.copy()
+    idx.prescan_submit(b % 2, assign, tbs[b % 6], R, 0, WORLD_EMU)
+for b in range(LEAD):
     prescan(b)
-    idx.submit(b % 3, assign, tbs[b % 4], R, prescan=np.tile(idx.prescan_collect(b % 2), (1, WORLD_EMU)))
-prescan(2)
+    idx.submit(b % 4, assign, tbs[b % 6], R, prescan=np.tile(idx.prescan_collect(b % 2), (1, WORLD_EMU)))
+prescan(LEAD)
 t_start = None; s0 = 0
 for i in range(STEPS):
     if i == STEPS // 3:
         for k in T: T[k] = 0.0
         t_start = time.perf_counter(); s0 = i
-    t0 = time.perf_counter(); prescan(i + 3); tick("prescan_submit", t0)
-    t0 = time.perf_counter(); res = idx.collect_candidates(i % 3); tick("collect_cand", t0)
-    t0 = time.perf_counter(); pv = idx.prescan_collect(i % 2); tick("prescan_collect", t0)
+    t0 = time.perf_counter(); prescan(i + LEAD + 1); tick("prescan_submit", t0)
+    t0 = time.perf_counter(); res = idx.collect_candidates(i % 4); tick("collect_cand", t0)
+    t0 = time.perf_counter(); pv = idx.prescan_collect((i + LEAD) % 2); tick("prescan_collect", t0)
     t0 = time.perf_counter(); out = sharded.merge_batch(res, NQ, R, res["status"], dev, extra=pv); tick("merge", t0)
-    t0 = time.perf_counter(); idx.submit((i + 2) % 3, assign, tbs[(i + 2) % 4], R, prescan=np.tile(out[3], (1, WORLD_EMU))); tick("submit", t0)
+    t0 = time.perf_counter(); idx.submit((i + LEAD) % 4, assign, tbs[(i + LEAD) % 6], R, prescan=np.tile(out[3], (1, WORLD_EMU))); tick("submit", t0)
 tot = (time.perf_counter() - t_start) * 1e3 / (STEPS - s0)
 print("per step (ms): " + ", ".join("%s %.3f" % (k, v * 1e3 / (STEPS - s0)) for k, v in T.items()) + "; loop %.3f" % tot)
-idx.collect_candidates(STEPS % 3); idx.collect_candidates((STEPS + 1) % 3)
+for b in range(STEPS, STEPS + LEAD):
+    idx.collect_candidates(b % 4)
 for sl in (0, 1):
     try:
         idx.prescan_collect(sl)
