@@ -16,7 +16,7 @@ cb = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
 q = rng.normal(size=(NQ, M, 1, 128 // M)).astype(np.float32)
 tables = np.ascontiguousarray(((q - cb[None]) ** 2).sum(-1).reshape(NQ, 1, M * 16), np.float32)
 assign = np.zeros((NQ, 1), np.int32)
-DEPTH = int(os.environ.get("DEPTH", 2))      # batches in flight (slots used)
+DEPTH = int(os.environ.get("DEPTH", 3))      # batches in flight (slots used), as bench.py
 def block(k):
     pend = []
     t0 = time.perf_counter()
