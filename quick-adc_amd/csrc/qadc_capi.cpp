@@ -273,20 +273,28 @@ struct ScopedMs {
     ~ScopedMs() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
-int plan_and_launch(qadc_index* idx, Slot& s) {
-    ScopedMs timer(idx->prof.host_plan_ms);
+// What the planner hands to the launcher: the work items of a batch in upload order.
+struct BatchPlan {
+    std::vector<ScanItem> all_items;             // runs, grouped by bound level (Slot::launches indexes into it)
+    std::vector<StartItem> sitems_a, sitems_b;   // pre-scan: phase A = unfiltered sample, phase B = filtered remainder
+    std::vector<uint32_t> fc_init;               // per query: {sample values, capacity} of its pre-scan buffer
+    uint64_t fc_stride = 1;
+};
+
+// Host planning of one batch: cuts every query's scan order into bound levels, emits the runs (ScanItem) and the
+// pre-scan items (StartItem), and decides kernel and grid per level launch (Slot::launches).  No GPU calls.
+int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
     const int M = idx->M, cs = idx->cs, nq = s.nq, ma = s.ma;
     const uint32_t cpl = 16 / cs;
-    hipStream_t st = idx->stream;
-    const size_t table_dim = (size_t)M * 16;
-
-    // ---- plan -------------------------------------------------------------------------------
     uint64_t L[kMaxLevels + 1];
     level_bounds(idx, L);
     std::vector<std::vector<ScanItem>> per_level(kMaxLevels);
-    std::vector<StartItem> sitems_a, sitems_b;   // phase A: unfiltered sample, phase B: filtered remainder
-    std::vector<uint32_t> fc_init(2 * (size_t)nq, 0);
-    uint64_t fc_stride = 1;
+    std::vector<StartItem>& sitems_a = plan.sitems_a;
+    std::vector<StartItem>& sitems_b = plan.sitems_b;
+    std::vector<uint32_t>& fc_init = plan.fc_init;
+    uint64_t& fc_stride = plan.fc_stride;
+    fc_init.assign(2 * (size_t)nq, 0);
+    fc_stride = 1;
     s.start_codes = 0;
     for (int q = 0; q < nq; ++q) {
         uint64_t c = 0;
@@ -388,7 +396,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     }
     size_t nitems = 0;
     for (auto& v : per_level) nitems += v.size();
-    std::vector<ScanItem> all_items(nitems);
+    std::vector<ScanItem>& all_items = plan.all_items;
+    all_items.assign(nitems, ScanItem());
     s.launches.clear();
     size_t off = 0;
     const int wgs_cap = idx->wgs_per_item > 0 ? idx->wgs_per_item : (M == 16 ? 512 : 256);
@@ -459,6 +468,23 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             off += cnt;
         }
     }
+
+    return QADC_OK;
+}
+
+// Plans the batch in slot s and enqueues all of its GPU work (front, levels, ordering, optional device replay).
+int plan_and_launch(qadc_index* idx, Slot& s) {
+    ScopedMs timer(idx->prof.host_plan_ms);
+    const int M = idx->M, cs = idx->cs, nq = s.nq, ma = s.ma;
+    hipStream_t st = idx->stream;
+    const size_t table_dim = (size_t)M * 16;
+    BatchPlan plan;
+    if (int rc = plan_batch(idx, s, plan)) return rc;
+    const std::vector<ScanItem>& all_items = plan.all_items;
+    const std::vector<StartItem>&sitems_a = plan.sitems_a, &sitems_b = plan.sitems_b;
+    const std::vector<uint32_t>& fc_init = plan.fc_init;
+    uint64_t fc_stride = plan.fc_stride;
+    const size_t nitems = all_items.size();
 
     // ---- upload: ONE block, ONE copy ----------------------------------------------------------
     const size_t nt = (size_t)nq * ma * table_dim;
