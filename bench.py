@@ -2,25 +2,55 @@
 
 Workload (BASELINE.json configs[3] shape, which fits one GPU): flat database of 1B synthetic
 16x4 PQ codes (8 B/code, counter-based generator), R = 100, keep = 1 %, every query scans the
-whole list.  A step = one batch of NQ = 32 queries (the reference's documented `-b32`,
-README.md:275-330) through the whole scanner_4::query_scan path (float pre-scan of the starts ->
-qmax, quantizer, int8 scan of every code, candidate replay).  The queries of a batch are launched
-as L2-sharing siblings: the codes cross the HBM interface about once per launch, not once per query.
-With --gpus N the SAME 1B-code list is sharded over the N ranks in contiguous ranges ("strong"
-scaling; keys are 32-bit as in the reference, so the list cannot grow past 2^32 anyway) and the
-per-shard push streams are gathered once per batch over RCCL and replayed (pyqadc/sharded.py).
+whole list, through the whole scanner_4::query_scan path (float pre-scan of the starts -> qmax,
+quantizer, int8 scan of every code, candidate replay).
+
+ONE JSON line, several legs (SURVEY.md §8d keeps the two scan modes apart):
+
+* headline `value` / `ms_per_step` (the timed region of the contract): a step = one batch of
+  NQ = 32 queries (the reference's documented `-b32`, README.md:275-330) launched as L2-sharing
+  siblings, 8 queries per pass — the codes cross the HBM interface about once per LAUNCH.  That
+  mode is LDS-bound; its kernel is described by `roofline_batched` (bound "lds").
+* `roofline` (bound "hbm", frac <= 1): ONE QUERY PER PASS over the same list — what the reference's
+  scan_avx_4 does (simd_scan.hpp:125-187, one call per query at db_query_4.cpp:287-308): every
+  query streams all 8 GB from HBM by itself (scan_i8_kernel<M,2,nt,chunk>), timed with HIP events
+  on the library's stream in its own region of `single_queries` sequential queries.
+  `roofline.traffic` = HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950,
+  WRITE_SIZE; separate passes) collected IN THIS RUN by child processes that run the same
+  one-query-per-pass leg (--pmc-leg); when rocprofv3 is not available the committed per-mode
+  profile (profiles/r02_single_hbm_traffic.json) is used if its keys match, else null.
+* `roofline_32x4`: the same one-query-per-pass leg on 1B x 32x4 codes (16 B/code).
+* `ivf`: BASELINE configs[2] shape (100M codes in K=4096 labelled-free synthetic partitions, nprobe 32,
+  1024-query pipelined batches through the device-side feeders).
+* `latency_us_single_query`: synchronous single query on a 10^5-code list (README.md:327-330: 86 us).
+* `cpu_baseline`: the reference's own scan_avx_4<16> (oracle/_ref), 1 thread; `cpu_baseline_all_cores`:
+  the same kernel on every physical core (C++ threads inside oracle/_ref, pinned, per-thread copies).
+
+With --gpus N and no WORLD_SIZE in the environment the script launches its own N ranks
+(torch.distributed.run, one per GPU, RCCL) BEFORE touching the GPU and relays rank 0's line; under
+the driver's torchrun launch it is a rank.  The SAME 1B-code list is sharded over the N ranks in
+contiguous ranges ("strong" scaling; keys are 32-bit as in the reference, so the list cannot grow
+past 2^32 anyway) and the per-shard push streams are gathered once per batch and replayed.
 
     python bench.py --gpus 1 --steps 20 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  Environment overrides for quick runs: QADC_BENCH_CODES, QADC_BENCH_NQ,
-QADC_BENCH_M, QADC_BENCH_CPU_SECONDS (0 disables the CPU leg).
+Environment overrides for quick runs: QADC_BENCH_CODES, QADC_BENCH_NQ, QADC_BENCH_M,
+QADC_BENCH_CPU_SECONDS (0 disables the CPU legs), QADC_BENCH_SINGLE_QUERIES, QADC_BENCH_PMC (0 = no
+in-run PMC child passes), QADC_BENCH_IVF_CODES (0 = no IVF leg), QADC_BENCH_32X4 (0 = no 32x4 leg),
+QADC_BENCH_REAL_CODES (0 = no real-encode recall leg), QADC_BENCH_LATENCY (0 = no latency leg).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,7 +58,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "quick-adc_amd"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+LDS_PEAK_GCYC = 256 * 2.4  # LDS-array cycles per second: 256 CUs x 2.4 GHz nominal (same guide)
+R, KEEP, SEED = 100, 0.01, 0x5EED0001
 
 
 def make_tables(rng, codebooks, nq):
@@ -39,7 +71,8 @@ def make_tables(rng, codebooks, nq):
     return np.ascontiguousarray(t.reshape(nq, 1, M * 16), np.float32)
 
 
-def cpu_baseline(M, n_total, seed, qtables, R, seconds):
+# --------------------------------------------------------------------------------------------- CPU legs
+def cpu_baseline(M, n_total, qtables, seconds):
     """Times the reference's own scan_avx_4<M> (oracle/_ref, built from /root/reference) — or, if
     that build is absent, the oracle's scalar C port — on a bounded prefix of the same synthetic
     list with the same int8 tables, one thread.  Reported, never the target."""
@@ -47,7 +80,7 @@ def cpu_baseline(M, n_total, seed, qtables, R, seconds):
     import pyoracle as po
     cs = M // 2
     n = int(min(n_total, 32 * 1024 * 1024))
-    codes = po.fill_codes(0, (n * cs + 7) // 8, seed)[:n * cs].reshape(n, cs)
+    codes = po.fill_codes(0, (n * cs + 7) // 8, SEED)[:n * cs].reshape(n, cs)
     kind = "reference" if po.have_ref() else "port"
     if kind == "reference":
         inter = po.ref_interleave(codes)
@@ -60,37 +93,39 @@ def cpu_baseline(M, n_total, seed, qtables, R, seconds):
         run(qtables[nqueries % len(qtables)])
         nqueries += 1
     dt = time.perf_counter() - t0
+    model, cpus = po.host_topology()
     return {"value": n * nqueries / dt, "unit": "codes/s", "cores": 1, "kind": kind,
+            "cpu_model": model, "physical_cores_available": len(cpus),
+            "build_flags": "g++ -std=c++14 -O3 -m64 -mavx2 -mfma -mpopcnt -mbmi2 -ffast-math (the reference's "
+                           "CMakeLists.txt:7 flags with -march=native replaced by that explicit ISA set so that the "
+                           "prebuilt library runs on any AVX2 host)" if kind == "reference" else "gcc -std=c11 -O2",
             "sample": "%d queries x first %d codes of the same synthetic list, same int8 tables, R=%d, "
                       "1 thread, %s" % (nqueries, n, R, "scan_avx_4<%d> compiled from the reference" % M
                                         if kind == "reference" else "scalar C port (oracle)")}
 
 
-def cpu_extra_legs(M, n_total, seed, qtables, R, seconds):
+def cpu_extra_legs(M, n_total, qtables, seconds):
     """Two more CPU figures asked for by BASELINE.md §3 (reported, never the target):
-    - the reference's AVX2 scan on ALL host cores (one query per thread: ctypes releases the GIL);
+    - the reference's AVX2 scan on ALL physical host cores, driven from C++ inside oracle/_ref (one pinned thread
+      per physical core, each scanning its own first-touched copy of the sample, whole queries back to back);
     - BASELINE config 1, PQ 8x8 float ADC over 1M codes (scanner_simple / scan_standard<uint8_t,8>), 1 thread,
       timed with the oracle's C port."""
-    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     out = {}
     if po.have_ref():
         cs = M // 2
-        n = int(min(n_total, 32 * 1024 * 1024))
-        codes = po.fill_codes(0, (n * cs + 7) // 8, seed)[:n * cs].reshape(n, cs)
+        model, cpus = po.host_topology()
+        # per-thread sample: 8 Mi codes (64 MB for 16x4) — larger than a core's share of the caches, so every
+        # thread streams from DRAM like a 1B-code scan would; bounded so that all copies stay below ~16 GB
+        n = int(min(n_total, 8 * 1024 * 1024, (16 << 30) // (len(cpus) * cs)))
+        codes = po.fill_codes(0, (n * cs + 7) // 8, SEED)[:n * cs].reshape(n, cs)
         inter = po.ref_interleave(codes)
-        cores = os.cpu_count() or 1
-        run = lambda i: po.ref_scan_interleaved(M, [inter], [n], None, qtables[i % len(qtables)], R)
-        with ThreadPoolExecutor(cores) as ex:
-            list(ex.map(run, range(cores)))                       # warm
-            t0, done = time.perf_counter(), 0
-            while time.perf_counter() - t0 < seconds:
-                list(ex.map(run, range(4 * cores)))
-                done += 4 * cores
-            dt = time.perf_counter() - t0
-        out["cpu_baseline_all_cores"] = {"value": n * done / dt, "unit": "codes/s", "cores": cores, "kind": "reference",
-                                         "sample": "%d queries x first %d codes, one query per thread" % (done, n)}
+        done, dt = po.ref_scan_mt(M, inter, n, qtables, R, cpus, seconds)
+        out["cpu_baseline_all_cores"] = {
+            "value": n * done / dt, "unit": "codes/s", "cores": len(cpus), "kind": "reference", "cpu_model": model,
+            "sample": "%d whole queries x %d codes in %.1f s: one pinned C++ thread per physical core (%d), each with "
+                      "its own first-touched copy of the first %d codes of the list" % (done, n, dt, len(cpus), n)}
     rng = np.random.default_rng(5)
     codes8 = rng.integers(0, 256, (1000000, 8), dtype=np.uint8)
     tables8 = rng.random((1, 8, 256)).astype(np.float32)
@@ -105,10 +140,14 @@ def cpu_extra_legs(M, n_total, seed, qtables, R, seconds):
     return out
 
 
-def real_encode_recall(M, R, keep, n, nq, local_rank):
+# --------------------------------------------------------------------------------------------- recall on real encodings
+def real_encode_recall(M, n, nq, local_rank):
     """Recall@R on REAL encodings (SURVEY.md §8d "real-encode variant"): clustered synthetic 128-d vectors,
     codebooks = sampled sub-vectors, PQ-encoded on the GPU (qadc_pq_encode), queried through the device-side
-    feeders (qadc_search); ground truth = exact float L2 nearest neighbour (torch, chunked).  Untimed."""
+    feeders (qadc_search); ground truth = exact float L2 nearest neighbour (torch, chunked).  Untimed.
+    The same queries also go through the host-table entry point and the resulting int8 tables are handed to the
+    reference's own scan_avx_4 (oracle/_ref) over the same codes: `reference_heaps_equal` says whether the
+    reference kernel ends with the same heaps — i.e. whether this recall IS the reference path's recall."""
     import torch
     import pyqadc
     dev = torch.device("cuda", local_rank)
@@ -136,14 +175,259 @@ def real_encode_recall(M, R, keep, n, nq, local_rank):
     torch.cuda.synchronize()
     idx = pyqadc.Index(M, local_rank)
     idx.add_partition_device(raw.data_ptr(), n, keepalive=raw)
-    idx.finalize(keep)
+    idx.finalize(KEEP)
     idx.set_pq(cb_host)
-    res = idx.search(queries.cpu().numpy(), 1, R)
+    qh = queries.cpu().numpy()
+    res = idx.search(qh, 1, R)
     hits = sum(int(gt[q] in set(res["keys"][q][:res["sizes"][q]].tolist())) for q in range(nq))
+    out = {"value": hits / nq, "codes": n, "queries": nq,
+           "data": "synthetic 128-d vectors, %d clusters (3*N(0,1) centres + N(0,1)), codebooks = sampled sub-vectors, PQ %dx4 "
+                   "encoded on the GPU; ground truth = exact float L2 NN" % (C, M)}
+    # the reference kernel on the same codes with the same int8 tables (CPU, bounded: n codes x nq queries)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    if po.have_ref() and float(os.environ.get("QADC_BENCH_CPU_SECONDS", 15)) > 0:
+        tables = np.ascontiguousarray(((qh.reshape(nq, M, 1, ds) - cb_host[None]) ** 2).sum(-1, dtype=np.float32)
+                                      .reshape(nq, 1, M * 16), np.float32)
+        r2 = idx.query_scan(np.zeros((nq, 1), np.int32), tables, R, want_qtables=True)
+        codes_h = raw[:n * cs].cpu().numpy().reshape(n, cs)
+        inter = po.ref_interleave(codes_h)
+        same, hits_ref = 0, 0
+        for q in range(nq):
+            k, v = po.ref_scan_interleaved(M, [inter], [n], None, r2["qtables"][q], R)
+            same += int(np.array_equal(k, r2["heaps"][q][0]) and np.array_equal(v, r2["heaps"][q][1]))
+            hits_ref += int(gt[q] in set(k.tolist()))
+        out["reference_heaps_equal"] = "%d/%d" % (same, nq)
+        out["reference_recall_at_100"] = hits_ref / nq
+        out["reference_note"] = ("the reference's scan_avx_4<%d> (oracle/_ref) run on the same codes with this engine's int8 "
+                                 "tables of the host-table entry point; heaps compared array for array" % M)
     idx.close()
-    return {"value": hits / nq, "codes": n, "queries": nq,
-            "data": "synthetic 128-d vectors, %d clusters (3*N(0,1) centres + N(0,1)), codebooks = sampled sub-vectors, PQ %dx4 "
-                    "encoded on the GPU; ground truth = exact float L2 NN" % (C, M)}
+    return out
+
+
+# --------------------------------------------------------------------------------------------- HBM traffic (PMC)
+def under_profiler():
+    return any(("rocprof" in (os.environ.get(k) or "").lower()) for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIB")) \
+        or any(k.startswith("ROCPROF") for k in os.environ)
+
+
+def pmc_leg_main():
+    """Child process of the in-run PMC passes (runs under `rocprofv3 --pmc ...`): the one-query-per-pass leg only,
+    a few queries, no torch.  Prints the profile counters it needs as one JSON line."""
+    import pyqadc
+    M = int(os.environ.get("QADC_BENCH_M", 16))
+    N = int(float(os.environ.get("QADC_BENCH_CODES", 1e9)))
+    idx = pyqadc.Index(M, 0)
+    idx.add_partition_synthetic_shard(N, 0, N, SEED, max(1, int(np.float32(N) * np.float32(KEEP))))
+    idx.finalize(KEEP)
+    idx.set_option("profile", 1)
+    rng = np.random.default_rng(1234)
+    codebooks = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
+    tb = make_tables(rng, codebooks, 4)
+    a1 = np.zeros((1, 1), np.int32)
+    for q in range(3):
+        idx.query_scan(a1, tb[q:q + 1].copy(), R)
+    p = idx.profile()
+    print(json.dumps({"pmc_leg": True, "scan_launches": p["scan_launches"], "scan_codes": p["scan_codes"]}), flush=True)
+    idx.close()
+
+
+def pmc_traffic_in_run(M, N):
+    """Runs the one-query-per-pass leg twice under rocprofv3 (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass,
+    MI355X_MICROARCH.md "rocprofv3 PMC slots") and returns HBM bytes per scan_i8_kernel launch, or (None, reason).
+    FETCH_SIZE is in KB and counts half of a 16-B/lane streaming read on gfx950 (same guide, "HBM"): x 1024 x 2."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    if under_profiler():
+        return None, "bench.py itself runs under a profiler"
+    tmp = tempfile.mkdtemp(prefix="qadc_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp", QADC_BENCH_M=str(M), QADC_BENCH_CODES=str(N))
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-leg"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode()[-300:])
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                name = row["Kernel_Name"]
+                if "scan_i8_kernel" in name and row["Counter_Name"] == counter:
+                    per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None, "no scan_i8_kernel dispatch in the %s pass" % counter
+            got[counter] = (sum(per.values()), len(per))
+    except Exception as e:  # noqa: BLE001 — the PMC leg is optional evidence, never fatal
+        return None, "in-run PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    (fk, fl), (wk, wl) = got["FETCH_SIZE"], got["WRITE_SIZE"]
+    return {"bytes_per_launch": fk * 1024 * 2 / fl + wk * 1024 / wl, "launches": fl,
+            "fetch_kb_total": fk, "write_kb_total": wk}, "in-run rocprofv3 --pmc passes"
+
+
+def pmc_traffic_from_profiles(M, N, alg_bytes_per_launch):
+    """Fallback: the committed one-query-per-pass PMC profile, only if it was taken on exactly this mode/config."""
+    f = os.path.join(ROOT, "profiles", "r02_single_hbm_traffic.json")
+    if not os.path.exists(f):
+        return None, "no in-run PMC pass and no committed profile"
+    pj = json.load(open(f))
+    if pj.get("mode") != "single" or pj.get("codes") != N or pj.get("M") != M:
+        return None, "committed PMC profile is for another mode/config (%s, %s codes, M=%s)" % (
+            pj.get("mode"), pj.get("codes"), pj.get("M"))
+    return pj["traffic_over_algorithmic"] * alg_bytes_per_launch, "profiles/r02_single_hbm_traffic.json (ratio x this run's bytes)"
+
+
+# --------------------------------------------------------------------------------------------- GPU side legs
+def single_query_leg(idx, M, N, pool, nqueries):
+    """ONE query per pass (the reference's mode): `nqueries` sequential single-query batches, three in flight.
+    Returns the HIP-event profile of the streaming launches and the wall-clock rate."""
+    import torch
+    a1 = np.zeros((1, 1), np.int32)
+    tabs = [pool[i % len(pool)][j:j + 1].copy() for i in range(2) for j in range(pool[0].shape[0])]
+
+    def run(k):
+        pend = []
+        for s in range(k):
+            idx.submit(s % 3, a1, tabs[s % len(tabs)].copy(), R)
+            pend.append(s % 3)
+            if len(pend) == 3:
+                idx.collect(pend.pop(0))
+        while pend:
+            idx.collect(pend.pop(0))
+
+    run(3)
+    idx.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(nqueries)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return idx.profile(), dt
+
+
+def roofline_single(M, N, prof, dt, nqueries, traffic, traffic_src):
+    cs = M // 2
+    scan_ms = prof["scan_ms"]
+    launches = max(prof["scan_launches"], 1)
+    alg = prof["scan_codes"] * cs / launches
+    achieved = prof["scan_codes"] * cs / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_over_algorithmic": None if traffic is None else traffic / alg,
+            "kernel": "scan_i8_kernel<%d,2,nt,chunk>" % M,
+            "mode": "one query per pass over the whole list (simd_scan.hpp:125-187 called once per query, "
+                    "db_query_4.cpp:287-308): every query streams the list from HBM by itself",
+            "timed_region": "%d sequential single-query batches (three in flight), HIP events around every run of "
+                            "consecutive streaming launches on the library's stream" % nqueries,
+            "launches": prof["scan_launches"], "avg_launch_ms": scan_ms / launches,
+            "algorithmic_bytes_per_launch": alg,
+            "algorithmic_bytes_rule": "%d B per (code, query) (SURVEY.md 8d) x codes of the launch's bound level" % cs,
+            "codes_per_sec_wall": float(N) * nqueries / dt, "ms_per_query_wall": dt * 1e3 / nqueries,
+            "small_run_codes_not_event_timed": prof["small_codes"]}
+
+
+def ivf_leg(local_rank):
+    """BASELINE configs[2] shape: 100M x 16x4 codes in K = 4096 ragged partitions, nprobe 32, R = 100, queries in
+    (coarse assignment, residual tables, pre-scan, quantizer, scan, heap all on the GPU), 1024-query batches pipelined."""
+    import pyqadc
+    M, K, MA, NQB, dim = 16, 4096, 32, 1024, 128
+    N = int(float(os.environ.get("QADC_BENCH_IVF_CODES", 1e8)))
+    rng = np.random.default_rng(0)
+    sizes = rng.multinomial(N, np.ones(K) / K)
+    idx = pyqadc.Index(M, local_rank)
+    for p in range(K):
+        idx.add_partition_synthetic(int(sizes[p]), 1000 + p)
+    idx.finalize(KEEP)
+    cb = rng.normal(size=(M, 16, dim // M)).astype(np.float32)
+    coarse = rng.normal(size=(K, dim)).astype(np.float32)
+    idx.set_pq(cb)
+    idx.set_coarse(coarse)
+    qs = [rng.normal(size=(NQB, dim)).astype(np.float32) for _ in range(4)]
+    for w in range(2):
+        idx.search_submit(w, qs[w], MA, R)
+    for w in range(2):
+        idx.search_collect(w)
+    steps, depth = 16, 3
+    idx.profile_reset()
+    t0 = time.perf_counter()
+    pend, ncodes = [], 0
+    for s in range(steps):
+        idx.search_submit(s % depth, qs[s % 4], MA, R)
+        pend.append(s % depth)
+        if len(pend) == depth:
+            ncodes += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
+    while pend:
+        ncodes += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
+    dt = time.perf_counter() - t0
+    p = idx.profile()
+    idx.close()
+    gbs = ncodes * (M // 2) / dt / 1e9
+    return {"workload": "IVF, %d x 16x4 codes in K=%d partitions (multinomial sizes), nprobe=%d, R=%d, keep=%.0f%%, "
+                        "%d-query batches, %d in flight, queries in -> heaps out (qadc_search)" % (N, K, MA, R, KEEP * 100, NQB, depth),
+            "codes_per_sec": ncodes / dt, "us_per_query": dt * 1e6 / (steps * NQB), "queries_per_sec": steps * NQB / dt,
+            "probed_codes_per_query": ncodes / (steps * NQB),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "rule": "8 B x probed codes / wall time of the pipelined batches (whole path, not one kernel)"},
+            "host_ms_per_batch": {"plan": p["host_plan_ms"] / steps, "stream_assembly": p["host_replay_ms"] / steps,
+                                  "heap": p["host_heap_ms"] / steps}}
+
+
+def latency_leg(local_rank):
+    """Synchronous single query (nq = 1) on a 10^5-code flat list: the reference's only published Quick-ADC point is
+    86 us of scan time on ~93 750 probed codes, one CPU thread (README.md:327-330)."""
+    import pyqadc
+    M, n = 16, 100000
+    idx = pyqadc.Index(M, local_rank)
+    idx.add_partition_synthetic(n, 1)
+    idx.finalize(KEEP)
+    rng = np.random.default_rng(0)
+    cb = rng.normal(size=(M, 16, 8)).astype(np.float32)
+    tb = make_tables(rng, cb, 1)
+    a = np.zeros((1, 1), np.int32)
+    for _ in range(20):
+        idx.query_scan(a, tb.copy(), R)
+    ts = []
+    for _ in range(200):
+        t = tb.copy()
+        t0 = time.perf_counter()
+        idx.query_scan(a, t, R)
+        ts.append(time.perf_counter() - t0)
+    idx.close()
+    ts = np.sort(np.array(ts)) * 1e6
+    return {"value": float(np.median(ts)), "p10": float(ts[len(ts) // 10]), "p90": float(ts[len(ts) * 9 // 10]),
+            "unit": "us", "codes": n, "note": "synchronous qadc_query_scan, nq=1, R=100, keep=1%, float tables in -> heap out "
+            "(host call to host return, through ctypes)"}
+
+
+# --------------------------------------------------------------------------------------------- launcher
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves — as CHILD processes, from a parent
+    that never touches the GPU (no exec of a GPU-initialised process) — and relay rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None)
+    line = None
+    for raw in proc.stdout:
+        txt = raw.decode(errors="replace")
+        if txt.startswith("{") and line is None:
+            line = txt.strip()
+        else:
+            sys.stderr.write(txt)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        raise SystemExit("bench.py: the %d-rank launch failed (exit code %d)" % (args.gpus, rc))
+    print(line, flush=True)
 
 
 def main():
@@ -151,16 +435,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pmc-leg", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_leg:
+        return pmc_leg_main()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or omit the launcher and let "
+                         "bench.py start the ranks itself)" % (args.gpus, world))
     M = int(os.environ.get("QADC_BENCH_M", 16))
     N = int(float(os.environ.get("QADC_BENCH_CODES", 1e9)))
     NQ = int(os.environ.get("QADC_BENCH_NQ", 32))
-    R, KEEP, SEED = 100, 0.01, 0x5EED0001
     cs = M // 2
+    backend = os.environ.get("QADC_BENCH_BACKEND", "nccl")
+
+    # ---- in-run HBM traffic of the one-query-per-pass mode: child processes under rocprofv3, BEFORE this process
+    # touches the GPU (single rank only) ----
+    pmc, pmc_src = None, "skipped"
+    if world == 1 and os.environ.get("QADC_BENCH_PMC", "1") != "0" and not os.environ.get("QADC_BENCH_FORCE_DIST"):
+        pmc, pmc_src = pmc_traffic_in_run(M, N)
 
     import torch
     import torch.distributed as dist
@@ -170,7 +468,6 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Quick-ADC engine has no CPU path")
     # test hooks (not used by the driver): run the multi-rank path on a 1-GPU box over gloo
-    backend = os.environ.get("QADC_BENCH_BACKEND", "nccl")
     if os.environ.get("QADC_BENCH_ONE_GPU"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -183,6 +480,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
     # ---- database: this rank's contiguous shard of the synthetic list + replica of the starts ----
     first, local_n = sharded.shard_ranges(N, world)[rank]
@@ -220,8 +519,8 @@ def main():
         pre-scan by starts); ONE all-gather per step carries the finished batch's candidate streams and the pre-scan
         values of the batch three steps ahead.  Per iteration i: enqueue the sliced pre-scan of batch i+4, collect batch i,
         gather [streams of i | pre-scan values of i+3], replay, submit batch i+3 — batches i+1 and i+2 keep the GPU
-        busy meanwhile (host jitter of a whole step is absorbed), and a pre-scan has a whole extra batch of lead (its kernels only find room at the boundaries
-        of the long scan launches)."""
+        busy meanwhile (host jitter of a whole step is absorbed), and a pre-scan has a whole extra batch of lead (its
+        kernels only find room at the boundaries of the long scan launches)."""
         last = None
         if k <= 0:
             return last
@@ -286,74 +585,102 @@ def main():
         hits += int(key in set(keys[q].tolist()))
     recall = hits / NQ
 
+    # ---- the one-query-per-pass leg (SURVEY.md §8d roofline), single rank only ----
+    single = None
+    if world == 1 and not use_dist:
+        nsingle = int(os.environ.get("QADC_BENCH_SINGLE_QUERIES", 64))
+        if nsingle > 0:
+            sprof, sdt = single_query_leg(idx, M, N, pool, nsingle)
+            alg = sprof["scan_codes"] * cs / max(sprof["scan_launches"], 1)
+            if pmc is not None:
+                traffic, tsrc = pmc["bytes_per_launch"], pmc_src
+            else:
+                traffic, tsrc2 = pmc_traffic_from_profiles(M, N, alg)
+                tsrc = "%s; %s" % (pmc_src, tsrc2)
+            single = roofline_single(M, N, sprof, sdt, nsingle, traffic, tsrc)
+            if pmc is not None:
+                single["pmc"] = pmc
+
     if rank == 0:
         total_codes = float(N) * NQ * args.steps
         scan_ms = prof["scan_ms"]
-        achieved = prof["scan_codes"] * cs / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if world == 1 and os.path.exists(pmc):
-            pj = json.load(open(pmc))
         launches = max(prof["scan_launches"], 1)
         avg_ms = scan_ms / launches
         alg_bytes = prof["scan_codes"] * cs / launches
-        if world == 1 and os.path.exists(pmc):
-            # HBM bytes per launch = the PMC ratio (FETCH_SIZE*2 + WRITE_SIZE over algorithmic bytes, longest launch of
-            # the profiled run of this same workload) x the algorithmic bytes of this run's average timed launch
-            if pj.get("queries_per_step") == NQ and pj.get("codes") == N and pj.get("M") == M:
-                traffic = pj.get("traffic_over_algorithmic") * alg_bytes
         mq = prof["mq_launches"] > 0
         # LDS-array cycles the launches need (MI355X_MICROARCH.md, LDS): multi-query kernel = one ds_read_b128 (4 cycles
         # per 64 lanes) per code nibble and pass; single-query kernel = one ds_read_u8 (2 cycles) per code byte and query
         lds_cycles = prof["pass_codes"] * (M * 4 if mq else (M // 2) * 2) / 64.0
-        lds_frac = lds_cycles / (256 * 2.4e9 * scan_ms * 1e-3) if scan_ms > 0 else 0.0
+        lds_rate = lds_cycles / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        batched = {
+            "bound": "lds", "achieved": lds_rate, "peak": LDS_PEAK_GCYC, "unit": "G LDS-array cycles/s",
+            "frac": lds_rate / LDS_PEAK_GCYC,
+            "kernel": ("scan_i8_mq_kernel<%d,2> (8 queries per pass, %d passes per launch as L2-sharing siblings)"
+                       % (M, (NQ + 7) // 8)) if mq else "scan_i8_kernel<%d,2> (sibling-major launch)" % M,
+            "mode": "the headline's timed region: %d queries per step share every pass over the codes" % NQ,
+            "launches": prof["scan_launches"], "avg_launch_ms": avg_ms,
+            "lds_cycles_rule": "code reads of the launch x %d lookups x %d LDS cycles / 64 lanes "
+                               "(MI355X_MICROARCH.md LDS table); peak = 256 CUs x 2.4 GHz nominal — the PMC passes in "
+                               "profiles/ measure an effective clock of ~1.9-2.1 GHz under this load, i.e. the pipe is "
+                               "busier than frac says" % ((M, 4) if mq else (M // 2, 2)),
+            "code_reads_per_launch": prof["pass_codes"] / launches,
+            "pair_rate": {"value": prof["scan_codes"] / (scan_ms * 1e-3) if scan_ms > 0 else 0.0,
+                          "unit": "(code, query) pairs/s inside the timed launches"},
+            "hbm_note": "the queries of a launch share the codes through L2, so the HBM interface moves about 1/%d of "
+                        "%d B x (code, query) — see profiles/r02_batched_hbm_traffic.json; this mode is NOT priced "
+                        "against the HBM roofline (SURVEY.md 8d)" % (NQ, cs)}
         out = {
             "metric": "pq_codes_scanned_per_sec", "value": total_codes / elapsed, "unit": "codes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-            "config": {"workload": "flat DB, %d x %dx4 PQ codes (%d B/code), R=%d, keep=%.2f%%, %d queries/step, "
-                                   "every query scans the whole list, sharded over %d GPU(s)" % (N, M, cs, R, KEEP * 100, NQ, world),
+            "config": {"workload": "flat DB, %d x %dx4 PQ codes (%d B/code), R=%d, keep=%.2f%%, sharded over %d GPU(s). "
+                                   "`value` = %d queries/step, every query scans the whole list, 8 queries per pass "
+                                   "(LDS-bound: `roofline_batched`).  `roofline` = the SAME list scanned ONE query per "
+                                   "pass (the reference's mode, HBM-bound), timed in its own region of this run"
+                                   % (N, M, cs, R, KEEP * 100, world, NQ),
                        "codes": N, "M": M, "R": R, "keep": KEEP, "queries_per_step": NQ,
                        "parallelism": "shard%d" % world},
             "recall_at_100": recall,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("scan_i8_mq_kernel<%d,2> (8 queries per pass, %d passes per launch as L2-sharing siblings)"
-                                    % (M, (NQ + 7) // 8)) if mq else
-                                   ("scan_i8_kernel<%d,2> (sibling-major launch, %d queries share each tile)" % (M, NQ)
-                                    if NQ > 1 else "scan_i8_kernel<%d,2,nt,chunk>" % M),
-                         "launches": prof["scan_launches"], "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         # what actually crossed the HBM interface (PMC pass, profiles/): below the algorithmic
-                         # bytes because the queries of a launch share tiles in L2 -- which is why frac can exceed 1
-                         "hbm_actual": None if traffic is None else
-                         {"achieved": traffic / (avg_ms * 1e-3) / 1e9, "unit": "GB/s",
-                          "frac": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "traffic_over_algorithmic": traffic / alg_bytes},
-                         # the limiter once a pass serves several queries: LDS-array cycles the lookups need over the
-                         # LDS cycles available (256 CUs x 2.4 GHz x duration); the VALU pipe is equally loaded
-                         "note": "achieved = algorithmic bytes (M/2 B per code and query) / launch time; the queries of a "
-                                 "launch share the codes through L2 (8 per pass, passes as siblings), so the HBM interface "
-                                 "moves far fewer bytes (hbm_actual) and frac exceeds 1; the launch is bound by LDS bandwidth (lds)",
-                         "lds": {"achieved": lds_cycles / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0,
-                                 "peak": 256 * 2.4, "unit": "G LDS cycles/s", "frac": lds_frac,
-                                 "code_reads_per_launch": prof["pass_codes"] / launches}},
+            "roofline": single if single is not None else
+            {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+             "note": "the one-query-per-pass leg runs on a single rank only (N=1 line)"},
+            "roofline_batched": batched,
             "phases": {"prescan_quantize_ms_per_step": prof["start_ms"] / args.steps,
                        "scan_kernel_ms_per_step": scan_ms / args.steps,
                        "host_sort_replay_ms_per_step": prof["host_replay_ms"] / args.steps,
                        "candidates_per_query": prof["candidates"] / (NQ * args.steps), "regrows": prof["regrows"]},
         }
-        n_real = int(float(os.environ.get("QADC_BENCH_REAL_CODES", 1e7)))
-        if world == 1 and n_real > 0:
-            out["recall_at_100_real_encode"] = real_encode_recall(M, R, KEEP, n_real, 64, local_rank)
-        cpu_s = float(os.environ.get("QADC_BENCH_CPU_SECONDS", 15))
-        if world == 1 and cpu_s > 0:
-            res = idx.query_scan(assign, pool[0].copy(), R, want_qtables=True)
-            out["cpu_baseline"] = cpu_baseline(M, N, SEED, res["qtables"][:, 0], R, cpu_s)
-            out.update(cpu_extra_legs(M, N, SEED, res["qtables"][:, 0], R, min(cpu_s, 6.0)))
-        print(json.dumps(out), flush=True)
+    cpu_s = float(os.environ.get("QADC_BENCH_CPU_SECONDS", 15))
+    if rank == 0 and world == 1 and not use_dist and cpu_s > 0:
+        # the int8 tables of one bench batch, for the CPU legs (same tables on both sides)
+        qt_cpu = idx.query_scan(assign, pool[0].copy(), R, want_qtables=True)["qtables"][:, 0]
     idx.close()
+    if rank == 0 and world == 1 and not use_dist:
+        torch.cuda.synchronize()
+        if os.environ.get("QADC_BENCH_32X4", "1") != "0" and M == 16:
+            i32 = pyqadc.Index(32, local_rank)
+            i32.add_partition_synthetic_shard(N, 0, N, SEED, starts)
+            i32.finalize(KEEP)
+            i32.set_option("profile", 1)
+            cb32 = rng.normal(size=(32, 16, 4)).astype(np.float32)
+            pool32 = [make_tables(rng, cb32, 8)]
+            p32, dt32 = single_query_leg(i32, 32, N, pool32, 24)
+            out["roofline_32x4"] = roofline_single(32, N, p32, dt32, 24, None, "not collected for this leg")
+            i32.close()
+        if int(float(os.environ.get("QADC_BENCH_IVF_CODES", 1e8))) > 0:
+            out["ivf"] = ivf_leg(local_rank)
+        if os.environ.get("QADC_BENCH_LATENCY", "1") != "0":
+            out["latency_us_single_query"] = latency_leg(local_rank)
+        n_real = int(float(os.environ.get("QADC_BENCH_REAL_CODES", 1e7)))
+        if n_real > 0:
+            out["recall_at_100_real_encode"] = real_encode_recall(M, n_real, 64, local_rank)
+        if cpu_s > 0:
+            out["cpu_baseline"] = cpu_baseline(M, N, qt_cpu, cpu_s)
+            out.update(cpu_extra_legs(M, N, qt_cpu, min(cpu_s, 6.0)))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

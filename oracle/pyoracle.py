@@ -273,6 +273,42 @@ def ref_scan_interleaved(M, inter_parts, sizes, labels, qtables, R, sentinel=Tru
     return ok[:osz.value].copy(), ov[:osz.value].copy()
 
 
+def host_topology():
+    """(cpu model, [one logical cpu per physical core, restricted to the cpus this process may run on])."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, cpus = set(), []
+    for c in allowed:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            cpus.append(c)
+    return model, cpus
+
+
+def ref_scan_mt(M, inter, size, qtables, R, cpus, seconds):
+    """All-cores CPU leg (qadc_ref_scan_mt): one pinned thread per entry of `cpus`, each with its own copy of the
+    interleaved partition.  Returns (whole queries finished, wall seconds)."""
+    inter = np.ascontiguousarray(inter, np.uint8)
+    qt = np.ascontiguousarray(qtables, np.int8).reshape(-1, M, 16)
+    cp = np.ascontiguousarray(cpus, np.int32)
+    nq, dt = C.c_long(0), C.c_double(0)
+    rc = ref().qadc_ref_scan_mt(M, _p(inter, u8p), C.c_uint32(size), _p(qt, i8p), qt.shape[0], R, len(cp),
+                                _p(cp, i32p), C.c_double(seconds), C.byref(nq), C.byref(dt))
+    assert rc == 0
+    return nq.value, dt.value
+
+
 def ref_heap_replay_i8(keys, vals, R):
     keys = np.ascontiguousarray(keys, np.uint32)
     vals = np.ascontiguousarray(vals, np.int8)

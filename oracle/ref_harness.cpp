@@ -20,9 +20,14 @@
 // push the (0,127) sentinel, then scan each probed partition in order into one heap.
 #include <immintrin.h>
 #include <x86intrin.h>
+#include <sched.h>
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
+#include <vector>
 #define _mm256_set_m128i qadc_ref_mm256_set_m128i
 #include "binheap.hpp"
 #include "simd_layout.hpp"
@@ -80,6 +85,57 @@ void qadc_ref_heap_replay_i8(long n, const std::uint32_t* keys, const std::int8_
     std::memcpy(out_keys, bh.keys(), sizeof(unsigned) * bh.size());
     std::memcpy(out_values, bh.values(), bh.size());
     if (out_sorted_keys) bh.sort_keys(out_sorted_keys);
+}
+
+// All-cores leg of bench.py's CPU baseline: `nthreads` host threads (one per PHYSICAL core when the caller passes
+// cpus[]; thread t is pinned to cpus[t]), each scanning its OWN first-touched copy of the interleaved partition
+// with scan_avx_4<M>, one whole query after the other with a fresh heap (what the reference's single-threaded
+// query loop does, query_common.hpp:351-365, replicated per core), until `seconds` have passed.
+// Returns the number of whole queries finished by all threads and the wall time they took.
+int qadc_ref_scan_mt(int M, const std::uint8_t* part, std::uint32_t size, const std::int8_t* qtables, int nqt, int R,
+                     int nthreads, const int* cpus, double seconds, long* out_queries, double* out_elapsed) {
+    if ((M != 16 && M != 32) || size == 0 || nqt <= 0 || nthreads <= 0) return -1;
+    const long bytes = compute_interleaved_size_4(size, M / 2, 16);
+    std::vector<long> done(nthreads, 0);
+    std::vector<double> elapsed(nthreads, 0.0);
+    auto work = [&](int t) {
+        if (cpus) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET(cpus[t], &set);
+            (void)sched_setaffinity(0, sizeof(set), &set);
+        }
+        void* mem = nullptr;
+        if (posix_memalign(&mem, 64, (bytes + 63) / 64 * 64) != 0) return;
+        std::uint8_t* mine = static_cast<std::uint8_t*>(mem);
+        std::memcpy(mine, part, bytes);                            // first touch on this thread's node
+        std::unique_ptr<__m128i[]> qt(new __m128i[M]);
+        const auto t0 = std::chrono::steady_clock::now();
+        long n = 0;
+        double dt = 0;
+        do {
+            const std::int8_t* q = qtables + static_cast<long>((n + t) % nqt) * M * 16;
+            for (int m = 0; m < M; ++m) qt[m] = _mm_loadu_si128(reinterpret_cast<const __m128i*>(q + m * 16));
+            kv_binheap<unsigned, std::int8_t> bh(R);
+            bh.push(0, 127);
+            if (M == 16) scan_avx_4<16>(mine, nullptr, 0, size, qt.get(), bh);
+            else         scan_avx_4<32>(mine, nullptr, 0, size, qt.get(), bh);
+            ++n;
+            dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        } while (dt < seconds);
+        done[t] = n;
+        elapsed[t] = dt;
+        std::free(mine);
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+    long total = 0;
+    double longest = 0;
+    for (int t = 0; t < nthreads; ++t) { total += done[t]; longest = elapsed[t] > longest ? elapsed[t] : longest; }
+    *out_queries = total;
+    *out_elapsed = longest;
+    return 0;
 }
 
 // Plain push replay through the reference heap (float values).

@@ -705,6 +705,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                            reinterpret_cast<uint64_t*>(d_result + off_heaps),
                            reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq), st);
     HIPCHECK(hipGetLastError());
+    HIPCHECK(take_launch_error());
 
     if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(s.ev_done, st));
@@ -1011,8 +1012,9 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
 int qadc_index_destroy(qadc_index* idx) {
     if (!idx) return QADC_OK;
     (void)hipSetDevice(idx->device);
-    (void)hipStreamSynchronize(idx->stream);
-    if (idx->sort_stream) (void)hipStreamSynchronize(idx->sort_stream);
+    // a pre-scan (front stream) or an on-demand copy may still be in flight: drain all four streams before freeing
+    for (hipStream_t st : {idx->stream, idx->front_stream, idx->copy_stream, idx->sort_stream})
+        if (st) (void)hipStreamSynchronize(st);
     for (auto& p : idx->parts) {
         if (p.own) {
             if (p.d_codes) (void)hipFree(p.d_codes);
@@ -1028,7 +1030,7 @@ int qadc_index_destroy(qadc_index* idx) {
         Slot& s = *sp;
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
         s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
-        s.h_cands.release();
+        s.h_cands.release(); s.d_stream.release();
         s.d_queries.release(); s.d_assign.release(); s.d_cdist.release(); s.h_queries.release(); s.h_assign.release();
         if (s.ev_feed) (void)hipEventDestroy(s.ev_feed);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
@@ -1521,6 +1523,7 @@ int qadc_candidates_i8(qadc_index* idx, int part, const int8_t* qtable, int8_t* 
     HIPCHECK(hipMemcpyAsync(d_t, qtable, idx->M * 16, hipMemcpyHostToDevice, idx->stream));
     launch_candidates_i8(idx->M, p.d_codes, p.n, d_t, d_o, idx->stream);
     HIPCHECK(hipGetLastError());
+    HIPCHECK(take_launch_error());
     HIPCHECK(hipMemcpyAsync(out, d_o, p.n, hipMemcpyDeviceToHost, idx->stream));
     HIPCHECK(hipStreamSynchronize(idx->stream));
     HIPCHECK(hipFree(d_t));

@@ -81,6 +81,9 @@ struct StartItem {
     uint32_t filter;       // 1: append only values <= QueryState::qmax (the sample's R-th smallest)
 };
 
+// A failed per-device setup step of a launcher (dynamic-LDS opt-in) since the last call, or hipSuccess.
+hipError_t take_launch_error();
+
 void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int wgs_per_item,
                     const int8_t* d_qtables, QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands,
                     uint32_t cap_per_query, uint32_t R, hipStream_t stream);

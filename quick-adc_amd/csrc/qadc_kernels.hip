@@ -11,6 +11,7 @@
 #include "qadc_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <type_traits>
 
@@ -19,6 +20,27 @@ namespace qadc {
 constexpr int kWG = 1024;       // threads per workgroup of the int8 scan (16 waves)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+// Dynamic-LDS opt-in above the default limit is a property of (kernel, DEVICE): it is requested once per device
+// the kernel is launched on (an index on GPU 1 after one on GPU 0 in the same process needs its own opt-in), and a
+// failure is kept for the host (take_launch_error) instead of being dropped.
+static thread_local hipError_t g_launch_err = hipSuccess;
+
+hipError_t take_launch_error() {
+    const hipError_t e = g_launch_err;
+    g_launch_err = hipSuccess;
+    return e;
+}
+
+static void ensure_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& done_devices) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+    const uint64_t bit = 1ull << dev;
+    if (done_devices.load(std::memory_order_acquire) & bit) return;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { g_launch_err = e; return; }
+    if (dev != 63) done_devices.fetch_or(bit, std::memory_order_release);
+}
 
 // ---------------------------------------------------------------------------------------------
 // int8 scan
@@ -600,9 +622,8 @@ static void launch_scan_variant(dim3 grid, hipStream_t stream, const ScanItem* d
                                 QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R,
                                 uint32_t sib_items) {
     auto k = &scan_i8_kernel<M, U, NT, CHUNK, PROBE, PF>;
-    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            ScanCfg<M>::LDS_BYTES), true);
-    (void)once;
+    static std::atomic<uint64_t> done{0};
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k), ScanCfg<M>::LDS_BYTES, done);
     hipLaunchKernelGGL(k, grid, dim3(kWG), ScanCfg<M>::LDS_BYTES, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, sib_items);
 }
 
@@ -966,9 +987,8 @@ void launch_replay_heap(const QueryState* d_qs, const uint64_t* d_entries, uint3
 void launch_sort_cands(QueryState* d_qs, const Cand* d_cands, uint32_t cap_per_query, int nq, QueryOut* d_qout,
                        uint64_t* d_entries, uint32_t out_cap, CandHeader* d_hdr, hipStream_t stream,
                        uint64_t* d_dev_entries) {
-    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_cands_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 8 + 4352), true);
-    (void)once;
+    static std::atomic<uint64_t> done{0};
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&sort_cands_kernel), kSortCap * 8 + 4352, done);
     hipLaunchKernelGGL(sort_cands_kernel, dim3(nq), dim3(1024), kSortCap * 8 + 4352, stream, d_qs, d_cands, cap_per_query, nq,
                        d_qout, d_entries, out_cap, d_hdr, d_dev_entries);
 }
@@ -1001,13 +1021,13 @@ void launch_candidates_i8(int M, const uint8_t* d_codes, uint64_t n, const int8_
     const uint64_t nvec = (n + (M == 16 ? 2 : 1) - 1) / (M == 16 ? 2 : 1);
     const int grid = (int)std::min<uint64_t>((nvec + kWG - 1) / kWG, 512);
     if (M == 16) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&candidates_i8_kernel<16>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, ScanCfg<16>::LDS_BYTES);
+        static std::atomic<uint64_t> done{0};
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&candidates_i8_kernel<16>), ScanCfg<16>::LDS_BYTES, done);
         hipLaunchKernelGGL(candidates_i8_kernel<16>, dim3(grid), dim3(kWG), ScanCfg<16>::LDS_BYTES, stream, d_codes, n,
                            d_qtable, d_out);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&candidates_i8_kernel<32>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, ScanCfg<32>::LDS_BYTES);
+        static std::atomic<uint64_t> done{0};
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&candidates_i8_kernel<32>), ScanCfg<32>::LDS_BYTES, done);
         hipLaunchKernelGGL(candidates_i8_kernel<32>, dim3(grid), dim3(kWG), ScanCfg<32>::LDS_BYTES, stream, d_codes, n,
                            d_qtable, d_out);
     }

@@ -36,9 +36,11 @@ _bufs = {}
 _cap_hint = {}
 
 
-def _staging(words, world, device):
-    """Persistent (pinned, when the collective runs on the GPU) staging tensors: no per-step allocation."""
-    key = (words, world, str(device))
+def _staging(words, world, device, tag="gather"):
+    """Persistent (pinned, when the collective runs on the GPU) staging tensors: no per-step allocation.
+    `tag` keeps buffers of different roles apart even when their sizes coincide (the result buffers of
+    merge_batch must never alias the gather buffers whose `extra` payload is sliced out afterwards)."""
+    key = (tag, words, world, str(device))
     b = _bufs.get(key)
     if b is None:
         pin = device.type == "cuda"
@@ -127,7 +129,7 @@ def merge_batch(local, nq, R, status, device, cap=1 << 15, ma=1, extra=None):
         cap = (int(totals.max()) * 9 // 8 + 4095) // 4096 * 4096
         _cap_hint[(nq, ma)] = cap
     # this rank replays queries rank, rank + world, ...; the others stay zero for the sum below
-    res_h, res_o, res_d, _ = _staging(2 * nq * R + nq, 1, device)
+    res_h, res_o, res_d, _ = _staging(2 * nq * R + nq, 1, device, tag="result")
     res = res_h.numpy()
     res[:] = 0
     keys = res[:nq * R].view(np.uint32).reshape(nq, R)

@@ -1,0 +1,89 @@
+"""bench.py's launch contract: `--gpus N` must yield N ranks (self-launch when no launcher set WORLD_SIZE), a
+mismatch must fail loudly, and the JSON line must keep the two scan modes apart."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({k: str(v) for k, v in kw.items()})
+    return env
+
+
+def test_world_size_mismatch_fails_before_touching_the_gpu():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(WORLD_SIZE=1),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0
+    assert b"--gpus 2 but WORLD_SIZE=1" in r.stderr
+
+
+def test_self_launch_builds_one_rank_per_gpu(monkeypatch):
+    """No WORLD_SIZE and --gpus 4: the parent starts torch.distributed.run with 4 ranks as a child process and relays
+    rank 0's line (checked with a fake child; no GPU here)."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, stderr=None):
+            seen["cmd"] = cmd
+            self.stdout = [b"some log line\n", b'{"metric": "pq_codes_scanned_per_sec", "n_gpus": 4}\n']
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    bench.main()
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--gpus") + 1] == "4" and cmd[cmd.index("--steps") + 1] == "3"
+
+
+SMALL = dict(QADC_BENCH_CODES=int(4e7), QADC_BENCH_CPU_SECONDS=0, QADC_BENCH_REAL_CODES=0, QADC_BENCH_IVF_CODES=0,
+             QADC_BENCH_32X4=0, QADC_BENCH_LATENCY=0, QADC_BENCH_PMC=0)
+
+
+@pytest.mark.gpu
+def test_gpus_2_self_launch_runs_two_ranks_over_gloo_on_one_gpu():
+    env = _env(QADC_BENCH_BACKEND="gloo", QADC_BENCH_ONE_GPU=1, **SMALL)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    assert line["recall_at_100"] == 1.0
+    assert line["roofline"]["frac"] is None           # the one-query-per-pass leg is an N=1 measurement
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_keeps_the_two_modes_apart():
+    env = _env(**dict(SMALL, QADC_BENCH_PMC=1, QADC_BENCH_IVF_CODES=int(4e6), QADC_BENCH_LATENCY=1, QADC_BENCH_32X4=1,
+                      QADC_BENCH_SINGLE_QUERIES=8))
+    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=1200)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1.0 and "scan_i8_kernel<16,2,nt,chunk>" in rf["kernel"]
+    assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-6)
+    assert line["roofline_batched"]["bound"] == "lds" and 0 < line["roofline_batched"]["frac"] <= 1.0
+    assert 0 < line["roofline_32x4"]["frac"] <= 1.0
+    assert line["ivf"]["us_per_query"] > 0 and line["latency_us_single_query"]["value"] > 0
+    assert line["n_gpus"] == 1 and line["recall_at_100"] == 1.0
+    # in-run PMC traffic: present when rocprofv3 exists on the box, and then close to the algorithmic bytes
+    if rf["traffic"] is not None:
+        assert 0.5 < rf["traffic_over_algorithmic"] < 1.5
