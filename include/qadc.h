@@ -214,6 +214,11 @@ int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vec
 int qadc_replay_i8(uint64_t n, const uint32_t* keys, const int8_t* vals, int R, int push_sentinel,
                    uint32_t* out_keys, int8_t* out_vals, int32_t* out_size);
 
+/* Host-only helper: kv_binheap<unsigned,int8_t>::sort_keys (binheap.hpp:129-137) of a heap whose arrays are
+ * heap_keys / heap_vals[size] (as returned by the entry points above): the keys ascending by value, tied values in
+ * the order std::sort leaves them on that array — what a caller of the reference gets from bh.sort_keys(). */
+int qadc_sort_keys_i8(int size, const uint32_t* heap_keys, const int8_t* heap_vals, uint32_t* out_keys);
+
 /* Host half of the multi-GPU merge: `gathered` = the world int32 buffers of buflen words each that the ranks
  * contributed to ONE all-gather, each laid out as [nq counts][cap keys][ceil(cap/4) words of int8 values]
  * [only when ma > 1: ceil(cap/2) words of u16 assign slots][anything else].  Replays queries q_first, q_first + q_step, ... in
@@ -253,6 +258,10 @@ typedef struct qadc_profile {
     uint64_t mq_launches;     /* of scan_launches: multi-query launches (scan_i8_mq_kernel, 8 queries per pass) */
     uint64_t pass_codes;      /* codes the streaming launches READ: a run's codes once per query, or once per group
                                  of 8 queries in a multi-query launch (LDS row reads = pass_codes * M there) */
+    uint64_t wgq_launches;    /* batches scanned by scan_query_kernel (one workgroup per query) */
+    uint64_t wgq_queries;     /* queries in them */
+    uint64_t wgq_codes;       /* codes they probed (algorithmic bytes = codes * M/2) */
+    double wgq_ms;            /* HIP-event time of those launches */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

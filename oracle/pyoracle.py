@@ -91,6 +91,15 @@ def heap_replay_f32(keys, vals, R):
     return ok[:osz.value].copy(), ov[:osz.value].copy()
 
 
+def sort_keys_i8(heap_keys, heap_vals):
+    """kv_binheap::sort_keys (binheap.hpp:129-137) of a heap in the given array state."""
+    k = np.ascontiguousarray(heap_keys, np.uint32)
+    v = np.ascontiguousarray(heap_vals, np.int8)
+    out = np.zeros(len(k), np.uint32)
+    lib().orc_sort_keys_i8(len(k), _p(k, u32p), _p(v, i8p), _p(out, u32p))
+    return out
+
+
 def pack4(assign, M):
     assign = np.ascontiguousarray(assign, np.int32)
     n = assign.shape[0]
@@ -309,12 +318,15 @@ def ref_scan_mt(M, inter, size, qtables, R, cpus, seconds):
     return nq.value, dt.value
 
 
-def ref_heap_replay_i8(keys, vals, R):
+def ref_heap_replay_i8(keys, vals, R, want_sorted=False):
     keys = np.ascontiguousarray(keys, np.uint32)
     vals = np.ascontiguousarray(vals, np.int8)
     ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.int8), C.c_int(0)
+    sk = np.zeros(R, np.uint32)
     ref().qadc_ref_heap_replay_i8(C.c_long(len(keys)), _p(keys, u32p), _p(vals, i8p), R,
-                                  _p(ok, u32p), _p(ov, i8p), C.byref(osz), None)
+                                  _p(ok, u32p), _p(ov, i8p), C.byref(osz), _p(sk, u32p) if want_sorted else None)
+    if want_sorted:
+        return ok[:osz.value].copy(), ov[:osz.value].copy(), sk[:osz.value].copy()
     return ok[:osz.value].copy(), ov[:osz.value].copy()
 
 

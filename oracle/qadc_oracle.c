@@ -81,6 +81,142 @@ void orc_heap_replay_f32(long n, const uint32_t* keys, const float* vals, int R,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * kv_binheap::sort_keys — binheap.hpp:129-137 (and sort, 118-127): std::sort of the index
+ * permutation 0..size-1 with comparator values_[a] < values_[b]; keys are emitted in that order.
+ * std::sort is not stable, so the order of tied values is whatever the library's algorithm yields
+ * on the heap array.  The algorithm lives in a third-party dependency of the reference: libstdc++
+ * (GCC 11.4 in this image; bits/stl_algo.h, bits/stl_heap.h — unchanged since GCC 4.x):
+ * introsort = median-of-3 quicksort loop down to ranges of 16 with a 2*floor(log2 n) depth limit
+ * (heapsort below it), then one final insertion sort.  Restated here step for step; pinned by the
+ * reference build's own sort_keys output on every golden case (tests/test_oracle_golden.py).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { const int8_t* v; } orc_sortctx;
+#define ORC_LESS(c, a, b) ((c)->v[(a)] < (c)->v[(b)])
+
+static void orc_ss_swap(int* a, int* b) { int t = *a; *a = *b; *b = t; }
+
+static void orc_ss_push_heap(const orc_sortctx* c, int* first, long hole, long top, int value) {
+    long parent = (hole - 1) / 2;
+    while (hole > top && ORC_LESS(c, first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+
+static void orc_ss_adjust_heap(const orc_sortctx* c, int* first, long hole, long len, int value) {
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (ORC_LESS(c, first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    orc_ss_push_heap(c, first, hole, top, value);
+}
+
+static void orc_ss_heapsort(const orc_sortctx* c, int* first, int* last) {   /* __partial_sort(first, last, last) */
+    const long len = last - first;
+    if (len >= 2)
+        for (long parent = (len - 2) / 2;; --parent) {                        /* __make_heap */
+            orc_ss_adjust_heap(c, first, parent, len, first[parent]);
+            if (parent == 0) break;
+        }
+    while (last - first > 1) {                                                /* __sort_heap / __pop_heap */
+        --last;
+        const int value = *last;
+        *last = *first;
+        orc_ss_adjust_heap(c, first, 0, last - first, value);
+    }
+}
+
+static void orc_ss_median_to_first(const orc_sortctx* c, int* result, int* a, int* b, int* d) {
+    if (ORC_LESS(c, *a, *b)) {
+        if (ORC_LESS(c, *b, *d)) orc_ss_swap(result, b);
+        else if (ORC_LESS(c, *a, *d)) orc_ss_swap(result, d);
+        else orc_ss_swap(result, a);
+    } else if (ORC_LESS(c, *a, *d)) orc_ss_swap(result, a);
+    else if (ORC_LESS(c, *b, *d)) orc_ss_swap(result, d);
+    else orc_ss_swap(result, b);
+}
+
+static int* orc_ss_partition(const orc_sortctx* c, int* first, int* last, int* pivot) {   /* __unguarded_partition */
+    for (;;) {
+        while (ORC_LESS(c, *first, *pivot)) ++first;
+        --last;
+        while (ORC_LESS(c, *pivot, *last)) --last;
+        if (!(first < last)) return first;
+        orc_ss_swap(first, last);
+        ++first;
+    }
+}
+
+static void orc_ss_introsort_loop(const orc_sortctx* c, int* first, int* last, long depth) {
+    while (last - first > 16) {
+        if (depth == 0) {
+            orc_ss_heapsort(c, first, last);
+            return;
+        }
+        --depth;
+        int* mid = first + (last - first) / 2;
+        orc_ss_median_to_first(c, first, first + 1, mid, last - 1);
+        int* cut = orc_ss_partition(c, first + 1, last, first);
+        orc_ss_introsort_loop(c, cut, last, depth);
+        last = cut;
+    }
+}
+
+static void orc_ss_linear_insert(const orc_sortctx* c, int* last) {          /* __unguarded_linear_insert */
+    const int val = *last;
+    int* next = last - 1;
+    while (ORC_LESS(c, val, *next)) {
+        *last = *next;
+        last = next;
+        --next;
+    }
+    *last = val;
+}
+
+static void orc_ss_insertion_sort(const orc_sortctx* c, int* first, int* last) {
+    if (first == last) return;
+    for (int* i = first + 1; i != last; ++i) {
+        if (ORC_LESS(c, *i, *first)) {
+            const int val = *i;
+            memmove(first + 1, first, (size_t)(i - first) * sizeof(int));
+            *first = val;
+        } else {
+            orc_ss_linear_insert(c, i);
+        }
+    }
+}
+
+/* out_keys[i] = heap_keys[perm[i]] for the std::sort-ed permutation of a heap array of `size` entries. */
+void orc_sort_keys_i8(int size, const uint32_t* heap_keys, const int8_t* heap_vals, uint32_t* out_keys) {
+    if (size <= 0) return;
+    int* perm = (int*)malloc(sizeof(int) * (size_t)size);
+    for (int i = 0; i < size; ++i) perm[i] = i;
+    const orc_sortctx c = { heap_vals };
+    long lg = 0;
+    for (long n = size; n > 1; n >>= 1) ++lg;                                 /* std::__lg */
+    orc_ss_introsort_loop(&c, perm, perm + size, lg * 2);
+    if (size > 16) {                                                          /* __final_insertion_sort */
+        orc_ss_insertion_sort(&c, perm, perm + 16);
+        for (int* i = perm + 16; i != perm + size; ++i) orc_ss_linear_insert(&c, i);
+    } else {
+        orc_ss_insertion_sort(&c, perm, perm + size);
+    }
+    for (int i = 0; i < size; ++i) out_keys[i] = heap_keys[perm[i]];
+    free(perm);
+}
+
+/* ------------------------------------------------------------------------------------------
  * multiple_set_bits_4 — quantizers.hpp:49-68.  assign is [n][M] centroid ids (0..15);
  * byte b of a code: low nibble = sub-quantizer 2b, high nibble = 2b+1.
  * ---------------------------------------------------------------------------------------- */

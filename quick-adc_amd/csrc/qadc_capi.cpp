@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cfloat>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -155,6 +156,15 @@ struct Slot {
     DevBuf<Cand> d_cands;
     DevBuf<float> d_fc;
 
+    // one-workgroup-per-query path (qadc_query_kernel.hip): no planner, no levels, no sort
+    bool wgq = false;
+    uint32_t wgq_cap = 0;               // stream entries per query (regrown on overflow)
+    uint64_t wgq_fcap = 0;              // pre-scan values per query in the global scratch (0 = they fit LDS)
+    DevBuf<uint32_t> d_qflags;          // [nq][4]: {flags, entries} for replay_heap_lanes_kernel
+    DevBuf<float> d_fvals;
+    PinBuf<uint64_t> h_fetch;           // streams fetched on demand when they were left in device memory
+    bool assign_on_device = false;      // qadc_search: assign[] was produced on the GPU and copied back asynchronously
+    hipEvent_t ev_assign = nullptr;
     bool full_prescan = false;          // survivor buffer overflowed: pre-scan everything unfiltered
     // sharded pre-scan (multi-GPU): mode 1 = pre-scan ONLY, of slice pre_slice of pre_nslices of every probed
     // partition's starts, exporting the R smallest values per query; mode 2 = a full batch whose pre-scan is
@@ -224,6 +234,16 @@ struct qadc_index {
     uint32_t small_vec_per_wg = 512;  // 16-byte vectors one small-run workgroup covers
     uint32_t small_run = 1u << 17;  // runs shorter than this use the small-run kernel
     int variant = 0x0d;    // kernel tuning variant (see launch_scan_i8): U=2, non-temporal loads, chunked tiles
+    // one workgroup per query (IVF batches, small lists): 0 = never, 1 = auto, 2 = whenever structurally possible
+    int wgq = 1;
+    int wgq_min_nq = 128;                // auto: batches of at least this many queries ...
+    uint64_t wgq_max_codes = 1ull << 24; //   ... probing at most this many codes per query (estimate), or
+    uint64_t wgq_small_codes = 1ull << 18;   // any batch probing at most this many codes per query
+    uint32_t wgq_capacity = 4096;        // stream entries per query to start with
+    DevBuf<PartDesc> d_partdesc;         // device partition table (qadc_index_finalize)
+    uint32_t max_start_n = 0;
+    uint64_t total_codes = 0;
+    uint32_t max_part_n = 0;
     bool profile = false;
     // N1: host feeders on the device
     int dim = 0;                 // vector dimension (0 = qadc_index_set_pq not called)
@@ -472,8 +492,11 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
     return QADC_OK;
 }
 
+int launch_wgq_batch(qadc_index* idx, Slot& s);
+
 // Plans the batch in slot s and enqueues all of its GPU work (front, levels, ordering, optional device replay).
 int plan_and_launch(qadc_index* idx, Slot& s) {
+    if (s.wgq) return launch_wgq_batch(idx, s);
     ScopedMs timer(idx->prof.host_plan_ms);
     const int M = idx->M, cs = idx->cs, nq = s.nq, ma = s.ma;
     hipStream_t st = idx->stream;
@@ -712,6 +735,145 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     return QADC_OK;
 }
 
+// Decides whether a batch takes the one-workgroup-per-query path.  codes_per_query: exact maximum when the host
+// knows assign[], an estimate (ma x mean partition size) when assign[] is produced on the GPU.
+bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64_t codes_per_query) {
+    if (idx->wgq == 0 || mode != 0 || ma > 4096 || R <= 0) return false;
+    if (idx->wgq >= 2) return true;
+    if (codes_per_query <= idx->wgq_small_codes) return true;
+    return nq >= idx->wgq_min_nq && codes_per_query <= idx->wgq_max_codes;
+}
+
+// One launch per batch: scan_query_kernel (one workgroup per query), then — for batches large enough to replay on
+// the device — replay_heap_lanes_kernel on the side stream.  No host planning: the kernel walks assign[] and the
+// device partition table itself.
+int launch_wgq_batch(qadc_index* idx, Slot& s) {
+    ScopedMs timer(idx->prof.host_plan_ms);
+    const int M = idx->M, nq = s.nq, ma = s.ma;
+    const size_t table_dim = (size_t)M * 16, nt = (size_t)nq * ma * table_dim;
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    s.launches.clear();
+    s.start_codes = 0;
+    // ---- upload block: [assign i32 nq*ma (host-assign path)][float or int8 tables (host-table path)] ----
+    const size_t assign_bytes = s.assign_on_device ? 0 : sizeof(int32_t) * (size_t)nq * ma;
+    const size_t off_tables = align16(assign_bytes);
+    const size_t tables_bytes = s.float_path ? (s.device_tables ? 0 : nt * sizeof(float)) : nt;
+    const size_t in_bytes = align16(off_tables + tables_bytes);
+    HIPCHECK(s.h_in.ensure(std::max<size_t>(in_bytes, 16)));
+    HIPCHECK(s.d_in.ensure(std::max<size_t>(in_bytes, 16)));
+    if (assign_bytes) std::memcpy(s.h_in.p, s.assign.data(), assign_bytes);
+    if (s.float_path && !s.device_tables) std::memcpy(s.h_in.p + off_tables, s.tables, nt * sizeof(float));
+    if (!s.float_path) std::memcpy(s.h_in.p + off_tables, s.qtables_in.data(), nt);
+
+    // ---- result block in pinned, device-mapped host memory: [QueryOut[nq]][streams u64[nq][cap] unless they stay
+    // on the device][heaps u64[nq][R]][sizes u32[nq]] ----
+    const uint32_t cap = s.wgq_cap;
+    s.dev_replay = idx->device_replay_nq > 0 && nq >= idx->device_replay_nq && (uint32_t)s.R <= replay_lanes_max_R();
+    const size_t stream_entries = (size_t)nq * cap;
+    if (stream_entries >= (1ull << 32)) return fail(QADC_E_CAPACITY, "candidate stream capacity exceeds 2^32 entries");
+    s.out_cap = (uint32_t)stream_entries;
+    const size_t host_stream_bytes = s.dev_replay ? 0 : sizeof(uint64_t) * stream_entries;
+    const size_t off_heaps = sizeof(QueryOut) * (size_t)nq + host_stream_bytes;
+    const size_t heaps_bytes = s.dev_replay ? (sizeof(uint64_t) * (size_t)s.R + sizeof(uint32_t)) * (size_t)nq : 0;
+    HIPCHECK(s.h_result.ensure(off_heaps + heaps_bytes + 16, hipHostMallocMapped | hipHostMallocCoherent));
+    if (s.h_result.p != s.h_result_mapped) {
+        HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.d_result_mapped), s.h_result.p, 0));
+        s.h_result_mapped = s.h_result.p;
+    }
+    unsigned char* d_result = s.d_result_mapped;
+    s.d_qout = reinterpret_cast<QueryOut*>(d_result);
+    s.h_qout = reinterpret_cast<QueryOut*>(s.h_result.p);
+    s.d_entries = reinterpret_cast<uint64_t*>(d_result + sizeof(QueryOut) * (size_t)nq);
+    s.h_entries = reinterpret_cast<uint64_t*>(s.h_result.p + sizeof(QueryOut) * (size_t)nq);
+    s.h_heaps = reinterpret_cast<uint64_t*>(s.h_result.p + off_heaps);
+    s.h_heap_sizes = reinterpret_cast<uint32_t*>(s.h_result.p + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
+    if (s.dev_replay) {
+        HIPCHECK(s.d_stream.ensure(stream_entries));
+        HIPCHECK(s.d_qflags.ensure((size_t)nq * 4));
+    }
+    HIPCHECK(s.d_qtables.ensure(nt));
+    // pre-scan values beyond the kernel's LDS budget go to a global scratch
+    uint64_t fcap = 0;
+    if (s.float_path) {
+        uint64_t worst = (uint64_t)ma * idx->max_start_n;
+        if (!s.assign_on_device) {
+            worst = 0;
+            for (int q = 0; q < nq; ++q) {
+                uint64_t t = 0;
+                for (int a = 0; a < ma; ++a) t += idx->parts[s.assign[(size_t)q * ma + a]].start_n;
+                worst = std::max(worst, t);
+            }
+        }
+        if (worst > query_kernel_lds_values(M)) fcap = worst;
+        for (int q = 0; q < nq && !s.assign_on_device; ++q)
+            for (int a = 0; a < ma; ++a) s.start_codes += idx->parts[s.assign[(size_t)q * ma + a]].start_n;
+    }
+    s.wgq_fcap = fcap;
+    if (fcap) HIPCHECK(s.d_fvals.ensure((size_t)nq * fcap));
+
+    bool alone = true;
+    for (int i = 0; i < kSlots; ++i) alone = alone && (&idx->slot[i] == &s || !idx->slot[i].busy);
+    alone = alone && !idx->pre_slot[0].busy && !idx->pre_slot[1].busy;
+    hipStream_t st = idx->stream;
+    if (in_bytes) {
+        if (alone) {
+            HIPCHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, st));
+        } else {                                            // never queue a copy behind the previous batch's kernels
+            HIPCHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, idx->copy_stream));
+            if (!s.ev_up) HIPCHECK(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(s.ev_up, idx->copy_stream));
+            HIPCHECK(hipStreamWaitEvent(st, s.ev_up, 0));
+        }
+    }
+    s.prof_used = 0;
+    QueryKernelArgs A;
+    A.parts = idx->d_partdesc.p;
+    A.assign = s.assign_on_device ? s.d_assign.p : reinterpret_cast<const int32_t*>(s.d_in.p);
+    A.ma = ma;
+    A.ftables = nullptr;
+    A.qtables = s.d_qtables.p;
+    if (s.float_path) {
+        if (s.device_tables) {
+            HIPCHECK(s.d_ftables.ensure(nt));
+            HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
+            launch_build_tables(s.d_queries.p, idx->K ? idx->d_coarse.p : nullptr, s.d_assign.p, idx->d_codebooks.p,
+                                idx->has_rotation ? idx->d_rotation.p : nullptr, nq, ma, M, idx->dim, s.d_ftables.p, st);
+            A.ftables = s.d_ftables.p;
+        } else {
+            A.ftables = reinterpret_cast<float*>(s.d_in.p + off_tables);
+        }
+    } else {
+        A.qtables = reinterpret_cast<int8_t*>(s.d_in.p + off_tables);    // the caller's int8 tables, as uploaded
+    }
+    s.d_qt = A.qtables;
+    A.fvals = fcap ? s.d_fvals.p : nullptr;
+    A.fcap = (uint32_t)fcap;
+    A.stream = s.dev_replay ? s.d_stream.p : s.d_entries;
+    A.stream2 = nullptr;
+    A.cap = cap;
+    A.qout = s.d_qout;
+    A.qstate_flags = s.dev_replay ? s.d_qflags.p : nullptr;
+    A.R = (uint32_t)s.R;
+    A.quant_mode = idx->quant_mode;
+    if (idx->profile) HIPCHECK(prof_event(s, st));
+    HIPCHECK(launch_scan_query(M, nq, A, st));
+    if (idx->profile) HIPCHECK(prof_event(s, st));
+    if (s.dev_replay) {
+        if (!alone) {                                       // replay on the side stream, under the next batch's scan
+            if (!s.ev_scanned) HIPCHECK(hipEventCreateWithFlags(&s.ev_scanned, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(s.ev_scanned, st));
+            st = idx->sort_stream;
+            HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
+        }
+        HIPCHECK(launch_replay_heap_lanes(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R,
+                                          reinterpret_cast<uint64_t*>(d_result + off_heaps),
+                                          reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq), st));
+    }
+    if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(s.ev_done, st));
+    return QADC_OK;
+}
+
 int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* assign, float* tables,
                   const int8_t* qtables, int R, int mode = 0, int slice = 0, int nslices = 1,
                   const float* inj_vals = nullptr, int inj_n = 0) {
@@ -748,8 +910,23 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
         s.qtables_in.assign(qtables, qtables + nt);
     }
     s.full_prescan = false;
+    s.assign_on_device = false;
+    {   // which path: levels (long shared lists) or one workgroup per query (IVF batches, small lists)
+        uint64_t max_codes = 0;
+        for (int q = 0; q < nq; ++q) {
+            uint64_t c = 0;
+            for (int a = 0; a < ma; ++a) {
+                const int p = s.assign[(size_t)q * ma + a];
+                if (p < 0 || p >= (int)idx->parts.size()) return fail(QADC_E_ARG, "assign[] names a partition that does not exist");
+                c += idx->parts[p].n;
+            }
+            max_codes = std::max(max_codes, c);
+        }
+        s.wgq = wgq_eligible(idx, nq, ma, R, mode, max_codes);
+    }
+    if (s.wgq) s.wgq_cap = std::max<uint32_t>(s.wgq_cap, idx->wgq_capacity);
     s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
-    s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)nq * 8192u, 1ull << 30));
+    if (!s.wgq) s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)nq * 8192u, 1ull << 30));
     if (int rc = plan_and_launch(idx, s)) return rc;
     s.busy = true;
     return QADC_OK;
@@ -790,18 +967,29 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
         HIPCHECK(s.d_cdist.ensure((size_t)nq * idx->K));
         launch_coarse_assign(s.d_queries.p, idx->d_coarse.p, nq, idx->K, dim, ma, s.d_cdist.p, s.d_assign.p, cs);
         HIPCHECK(hipGetLastError());
+        if (!s.ev_feed) HIPCHECK(hipEventCreateWithFlags(&s.ev_feed, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(s.ev_feed, cs));             // the tables need assign[] on the device, not the copy below
         HIPCHECK(hipMemcpyAsync(s.h_assign.p, s.d_assign.p, sizeof(int32_t) * (size_t)nq * ma, hipMemcpyDeviceToHost, cs));
     } else {
         HIPCHECK(hipMemsetAsync(s.d_assign.p, 0, sizeof(int32_t) * (size_t)nq * ma, cs));
         std::memset(s.h_assign.p, 0, sizeof(int32_t) * (size_t)nq * ma);
+        if (!s.ev_feed) HIPCHECK(hipEventCreateWithFlags(&s.ev_feed, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(s.ev_feed, cs));
     }
-    if (!s.ev_feed) HIPCHECK(hipEventCreateWithFlags(&s.ev_feed, hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(s.ev_feed, cs));
-    HIPCHECK(hipStreamSynchronize(cs));                      // the planner needs assign[] on the host
-    s.assign.assign(s.h_assign.p, s.h_assign.p + (size_t)nq * ma);
+    if (!s.ev_assign) HIPCHECK(hipEventCreateWithFlags(&s.ev_assign, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(s.ev_assign, cs));
+    // one workgroup per query: the kernel reads assign[] on the device, the host only wants it back for the caller
+    const uint64_t est_codes = idx->parts.empty() ? 0 : idx->total_codes / idx->parts.size() * (uint64_t)(idx->K ? ma : 1);
+    s.wgq = wgq_eligible(idx, nq, ma, R, 0, est_codes);
+    s.assign_on_device = s.wgq;
+    if (!s.wgq) {
+        HIPCHECK(hipStreamSynchronize(cs));                  // the planner needs assign[] on the host
+        s.assign.assign(s.h_assign.p, s.h_assign.p + (size_t)nq * ma);
+    }
     s.full_prescan = false;
+    if (s.wgq) s.wgq_cap = std::max<uint32_t>(s.wgq_cap, idx->wgq_capacity);
     s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
-    s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)nq * 8192u, 1ull << 30));
+    if (!s.wgq) s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)nq * 8192u, 1ull << 30));
     if (int rc = plan_and_launch(idx, s)) return rc;
     s.busy = true;
     return QADC_OK;
@@ -818,7 +1006,27 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
     if (int rc = use_device(idx)) return rc;
     const uint32_t sort_limit_max = kSortCap;
     uint64_t total_sorted = 0;
-    for (int attempt = 0;; ++attempt) {
+    for (int attempt = 0; s.wgq; ++attempt) {                  // one workgroup per query: per-query stream capacity only
+        HIPCHECK(hipEventSynchronize(s.ev_done));
+        uint64_t max_count = 0;
+        for (int q = 0; q < s.nq; ++q) max_count = std::max<uint64_t>(max_count, s.h_qout[q].count);
+        if (max_count <= s.wgq_cap) break;
+        if (attempt >= 2 || max_count + 64 > (1ull << 31)) {
+            s.busy = false;
+            return fail(QADC_E_CAPACITY, "candidate stream overflow persists");
+        }
+        s.wgq_cap = (uint32_t)(max_count + max_count / 8 + 64);  // every entry was counted: size for all of them, run again
+        idx->prof.regrows++;
+        if (int rc = plan_and_launch(idx, s)) {
+            s.busy = false;
+            return rc;
+        }
+    }
+    if (s.assign_on_device) {                                  // qadc_search: assign[] comes back for the caller
+        HIPCHECK(hipEventSynchronize(s.ev_assign));
+        s.assign.assign(s.h_assign.p, s.h_assign.p + (size_t)s.nq * s.ma);
+    }
+    for (int attempt = 0; !s.wgq; ++attempt) {
         HIPCHECK(hipEventSynchronize(s.ev_done));
         const uint32_t limit = std::min<uint32_t>(s.cap_q, sort_limit_max);
         uint64_t max_count = 0;
@@ -848,7 +1056,17 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
         }
     }
     s.busy = false;
-    if (idx->profile) {
+    if (idx->profile && s.wgq) {
+        float ms = 0;
+        if (s.prof_used >= 2) HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[0], s.prof_ev[1]));
+        idx->prof.wgq_ms += ms;
+        idx->prof.wgq_launches++;
+        idx->prof.wgq_queries += (uint64_t)s.nq;
+        for (int q = 0; q < s.nq; ++q)
+            for (int a = 0; a < s.ma; ++a) idx->prof.wgq_codes += idx->parts[s.assign[(size_t)q * s.ma + a]].n;
+        if (s.float_path) idx->prof.start_codes += s.start_codes;
+    }
+    if (idx->profile && !s.wgq) {
         float ms = 0;
         if (s.prof_used >= 2) {
             HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[0], s.prof_ev[1]));
@@ -874,6 +1092,23 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
     s.out_entries.clear();
     s.out_off.assign((size_t)s.nq + 1, 0);
     s.skipped_streams = false;
+    if (s.wgq && s.dev_replay) {
+        // the streams stayed in device memory; fetch them only if the caller wants them (or a query could not be
+        // replayed on the device): one strided copy of the used part of every query's region
+        bool need = need_stream;
+        uint32_t max_count = 0;
+        for (int q = 0; q < s.nq; ++q) {
+            need = need || s.h_heap_sizes[q] == 0xffffffffu;
+            max_count = std::max(max_count, s.h_qout[q].count);
+        }
+        if (need && max_count) {
+            HIPCHECK(s.h_fetch.ensure((size_t)s.nq * s.wgq_cap));
+            HIPCHECK(hipMemcpy2DAsync(s.h_fetch.p, sizeof(uint64_t) * s.wgq_cap, s.d_stream.p, sizeof(uint64_t) * s.wgq_cap,
+                                      sizeof(uint64_t) * max_count, s.nq, hipMemcpyDeviceToHost, idx->copy_stream));
+            HIPCHECK(hipStreamSynchronize(idx->copy_stream));
+            s.h_entries = s.h_fetch.p;
+        }
+    }
     for (int q = 0; q < s.nq; ++q) {
         const QueryOut& qs = s.h_qout[q];
         s.out_off[q] = s.out_entries.size();
@@ -1025,12 +1260,14 @@ int qadc_index_destroy(qadc_index* idx) {
     idx->d_codebooks.release();
     idx->d_rotation.release();
     idx->d_coarse.release();
+    idx->d_partdesc.release();
     Slot* all_slots[kSlots + 2] = {&idx->slot[0], &idx->slot[1], &idx->slot[2], &idx->slot[3], &idx->pre_slot[0], &idx->pre_slot[1]};
     for (Slot* sp : all_slots) {
         Slot& s = *sp;
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
         s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
-        s.h_cands.release(); s.d_stream.release();
+        s.h_cands.release(); s.d_stream.release(); s.d_qflags.release(); s.d_fvals.release(); s.h_fetch.release();
+        if (s.ev_assign) (void)hipEventDestroy(s.ev_assign);
         s.d_queries.release(); s.d_assign.release(); s.d_cdist.release(); s.h_queries.release(); s.h_assign.release();
         if (s.ev_feed) (void)hipEventDestroy(s.ev_feed);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
@@ -1211,6 +1448,11 @@ int qadc_index_add_partition_synthetic_shard(qadc_index* idx, uint32_t global_n,
 int qadc_index_set_key_base(qadc_index* idx, int part, uint32_t key_base) {
     if (!idx || part < 0 || part >= (int)idx->parts.size()) return fail(QADC_E_ARG, "bad partition");
     idx->parts[part].key_base = key_base;
+    if (idx->finalized && idx->d_partdesc.p) {                  // keep the device partition table in step
+        if (int rc = use_device(idx)) return rc;
+        HIPCHECK(hipMemcpy(reinterpret_cast<unsigned char*>(idx->d_partdesc.p + part) + offsetof(PartDesc, key_base), &key_base,
+                           sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     return QADC_OK;
 }
 
@@ -1230,6 +1472,30 @@ int qadc_index_finalize(qadc_index* idx, float keep) {
         if (p.start_n > p.starts_cap)
             return fail(QADC_E_ARG, "shard holds fewer start codes than max(1, unsigned(global_size * keep))");
     }
+    // device partition table for the one-workgroup-per-query kernel
+    if (int rc = use_device(idx)) return rc;
+    std::vector<PartDesc> pd(idx->parts.size());
+    idx->max_start_n = 0;
+    idx->total_codes = 0;
+    idx->max_part_n = 0;
+    for (size_t i = 0; i < idx->parts.size(); ++i) {
+        const Part& p = idx->parts[i];
+        PartDesc& d = pd[i];
+        d.codes = p.d_codes;
+        d.labels = p.d_labels;
+        d.starts = p.d_starts;
+        d.n = p.n;
+        d.global_n = p.global_n;
+        d.first_pos = p.first_pos;
+        d.key_base = p.key_base;
+        d.start_n = p.start_n;
+        d.pad = 0;
+        idx->max_start_n = std::max(idx->max_start_n, p.start_n);
+        idx->max_part_n = std::max(idx->max_part_n, p.n);
+        idx->total_codes += p.n;
+    }
+    HIPCHECK(idx->d_partdesc.ensure(pd.size()));
+    HIPCHECK(hipMemcpy(idx->d_partdesc.p, pd.data(), pd.size() * sizeof(PartDesc), hipMemcpyHostToDevice));
     idx->finalized = true;
     return QADC_OK;
 }
@@ -1266,9 +1532,15 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "replay_threads") idx->replay_threads = (int)value;
     else if (n == "small_vec_per_wg") idx->small_vec_per_wg = (uint32_t)std::max(256.0, value);
     else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
+    else if (n == "wgq") idx->wgq = (int)value;
+    else if (n == "wgq_min_nq") idx->wgq_min_nq = (int)std::max(value, 1.0);
+    else if (n == "wgq_max_codes") idx->wgq_max_codes = (uint64_t)std::max(value, 0.0);
+    else if (n == "wgq_small_codes") idx->wgq_small_codes = (uint64_t)std::max(value, 0.0);
+    else if (n == "wgq_capacity") idx->wgq_capacity = (uint32_t)std::max(16.0, std::min(value, 1048576.0));
     else if (n == "profile") idx->profile = value != 0;
     else return fail(QADC_E_ARG, "unknown option: " + n);
     if (n == "cand_capacity") for (auto& sl : idx->slot) sl.cap_q = 0;
+    if (n == "wgq_capacity") for (auto& sl : idx->slot) sl.wgq_cap = 0;
     return QADC_OK;
 }
 
@@ -1447,6 +1719,14 @@ int qadc_replay_i8(uint64_t n, const uint32_t* keys, const int8_t* vals, int R, 
     *out_size = bh.size();
     if (out_keys) std::memcpy(out_keys, bh.keys(), sizeof(uint32_t) * bh.size());
     if (out_vals) std::memcpy(out_vals, bh.values(), bh.size());
+    return QADC_OK;
+}
+
+int qadc_sort_keys_i8(int size, const uint32_t* heap_keys, const int8_t* heap_vals, uint32_t* out_keys) {
+    if (size < 0 || (size && (!heap_keys || !heap_vals || !out_keys))) return fail(QADC_E_ARG, "bad arguments");
+    kv_heap<uint32_t, int8_t> bh(std::max(size, 1));
+    bh.assign(heap_keys, heap_vals, size);
+    bh.sort_keys(out_keys);
     return QADC_OK;
 }
 

@@ -81,6 +81,45 @@ struct StartItem {
     uint32_t filter;       // 1: append only values <= QueryState::qmax (the sample's R-th smallest)
 };
 
+// ---- one workgroup per query (qadc_query_kernel.hip): IVF batches and small lists ---------------------
+// Device-resident partition table, one entry per database partition (built by qadc_index_finalize).
+struct PartDesc {
+    const uint8_t* codes;    // row-major codes of the local range
+    const uint32_t* labels;  // labels of the local range, or nullptr
+    const uint8_t* starts;   // replica of the partition's first codes (sharded lists), or nullptr: codes
+    uint32_t n;              // codes held here
+    uint32_t global_n;       // codes of the whole partition
+    uint32_t first_pos;      // global position of local code 0
+    uint32_t key_base;
+    uint32_t start_n;        // max(1, unsigned(global_n * keep)), 0 for an empty partition
+    uint32_t pad;
+};
+
+struct QueryKernelArgs {
+    const PartDesc* parts;
+    const int32_t* assign;   // [nq][ma] probed partitions in scan order
+    int ma;
+    float* ftables;          // [nq][ma][M*16] float tables (negatives clamped in place), or nullptr: int8 path
+    int8_t* qtables;         // [nq][ma][M*16]: written by the quantizer (float path) / read as given (int8 path)
+    float* fvals;            // [nq][fcap] scratch for a query's pre-scan values when they exceed the LDS budget
+    uint32_t fcap;
+    uint64_t* stream;        // [nq][cap] ordered push stream: key | value << 32 | assign slot << 40
+    uint64_t* stream2;       // optional second copy (device memory, for the device replay), or nullptr
+    uint32_t cap;
+    QueryOut* qout;          // [nq]
+    uint32_t* qstate_flags;  // optional [nq][4]: {flags, entries} for replay_heap_lanes_kernel, or nullptr
+    uint32_t R;
+    int quant_mode;
+};
+
+size_t query_kernel_lds_bytes(int M);
+uint32_t query_kernel_lds_values(int M);       // pre-scan values a query may have before fvals is needed
+hipError_t launch_scan_query(int M, int nq, const QueryKernelArgs& args, hipStream_t stream);
+// kv_binheap push replay of the ordered streams, 64 queries per wave (one lane each); R <= replay_lanes_max_R().
+uint32_t replay_lanes_max_R();
+hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
+                                    uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
+
 // A failed per-device setup step of a launcher (dynamic-LDS opt-in) since the last call, or hipSuccess.
 hipError_t take_launch_error();
 

@@ -32,6 +32,11 @@ public:
     int capacity() const { return cap_; }
     int size() const { return size_; }
     Value max() const { return vals_[0]; }           // caller guarantees size() >= 1 (binheap.hpp:63-65)
+    // adopt an existing heap array (size <= capacity entries already in heap order)
+    void assign(const Key* keys, const Value* values, int size) {
+        size_ = size;
+        for (int i = 0; i < size; ++i) { keys_[i] = keys[i]; vals_[i] = values[i]; }
+    }
     const Key* keys() const { return keys_.data(); }
     const Value* values() const { return vals_.data(); }
 

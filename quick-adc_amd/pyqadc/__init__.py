@@ -30,7 +30,7 @@ SYMBOLS = [
     "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit", "qadc_prescan_submit",
     "qadc_prescan_collect", "qadc_query_scan_submit_prescanned",
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
-    "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_replay_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
+    "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
 ]
 
 
@@ -40,7 +40,8 @@ class Profile(C.Structure):
                 ("start_codes", C.c_uint64), ("start_ms", C.c_double), ("candidates", C.c_uint64),
                 ("regrows", C.c_uint64), ("host_replay_ms", C.c_double), ("host_plan_ms", C.c_double),
                 ("host_heap_ms", C.c_double), ("host_sorted_queries", C.c_uint64), ("mq_launches", C.c_uint64),
-                ("pass_codes", C.c_uint64)]
+                ("pass_codes", C.c_uint64), ("wgq_launches", C.c_uint64), ("wgq_queries", C.c_uint64),
+                ("wgq_codes", C.c_uint64), ("wgq_ms", C.c_double)]
 
 
 class QadcError(RuntimeError):
@@ -103,6 +104,7 @@ def lib():
         L.qadc_pq_encode.argtypes = [C.c_int, C.c_int, f32p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.qadc_pq_encode_host.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_uint64, u8p, C.c_int]
         L.qadc_replay_i8.argtypes = [C.c_uint64, u32p, i8p, C.c_int, C.c_int, u32p, i8p, i32p]
+        L.qadc_sort_keys_i8.argtypes = [C.c_int, u32p, i8p, u32p]
         L.qadc_merge_streams_i8.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, i32p, C.c_uint64, C.c_int,
                                             C.c_int, i32p, u32p, i8p, i32p]
         L.qadc_candidates_i8.argtypes = [C.c_void_p, C.c_int, i8p, i8p]
@@ -130,6 +132,15 @@ def replay_i8(keys, vals, R, sentinel=False):
     _check(lib().qadc_replay_i8(len(keys), _p(keys, u32p), _p(vals, i8p), R, int(sentinel), _p(ok, u32p),
                                 _p(ov, i8p), C.byref(osz)))
     return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def sort_keys_i8(heap_keys, heap_vals):
+    """Host-only: kv_binheap::sort_keys of a heap array (binheap.hpp:129-137)."""
+    k = np.ascontiguousarray(heap_keys, np.uint32)
+    v = np.ascontiguousarray(heap_vals, np.int8)
+    out = np.zeros(len(k), np.uint32)
+    _check(lib().qadc_sort_keys_i8(len(k), _p(k, u32p), _p(v, i8p), _p(out, u32p)))
+    return out
 
 
 def merge_streams_i8(gathered, world, nq, R, cap, ma, q_first, q_step, status, keys, vals, sizes):

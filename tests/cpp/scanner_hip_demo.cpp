@@ -11,6 +11,15 @@
 #include <vector>
 
 #include "../../quick-adc_amd/host/scanner_hip.hpp"
+#ifdef QADC_USE_REFERENCE_HEAP
+// Built by oracle/Makefile with -I/root/reference: BhType is then the reference's OWN kv_binheap<unsigned, int8_t>
+// (binheap.hpp, compiled from where it lies) — the type nns_engine<scanner_4> hands to query_scan
+// (db_query_4.cpp:244).  The output of this flavour must equal the kv_heap flavour's line for line.
+#include "binheap.hpp"
+typedef kv_binheap<unsigned, std::int8_t> demo_heap;
+#else
+typedef qadc::kv_heap<unsigned, std::int8_t> demo_heap;
+#endif
 
 static std::uint64_t splitmix64(std::uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -62,7 +71,7 @@ int main(int argc, char** argv) {
         for (unsigned i = 0; i < sizes[p]; ++i) l[i] = 1000000u * (p + 1) + 7u * i;
         db.labels.push_back(l);
     }
-    typedef qadc::scanner_hip<mini_db> Scanner;
+    typedef qadc::scanner_hip<mini_db, demo_heap> Scanner;
     Scanner scanner(keep);
     scanner.prepare_database(db);
     qadc::no_metrics metrics;
@@ -76,6 +85,11 @@ int main(int argc, char** argv) {
         scanner.query_scan(nullptr, assign.data(), ma, tables.data(), M * 16, bh, metrics);
         std::printf("q %d size %d\n", q, bh.size());
         for (int i = 0; i < bh.size(); ++i) std::printf("%u %d\n", bh.keys()[i], (int)bh.values()[i]);
+        std::vector<unsigned> sorted(bh.size() > 0 ? bh.size() : 1);
+        bh.sort_keys(sorted.data());                       // binheap.hpp:129-137
+        std::printf("sorted");
+        for (int i = 0; i < bh.size(); ++i) std::printf(" %u", sorted[i]);
+        std::printf("\n");
     }
     return 0;
 }

@@ -39,6 +39,17 @@ def test_host_replay_matches_reference_golden(pyqadc):
         assert np.array_equal(k, g["h%d_keys" % i]) and np.array_equal(v, g["h%d_vals" % i]), i
 
 
+def test_sort_keys_matches_reference_golden(pyqadc, po):
+    """kv_heap::sort_keys on the reference's final heap arrays == the reference's own bh.sort_keys() output
+    (binheap.hpp:129-137; tie order of an unstable std::sort), all golden scan cases."""
+    g = golden_cases.load()
+    n = 0
+    for c in golden_cases.scan_cases(g, po):
+        assert np.array_equal(pyqadc.sort_keys_i8(c["keys"], c["vals"]), c["sorted"]), c["cid"]
+        n += 1
+    assert n >= 50
+
+
 def test_host_replay_random_vs_oracle(pyqadc, po):
     rng = np.random.default_rng(0)
     for n, R, vmax in ((0, 5, 3), (1, 1, 3), (1000, 7, 2), (20000, 100, 126)):

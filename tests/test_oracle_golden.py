@@ -118,3 +118,26 @@ def test_scan_standard_8x8(po):
     for m in range(8):
         s = (s + d[:, m]).astype(np.float32)
     assert len(keys) == 100 and np.array_equal(np.sort(vals), np.sort(s)[:100])
+
+
+def test_oracle_sort_keys_matches_reference_golden(po):
+    """The oracle's restatement of libstdc++'s introsort (orc_sort_keys_i8) reproduces the reference build's
+    bh.sort_keys() on every golden case — including the order of tied values."""
+    g = golden_cases.load()
+    ties = 0
+    for c in golden_cases.scan_cases(g, po):
+        got = po.sort_keys_i8(c["keys"], c["vals"])
+        assert np.array_equal(got, c["sorted"]), c["cid"]
+        ties += int(len(np.unique(c["vals"])) < len(c["vals"]))
+    assert ties > 10          # the pin is only meaningful if ties occur
+
+
+def test_oracle_sort_keys_vs_reference_build_random(po):
+    if not po.have_ref():
+        pytest.skip("reference build absent")
+    rng = np.random.default_rng(11)
+    for n, R, vmax in ((3, 5, 2), (16, 16, 3), (17, 17, 1), (100, 100, 5), (400, 257, 3), (5000, 1000, 2), (3000, 2048, 126)):
+        keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+        vals = rng.integers(0, vmax + 1, n).astype(np.int8)
+        k, v, want = po.ref_heap_replay_i8(keys, vals, R, want_sorted=True)
+        assert np.array_equal(po.sort_keys_i8(k, v), want), (n, R, vmax)

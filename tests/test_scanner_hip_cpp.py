@@ -28,13 +28,35 @@ def test_scanner_hip_builds_as_cxx14():
     assert os.path.exists(EXE)
 
 
+REFHEAP_EXE = os.path.join(ROOT, "oracle", "_ref", "scanner_hip_demo_refheap")
+
+
+def test_scanner_hip_builds_with_the_reference_kv_binheap():
+    """scanner_hip<mini_db, kv_binheap<unsigned, int8_t>> compiled (-Wall -Werror, C++14) against the reference's own
+    binheap.hpp where it lies — the BhType nns_engine<scanner_4> uses (db_query_4.cpp:244).  Only possible where
+    /root/reference exists (oracle/Makefile `ref`); the binary travels to the GPU box in oracle/_ref/."""
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("/root/reference absent (GPU box): the prebuilt binary is used")
+    import __graft_entry__
+    __graft_entry__.build()
+    assert os.path.exists(REFHEAP_EXE)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("flavour", ["kv_heap", "reference_kv_binheap"])
 @pytest.mark.parametrize("M,sizes,labeled,ma", [(16, [60000], 0, 1), (16, [20000, 37, 9000, 15001], 1, 3),
                                                  (32, [30000, 12345], 1, 2)])
-def test_scanner_hip_fills_heap_like_oracle(po, M, sizes, labeled, ma):
+def test_scanner_hip_fills_heap_like_oracle(po, M, sizes, labeled, ma, flavour):
+    """Both heap types the scanner can be instantiated with — the library's kv_heap and the reference's own
+    kv_binheap (binheap.hpp compiled from /root/reference) — end in the oracle's heap arrays and sort_keys order."""
     build_demo()
+    exe = EXE
+    if flavour == "reference_kv_binheap":
+        exe = REFHEAP_EXE
+        if not os.path.exists(exe):
+            pytest.skip("oracle/_ref/scanner_hip_demo_refheap was not built (needs /root/reference at build time)")
     keep, R, nq, seed = 0.02, 100, 3, 4242
-    out = subprocess.check_output([EXE, str(M), str(len(sizes))] + [str(s) for s in sizes] +
+    out = subprocess.check_output([exe, str(M), str(len(sizes))] + [str(s) for s in sizes] +
                                   [str(labeled), str(keep), str(R), str(nq), str(ma), str(seed)]).decode().split("\n")
     cs = M // 2
     parts = [po.fill_codes(0, (s * cs + 7) // 8, seed + p)[:s * cs].reshape(s, cs).copy() for p, s in enumerate(sizes)]
@@ -52,9 +74,12 @@ def test_scanner_hip_fills_heap_like_oracle(po, M, sizes, labeled, ma):
         assert hdr[0] == "q" and int(hdr[1]) == q
         size = int(hdr[3])
         rows = np.array([[int(x) for x in l.split()] for l in out[line + 1:line + 1 + size]], np.int64).reshape(size, 2)
-        line += 1 + size
+        srt = out[line + 1 + size].split()
+        assert srt[0] == "sorted"
+        line += 2 + size
         assert size == len(want["keys"])
         assert np.array_equal(rows[:, 0].astype(np.uint32), want["keys"]) and np.array_equal(rows[:, 1].astype(np.int8), want["values"])
+        assert np.array_equal(np.array(srt[1:], np.uint64).astype(np.uint32), po.sort_keys_i8(want["keys"], want["values"]))
 
 
 DRIVER = os.path.join(ROOT, "tests", "cpp", "db_query_4_hip")
