@@ -18,6 +18,7 @@
 #include <cfloat>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -1226,6 +1227,7 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     idx->M = M;
     idx->cs = M / 2;
     idx->device = device_id;
+    if (const char* e = std::getenv("QADC_WGQ")) idx->wgq = std::atoi(e);   // test hook: force (2) / forbid (0) the one-workgroup-per-query path
     // The streaming launches fill every CU for milliseconds.  They go on the LOWEST-priority queue so that the
     // short work that must overlap them is dispatched as soon as a workgroup slot frees up instead of waiting for
     // the whole batch: the previous batch's candidate sort, the next batch's front (own streams, highest priority) and

@@ -33,3 +33,22 @@ def po():
     import pyoracle
     pyoracle.build()
     return pyoracle
+
+
+def pytest_generate_tests(metafunc):
+    """Every GPU parity test runs through BOTH scan paths of the library: the level-structured one (QADC_WGQ=0:
+    bound levels, many workgroups per run, candidate sort) and the one-workgroup-per-query one (QADC_WGQ=2, wherever
+    it is structurally possible).  The environment variable is read by qadc_index_create; a test that sets the `wgq`
+    option itself overrides it."""
+    if metafunc.module.__name__.endswith("test_bench_launch"):
+        return                                             # bench.py picks its own paths (and clears QADC_WGQ)
+    if metafunc.definition.get_closest_marker("gpu") and "scan_path" in metafunc.fixturenames:
+        metafunc.parametrize("scan_path", ["levels", "wgq"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def scan_path(request, monkeypatch):
+    mode = getattr(request, "param", None)
+    if mode is not None:
+        monkeypatch.setenv("QADC_WGQ", "0" if mode == "levels" else "2")
+    return mode

@@ -189,6 +189,7 @@ def test_candidate_buffer_regrow_is_exact(pyqadc, po):
     idx = pyqadc.Index(16)
     idx.add_partitions([codes])
     idx.finalize(0.01)
+    idx.set_option("wgq", 0)                # this test is about the level-structured path's own fallbacks
     idx.set_option("cand_capacity", 16)      # far too small: forces the overflow -> regrow -> rerun path
     idx.set_option("profile", 1)
     qt = rand_qtables(rng, (2, 1), 16, 20)
@@ -242,6 +243,7 @@ def test_host_sort_fallback_when_a_query_has_too_many_candidates(pyqadc, po):
     idx = pyqadc.Index(16)
     idx.add_partitions([codes])
     idx.finalize(0.01)
+    idx.set_option("wgq", 0)                # this test is about the level-structured path's own fallbacks
     idx.set_option("level_base", 1 << 20)
     idx.set_option("profile", 1)
     qt = rand_qtables(rng, (2, 1), 16, 30)
@@ -288,6 +290,7 @@ def test_prescan_survivor_overflow_falls_back_to_full_prescan(pyqadc, po):
     idx = pyqadc.Index(M)
     idx.add_partitions([codes])
     idx.finalize(keep)
+    idx.set_option("wgq", 0)                # this test is about the level-structured path's own fallbacks
     idx.set_option("prescan_sample", 4096)
     idx.set_option("profile", 1)
     res = idx.query_scan(np.zeros((2, 1), np.int32), tables.copy(), 100, want_qtables=True)
@@ -750,6 +753,7 @@ def test_pipelined_slots_with_regrows_and_changing_batch_shapes(pyqadc, po):
     idx = pyqadc.Index(M)
     idx.add_partitions(parts)
     idx.finalize(keep)
+    idx.set_option("wgq", 0)                # this test is about the level-structured path's own fallbacks
     idx.set_option("small_run", 8192)
     idx.set_option("cand_capacity", 32)
     batches = []
@@ -779,4 +783,147 @@ def test_pipelined_slots_with_regrows_and_changing_batch_shapes(pyqadc, po):
             want = po.query_scan(M, parts, None, keep, assign[q], tables[q].copy(), R)
             n = int(r["sizes"][q])
             assert heaps_equal((r["keys"][q, :n], r["values"][q, :n]), (want["keys"], want["values"])), (b, q)
+    idx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one workgroup per query (qadc_query_kernel.hip): the path IVF batches and small lists take
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 32])
+def test_wgq_stream_capacity_regrow_is_exact(pyqadc, po, M):
+    rng = np.random.default_rng(80 + M)
+    parts = [rand_codes(rng, n, M) for n in (90001, 37, 20000)]
+    labels = [rng.permutation(1 << 20)[:len(p)].astype(np.uint32) for p in parts]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(0.01)
+    idx.set_option("wgq", 2)
+    idx.set_option("wgq_capacity", 16)       # far too small: overflow -> every entry counted -> regrown -> re-run
+    idx.set_option("profile", 1)
+    assign = np.array([[0, 1, 2], [2, 0, 1], [1, 1, 0]], np.int32)
+    qt = rand_qtables(rng, (3, 3), M, 20)
+    got = idx.scan_i8(assign, qt, 100)
+    pr = idx.profile()
+    assert pr["regrows"] >= 1 and pr["wgq_launches"] >= 2 and pr["scan_launches"] == 0
+    for q in range(3):
+        want = po.scan_i8(M, [parts[p] for p in assign[q]], [labels[p] for p in assign[q]], qt[q], 100)
+        assert heaps_equal(got[q], want), q
+    idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,n,keep", [(16, 2000003, 0.01), (32, 1200001, 0.02)])
+def test_wgq_prescan_values_beyond_the_lds_budget(pyqadc, po, M, n, keep):
+    """More starts than the kernel keeps in LDS (12288 / 8192 values): the values go through the global scratch and
+    the select reads them from there — qmin, qmax, int8 tables and heaps must still equal the oracle's."""
+    rng = np.random.default_rng(5 + M)
+    codes = rand_codes(rng, n, M)
+    idx = pyqadc.Index(M)
+    idx.add_partitions([codes])
+    idx.finalize(keep)
+    idx.set_option("wgq", 2)
+    tables = float_tables(rng, 2, 1, M)
+    got = idx.query_scan(np.zeros((2, 1), np.int32), tables.copy(), 100, want_qtables=True)
+    for q in range(2):
+        want = po.query_scan(M, [codes], None, keep, [0], tables[q].copy(), 100)
+        assert got["qmax"][q] == np.float32(want["qmax"]) and got["qmin"][q] == np.float32(want["qmin"])
+        assert np.array_equal(got["qtables"][q], want["qtables"])
+        assert heaps_equal(got["heaps"][q], (want["keys"], want["values"])), q
+    idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [1, 7, 100, 288, 289, 1000])
+def test_wgq_device_replay_lanes_and_host_replay_agree(pyqadc, po, R):
+    """Batches of >= 64 queries replay on the device, one lane per query (replay_heap_lanes_kernel, R <= 288);
+    larger heaps and small batches replay on the host.  Ragged labelled partitions, tie-heavy tables, ma = 5."""
+    rng = np.random.default_rng(R)
+    M, K, ma, nq = 16, 12, 5, 130
+    sizes = [int(x) for x in rng.integers(1, 9000, K)]
+    sizes[3] = 0
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(0.05)
+    idx.set_option("wgq", 2)
+    assign = np.stack([rng.permutation(K)[:ma] for _ in range(nq)]).astype(np.int32)
+    qt = rand_qtables(rng, (nq, ma), M, 9)
+    got = idx.scan_i8(assign, qt, R)
+    idx.set_option("device_replay_nq", 0)
+    got_host = idx.scan_i8(assign, qt, R)
+    for q in range(nq):
+        want = po.scan_i8(M, [parts[p] for p in assign[q]], [labels[p] for p in assign[q]], qt[q], R)
+        assert heaps_equal(got[q], want), q
+        assert heaps_equal(got_host[q], want), q
+    idx.close()
+
+
+@pytest.mark.gpu
+def test_wgq_pipelined_slots_changing_shapes_with_regrows(pyqadc, po):
+    rng = np.random.default_rng(321)
+    M, keep = 16, 0.02
+    sizes = [120000, 3000, 45001, 16, 0, 70000]
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts)
+    idx.finalize(keep)
+    idx.set_option("wgq", 2)
+    idx.set_option("wgq_capacity", 64)
+    idx.set_option("profile", 1)
+    batches = []
+    for b in range(9):
+        nq = int(rng.choice([1, 3, 12, 70]))
+        ma = int(rng.integers(1, 5))
+        R = int(rng.choice([5, 50, 100]))
+        assign = np.stack([rng.permutation(len(sizes))[:ma] for _ in range(nq)]).astype(np.int32)
+        batches.append((assign, float_tables(rng, nq, ma, M, negatives=(b % 3 == 0)), R))
+    pending, results = [], {}
+    for b, (assign, tables, R) in enumerate(batches):
+        idx.submit(b % 3, assign, tables, R)
+        pending.append(b)
+        if len(pending) == 3:
+            d = pending.pop(0)
+            results[d] = idx.collect(d % 3)
+    while pending:
+        d = pending.pop(0)
+        results[d] = idx.collect(d % 3)
+    assert idx.profile()["regrows"] >= 3
+    for b, (assign, tables, R) in enumerate(batches):
+        res = results[b]
+        for q in range(assign.shape[0]):
+            # the submitted tables were clamped in place by collect; the oracle clamps its own copy the same way
+            want = po.query_scan(M, parts, None, keep, assign[q], tables[q].copy(), R)
+            if want["rc"] != 0:
+                assert res["status"][q] == 1
+                continue
+            sz = res["sizes"][q]
+            assert heaps_equal((res["keys"][q, :sz], res["values"][q, :sz]), (want["keys"], want["values"])), (b, q)
+    idx.close()
+
+
+@pytest.mark.gpu
+def test_wgq_search_keeps_assign_on_the_device(pyqadc, po):
+    """qadc_search on the one-workgroup-per-query path: coarse assignment, tables, pre-scan, quantizer, scan and (for
+    >= 64 queries) the heap replay all stay on the GPU; assign[] only comes back for the caller.  Equal to the
+    level-structured path of the same index, query for query."""
+    rng = np.random.default_rng(77)
+    M, K, ma, nq, dim = 16, 40, 6, 96, 64
+    sizes = [int(x) for x in rng.integers(200, 6000, K)]
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    labels = [rng.permutation(1 << 22)[:n].astype(np.uint32) for n in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(0.03)
+    idx.set_pq(rng.normal(size=(M, 16, dim // M)).astype(np.float32))
+    idx.set_coarse(rng.normal(size=(K, dim)).astype(np.float32))
+    queries = rng.normal(size=(nq, dim)).astype(np.float32)
+    idx.set_option("wgq", 2)
+    a = idx.search(queries, ma, 100)
+    idx.set_option("wgq", 0)
+    b = idx.search(queries, ma, 100)
+    assert np.array_equal(a["assign"], b["assign"]) and np.array_equal(a["status"], b["status"])
+    for q in range(nq):
+        assert heaps_equal(a["heaps"][q], b["heaps"][q]), q
     idx.close()
