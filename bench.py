@@ -95,7 +95,7 @@ def cpu_baseline(M, n_total, qtables, seconds):
     dt = time.perf_counter() - t0
     model, cpus = po.host_topology()
     return {"value": n * nqueries / dt, "unit": "codes/s", "cores": 1, "kind": kind,
-            "cpu_model": model, "physical_cores_available": len(cpus),
+            "cpu_model": model, "physical_cores_usable": len(cpus),
             "build_flags": "g++ -std=c++14 -O3 -m64 -mavx2 -mfma -mpopcnt -mbmi2 -ffast-math (the reference's "
                            "CMakeLists.txt:7 flags with -march=native replaced by that explicit ISA set so that the "
                            "prebuilt library runs on any AVX2 host)" if kind == "reference" else "gcc -std=c11 -O2",
@@ -124,8 +124,9 @@ def cpu_extra_legs(M, n_total, qtables, seconds):
         done, dt = po.ref_scan_mt(M, inter, n, qtables, R, cpus, seconds)
         out["cpu_baseline_all_cores"] = {
             "value": n * done / dt, "unit": "codes/s", "cores": len(cpus), "kind": "reference", "cpu_model": model,
-            "sample": "%d whole queries x %d codes in %.1f s: one pinned C++ thread per physical core (%d), each with "
-                      "its own first-touched copy of the first %d codes of the list" % (done, n, dt, len(cpus), n)}
+            "sample": "%d whole queries x %d codes in %.1f s: one pinned C++ thread per physical core this process may "
+                      "keep busy (%d: physical cores in its affinity mask, capped by the container's cgroup CPU quota), "
+                      "each with its own first-touched copy of the first %d codes of the list" % (done, n, dt, len(cpus), n)}
     rng = np.random.default_rng(5)
     codes8 = rng.integers(0, 256, (1000000, 8), dtype=np.uint8)
     tables8 = rng.random((1, 8, 256)).astype(np.float32)

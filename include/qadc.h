@@ -262,6 +262,8 @@ typedef struct qadc_profile {
     uint64_t wgq_queries;     /* queries in them */
     uint64_t wgq_codes;       /* codes they probed (algorithmic bytes = codes * M/2) */
     double wgq_ms;            /* HIP-event time of those launches */
+    uint64_t wgq_front_cycles; /* shader cycles the query workgroups spent in pre-scan + select + quantizer (summed over queries) */
+    uint64_t wgq_scan_cycles;  /* ... and in the int8 scan */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

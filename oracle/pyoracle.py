@@ -302,6 +302,23 @@ def host_topology():
         if sib not in seen:
             seen.add(sib)
             cpus.append(c)
+    # a container may see every core of the host but be allowed only a CPU-time quota (cgroup v2 cpu.max / v1
+    # cfs_quota): more runnable threads than that are throttled, so the "all cores" leg uses at most that many
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < len(cpus):
+        cpus = cpus[:max(1, int(quota))]
     return model, cpus
 
 

@@ -163,6 +163,7 @@ struct Slot {
     uint64_t wgq_fcap = 0;              // pre-scan values per query in the global scratch (0 = they fit LDS)
     DevBuf<uint32_t> d_qflags;          // [nq][4]: {flags, entries} for replay_heap_lanes_kernel
     DevBuf<float> d_fvals;
+    DevBuf<QCand> d_qcands;             // unordered candidates of the query workgroups (scratch)
     PinBuf<uint64_t> h_fetch;           // streams fetched on demand when they were left in device memory
     bool assign_on_device = false;      // qadc_search: assign[] was produced on the GPU and copied back asynchronously
     hipEvent_t ev_assign = nullptr;
@@ -241,6 +242,8 @@ struct qadc_index {
     uint64_t wgq_max_codes = 1ull << 24; //   ... probing at most this many codes per query (estimate), or
     uint64_t wgq_small_codes = 1ull << 18;   // any batch probing at most this many codes per query
     uint32_t wgq_capacity = 4096;        // stream entries per query to start with
+    int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
+    uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)
     DevBuf<PartDesc> d_partdesc;         // device partition table (qadc_index_finalize)
     uint32_t max_start_n = 0;
     uint64_t total_codes = 0;
@@ -811,6 +814,8 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     }
     s.wgq_fcap = fcap;
     if (fcap) HIPCHECK(s.d_fvals.ensure((size_t)nq * fcap));
+    const uint32_t ccap = std::min<uint32_t>(idx->wgq_cand_cap, kQueryCandCap);
+    HIPCHECK(s.d_qcands.ensure((size_t)nq * ccap));
 
     bool alone = true;
     for (int i = 0; i < kSlots; ++i) alone = alone && (&idx->slot[i] == &s || !idx->slot[i].busy);
@@ -850,14 +855,15 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     A.fvals = fcap ? s.d_fvals.p : nullptr;
     A.fcap = (uint32_t)fcap;
     A.stream = s.dev_replay ? s.d_stream.p : s.d_entries;
-    A.stream2 = nullptr;
     A.cap = cap;
+    A.cands = s.d_qcands.p;
+    A.ccap = ccap;
     A.qout = s.d_qout;
     A.qstate_flags = s.dev_replay ? s.d_qflags.p : nullptr;
     A.R = (uint32_t)s.R;
     A.quant_mode = idx->quant_mode;
     if (idx->profile) HIPCHECK(prof_event(s, st));
-    HIPCHECK(launch_scan_query(M, nq, A, st));
+    HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st));
     if (idx->profile) HIPCHECK(prof_event(s, st));
     if (s.dev_replay) {
         if (!alone) {                                       // replay on the side stream, under the next batch's scan
@@ -1007,10 +1013,31 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
     if (int rc = use_device(idx)) return rc;
     const uint32_t sort_limit_max = kSortCap;
     uint64_t total_sorted = 0;
+    if (s.assign_on_device) {                                  // qadc_search: assign[] comes back for the caller (and the planner)
+        HIPCHECK(hipEventSynchronize(s.ev_assign));
+        s.assign.assign(s.h_assign.p, s.h_assign.p + (size_t)s.nq * s.ma);
+        s.assign_on_device = false;
+    }
     for (int attempt = 0; s.wgq; ++attempt) {                  // one workgroup per query: per-query stream capacity only
         HIPCHECK(hipEventSynchronize(s.ev_done));
         uint64_t max_count = 0;
-        for (int q = 0; q < s.nq; ++q) max_count = std::max<uint64_t>(max_count, s.h_qout[q].count);
+        bool cand_overflow = false;
+        for (int q = 0; q < s.nq; ++q) {
+            max_count = std::max<uint64_t>(max_count, s.h_qout[q].count);
+            cand_overflow |= (s.h_qout[q].flags & 32u) != 0;
+        }
+        if (cand_overflow) {
+            // some query emitted more candidates than a workgroup sorts in LDS (adversarial order, all-equal tables):
+            // the level-structured path has the machinery for that (regrow, host sort) — run the batch through it
+            idx->prof.regrows++;
+            s.wgq = false;
+            s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)s.nq * 8192u, 1ull << 30));
+            if (int rc = plan_and_launch(idx, s)) {
+                s.busy = false;
+                return rc;
+            }
+            break;
+        }
         if (max_count <= s.wgq_cap) break;
         if (attempt >= 2 || max_count + 64 > (1ull << 31)) {
             s.busy = false;
@@ -1022,10 +1049,6 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
             s.busy = false;
             return rc;
         }
-    }
-    if (s.assign_on_device) {                                  // qadc_search: assign[] comes back for the caller
-        HIPCHECK(hipEventSynchronize(s.ev_assign));
-        s.assign.assign(s.h_assign.p, s.h_assign.p + (size_t)s.nq * s.ma);
     }
     for (int attempt = 0; !s.wgq; ++attempt) {
         HIPCHECK(hipEventSynchronize(s.ev_done));
@@ -1062,6 +1085,10 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
         if (s.prof_used >= 2) HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[0], s.prof_ev[1]));
         idx->prof.wgq_ms += ms;
         idx->prof.wgq_launches++;
+        for (int q = 0; q < s.nq; ++q) {
+            idx->prof.wgq_front_cycles += (uint64_t)s.h_qout[q].pad[0] << 4;
+            idx->prof.wgq_scan_cycles += (uint64_t)s.h_qout[q].pad[1] << 4;
+        }
         idx->prof.wgq_queries += (uint64_t)s.nq;
         for (int q = 0; q < s.nq; ++q)
             for (int a = 0; a < s.ma; ++a) idx->prof.wgq_codes += idx->parts[s.assign[(size_t)q * s.ma + a]].n;
@@ -1268,7 +1295,7 @@ int qadc_index_destroy(qadc_index* idx) {
         Slot& s = *sp;
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
         s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
-        s.h_cands.release(); s.d_stream.release(); s.d_qflags.release(); s.d_fvals.release(); s.h_fetch.release();
+        s.h_cands.release(); s.d_stream.release(); s.d_qflags.release(); s.d_fvals.release(); s.d_qcands.release(); s.h_fetch.release();
         if (s.ev_assign) (void)hipEventDestroy(s.ev_assign);
         s.d_queries.release(); s.d_assign.release(); s.d_cdist.release(); s.h_queries.release(); s.h_assign.release();
         if (s.ev_feed) (void)hipEventDestroy(s.ev_feed);
@@ -1535,6 +1562,8 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "small_vec_per_wg") idx->small_vec_per_wg = (uint32_t)std::max(256.0, value);
     else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
     else if (n == "wgq") idx->wgq = (int)value;
+    else if (n == "wgq_variant") idx->wgq_variant = (int)value;
+    else if (n == "wgq_cand_cap") idx->wgq_cand_cap = (uint32_t)std::max(1.0, std::min(value, (double)kQueryCandCap));
     else if (n == "wgq_min_nq") idx->wgq_min_nq = (int)std::max(value, 1.0);
     else if (n == "wgq_max_codes") idx->wgq_max_codes = (uint64_t)std::max(value, 0.0);
     else if (n == "wgq_small_codes") idx->wgq_small_codes = (uint64_t)std::max(value, 0.0);

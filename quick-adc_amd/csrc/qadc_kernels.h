@@ -95,6 +95,15 @@ struct PartDesc {
     uint32_t pad;
 };
 
+// Unordered candidate of the one-workgroup-per-query scan (sorted by (slot, pos) inside the workgroup afterwards).
+struct QCand {
+    uint32_t key;       // label, or key_base + first_pos + pos
+    uint32_t val_reps;  // value | extra padding-lane replays << 8
+    uint32_t pos;       // position inside the partition's local range
+    uint32_t slot;      // assign slot
+};
+constexpr uint32_t kQueryCandCap = 4096;   // candidates per query the in-workgroup sort takes (64 KiB of LDS)
+
 struct QueryKernelArgs {
     const PartDesc* parts;
     const int32_t* assign;   // [nq][ma] probed partitions in scan order
@@ -104,8 +113,9 @@ struct QueryKernelArgs {
     float* fvals;            // [nq][fcap] scratch for a query's pre-scan values when they exceed the LDS budget
     uint32_t fcap;
     uint64_t* stream;        // [nq][cap] ordered push stream: key | value << 32 | assign slot << 40
-    uint64_t* stream2;       // optional second copy (device memory, for the device replay), or nullptr
     uint32_t cap;
+    QCand* cands;            // [nq][ccap] unordered candidates (scratch)
+    uint32_t ccap;           // <= kQueryCandCap
     QueryOut* qout;          // [nq]
     uint32_t* qstate_flags;  // optional [nq][4]: {flags, entries} for replay_heap_lanes_kernel, or nullptr
     uint32_t R;
@@ -114,7 +124,7 @@ struct QueryKernelArgs {
 
 size_t query_kernel_lds_bytes(int M);
 uint32_t query_kernel_lds_values(int M);       // pre-scan values a query may have before fvals is needed
-hipError_t launch_scan_query(int M, int nq, const QueryKernelArgs& args, hipStream_t stream);
+hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& args, hipStream_t stream);
 // kv_binheap push replay of the ordered streams, 64 queries per wave (one lane each); R <= replay_lanes_max_R().
 uint32_t replay_lanes_max_R();
 hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,

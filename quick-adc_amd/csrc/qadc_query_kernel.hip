@@ -29,6 +29,7 @@
 #include "qadc_kernels.h"
 
 #include <cfloat>
+#include <type_traits>
 
 namespace qadc {
 
@@ -52,18 +53,82 @@ __device__ __forceinline__ void q_wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store
+// (s_waitcnt vmcnt(0)): in the scan loop that would stall all 16 waves for the write latency of the few stream
+// entries one of them just stored — to device memory, or over PCIe to the host-mapped result block.
+__device__ __forceinline__ void q_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// LDS image.  The scan's pair tables are BANK-REPLICATED (conflict-free for any code data, see qadc_kernels.hip):
+// for code byte b = 4g + j the table P_b[x] = T[2b][x & 15] + T[2b+1][x >> 4] sits at
+//     region(g) + x*256 + (g&1)*128 + bank*4 + j,  bank = 0..31,  region(g) = (g>>1) * 64 KiB,
+// one dword = the four tables of a code dword, replicated over the 32 banks of a ds_read lane group; a lane reads
+// with bank = lane & 31.  64 KiB (16x4: two workgroups per CU) / 128 KiB (32x4: one).  The tables start at LDS
+// address 0 (absolute addressing spares an add per lookup) and OVERLAY the pre-scan's buffers, which are dead by then.
 template <int M>
 struct QCfg {
     static constexpr int CS = M / 2, DW = M / 8, CPL = 16 / CS;
-    static constexpr int FCAP = M == 16 ? 12288 : 8192;          // pre-scan values kept in LDS
-    static constexpr int VALS_OFF = 0;                           // float[FCAP]
-    static constexpr int WTAB_OFF = VALS_OFF + FCAP * 4;         // float[16 waves][M*16] (pre-scan); later:
-    static constexpr int PTAB_OFF = WTAB_OFF;                    //   u8[CS*256] pair tables
-    static constexpr int TQ_OFF = PTAB_OFF + CS * 256;           //   u8[M*16] staged int8 table
-    static constexpr int MISC_OFF = WTAB_OFF + kQWaves * M * 16 * 4;
+    static constexpr int TABLE_BYTES = (M / 16) * 65536;
+    static constexpr int WTAB_BYTES = kQWaves * M * 16 * 4;      // float[16 waves][M*16] (pre-scan)
+    static constexpr int FCAP = (TABLE_BYTES - WTAB_BYTES) / 4;  // pre-scan values kept in LDS: 12288 / 24576
+    static constexpr int VALS_OFF = 0;                           // float[FCAP]        } pre-scan phase
+    static constexpr int WTAB_OFF = FCAP * 4;                    // float[16][M*16]    }
+    static constexpr int TQ_OFF = TABLE_BYTES;                   // u8[M*16] staged int8 table
+    static constexpr int MISC_OFF = TABLE_BYTES + 512;
     // misc (u32 words): [0..255] radix histogram / [0..127] value histogram, then scalars
     static constexpr int LDS_BYTES = MISC_OFF + (256 + 64 + 64) * 4;
+    static constexpr int OCC = M == 16 ? 8 : 4;                  // waves per SIMD the register budget is sized for
 };
+
+typedef const __attribute__((address_space(3))) unsigned char* q_lds_bytes_t;
+
+// sum of the M/2 pair-table entries of one code (DW dwords at d): ONE v_perm_b32 forms each LDS address
+// (byte0 = bank*4 of the lane, byte1 = code byte, byte2 = region), the table index rides in the immediate offset
+template <int M>
+__device__ __forceinline__ uint32_t q_pair_sum(const uint32_t* d, uint32_t lane_lo, uint32_t lane_hi) {
+    // all M/2 addresses first, then all M/2 reads, then the adds: the reads of a code (and, unrolled, of the codes
+    // around it) are in flight together instead of waiting out one LDS latency per pair
+    uint32_t a[M / 2], v[M / 2];
+#pragma unroll
+    for (int w = 0; w < M / 8; ++w) {
+        const uint32_t lo = (w >> 1) ? lane_hi : lane_lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[w * 4 + k] = __builtin_amdgcn_perm(d[w], lo, 0x0c020000u | ((4u + k) << 8));
+    }
+#pragma unroll
+    for (int w = 0; w < M / 8; ++w)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            v[w * 4 + k] = *reinterpret_cast<q_lds_bytes_t>(static_cast<uintptr_t>(a[w * 4 + k] + (w & 1) * 128 + k));
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < M / 2; ++i) s += v[i];
+    return s;
+}
+
+// A partition descriptor whose fields are forced into scalar registers: the probed partition is the same for the
+// whole workgroup, but the compiler cannot prove that loads through assign[] are uniform.
+struct UDesc {
+    const uint8_t* codes;
+    const uint32_t* labels;
+    uint32_t n, global_n, first_pos, key_base;
+};
+__device__ __forceinline__ uint32_t q_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t q_uni64(uint64_t v) {
+    return ((uint64_t)q_uni((uint32_t)(v >> 32)) << 32) | q_uni((uint32_t)v);
+}
+__device__ __forceinline__ UDesc q_load_desc(const PartDesc* __restrict__ parts, int p) {
+    const PartDesc& s = parts[p];
+    UDesc d;
+    d.codes = reinterpret_cast<const uint8_t*>(q_uni64(reinterpret_cast<uint64_t>(s.codes)));
+    d.labels = reinterpret_cast<const uint32_t*>(q_uni64(reinterpret_cast<uint64_t>(s.labels)));
+    d.n = q_uni(s.n);
+    d.global_n = q_uni(s.global_n);
+    d.first_pos = q_uni(s.first_pos);
+    d.key_base = q_uni(s.key_base);
+    return d;
+}
 
 // Bound = smallest v such that at least R emitted candidates have value <= v, else 127 (wave 0, lanes own bins 2l, 2l+1).
 __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint32_t R, uint32_t lane) {
@@ -83,17 +148,18 @@ __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint
     return min(b, 127u);
 }
 
-template <int M, int U>
-__global__ __launch_bounds__(kQWG, 8) void scan_query_kernel(QueryKernelArgs A) {
+// OCC = waves per SIMD the register budget is sized for: 8 = two workgroups per CU (64 VGPRs), 4 = one (128 VGPRs).
+template <int M, int U, int OCC>
+__global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A) {
     using C = QCfg<M>;
+    if (reinterpret_cast<uintptr_t>((q_lds_bytes_t)qsmem) != 0) __builtin_trap();   // the lookups use absolute LDS addresses
     constexpr int CS = C::CS, DW = C::DW, CPL = C::CPL;
     float* vals = reinterpret_cast<float*>(qsmem + C::VALS_OFF);
     float* wtab = reinterpret_cast<float*>(qsmem + C::WTAB_OFF);
-    unsigned char* ptab = qsmem + C::PTAB_OFF;
     unsigned char* tq = qsmem + C::TQ_OFF;
     uint32_t* misc = reinterpret_cast<uint32_t*>(qsmem + C::MISC_OFF);
     uint32_t* hist = misc;                       // [256] during the select, [128] value histogram during the scan
-    uint32_t* wcnt = misc + 256;                 // [U][16] per-wave entry counts of one emission round
+    uint32_t* wcnt = misc + 256;                 // [16] per-wave entry counts of one segment (+ pre-scan hand-over slots)
     uint32_t& s_nvals = misc[320];
     uint32_t& s_prefix = misc[321];
     uint32_t& s_k = misc[322];
@@ -110,9 +176,9 @@ __global__ __launch_bounds__(kQWG, 8) void scan_query_kernel(QueryKernelArgs A) 
     const size_t tbase = (size_t)q * ma * (M * 16);
     int8_t* __restrict__ qt_all = A.qtables + tbase;
     uint64_t* __restrict__ stream = A.stream + (size_t)q * A.cap;
-    uint64_t* __restrict__ stream2 = A.stream2 ? A.stream2 + (size_t)q * A.cap : nullptr;
     const uint32_t R = A.R;
 
+    const uint64_t clk0 = __builtin_readcyclecounter();          // phase clocks (QueryOut::pad): 1/16 shader cycles
     if (tid < 256) hist[tid] = 0;
     if (tid == 0) { s_nvals = 0; s_any[0] = s_any[1] = s_any[2] = 0; s_count = 0; s_bound = 127; }
     __syncthreads();
@@ -281,135 +347,243 @@ __global__ __launch_bounds__(kQWG, 8) void scan_query_kernel(QueryKernelArgs A) 
         return;
     }
 
-    // ---- 3. int8 scan in assign[] order ----
+    const uint64_t clk1 = __builtin_readcyclecounter();
+    // ---- 3. int8 scan in assign[] order: free-running waves, epochs, one in-workgroup sort at the end ----
+    // The query's scan order is cut into EPOCHS: 64, 128, 256, ... vectors at the start (while the bound is loose),
+    // then one epoch per probed partition (long partitions: one per kEpochVec vectors).  Inside an epoch the 16 waves
+    // run WITHOUT any barrier: wave w takes the tiles (round*16 + w) of 64 vectors, kRounds 16-byte loads per lane in
+    // flight, sums every code and compares with the epoch's bound — the R-th smallest value among the candidates of all
+    // EARLIER epochs, i.e. of codes that precede every code of this epoch in scan order (the prefix-bound rule,
+    // DESIGN.md section 4).  The rare qualifying code is appended, UNORDERED, to the query's candidate list in global
+    // memory (one LDS atomic for the slot) and counted in the epoch's value histogram.  An epoch ends with two
+    // barriers: histogram merge + the next partition's pair tables between them, the new bound after them.
+    // When the walk is over, the workgroup sorts its candidates (typically ~1 K, at most kCandCap) by
+    // (assign slot, position) with a bitonic network in the LDS the tables no longer need, expands the padding-lane
+    // replays and writes the ordered stream.  Exactness does not depend on how the waves interleave: the bound of an
+    // epoch is fixed before its first code is tested, and the order is restored by the sort.
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) u32x4* gvec_t;
-    uint32_t ramp = 64;                                          // vectors of the next tile: 64, 128, ... up to U*1024
-    // "some lane of the tile qualifies" flag: tile i uses s_any[i % 3].  After tile i's barrier every wave has read
-    // tile i-1's flag, and nobody can set tile i+2's flag before passing tile i+1's barrier — so the flag of tile
-    // i+2 (= the one of tile i-1) is cleared by thread 0 between those two barriers.
-    uint32_t fi = 0;
-    for (int a = 0; a < ma; ++a) {
-        const PartDesc d = parts[assign[a]];
-        if (d.n == 0) continue;                                  // empty partition (db_query_4.cpp:291-293) / no local codes
-        // pair tables of this probe: P_b[x] = T[2b][x & 15] + T[2b+1][x >> 4]
-        if (tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] = reinterpret_cast<const uint32_t*>(qt_all + (size_t)a * (M * 16))[tid];
-        __syncthreads();
-        for (int e = tid; e < CS * 256; e += kQWG) {
-            const int b = e >> 8, x = e & 255;
-            ptab[e] = (unsigned char)(tq[(2 * b) * 16 + (x & 15)] + tq[(2 * b + 1) * 16 + (x >> 4)]);
+    constexpr int kRounds = U;                                   // loads per lane in flight
+    constexpr uint32_t kEpochVec = 32768;                        // longest epoch (vectors): bounds how stale a bound gets
+    uint32_t* hist_done = misc;                                  // [128] candidates of the finished epochs, by value
+    uint32_t* hist_cur = misc + 128;                             // [128] candidates of the running epoch
+    uint32_t& s_ccount = misc[326];                              // candidates appended so far
+    QCand* __restrict__ cands = A.cands + (size_t)q * A.ccap;
+    auto next_part = [&](int a_) {
+        ++a_;
+        while (a_ < ma && q_uni(parts[assign[a_]].n) == 0) ++a_; // empty partition (db_query_4.cpp:291-293) / no local codes
+        return a_;
+    };
+    auto table_word = [&](int a_) -> uint32_t {
+        return tid < M * 4 ? reinterpret_cast<const uint32_t*>(qt_all + (size_t)a_ * (M * 16))[tid] : 0u;
+    };
+    auto write_tables = [&]() {                                  // replicated pair tables from the staged int8 table (layout: QCfg)
+        constexpr int PAIRS = (M / 8) * 256;                     // (code dword g, byte value x)
+        constexpr int TPP = kQWG / PAIRS;                        // threads per pair (16x4: 2, 32x4: 1)
+        constexpr int REPL = 32 / TPP;                           // bank replicas written per thread
+        const int pr = (int)tid / TPP, part = (int)tid % TPP;
+        const int g = pr >> 8, x = pr & 255;
+        uint32_t w = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int b = 4 * g + jj;
+            w |= ((uint32_t)tq[(2 * b) * 16 + (x & 15)] + (uint32_t)tq[(2 * b + 1) * 16 + (x >> 4)]) << (8 * jj);
         }
-        __syncthreads();
+        unsigned char* dst = qsmem + (g >> 1) * 65536 + x * 256 + (g & 1) * 128 + part * (REPL * 4);
+        const uint4 w4 = make_uint4(w, w, w, w);
+#pragma unroll
+        for (int r = 0; r < REPL / 4; ++r) reinterpret_cast<uint4*>(dst)[r] = w4;
+    };
+    const uint32_t lane_lo = (tid & 31u) * 4u, lane_hi = lane_lo | 0x10000u;
+    if (tid < 256) misc[tid] = 0;                                // both histograms
+    if (tid == 0) s_ccount = 0;
+    uint32_t bound = 127, ramp = 64, last_cnt = 0;
+    int a = next_part(-1);
+    if (a < ma) {
+        if (tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] = table_word(a);
+        q_lds_barrier();
+        write_tables();
+        q_lds_barrier();
+    }
+    while (a < ma) {
+        const UDesc d = q_load_desc(parts, (int)q_uni((uint32_t)assign[a]));
+        const int a_next = next_part(a);
+        const uint32_t tqv = a_next < ma ? table_word(a_next) : 0u;   // in flight during the partition's epochs
         const gvec_t src = (gvec_t)(uintptr_t)d.codes;
         const uint32_t n = d.n;
         const uint32_t nvec = (n + CPL - 1) / CPL;
         const uint32_t dup_pos = (d.first_pos + d.n == d.global_n) ? d.n - 1u : 0xffffffffu;
         const uint32_t dup_reps = (16u - d.global_n % 16u) % 16u;
         const uint32_t key_base = d.key_base + d.first_pos;
-        const uint64_t slot_bits = (uint64_t)(uint32_t)a << 40;
-
-        for (uint32_t t0 = 0; t0 < nvec;) {
-            const uint32_t width = min(ramp, (uint32_t)(U * kQWG));
-            u32x4 v[U];
-            uint32_t e[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t off = u * kQWG + tid;
-                e[u] = t0 + off;
-                v[u] = u32x4{0, 0, 0, 0};
-                if (off < width && e[u] < nvec) v[u] = __builtin_nontemporal_load(src + e[u]);
-                else e[u] = 0xffffffffu;
+        auto emit = [&](uint32_t cv, uint32_t p) {               // rare: append one candidate, unordered
+            const uint32_t slot = atomicAdd(&s_ccount, 1u);
+            if (slot < A.ccap) {
+                QCand qc;
+                qc.key = d.labels ? d.labels[p] : key_base + p;
+                qc.val_reps = cv | ((p == dup_pos ? dup_reps : 0u) << 8);
+                qc.pos = p;
+                qc.slot = (uint32_t)a;
+                cands[slot] = qc;
             }
-            const uint32_t bound = s_bound;
-            uint32_t cand[U * CPL];
+            atomicAdd(&hist_cur[cv], 1u);
+        };
+        // FULL = every lane of every tile of the iteration holds CPL complete codes: no predicates, so all the lookups
+        // of the iteration sit in one basic block and overlap (a predicated copy handles ramp epochs and ragged ends)
+        auto load_tiles = [&](u32x4 (&v)[kRounds], uint32_t t0, uint32_t width, uint32_t tl, auto full) {
+#pragma unroll
+            for (int i = 0; i < kRounds; ++i) {
+                const uint32_t off = (tl + (uint32_t)i * kQWaves) * 64u + lane;
+                if (decltype(full)::value) {
+                    v[i] = __builtin_nontemporal_load(src + t0 + off);
+                } else {
+                    v[i] = u32x4{0, 0, 0, 0};
+                    if (off < width) v[i] = __builtin_nontemporal_load(src + t0 + off);
+                }
+            }
+        };
+        auto sums_of = [&](uint32_t (&cand)[kRounds * CPL], const u32x4 (&v)[kRounds], uint32_t t0, uint32_t width, uint32_t tl,
+                           auto full) {
             uint32_t best = 127u;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t dd[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            for (int i = 0; i < kRounds; ++i) {
+                const uint32_t dd[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                const uint32_t off = (tl + (uint32_t)i * kQWaves) * 64u + lane;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
-                    uint32_t sum = 0;
-#pragma unroll
-                    for (int b = 0; b < CS; ++b) {
-                        const uint32_t w = dd[c * DW + (b >> 2)];
-                        sum += ptab[b * 256 + ((w >> (8 * (b & 3))) & 0xffu)];
+                    const uint32_t sum = q_pair_sum<M>(dd + c * DW, lane_lo, lane_hi);
+                    uint32_t cv = min(sum, 127u);
+                    if (!decltype(full)::value) {
+                        const bool live = off < width && (t0 + off) * CPL + c < n;
+                        cv = live ? cv : 127u;
                     }
-                    const bool live = e[u] != 0xffffffffu && e[u] * CPL + c < n;
-                    cand[u * CPL + c] = live ? min(sum, 127u) : 127u;
-                    best = min(best, cand[u * CPL + c]);
+                    cand[i * CPL + c] = cv;
+                    best = min(best, cv);
                 }
             }
-            const bool hit = best < bound;
-            if (__builtin_amdgcn_ballot_w64(hit) != 0 && lane == 0) s_any[fi] = 1;
-            __syncthreads();
-            const uint32_t any = s_any[fi];
-            if (tid == 0) s_any[fi == 0 ? 2 : fi - 1] = 0;       // the flag of tile i+2
-            fi = fi == 2 ? 0 : fi + 1;
-            if (any) {
-                // ---- ordered emission: tile u before tile u+1, wave w before w+1, lane order inside a wave ----
-                uint32_t cnt[U], incl[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    uint32_t c_ = 0;
-#pragma unroll
-                    for (int c = 0; c < CPL; ++c)
-                        if (cand[u * CPL + c] < bound) c_ += 1u + ((e[u] * CPL + c == dup_pos) ? dup_reps : 0u);
-                    cnt[u] = c_;
-                    uint32_t in_ = c_;
-#pragma unroll
-                    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                        const uint32_t o = __shfl_up(in_, dlt, 64);
-                        if (lane >= (uint32_t)dlt) in_ += o;
-                    }
-                    incl[u] = in_;
-                    if (lane == 63) wcnt[u * kQWaves + wave] = in_;
-                }
-                __syncthreads();
-                uint32_t before = s_count, total = 0;
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int w = 0; w < kQWaves; ++w) {
-                        const uint32_t c_ = wcnt[u * kQWaves + w];
-                        total += c_;
-                    }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (cnt[u]) {
-                        uint32_t pos = before + incl[u] - cnt[u];
-                        for (int uu = 0; uu < u; ++uu)
-                            for (int w = 0; w < kQWaves; ++w) pos += wcnt[uu * kQWaves + w];
-                        for (uint32_t w = 0; w < wave; ++w) pos += wcnt[u * kQWaves + w];
-#pragma unroll
-                        for (int c = 0; c < CPL; ++c) {
-                            const uint32_t cv = cand[u * CPL + c];
-                            if (cv < bound) {
-                                const uint32_t p = e[u] * CPL + c;
-                                const uint32_t key = d.labels ? d.labels[p] : key_base + p;
-                                const uint64_t en = (uint64_t)key | ((uint64_t)cv << 32) | slot_bits;
-                                const uint32_t reps = 1u + (p == dup_pos ? dup_reps : 0u);
-                                for (uint32_t r = 0; r < reps; ++r, ++pos)
-                                    if (pos < A.cap) {
-                                        stream[pos] = en;
-                                        if (stream2) stream2[pos] = en;
-                                    }
-                                atomicAdd(&hist[cv], 1u);
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                if (wave == 0) {
-                    const uint32_t b = q_bound_from_hist(hist, R, lane);
-                    if (lane == 0) { s_bound = b; s_count = before + total; }
-                }
-                __syncthreads();
+            return best;
+        };
+        auto end_epoch = [&](bool switch_part) {
+            if (switch_part && tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] = tqv;
+            q_lds_barrier();                                     // every candidate of the epoch is counted; the tables are idle
+            const uint32_t cnt = s_ccount;
+            if (cnt != last_cnt && tid < 128) {
+                hist_done[tid] += hist_cur[tid];
+                hist_cur[tid] = 0;
             }
+            if (switch_part) write_tables();
+            q_lds_barrier();
+            if (cnt != last_cnt) {
+                bound = q_uni(q_bound_from_hist(hist_done, R, lane));
+                last_cnt = cnt;
+            }
+        };
+        for (uint32_t t0 = 0; t0 < nvec;) {
+            const uint32_t rest = nvec - t0;
+            uint32_t width;
+            if (ramp < kEpochVec) {
+                width = min(ramp, rest);
+                ramp *= 2u;
+            } else {
+                width = min(rest, kEpochVec);
+            }
+            const uint32_t tiles = (width + 63u) / 64u;          // 64-vector tiles of the epoch; wave w takes w, w+16, ...
+            // (tried and dropped: loads of the next tiles in flight across iterations, and a register-resident first
+            // block for the ramp — both cost registers the lookups need; the walk is bound by issue, not by memory)
+            // tiles [0, full_tiles) hold only complete vectors of complete codes
+            const uint32_t full_tiles = min(width, n / CPL - min(n / CPL, t0)) / 64u;
+            auto step = [&](uint32_t tl, auto full) {
+                u32x4 v[kRounds];
+                load_tiles(v, t0, width, tl, full);
+                uint32_t cand[kRounds * CPL];
+                const uint32_t best = sums_of(cand, v, t0, width, tl, full);
+                if (__builtin_expect(best < bound, 0)) {         // rare
+#pragma unroll
+                    for (int i = 0; i < kRounds; ++i)
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c)
+                            if (cand[i * CPL + c] < bound)
+                                emit(cand[i * CPL + c], (t0 + (tl + (uint32_t)i * kQWaves) * 64u + lane) * CPL + c);
+                }
+            };
+            uint32_t tl = wave;
+            for (; tl + (kRounds - 1) * kQWaves < full_tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, true>());
+            for (; tl < tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, false>());
             t0 += width;
-            ramp = min(ramp * 2u, (uint32_t)(U * kQWG));
+            end_epoch(t0 >= nvec && a_next < ma);
         }
-        __syncthreads();                                         // ptab / tq are rebuilt for the next probe
+        a = a_next;
     }
+    // ---- 4. order the candidates: (assign slot, position) ascending = scan order ----
+    __syncthreads();                                             // the candidate stores of every wave are complete
+    const uint32_t ncand = s_ccount;
+    uint32_t out_count = 0;
+    if (ncand > A.ccap) {
+        flags |= 32u;                                            // more candidates than the in-workgroup sort takes: host falls back
+    } else if (ncand) {
+        uint64_t* skey = reinterpret_cast<uint64_t*>(qsmem);             // [n2] (slot << 44 | pos << 12 | index)
+        uint64_t* spay = reinterpret_cast<uint64_t*>(qsmem + 32768);     // [ncand] key | val << 32 | reps << 40 | slot << 48
+        uint32_t n2 = 64;
+        while (n2 < ncand) n2 <<= 1;
+        for (uint32_t i = tid; i < n2; i += kQWG) {
+            uint64_t k = ~0ull;
+            if (i < ncand) {
+                const QCand c = cands[i];
+                k = ((uint64_t)c.slot << 44) | ((uint64_t)c.pos << 12) | i;
+                spay[i] = (uint64_t)c.key | ((uint64_t)(c.val_reps & 0xfffu) << 32) | ((uint64_t)c.slot << 48);
+            }
+            skey[i] = k;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= n2; k <<= 1)
+            for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+                for (uint32_t i = tid; i < n2; i += kQWG) {
+                    const uint32_t pi = i ^ jj;
+                    if (pi > i) {
+                        const uint64_t x = skey[i], y = skey[pi];
+                        if ((x > y) == ((i & k) == 0)) { skey[i] = y; skey[pi] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        // expand the padding-lane replays while writing: thread t owns sorted entries [4t, 4t+4)
+        uint64_t pay[4];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = tid * 4u + u;
+            pay[u] = 0;
+            if (i < ncand) {
+                pay[u] = spay[skey[i] & 0xfffu];
+                mine += 1u + ((uint32_t)(pay[u] >> 40) & 15u);
+            }
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const uint32_t o = __shfl_up(incl, dlt, 64);
+            if (lane >= (uint32_t)dlt) incl += o;
+        }
+        __syncthreads();                                         // (skey / spay reads done before wcnt reuse is irrelevant: wcnt is in misc)
+        if (lane == 63) wcnt[wave] = incl;
+        __syncthreads();
+        uint32_t wp = incl - mine;
+        for (uint32_t w = 0; w < kQWaves; ++w) {
+            const uint32_t c_ = wcnt[w];
+            if (w < wave) wp += c_;
+            out_count += c_;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = tid * 4u + u;
+            if (i < ncand) {
+                const uint32_t reps = 1u + ((uint32_t)(pay[u] >> 40) & 15u);
+                const uint64_t en = (pay[u] & 0xffffffffffull & ~(0xffull << 40)) | ((pay[u] >> 48) << 40);
+                for (uint32_t r = 0; r < reps; ++r, ++wp)
+                    if (wp < A.cap) stream[wp] = en;
+            }
+        }
+    }
+    s_count = out_count;
     if (tid == 0) {
         QueryOut o;
         o.count = s_count;                                       // entries requested (replays included); > cap = overflow
@@ -418,7 +592,8 @@ __global__ __launch_bounds__(kQWG, 8) void scan_query_kernel(QueryKernelArgs A) 
         o.out_off = (uint32_t)((size_t)q * A.cap);
         o.qmin = qmin;
         o.qmax = qmax;
-        o.pad[0] = o.pad[1] = 0;
+        o.pad[0] = (uint32_t)((clk1 - clk0) >> 4);               // pre-scan + select + quantizer
+        o.pad[1] = (uint32_t)((__builtin_readcyclecounter() - clk1) >> 4);   // int8 scan
         A.qout[q] = o;
         if (A.qstate_flags) {                                    // what replay_heap_lanes_kernel reads
             A.qstate_flags[4 * q + 0] = flags | 4u;
@@ -515,25 +690,37 @@ __global__ __launch_bounds__(64) void replay_heap_lanes_kernel(const uint32_t* _
 size_t query_kernel_lds_bytes(int M) { return M == 16 ? QCfg<16>::LDS_BYTES : QCfg<32>::LDS_BYTES; }
 uint32_t query_kernel_lds_values(int M) { return M == 16 ? QCfg<16>::FCAP : QCfg<32>::FCAP; }
 
-hipError_t launch_scan_query(int M, int nq, const QueryKernelArgs& args, hipStream_t stream) {
+template <int M, int U, int OCC>
+static hipError_t launch_scan_query_v(int nq, const QueryKernelArgs& args, hipStream_t stream) {
     // dynamic LDS above the default limit is opted into per (kernel, device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    static uint64_t done16 = 0, done32 = 0;
-    uint64_t& done = M == 16 ? done16 : done32;
-    const size_t lds = query_kernel_lds_bytes(M);
+    static uint64_t done = 0;
+    const size_t lds = QCfg<M>::LDS_BYTES;
     if (dev < 64 && !(done & (1ull << dev))) {
-        e = M == 16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<16, 2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                    : hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<32, 2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         done |= 1ull << dev;
     }
-    if (M == 16) hipLaunchKernelGGL((scan_query_kernel<16, 2>), dim3(nq), dim3(kQWG), lds, stream, args);
-    else         hipLaunchKernelGGL((scan_query_kernel<32, 2>), dim3(nq), dim3(kQWG), lds, stream, args);
+    hipLaunchKernelGGL((scan_query_kernel<M, U, OCC>), dim3(nq), dim3(kQWG), lds, stream, args);
     return hipGetLastError();
+}
+
+// variant = 64-vector tiles (16-byte loads per lane in flight) per wave and iteration: 0 -> 2 (default), 1 -> 3, 2 -> 4, 3 -> 6.
+// 16x4: two workgroups per CU (64 KiB of tables each); 32x4: one (128 KiB).
+hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& args, hipStream_t stream) {
+    if (M == 16) {
+        if (variant == 1) return launch_scan_query_v<16, 3, QCfg<16>::OCC>(nq, args, stream);
+        if (variant == 2) return launch_scan_query_v<16, 4, QCfg<16>::OCC>(nq, args, stream);
+        if (variant == 3) return launch_scan_query_v<16, 6, 4>(nq, args, stream);   // one workgroup per CU, 128 VGPRs
+        return launch_scan_query_v<16, 2, QCfg<16>::OCC>(nq, args, stream);
+    }
+    if (variant == 1) return launch_scan_query_v<32, 3, QCfg<32>::OCC>(nq, args, stream);
+    if (variant == 2) return launch_scan_query_v<32, 4, QCfg<32>::OCC>(nq, args, stream);
+    if (variant == 3) return launch_scan_query_v<32, 6, QCfg<32>::OCC>(nq, args, stream);
+    return launch_scan_query_v<32, 2, QCfg<32>::OCC>(nq, args, stream);
 }
 
 uint32_t replay_lanes_max_R() { return 288; }                    // R * 512 B of LDS per wave (<= 144 KiB)

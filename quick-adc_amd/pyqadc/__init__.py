@@ -41,7 +41,8 @@ class Profile(C.Structure):
                 ("regrows", C.c_uint64), ("host_replay_ms", C.c_double), ("host_plan_ms", C.c_double),
                 ("host_heap_ms", C.c_double), ("host_sorted_queries", C.c_uint64), ("mq_launches", C.c_uint64),
                 ("pass_codes", C.c_uint64), ("wgq_launches", C.c_uint64), ("wgq_queries", C.c_uint64),
-                ("wgq_codes", C.c_uint64), ("wgq_ms", C.c_double)]
+                ("wgq_codes", C.c_uint64), ("wgq_ms", C.c_double), ("wgq_front_cycles", C.c_uint64),
+                ("wgq_scan_cycles", C.c_uint64)]
 
 
 class QadcError(RuntimeError):
