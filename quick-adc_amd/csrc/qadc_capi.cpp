@@ -243,6 +243,7 @@ struct qadc_index {
     uint64_t wgq_small_codes = 1ull << 18;   // any batch probing at most this many codes per query
     uint32_t wgq_capacity = 4096;        // stream entries per query to start with
     int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
+    int table_form = 2;                  // float tables of qadc_search: 0 direct, 1 BLAS expansion, 2 the reference's nns_engine rule
     uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)
     DevBuf<PartDesc> d_partdesc;         // device partition table (qadc_index_finalize)
     uint32_t max_start_n = 0;
@@ -264,9 +265,18 @@ struct qadc_index {
 
 namespace {
 
+// Which float-table form qadc_search builds (option "table_form"): 0 = direct ||x - c||^2 always
+// (compute_dists_single_simd_cg, distances.hpp:294-311), 1 = BLAS expansion always (nns_engine_batch,
+// query_common.hpp:194-213), 2 = the rule of nns_engine (query_common.hpp:292-297): direct for ma == 1, expansion otherwise.
+int table_expansion(const qadc_index* idx, int ma);
+
 int use_device(const qadc_index* idx) {
     HIPCHECK(hipSetDevice(idx->device));
     return QADC_OK;
+}
+
+int table_expansion(const qadc_index* idx, int ma) {
+    return idx->table_form == 1 || (idx->table_form == 2 && ma > 1);
 }
 
 hipError_t prof_event(Slot& s, hipStream_t st) {
@@ -601,7 +611,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             d_ft = s.d_ftables.p;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
             launch_build_tables(s.d_queries.p, idx->K ? idx->d_coarse.p : nullptr, s.d_assign.p, idx->d_codebooks.p,
-                                idx->has_rotation ? idx->d_rotation.p : nullptr, nq, ma, M, idx->dim, d_ft, st);
+                                idx->has_rotation ? idx->d_rotation.p : nullptr, nq, ma, M, idx->dim, table_expansion(idx, ma), d_ft, st);
         }
         HIPCHECK(s.d_fc.ensure((size_t)nq * fc_stride));
         if (idx->profile) HIPCHECK(prof_event(s, st));
@@ -843,7 +853,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             HIPCHECK(s.d_ftables.ensure(nt));
             HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
             launch_build_tables(s.d_queries.p, idx->K ? idx->d_coarse.p : nullptr, s.d_assign.p, idx->d_codebooks.p,
-                                idx->has_rotation ? idx->d_rotation.p : nullptr, nq, ma, M, idx->dim, s.d_ftables.p, st);
+                                idx->has_rotation ? idx->d_rotation.p : nullptr, nq, ma, M, idx->dim, table_expansion(idx, ma), s.d_ftables.p, st);
             A.ftables = s.d_ftables.p;
         } else {
             A.ftables = reinterpret_cast<float*>(s.d_in.p + off_tables);
@@ -1563,6 +1573,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
     else if (n == "wgq") idx->wgq = (int)value;
     else if (n == "wgq_variant") idx->wgq_variant = (int)value;
+    else if (n == "table_form") idx->table_form = std::max(0, std::min((int)value, 2));
     else if (n == "wgq_cand_cap") idx->wgq_cand_cap = (uint32_t)std::max(1.0, std::min(value, (double)kQueryCandCap));
     else if (n == "wgq_min_nq") idx->wgq_min_nq = (int)std::max(value, 1.0);
     else if (n == "wgq_max_codes") idx->wgq_max_codes = (uint64_t)std::max(value, 0.0);

@@ -187,8 +187,11 @@ void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq,
 // tables[q][a][m][c] = sum_d ((x - centroid[assign])[m*ds+d] - codebook[m][c][d])^2, d ascending.
 // d_coarse == nullptr (flat DB): residual = query.  d_rotation != nullptr (OPQ): the residual is rotated first,
 // rotated[r] = sum_c x[c] * rotation[r][c]  (opq::rotate_multiple_vectors, quantizers.hpp:289-301).
+// expansion != 0: the BLAS-expansion form (||v||^2 + ||c||^2) - 2 v.c of compute_cross_dists_blas
+// (distances.hpp:151-183, 277-292) — what the reference evaluates for ma > 1 and in batch mode; may yield negatives.
 void launch_build_tables(const float* d_queries, const float* d_coarse, const int32_t* d_assign, const float* d_codebooks,
-                         const float* d_rotation, int nq, int ma, int M, int dim, float* d_ftables, hipStream_t stream);
+                         const float* d_rotation, int nq, int ma, int M, int dim, int expansion, float* d_ftables,
+                         hipStream_t stream);
 
 // R-th smallest of each query's stored float values (one workgroup per query) -> QueryState::qmax
 // (FLT_MAX if fewer than R values).  max_passes < 4: upper bound only (survivor filter of the pre-scan).

@@ -1657,7 +1657,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restri
                                                            const int32_t* __restrict__ assign,
                                                            const float* __restrict__ codebooks,
                                                            const float* __restrict__ rotation, int ma, int M, int dim,
-                                                           float* __restrict__ ftables) {
+                                                           int expansion, float* __restrict__ ftables) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     float* res = reinterpret_cast<float*>(dyn);               // [dim] residual of this (query, probe)
     float* tmp = res + dim;                                   // [dim] un-rotated residual (OPQ only)
@@ -1685,18 +1685,34 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restri
         const int m = e >> 4;
         const float* __restrict__ ce = codebooks + (size_t)e * ds;   // [m][c][ds] is contiguous in e
         float s = 0.0f;
-        for (int d = 0; d < ds; ++d) {
-            const float t = res[m * ds + d] - ce[d];
-            s += t * t;
+        if (expansion) {
+            // compute_cross_dists_blas (distances.hpp:151-183): ||v||^2 + ||c||^2, then sgemm(alpha = -2, beta = 1) adds
+            // -2 v.c: the BLAS-expansion form nns_engine uses for ma > 1 and nns_engine_batch always.  It can come out
+            // slightly NEGATIVE when v ~ c — the case query_scan clamps (db_query_4.cpp:258-269).  Sequential sums,
+            // no contraction; host twin: pq4::tables_blas.
+            float vn = 0.0f, cn = 0.0f, dot = 0.0f;
+            for (int d = 0; d < ds; ++d) {
+                const float v = res[m * ds + d], c = ce[d];
+                vn += v * v;
+                cn += c * c;
+                dot += v * c;
+            }
+            s = (vn + cn) + (-2.0f * dot);
+        } else {
+            for (int d = 0; d < ds; ++d) {
+                const float t = res[m * ds + d] - ce[d];
+                s += t * t;
+            }
         }
         out[e] = s;
     }
 }
 
 void launch_build_tables(const float* d_queries, const float* d_coarse, const int32_t* d_assign, const float* d_codebooks,
-                         const float* d_rotation, int nq, int ma, int M, int dim, float* d_ftables, hipStream_t stream) {
+                         const float* d_rotation, int nq, int ma, int M, int dim, int expansion, float* d_ftables,
+                         hipStream_t stream) {
     hipLaunchKernelGGL(build_tables_kernel, dim3(ma, nq), dim3(256), 2 * dim * sizeof(float), stream, d_queries, d_coarse,
-                       d_assign, d_codebooks, d_rotation, ma, M, dim, d_ftables);
+                       d_assign, d_codebooks, d_rotation, ma, M, dim, expansion, d_ftables);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -3,7 +3,8 @@
 // The pieces of the reference that stay on the host next to the accelerated scan (SURVEY.md §8 rows
 // A9/A10), restated for this repo's stand-alone driver and examples:
 //   pq4            base_pq for 4-bit sub-quantizers: encode + per-query float distance tables
-//                  (quantizers.hpp:96-246, distances.hpp:294-311 "single" form ||x_m - c||^2)
+//                  (quantizers.hpp:96-246; distances.hpp:294-311 "single" form ||x_m - c||^2 and the
+//                  BLAS-expansion form of distances.hpp:151-183, 277-292)
 //   flat_database  flat_db  (databases.hpp:77-167): one partition, key = position
 //   ivf_database   index_db (databases.hpp:176-331): coarse centroids, per-partition codes + labels,
 //                  assign = the ma nearest centroids in ascending distance, residual = x - centroid
@@ -73,6 +74,31 @@ struct pq4 {
                 }
                 out[m * 16 + c] = s;
             }
+    }
+
+    // The BLAS-expansion form of `count` vectors' tables (compute_dists_multiple_blas_cg -> compute_cross_dists_blas,
+    // distances.hpp:151-183, 277-292): per sub-quantizer ||v||^2 + ||c||^2 first, then sgemm(alpha = -2, beta = 1) adds
+    // -2 v.c.  What nns_engine evaluates for ma > 1 and nns_engine_batch always (query_common.hpp:194-213, 292-297).
+    // Cancellation makes entries slightly NEGATIVE when v ~ c: the case scanner_4::query_scan clamps in place
+    // (db_query_4.cpp:258-269).  Sequential float sums (the device twin, build_tables_kernel, adds in the same order;
+    // OpenBLAS associates differently, so this form is bit-compatible with the device, not with the reference binary).
+    void tables_blas(const float* vecs, int count, float* out) const {
+        const int ds = sq_dim();
+        for (int v = 0; v < count; ++v) {
+            const float* x = vecs + (size_t)v * dim;
+            float* o = out + (size_t)v * sq_count * 16;
+            for (int m = 0; m < sq_count; ++m)
+                for (int c = 0; c < 16; ++c) {
+                    const float* ce = centroid(m, c);
+                    float vn = 0, cn = 0, dot = 0;
+                    for (int d = 0; d < ds; ++d) {
+                        vn += x[m * ds + d] * x[m * ds + d];
+                        cn += ce[d] * ce[d];
+                        dot += x[m * ds + d] * ce[d];
+                    }
+                    o[m * 16 + c] = (vn + cn) + (-2.0f * dot);
+                }
+        }
     }
 
     // nearest centroid per sub-quantizer (first minimum), packed two per byte: even sub-quantizer in the low
@@ -211,13 +237,13 @@ struct nns_engine {  // query_common.hpp:245-309
     void prepare_database() { scanner.prepare_database(db); }
     template <typename Heap>
     void process_query(const float* query, Heap& bh, query_metrics& metrics) {
-        const int dim = db.pq->dim;  // read before free_partition could matter; pq outlives the partitions
         const std::uint64_t t0 = ustime();
         db.assign_compute_residuals(query, ma, assign.data(), residuals.data());
         const std::uint64_t t1 = ustime();
         db.pq->rotate_multiple_vectors(residuals.data(), ma);   // query_common.hpp:206-207 (no-op for plain PQ)
         const std::uint64_t t2 = ustime();
-        for (int a = 0; a < ma; ++a) db.pq->tables(residuals.data() + (size_t)a * dim, dists.data() + (size_t)a * table_dim);
+        if (ma == 1) db.pq->tables(residuals.data(), dists.data());       // "Optimized" single form (query_common.hpp:292-294)
+        else db.pq->tables_blas(residuals.data(), ma, dists.data());       // dist_mult_func_ (295-297)
         const std::uint64_t t3 = ustime();
         scanner.query_scan(residuals.data(), assign.data(), ma, dists.data(), table_dim, bh, metrics);
         metrics.scan_us = ustime() - t3;
@@ -258,7 +284,7 @@ struct nns_engine_batch {
             db.pq->rotate_multiple_vectors(residuals.data(), nb * ma);
             const std::uint64_t tr = ustime();
             metrics.rotate_us = tr - t1;
-            for (int i = 0; i < nb * ma; ++i) db.pq->tables(residuals.data() + (size_t)i * dim, dists.data() + (size_t)i * table_dim);
+            db.pq->tables_blas(residuals.data(), nb * ma, dists.data());       // dist_func (query_common.hpp:209-213)
             const std::uint64_t t2 = ustime();
             scanner.batch_scan(nb, assign.data(), ma, dists.data(), table_dim, r);
             metrics.scan_us = ustime() - t2;

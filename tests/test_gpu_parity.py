@@ -342,9 +342,24 @@ def _seq_sqdist(x, c):
     return s
 
 
+def _seq_expansion(x, c):
+    """(||x||^2 + ||c||^2) + (-2 x.c), every sum accumulated in float32 in ascending d: the BLAS-expansion table
+    form (distances.hpp:151-183) as the device feeder and host/query_driver.hpp evaluate it."""
+    vn = np.zeros(np.broadcast_shapes(x.shape[:-1], c.shape[:-1]), np.float32)
+    cn = np.zeros_like(vn)
+    dot = np.zeros_like(vn)
+    for d in range(c.shape[-1]):
+        xv, cv = x[..., d].astype(np.float32), c[..., d].astype(np.float32)
+        vn = (vn + (xv * xv).astype(np.float32)).astype(np.float32)
+        cn = (cn + (cv * cv).astype(np.float32)).astype(np.float32)
+        dot = (dot + (xv * cv).astype(np.float32)).astype(np.float32)
+    return ((vn + cn).astype(np.float32) + (np.float32(-2.0) * dot).astype(np.float32)).astype(np.float32)
+
+
+@pytest.mark.parametrize("form", [0, 1, 2])
 @pytest.mark.parametrize("M,K,ma,opq", [(16, 37, 5, False), (32, 16, 3, False), (16, 0, 1, False), (16, 21, 4, True),
                                          (32, 0, 1, True)])
-def test_search_with_device_side_feeders(pyqadc, po, M, K, ma, opq):
+def test_search_with_device_side_feeders(pyqadc, po, M, K, ma, opq, form):
     """N1: queries in -> coarse assignment, residuals and float tables on the GPU -> same heaps as feeding
     the oracle with tables/assignments evaluated by the same float loops on the host."""
     rng = np.random.default_rng(M * 100 + K)
@@ -372,6 +387,8 @@ def test_search_with_device_side_feeders(pyqadc, po, M, K, ma, opq):
         rot = np.linalg.qr(rng.normal(size=(dim, dim)))[0].astype(np.float32)
         idx.set_rotation(rot)
     queries = rng.normal(size=(nq, dim)).astype(np.float32)
+    idx.set_option("table_form", form)      # 0 direct, 1 BLAS expansion, 2 (default) nns_engine's rule: expansion iff ma > 1
+    table_fn = _seq_expansion if (form == 1 or (form == 2 and ma > 1)) else _seq_sqdist
     res = idx.search(queries, ma, R)
     for q in range(nq):
         if K:
@@ -389,7 +406,7 @@ def test_search_with_device_side_feeders(pyqadc, po, M, K, ma, opq):
             resid = acc
         tables = np.zeros((ma, M, 16), np.float32)
         for a in range(ma):
-            tables[a] = _seq_sqdist(resid[a].reshape(M, 1, ds), cb)
+            tables[a] = table_fn(resid[a].reshape(M, 1, ds), cb)
         want = po.query_scan(M, parts, labels, keep, assign, np.ascontiguousarray(tables.reshape(ma, M * 16)), R)
         assert want["rc"] == res["status"][q] == 0
         assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
@@ -926,4 +943,70 @@ def test_wgq_search_keeps_assign_on_the_device(pyqadc, po):
     assert np.array_equal(a["assign"], b["assign"]) and np.array_equal(a["status"], b["status"])
     for q in range(nq):
         assert heaps_equal(a["heaps"][q], b["heaps"][q]), q
+    idx.close()
+
+
+@pytest.mark.gpu
+def test_wgq_candidate_overflow_falls_back_to_the_level_path(pyqadc, po):
+    """A query with more candidates than a workgroup sorts in LDS (here: cap forced to 64; in production 4096, e.g. an
+    all-zero table where every code ties) is re-run through the level-structured path; heaps stay exact."""
+    rng = np.random.default_rng(99)
+    M = 16
+    parts = [rand_codes(rng, n, M) for n in (50001, 7000)]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts)
+    idx.finalize(0.01)
+    idx.set_option("wgq", 2)
+    idx.set_option("wgq_cand_cap", 64)
+    idx.set_option("profile", 1)
+    assign = np.array([[0, 1], [1, 0]], np.int32)
+    qt = rand_qtables(rng, (2, 2), M, 15)
+    qt[1] = 0                                              # every code of query 1 sums to 0
+    got = idx.scan_i8(assign, qt, 100)
+    pr = idx.profile()
+    assert pr["regrows"] >= 1 and pr["scan_launches"] + pr["small_launches"] >= 1
+    for q in range(2):
+        assert heaps_equal(got[q], po.scan_i8(M, [parts[p] for p in assign[q]], None, qt[q], 100)), q
+    idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 32])
+def test_blas_expansion_tables_go_negative_and_are_clamped_like_the_reference(pyqadc, po, M):
+    """Real-encoded data, queries that nearly coincide with database vectors: the BLAS-expansion tables
+    (distances.hpp:151-183; what nns_engine_batch / ma > 1 evaluate) contain slightly NEGATIVE entries, so
+    query_scan's `qmin < 0 -> qmin = 0, clamp in place` branch (db_query_4.cpp:258-269) runs inside the engine —
+    on the device for qadc_search, on the host for the C-ABI's float-table entry point — with the oracle's result."""
+    rng = np.random.default_rng(500 + M)
+    dim, n, nq, R, keep = 64, 40000, 24, 50, 0.02
+    ds = dim // M
+    base = (rng.normal(size=(n, dim)) * 3).astype(np.float32)
+    cb = np.stack([base[rng.integers(0, n, 16), m * ds:(m + 1) * ds] for m in range(M)]).astype(np.float32)
+    codes = pyqadc.pq_encode(cb, base)
+    idx = pyqadc.Index(M)
+    idx.add_partitions([codes])
+    idx.finalize(keep)
+    idx.set_pq(cb)
+    idx.set_option("table_form", 1)
+    # queries = concatenations of codebook entries (what a decoded database vector is) + a hair of noise
+    pick = rng.integers(0, 16, (nq, M))
+    queries = np.concatenate([cb[m][pick[:, m]] for m in range(M)], axis=1).astype(np.float32)
+    queries *= (1 + rng.normal(size=queries.shape).astype(np.float32) * np.float32(3e-4))
+    res = idx.search(queries, 1, R)
+    negatives = 0
+    for q in range(nq):
+        tables = _seq_expansion(queries[q].reshape(M, 1, ds), cb).reshape(1, M * 16)
+        negatives += int((tables < 0).any())
+        mine = np.ascontiguousarray(tables.copy())
+        want = po.query_scan(M, [codes], None, keep, [0], mine, R)
+        assert want["rc"] == res["status"][q] == 0
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
+        if (tables < 0).any():
+            assert want["qmin"] == 0.0 and (mine >= 0).all()        # the oracle clamped its copy in place
+            # the float-table entry point clamps the caller's buffer the same way and ends in the same heap
+            t2 = np.ascontiguousarray(tables.copy())
+            r2 = idx.query_scan(np.zeros((1, 1), np.int32), t2.reshape(1, 1, M * 16), R)
+            assert r2["qmin"][0] == 0.0 and np.array_equal(t2.reshape(-1), mine.reshape(-1))
+            assert heaps_equal(r2["heaps"][0], (want["keys"], want["values"]))
+    assert negatives >= nq // 4, negatives
     idx.close()

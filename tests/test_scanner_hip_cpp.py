@@ -170,7 +170,16 @@ def test_batched_engine_equals_per_query_engine(po, tmp_path, mode, M, N, ma, K)
     (parts, labels, q1), (_, _, q5) = dumps
     keep = float(np.float32(keep_pct) * np.float32(0.01))
     for q in range(nq):
-        assert np.array_equal(q1[q][0], q5[q][0]) and np.array_equal(q1[q][1], q5[q][1])        # same inputs
-        assert np.array_equal(q1[q][2], q5[q][2]) and np.array_equal(q1[q][3], q5[q][3]), q     # same heaps
-        want = po.query_scan(M, parts, labels, keep, q5[q][0], np.ascontiguousarray(q5[q][1].reshape(ma, M * 16)), R)
-        assert np.array_equal(q5[q][2], want["keys"]) and np.array_equal(q5[q][3], want["values"]), q
+        assert np.array_equal(q1[q][0], q5[q][0])                                               # same assignments
+        if ma > 1:
+            # both engines build BLAS-expansion tables for ma > 1 (query_common.hpp:209-213, 295-297): same inputs,
+            # so the batched scan must leave the very same heaps
+            assert np.array_equal(q1[q][1], q5[q][1])
+            assert np.array_equal(q1[q][2], q5[q][2]) and np.array_equal(q1[q][3], q5[q][3]), q
+        else:
+            # ma == 1: nns_engine uses the direct form, nns_engine_batch the expansion — the reference's "two numerically
+            # different table paths"; close, not equal
+            assert np.allclose(q1[q][1], q5[q][1], rtol=1e-4, atol=1e-3)
+        for dump_q in (q1[q], q5[q]):                                                           # each equals the oracle on ITS tables
+            want = po.query_scan(M, parts, labels, keep, dump_q[0], np.ascontiguousarray(dump_q[1].reshape(ma, M * 16)), R)
+            assert np.array_equal(dump_q[2], want["keys"]) and np.array_equal(dump_q[3], want["values"]), q
