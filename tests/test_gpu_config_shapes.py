@@ -1,0 +1,95 @@
+"""IVF at the shape of BASELINE.json's configurations (C3 = IVF 16x4, nprobe 32, K = 4096;
+C5 = IVF 32x4 on 96-d vectors (sq_dim 3, which the reference's own dispatch cannot do, distances.cpp:15-121),
+nprobe 64): queries go in through qadc_search (coarse assignment, residuals, BLAS-expansion tables, pre-scan,
+quantizer, scan, heap — all on the GPU) and every sampled query must end in the oracle's heap arrays.  The oracle
+gets the assignments and float tables from a numpy restatement of the same sequential float loops."""
+import numpy as np
+import pytest
+
+from helpers import heaps_equal, rand_codes
+
+
+@pytest.fixture(scope="module")
+def pyqadc():
+    import pyqadc
+    return pyqadc
+
+
+def _seq_sqdist(x, c):
+    s = np.zeros(np.broadcast_shapes(x.shape[:-1], c.shape[:-1]), np.float32)
+    for d in range(c.shape[-1]):
+        t = (x[..., d] - c[..., d]).astype(np.float32)
+        s = (s + (t * t).astype(np.float32)).astype(np.float32)
+    return s
+
+
+def _seq_expansion(x, c):
+    vn = np.zeros(np.broadcast_shapes(x.shape[:-1], c.shape[:-1]), np.float32)
+    cn, dot = np.zeros_like(vn), np.zeros_like(vn)
+    for d in range(c.shape[-1]):
+        xv, cv = x[..., d].astype(np.float32), c[..., d].astype(np.float32)
+        vn = (vn + (xv * xv).astype(np.float32)).astype(np.float32)
+        cn = (cn + (cv * cv).astype(np.float32)).astype(np.float32)
+        dot = (dot + (xv * cv).astype(np.float32)).astype(np.float32)
+    return ((vn + cn).astype(np.float32) + (np.float32(-2.0) * dot).astype(np.float32)).astype(np.float32)
+
+
+def _build(pyqadc, rng, M, K, N, dim, keep):
+    sizes = rng.multinomial(N, np.ones(K) / K).astype(np.int64)
+    sizes[rng.integers(0, K, 3)] = 0                             # a few empty partitions, as real indexes have
+    codes_all = rand_codes(rng, int(sizes.sum()), M)
+    perm = rng.permutation(int(sizes.sum())).astype(np.uint32)   # labels != positions
+    cuts = np.cumsum(sizes)[:-1]
+    parts, labels = np.split(codes_all, cuts), np.split(perm, cuts)
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(keep)
+    cb = rng.normal(size=(M, 16, dim // M)).astype(np.float32)
+    coarse = rng.normal(size=(K, dim)).astype(np.float32)
+    idx.set_pq(cb)
+    idx.set_coarse(coarse)
+    return idx, parts, labels, cb, coarse, sizes
+
+
+def _check(po, res, sample, queries, parts, labels, cb, coarse, M, ma, keep, R):
+    K, dim = coarse.shape
+    ds = dim // M
+    for q in sample:
+        dist = _seq_sqdist(queries[q][None, :], coarse)
+        assign = np.lexsort((np.arange(K), dist))[:ma].astype(np.int32)
+        assert np.array_equal(res["assign"][q], assign), q
+        resid = (queries[q][None, :] - coarse[assign]).astype(np.float32)
+        tables = np.stack([_seq_expansion(resid[a].reshape(M, 1, ds), cb) for a in range(ma)])     # ma > 1: expansion form
+        want = po.query_scan(M, parts, labels, keep, assign, np.ascontiguousarray(tables.reshape(ma, M * 16)), R)
+        assert want["rc"] == res["status"][q] == 0, q
+        sz = res["sizes"][q]
+        assert heaps_equal((res["keys"][q, :sz], res["values"][q, :sz]), (want["keys"], want["values"])), q
+
+
+@pytest.mark.gpu
+def test_c3_shape_ivf_16x4_k4096_nprobe32(pyqadc, po):
+    """BASELINE configs[2] shape at 1.2e7 codes: K = 4096 ragged labelled partitions, nprobe = 32, 128-d, R = 100,
+    keep = 1 %, a 1024-query batch (the batch size bench.py's `ivf` leg pipelines); 48 sampled queries vs the oracle."""
+    rng = np.random.default_rng(4096)
+    M, K, N, dim, ma, R, keep, nq = 16, 4096, 12_000_000, 128, 32, 100, 0.01, 1024
+    idx, parts, labels, cb, coarse, sizes = _build(pyqadc, rng, M, K, N, dim, keep)
+    queries = rng.normal(size=(nq, dim)).astype(np.float32)
+    res = idx.search(queries, ma, R)
+    assert int(res["status"].sum()) == 0
+    _check(po, res, rng.choice(nq, 48, replace=False), queries, parts, labels, cb, coarse, M, ma, keep, R)
+    idx.close()
+
+
+@pytest.mark.gpu
+def test_c5_shape_ivf_32x4_dim96_nprobe64(pyqadc, po):
+    """BASELINE configs[4] shape on one GPU's worth of data: 32x4 codes (16 B), 96-d vectors => sq_dim 3 (the generic
+    sub-vector loops; the reference's table dispatch has no such case), K = 1024, nprobe = 64, R = 100, 4e6 codes;
+    a 256-query batch, 32 sampled queries vs the oracle."""
+    rng = np.random.default_rng(96)
+    M, K, N, dim, ma, R, keep, nq = 32, 1024, 4_000_000, 96, 64, 100, 0.01, 256
+    idx, parts, labels, cb, coarse, sizes = _build(pyqadc, rng, M, K, N, dim, keep)
+    queries = rng.normal(size=(nq, dim)).astype(np.float32)
+    res = idx.search(queries, ma, R)
+    assert int(res["status"].sum()) == 0
+    _check(po, res, rng.choice(nq, 32, replace=False), queries, parts, labels, cb, coarse, M, ma, keep, R)
+    idx.close()
