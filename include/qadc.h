@@ -239,6 +239,31 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
  * Measurement (bench.py): HIP-event timing of the int8 scan kernel on the index's stream.
  * Enabled with qadc_set_option(idx, "profile", 1).  Totals since the last reset.
  * ------------------------------------------------------------------------------------------- */
+/* ---- Multi-GPU (north star: "the code list shards across the 8 GPUs of one node with a final RCCL
+ * allgather of per-shard top-k over xGMI").  One process per GPU; every rank holds a contiguous range of every
+ * partition (qadc_index_add_partition_shard) and submits the same batches.  What is gathered is each shard's ordered
+ * PUSH STREAM, not its final top-R: re-pushing final heaps is not exact under ties (binheap.hpp:75-116 resolves ties by
+ * push order).  qadc_dist_collect replaces qadc_query_scan_collect: it packs this rank's streams (already in device
+ * memory), runs ONE ncclAllGather (device to device, no host staging), and replays the world's streams in global
+ * scan order (assign slot, rank, position) on the GPU, one lane per query — every rank ends with every query's heap,
+ * so there is no second collective.  `extra` (optional, extra_n floats per rank) rides in the same all-gather and comes
+ * back as extra_out[world][extra_n]: the multi-rank loop of bench.py ships the next batch's sharded pre-scan values
+ * this way (qadc_prescan_submit).  RCCL is loaded with dlopen by qadc_dist_unique_id / qadc_dist_init; a single-GPU
+ * user never loads it.  R <= 288 (the replay keeps 64 heaps per wave in LDS); world <= 16.
+ *   rank 0:      qadc_dist_unique_id(id)  ... ship the 128 bytes to the other ranks by any means ...
+ *   every rank:  qadc_dist_init(idx, rank, world, id);  then per batch  qadc_query_scan_submit(...); qadc_dist_collect(...) */
+#define QADC_DIST_ID_BYTES 128
+int qadc_dist_unique_id(uint8_t* id128);
+int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128);
+int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
+                      const float* extra, int extra_n, float* extra_out);
+int qadc_dist_shutdown(qadc_index* idx);
+/* The merge half of qadc_dist_collect on a caller-assembled gather result (host memory; `world` blocks of block_words
+ * u64 each: [nq x {offset, count, flags, 0} as u32][entries = key | value << 32 | assign slot << 40]...): lets a single
+ * GPU check the multi-rank replay order.  sizes[q] = -1 when a block reports an overflow / unordered query. */
+int qadc_dist_merge_blocks(int device_id, int world, int nq, int ma, int R, const uint64_t* gathered, uint64_t block_words,
+                           uint32_t* keys, int8_t* values, int32_t* sizes);
+
 typedef struct qadc_profile {
     uint64_t scan_launches;   /* launches of the streaming int8 scan kernels (scan_i8_kernel, scan_i8_mq_kernel) */
     uint64_t scan_codes;      /* codes those launches scanned (algorithmic bytes = codes * M/2) */
@@ -263,7 +288,8 @@ typedef struct qadc_profile {
     uint64_t wgq_codes;       /* codes they probed (algorithmic bytes = codes * M/2) */
     double wgq_ms;            /* HIP-event time of those launches */
     uint64_t wgq_front_cycles; /* shader cycles the query workgroups spent in pre-scan + select + quantizer (summed over queries) */
-    uint64_t wgq_scan_cycles;  /* ... and in the int8 scan */
+    uint64_t wgq_scan_cycles;  /* ... in the int8 scan */
+    uint64_t wgq_sort_cycles;  /* ... and in the final candidate sort + ordered stream write */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

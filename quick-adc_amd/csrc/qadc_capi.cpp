@@ -12,6 +12,7 @@
 #include "../../include/qadc.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -20,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -159,6 +161,7 @@ struct Slot {
 
     // one-workgroup-per-query path (qadc_query_kernel.hip): no planner, no levels, no sort
     bool wgq = false;
+    bool dist_batch = false;            // launched with the native multi-GPU merge active: streams kept in device memory
     uint32_t wgq_cap = 0;               // stream entries per query (regrown on overflow)
     uint64_t wgq_fcap = 0;              // pre-scan values per query in the global scratch (0 = they fit LDS)
     DevBuf<uint32_t> d_qflags;          // [nq][4]: {flags, entries} for replay_heap_lanes_kernel
@@ -200,6 +203,47 @@ struct Slot {
     std::vector<uint64_t> out_entries;
     std::vector<uint64_t> out_off;
 };
+
+// ---- native multi-GPU merge (qadc_dist_*): RCCL through dlopen, so that the library has no link-time dependency
+// on it and a single-GPU user never loads it ----
+struct QadcNcclId { char internal[128]; };                  // layout of ncclUniqueId (rccl.h)
+struct DistState {
+    void* lib = nullptr;
+    int (*GetUniqueId)(QadcNcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, QadcNcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+    uint32_t cap_entries = 1u << 16;                         // entries per rank block; regrown (by every rank alike) on overflow
+    DevBuf<uint64_t> d_block, d_gathered;
+    DevBuf<uint32_t> d_src;                                  // [3][nq]: offset, count, flags of this rank's streams
+    PinBuf<uint32_t> h_src;
+    DevBuf<float> d_extra;
+    PinBuf<float> h_extra;
+    PinBuf<unsigned char> h_out;                             // mapped: heaps u64[nq][R], sizes u32[nq]
+    unsigned char* d_out = nullptr;
+    unsigned char* h_out_mapped = nullptr;
+    PinBuf<uint32_t> h_hdr;                                  // gathered headers [world][nq][4]
+    PinBuf<float> h_extra_all;                               // gathered extra payload [world][extra_n]
+};
+
+int load_rccl(DistState& d, std::string& err) {
+    if (d.lib) return 0;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        d.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (d.lib) break;
+    }
+    if (!d.lib) { err = std::string("cannot load RCCL: ") + dlerror(); return -1; }
+    d.GetUniqueId = reinterpret_cast<int (*)(QadcNcclId*)>(dlsym(d.lib, "ncclGetUniqueId"));
+    d.CommInitRank = reinterpret_cast<int (*)(void**, int, QadcNcclId, int)>(dlsym(d.lib, "ncclCommInitRank"));
+    d.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(d.lib, "ncclAllGather"));
+    d.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(d.lib, "ncclCommDestroy"));
+    d.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(d.lib, "ncclGetErrorString"));
+    if (!d.GetUniqueId || !d.CommInitRank || !d.AllGather || !d.CommDestroy) { err = "RCCL lacks an expected symbol"; return -1; }
+    return 0;
+}
 
 }  // namespace
 
@@ -261,6 +305,7 @@ struct qadc_index {
     Slot pre_slot[2];                   // sharded pre-scan passes (mode 1): own buffers, so that one can run
                                         // while slot[i] still holds an uncollected batch
     qadc_profile prof{};
+    DistState* dist = nullptr;          // qadc_dist_init
 };
 
 namespace {
@@ -570,7 +615,9 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     s.h_entries = reinterpret_cast<uint64_t*>(s.h_result.p + sizeof(QueryOut) * (size_t)nq);
     s.h_heaps = reinterpret_cast<uint64_t*>(s.h_result.p + off_heaps);
     s.h_heap_sizes = reinterpret_cast<uint32_t*>(s.h_result.p + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
-    if (s.dev_replay) HIPCHECK(s.d_stream.ensure(s.out_cap));
+    s.dist_batch = idx->dist != nullptr;
+    const bool dev_stream = s.dev_replay || s.dist_batch;          // the native multi-GPU merge gathers from device memory
+    if (dev_stream) HIPCHECK(s.d_stream.ensure(s.out_cap));
     s.h_export = reinterpret_cast<float*>(s.h_result.p);
     s.h_export_flags = reinterpret_cast<uint32_t*>(s.h_result.p + sizeof(float) * (size_t)s.R * nq);
     HIPCHECK(s.d_cands.ensure((size_t)nq * s.cap_q));
@@ -736,7 +783,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
     }
     launch_sort_cands(s.d_qs, s.d_cands.p, s.cap_q, nq, s.d_qout, s.d_entries, s.out_cap, s.d_hdr, st,
-                      s.dev_replay ? s.d_stream.p : nullptr);
+                      dev_stream ? s.d_stream.p : nullptr);
     if (s.dev_replay)
         launch_replay_heap(s.d_qs, s.d_stream.p, s.out_cap, nq, (uint32_t)s.R,
                            reinterpret_cast<uint64_t*>(d_result + off_heaps),
@@ -783,6 +830,8 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     // on the device][heaps u64[nq][R]][sizes u32[nq]] ----
     const uint32_t cap = s.wgq_cap;
     s.dev_replay = idx->device_replay_nq > 0 && nq >= idx->device_replay_nq && (uint32_t)s.R <= replay_lanes_max_R();
+    s.dist_batch = idx->dist != nullptr;
+    if (s.dist_batch) s.dev_replay = true;                   // streams stay on the device for the gather (qadc_dist_collect)
     const size_t stream_entries = (size_t)nq * cap;
     if (stream_entries >= (1ull << 32)) return fail(QADC_E_CAPACITY, "candidate stream capacity exceeds 2^32 entries");
     s.out_cap = (uint32_t)stream_entries;
@@ -872,6 +921,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     A.qstate_flags = s.dev_replay ? s.d_qflags.p : nullptr;
     A.R = (uint32_t)s.R;
     A.quant_mode = idx->quant_mode;
+    A.nontemporal = idx->total_codes * (uint64_t)idx->cs > (200ull << 20);   // (same rule as the level path)
     if (idx->profile) HIPCHECK(prof_event(s, st));
     HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st));
     if (idx->profile) HIPCHECK(prof_event(s, st));
@@ -882,6 +932,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             st = idx->sort_stream;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
         }
+        if (!s.dist_batch)
         HIPCHECK(launch_replay_heap_lanes(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R,
                                           reinterpret_cast<uint64_t*>(d_result + off_heaps),
                                           reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq), st));
@@ -1096,7 +1147,8 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
         idx->prof.wgq_ms += ms;
         idx->prof.wgq_launches++;
         for (int q = 0; q < s.nq; ++q) {
-            idx->prof.wgq_front_cycles += (uint64_t)s.h_qout[q].pad[0] << 4;
+            idx->prof.wgq_front_cycles += (uint64_t)(s.h_qout[q].pad[0] & 0xffffu) << 6;
+            idx->prof.wgq_sort_cycles += (uint64_t)(s.h_qout[q].pad[0] >> 16) << 6;
             idx->prof.wgq_scan_cycles += (uint64_t)s.h_qout[q].pad[1] << 4;
         }
         idx->prof.wgq_queries += (uint64_t)s.nq;
@@ -1130,7 +1182,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
     s.out_entries.clear();
     s.out_off.assign((size_t)s.nq + 1, 0);
     s.skipped_streams = false;
-    if (s.wgq && s.dev_replay) {
+    if (s.wgq && s.dev_replay && !s.dist_batch) {
         // the streams stayed in device memory; fetch them only if the caller wants them (or a query could not be
         // replayed on the device): one strided copy of the used part of every query's region
         bool need = need_stream;
@@ -1319,6 +1371,7 @@ int qadc_index_destroy(qadc_index* idx) {
     if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
     if (idx->front_stream) (void)hipStreamDestroy(idx->front_stream);
     if (idx->sort_stream) (void)hipStreamDestroy(idx->sort_stream);
+    (void)qadc_dist_shutdown(idx);
     delete idx;
     return QADC_OK;
 }
@@ -1573,6 +1626,10 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
     else if (n == "wgq") idx->wgq = (int)value;
     else if (n == "wgq_variant") idx->wgq_variant = (int)value;
+    else if (n == "dist_cap_entries") {                       // entries per rank block of the native gather (test knob)
+        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
+        idx->dist->cap_entries = (uint32_t)std::max(16.0, std::min(value, 1073741824.0));
+    }
     else if (n == "table_form") idx->table_form = std::max(0, std::min((int)value, 2));
     else if (n == "wgq_cand_cap") idx->wgq_cand_cap = (uint32_t)std::max(1.0, std::min(value, (double)kQueryCandCap));
     else if (n == "wgq_min_nq") idx->wgq_min_nq = (int)std::max(value, 1.0);
@@ -1973,6 +2030,175 @@ int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vec
     HIPCHECK(hipFree(d_v));
     HIPCHECK(hipFree(d_c));
     return rc;
+}
+
+/* ---- native multi-GPU merge: one ncclAllGather per batch, device memory to device memory ---- */
+int qadc_dist_unique_id(uint8_t* id128) {
+    if (!id128) return fail(QADC_E_ARG, "id is null");
+    DistState tmp;
+    std::string err;
+    if (load_rccl(tmp, err)) return fail(QADC_E_HIP, err);
+    QadcNcclId id;
+    const int rc = tmp.GetUniqueId(&id);
+    if (rc != 0) return fail(QADC_E_HIP, std::string("ncclGetUniqueId: ") + (tmp.GetErrorString ? tmp.GetErrorString(rc) : "error"));
+    std::memcpy(id128, id.internal, 128);
+    return QADC_OK;                                          // (the library handle stays loaded for the process)
+}
+
+int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
+    if (!idx || !id128 || world < 1 || world > 16 || rank < 0 || rank >= world) return fail(QADC_E_ARG, "need 0 <= rank < world <= 16");
+    if (idx->dist) return fail(QADC_E_STATE, "qadc_dist_init was already called");
+    for (auto& sl : idx->slot)
+        if (sl.busy) return fail(QADC_E_STATE, "collect every batch before qadc_dist_init");
+    if (int rc = use_device(idx)) return rc;
+    std::unique_ptr<DistState> d(new DistState());
+    std::string err;
+    if (load_rccl(*d, err)) return fail(QADC_E_HIP, err);
+    QadcNcclId id;
+    std::memcpy(id.internal, id128, 128);
+    const int rc = d->CommInitRank(&d->comm, world, id, rank);
+    if (rc != 0) return fail(QADC_E_HIP, std::string("ncclCommInitRank: ") + (d->GetErrorString ? d->GetErrorString(rc) : "error"));
+    d->rank = rank;
+    d->world = world;
+    idx->dist = d.release();
+    return QADC_OK;
+}
+
+int qadc_dist_merge_blocks(int device_id, int world, int nq, int ma, int R, const uint64_t* gathered, uint64_t block_words,
+                           uint32_t* keys, int8_t* values, int32_t* sizes) {
+    if (world < 1 || world > 16 || nq <= 0 || ma <= 0 || R <= 0 || (uint32_t)R > replay_lanes_max_R() || !gathered || !sizes)
+        return fail(QADC_E_ARG, "bad arguments");
+    HIPCHECK(hipSetDevice(device_id));
+    DevBuf<uint64_t> d_g, d_h;
+    DevBuf<uint32_t> d_s;
+    HIPCHECK(d_g.ensure((size_t)block_words * world));
+    HIPCHECK(d_h.ensure((size_t)nq * R));
+    HIPCHECK(d_s.ensure(nq));
+    HIPCHECK(hipMemcpy(d_g.p, gathered, sizeof(uint64_t) * (size_t)block_words * world, hipMemcpyHostToDevice));
+    HIPCHECK(launch_dist_merge_lanes(d_g.p, (size_t)block_words, world, nq, ma, (uint32_t)R, d_h.p, d_s.p, nullptr));
+    std::vector<uint64_t> hv((size_t)nq * R);
+    std::vector<uint32_t> hs(nq);
+    HIPCHECK(hipMemcpy(hv.data(), d_h.p, sizeof(uint64_t) * hv.size(), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(hs.data(), d_s.p, sizeof(uint32_t) * nq, hipMemcpyDeviceToHost));
+    d_g.release(); d_h.release(); d_s.release();
+    for (int q = 0; q < nq; ++q) {
+        sizes[q] = hs[q] == 0xffffffffu ? -1 : (int32_t)hs[q];
+        for (uint32_t i = 0; hs[q] != 0xffffffffu && i < hs[q]; ++i) {
+            if (keys) keys[(size_t)q * R + i] = (uint32_t)hv[(size_t)q * R + i];
+            if (values) values[(size_t)q * R + i] = (int8_t)(hv[(size_t)q * R + i] >> 32);
+        }
+    }
+    return QADC_OK;
+}
+
+int qadc_dist_shutdown(qadc_index* idx) {
+    if (!idx || !idx->dist) return QADC_OK;
+    (void)hipSetDevice(idx->device);
+    (void)hipStreamSynchronize(idx->stream);
+    DistState* d = idx->dist;
+    if (d->comm) (void)d->CommDestroy(d->comm);
+    d->d_block.release(); d->d_gathered.release(); d->d_src.release(); d->h_src.release(); d->d_extra.release();
+    d->h_extra.release(); d->h_out.release(); d->h_hdr.release(); d->h_extra_all.release();
+    delete d;
+    idx->dist = nullptr;
+    return QADC_OK;
+}
+
+int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
+                      const float* extra, int extra_n, float* extra_out) {
+    if (!idx || !idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
+    if (slot < 0 || slot >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1, 2 or 3");
+    if (extra_n < 0 || (extra_n && (!extra || !extra_out))) return fail(QADC_E_ARG, "extra payload buffers missing");
+    DistState& d = *idx->dist;
+    Slot& s = idx->slot[slot];
+    if (s.busy && !s.dist_batch) return fail(QADC_E_STATE, "the batch was submitted before qadc_dist_init");
+    if ((uint32_t)s.R > replay_lanes_max_R()) return fail(QADC_E_ARG, "qadc_dist_collect needs R <= 288");
+    if (int rc = collect_common(idx, slot, /*need_stream=*/false)) return rc;
+    const int nq = s.nq, R = s.R, world = d.world;
+    std::vector<int32_t> st_local;
+    if (!status) {
+        st_local.resize(nq);
+        status = st_local.data();
+    }
+    finish_float_outputs(idx, s, status, nullptr, nullptr);
+    // where this rank's ordered streams lie in device memory
+    HIPCHECK(d.h_src.ensure(3 * (size_t)nq));
+    HIPCHECK(d.d_src.ensure(3 * (size_t)nq));
+    for (int q = 0; q < nq; ++q) {
+        const QueryOut& qs = s.h_qout[q];
+        const bool ordered = (qs.flags & 4u) != 0;
+        d.h_src.p[q] = qs.out_off;
+        d.h_src.p[nq + q] = ordered ? qs.count + qs.reps : 0u;
+        d.h_src.p[2 * nq + q] = qs.flags;
+        if (!ordered && !(qs.flags & 1u))
+            return fail(QADC_E_CAPACITY, "a query was not ordered on the device (more than 16384 candidates): not supported by "
+                                         "the native merge; use the stream interface");
+    }
+    if (extra_n) {
+        HIPCHECK(d.h_extra.ensure(extra_n));
+        HIPCHECK(d.d_extra.ensure(extra_n));
+        std::memcpy(d.h_extra.p, extra, sizeof(float) * extra_n);
+    }
+    const size_t heaps_bytes = (sizeof(uint64_t) * (size_t)R + sizeof(uint32_t)) * (size_t)nq;
+    HIPCHECK(d.h_out.ensure(heaps_bytes + 16, hipHostMallocMapped | hipHostMallocCoherent));
+    if (d.h_out.p != d.h_out_mapped) {
+        HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d.d_out), d.h_out.p, 0));
+        d.h_out_mapped = d.h_out.p;
+    }
+    HIPCHECK(d.h_hdr.ensure((size_t)world * nq * 4));
+    if (extra_n) HIPCHECK(d.h_extra_all.ensure((size_t)world * extra_n));
+    hipStream_t st = idx->stream;
+    uint64_t* h_heaps = reinterpret_cast<uint64_t*>(d.h_out.p);
+    uint32_t* h_sizes = reinterpret_cast<uint32_t*>(d.h_out.p + sizeof(uint64_t) * (size_t)R * nq);
+    for (int attempt = 0;; ++attempt) {
+        const size_t bw = dist_block_words(nq, d.cap_entries, (uint32_t)extra_n);
+        HIPCHECK(d.d_block.ensure(bw));
+        HIPCHECK(d.d_gathered.ensure(bw * world));
+        HIPCHECK(hipMemcpyAsync(d.d_src.p, d.h_src.p, sizeof(uint32_t) * 3 * nq, hipMemcpyHostToDevice, st));
+        if (extra_n) HIPCHECK(hipMemcpyAsync(d.d_extra.p, d.h_extra.p, sizeof(float) * extra_n, hipMemcpyHostToDevice, st));
+        HIPCHECK(launch_dist_pack(d.d_src.p, d.d_src.p + nq, d.d_src.p + 2 * nq, nq, s.d_stream.p, d.cap_entries,
+                                  extra_n ? d.d_extra.p : nullptr, (uint32_t)extra_n, d.d_block.p, st));
+        const int rc = d.AllGather(d.d_block.p, d.d_gathered.p, bw, /*ncclUint64*/ 5, d.comm, st);
+        if (rc != 0) return fail(QADC_E_HIP, std::string("ncclAllGather: ") + (d.GetErrorString ? d.GetErrorString(rc) : "error"));
+        HIPCHECK(launch_dist_merge_lanes(d.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, reinterpret_cast<uint64_t*>(d.d_out),
+                                         reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq), st));
+        // every rank's header (to size a retry identically everywhere) and extra payload come back with the heaps
+        HIPCHECK(hipMemcpy2DAsync(d.h_hdr.p, sizeof(uint32_t) * 4 * nq, d.d_gathered.p, sizeof(uint64_t) * bw,
+                                  sizeof(uint32_t) * 4 * nq, world, hipMemcpyDeviceToHost, st));
+        if (extra_n)
+            HIPCHECK(hipMemcpy2DAsync(d.h_extra_all.p, sizeof(float) * extra_n, d.d_gathered.p + 2 * (size_t)nq + d.cap_entries,
+                                      sizeof(uint64_t) * bw, sizeof(float) * extra_n, world, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        uint64_t need = 0;
+        bool overflow = false, unordered = false;
+        for (int g = 0; g < world; ++g) {
+            uint64_t tot = 0;
+            for (int q = 0; q < nq; ++q) {
+                const uint32_t* h = d.h_hdr.p + ((size_t)g * nq + q) * 4;
+                tot += h[1];
+                overflow |= (h[2] & 64u) != 0;
+                unordered |= !(h[2] & 4u) && !(h[2] & 1u);
+            }
+            need = std::max(need, tot);
+        }
+        if (unordered) return fail(QADC_E_CAPACITY, "a rank could not order a query on the device: not supported by the native merge");
+        if (!overflow) break;
+        if (attempt >= 2 || need >= (1ull << 31)) return fail(QADC_E_CAPACITY, "gather block overflow persists");
+        d.cap_entries = (uint32_t)((need + need / 8 + 4095) / 4096 * 4096);   // the same on every rank: they all saw the same headers
+        idx->prof.regrows++;
+    }
+    for (int q = 0; q < nq; ++q) {
+        uint32_t sz = h_sizes[q];
+        if (status[q] || sz == 0xffffffffu) sz = 0;
+        if (sizes) sizes[q] = (int32_t)sz;
+        const uint64_t* hv = h_heaps + (size_t)q * R;
+        for (uint32_t i = 0; i < sz; ++i) {
+            if (keys) keys[(size_t)q * R + i] = (uint32_t)hv[i];
+            if (values) values[(size_t)q * R + i] = (int8_t)(hv[i] >> 32);
+        }
+    }
+    if (extra_n) std::memcpy(extra_out, d.h_extra_all.p, sizeof(float) * (size_t)world * extra_n);
+    return QADC_OK;
 }
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out) {

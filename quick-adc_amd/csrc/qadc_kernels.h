@@ -120,6 +120,7 @@ struct QueryKernelArgs {
     uint32_t* qstate_flags;  // optional [nq][4]: {flags, entries} for replay_heap_lanes_kernel, or nullptr
     uint32_t R;
     int quant_mode;
+    int nontemporal;         // non-temporal code loads (database larger than the Infinity Cache)
 };
 
 size_t query_kernel_lds_bytes(int M);
@@ -129,6 +130,20 @@ hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& 
 uint32_t replay_lanes_max_R();
 hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
                                     uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
+
+// ---- multi-GPU merge around one ncclAllGather (qadc_dist_collect) ----
+// Per-rank block (u64 words): [nq x {offset, count, flags, 0} as u32][cap_entries entries][extra floats, padded to u64].
+inline size_t dist_block_words(int nq, uint32_t cap_entries, uint32_t extra_n) {
+    return 2 * (size_t)nq + cap_entries + (extra_n + 1) / 2;
+}
+// d_src_off/cnt/flags[q]: where query q's ordered stream starts inside d_stream, its entries, its QueryState flags.
+hipError_t launch_dist_pack(const uint32_t* d_src_off, const uint32_t* d_src_cnt, const uint32_t* d_src_flags, int nq,
+                            const uint64_t* d_stream, uint32_t cap_entries, const float* d_extra, uint32_t extra_n,
+                            uint64_t* d_block, hipStream_t stream);
+// world blocks -> heaps [nq][R] (key | value << 32) + sizes (0xffffffff: some rank's block overflowed / query not
+// ordered on a device: the caller regrows and repeats, or falls back).  world <= 16, R <= replay_lanes_max_R().
+hipError_t launch_dist_merge_lanes(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
+                                   uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
 
 // A failed per-device setup step of a launcher (dynamic-LDS opt-in) since the last call, or hipSuccess.
 hipError_t take_launch_error();

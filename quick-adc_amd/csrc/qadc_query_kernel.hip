@@ -149,7 +149,9 @@ __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint
 }
 
 // OCC = waves per SIMD the register budget is sized for: 8 = two workgroups per CU (64 VGPRs), 4 = one (128 VGPRs).
-template <int M, int U, int OCC>
+// NT = non-temporal code loads (lists that stream from HBM anyway); a database that fits the 256 MiB Infinity Cache
+// keeps the default policy and is re-read from the cache by every query.
+template <int M, int U, int OCC, bool NT>
 __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A) {
     using C = QCfg<M>;
     if (reinterpret_cast<uintptr_t>((q_lds_bytes_t)qsmem) != 0) __builtin_trap();   // the lookups use absolute LDS addresses
@@ -434,10 +436,10 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             for (int i = 0; i < kRounds; ++i) {
                 const uint32_t off = (tl + (uint32_t)i * kQWaves) * 64u + lane;
                 if (decltype(full)::value) {
-                    v[i] = __builtin_nontemporal_load(src + t0 + off);
+                    v[i] = NT ? __builtin_nontemporal_load(src + t0 + off) : src[t0 + off];
                 } else {
                     v[i] = u32x4{0, 0, 0, 0};
-                    if (off < width) v[i] = __builtin_nontemporal_load(src + t0 + off);
+                    if (off < width) v[i] = NT ? __builtin_nontemporal_load(src + t0 + off) : src[t0 + off];
                 }
             }
         };
@@ -477,7 +479,10 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
                 last_cnt = cnt;
             }
         };
-        for (uint32_t t0 = 0; t0 < nvec;) {
+        // (tried and dropped: a register-resident first block that walks the ramp epochs without a memory round trip
+        // each — no measurable gain on the 10^5-code latency point, and its registers cost the IVF shape 10 %)
+        uint32_t t0 = 0;
+        while (t0 < nvec) {
             const uint32_t rest = nvec - t0;
             uint32_t width;
             if (ramp < kEpochVec) {
@@ -514,6 +519,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
         a = a_next;
     }
     // ---- 4. order the candidates: (assign slot, position) ascending = scan order ----
+    const uint64_t clk2 = __builtin_readcyclecounter();
     __syncthreads();                                             // the candidate stores of every wave are complete
     const uint32_t ncand = s_ccount;
     uint32_t out_count = 0;
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     } else if (ncand) {
         uint64_t* skey = reinterpret_cast<uint64_t*>(qsmem);             // [n2] (slot << 44 | pos << 12 | index)
         uint64_t* spay = reinterpret_cast<uint64_t*>(qsmem + 32768);     // [ncand] key | val << 32 | reps << 40 | slot << 48
-        uint32_t n2 = 64;
+        uint32_t n2 = kQWG;                                      // >= one element per thread: every wave owns n2/16 >= 64
         while (n2 < ncand) n2 <<= 1;
         for (uint32_t i = tid; i < n2; i += kQWG) {
             uint64_t k = ~0ull;
@@ -533,18 +539,27 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             }
             skey[i] = k;
         }
-        __syncthreads();
+        q_lds_barrier();
+        // bitonic network, wave-major ownership: wave w owns elements [w*chunk, (w+1)*chunk).  An exchange at distance
+        // j < chunk stays inside one wave's elements and needs no workgroup barrier (LDS traffic of a wave is in order);
+        // only the few steps with j >= chunk synchronise the workgroup: 10 barriers instead of 55 for 1024 elements.
+        const uint32_t chunk = n2 / kQWaves;
         for (uint32_t k = 2; k <= n2; k <<= 1)
             for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
-                for (uint32_t i = tid; i < n2; i += kQWG) {
+                const bool local = jj < chunk;
+                if (!local) q_lds_barrier();
+                for (uint32_t r = 0; r < chunk; r += 64) {
+                    const uint32_t i = wave * chunk + r + lane;
                     const uint32_t pi = i ^ jj;
                     if (pi > i) {
                         const uint64_t x = skey[i], y = skey[pi];
                         if ((x > y) == ((i & k) == 0)) { skey[i] = y; skey[pi] = x; }
                     }
                 }
-                __syncthreads();
+                if (local) q_wave_lds_sync();
+                else q_lds_barrier();
             }
+        q_lds_barrier();
         // expand the padding-lane replays while writing: thread t owns sorted entries [4t, 4t+4)
         uint64_t pay[4];
         uint32_t mine = 0;
@@ -563,9 +578,8 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             const uint32_t o = __shfl_up(incl, dlt, 64);
             if (lane >= (uint32_t)dlt) incl += o;
         }
-        __syncthreads();                                         // (skey / spay reads done before wcnt reuse is irrelevant: wcnt is in misc)
         if (lane == 63) wcnt[wave] = incl;
-        __syncthreads();
+        q_lds_barrier();
         uint32_t wp = incl - mine;
         for (uint32_t w = 0; w < kQWaves; ++w) {
             const uint32_t c_ = wcnt[w];
@@ -592,8 +606,10 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
         o.out_off = (uint32_t)((size_t)q * A.cap);
         o.qmin = qmin;
         o.qmax = qmax;
-        o.pad[0] = (uint32_t)((clk1 - clk0) >> 4);               // pre-scan + select + quantizer
-        o.pad[1] = (uint32_t)((__builtin_readcyclecounter() - clk1) >> 4);   // int8 scan
+        const uint64_t clk3 = __builtin_readcyclecounter();
+        // phase clocks: pad[0] = (pre-scan + select + quantizer) >> 6 | (sort + ordered write) >> 6 << 16; pad[1] = scan >> 4
+        o.pad[0] = (uint32_t)min((clk1 - clk0) >> 6, (uint64_t)0xffff) | ((uint32_t)min((clk3 - clk2) >> 6, (uint64_t)0xffff) << 16);
+        o.pad[1] = (uint32_t)((clk2 - clk1) >> 4);
         A.qout[q] = o;
         if (A.qstate_flags) {                                    // what replay_heap_lanes_kernel reads
             A.qstate_flags[4 * q + 0] = flags | 4u;
@@ -610,24 +626,15 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
 // sequential (each is a dependent chain of LDS round trips); 64 of them per wave, and a few waves per batch,
 // replay a 1024-query IVF batch in the shadow of the next batch's scan, on a handful of CUs.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void replay_heap_lanes_kernel(const uint32_t* __restrict__ qflags,
-                                                               const uint64_t* __restrict__ stream, uint32_t cap, int nq,
-                                                               uint32_t R, uint64_t* __restrict__ heaps,
-                                                               uint32_t* __restrict__ heap_sizes) {
-    uint64_t* hv = reinterpret_cast<uint64_t*>(qsmem);          // [R][64]
-    const uint32_t lane = threadIdx.x;
-    const int q = blockIdx.x * 64 + (int)lane;
-    const bool have = q < nq;
-    uint32_t flags = 0, n = 0;
-    if (have) { flags = qflags[4 * q]; n = qflags[4 * q + 1]; }
-    bool host_replay = false;                                   // overflowed stream: the batch is re-run / replayed on the host
-    if (have && n > cap) { host_replay = true; n = 0; }
-    if (flags & 1u) n = 0;                                      // qmax too high: the reference exits, no result
-    const uint64_t* __restrict__ src = stream + (size_t)(have ? q : 0) * cap;
-    uint32_t size = 0;
-    auto val_of = [](uint64_t e) { return (int32_t)((e >> 32) & 0xffu); };
-    auto at = [&](uint32_t i) -> uint64_t& { return hv[i * 64u + lane]; };
-    auto push = [&](uint64_t e) {
+// One lane's max-heap of capacity R in LDS, slot i at (i*64 + lane) * 8 bytes.  push() = kv_binheap::push
+// (binheap.hpp:75-116): appended and bubbled up past strictly smaller parents while there is room; afterwards accepted
+// only if strictly below the root, sinking with the left child preferred on ties, stopping at a child <= the value.
+struct LaneHeap {
+    uint64_t* hv;
+    uint32_t lane, R, size;
+    __device__ __forceinline__ static int32_t val_of(uint64_t e) { return (int32_t)((e >> 32) & 0xffu); }
+    __device__ __forceinline__ uint64_t& at(uint32_t i) { return hv[i * 64u + lane]; }
+    __device__ __forceinline__ void push(uint64_t e) {
         const int32_t value = val_of(e);
         if (size != R) {
             uint32_t i = size++;
@@ -657,22 +664,16 @@ __global__ __launch_bounds__(64) void replay_heap_lanes_kernel(const uint32_t* _
             i = c;
         }
         at(i) = e;
-    };
-    if (have && !host_replay && !(flags & 1u)) push((uint64_t)127 << 32);   // the sentinel: key 0, value 127
-    // four entries per lane in flight: the stream of a lane is sequential in memory, 8 bytes at a time
-    for (uint32_t j = 0; j < n; j += 4) {
-        uint64_t e4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) e4[u] = j + u < n ? src[j + u] & 0xffffffffffull : 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (j + u < n) push(e4[u]);
     }
-    // write the heaps out query by query, coalesced
+};
+
+// heaps of the 64 queries of a wave -> global, query by query, coalesced; 0xffffffff marks "replay on the host"
+__device__ __forceinline__ void lane_heaps_out(const uint64_t* hv, uint32_t lane, uint32_t size, bool host_replay, int q0, int nq,
+                                               uint32_t R, uint64_t* __restrict__ heaps, uint32_t* __restrict__ heap_sizes) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int l = 0; l < 64; ++l) {
-        const int qq = blockIdx.x * 64 + l;
+        const int qq = q0 + l;
         if (qq >= nq) break;
         const uint32_t sz = __shfl(size, l, 64);
         const uint32_t hr = __shfl((uint32_t)host_replay, l, 64);
@@ -685,13 +686,122 @@ __global__ __launch_bounds__(64) void replay_heap_lanes_kernel(const uint32_t* _
     }
 }
 
+__global__ __launch_bounds__(64) void replay_heap_lanes_kernel(const uint32_t* __restrict__ qflags,
+                                                               const uint64_t* __restrict__ stream, uint32_t cap, int nq,
+                                                               uint32_t R, uint64_t* __restrict__ heaps,
+                                                               uint32_t* __restrict__ heap_sizes) {
+    LaneHeap h{reinterpret_cast<uint64_t*>(qsmem), threadIdx.x, R, 0};
+    const uint32_t lane = threadIdx.x;
+    const int q = blockIdx.x * 64 + (int)lane;
+    const bool have = q < nq;
+    uint32_t flags = 0, n = 0;
+    if (have) { flags = qflags[4 * q]; n = qflags[4 * q + 1]; }
+    bool host_replay = false;                                   // overflowed stream: the batch is re-run / replayed on the host
+    if (have && n > cap) { host_replay = true; n = 0; }
+    if (flags & (1u | 32u)) n = 0;                              // qmax too high: the reference exits, no result / fallback pending
+    const uint64_t* __restrict__ src = stream + (size_t)(have ? q : 0) * cap;
+    if (have && !host_replay && !(flags & 1u)) h.push((uint64_t)127 << 32);   // the sentinel: key 0, value 127
+    // four entries per lane in flight: the stream of a lane is sequential in memory, 8 bytes at a time
+    for (uint32_t j = 0; j < n; j += 4) {
+        uint64_t e4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e4[u] = j + u < n ? src[j + u] & 0xffffffffffull : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j + u < n) h.push(e4[u]);
+    }
+    lane_heaps_out(h.hv, lane, h.size, host_replay, blockIdx.x * 64, nq, R, heaps, heap_sizes);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU: the code list is range-sharded over the ranks; every rank's ordered push stream is a
+// superset of the pushes the sequential scan's heap accepts from that range, so replaying the streams in GLOBAL scan
+// order (assign slot, rank, position) reproduces the reference heap array for array.  Two kernels around ONE
+// ncclAllGather (host side: qadc_dist_collect):
+//   dist_pack_kernel       this rank's streams -> one contiguous block  [nq x {offset, count, flags, -}][entries][extra]
+//   dist_merge_lanes_kernel  the world's blocks -> heaps, one lane per query (every rank computes every heap:
+//                            there is no second collective)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dist_pack_kernel(const uint32_t* __restrict__ src_off, const uint32_t* __restrict__ src_cnt,
+                                                        const uint32_t* __restrict__ src_flags, int nq,
+                                                        const uint64_t* __restrict__ stream, uint32_t cap_entries,
+                                                        const float* __restrict__ extra, uint32_t extra_n,
+                                                        uint64_t* __restrict__ block) {
+    __shared__ uint32_t red[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(block);         // [nq][4]
+    uint64_t* ent = block + 2 * (size_t)nq;
+    if (q == nq) {                                              // the extra payload rides behind the entries
+        float* dst = reinterpret_cast<float*>(ent + cap_entries);
+        for (uint32_t i = tid; i < extra_n; i += 256) dst[i] = extra[i];
+        return;
+    }
+    uint32_t part = 0;
+    for (int p = tid; p < q; p += 256) part += src_cnt[p];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const uint32_t off = red[0] + red[1] + red[2] + red[3];
+    const uint32_t n = src_cnt[q];
+    const bool fits = (uint64_t)off + n <= cap_entries;
+    if (tid == 0) {
+        hdr[4 * q + 0] = off;
+        hdr[4 * q + 1] = n;
+        hdr[4 * q + 2] = src_flags[q] | (fits ? 0u : 64u);      // bit6: this rank's block was too small
+        hdr[4 * q + 3] = 0;
+    }
+    if (!fits) return;
+    const uint64_t* __restrict__ s = stream + src_off[q];
+    for (uint32_t i = tid; i < n; i += 256) ent[off + i] = s[i];
+}
+
+__global__ __launch_bounds__(64) void dist_merge_lanes_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world,
+                                                              int nq, int ma, uint32_t R, uint64_t* __restrict__ heaps,
+                                                              uint32_t* __restrict__ heap_sizes) {
+    LaneHeap h{reinterpret_cast<uint64_t*>(qsmem), threadIdx.x, R, 0};
+    const uint32_t lane = threadIdx.x;
+    const int q = blockIdx.x * 64 + (int)lane;
+    const bool have = q < nq;
+    constexpr int kMaxWorld = 16;
+    uint32_t cur[kMaxWorld], end[kMaxWorld];
+    bool skip = !have, overflow = false;
+    for (int g = 0; g < world && g < kMaxWorld; ++g) {
+        cur[g] = end[g] = 0;
+        if (!have) continue;
+        const uint32_t* hdr = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * block_words);
+        cur[g] = hdr[4 * q + 0];
+        end[g] = cur[g] + hdr[4 * q + 1];
+        const uint32_t fl = hdr[4 * q + 2];
+        if (fl & 1u) skip = true;                               // qmax too high (identical on every rank)
+        if (fl & 64u) overflow = true;
+        if (!(fl & 4u)) overflow = true;                        // a rank could not order this query on the device
+    }
+    if (overflow) skip = true;
+    if (!skip) {
+        h.push((uint64_t)127 << 32);                            // db_query_4.cpp:276
+        for (int slot = 0; slot < ma; ++slot)
+            for (int g = 0; g < world && g < kMaxWorld; ++g) {
+                const uint64_t* __restrict__ ent = gathered + (size_t)g * block_words + 2 * (size_t)nq;
+                // a rank scans its partitions in assign order: its slots are ascending
+                while (cur[g] < end[g]) {
+                    const uint64_t e = ent[cur[g]];
+                    if (ma > 1 && (uint32_t)((e >> 40) & 0x3fffu) != (uint32_t)slot) break;
+                    h.push(e & 0xffffffffffull);
+                    ++cur[g];
+                }
+            }
+    }
+    lane_heaps_out(h.hv, lane, h.size, overflow, blockIdx.x * 64, nq, R, heaps, heap_sizes);
+}
+
 }  // namespace
 
 size_t query_kernel_lds_bytes(int M) { return M == 16 ? QCfg<16>::LDS_BYTES : QCfg<32>::LDS_BYTES; }
 uint32_t query_kernel_lds_values(int M) { return M == 16 ? QCfg<16>::FCAP : QCfg<32>::FCAP; }
 
-template <int M, int U, int OCC>
-static hipError_t launch_scan_query_v(int nq, const QueryKernelArgs& args, hipStream_t stream) {
+template <int M, int U, int OCC, bool NT>
+static hipError_t launch_scan_query_nt(int nq, const QueryKernelArgs& args, hipStream_t stream) {
     // dynamic LDS above the default limit is opted into per (kernel, device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -699,13 +809,19 @@ static hipError_t launch_scan_query_v(int nq, const QueryKernelArgs& args, hipSt
     static uint64_t done = 0;
     const size_t lds = QCfg<M>::LDS_BYTES;
     if (dev < 64 && !(done & (1ull << dev))) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         done |= 1ull << dev;
     }
-    hipLaunchKernelGGL((scan_query_kernel<M, U, OCC>), dim3(nq), dim3(kQWG), lds, stream, args);
+    hipLaunchKernelGGL((scan_query_kernel<M, U, OCC, NT>), dim3(nq), dim3(kQWG), lds, stream, args);
     return hipGetLastError();
+}
+
+template <int M, int U, int OCC>
+static hipError_t launch_scan_query_v(int nq, const QueryKernelArgs& args, hipStream_t stream) {
+    return args.nontemporal ? launch_scan_query_nt<M, U, OCC, true>(nq, args, stream)
+                            : launch_scan_query_nt<M, U, OCC, false>(nq, args, stream);
 }
 
 // variant = 64-vector tiles (16-byte loads per lane in flight) per wave and iteration: 0 -> 2 (default), 1 -> 3, 2 -> 4, 3 -> 6.
@@ -724,6 +840,37 @@ hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& 
 }
 
 uint32_t replay_lanes_max_R() { return 288; }                    // R * 512 B of LDS per wave (<= 144 KiB)
+
+static hipError_t lane_heap_lds_optin(const void* fn, uint64_t& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && !(done & (1ull << dev))) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(replay_lanes_max_R() * 512));
+        if (e != hipSuccess) return e;
+        done |= 1ull << dev;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_dist_pack(const uint32_t* d_src_off, const uint32_t* d_src_cnt, const uint32_t* d_src_flags, int nq,
+                            const uint64_t* d_stream, uint32_t cap_entries, const float* d_extra, uint32_t extra_n,
+                            uint64_t* d_block, hipStream_t stream) {
+    hipLaunchKernelGGL(dist_pack_kernel, dim3(nq + 1), dim3(256), 0, stream, d_src_off, d_src_cnt, d_src_flags, nq, d_stream,
+                       cap_entries, d_extra, extra_n, d_block);
+    return hipGetLastError();
+}
+
+hipError_t launch_dist_merge_lanes(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
+                                   uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
+    static uint64_t done = 0;
+    if (world > 16) return hipErrorInvalidValue;
+    hipError_t e = lane_heap_lds_optin(reinterpret_cast<const void*>(&dist_merge_lanes_kernel), done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dist_merge_lanes_kernel, dim3((nq + 63) / 64), dim3(64), (size_t)R * 512, stream, d_gathered, block_words,
+                       world, nq, ma, R, d_heaps, d_heap_sizes);
+    return hipGetLastError();
+}
 
 hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
                                     uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {

@@ -31,6 +31,7 @@ SYMBOLS = [
     "qadc_prescan_collect", "qadc_query_scan_submit_prescanned",
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
     "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
+    "qadc_dist_unique_id", "qadc_dist_init", "qadc_dist_collect", "qadc_dist_shutdown", "qadc_dist_merge_blocks",
 ]
 
 
@@ -42,7 +43,7 @@ class Profile(C.Structure):
                 ("host_heap_ms", C.c_double), ("host_sorted_queries", C.c_uint64), ("mq_launches", C.c_uint64),
                 ("pass_codes", C.c_uint64), ("wgq_launches", C.c_uint64), ("wgq_queries", C.c_uint64),
                 ("wgq_codes", C.c_uint64), ("wgq_ms", C.c_double), ("wgq_front_cycles", C.c_uint64),
-                ("wgq_scan_cycles", C.c_uint64)]
+                ("wgq_scan_cycles", C.c_uint64), ("wgq_sort_cycles", C.c_uint64)]
 
 
 class QadcError(RuntimeError):
@@ -110,6 +111,11 @@ def lib():
                                             C.c_int, i32p, u32p, i8p, i32p]
         L.qadc_candidates_i8.argtypes = [C.c_void_p, C.c_int, i8p, i8p]
         L.qadc_float_top1.argtypes = [C.c_void_p, C.c_int, f32p, u32p, u32p, f32p]
+        L.qadc_dist_unique_id.argtypes = [u8p]
+        L.qadc_dist_init.argtypes = [C.c_void_p, C.c_int, C.c_int, u8p]
+        L.qadc_dist_collect.argtypes = [C.c_void_p, C.c_int, u32p, i8p, i32p, i32p, f32p, C.c_int, f32p]
+        L.qadc_dist_shutdown.argtypes = [C.c_void_p]
+        L.qadc_dist_merge_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_uint64, u32p, i8p, i32p]
         L.qadc_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.qadc_profile_reset.argtypes = [C.c_void_p]
         _lib = L
@@ -142,6 +148,37 @@ def sort_keys_i8(heap_keys, heap_vals):
     out = np.zeros(len(k), np.uint32)
     _check(lib().qadc_sort_keys_i8(len(k), _p(k, u32p), _p(v, i8p), _p(out, u32p)))
     return out
+
+
+def dist_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it, the other ranks receive it by any means)."""
+    uid = np.zeros(128, np.uint8)
+    _check(lib().qadc_dist_unique_id(_p(uid, u8p)))
+    return uid
+
+
+def dist_merge_blocks(streams, nq, ma, R, device=0):
+    """streams[g] = dict(keys, vals, slots, offsets) of virtual rank g (Index.query_scan_shard_streams): assembles the
+    blocks qadc_dist_collect would gather and runs the device-side merge.  -> list of (keys, values) heaps."""
+    world = len(streams)
+    cap = max(int(st["offsets"][-1]) for st in streams) + 3
+    bw = 2 * nq + cap
+    g = np.zeros((world, bw), np.uint64)
+    for r, st in enumerate(streams):
+        hdr = g[r, :2 * nq].view(np.uint32).reshape(nq, 4)
+        off = st["offsets"].astype(np.int64)
+        hdr[:, 0] = off[:-1]
+        hdr[:, 1] = np.diff(off)
+        hdr[:, 2] = 4
+        tot = int(off[-1])
+        ent = st["keys"][:tot].astype(np.uint64) | (st["vals"][:tot].astype(np.uint8).astype(np.uint64) << np.uint64(32)) | \
+            (st["slots"][:tot].astype(np.uint64) << np.uint64(40))
+        g[r, 2 * nq:2 * nq + tot] = ent
+    keys = np.zeros((nq, R), np.uint32)
+    vals = np.zeros((nq, R), np.int8)
+    sizes = np.zeros(nq, np.int32)
+    _check(lib().qadc_dist_merge_blocks(device, world, nq, ma, R, _p(g, u64p), bw, _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p)))
+    return [(keys[q, :sizes[q]].copy(), vals[q, :sizes[q]].copy()) for q in range(nq)]
 
 
 def merge_streams_i8(gathered, world, nq, R, cap, ma, q_first, q_step, status, keys, vals, sizes):
@@ -336,6 +373,31 @@ class Index:
                                                           _p(off, u64p), _p(status, i32p), _p(qmin, f32p), _p(qmax, f32p))
         _check(rc)
         return dict(keys=ck, vals=cv, slots=cs_, offsets=off.astype(np.int64), status=status, qmin=qmin, qmax=qmax)
+
+    # ---- native multi-GPU merge (RCCL inside the library) ----------------------------------
+    def dist_init(self, rank, world, unique_id):
+        uid = np.ascontiguousarray(unique_id, np.uint8)
+        assert uid.size == 128
+        _check(lib().qadc_dist_init(self._h, rank, world, _p(uid, u8p)))
+        self._dist_world = world
+
+    def dist_collect(self, slot, extra=None):
+        """Replaces collect(): one ncclAllGather of the ranks' push streams + device-side replay in global scan order.
+        Returns dict(keys, values, sizes, status[, extra = float32 [world][n]])."""
+        nq, R, tables, assign = self._pending.pop(slot)
+        keys = np.zeros((nq, R), np.uint32)
+        vals = np.zeros((nq, R), np.int8)
+        sizes = np.zeros(nq, np.int32)
+        status = np.zeros(nq, np.int32)
+        ex = None if extra is None else np.ascontiguousarray(extra, np.float32).reshape(-1)
+        world = getattr(self, "_dist_world", 1)
+        ex_out = None if ex is None else np.zeros((world, ex.size), np.float32)
+        _check(lib().qadc_dist_collect(self._h, slot, _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p), _p(status, i32p),
+                                       _p(ex, f32p), 0 if ex is None else ex.size, _p(ex_out, f32p)))
+        out = dict(keys=keys, values=vals, sizes=sizes, status=status)
+        if ex is not None:
+            out["extra"] = ex_out
+        return out
 
     def set_pq(self, codebooks):
         cb = np.ascontiguousarray(codebooks, np.float32)

@@ -1010,3 +1010,82 @@ def test_blas_expansion_tables_go_negative_and_are_clamped_like_the_reference(py
             assert heaps_equal(r2["heaps"][0], (want["keys"], want["values"]))
     assert negatives >= nq // 4, negatives
     idx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# native multi-GPU merge (qadc_dist_*): one ncclAllGather + device-side replay in global scan order
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,world", [(16, 3), (32, 4), (16, 8)])
+def test_dist_merge_kernel_on_virtual_ranks(pyqadc, po, M, world):
+    """The device half of qadc_dist_collect (dist_merge_lanes_kernel) on the blocks `world` virtual ranks of ONE GPU
+    would contribute to the all-gather: every partition (labelled, ragged, some so small that a rank holds none of it)
+    range-sharded, tie-heavy tables, ma = 3: the merged heaps equal the unsharded oracle's, array for array."""
+    from pyqadc import sharded
+    rng = np.random.default_rng(70 + M + world)
+    sizes = [20011, 37, 6000, 16, 9003, 0, 12345]
+    keep, R, nq, ma = 0.05, 100, 70, 3
+    parts = [rand_codes(rng, s, M) for s in sizes]
+    perm = rng.permutation(sum(sizes)).astype(np.uint32)
+    labels = list(np.split(perm, np.cumsum(sizes)[:-1]))
+    assign = np.stack([rng.choice([0, 1, 2, 3, 4, 6], ma, replace=False) for _ in range(nq)]).astype(np.int32)
+    tables = float_tables(rng, nq, ma, M, scale=0.3)
+    streams = []
+    for r in range(world):
+        idx = pyqadc.Index(M)
+        for p, s_ in enumerate(sizes):
+            if s_ == 0:
+                idx.add_partitions([np.zeros((0, M // 2), np.uint8)], [np.zeros(0, np.uint32)])
+                continue
+            first, ln = sharded.shard_ranges(s_, world)[r]
+            st = po.start_size(s_, keep)
+            idx.add_partition_shard(parts[p][first:first + ln], first, s_, labels=labels[p][first:first + ln] if ln else None,
+                                    starts=parts[p][:st])
+        idx.finalize(keep)
+        streams.append(idx.query_scan_shard_streams(assign, tables.copy(), R))
+        idx.close()
+    got = pyqadc.dist_merge_blocks(streams, nq, ma, R)
+    for q in range(nq):
+        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
+        assert want["rc"] == 0
+        assert heaps_equal(got[q], (want["keys"], want["values"])), q
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["flat_levels", "flat_small", "ivf"])
+def test_dist_collect_world_1_over_rccl(pyqadc, po, shape):
+    """qadc_dist_init / qadc_dist_collect end to end with a world of ONE rank over real RCCL (all a 1-GPU box allows):
+    pack kernel -> ncclAllGather -> merge kernel -> heaps; the extra payload comes back; a deliberately tiny gather block
+    is regrown; results equal the plain collect of the same batches."""
+    rng = np.random.default_rng(len(shape))
+    M, R, keep = 16, 100, 0.01
+    if shape == "flat_levels":
+        parts, labels, nq, ma = [rand_codes(rng, 600000, M)], None, 5, 1
+    elif shape == "flat_small":
+        parts, labels, nq, ma = [rand_codes(rng, 50001, M)], None, 3, 1
+    else:
+        sizes = [int(x) for x in rng.integers(100, 7000, 30)]
+        parts = [rand_codes(rng, n, M) for n in sizes]
+        labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
+        nq, ma = 80, 4
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(keep)
+    assign = np.stack([rng.permutation(len(parts))[:ma] for _ in range(nq)]).astype(np.int32)
+    tables = float_tables(rng, nq, ma, M)
+    idx.submit(0, assign, tables.copy(), R)
+    plain = idx.collect(0)
+    idx.dist_init(0, 1, pyqadc.dist_unique_id())
+    extra = rng.random(37).astype(np.float32)
+    idx.set_option("dist_cap_entries", 64)            # far too small: every rank sees the overflow in the gathered headers
+    idx.set_option("profile", 1)                      # and regrows its block alike; the gather is repeated
+    for attempt in range(2):
+        idx.submit(attempt, assign, tables.copy(), R)
+        got = idx.dist_collect(attempt, extra=extra)
+        assert np.array_equal(got["extra"], extra[None, :])
+        assert np.array_equal(got["sizes"], plain["sizes"]) and np.array_equal(got["status"], plain["status"])
+        for q in range(nq):
+            sz = plain["sizes"][q]
+            assert np.array_equal(got["keys"][q, :sz], plain["keys"][q, :sz]) and np.array_equal(got["values"][q, :sz], plain["values"][q, :sz]), q
+    assert idx.profile()["regrows"] >= 1
+    idx.close()

@@ -183,3 +183,45 @@ def test_batched_engine_equals_per_query_engine(po, tmp_path, mode, M, N, ma, K)
         for dump_q in (q1[q], q5[q]):                                                           # each equals the oracle on ITS tables
             want = po.query_scan(M, parts, labels, keep, dump_q[0], np.ascontiguousarray(dump_q[1].reshape(ma, M * 16)), R)
             assert np.array_equal(dump_q[2], want["keys"]) and np.array_equal(dump_q[3], want["values"]), q
+
+
+DIST_DEMO = os.path.join(ROOT, "tests", "cpp", "dist_demo")
+
+
+def build_dist_demo():
+    libdir = os.path.join(ROOT, "quick-adc_amd")
+    if not os.path.exists(os.path.join(libdir, "libqadc_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "dist_demo.cpp"),
+                           "-o", DIST_DEMO, "-L" + libdir, "-lqadc_hip", "-Wl,-rpath," + libdir])
+
+
+def test_dist_demo_builds_as_cxx14():
+    build_dist_demo()
+    assert os.path.exists(DIST_DEMO)
+
+
+@pytest.mark.gpu
+def test_dist_demo_world_1_equals_plain_scan(po, tmp_path):
+    """The C++14 multi-process driver of the native merge, with the one rank a 1-GPU box allows: its heap checksum is
+    the checksum of the oracle's heaps for the same list and tables (on an 8-GPU node every rank prints this value)."""
+    build_dist_demo()
+    n, nq, R, M = 300000, 6, 100, 16
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.check_output([DIST_DEMO, str(tmp_path / "id.bin"), str(n), str(nq), str(R)], env=env).decode()
+    assert "extra payload ok" in out
+    got = int(out.split("heap checksum ")[1].split(",")[0], 16)
+    codes = po.fill_codes(0, (n * 8 + 7) // 8, 0x5EED0001)[:n * 8].reshape(n, 8)
+    i = np.arange(nq * M * 16, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        tables = ((splitmix64(np.uint64(977) + i) >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0) * np.float32(4.0))
+    tables = tables.reshape(nq, M * 16)
+    acc = np.uint64(0)
+    for q in range(nq):
+        want = po.query_scan(M, [codes], None, 0.01, [0], np.ascontiguousarray(tables[q:q + 1].copy()), R)
+        assert want["rc"] == 0
+        for k, v in zip(want["keys"], want["values"]):
+            with np.errstate(over="ignore"):
+                acc = splitmix64(np.uint64(acc) ^ ((np.uint64(k) << np.uint64(8)) | np.uint64(np.uint8(v))))
+    assert got == int(acc)

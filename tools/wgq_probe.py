@@ -35,10 +35,10 @@ for rep in range(2):
         steps = 16
         dt, nc = run(steps); p = idx.profile()
         nqq = max(p["wgq_queries"], 1)
-        print("ivf %s: %.3f us/query  %.2f TB/s | kernel %.3f ms/batch (%d launches) plan %.3f heap %.3f ms/batch | per query workgroup: front %.0f kcyc scan %.0f kcyc" % (
+        print("ivf %s: %.3f us/query  %.2f TB/s | kernel %.3f ms/batch (%d launches) plan %.3f heap %.3f ms/batch | per query workgroup: front %.0f kcyc scan %.0f kcyc sort %.0f kcyc" % (
             "levels   " if v < 0 else "variant %d" % v, dt * 1e6 / (steps * NQB), nc * (M // 2) / dt / 1e12,
             p["wgq_ms"] / max(p["wgq_launches"], 1), p["wgq_launches"], p["host_plan_ms"] / steps, p["host_heap_ms"] / steps,
-            p["wgq_front_cycles"] / nqq / 1e3, p["wgq_scan_cycles"] / nqq / 1e3), flush=True)
+            p["wgq_front_cycles"] / nqq / 1e3, p["wgq_scan_cycles"] / nqq / 1e3, p["wgq_sort_cycles"] / nqq / 1e3), flush=True)
 idx.close()
 # ---- latency point ----
 idx = pyqadc.Index(16); idx.add_partition_synthetic(100000, 1); idx.finalize(0.01); idx.set_option("profile", 1)
@@ -56,6 +56,7 @@ for v in variants + [-1]:
     for _ in range(200):
         t = tb.copy(); t0 = time.perf_counter(); idx.query_scan(a, t, R); ts.append(time.perf_counter() - t0)
     p = idx.profile()
-    print("latency %s: median %.1f us p10 %.1f | kernel %.1f us  cands %.0f | front %.1f kcyc scan %.1f kcyc" % ("levels   " if v < 0 else "variant %d" % v,
+    print("latency %s: median %.1f us p10 %.1f | kernel %.1f us  cands %.0f | front %.1f kcyc scan %.1f kcyc sort %.1f" % ("levels   " if v < 0 else "variant %d" % v,
           np.median(ts) * 1e6, np.sort(ts)[20] * 1e6, p["wgq_ms"] * 1e3 / max(p["wgq_launches"], 1), p["candidates"] / 200,
-          p["wgq_front_cycles"] / max(p["wgq_queries"], 1) / 1e3, p["wgq_scan_cycles"] / max(p["wgq_queries"], 1) / 1e3), flush=True)
+          p["wgq_front_cycles"] / max(p["wgq_queries"], 1) / 1e3, p["wgq_scan_cycles"] / max(p["wgq_queries"], 1) / 1e3,
+          p["wgq_sort_cycles"] / max(p["wgq_queries"], 1) / 1e3), flush=True)
