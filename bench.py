@@ -477,6 +477,12 @@ def main():
     # QADC_BENCH_FORCE_DIST=1 takes the multi-rank code path (collectives included) even with one rank
     use_dist = world > 1 or bool(os.environ.get("QADC_BENCH_FORCE_DIST"))
     if use_dist:
+        if world == 1:                                         # QADC_BENCH_FORCE_DIST without a launcher: rendezvous with ourselves
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -493,6 +499,24 @@ def main():
     idx.set_option("profile", 1)
     for kv in filter(None, os.environ.get("QADC_BENCH_OPTS", "").split(",")):     # tuning experiments only
         idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+
+    # ---- native RCCL merge inside the library (default for real multi-rank runs): rank 0's unique id travels over the
+    # process group that is up already; any failure on any rank sends ALL ranks to the torch.distributed path ----
+    native_dist = False
+    if use_dist and backend == "nccl" and os.environ.get("QADC_BENCH_NATIVE_DIST", "1") != "0":
+        ok = 1
+        try:
+            uid = torch.from_numpy(pyqadc.dist_unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
+            dist.broadcast(uid, 0)
+            idx.dist_init(rank, world, uid.cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("rank %d: native RCCL merge unavailable (%r), using the torch.distributed path\n" % (rank, e))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native_dist = bool(flag.item())
+        if ok and not native_dist:
+            idx.dist_shutdown()
 
     rng = np.random.default_rng(1234)
     codebooks = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
@@ -532,6 +556,20 @@ def main():
             tbs[b % 6] = pool[b % len(pool)].copy()
             idx.prescan_submit(b % 2, assign, tbs[b % 6], R, rank, world)
 
+        def merge(slot_i, pv):
+            """Finished batch -> (keys, vals, sizes[, gathered pre-scan values]).  Native: qadc_dist_collect — ONE
+            ncclAllGather straight from the device-resident streams + device-side replay, no host staging, no second
+            collective.  Fallback (QADC_BENCH_NATIVE_DIST=0, gloo test hook): pyqadc/sharded.py over torch.distributed."""
+            if native_dist:
+                out = idx.dist_collect(slot_i, extra=None if pv is None else pv.reshape(-1))
+                res3 = (out["keys"], out["values"], out["sizes"])
+                if pv is None:
+                    return res3
+                g = out["extra"].reshape(world, NQ, -1)
+                return res3 + (np.ascontiguousarray(g.transpose(1, 0, 2)).reshape(NQ, -1),)
+            res = idx.collect_candidates(slot_i)
+            return sharded.merge_batch(res, NQ, R, res["status"], cdev, extra=pv)
+
         nb = min(LEAD, k)                                      # the first batches: one stand-alone gather for all
         pvs = []
         for b in range(nb):
@@ -545,9 +583,8 @@ def main():
         for i in range(k):                                     # batches i .. i+LEAD-1 are in flight; i is collected now
             if i + LEAD + 1 < k:
                 prescan(i + LEAD + 1)                          # pre-slot of batch i+LEAD-1, collected an iteration ago
-            res = idx.collect_candidates(i % 4)
             pv = idx.prescan_collect((i + LEAD) % 2) if i + LEAD < k else None   # batch i+LEAD's, enqueued an iteration ago
-            out = sharded.merge_batch(res, NQ, R, res["status"], cdev, extra=pv)
+            out = merge(i % 4, pv)
             last = out[:3]
             if i + LEAD < k:
                 idx.submit((i + LEAD) % 4, assign, tbs[(i + LEAD) % 6], R, prescan=out[3])
@@ -633,6 +670,8 @@ def main():
         out = {
             "metric": "pq_codes_scanned_per_sec", "value": total_codes / elapsed, "unit": "codes/s",
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 1,
+            "multi_gpu_merge": ("native: qadc_dist_collect (one ncclAllGather of device-resident push streams + device replay)"
+                                if native_dist else "pyqadc/sharded.py over torch.distributed (%s)" % backend) if use_dist else None,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",

@@ -215,6 +215,8 @@ struct DistState {
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     void* comm = nullptr;
+    hipStream_t stream = nullptr;                            // own high-priority stream: the merge of batch s must not queue
+                                                             // behind the scan kernels of batches s+1.. on the main stream
     int rank = 0, world = 1;
     uint32_t cap_entries = 1u << 16;                         // entries per rank block; regrown (by every rank alike) on overflow
     DevBuf<uint64_t> d_block, d_gathered;
@@ -227,6 +229,14 @@ struct DistState {
     unsigned char* h_out_mapped = nullptr;
     PinBuf<uint32_t> h_hdr;                                  // gathered headers [world][nq][4]
     PinBuf<float> h_extra_all;                               // gathered extra payload [world][extra_n]
+    // few-query batches: the gathered streams come back to the host, rank r replays queries q = r (mod world) there,
+    // and a second, tiny all-gather shares the heaps (a lane-per-query device replay of ~10^4 sequential pushes per
+    // query would take milliseconds when only a few dozen lanes have work)
+    PinBuf<uint64_t> h_gathered;
+    PinBuf<uint64_t> h_myheaps;                              // [per][R + 1]: heap entries, then the size
+    DevBuf<uint64_t> d_myheaps, d_allheaps;
+    PinBuf<uint64_t> h_allheaps;
+    int device_nq = 256;                                     // batches of at least this many queries replay on the device
 };
 
 int load_rccl(DistState& d, std::string& err) {
@@ -1630,6 +1640,10 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
         idx->dist->cap_entries = (uint32_t)std::max(16.0, std::min(value, 1073741824.0));
     }
+    else if (n == "dist_device_nq") {                         // batches of at least this many queries replay on the device
+        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
+        idx->dist->device_nq = (int)std::max(1.0, value);
+    }
     else if (n == "table_form") idx->table_form = std::max(0, std::min((int)value, 2));
     else if (n == "wgq_cand_cap") idx->wgq_cand_cap = (uint32_t)std::max(1.0, std::min(value, (double)kQueryCandCap));
     else if (n == "wgq_min_nq") idx->wgq_min_nq = (int)std::max(value, 1.0);
@@ -2060,6 +2074,9 @@ int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
     if (rc != 0) return fail(QADC_E_HIP, std::string("ncclCommInitRank: ") + (d->GetErrorString ? d->GetErrorString(rc) : "error"));
     d->rank = rank;
     d->world = world;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
     idx->dist = d.release();
     return QADC_OK;
 }
@@ -2096,9 +2113,12 @@ int qadc_dist_shutdown(qadc_index* idx) {
     (void)hipSetDevice(idx->device);
     (void)hipStreamSynchronize(idx->stream);
     DistState* d = idx->dist;
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
     if (d->comm) (void)d->CommDestroy(d->comm);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
     d->d_block.release(); d->d_gathered.release(); d->d_src.release(); d->h_src.release(); d->d_extra.release();
     d->h_extra.release(); d->h_out.release(); d->h_hdr.release(); d->h_extra_all.release();
+    d->h_gathered.release(); d->h_myheaps.release(); d->d_myheaps.release(); d->d_allheaps.release(); d->h_allheaps.release();
     delete d;
     idx->dist = nullptr;
     return QADC_OK;
@@ -2147,7 +2167,7 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
     }
     HIPCHECK(d.h_hdr.ensure((size_t)world * nq * 4));
     if (extra_n) HIPCHECK(d.h_extra_all.ensure((size_t)world * extra_n));
-    hipStream_t st = idx->stream;
+    hipStream_t st = d.stream;                               // the batch itself is complete (collect_common waited for it)
     uint64_t* h_heaps = reinterpret_cast<uint64_t*>(d.h_out.p);
     uint32_t* h_sizes = reinterpret_cast<uint32_t*>(d.h_out.p + sizeof(uint64_t) * (size_t)R * nq);
     for (int attempt = 0;; ++attempt) {
@@ -2160,8 +2180,14 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
                                   extra_n ? d.d_extra.p : nullptr, (uint32_t)extra_n, d.d_block.p, st));
         const int rc = d.AllGather(d.d_block.p, d.d_gathered.p, bw, /*ncclUint64*/ 5, d.comm, st);
         if (rc != 0) return fail(QADC_E_HIP, std::string("ncclAllGather: ") + (d.GetErrorString ? d.GetErrorString(rc) : "error"));
-        HIPCHECK(launch_dist_merge_lanes(d.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, reinterpret_cast<uint64_t*>(d.d_out),
-                                         reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq), st));
+        const bool on_device = nq >= d.device_nq;
+        if (on_device)
+            HIPCHECK(launch_dist_merge_lanes(d.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, reinterpret_cast<uint64_t*>(d.d_out),
+                                             reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq), st));
+        else {
+            HIPCHECK(d.h_gathered.ensure(bw * world));
+            HIPCHECK(hipMemcpyAsync(d.h_gathered.p, d.d_gathered.p, sizeof(uint64_t) * bw * world, hipMemcpyDeviceToHost, st));
+        }
         // every rank's header (to size a retry identically everywhere) and extra payload come back with the heaps
         HIPCHECK(hipMemcpy2DAsync(d.h_hdr.p, sizeof(uint32_t) * 4 * nq, d.d_gathered.p, sizeof(uint64_t) * bw,
                                   sizeof(uint32_t) * 4 * nq, world, hipMemcpyDeviceToHost, st));
@@ -2182,10 +2208,71 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
             need = std::max(need, tot);
         }
         if (unordered) return fail(QADC_E_CAPACITY, "a rank could not order a query on the device: not supported by the native merge");
-        if (!overflow) break;
-        if (attempt >= 2 || need >= (1ull << 31)) return fail(QADC_E_CAPACITY, "gather block overflow persists");
-        d.cap_entries = (uint32_t)((need + need / 8 + 4095) / 4096 * 4096);   // the same on every rank: they all saw the same headers
-        idx->prof.regrows++;
+        if (overflow) {
+            if (attempt >= 2 || need >= (1ull << 31)) return fail(QADC_E_CAPACITY, "gather block overflow persists");
+            d.cap_entries = (uint32_t)((need + need / 8 + 4095) / 4096 * 4096);   // the same on every rank: they all saw the same headers
+            idx->prof.regrows++;
+            continue;
+        }
+        if (on_device) break;
+        // ---- few queries: replay my share on the host (global scan order: assign slot, rank, position), share the heaps ----
+        const int per = (nq + world - 1) / world;
+        const size_t hw = (size_t)R + 1;                       // words per query in the heap exchange
+        HIPCHECK(d.h_myheaps.ensure((size_t)per * hw));
+        HIPCHECK(d.d_myheaps.ensure((size_t)per * hw));
+        HIPCHECK(d.d_allheaps.ensure((size_t)per * hw * world));
+        HIPCHECK(d.h_allheaps.ensure((size_t)per * hw * world));
+        std::memset(d.h_myheaps.p, 0, sizeof(uint64_t) * (size_t)per * hw);
+        {
+            ScopedMs timer(idx->prof.host_heap_ms);
+            auto work = [&](int j0, int j1) {
+                kv_heap<uint32_t, int8_t> bh(R);
+                std::vector<uint32_t> cur(world), end(world);
+                for (int j = j0; j < j1; ++j) {
+                    const int q = j * world + d.rank;
+                    if (q >= nq || status[q]) continue;
+                    bh.reset();
+                    bh.push(0, 127);                             // db_query_4.cpp:276
+                    for (int g = 0; g < world; ++g) {
+                        const uint32_t* h = reinterpret_cast<const uint32_t*>(d.h_gathered.p + (size_t)g * bw) + 4 * (size_t)q;
+                        cur[g] = h[0];
+                        end[g] = h[0] + h[1];
+                    }
+                    for (int slot = 0; slot < s.ma; ++slot)
+                        for (int g = 0; g < world; ++g) {
+                            const uint64_t* ent = d.h_gathered.p + (size_t)g * bw + 2 * (size_t)nq;
+                            while (cur[g] < end[g]) {            // a rank scans its partitions in assign order: slots ascend
+                                const uint64_t e = ent[cur[g]];
+                                if (s.ma > 1 && (int)((e >> 40) & 0x3fffu) != slot) break;
+                                bh.push((uint32_t)e, (int8_t)(e >> 32));
+                                ++cur[g];
+                            }
+                        }
+                    uint64_t* o = d.h_myheaps.p + (size_t)j * hw;
+                    for (int i = 0; i < bh.size(); ++i) o[i] = (uint64_t)bh.keys()[i] | ((uint64_t)(uint8_t)bh.values()[i] << 32);
+                    o[R] = (uint64_t)bh.size();
+                }
+            };
+            const int nt = std::max(1, std::min<int>(std::min(per, 4), (int)std::thread::hardware_concurrency()));
+            if (nt == 1) {
+                work(0, per);
+            } else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < nt; ++t) th.emplace_back(work, per * t / nt, per * (t + 1) / nt);
+                for (auto& x : th) x.join();
+            }
+        }
+        HIPCHECK(hipMemcpyAsync(d.d_myheaps.p, d.h_myheaps.p, sizeof(uint64_t) * (size_t)per * hw, hipMemcpyHostToDevice, st));
+        const int rc2 = d.AllGather(d.d_myheaps.p, d.d_allheaps.p, (size_t)per * hw, /*ncclUint64*/ 5, d.comm, st);
+        if (rc2 != 0) return fail(QADC_E_HIP, std::string("ncclAllGather: ") + (d.GetErrorString ? d.GetErrorString(rc2) : "error"));
+        HIPCHECK(hipMemcpyAsync(d.h_allheaps.p, d.d_allheaps.p, sizeof(uint64_t) * (size_t)per * hw * world, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        for (int q = 0; q < nq; ++q) {
+            const uint64_t* o = d.h_allheaps.p + ((size_t)(q % world) * per + q / world) * hw;
+            h_sizes[q] = (uint32_t)o[R];
+            std::memcpy(h_heaps + (size_t)q * R, o, sizeof(uint64_t) * (size_t)R);
+        }
+        break;
     }
     for (int q = 0; q < nq; ++q) {
         uint32_t sz = h_sizes[q];

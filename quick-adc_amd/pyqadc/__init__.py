@@ -381,6 +381,9 @@ class Index:
         _check(lib().qadc_dist_init(self._h, rank, world, _p(uid, u8p)))
         self._dist_world = world
 
+    def dist_shutdown(self):
+        _check(lib().qadc_dist_shutdown(self._h))
+
     def dist_collect(self, slot, extra=None):
         """Replaces collect(): one ncclAllGather of the ranks' push streams + device-side replay in global scan order.
         Returns dict(keys, values, sizes, status[, extra = float32 [world][n]])."""

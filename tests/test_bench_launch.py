@@ -87,3 +87,18 @@ def test_single_gpu_line_keeps_the_two_modes_apart():
     # in-run PMC traffic: present when rocprofv3 exists on the box, and then close to the algorithmic bytes
     if rf["traffic"] is not None:
         assert 0.5 < rf["traffic_over_algorithmic"] < 1.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("native", [1, 0])
+def test_multi_rank_loop_with_one_rank_over_rccl(native):
+    """bench.py's multi-rank loop (sliced pre-scan, one gather per step carrying streams + next pre-scan values) with
+    the one RCCL rank a 1-GPU box allows: through the library's native merge (qadc_dist_collect) and through the
+    torch.distributed path; recall 1.0 either way."""
+    env = _env(QADC_BENCH_FORCE_DIST=1, QADC_BENCH_NATIVE_DIST=native, **SMALL)
+    r = subprocess.run([sys.executable, BENCH, "--steps", "6", "--warmup", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["recall_at_100"] == 1.0 and line["rccl_ranks"] == 1
+    assert line["multi_gpu_merge"].startswith("native" if native else "pyqadc/sharded.py")

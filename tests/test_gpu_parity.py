@@ -1052,8 +1052,9 @@ def test_dist_merge_kernel_on_virtual_ranks(pyqadc, po, M, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("replay", ["host_share", "device_lanes"])
 @pytest.mark.parametrize("shape", ["flat_levels", "flat_small", "ivf"])
-def test_dist_collect_world_1_over_rccl(pyqadc, po, shape):
+def test_dist_collect_world_1_over_rccl(pyqadc, po, shape, replay):
     """qadc_dist_init / qadc_dist_collect end to end with a world of ONE rank over real RCCL (all a 1-GPU box allows):
     pack kernel -> ncclAllGather -> merge kernel -> heaps; the extra payload comes back; a deliberately tiny gather block
     is regrown; results equal the plain collect of the same batches."""
@@ -1077,6 +1078,9 @@ def test_dist_collect_world_1_over_rccl(pyqadc, po, shape):
     plain = idx.collect(0)
     idx.dist_init(0, 1, pyqadc.dist_unique_id())
     extra = rng.random(37).astype(np.float32)
+    # few-query batches replay their share of the gathered streams on the host and exchange heaps with a second,
+    # tiny all-gather; large ones replay everything on the device, one lane per query: both must give the same heaps
+    idx.set_option("dist_device_nq", 1 if replay == "device_lanes" else 1 << 20)
     idx.set_option("dist_cap_entries", 64)            # far too small: every rank sees the overflow in the gathered headers
     idx.set_option("profile", 1)                      # and regrows its block alike; the gather is repeated
     for attempt in range(2):
