@@ -162,7 +162,9 @@ struct Slot {
     // one-workgroup-per-query path (qadc_query_kernel.hip): no planner, no levels, no sort
     bool wgq = false;
     bool dist_batch = false;            // launched with the native multi-GPU merge active: streams kept in device memory
-    uint32_t wgq_cap = 0;               // stream entries per query (regrown on overflow)
+    uint32_t wgq_cap = 0;               // stream entries per query workgroup (regrown on overflow)
+    int wgq_G = 1;                      // workgroups per query (small batches: the scan order of a query is split)
+    uint64_t wgq_codes = 0;             // codes a query probes (exact maximum, or an estimate) — sizes wgq_G
     uint64_t wgq_fcap = 0;              // pre-scan values per query in the global scratch (0 = they fit LDS)
     DevBuf<uint32_t> d_qflags;          // [nq][4]: {flags, entries} for replay_heap_lanes_kernel
     DevBuf<float> d_fvals;
@@ -296,6 +298,7 @@ struct qadc_index {
     uint64_t wgq_max_codes = 1ull << 24; //   ... probing at most this many codes per query (estimate), or
     uint64_t wgq_small_codes = 1ull << 18;   // any batch probing at most this many codes per query
     uint32_t wgq_capacity = 4096;        // stream entries per query to start with
+    int wgq_split = 8;                   // at most this many workgroups per query (batches too small to fill the GPU)
     int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
     int table_form = 2;                  // float tables of qadc_search: 0 direct, 1 BLAS expansion, 2 the reference's nns_engine rule
     uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)
@@ -842,11 +845,21 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     s.dev_replay = idx->device_replay_nq > 0 && nq >= idx->device_replay_nq && (uint32_t)s.R <= replay_lanes_max_R();
     s.dist_batch = idx->dist != nullptr;
     if (s.dist_batch) s.dev_replay = true;                   // streams stay on the device for the gather (qadc_dist_collect)
-    const size_t stream_entries = (size_t)nq * cap;
+    // A batch too small to fill the GPU splits every query's scan order over G workgroups (each tightens its bound on
+    // the query's first block, then scans its own chunk); the sub-streams are concatenated in workgroup order.
+    int G = 1;
+    if (!s.dev_replay && nq * 2 <= 256) {
+        G = std::min<int>(idx->wgq_split, 256 / nq);
+        G = (int)std::min<uint64_t>((uint64_t)G, s.wgq_codes / 16384);   // at least 16 Ki codes per workgroup
+        G = std::max(G, 1);
+    }
+    s.wgq_G = G;
+    const int nsub = nq * G;
+    const size_t stream_entries = (size_t)nsub * cap;
     if (stream_entries >= (1ull << 32)) return fail(QADC_E_CAPACITY, "candidate stream capacity exceeds 2^32 entries");
     s.out_cap = (uint32_t)stream_entries;
     const size_t host_stream_bytes = s.dev_replay ? 0 : sizeof(uint64_t) * stream_entries;
-    const size_t off_heaps = sizeof(QueryOut) * (size_t)nq + host_stream_bytes;
+    const size_t off_heaps = sizeof(QueryOut) * (size_t)nsub + host_stream_bytes;
     const size_t heaps_bytes = s.dev_replay ? (sizeof(uint64_t) * (size_t)s.R + sizeof(uint32_t)) * (size_t)nq : 0;
     HIPCHECK(s.h_result.ensure(off_heaps + heaps_bytes + 16, hipHostMallocMapped | hipHostMallocCoherent));
     if (s.h_result.p != s.h_result_mapped) {
@@ -856,8 +869,8 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     unsigned char* d_result = s.d_result_mapped;
     s.d_qout = reinterpret_cast<QueryOut*>(d_result);
     s.h_qout = reinterpret_cast<QueryOut*>(s.h_result.p);
-    s.d_entries = reinterpret_cast<uint64_t*>(d_result + sizeof(QueryOut) * (size_t)nq);
-    s.h_entries = reinterpret_cast<uint64_t*>(s.h_result.p + sizeof(QueryOut) * (size_t)nq);
+    s.d_entries = reinterpret_cast<uint64_t*>(d_result + sizeof(QueryOut) * (size_t)nsub);
+    s.h_entries = reinterpret_cast<uint64_t*>(s.h_result.p + sizeof(QueryOut) * (size_t)nsub);
     s.h_heaps = reinterpret_cast<uint64_t*>(s.h_result.p + off_heaps);
     s.h_heap_sizes = reinterpret_cast<uint32_t*>(s.h_result.p + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
     if (s.dev_replay) {
@@ -882,9 +895,9 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             for (int a = 0; a < ma; ++a) s.start_codes += idx->parts[s.assign[(size_t)q * ma + a]].start_n;
     }
     s.wgq_fcap = fcap;
-    if (fcap) HIPCHECK(s.d_fvals.ensure((size_t)nq * fcap));
+    if (fcap) HIPCHECK(s.d_fvals.ensure((size_t)nsub * fcap));
     const uint32_t ccap = std::min<uint32_t>(idx->wgq_cand_cap, kQueryCandCap);
-    HIPCHECK(s.d_qcands.ensure((size_t)nq * ccap));
+    HIPCHECK(s.d_qcands.ensure((size_t)nsub * ccap));
 
     bool alone = true;
     for (int i = 0; i < kSlots; ++i) alone = alone && (&idx->slot[i] == &s || !idx->slot[i].busy);
@@ -932,6 +945,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     A.R = (uint32_t)s.R;
     A.quant_mode = idx->quant_mode;
     A.nontemporal = idx->total_codes * (uint64_t)idx->cs > (200ull << 20);   // (same rule as the level path)
+    A.G = G;
     if (idx->profile) HIPCHECK(prof_event(s, st));
     HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st));
     if (idx->profile) HIPCHECK(prof_event(s, st));
@@ -1001,6 +1015,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
             max_codes = std::max(max_codes, c);
         }
         s.wgq = wgq_eligible(idx, nq, ma, R, mode, max_codes);
+        s.wgq_codes = max_codes;
     }
     if (s.wgq) s.wgq_cap = std::max<uint32_t>(s.wgq_cap, idx->wgq_capacity);
     s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
@@ -1059,6 +1074,7 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
     // one workgroup per query: the kernel reads assign[] on the device, the host only wants it back for the caller
     const uint64_t est_codes = idx->parts.empty() ? 0 : idx->total_codes / idx->parts.size() * (uint64_t)(idx->K ? ma : 1);
     s.wgq = wgq_eligible(idx, nq, ma, R, 0, est_codes);
+    s.wgq_codes = est_codes;
     s.assign_on_device = s.wgq;
     if (!s.wgq) {
         HIPCHECK(hipStreamSynchronize(cs));                  // the planner needs assign[] on the host
@@ -1093,7 +1109,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
         HIPCHECK(hipEventSynchronize(s.ev_done));
         uint64_t max_count = 0;
         bool cand_overflow = false;
-        for (int q = 0; q < s.nq; ++q) {
+        for (int q = 0; q < s.nq * s.wgq_G; ++q) {
             max_count = std::max<uint64_t>(max_count, s.h_qout[q].count);
             cand_overflow |= (s.h_qout[q].flags & 32u) != 0;
         }
@@ -1102,6 +1118,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
             // the level-structured path has the machinery for that (regrow, host sort) — run the batch through it
             idx->prof.regrows++;
             s.wgq = false;
+            s.wgq_G = 1;
             s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)s.nq * 8192u, 1ull << 30));
             if (int rc = plan_and_launch(idx, s)) {
                 s.busy = false;
@@ -1156,7 +1173,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
         if (s.prof_used >= 2) HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[0], s.prof_ev[1]));
         idx->prof.wgq_ms += ms;
         idx->prof.wgq_launches++;
-        for (int q = 0; q < s.nq; ++q) {
+        for (int q = 0; q < s.nq * s.wgq_G; ++q) {
             idx->prof.wgq_front_cycles += (uint64_t)(s.h_qout[q].pad[0] & 0xffffu) << 6;
             idx->prof.wgq_sort_cycles += (uint64_t)(s.h_qout[q].pad[0] >> 16) << 6;
             idx->prof.wgq_scan_cycles += (uint64_t)s.h_qout[q].pad[1] << 4;
@@ -1209,7 +1226,15 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
             s.h_entries = s.h_fetch.p;
         }
     }
-    for (int q = 0; q < s.nq; ++q) {
+    for (int q = 0; q < s.nq && s.wgq && s.wgq_G > 1; ++q) {   // sub-streams of a query's workgroups, in workgroup order
+        s.out_off[q] = s.out_entries.size();
+        for (int g = 0; g < s.wgq_G; ++g) {
+            const QueryOut& qs = s.h_qout[(size_t)q * s.wgq_G + g];
+            idx->prof.candidates += qs.count;
+            s.out_entries.insert(s.out_entries.end(), s.h_entries + qs.out_off, s.h_entries + qs.out_off + qs.count);
+        }
+    }
+    for (int q = 0; q < s.nq && !(s.wgq && s.wgq_G > 1); ++q) {
         const QueryOut& qs = s.h_qout[q];
         s.out_off[q] = s.out_entries.size();
         idx->prof.candidates += qs.count;
@@ -1248,8 +1273,9 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
 
 void finish_float_outputs(qadc_index* idx, Slot& s, int32_t* status, float* qmin, float* qmax) {
     const size_t per_q = (size_t)s.ma * idx->M * 16;
+    const int stride = s.wgq ? s.wgq_G : 1;                      // (a query's workgroups report the same qmin / qmax / flags)
     for (int q = 0; q < s.nq; ++q) {
-        const QueryOut& qs = s.h_qout[q];
+        const QueryOut& qs = s.h_qout[(size_t)q * stride];
         if (status) status[q] = (qs.flags & 1u) ? 1 : 0;
         if (qmin) qmin[q] = qs.qmin;
         if (qmax) qmax[q] = qs.qmax;
@@ -1649,6 +1675,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "wgq_min_nq") idx->wgq_min_nq = (int)std::max(value, 1.0);
     else if (n == "wgq_max_codes") idx->wgq_max_codes = (uint64_t)std::max(value, 0.0);
     else if (n == "wgq_small_codes") idx->wgq_small_codes = (uint64_t)std::max(value, 0.0);
+    else if (n == "wgq_split") idx->wgq_split = (int)std::max(1.0, std::min(value, 64.0));
     else if (n == "wgq_capacity") idx->wgq_capacity = (uint32_t)std::max(16.0, std::min(value, 1048576.0));
     else if (n == "profile") idx->profile = value != 0;
     else return fail(QADC_E_ARG, "unknown option: " + n);
@@ -1819,7 +1846,7 @@ int qadc_scan_start(qadc_index* idx, int nq, int ma, const int32_t* assign, cons
     std::vector<float> qm(nq);
     if (int rc = submit_common(idx, 0, nq, ma, assign, copy.data(), nullptr, R)) return rc;
     if (int rc = collect_common(idx, 0)) return rc;
-    for (int q = 0; q < nq; ++q) qmax[q] = idx->slot[0].h_qout[q].qmax;
+    for (int q = 0; q < nq; ++q) qmax[q] = idx->slot[0].h_qout[(size_t)q * (idx->slot[0].wgq ? idx->slot[0].wgq_G : 1)].qmax;
     return QADC_OK;
 }
 

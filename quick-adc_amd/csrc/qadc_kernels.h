@@ -121,6 +121,8 @@ struct QueryKernelArgs {
     uint32_t R;
     int quant_mode;
     int nontemporal;         // non-temporal code loads (database larger than the Infinity Cache)
+    int G;                   // workgroups per query (>= 1): the grid is nq * G, every output array is indexed by q * G + g;
+                             // workgroup g scans the first block (bound only, g > 0) and the g-th chunk of the rest
 };
 
 size_t query_kernel_lds_bytes(int M);

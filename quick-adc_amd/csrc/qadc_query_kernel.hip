@@ -151,7 +151,8 @@ __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint
 // OCC = waves per SIMD the register budget is sized for: 8 = two workgroups per CU (64 VGPRs), 4 = one (128 VGPRs).
 // NT = non-temporal code loads (lists that stream from HBM anyway); a database that fits the 256 MiB Infinity Cache
 // keeps the default policy and is re-read from the cache by every query.
-template <int M, int U, int OCC, bool NT>
+// MULTI = several workgroups per query (small batches; A.G); the single-workgroup instantiation stays lean.
+template <int M, int U, int OCC, bool NT, bool MULTI>
 __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A) {
     using C = QCfg<M>;
     if (reinterpret_cast<uintptr_t>((q_lds_bytes_t)qsmem) != 0) __builtin_trap();   // the lookups use absolute LDS addresses
@@ -170,14 +171,16 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     uint32_t& s_count = misc[325];
     float* redf = reinterpret_cast<float*>(misc + 336);   // [16] per-wave minima
 
-    const int q = blockIdx.x;
+    const int G = MULTI ? A.G : 1;                               // workgroups per query (small batches: > 1)
+    const int q = (int)blockIdx.x / G, g = (int)blockIdx.x % G;
+    const int wgi = (int)blockIdx.x;                             // index of this workgroup's output regions
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const int ma = A.ma;
     const int32_t* __restrict__ assign = A.assign + (size_t)q * ma;
     const PartDesc* __restrict__ parts = A.parts;
     const size_t tbase = (size_t)q * ma * (M * 16);
     int8_t* __restrict__ qt_all = A.qtables + tbase;
-    uint64_t* __restrict__ stream = A.stream + (size_t)q * A.cap;
+    uint64_t* __restrict__ stream = A.stream + (size_t)wgi * A.cap;
     const uint32_t R = A.R;
 
     const uint64_t clk0 = __builtin_readcyclecounter();          // phase clocks (QueryOut::pad): 1/16 shader cycles
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
 #pragma unroll
         for (int w = 0; w < kQWaves; ++w) total_starts += wcnt[w];
         const bool in_lds = total_starts <= (uint32_t)C::FCAP;
-        float* __restrict__ gvals = A.fvals + (size_t)q * A.fcap;
+        float* __restrict__ gvals = A.fvals + (size_t)wgi * A.fcap;
         __syncthreads();
 
         const int wpp = ma >= kQWaves ? 1 : kQWaves / ma;        // waves per probe
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
         const int all = ma * M * 16;
         for (int i = tid; i < all; i += kQWG) {
             float v = ft_all[i];
-            if (v < 0) { v = 0; ft_all[i] = 0; }
+            if (v < 0) { v = 0; if (G == 1) ft_all[i] = 0; }    // (G > 1: another workgroup may still pre-scan the unclamped tables)
             int8_t o;
             if (flags & 1u) o = 127;
             else if (v >= qmax) o = 127;
@@ -342,9 +345,9 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     if (flags & 1u) {                                            // the reference prints a warning and exits: no scan
         if (tid == 0) {
             QueryOut o;
-            o.count = 0; o.reps = 0; o.flags = flags | 4u; o.out_off = (uint32_t)((size_t)q * A.cap);
+            o.count = 0; o.reps = 0; o.flags = flags | 4u; o.out_off = (uint32_t)((size_t)wgi * A.cap);
             o.qmin = qmin; o.qmax = qmax; o.pad[0] = o.pad[1] = 0;
-            A.qout[q] = o;
+            A.qout[wgi] = o;
         }
         return;
     }
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     uint32_t* hist_done = misc;                                  // [128] candidates of the finished epochs, by value
     uint32_t* hist_cur = misc + 128;                             // [128] candidates of the running epoch
     uint32_t& s_ccount = misc[326];                              // candidates appended so far
-    QCand* __restrict__ cands = A.cands + (size_t)q * A.ccap;
+    QCand* __restrict__ cands = A.cands + (size_t)wgi * A.ccap;
     auto next_part = [&](int a_) {
         ++a_;
         while (a_ < ma && q_uni(parts[assign[a_]].n) == 0) ++a_; // empty partition (db_query_4.cpp:291-293) / no local codes
@@ -399,124 +402,170 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     const uint32_t lane_lo = (tid & 31u) * 4u, lane_hi = lane_lo | 0x10000u;
     if (tid < 256) misc[tid] = 0;                                // both histograms
     if (tid == 0) s_ccount = 0;
-    uint32_t bound = 127, ramp = 64, last_cnt = 0;
-    int a = next_part(-1);
-    if (a < ma) {
-        if (tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] = table_word(a);
-        q_lds_barrier();
-        write_tables();
-        q_lds_barrier();
-    }
-    while (a < ma) {
-        const UDesc d = q_load_desc(parts, (int)q_uni((uint32_t)assign[a]));
-        const int a_next = next_part(a);
-        const uint32_t tqv = a_next < ma ? table_word(a_next) : 0u;   // in flight during the partition's epochs
-        const gvec_t src = (gvec_t)(uintptr_t)d.codes;
-        const uint32_t n = d.n;
-        const uint32_t nvec = (n + CPL - 1) / CPL;
-        const uint32_t dup_pos = (d.first_pos + d.n == d.global_n) ? d.n - 1u : 0xffffffffu;
-        const uint32_t dup_reps = (16u - d.global_n % 16u) % 16u;
-        const uint32_t key_base = d.key_base + d.first_pos;
-        auto emit = [&](uint32_t cv, uint32_t p) {               // rare: append one candidate, unordered
-            const uint32_t slot = atomicAdd(&s_ccount, 1u);
-            if (slot < A.ccap) {
-                QCand qc;
-                qc.key = d.labels ? d.labels[p] : key_base + p;
-                qc.val_reps = cv | ((p == dup_pos ? dup_reps : 0u) << 8);
-                qc.pos = p;
-                qc.slot = (uint32_t)a;
-                cands[slot] = qc;
+    // ---- how the query's scan order is shared by the G workgroups of the query (G = 1: everything is "mine") ----
+    // total vectors of the probed partitions, in scan order
+    uint32_t vmine = 0;
+    for (int a_ = tid; a_ < ma; a_ += kQWG) vmine += (parts[assign[a_]].n + CPL - 1) / CPL;
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) vmine += __shfl_xor(vmine, dlt, 64);
+    if (lane == 0) wcnt[wave] = vmine;
+    q_lds_barrier();
+    uint64_t V = 0;
+#pragma unroll
+    for (int w = 0; w < kQWaves; ++w) V += wcnt[w];
+    q_lds_barrier();
+    // Every workgroup walks the first block [0, B) to tighten its bound (only workgroup 0 emits from it), then its own
+    // chunk of the rest.  The bound a workgroup uses for a code is the R-th smallest value of candidates from the
+    // first block and from its own chunk before that code: a subset of the code's scan-order prefix, hence valid.
+    constexpr uint32_t kFirstBlock = 4096;
+    const uint64_t B = MULTI ? min(V, (uint64_t)kFirstBlock) : 0;
+    const uint64_t chunk = MULTI ? ((V - B + G - 1) / G + 63) / 64 * 64 : V;
+    const uint64_t my_lo = min(V, B + (uint64_t)g * chunk), my_hi = min(V, my_lo + chunk);
+
+    uint32_t bound = 127, ramp = MULTI ? 256 : 64, last_cnt = 0;   // (several workgroups per query: fewer, larger ramp epochs)
+    uint32_t& s_dirty = misc[327];                               // bumped by a histogram-only walk that found a candidate
+    int tables_of = -1;                                          // probe whose pair tables are in LDS
+    if (tid == 0) s_dirty = 0;
+    q_lds_barrier();
+    // pass 0: the first block [0, B) (bound only unless this is workgroup 0); pass 1: this workgroup's chunk.
+    // (one loop body for both: inlining the walk twice doubles the register pressure of the hot loop)
+    for (int pass = (MULTI && B) ? 0 : 1; pass < 2; ++pass) {
+        const uint64_t lo = pass == 0 ? 0 : my_lo, hi = pass == 0 ? B : my_hi;
+        const bool do_emit = pass == 1 || g == 0;
+        uint64_t pbase = 0;
+        int a = next_part(-1);
+        while (a < ma) {                                         // skip the partitions that end before lo
+            const uint32_t nv = (q_uni(parts[assign[a]].n) + CPL - 1) / CPL;
+            if (pbase + nv > lo) break;
+            pbase += nv;
+            a = next_part(a);
+        }
+        while (a < ma && pbase < hi) {
+            const UDesc d = q_load_desc(parts, (int)q_uni((uint32_t)assign[a]));
+            const uint32_t n = d.n;
+            const uint32_t nvec = (n + CPL - 1) / CPL;
+            const uint32_t t_begin = (uint32_t)(max(lo, pbase) - pbase), t_end = (uint32_t)(min(hi, pbase + nvec) - pbase);
+            if (tables_of != a) {                                // (the partition switch inside end_epoch covers the common case)
+                q_lds_barrier();
+                if (tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] = table_word(a);
+                q_lds_barrier();
+                write_tables();
+                q_lds_barrier();
+                tables_of = a;
             }
-            atomicAdd(&hist_cur[cv], 1u);
-        };
-        // FULL = every lane of every tile of the iteration holds CPL complete codes: no predicates, so all the lookups
-        // of the iteration sit in one basic block and overlap (a predicated copy handles ramp epochs and ragged ends)
-        auto load_tiles = [&](u32x4 (&v)[kRounds], uint32_t t0, uint32_t width, uint32_t tl, auto full) {
-#pragma unroll
-            for (int i = 0; i < kRounds; ++i) {
-                const uint32_t off = (tl + (uint32_t)i * kQWaves) * 64u + lane;
-                if (decltype(full)::value) {
-                    v[i] = NT ? __builtin_nontemporal_load(src + t0 + off) : src[t0 + off];
-                } else {
-                    v[i] = u32x4{0, 0, 0, 0};
-                    if (off < width) v[i] = NT ? __builtin_nontemporal_load(src + t0 + off) : src[t0 + off];
-                }
-            }
-        };
-        auto sums_of = [&](uint32_t (&cand)[kRounds * CPL], const u32x4 (&v)[kRounds], uint32_t t0, uint32_t width, uint32_t tl,
-                           auto full) {
-            uint32_t best = 127u;
-#pragma unroll
-            for (int i = 0; i < kRounds; ++i) {
-                const uint32_t dd[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-                const uint32_t off = (tl + (uint32_t)i * kQWaves) * 64u + lane;
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    const uint32_t sum = q_pair_sum<M>(dd + c * DW, lane_lo, lane_hi);
-                    uint32_t cv = min(sum, 127u);
-                    if (!decltype(full)::value) {
-                        const bool live = off < width && (t0 + off) * CPL + c < n;
-                        cv = live ? cv : 127u;
+            const int a_next = next_part(a);
+            const bool more = a_next < ma && pbase + nvec < hi;  // the walk continues in the next probed partition
+            const uint32_t tqv = more ? table_word(a_next) : 0u; // in flight during this partition's epochs
+            const gvec_t src = (gvec_t)(uintptr_t)d.codes;
+            const uint32_t dup_pos = (d.first_pos + d.n == d.global_n) ? d.n - 1u : 0xffffffffu;
+            const uint32_t dup_reps = (16u - d.global_n % 16u) % 16u;
+            const uint32_t key_base = d.key_base + d.first_pos;
+            auto emit = [&](uint32_t cv, uint32_t p) {           // rare: count (and append, unordered) one candidate
+                if (do_emit) {
+                    const uint32_t slot = atomicAdd(&s_ccount, 1u);
+                    if (slot < A.ccap) {
+                        QCand qc;
+                        qc.key = d.labels ? d.labels[p] : key_base + p;
+                        qc.val_reps = cv | ((p == dup_pos ? dup_reps : 0u) << 8);
+                        qc.pos = p;
+                        qc.slot = (uint32_t)a;
+                        cands[slot] = qc;
                     }
-                    cand[i * CPL + c] = cv;
-                    best = min(best, cv);
+                } else {
+                    atomicAdd(&s_dirty, 1u);                     // (histogram-only walk: still makes the epoch "dirty")
                 }
-            }
-            return best;
-        };
-        auto end_epoch = [&](bool switch_part) {
-            if (switch_part && tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] = tqv;
-            q_lds_barrier();                                     // every candidate of the epoch is counted; the tables are idle
-            const uint32_t cnt = s_ccount;
-            if (cnt != last_cnt && tid < 128) {
-                hist_done[tid] += hist_cur[tid];
-                hist_cur[tid] = 0;
-            }
-            if (switch_part) write_tables();
-            q_lds_barrier();
-            if (cnt != last_cnt) {
-                bound = q_uni(q_bound_from_hist(hist_done, R, lane));
-                last_cnt = cnt;
-            }
-        };
-        // (tried and dropped: a register-resident first block that walks the ramp epochs without a memory round trip
-        // each — no measurable gain on the 10^5-code latency point, and its registers cost the IVF shape 10 %)
-        uint32_t t0 = 0;
-        while (t0 < nvec) {
-            const uint32_t rest = nvec - t0;
-            uint32_t width;
-            if (ramp < kEpochVec) {
-                width = min(ramp, rest);
-                ramp *= 2u;
-            } else {
-                width = min(rest, kEpochVec);
-            }
-            const uint32_t tiles = (width + 63u) / 64u;          // 64-vector tiles of the epoch; wave w takes w, w+16, ...
-            // (tried and dropped: loads of the next tiles in flight across iterations, and a register-resident first
-            // block for the ramp — both cost registers the lookups need; the walk is bound by issue, not by memory)
-            // tiles [0, full_tiles) hold only complete vectors of complete codes
-            const uint32_t full_tiles = min(width, n / CPL - min(n / CPL, t0)) / 64u;
-            auto step = [&](uint32_t tl, auto full) {
-                u32x4 v[kRounds];
-                load_tiles(v, t0, width, tl, full);
-                uint32_t cand[kRounds * CPL];
-                const uint32_t best = sums_of(cand, v, t0, width, tl, full);
-                if (__builtin_expect(best < bound, 0)) {         // rare
+                atomicAdd(&hist_cur[cv], 1u);
+            };
+            // FULL = every lane of every tile of the iteration holds CPL complete codes: no predicates, so all the
+            // lookups of the iteration sit in one basic block and overlap (a predicated copy handles ragged ends)
+            auto load_tiles = [&](u32x4 (&v)[kRounds], uint32_t t0, uint32_t width, uint32_t tl, auto full) {
 #pragma unroll
-                    for (int i = 0; i < kRounds; ++i)
-#pragma unroll
-                        for (int c = 0; c < CPL; ++c)
-                            if (cand[i * CPL + c] < bound)
-                                emit(cand[i * CPL + c], (t0 + (tl + (uint32_t)i * kQWaves) * 64u + lane) * CPL + c);
+                for (int i = 0; i < kRounds; ++i) {
+                    const uint32_t off = (tl + (uint32_t)i * kQWaves) * 64u + lane;
+                    if (decltype(full)::value) {
+                        v[i] = NT ? __builtin_nontemporal_load(src + t0 + off) : src[t0 + off];
+                    } else {
+                        v[i] = u32x4{0, 0, 0, 0};
+                        if (off < width) v[i] = NT ? __builtin_nontemporal_load(src + t0 + off) : src[t0 + off];
+                    }
                 }
             };
-            uint32_t tl = wave;
-            for (; tl + (kRounds - 1) * kQWaves < full_tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, true>());
-            for (; tl < tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, false>());
-            t0 += width;
-            end_epoch(t0 >= nvec && a_next < ma);
+            auto sums_of = [&](uint32_t (&cand)[kRounds * CPL], const u32x4 (&v)[kRounds], uint32_t t0, uint32_t width,
+                               uint32_t tl, auto full) {
+                uint32_t best = 127u;
+#pragma unroll
+                for (int i = 0; i < kRounds; ++i) {
+                    const uint32_t dd[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                    const uint32_t off = (tl + (uint32_t)i * kQWaves) * 64u + lane;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        const uint32_t sum = q_pair_sum<M>(dd + c * DW, lane_lo, lane_hi);
+                        uint32_t cv = min(sum, 127u);
+                        if (!decltype(full)::value) {
+                            const bool live = off < width && (t0 + off) * CPL + c < n;
+                            cv = live ? cv : 127u;
+                        }
+                        cand[i * CPL + c] = cv;
+                        best = min(best, cv);
+                    }
+                }
+                return best;
+            };
+            auto end_epoch = [&](bool switch_part) {
+                if (switch_part && tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] = tqv;
+                q_lds_barrier();                                 // every candidate of the epoch is counted; the tables are idle
+                const uint32_t cnt = s_ccount + s_dirty;
+                if (cnt != last_cnt && tid < 128) {
+                    hist_done[tid] += hist_cur[tid];
+                    hist_cur[tid] = 0;
+                }
+                if (switch_part) write_tables();
+                q_lds_barrier();
+                if (cnt != last_cnt) {
+                    bound = q_uni(q_bound_from_hist(hist_done, R, lane));
+                    last_cnt = cnt;
+                }
+            };
+            uint32_t t0 = t_begin;
+            while (t0 < t_end) {
+                const uint32_t rest = t_end - t0;
+                uint32_t width;
+                if (ramp < kEpochVec) {
+                    width = min(ramp, rest);
+                    ramp *= 2u;
+                } else {
+                    width = min(rest, kEpochVec);
+                }
+                const uint32_t tiles = (width + 63u) / 64u;      // 64-vector tiles of the epoch; wave w takes w, w+16, ...
+                // (tried and dropped: loads of the next tiles in flight across iterations, and a register-resident first
+                // block for the ramp — both cost registers the lookups need; the walk is bound by issue, not by memory)
+                // tiles [0, full_tiles) hold only complete vectors of complete codes
+                const uint32_t full_tiles = min(width, n / CPL - min(n / CPL, t0)) / 64u;
+                auto step = [&](uint32_t tl, auto full) {
+                    u32x4 v[kRounds];
+                    load_tiles(v, t0, width, tl, full);
+                    uint32_t cand[kRounds * CPL];
+                    const uint32_t best = sums_of(cand, v, t0, width, tl, full);
+                    if (__builtin_expect(best < bound, 0)) {     // rare
+#pragma unroll
+                        for (int i = 0; i < kRounds; ++i)
+#pragma unroll
+                            for (int c = 0; c < CPL; ++c)
+                                if (cand[i * CPL + c] < bound)
+                                    emit(cand[i * CPL + c], (t0 + (tl + (uint32_t)i * kQWaves) * 64u + lane) * CPL + c);
+                    }
+                };
+                uint32_t tl = wave;
+                for (; tl + (kRounds - 1) * kQWaves < full_tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, true>());
+                for (; tl < tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, false>());
+                t0 += width;
+                const bool sw = t0 >= t_end && more;
+                end_epoch(sw);
+                if (sw) tables_of = a_next;
+            }
+            pbase += nvec;
+            a = a_next;
         }
-        a = a_next;
     }
     // ---- 4. order the candidates: (assign slot, position) ascending = scan order ----
     const uint64_t clk2 = __builtin_readcyclecounter();
@@ -528,7 +577,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     } else if (ncand) {
         uint64_t* skey = reinterpret_cast<uint64_t*>(qsmem);             // [n2] (slot << 44 | pos << 12 | index)
         uint64_t* spay = reinterpret_cast<uint64_t*>(qsmem + 32768);     // [ncand] key | val << 32 | reps << 40 | slot << 48
-        uint32_t n2 = kQWG;                                      // >= one element per thread: every wave owns n2/16 >= 64
+        uint32_t n2 = 64;
         while (n2 < ncand) n2 <<= 1;
         for (uint32_t i = tid; i < n2; i += kQWG) {
             uint64_t k = ~0ull;
@@ -543,7 +592,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
         // bitonic network, wave-major ownership: wave w owns elements [w*chunk, (w+1)*chunk).  An exchange at distance
         // j < chunk stays inside one wave's elements and needs no workgroup barrier (LDS traffic of a wave is in order);
         // only the few steps with j >= chunk synchronise the workgroup: 10 barriers instead of 55 for 1024 elements.
-        const uint32_t chunk = n2 / kQWaves;
+        const uint32_t chunk = max(64u, n2 / kQWaves);           // (fewer than 1024 elements: only the first n2/64 waves work)
         for (uint32_t k = 2; k <= n2; k <<= 1)
             for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
                 const bool local = jj < chunk;
@@ -551,7 +600,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
                 for (uint32_t r = 0; r < chunk; r += 64) {
                     const uint32_t i = wave * chunk + r + lane;
                     const uint32_t pi = i ^ jj;
-                    if (pi > i) {
+                    if (i < n2 && pi > i) {
                         const uint64_t x = skey[i], y = skey[pi];
                         if ((x > y) == ((i & k) == 0)) { skey[i] = y; skey[pi] = x; }
                     }
@@ -603,17 +652,17 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
         o.count = s_count;                                       // entries requested (replays included); > cap = overflow
         o.reps = 0;
         o.flags = flags | 4u;
-        o.out_off = (uint32_t)((size_t)q * A.cap);
+        o.out_off = (uint32_t)((size_t)wgi * A.cap);
         o.qmin = qmin;
         o.qmax = qmax;
         const uint64_t clk3 = __builtin_readcyclecounter();
         // phase clocks: pad[0] = (pre-scan + select + quantizer) >> 6 | (sort + ordered write) >> 6 << 16; pad[1] = scan >> 4
         o.pad[0] = (uint32_t)min((clk1 - clk0) >> 6, (uint64_t)0xffff) | ((uint32_t)min((clk3 - clk2) >> 6, (uint64_t)0xffff) << 16);
         o.pad[1] = (uint32_t)((clk2 - clk1) >> 4);
-        A.qout[q] = o;
+        A.qout[wgi] = o;
         if (A.qstate_flags) {                                    // what replay_heap_lanes_kernel reads
-            A.qstate_flags[4 * q + 0] = flags | 4u;
-            A.qstate_flags[4 * q + 1] = s_count;
+            A.qstate_flags[4 * wgi + 0] = flags | 4u;
+            A.qstate_flags[4 * wgi + 1] = s_count;
         }
     }
 }
@@ -800,7 +849,7 @@ __global__ __launch_bounds__(64) void dist_merge_lanes_kernel(const uint64_t* __
 size_t query_kernel_lds_bytes(int M) { return M == 16 ? QCfg<16>::LDS_BYTES : QCfg<32>::LDS_BYTES; }
 uint32_t query_kernel_lds_values(int M) { return M == 16 ? QCfg<16>::FCAP : QCfg<32>::FCAP; }
 
-template <int M, int U, int OCC, bool NT>
+template <int M, int U, int OCC, bool NT, bool MULTI>
 static hipError_t launch_scan_query_nt(int nq, const QueryKernelArgs& args, hipStream_t stream) {
     // dynamic LDS above the default limit is opted into per (kernel, device)
     int dev = 0;
@@ -809,19 +858,22 @@ static hipError_t launch_scan_query_nt(int nq, const QueryKernelArgs& args, hipS
     static uint64_t done = 0;
     const size_t lds = QCfg<M>::LDS_BYTES;
     if (dev < 64 && !(done & (1ull << dev))) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         done |= 1ull << dev;
     }
-    hipLaunchKernelGGL((scan_query_kernel<M, U, OCC, NT>), dim3(nq), dim3(kQWG), lds, stream, args);
+    hipLaunchKernelGGL((scan_query_kernel<M, U, OCC, NT, MULTI>), dim3(nq * (MULTI ? args.G : 1)), dim3(kQWG), lds, stream, args);
     return hipGetLastError();
 }
 
 template <int M, int U, int OCC>
 static hipError_t launch_scan_query_v(int nq, const QueryKernelArgs& args, hipStream_t stream) {
-    return args.nontemporal ? launch_scan_query_nt<M, U, OCC, true>(nq, args, stream)
-                            : launch_scan_query_nt<M, U, OCC, false>(nq, args, stream);
+    if (args.G > 1)
+        return args.nontemporal ? launch_scan_query_nt<M, U, OCC, true, true>(nq, args, stream)
+                                : launch_scan_query_nt<M, U, OCC, false, true>(nq, args, stream);
+    return args.nontemporal ? launch_scan_query_nt<M, U, OCC, true, false>(nq, args, stream)
+                            : launch_scan_query_nt<M, U, OCC, false, false>(nq, args, stream);
 }
 
 // variant = 64-vector tiles (16-byte loads per lane in flight) per wave and iteration: 0 -> 2 (default), 1 -> 3, 2 -> 4, 3 -> 6.

@@ -1093,3 +1093,43 @@ def test_dist_collect_world_1_over_rccl(pyqadc, po, shape, replay):
             assert np.array_equal(got["keys"][q, :sz], plain["keys"][q, :sz]) and np.array_equal(got["values"][q, :sz], plain["values"][q, :sz]), q
     assert idx.profile()["regrows"] >= 1
     idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,split", [(16, 8), (16, 3), (32, 5)])
+def test_wgq_small_batches_split_a_query_over_several_workgroups(pyqadc, po, M, split):
+    """A batch too small to fill the GPU gives every query several workgroups: each tightens its bound on the query's
+    first block (only workgroup 0 emits from it), scans its own chunk of the rest, and the sub-streams are concatenated
+    in workgroup order.  Labelled ragged partitions, ma = 4, chunks that cut partitions in the middle: heaps == oracle."""
+    rng = np.random.default_rng(40 + M + split)
+    sizes = [70001, 37, 52000, 16, 90003, 0, 33333]
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
+    keep, R, nq, ma = 0.01, 100, 3, 4
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(keep)
+    idx.set_option("wgq", 2)
+    idx.set_option("wgq_split", split)
+    idx.set_option("profile", 1)
+    assign = np.array([[0, 2, 4, 6], [4, 1, 0, 3], [6, 5, 2, 0]], np.int32)
+    tables = float_tables(rng, nq, ma, M)
+    got = idx.query_scan(assign, tables.copy(), R, want_qtables=True)
+    assert idx.profile()["wgq_launches"] == 1
+    for q in range(nq):
+        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
+        assert want["rc"] == 0 and np.array_equal(got["qtables"][q], want["qtables"])
+        assert heaps_equal(got["heaps"][q], (want["keys"], want["values"])), q
+    # and a flat list, one query (the latency shape): 1 partition cut into `split` chunks
+    flat = rand_codes(rng, 200003, M)
+    i2 = pyqadc.Index(M)
+    i2.add_partitions([flat])
+    i2.finalize(keep)
+    i2.set_option("wgq", 2)
+    i2.set_option("wgq_split", split)
+    t1 = float_tables(rng, 1, 1, M)
+    g1 = i2.query_scan(np.zeros((1, 1), np.int32), t1.copy(), R)
+    w1 = po.query_scan(M, [flat], None, keep, [0], t1[0].copy(), R)
+    assert heaps_equal(g1["heaps"][0], (w1["keys"], w1["values"]))
+    idx.close()
+    i2.close()
