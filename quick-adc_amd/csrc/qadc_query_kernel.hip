@@ -434,17 +434,18 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
         const bool do_emit = pass == 1 || g == 0;
         uint64_t pbase = 0;
         int a = next_part(-1);
-        while (a < ma) {                                         // skip the partitions that end before lo
+        while (MULTI && a < ma) {                                // skip the partitions that end before lo
             const uint32_t nv = (q_uni(parts[assign[a]].n) + CPL - 1) / CPL;
             if (pbase + nv > lo) break;
             pbase += nv;
             a = next_part(a);
         }
-        while (a < ma && pbase < hi) {
+        while (a < ma && (!MULTI || pbase < hi)) {
             const UDesc d = q_load_desc(parts, (int)q_uni((uint32_t)assign[a]));
             const uint32_t n = d.n;
             const uint32_t nvec = (n + CPL - 1) / CPL;
-            const uint32_t t_begin = (uint32_t)(max(lo, pbase) - pbase), t_end = (uint32_t)(min(hi, pbase + nvec) - pbase);
+            const uint32_t t_begin = MULTI ? (uint32_t)(max(lo, pbase) - pbase) : 0u;
+            const uint32_t t_end = MULTI ? (uint32_t)(min(hi, pbase + nvec) - pbase) : nvec;
             if (tables_of != a) {                                // (the partition switch inside end_epoch covers the common case)
                 q_lds_barrier();
                 if (tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] = table_word(a);
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
                 tables_of = a;
             }
             const int a_next = next_part(a);
-            const bool more = a_next < ma && pbase + nvec < hi;  // the walk continues in the next probed partition
+            const bool more = a_next < ma && (!MULTI || pbase + nvec < hi);   // the walk continues in the next probed partition
             const uint32_t tqv = more ? table_word(a_next) : 0u; // in flight during this partition's epochs
             const gvec_t src = (gvec_t)(uintptr_t)d.codes;
             const uint32_t dup_pos = (d.first_pos + d.n == d.global_n) ? d.n - 1u : 0xffffffffu;
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
                 end_epoch(sw);
                 if (sw) tables_of = a_next;
             }
-            pbase += nvec;
+            if (MULTI) pbase += nvec;
             a = a_next;
         }
     }
