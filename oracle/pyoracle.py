@@ -318,7 +318,10 @@ def host_topology():
         except (OSError, ValueError):
             pass
     if quota is not None and quota < len(cpus):
-        cpus = cpus[:max(1, int(quota))]
+        k = max(1, int(quota))
+        # spread the threads over the whole package (core complexes share an L3 slice and a memory link: the first k
+        # cores would sit on one or two of them and measure that link, not the CPU)
+        cpus = [cpus[(i * len(cpus)) // k] for i in range(k)]
     return model, cpus
 
 
