@@ -950,10 +950,13 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st));
     if (idx->profile) HIPCHECK(prof_event(s, st));
     if (s.dev_replay) {
-        if (!alone) {                                       // replay on the side stream, under the next batch's scan
+        if (!alone) {
+            // replay on a side stream, under the next batches' scans.  A 1024-query replay (16 waves, one lane per
+            // query, ~1.5 K dependent pushes each) lasts about as long as the batch's scan: consecutive batches use two
+            // side streams alternately, so that a replay never waits for the previous batch's replay.
             if (!s.ev_scanned) HIPCHECK(hipEventCreateWithFlags(&s.ev_scanned, hipEventDisableTiming));
             HIPCHECK(hipEventRecord(s.ev_scanned, st));
-            st = idx->sort_stream;
+            st = ((&s - idx->slot) & 1) ? idx->front_stream : idx->sort_stream;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
         }
         if (!s.dist_batch)

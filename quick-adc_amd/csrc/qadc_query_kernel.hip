@@ -682,6 +682,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
 struct LaneHeap {
     uint64_t* hv;
     uint32_t lane, R, size;
+    uint32_t depth;                                           // levels of a full heap: floor(log2(R)) + 1 (wave-uniform)
     __device__ __forceinline__ static int32_t val_of(uint64_t e) { return (int32_t)((e >> 32) & 0xffu); }
     __device__ __forceinline__ uint64_t& at(uint32_t i) { return hv[i * 64u + lane]; }
     __device__ __forceinline__ void push(uint64_t e) {
@@ -698,22 +699,29 @@ struct LaneHeap {
             at(i) = e;
             return;
         }
-        if (!(value < val_of(at(0)))) return;
+        // Full heap: replace the root if strictly smaller, then sink.  The 64 lanes of a wave sift 64 different heaps
+        // in lockstep, so the loop runs a wave-uniform number of levels with the per-lane state in a predicate (a
+        // data-dependent `break` per lane costs an exec-mask round trip per level and buys nothing: some lane almost
+        // always sinks to the bottom).
+        const bool accept = value < val_of(at(0));
+        if (__builtin_amdgcn_ballot_w64(accept) == 0) return;
+        bool sinking = accept;
         uint32_t i = 0;
-        for (;;) {
+        for (uint32_t lvl = 0; lvl < depth; ++lvl) {
             const uint32_t l = 2 * i + 1;
-            if (l >= size) break;
-            uint64_t ce = at(l);
+            const bool has_l = sinking && l < size, has_r = sinking && l + 1 < size;
+            const uint64_t le = has_l ? at(l) : 0, re = has_r ? at(l + 1) : 0;
+            uint64_t ce = le;
             uint32_t c = l;
-            if (l + 1 < size) {
-                const uint64_t re = at(l + 1);
-                if (val_of(re) > val_of(ce)) { ce = re; c = l + 1; }
+            if (has_r && val_of(re) > val_of(le)) { ce = re; c = l + 1; }
+            const bool down = has_l && val_of(ce) > value;       // stop at a child <= the value
+            if (down) {
+                at(i) = ce;
+                i = c;
             }
-            if (val_of(ce) <= value) break;
-            at(i) = ce;
-            i = c;
+            sinking = down;
         }
-        at(i) = e;
+        if (accept) at(i) = e;
     }
 };
 
@@ -740,7 +748,7 @@ __global__ __launch_bounds__(64) void replay_heap_lanes_kernel(const uint32_t* _
                                                                const uint64_t* __restrict__ stream, uint32_t cap, int nq,
                                                                uint32_t R, uint64_t* __restrict__ heaps,
                                                                uint32_t* __restrict__ heap_sizes) {
-    LaneHeap h{reinterpret_cast<uint64_t*>(qsmem), threadIdx.x, R, 0};
+    LaneHeap h{reinterpret_cast<uint64_t*>(qsmem), threadIdx.x, R, 0, 32u - (uint32_t)__builtin_clz(R)};
     const uint32_t lane = threadIdx.x;
     const int q = blockIdx.x * 64 + (int)lane;
     const bool have = q < nq;
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(256) void dist_pack_kernel(const uint32_t* __restri
 __global__ __launch_bounds__(64) void dist_merge_lanes_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world,
                                                               int nq, int ma, uint32_t R, uint64_t* __restrict__ heaps,
                                                               uint32_t* __restrict__ heap_sizes) {
-    LaneHeap h{reinterpret_cast<uint64_t*>(qsmem), threadIdx.x, R, 0};
+    LaneHeap h{reinterpret_cast<uint64_t*>(qsmem), threadIdx.x, R, 0, 32u - (uint32_t)__builtin_clz(R)};
     const uint32_t lane = threadIdx.x;
     const int q = blockIdx.x * 64 + (int)lane;
     const bool have = q < nq;
