@@ -1563,93 +1563,124 @@ void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_
 // Every thread accumulates ITS centroid's dimensions in ascending order (bit-exact with the host loop); a
 // thread walks one row sequentially, so each cache line it touches is reused 16 times from L1 and the K x dim
 // matrix (shared by every query's workgroup) stays in L2.
-template <int KPT>
+// QB = queries per workgroup: a thread walks ITS centroid rows once and accumulates the QB queries' distances side by
+// side (each in its own ascending-d order, so every sum is bit-exact with the host loop) — the K x dim matrix is read
+// nq/QB times instead of nq times, which is what this kernel is bound by.
+template <int KPT, int QB>
 __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restrict__ queries,
-                                                            const float* __restrict__ coarse, int K, int dim, int ma,
+                                                            const float* __restrict__ coarse, int nq, int K, int dim, int ma,
                                                             float* __restrict__ dist, int32_t* __restrict__ assign) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    float* q = reinterpret_cast<float*>(dyn);                 // [dim]
+    float* q = reinterpret_cast<float*>(dyn);                 // [QB][dim]
     __shared__ float rv[4];
     __shared__ int rk[4];
-    const int qi = blockIdx.x, tid = threadIdx.x;
-    for (int d = tid; d < dim; d += 256) q[d] = queries[(size_t)qi * dim + d];
+    const int q0 = blockIdx.x * QB, tid = threadIdx.x;
+    const int nqb = min(QB, nq - q0);
+    for (int i = tid; i < QB * dim; i += 256) {
+        const int b = i / dim, d = i - b * dim;
+        q[i] = b < nqb ? queries[(size_t)(q0 + b) * dim + d] : 0.0f;
+    }
     __syncthreads();
-    float* __restrict__ dq = dist + (size_t)qi * K;
     constexpr int NR = KPT > 0 ? KPT : 1;
-    float mine[NR];
+    float mine[NR][QB];
 #pragma unroll
-    for (int j = 0; j < NR; ++j) mine[j] = FLT_MAX;
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int b = 0; b < QB; ++b) mine[j][b] = FLT_MAX;
     const int nblk = (K + 255) / 256;
-    auto row_dist = [&](int k) {
+    auto row_dist = [&](int k, float (&s)[QB]) {
         const float* __restrict__ c = coarse + (size_t)k * dim;
-        float s = 0.0f;
+#pragma unroll
+        for (int b = 0; b < QB; ++b) s[b] = 0.0f;
         for (int d = 0; d < dim; ++d) {
-            const float t = q[d] - c[d];
-            s += t * t;
+            const float cv = c[d];
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                const float t = q[b * dim + d] - cv;
+                s[b] += t * t;
+            }
         }
-        return s;
     };
     if (KPT > 0) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int k = j * 256 + tid;
-            if (j < nblk && k < K) mine[j] = row_dist(k);
+            if (j < nblk && k < K) row_dist(k, mine[j]);
         }
     } else {
-        for (int k = tid; k < K; k += 256) dq[k] = row_dist(k);
+        for (int k = tid; k < K; k += 256) {
+            float s[QB];
+            row_dist(k, s);
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+                if (b < nqb) dist[(size_t)(q0 + b) * K + k] = s[b];
+        }
     }
     __syncthreads();
-    // ma rounds of "smallest (distance, index) strictly after the previous pick"
-    float last_v = -1.0f;
-    int last_k = -1;
-    for (int a = 0; a < ma; ++a) {
-        float bv = FLT_MAX;
-        int bk = 0x7fffffff;
-        if (KPT > 0) {
+    // per query: ma rounds of "smallest (distance, index) strictly after the previous pick"
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const int k = j * 256 + tid;
-                const float v = mine[j];
-                const bool after = v > last_v || (v == last_v && k > last_k);
-                if (k < K && after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
+    for (int b = 0; b < QB; ++b) {
+        if (b >= nqb) break;
+        const float* __restrict__ dq = dist + (size_t)(q0 + b) * K;
+        float last_v = -1.0f;
+        int last_k = -1;
+        for (int a = 0; a < ma; ++a) {
+            float bv = FLT_MAX;
+            int bk = 0x7fffffff;
+            if (KPT > 0) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int k = j * 256 + tid;
+                    const float v = mine[j][b];
+                    const bool after = v > last_v || (v == last_v && k > last_k);
+                    if (k < K && after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
+                }
+            } else {
+                for (int k = tid; k < K; k += 256) {
+                    const float v = dq[k];
+                    const bool after = v > last_v || (v == last_v && k > last_k);
+                    if (after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
+                }
             }
-        } else {
-            for (int k = tid; k < K; k += 256) {
-                const float v = dq[k];
-                const bool after = v > last_v || (v == last_v && k > last_k);
-                if (after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
+            // wave-level reduction first (no barrier), then across the 4 waves through LDS
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float ov = __shfl_xor(bv, d, 64);
+                const int ok = __shfl_xor(bk, d, 64);
+                if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
             }
-        }
-        // wave-level reduction first (no barrier), then across the 4 waves through LDS
+            if ((tid & 63) == 0) { rv[tid >> 6] = bv; rk[tid >> 6] = bk; }
+            __syncthreads();
+            bv = rv[0];
+            bk = rk[0];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const float ov = __shfl_xor(bv, d, 64);
-            const int ok = __shfl_xor(bk, d, 64);
-            if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+            for (int w = 1; w < 4; ++w)
+                if (rv[w] < bv || (rv[w] == bv && rk[w] < bk)) { bv = rv[w]; bk = rk[w]; }
+            last_v = bv;
+            last_k = bk;
+            if (tid == 0) assign[(size_t)(q0 + b) * ma + a] = last_k;
+            __syncthreads();
         }
-        if ((tid & 63) == 0) { rv[tid >> 6] = bv; rk[tid >> 6] = bk; }
-        __syncthreads();
-        bv = rv[0];
-        bk = rk[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (rv[w] < bv || (rv[w] == bv && rk[w] < bk)) { bv = rv[w]; bk = rk[w]; }
-        last_v = bv;
-        last_k = bk;
-        if (tid == 0) assign[(size_t)qi * ma + a] = last_k;
-        __syncthreads();
     }
 }
 
 void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
                           int32_t* d_assign, hipStream_t stream) {
-    const size_t lds = (size_t)dim * sizeof(float);
     const int kpt = (K + 255) / 256;
-#define QADC_CA(N) hipLaunchKernelGGL(coarse_assign_kernel<N>, dim3(nq), dim3(256), lds, stream, d_queries, d_coarse, K, dim, ma, d_dist, d_assign)
-    if (kpt <= 4) QADC_CA(4);
-    else if (kpt <= 16) QADC_CA(16);
-    else if (kpt <= 32) QADC_CA(32);
-    else QADC_CA(0);
+    // large batches share every centroid row between 4 queries (registers: KPT x 4 distances per thread)
+#define QADC_CA(N, QB) hipLaunchKernelGGL((coarse_assign_kernel<N, QB>), dim3((nq + QB - 1) / QB), dim3(256), (size_t)QB * dim * sizeof(float), \
+                                          stream, d_queries, d_coarse, nq, K, dim, ma, d_dist, d_assign)
+    if (nq >= 512) {
+        if (kpt <= 4) QADC_CA(4, 4);
+        else if (kpt <= 16) QADC_CA(16, 4);
+        else if (kpt <= 32) QADC_CA(32, 2);
+        else QADC_CA(0, 4);
+    } else {
+        if (kpt <= 4) QADC_CA(4, 1);
+        else if (kpt <= 16) QADC_CA(16, 1);
+        else if (kpt <= 32) QADC_CA(32, 1);
+        else QADC_CA(0, 1);
+    }
 #undef QADC_CA
 }
 

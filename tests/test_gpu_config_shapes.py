@@ -84,12 +84,12 @@ def test_c3_shape_ivf_16x4_k4096_nprobe32(pyqadc, po):
 def test_c5_shape_ivf_32x4_dim96_nprobe64(pyqadc, po):
     """BASELINE configs[4] shape on one GPU's worth of data: 32x4 codes (16 B), 96-d vectors => sq_dim 3 (the generic
     sub-vector loops; the reference's table dispatch has no such case), K = 1024, nprobe = 64, R = 100, 4e6 codes;
-    a 256-query batch, 32 sampled queries vs the oracle."""
+    a 513-query batch, 32 sampled queries (the last one always) vs the oracle."""
     rng = np.random.default_rng(96)
-    M, K, N, dim, ma, R, keep, nq = 32, 1024, 4_000_000, 96, 64, 100, 0.01, 256
+    M, K, N, dim, ma, R, keep, nq = 32, 1024, 4_000_000, 96, 64, 100, 0.01, 513   # (513: a ragged last group of the 4-queries-per-workgroup coarse kernel)
     idx, parts, labels, cb, coarse, sizes = _build(pyqadc, rng, M, K, N, dim, keep)
     queries = rng.normal(size=(nq, dim)).astype(np.float32)
     res = idx.search(queries, ma, R)
     assert int(res["status"].sum()) == 0
-    _check(po, res, rng.choice(nq, 32, replace=False), queries, parts, labels, cb, coarse, M, ma, keep, R)
+    _check(po, res, list(rng.choice(nq - 1, 31, replace=False)) + [nq - 1], queries, parts, labels, cb, coarse, M, ma, keep, R)
     idx.close()
