@@ -349,28 +349,34 @@ def ivf_leg(local_rank):
     idx.set_pq(cb)
     idx.set_coarse(coarse)
     qs = [rng.normal(size=(NQB, dim)).astype(np.float32) for _ in range(4)]
-    for w in range(2):
-        idx.search_submit(w, qs[w], MA, R)
-    for w in range(2):
-        idx.search_collect(w)
+    def pipelined(batches, steps, depth=3):
+        for w in range(2):
+            idx.search_submit(w, batches[w], MA, R)
+        for w in range(2):
+            idx.search_collect(w)
+        idx.profile_reset()
+        t0 = time.perf_counter()
+        pend, nc = [], 0
+        for s in range(steps):
+            idx.search_submit(s % depth, batches[s % 4], MA, R)
+            pend.append(s % depth)
+            if len(pend) == depth:
+                nc += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
+        while pend:
+            nc += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
+        return time.perf_counter() - t0, nc
+
     steps, depth = 16, 3
-    idx.profile_reset()
-    t0 = time.perf_counter()
-    pend, ncodes = [], 0
-    for s in range(steps):
-        idx.search_submit(s % depth, qs[s % 4], MA, R)
-        pend.append(s % depth)
-        if len(pend) == depth:
-            ncodes += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
-    while pend:
-        ncodes += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
-    dt = time.perf_counter() - t0
+    dt, ncodes = pipelined(qs, steps, depth)
     p = idx.profile()
+    qs2 = [rng.normal(size=(2 * NQB, dim)).astype(np.float32) for _ in range(4)]       # and at twice the batch size
+    dt2, _ = pipelined(qs2, 8, depth)
     idx.close()
     gbs = ncodes * (M // 2) / dt / 1e9
     return {"workload": "IVF, %d x 16x4 codes in K=%d partitions (multinomial sizes), nprobe=%d, R=%d, keep=%.0f%%, "
                         "%d-query batches, %d in flight, queries in -> heaps out (qadc_search)" % (N, K, MA, R, KEEP * 100, NQB, depth),
             "codes_per_sec": ncodes / dt, "us_per_query": dt * 1e6 / (steps * NQB), "queries_per_sec": steps * NQB / dt,
+            "us_per_query_at_2048_query_batches": dt2 * 1e6 / (8 * 2 * NQB),
             "probed_codes_per_query": ncodes / (steps * NQB),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "rule": "8 B x probed codes / wall time of the pipelined batches (whole path, not one kernel)"},
