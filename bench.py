@@ -350,9 +350,9 @@ def ivf_leg(local_rank):
     idx.set_coarse(coarse)
     qs = [rng.normal(size=(NQB, dim)).astype(np.float32) for _ in range(4)]
     def pipelined(batches, steps, depth=3):
-        for w in range(2):
+        for w in range(depth):                             # every slot used below sizes its buffers before the clock starts
             idx.search_submit(w, batches[w], MA, R)
-        for w in range(2):
+        for w in range(depth):
             idx.search_collect(w)
         idx.profile_reset()
         t0 = time.perf_counter()

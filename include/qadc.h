@@ -290,6 +290,7 @@ typedef struct qadc_profile {
     uint64_t wgq_front_cycles; /* shader cycles the query workgroups spent in pre-scan + select + quantizer (summed over queries) */
     uint64_t wgq_scan_cycles;  /* ... in the int8 scan */
     uint64_t wgq_sort_cycles;  /* ... and in the final candidate sort + ordered stream write */
+    uint64_t head_launches;    /* level path: batches whose first bound levels were scanned by one head launch */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

@@ -165,6 +165,7 @@ struct Slot {
     uint32_t wgq_cap = 0;               // stream entries per query workgroup (regrown on overflow)
     int wgq_G = 1;                      // workgroups per query (small batches: the scan order of a query is split)
     uint64_t wgq_codes = 0;             // codes a query probes (exact maximum, or an estimate) — sizes wgq_G
+    uint64_t head_codes = 0;            // level path: codes of every query's scan order covered by the head launch (0 = none)
     uint64_t wgq_fcap = 0;              // pre-scan values per query in the global scratch (0 = they fit LDS)
     DevBuf<uint32_t> d_qflags;          // [nq][4]: {flags, entries} for replay_heap_lanes_kernel
     DevBuf<float> d_fvals;
@@ -299,6 +300,8 @@ struct qadc_index {
     uint64_t wgq_small_codes = 1ull << 18;   // any batch probing at most this many codes per query
     uint32_t wgq_capacity = 4096;        // stream entries per query to start with
     int wgq_split = 8;                   // at most this many workgroups per query (batches too small to fill the GPU)
+    int head_level = 0;                  // level path: bound levels 0..head_level-1 are scanned by ONE launch of the query kernel
+                                         // in head mode instead of head_level dependent level launches (0 = off)
     int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
     int table_form = 2;                  // float tables of qadc_search: 0 direct, 1 BLAS expansion, 2 the reference's nns_engine rule
     uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)
@@ -381,6 +384,8 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
     uint64_t L[kMaxLevels + 1];
     level_bounds(idx, L);
     std::vector<std::vector<ScanItem>> per_level(kMaxLevels);
+    const int k0 = (s.mode != 1 && idx->head_level > 0) ? idx->head_level : 0;   // levels < k0 belong to the head launch
+    s.head_codes = k0 ? L[k0] : 0;
     std::vector<StartItem>& sitems_a = plan.sitems_a;
     std::vector<StartItem>& sitems_b = plan.sitems_b;
     std::vector<uint32_t>& fc_init = plan.fc_init;
@@ -455,6 +460,10 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
                     cut -= cut % cpl;  // keep every run 16-byte aligned
                 }
                 if (cut <= prev) continue;
+                if (k < k0) {                                 // scanned by the head launch (same cut: scan_query_kernel, HEAD)
+                    prev = cut;
+                    continue;
+                }
                 // runs longer than 2^31 codes are cut so that 32-bit vector indices cannot wrap
                 for (uint64_t b0 = prev; b0 < cut;) {
                     const uint64_t len = std::min<uint64_t>(cut - b0, 1ull << 31);
@@ -592,7 +601,9 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     const size_t tables_bytes = s.float_path ? (s.device_tables ? 0 : nt * sizeof(float)) : nt;
     const size_t off_inj = align16(off_tables + tables_bytes);
     const size_t inj_bytes = s.mode == 2 ? sizeof(float) * (size_t)nq * s.inj_n : 0;
-    const size_t in_bytes = align16(off_inj + inj_bytes);
+    const size_t off_hassign = align16(off_inj + inj_bytes);  // assign[] for the head launch (it walks the partition table itself)
+    const size_t hassign_bytes = s.head_codes ? sizeof(int32_t) * (size_t)nq * ma : 0;
+    const size_t in_bytes = align16(off_hassign + hassign_bytes);
     HIPCHECK(s.h_in.ensure(in_bytes));
     HIPCHECK(s.d_in.ensure(in_bytes));
     if (nitems) std::memcpy(s.h_in.p + off_items, all_items.data(), nitems * sizeof(ScanItem));
@@ -602,6 +613,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     if (s.float_path && !s.device_tables) std::memcpy(s.h_in.p + off_tables, s.tables, nt * sizeof(float));
     if (!s.float_path) std::memcpy(s.h_in.p + off_tables, s.qtables_in.data(), nt);
     if (inj_bytes) std::memcpy(s.h_in.p + off_inj, s.inj_vals.data(), inj_bytes);
+    if (hassign_bytes) std::memcpy(s.h_in.p + off_hassign, s.assign.data(), hassign_bytes);
     s.d_items = reinterpret_cast<ScanItem*>(s.d_in.p + off_items);
     s.d_sitems = reinterpret_cast<StartItem*>(s.d_in.p + off_sitems);
     s.d_fc_init = reinterpret_cast<uint32_t*>(s.d_in.p + off_init);
@@ -772,6 +784,28 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         st = main_stream;
         HIPCHECK(hipStreamWaitEvent(st, s.ev_front, 0));
     }
+    if (s.head_codes) {
+        // ONE launch scans the first head_codes codes of every query (bound levels 0..k0-1): every query's scan order
+        // split over G workgroups that refresh their bound in LDS, instead of k0 dependent launches of a few
+        // microseconds of work each.  It emits into the same candidate regions / level-0 histogram the levels use.
+        QueryKernelArgs H{};
+        H.parts = idx->d_partdesc.p;
+        H.assign = reinterpret_cast<const int32_t*>(s.d_in.p + off_hassign);
+        H.ma = ma;
+        H.qtables = const_cast<int8_t*>(s.d_qt);
+        H.R = (uint32_t)s.R;
+        H.head_codes = s.head_codes;
+        H.qstates = s.d_qs;
+        H.cand_regions = s.d_cands.p;
+        H.cand_cap = s.cap_q;
+        H.hdr = s.d_hdr;
+        H.nontemporal = 0;                                   // the queries of a batch share the head of a flat list through L2
+        int G = std::min<int>(idx->wgq_split, std::max(1, 256 / nq));
+        G = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)G, s.head_codes / 16384));
+        H.G = G;
+        HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));
+        idx->prof.head_launches++;
+    }
     // HIP events cost ~10 us of stream time each: with profiling on, every run of consecutive streaming-kernel
     // launches (the roofline figure) shares ONE event pair; small-run launches are counted, not timed
     for (size_t li = n_early; li < s.launches.size(); ++li) {
@@ -914,7 +948,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         }
     }
     s.prof_used = 0;
-    QueryKernelArgs A;
+    QueryKernelArgs A{};
     A.parts = idx->d_partdesc.p;
     A.assign = s.assign_on_device ? s.d_assign.p : reinterpret_cast<const int32_t*>(s.d_in.p);
     A.ma = ma;
@@ -1356,6 +1390,7 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     idx->cs = M / 2;
     idx->device = device_id;
     if (const char* e = std::getenv("QADC_WGQ")) idx->wgq = std::atoi(e);   // test hook: force (2) / forbid (0) the one-workgroup-per-query path
+    if (const char* e = std::getenv("QADC_HEAD_LEVEL")) idx->head_level = std::max(0, std::min(std::atoi(e), kMaxLevels - 1));   // test hook
     // The streaming launches fill every CU for milliseconds.  They go on the LOWEST-priority queue so that the
     // short work that must overlap them is dispatched as soon as a workgroup slot frees up instead of waiting for
     // the whole batch: the previous batch's candidate sort, the next batch's front (own streams, highest priority) and
@@ -1678,6 +1713,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "wgq_min_nq") idx->wgq_min_nq = (int)std::max(value, 1.0);
     else if (n == "wgq_max_codes") idx->wgq_max_codes = (uint64_t)std::max(value, 0.0);
     else if (n == "wgq_small_codes") idx->wgq_small_codes = (uint64_t)std::max(value, 0.0);
+    else if (n == "head_level") idx->head_level = (int)std::max(0.0, std::min(value, (double)(kMaxLevels - 1)));
     else if (n == "wgq_split") idx->wgq_split = (int)std::max(1.0, std::min(value, 64.0));
     else if (n == "wgq_capacity") idx->wgq_capacity = (uint32_t)std::max(16.0, std::min(value, 1048576.0));
     else if (n == "profile") idx->profile = value != 0;

@@ -121,6 +121,13 @@ struct QueryKernelArgs {
     uint32_t R;
     int quant_mode;
     int nontemporal;         // non-temporal code loads (database larger than the Infinity Cache)
+    // head mode (level-structured path): scan only the first head_codes codes of every query's scan order with the int8
+    // tables in `qtables`, emit Cand records / level-0 histogram counts like emit_candidate does (0 = normal mode)
+    uint64_t head_codes;
+    QueryState* qstates;
+    Cand* cand_regions;      // [nq][cand_cap]
+    uint32_t cand_cap;
+    CandHeader* hdr;
     int G;                   // workgroups per query (>= 1): the grid is nq * G, every output array is indexed by q * G + g;
                              // workgroup g scans the first block (bound only, g > 0) and the g-th chunk of the rest
 };

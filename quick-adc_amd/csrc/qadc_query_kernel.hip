@@ -152,7 +152,12 @@ __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint
 // NT = non-temporal code loads (lists that stream from HBM anyway); a database that fits the 256 MiB Infinity Cache
 // keeps the default policy and is re-read from the cache by every query.
 // MULTI = several workgroups per query (small batches; A.G); the single-workgroup instantiation stays lean.
-template <int M, int U, int OCC, bool NT, bool MULTI>
+// HEAD  = the kernel serves as the HEAD of the level-structured path: it scans only the first A.head_codes codes of
+//         every query's scan order (what the planner's bound levels 0..k0-1 would cover, same cuts) with the caller's
+//         int8 tables, and emits straight into that path's structures — unordered Cand records in the query's region,
+//         counts in QueryState::hist[level 0] — so that ONE launch replaces a dependent chain of k0 short level
+//         launches; the later levels derive their bounds from it and sort_cands_kernel orders everything.
+template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD>
 __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A) {
     using C = QCfg<M>;
     if (reinterpret_cast<uintptr_t>((q_lds_bytes_t)qsmem) != 0) __builtin_trap();   // the lookups use absolute LDS addresses
@@ -404,16 +409,33 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     if (tid == 0) s_ccount = 0;
     // ---- how the query's scan order is shared by the G workgroups of the query (G = 1: everything is "mine") ----
     // total vectors of the probed partitions, in scan order
-    uint32_t vmine = 0;
-    for (int a_ = tid; a_ < ma; a_ += kQWG) vmine += (parts[assign[a_]].n + CPL - 1) / CPL;
-#pragma unroll
-    for (int dlt = 32; dlt >= 1; dlt >>= 1) vmine += __shfl_xor(vmine, dlt, 64);
-    if (lane == 0) wcnt[wave] = vmine;
-    q_lds_barrier();
+    // (HEAD: codes of a partition the head covers = the planner's cut of bound level k0 in that partition: everything if
+    // the partition ends before head_codes, else (head_codes - codes before it) rounded down to whole 16-byte vectors)
+    auto eff_n = [&](uint32_t n_, uint64_t cbase_) -> uint32_t {
+        if (!HEAD) return n_;
+        if (A.head_codes >= cbase_ + n_) return n_;
+        const uint64_t cut = A.head_codes > cbase_ ? A.head_codes - cbase_ : 0;
+        return (uint32_t)(cut - cut % CPL);
+    };
     uint64_t V = 0;
+    if (HEAD) {
+        uint64_t cb_ = 0;
+        for (int a_ = 0; a_ < ma && cb_ < A.head_codes; ++a_) {
+            const uint32_t n_ = q_uni(parts[assign[a_]].n);
+            V += (eff_n(n_, cb_) + CPL - 1) / CPL;
+            cb_ += n_;
+        }
+    } else {
+        uint32_t vmine = 0;
+        for (int a_ = tid; a_ < ma; a_ += kQWG) vmine += (parts[assign[a_]].n + CPL - 1) / CPL;
 #pragma unroll
-    for (int w = 0; w < kQWaves; ++w) V += wcnt[w];
-    q_lds_barrier();
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) vmine += __shfl_xor(vmine, dlt, 64);
+        if (lane == 0) wcnt[wave] = vmine;
+        q_lds_barrier();
+#pragma unroll
+        for (int w = 0; w < kQWaves; ++w) V += wcnt[w];
+        q_lds_barrier();
+    }
     // Every workgroup walks the first block [0, B) to tighten its bound (only workgroup 0 emits from it), then its own
     // chunk of the rest.  The bound a workgroup uses for a code is the R-th smallest value of candidates from the
     // first block and from its own chunk before that code: a subset of the code's scan-order prefix, hence valid.
@@ -432,16 +454,27 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     for (int pass = (MULTI && B) ? 0 : 1; pass < 2; ++pass) {
         const uint64_t lo = pass == 0 ? 0 : my_lo, hi = pass == 0 ? B : my_hi;
         const bool do_emit = pass == 1 || g == 0;
-        uint64_t pbase = 0;
-        int a = next_part(-1);
+        uint64_t pbase = 0, cbase = 0;                           // vectors / codes of the scan order before partition a
+        int a = HEAD ? 0 : next_part(-1);                        // (HEAD walks every slot: cbase counts empty-here partitions too)
         while (MULTI && a < ma) {                                // skip the partitions that end before lo
-            const uint32_t nv = (q_uni(parts[assign[a]].n) + CPL - 1) / CPL;
+            const uint32_t n_ = q_uni(parts[assign[a]].n);
+            const uint32_t nv = (eff_n(n_, cbase) + CPL - 1) / CPL;
             if (pbase + nv > lo) break;
             pbase += nv;
-            a = next_part(a);
+            cbase += n_;
+            a = HEAD ? a + 1 : next_part(a);
         }
         while (a < ma && (!MULTI || pbase < hi)) {
-            const UDesc d = q_load_desc(parts, (int)q_uni((uint32_t)assign[a]));
+            UDesc d = q_load_desc(parts, (int)q_uni((uint32_t)assign[a]));
+            const uint32_t n_full = d.n;
+            if (HEAD) {
+                d.n = eff_n(n_full, cbase);
+                if (d.n == 0) {                                  // nothing of this partition lies inside the head
+                    cbase += n_full;
+                    ++a;
+                    continue;
+                }
+            }
             const uint32_t n = d.n;
             const uint32_t nvec = (n + CPL - 1) / CPL;
             const uint32_t t_begin = MULTI ? (uint32_t)(max(lo, pbase) - pbase) : 0u;
@@ -454,15 +487,32 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
                 q_lds_barrier();
                 tables_of = a;
             }
-            const int a_next = next_part(a);
-            const bool more = a_next < ma && (!MULTI || pbase + nvec < hi);   // the walk continues in the next probed partition
+            const int a_next = HEAD ? a + 1 : next_part(a);
+            const bool more = !HEAD && a_next < ma && (!MULTI || pbase + nvec < hi);   // the walk continues in the next probed partition
             const uint32_t tqv = more ? table_word(a_next) : 0u; // in flight during this partition's epochs
             const gvec_t src = (gvec_t)(uintptr_t)d.codes;
-            const uint32_t dup_pos = (d.first_pos + d.n == d.global_n) ? d.n - 1u : 0xffffffffu;
+            const uint32_t dup_pos = (d.first_pos + n_full == d.global_n && n == n_full) ? n_full - 1u : 0xffffffffu;
             const uint32_t dup_reps = (16u - d.global_n % 16u) % 16u;
             const uint32_t key_base = d.key_base + d.first_pos;
             auto emit = [&](uint32_t cv, uint32_t p) {           // rare: count (and append, unordered) one candidate
-                if (do_emit) {
+                if (HEAD && do_emit) {                           // into the level path's structures (emit_candidate's twin)
+                    QueryState* qs = A.qstates + q;
+                    const uint32_t reps = p == dup_pos ? dup_reps : 0u;
+                    const uint32_t slot = atomicAdd(&qs->count, 1u);
+                    if (slot < A.cand_cap) {
+                        Cand c_;
+                        c_.order = (uint32_t)a | (reps << 20);   // level 0, assign slot a
+                        c_.pos = p;
+                        c_.key = d.labels ? d.labels[p] : key_base + p;
+                        c_.val = cv;
+                        A.cand_regions[(size_t)q * A.cand_cap + slot] = c_;
+                    } else {
+                        atomicAdd(&A.hdr->overflow, 1u);
+                    }
+                    if (reps) atomicAdd(&qs->reps, reps);
+                    atomicAdd(&qs->hist[cv], 1u);
+                    atomicAdd(&s_dirty, 1u);
+                } else if (do_emit) {
                     const uint32_t slot = atomicAdd(&s_ccount, 1u);
                     if (slot < A.ccap) {
                         QCand qc;
@@ -565,9 +615,11 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
                 if (sw) tables_of = a_next;
             }
             if (MULTI) pbase += nvec;
+            if (HEAD) cbase += n_full;
             a = a_next;
         }
     }
+    if (HEAD) return;                                            // the level path orders and reports
     // ---- 4. order the candidates: (assign slot, position) ascending = scan order ----
     const uint64_t clk2 = __builtin_readcyclecounter();
     __syncthreads();                                             // the candidate stores of every wave are complete
@@ -858,7 +910,7 @@ __global__ __launch_bounds__(64) void dist_merge_lanes_kernel(const uint64_t* __
 size_t query_kernel_lds_bytes(int M) { return M == 16 ? QCfg<16>::LDS_BYTES : QCfg<32>::LDS_BYTES; }
 uint32_t query_kernel_lds_values(int M) { return M == 16 ? QCfg<16>::FCAP : QCfg<32>::FCAP; }
 
-template <int M, int U, int OCC, bool NT, bool MULTI>
+template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD = false>
 static hipError_t launch_scan_query_nt(int nq, const QueryKernelArgs& args, hipStream_t stream) {
     // dynamic LDS above the default limit is opted into per (kernel, device)
     int dev = 0;
@@ -867,17 +919,20 @@ static hipError_t launch_scan_query_nt(int nq, const QueryKernelArgs& args, hipS
     static uint64_t done = 0;
     const size_t lds = QCfg<M>::LDS_BYTES;
     if (dev < 64 && !(done & (1ull << dev))) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         done |= 1ull << dev;
     }
-    hipLaunchKernelGGL((scan_query_kernel<M, U, OCC, NT, MULTI>), dim3(nq * (MULTI ? args.G : 1)), dim3(kQWG), lds, stream, args);
+    hipLaunchKernelGGL((scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>), dim3(nq * (MULTI ? args.G : 1)), dim3(kQWG), lds, stream, args);
     return hipGetLastError();
 }
 
 template <int M, int U, int OCC>
 static hipError_t launch_scan_query_v(int nq, const QueryKernelArgs& args, hipStream_t stream) {
+    if (args.head_codes)
+        return args.nontemporal ? launch_scan_query_nt<M, U, OCC, true, true, true>(nq, args, stream)
+                                : launch_scan_query_nt<M, U, OCC, false, true, true>(nq, args, stream);
     if (args.G > 1)
         return args.nontemporal ? launch_scan_query_nt<M, U, OCC, true, true>(nq, args, stream)
                                 : launch_scan_query_nt<M, U, OCC, false, true>(nq, args, stream);
