@@ -300,8 +300,9 @@ struct qadc_index {
     uint64_t wgq_small_codes = 1ull << 18;   // any batch probing at most this many codes per query
     uint32_t wgq_capacity = 4096;        // stream entries per query to start with
     int wgq_split = 8;                   // at most this many workgroups per query (batches too small to fill the GPU)
-    int head_level = 0;                  // level path: bound levels 0..head_level-1 are scanned by ONE launch of the query kernel
-                                         // in head mode instead of head_level dependent level launches (0 = off)
+    int head_level = 5;                  // level path: bound levels 0..head_level-1 (the first 512 Ki codes of every query) are
+                                         // scanned by ONE launch of the query kernel in head mode instead of head_level dependent
+                                         // level launches (0 = off): -5 % per step on a 125M-code shard, neutral at 1B
     int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
     int table_form = 2;                  // float tables of qadc_search: 0 direct, 1 BLAS expansion, 2 the reference's nns_engine rule
     uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)

@@ -190,6 +190,7 @@ def test_candidate_buffer_regrow_is_exact(pyqadc, po):
     idx.add_partitions([codes])
     idx.finalize(0.01)
     idx.set_option("wgq", 0)                # this test is about the level-structured path's own fallbacks
+    idx.set_option("head_level", 0)         # (with every bound level launched separately)
     idx.set_option("cand_capacity", 16)      # far too small: forces the overflow -> regrow -> rerun path
     idx.set_option("profile", 1)
     qt = rand_qtables(rng, (2, 1), 16, 20)
@@ -244,6 +245,7 @@ def test_host_sort_fallback_when_a_query_has_too_many_candidates(pyqadc, po):
     idx.add_partitions([codes])
     idx.finalize(0.01)
     idx.set_option("wgq", 0)                # this test is about the level-structured path's own fallbacks
+    idx.set_option("head_level", 0)         # (with every bound level launched separately)
     idx.set_option("level_base", 1 << 20)
     idx.set_option("profile", 1)
     qt = rand_qtables(rng, (2, 1), 16, 30)
@@ -291,6 +293,7 @@ def test_prescan_survivor_overflow_falls_back_to_full_prescan(pyqadc, po):
     idx.add_partitions([codes])
     idx.finalize(keep)
     idx.set_option("wgq", 0)                # this test is about the level-structured path's own fallbacks
+    idx.set_option("head_level", 0)         # (with every bound level launched separately)
     idx.set_option("prescan_sample", 4096)
     idx.set_option("profile", 1)
     res = idx.query_scan(np.zeros((2, 1), np.int32), tables.copy(), 100, want_qtables=True)
@@ -771,6 +774,7 @@ def test_pipelined_slots_with_regrows_and_changing_batch_shapes(pyqadc, po):
     idx.add_partitions(parts)
     idx.finalize(keep)
     idx.set_option("wgq", 0)                # this test is about the level-structured path's own fallbacks
+    idx.set_option("head_level", 0)         # (with every bound level launched separately)
     idx.set_option("small_run", 8192)
     idx.set_option("cand_capacity", 32)
     batches = []
