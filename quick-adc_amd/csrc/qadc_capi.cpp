@@ -502,7 +502,7 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
     all_items.assign(nitems, ScanItem());
     s.launches.clear();
     size_t off = 0;
-    const int wgs_cap = idx->wgs_per_item > 0 ? idx->wgs_per_item : (M == 16 ? 512 : 256);
+    const int wgs_cap = idx->wgs_per_item > 0 ? idx->wgs_per_item : (M == 16 ? 1024 : 512);   // (r02 sweep: 1024 reaches the streaming ceiling of the "probe" variant, 512 is 1.6 % below)
     for (int k = 0; k < kMaxLevels; ++k) {
         if (per_level[k].empty()) continue;
         // one launch for the short runs of the level, one for the long ones
