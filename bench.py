@@ -586,14 +586,29 @@ def main():
             idx.submit(b % 4, assign, tbs[b % 6], R, prescan=g[b * NQ:(b + 1) * NQ])
         if k > LEAD:
             prescan(LEAD)
+        stamps = [] if os.environ.get("QADC_BENCH_STEP_LOG") else None
         for i in range(k):                                     # batches i .. i+LEAD-1 are in flight; i is collected now
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+            ta = time.perf_counter()
             if i + LEAD + 1 < k:
                 prescan(i + LEAD + 1)                          # pre-slot of batch i+LEAD-1, collected an iteration ago
+            tb_ = time.perf_counter()
             pv = idx.prescan_collect((i + LEAD) % 2) if i + LEAD < k else None   # batch i+LEAD's, enqueued an iteration ago
+            tc = time.perf_counter()
             out = merge(i % 4, pv)
+            td = time.perf_counter()
             last = out[:3]
             if i + LEAD < k:
                 idx.submit((i + LEAD) % 4, assign, tbs[(i + LEAD) % 6], R, prescan=out[3])
+            te = time.perf_counter()
+            if stamps is not None and te - ta > 5e-3 and rank == 0:
+                print("SLOW iter %d: prescan %.2f collect_pv %.2f merge %.2f submit %.2f ms" % (i, (tb_-ta)*1e3, (tc-tb_)*1e3, (td-tc)*1e3, (te-td)*1e3), file=sys.stderr)
+        if stamps and rank == 0:                                # tuning aid: per-iteration host times of the loop
+            d = np.diff(np.array(stamps)) * 1e3
+            with open(os.environ["QADC_BENCH_STEP_LOG"], "a") as f:
+                f.write("steps %d: median %.3f ms, max %.3f at %d, >2x median: %s\n" % (
+                    k, np.median(d), d.max(), int(d.argmax()), [(int(j), round(float(d[j]), 2)) for j in np.nonzero(d > 2 * np.median(d))[0]][:40]))
         return last
 
     def sync():

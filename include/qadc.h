@@ -90,7 +90,7 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * "cand_capacity" (candidate region entries per query), "level_base", "level_growth" (bound levels),
  * "prescan_sample", "small_run", "small_vec_per_wg", "wgs_per_item", "variant", "share_variant" (0 = never
  * launch the queries of a batch as L2-sharing siblings), "share_codes_per_wg", "mq" (8 queries per pass),
- * "mq_codes_per_wg", "mq_min_wgs", "mq_min_tiles", "prescan_mq", "overlap_front", "front_run_max",
+ * "mq_codes_per_wg", "mq_min_wgs", "mq_min_tiles", "prescan_mq", "overlap_front", "head_early", "front_run_max",
  * "front_min_batch" (kernel and launch tuning), "device_replay_nq" (batches of at least this many queries replay
  * their candidate streams through the heap on the device; 0 = always on the host), "replay_threads". */
 int qadc_set_option(qadc_index* idx, const char* name, double value);

@@ -280,13 +280,15 @@ struct qadc_index {
     uint32_t share_codes_per_wg = 1u << 20;
     int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
     int device_replay_nq = 64;           // batches of at least this many queries replay their streams on the device (0 = never)
-    uint64_t front_run_max = 0;          // leading levels whose runs are at most this long join the front (0 = none, the default:
-                                         // -1 % at 1B x 32 with 8 Mi, but those launches then escape the event-timed roofline figure)
-    uint64_t front_min_batch = 10000000000ull;   // ... in batches of at least this many (code, query) pairs
+    uint64_t front_run_max = 2u << 20;   // leading levels whose runs are at most this long join the front (0 = none); they are
+                                         // counted with the small launches, not event-timed.  125M x 32: 2 Mi -4 %, 8 Mi +1 %
+    uint64_t front_min_batch = 0;        // ... in batches of at least this many (code, query) pairs
     int prescan_mq = 1;                  // ... and so does the float pre-scan when every query pre-scans the same starts
     uint32_t mq_codes_per_wg = 1u << 16;
     uint32_t mq_min_wgs = 4096;          // workgroups a multi-query launch should have at least (2 rounds of the chip)
     uint32_t mq_min_tiles = 4;           // ... but never fewer than this many 4 KiB tiles per workgroup
+    int front_dist = 1;    // early levels also for the multi-GPU loop's batches (pre-scan injected)
+    int head_early = 1;    // the head launch joins the front stream (under the previous batch's long levels)
     int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
     int replay_threads = 0;            // 0 = auto
@@ -762,30 +764,12 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                            s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q, (uint32_t)s.R, str);
     };
     // The first levels of a batch are short launches in a dependent chain (each level's bound needs the previous
-    // levels' candidates): latency, not work.  They join the front — same stream, after the quantizer — and so run
-    // under the previous batch's long levels instead of in front of this batch's; only the long levels stay on the
-    // main stream.  (Strong scaling: on a 125M-code shard that chain is a sixth of the step.)
-    // Only for long single-GPU batches: front kernels only find room at the boundaries of the long launches, so under
-    // a short batch (a small shard), or with the multi-GPU loop's extra pre-scan pass on the same stream, the front is
-    // the critical path already and the extra launches cost more than they save (125M x 32: +2 %; 1B x 32: -1 %).
-    size_t n_early = 0;
-    uint64_t batch_codes = 0;
-    for (auto& ll : s.launches) batch_codes += ll.codes;
-    if (st != main_stream && s.mode == 0 && batch_codes >= idx->front_min_batch)
-        while (n_early < s.launches.size() && s.launches[n_early].maxn <= idx->front_run_max) ++n_early;
-    if (n_early == s.launches.size() && n_early) --n_early;        // the last level closes the batch on the main stream
-    for (size_t li = 0; li < n_early; ++li) {
-        s.launches[li].early = true;
-        s.launches[li].ev = -1;
-        launch_level(s.launches[li], st);
-    }
-    if (st != main_stream) {
-        if (!s.ev_front) HIPCHECK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
-        HIPCHECK(hipEventRecord(s.ev_front, st));
-        st = main_stream;
-        HIPCHECK(hipStreamWaitEvent(st, s.ev_front, 0));
-    }
-    if (s.head_codes) {
+    // levels' candidates): latency, not work.  The head launch and the levels with short runs join the front — same
+    // stream, after the quantizer — and so run under the previous batch's long levels instead of in front of this
+    // batch's; only the long levels stay on the main stream.  Front-stream kernels only find room as workgroups of
+    // the long launches retire, so a level with real work is slower there than on the main stream: runs of <= 2 Mi
+    // codes go early (125M x 32 queries: 1.143 -> 1.10 ms per step; 1B x 32: -1 %), 8 Mi already costs more than it hides.
+    auto launch_head = [&](hipStream_t str) -> int {
         // ONE launch scans the first head_codes codes of every query (bound levels 0..k0-1): every query's scan order
         // split over G workgroups that refresh their bound in LDS, instead of k0 dependent launches of a few
         // microseconds of work each.  It emits into the same candidate regions / level-0 histogram the levels use.
@@ -804,9 +788,35 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         int G = std::min<int>(idx->wgq_split, std::max(1, 256 / nq));
         G = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)G, s.head_codes / 16384));
         H.G = G;
-        HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));
+        HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, str));
         idx->prof.head_launches++;
+        return QADC_OK;
+    };
+    size_t n_early = 0;
+    uint64_t batch_codes = 0;
+    for (auto& ll : s.launches) batch_codes += ll.codes;
+    if (st != main_stream && (s.mode == 0 || (s.mode == 2 && idx->front_dist)) && batch_codes >= idx->front_min_batch)
+        while (n_early < s.launches.size() && s.launches[n_early].maxn <= idx->front_run_max) ++n_early;
+    if (n_early == s.launches.size() && n_early) --n_early;        // the last level closes the batch on the main stream
+    // the head precedes every level: with the early levels (or on request) it joins the front as well
+    bool head_pending = s.head_codes != 0;
+    if (head_pending && st != main_stream && (n_early || idx->head_early)) {
+        if (int rc = launch_head(st)) return rc;
+        head_pending = false;
     }
+    for (size_t li = 0; li < n_early; ++li) {
+        s.launches[li].early = true;
+        s.launches[li].ev = -1;
+        launch_level(s.launches[li], st);
+    }
+    if (st != main_stream) {
+        if (!s.ev_front) HIPCHECK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(s.ev_front, st));
+        st = main_stream;
+        HIPCHECK(hipStreamWaitEvent(st, s.ev_front, 0));
+    }
+    if (head_pending)
+        if (int rc = launch_head(st)) return rc;
     // HIP events cost ~10 us of stream time each: with profiling on, every run of consecutive streaming-kernel
     // launches (the roofline figure) shares ONE event pair; small-run launches are counted, not timed
     for (size_t li = n_early; li < s.launches.size(); ++li) {
@@ -1684,6 +1694,8 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "level_growth") idx->level_growth = (uint64_t)std::max(2.0, value);
     else if (n == "wgs_per_item") idx->wgs_per_item = (int)value;
     else if (n == "overlap_front") idx->overlap_front = value != 0;
+    else if (n == "head_early") idx->head_early = value != 0;
+    else if (n == "front_dist") idx->front_dist = value != 0;
     else if (n == "share_variant") idx->share_variant = (int)value;
     else if (n == "mq") idx->mq = value != 0;
     else if (n == "prescan_mq") idx->prescan_mq = value != 0;
@@ -2144,6 +2156,22 @@ int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
+    // RCCL finishes setting up its channels lazily, inside the first collectives of a communicator (the very first
+    // all-gather takes ~8 ms); a few throw-away gathers here keep that out of the first batches' collect calls.
+    {
+        constexpr size_t kWords = 1 << 16;
+        DevBuf<uint64_t> src, dst;
+        HIPCHECK(src.ensure(kWords));
+        HIPCHECK(dst.ensure(kWords * world));
+        hipError_t he = hipMemsetAsync(src.p, 0, sizeof(uint64_t) * kWords, d->stream);
+        int rc2 = 0;
+        for (int i = 0; i < 16 && he == hipSuccess && rc2 == 0; ++i)
+            rc2 = d->AllGather(src.p, dst.p, kWords, /*ncclUint64*/ 5, d->comm, d->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(d->stream);
+        src.release(); dst.release();
+        if (rc2 != 0) return fail(QADC_E_HIP, std::string("ncclAllGather: ") + (d->GetErrorString ? d->GetErrorString(rc2) : "error"));
+        HIPCHECK(he);
+    }
     idx->dist = d.release();
     return QADC_OK;
 }

@@ -4,28 +4,29 @@
 // level, many workgroups per run: right for a flat list of 10^8..10^9 codes, wrong for an IVF batch, where a
 // query probes a few 10^5 codes in dozens of short partitions, there are hundreds of queries in flight, and
 // the dependent chain of launches, the per-item table builds, the candidate sort and the host planner cost more
-// than the scan.  Here a query belongs to one 1024-thread workgroup that walks the query's scan order
-// SEQUENTIALLY, tile by tile:
+// than the scan.  Here a query belongs to one 1024-thread workgroup that walks the query's scan order itself:
 //
 //   1. float pre-scan of the probed partitions' starts (scan_4<M>, query_common.hpp:59-90; same add order) into
 //      LDS, R-th smallest by a 4-pass radix select in LDS  -> qmax            (db_query_4.cpp:230-242, 259)
 //   2. qmin over all ma tables, negative clamp, QuantizerMAX<int8_t>           (db_query_4.cpp:37-71, 258-284)
 //   3. int8 scan of every probed partition in assign[] order                   (simd_scan.hpp:125-187):
-//      pair-fused 256-entry byte tables in LDS (conflict-free: a 256-byte table covers every bank once),
-//      cand = min(127, sum).  Because ONE workgroup sees the query's codes in scan order, the prefix bound
-//       is refreshed after every tile from a 128-bin histogram in LDS — no levels, no launch
-//      boundaries — and the qualifying codes are appended IN SCAN ORDER by a wave-ordered compaction, so there
-//      is no sort pass either.  The padding-lane replays of a partition's last code (simd_layout.hpp:46-50,
-//      simd_scan.hpp:67) are expanded while writing.
+//      pair-fused 256-entry byte tables in LDS, bank-replicated so that any code data reads conflict-free,
+//      cand = min(127, sum).  The scan order is cut into EPOCHS (64, 128, 256 ... codes, then one per <= 32 Ki
+//      vectors of a partition); inside an epoch the 16 waves run free — no workgroup barrier per tile — against
+//      the bound of the epochs that are FINISHED (a 128-bin histogram in LDS, swapped at the epoch boundary), and
+//      append the qualifying codes unordered to the workgroup's candidate buffer in global memory.
+//   4. the workgroup sorts its candidates by (assign slot, position) — bitonic, LDS-tiled — and writes the
+//      ordered push stream, expanding the padding-lane replays of a partition's last code
+//      (simd_layout.hpp:46-50, simd_scan.hpp:67) while writing.
 //
 // Output per query: the ordered push stream (entry = key | value << 32 | assign slot << 40, the format of the
-// sorted output of sort_cands_kernel) and a QueryOut record; the heap replay stays where it was (host for small
-// batches, replay_heap_lanes_kernel for large ones).  Exactness argument: every dropped code has
-// cand >= the R-th smallest (<127) value of a set of codes that all PRECEDE it in this query's scan order.
+// sorted output of sort_cands_kernel) and a QueryOut record; the heap replay follows (host for small batches,
+// replay_heap_lanes_kernel — one LANE per query — for large ones).  Exactness argument: every dropped code has
+// cand >= the R-th smallest (<127) value of a set of codes that all PRECEDE it in this query's scan order
+// (the finished epochs), DESIGN.md section 4.
 //
-// The workgroups of a batch are independent and each streams its own codes: 256 CUs x 2 resident workgroups
-// keep ~64 KiB of 16-byte loads in flight per CU, which is what it takes to pull HBM bandwidth with one query
-// per workgroup.  gfx950 only.
+// Variants of the same kernel: MULTI (a small batch spreads each query over G workgroups, which share the first
+// block of the scan order for their bound) and HEAD (the first launch of the level-structured path).  gfx950 only.
 #include "qadc_kernels.h"
 
 #include <cfloat>
@@ -171,8 +172,6 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     uint32_t& s_nvals = misc[320];
     uint32_t& s_prefix = misc[321];
     uint32_t& s_k = misc[322];
-    uint32_t& s_bound = misc[323];
-    uint32_t* s_any = misc + 328;                // [3] "some lane qualifies" flags, rotated per tile (see the scan loop)
     uint32_t& s_count = misc[325];
     float* redf = reinterpret_cast<float*>(misc + 336);   // [16] per-wave minima
 
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
 
     const uint64_t clk0 = __builtin_readcyclecounter();          // phase clocks (QueryOut::pad): 1/16 shader cycles
     if (tid < 256) hist[tid] = 0;
-    if (tid == 0) { s_nvals = 0; s_any[0] = s_any[1] = s_any[2] = 0; s_count = 0; s_bound = 127; }
+    if (tid == 0) { s_nvals = 0; s_count = 0; }
     __syncthreads();
 
     float qmin = 0.0f, qmax = 0.0f;
