@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cfloat>
 #include <cstddef>
@@ -163,6 +164,7 @@ struct Slot {
     bool wgq = false;
     bool dist_batch = false;            // launched with the native multi-GPU merge active: streams kept in device memory
     uint32_t wgq_cap = 0;               // stream entries per query workgroup (regrown on overflow)
+    bool poll = false;                  // collect watches the workgroups' done bits instead of the completion event
     int wgq_G = 1;                      // workgroups per query (small batches: the scan order of a query is split)
     uint64_t wgq_codes = 0;             // codes a query probes (exact maximum, or an estimate) — sizes wgq_G
     uint64_t head_codes = 0;            // level path: codes of every query's scan order covered by the head launch (0 = none)
@@ -288,6 +290,9 @@ struct qadc_index {
     uint32_t mq_min_wgs = 4096;          // workgroups a multi-query launch should have at least (2 rounds of the chip)
     uint32_t mq_min_tiles = 4;           // ... but never fewer than this many 4 KiB tiles per workgroup
     int front_dist = 1;    // early levels also for the multi-GPU loop's batches (pre-scan injected)
+    uint32_t wgq_split_codes = 8192;    // a query is split over several workgroups only down to this many codes each
+    int wgq_poll = 1;      // ... and its completion is read from the result block, not from the event
+    int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
     int head_early = 1;    // the head launch joins the front stream (under the previous batch's long levels)
     int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
@@ -301,7 +306,7 @@ struct qadc_index {
     uint64_t wgq_max_codes = 1ull << 24; //   ... probing at most this many codes per query (estimate), or
     uint64_t wgq_small_codes = 1ull << 18;   // any batch probing at most this many codes per query
     uint32_t wgq_capacity = 4096;        // stream entries per query to start with
-    int wgq_split = 8;                   // at most this many workgroups per query (batches too small to fill the GPU)
+    int wgq_split = 12;                 // workgroups a small batch may spread one query's scan order over
     int head_level = 5;                  // level path: bound levels 0..head_level-1 (the first 512 Ki codes of every query) are
                                          // scanned by ONE launch of the query kernel in head mode instead of head_level dependent
                                          // level launches (0 = off): -5 % per step on a 125M-code shard, neutral at 1B
@@ -309,6 +314,7 @@ struct qadc_index {
     int table_form = 2;                  // float tables of qadc_search: 0 direct, 1 BLAS expansion, 2 the reference's nns_engine rule
     uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)
     DevBuf<PartDesc> d_partdesc;         // device partition table (qadc_index_finalize)
+    std::vector<PartDesc> h_partdesc;    // its host copy (a lone small query carries the descriptors it needs in its launch)
     uint32_t max_start_n = 0;
     uint64_t total_codes = 0;
     uint32_t max_part_n = 0;
@@ -895,7 +901,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     int G = 1;
     if (!s.dev_replay && nq * 2 <= 256) {
         G = std::min<int>(idx->wgq_split, 256 / nq);
-        G = (int)std::min<uint64_t>((uint64_t)G, s.wgq_codes / 16384);   // at least 16 Ki codes per workgroup
+        G = (int)std::min<uint64_t>((uint64_t)G, s.wgq_codes / idx->wgq_split_codes);   // at least wgq_split_codes codes per workgroup
         G = std::max(G, 1);
     }
     s.wgq_G = G;
@@ -948,7 +954,25 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     for (int i = 0; i < kSlots; ++i) alone = alone && (&idx->slot[i] == &s || !idx->slot[i].busy);
     alone = alone && !idx->pre_slot[0].busy && !idx->pre_slot[1].busy;
     hipStream_t st = idx->stream;
-    if (in_bytes) {
+    // A lone small query (the synchronous single-query call): its input — which partitions, their descriptors, the
+    // float tables — fits the kernel-argument segment and rides in the dispatch packet; no copy precedes the launch.
+    alignas(16) unsigned char inl[kInlineBytes];
+    size_t inl_bytes = 0, inl_off_parts = 0, inl_off_tables = 0;
+    if (alone && G > 1 && idx->wgq_inline && s.float_path && !s.device_tables && !s.assign_on_device) {
+        const size_t na = (size_t)nq * ma;
+        inl_off_parts = align16(sizeof(int32_t) * na);
+        inl_off_tables = align16(inl_off_parts + sizeof(PartDesc) * na);
+        const size_t total = inl_off_tables + nt * sizeof(float);
+        if (total <= kInlineBytes) {
+            for (size_t i = 0; i < na; ++i) {
+                reinterpret_cast<int32_t*>(inl)[i] = (int32_t)i;
+                std::memcpy(inl + inl_off_parts + sizeof(PartDesc) * i, &idx->h_partdesc[s.assign[i]], sizeof(PartDesc));
+            }
+            std::memcpy(inl + inl_off_tables, s.tables, nt * sizeof(float));
+            inl_bytes = total;
+        }
+    }
+    if (in_bytes && !inl_bytes) {
         if (alone) {
             HIPCHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, st));
         } else {                                            // never queue a copy behind the previous batch's kernels
@@ -992,7 +1016,12 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     A.nontemporal = idx->total_codes * (uint64_t)idx->cs > (200ull << 20);   // (same rule as the level path)
     A.G = G;
     if (idx->profile) HIPCHECK(prof_event(s, st));
-    HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st));
+    s.poll = alone && G > 1 && !s.dev_replay && !idx->profile && idx->wgq_poll;
+    if (s.poll)
+        for (int i = 0; i < nsub; ++i) s.h_qout[i].flags = 0;
+    A.inline_off_parts = (uint32_t)inl_off_parts;
+    A.inline_off_tables = (uint32_t)inl_off_tables;
+    HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st, inl_bytes ? inl : nullptr, inl_bytes));
     if (idx->profile) HIPCHECK(prof_event(s, st));
     if (s.dev_replay) {
         if (!alone) {
@@ -1154,7 +1183,24 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
         s.assign_on_device = false;
     }
     for (int attempt = 0; s.wgq; ++attempt) {                  // one workgroup per query: per-query stream capacity only
-        HIPCHECK(hipEventSynchronize(s.ev_done));
+        bool seen = false;
+        if (s.poll) {
+            // a lone small batch: the kernel's workgroups set the done bit of their records in the mapped result block as
+            // they finish; watching those spares the completion-signal path (end-of-kernel release, signal, wake-up).
+            // Bounded: a batch that takes longer is waited for the ordinary way.
+            const auto t_poll = std::chrono::steady_clock::now();
+            const int nsub = s.nq * s.wgq_G;
+            for (uint32_t spins = 0; !seen; ++spins) {
+                seen = true;
+                for (int i = 0; i < nsub && seen; ++i)
+                    seen = (reinterpret_cast<const volatile uint32_t*>(&s.h_qout[i].flags)[0] & 4u) != 0;
+                if (!seen && (spins & 63u) == 63u &&
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count() > 300e-6)
+                    break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) HIPCHECK(hipEventSynchronize(s.ev_done));
         uint64_t max_count = 0;
         bool cand_overflow = false;
         for (int q = 0; q < s.nq * s.wgq_G; ++q) {
@@ -1401,6 +1447,8 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     idx->cs = M / 2;
     idx->device = device_id;
     if (const char* e = std::getenv("QADC_WGQ")) idx->wgq = std::atoi(e);   // test hook: force (2) / forbid (0) the one-workgroup-per-query path
+    if (const char* e = std::getenv("QADC_WGQ_POLL")) idx->wgq_poll = std::atoi(e);     // test hooks for the lone-small-batch shortcuts
+    if (const char* e = std::getenv("QADC_WGQ_INLINE")) idx->wgq_inline = std::atoi(e);
     if (const char* e = std::getenv("QADC_HEAD_LEVEL")) idx->head_level = std::max(0, std::min(std::atoi(e), kMaxLevels - 1));   // test hook
     // The streaming launches fill every CU for milliseconds.  They go on the LOWEST-priority queue so that the
     // short work that must overlap them is dispatched as soon as a workgroup slot frees up instead of waiting for
@@ -1625,6 +1673,7 @@ int qadc_index_add_partition_synthetic_shard(qadc_index* idx, uint32_t global_n,
 int qadc_index_set_key_base(qadc_index* idx, int part, uint32_t key_base) {
     if (!idx || part < 0 || part >= (int)idx->parts.size()) return fail(QADC_E_ARG, "bad partition");
     idx->parts[part].key_base = key_base;
+    if (idx->finalized && (size_t)part < idx->h_partdesc.size()) idx->h_partdesc[part].key_base = key_base;
     if (idx->finalized && idx->d_partdesc.p) {                  // keep the device partition table in step
         if (int rc = use_device(idx)) return rc;
         HIPCHECK(hipMemcpy(reinterpret_cast<unsigned char*>(idx->d_partdesc.p + part) + offsetof(PartDesc, key_base), &key_base,
@@ -1651,7 +1700,8 @@ int qadc_index_finalize(qadc_index* idx, float keep) {
     }
     // device partition table for the one-workgroup-per-query kernel
     if (int rc = use_device(idx)) return rc;
-    std::vector<PartDesc> pd(idx->parts.size());
+    std::vector<PartDesc>& pd = idx->h_partdesc;
+    pd.assign(idx->parts.size(), PartDesc{});
     idx->max_start_n = 0;
     idx->total_codes = 0;
     idx->max_part_n = 0;
@@ -1695,6 +1745,9 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "wgs_per_item") idx->wgs_per_item = (int)value;
     else if (n == "overlap_front") idx->overlap_front = value != 0;
     else if (n == "head_early") idx->head_early = value != 0;
+    else if (n == "wgq_inline") idx->wgq_inline = value != 0;
+    else if (n == "wgq_poll") idx->wgq_poll = value != 0;
+    else if (n == "wgq_split_codes") idx->wgq_split_codes = (uint32_t)std::max(value, 1024.0);
     else if (n == "front_dist") idx->front_dist = value != 0;
     else if (n == "share_variant") idx->share_variant = (int)value;
     else if (n == "mq") idx->mq = value != 0;

@@ -130,11 +130,23 @@ struct QueryKernelArgs {
     CandHeader* hdr;
     int G;                   // workgroups per query (>= 1): the grid is nq * G, every output array is indexed by q * G + g;
                              // workgroup g scans the first block (bound only, g > 0) and the g-th chunk of the rest
+    // inline input (G > 1 only): assign / parts / ftables are NOT pointers the host filled in but live in the kernel-argument
+    // segment itself, behind this struct (QueryKernelInline::payload) — a single query's 1-2 KiB of input ride in the
+    // dispatch packet and no host-to-device copy precedes the launch.  payload = [i32 assign[nq*ma] = 0,1,2...]
+    // [PartDesc[nq*ma] of the probed partitions, at inline_off_parts][float tables, at inline_off_tables].
+    uint32_t inline_input, inline_off_parts, inline_off_tables;
+};
+
+constexpr size_t kInlineBytes = 3072;            // kernel arguments are limited to 4 KiB
+struct QueryKernelInline {
+    QueryKernelArgs a;
+    alignas(16) unsigned char payload[kInlineBytes];
 };
 
 size_t query_kernel_lds_bytes(int M);
 uint32_t query_kernel_lds_values(int M);       // pre-scan values a query may have before fvals is needed
-hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& args, hipStream_t stream);
+hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& args, hipStream_t stream,
+                             const void* inline_payload = nullptr, size_t inline_bytes = 0);
 // kv_binheap push replay of the ordered streams, 64 queries per wave (one lane each); R <= replay_lanes_max_R().
 uint32_t replay_lanes_max_R();
 hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,

@@ -30,6 +30,8 @@
 #include "qadc_kernels.h"
 
 #include <cfloat>
+#include <cstddef>
+#include <cstring>
 #include <type_traits>
 
 namespace qadc {
@@ -131,22 +133,43 @@ __device__ __forceinline__ UDesc q_load_desc(const PartDesc* __restrict__ parts,
     return d;
 }
 
-// Bound = smallest v such that at least R emitted candidates have value <= v, else 127 (wave 0, lanes own bins 2l, 2l+1).
+// Wave-wide scans and reductions on the DPP path (row shifts inside the 16-lane rows, then row broadcasts: 7 VALU
+// operations), not __shfl_*: those go through the LDS crossbar, ~100 cycles each in a dependent chain of six — the
+// epoch ends, the select passes and the write-out of a single small query are chains of exactly these.
+template <typename Op>
+__device__ __forceinline__ uint32_t q_wave_scan_bits(uint32_t x, uint32_t identity, Op op) {
+    const int id = (int)identity;
+    uint32_t v = x;
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x113, 0xf, 0xf, false));   // row_shr:3
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x114, 0xf, 0xe, false));   // row_shr:4, banks 1-3
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x118, 0xf, 0xc, false));   // row_shr:8, banks 2-3
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return v;                                                    // inclusive scan; lane 63 holds the reduction
+}
+__device__ __forceinline__ uint32_t q_wave_incl_sum(uint32_t x) {
+    return q_wave_scan_bits(x, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+}
+__device__ __forceinline__ uint32_t q_wave_sum(uint32_t x) {     // the wave's total, in every lane
+    return (uint32_t)__builtin_amdgcn_readlane((int)q_wave_incl_sum(x), 63);
+}
+__device__ __forceinline__ float q_wave_min(float x) {
+    const uint32_t r = q_wave_scan_bits(__float_as_uint(x), __float_as_uint(FLT_MAX),
+                                        [](uint32_t a, uint32_t b) { return __float_as_uint(fminf(__uint_as_float(a), __uint_as_float(b))); });
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)r, 63));
+}
+
+// Bound = smallest v such that at least R emitted candidates have value <= v, else 127 (lanes own bins 2l, 2l+1).
 __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint32_t R, uint32_t lane) {
     const uint32_t c0 = hist[2 * lane], c1 = hist[2 * lane + 1];
-    uint32_t incl = c0 + c1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += o;
-    }
+    const uint32_t incl = q_wave_incl_sum(c0 + c1);
     const uint32_t excl = incl - (c0 + c1);
-    uint32_t b = 127;
-    if (excl + c0 >= R) b = 2 * lane;
-    else if (incl >= R) b = 2 * lane + 1;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) b = min(b, (uint32_t)__shfl_xor(b, d, 64));
-    return min(b, 127u);
+    const uint64_t reached = __builtin_amdgcn_ballot_w64(incl >= R);
+    if (reached == 0) return 127u;
+    const uint32_t b = excl + c0 >= R ? 2 * lane : 2 * lane + 1;   // (meaningful in the first lane that reaches R)
+    return min((uint32_t)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(reached)), 127u);
 }
 
 // OCC = waves per SIMD the register budget is sized for: 8 = two workgroups per CU (64 VGPRs), 4 = one (128 VGPRs).
@@ -159,7 +182,7 @@ __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint
 //         counts in QueryState::hist[level 0] — so that ONE launch replaces a dependent chain of k0 short level
 //         launches; the later levels derive their bounds from it and sort_cands_kernel orders everything.
 template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD>
-__global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A) {
+__device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     using C = QCfg<M>;
     if (reinterpret_cast<uintptr_t>((q_lds_bytes_t)qsmem) != 0) __builtin_trap();   // the lookups use absolute LDS addresses
     constexpr int CS = C::CS, DW = C::DW, CPL = C::CPL;
@@ -188,10 +211,94 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     const uint32_t R = A.R;
 
     const uint64_t clk0 = __builtin_readcyclecounter();          // phase clocks (QueryOut::pad): 1/16 shader cycles
+#ifdef QADC_STAMPS
+    uint64_t stamps[16];
+#define STAMP(k) stamps[k] = __builtin_readcyclecounter()
+    for (int i_ = 0; i_ < 16; ++i_) stamps[i_] = clk0;
+#else
+#define STAMP(k) do {} while (0)
+#endif
     if (tid < 256) hist[tid] = 0;
     if (tid == 0) { s_nvals = 0; s_count = 0; }
     __syncthreads();
 
+    // ---- small batches (MULTI): a query's time is LATENCY — every ramp epoch of the walk below would wait out one
+    // memory round trip.  The codes a workgroup is going to walk first do not depend on the front at all: the first
+    // block (kFirstBlock vectors, the bound's ramp) and the first kResident vectors of the workgroup's own chunk are
+    // loaded into registers as soon as the pre-scan loop is through (prefetch() below), 8 / 12 loads per lane in flight
+    // under the select and the quantizer, and the walk starts from registers.  Only when they lie in the query's first probed partition as complete vectors of
+    // complete codes (a flat list, or a first partition of >= 4096 vectors); anything else takes the plain walk. ----
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4* gvec_t;
+    constexpr uint32_t kFirstBlock = 4096, kResident = M == 16 ? 4096 : 8192;   // (16x4: more would spill)
+    constexpr bool RES = MULTI && !HEAD;
+    u32x4 fb[RES ? kFirstBlock / kQWG : 1], cf[RES ? kResident / kQWG : 1];
+    uint64_t V_top = 0;
+    bool resident = false;
+    int a_res = 0;
+    uint32_t res_lo = 0, res_hi = 0;                             // vectors [res_lo, res_hi) of partition a_res are in cf[]
+    UDesc d_res{};
+    if constexpr (RES) {
+        auto part_of = [&](int a_) { return A.inline_input ? q * ma + a_ : assign[a_]; };   // (inline input: assign[] = 0, 1, 2 ...)
+        if (ma == 1) {                                           // a flat list: nothing to add up
+            V_top = (q_uni(parts[part_of(0)].n) + CPL - 1) / CPL;
+        } else {
+            uint32_t vmine = 0;
+            for (int a_ = tid; a_ < ma; a_ += kQWG) vmine += (parts[part_of(a_)].n + CPL - 1) / CPL;
+            vmine = q_wave_sum(vmine);
+            if (lane == 0) wcnt[wave] = vmine;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < kQWaves; ++w) V_top += wcnt[w];
+            __syncthreads();
+        }
+        while (a_res < ma && q_uni(parts[part_of(a_res)].n) == 0) ++a_res;
+        if (a_res < ma) {
+            d_res = q_load_desc(parts, (int)q_uni((uint32_t)part_of(a_res)));
+            const uint64_t B_ = min(V_top, (uint64_t)kFirstBlock);
+            const uint64_t chunk_ = ((V_top - B_ + G - 1) / G + 63) / 64 * 64;
+            const uint64_t lo_ = min(V_top, B_ + (uint64_t)g * chunk_), hi_ = min(V_top, lo_ + chunk_);
+            const uint32_t nfull0 = d_res.n / CPL;
+            resident = B_ == kFirstBlock && nfull0 >= kFirstBlock;
+            if (resident) {
+                res_lo = res_hi = (uint32_t)min(lo_, (uint64_t)nfull0);
+                if (lo_ < nfull0) res_hi = (uint32_t)min(min(hi_, (uint64_t)nfull0), lo_ + kResident);
+            }
+        }
+    }
+    STAMP(1);
+    auto prefetch = [&]() {
+        if constexpr (RES) {
+            if (resident) {
+                const gvec_t src0 = (gvec_t)(uintptr_t)d_res.codes;
+#pragma unroll
+                for (int j = 0; j < (int)(kFirstBlock / kQWG); ++j) fb[j] = src0[j * kQWG + tid];
+#pragma unroll
+                for (int j = 0; j < (int)(kResident / kQWG); ++j) {
+                    cf[j] = u32x4{0, 0, 0, 0};
+                    if (res_lo + j * kQWG + tid < res_hi) cf[j] = src0[res_lo + j * kQWG + tid];
+                }
+            }
+        }
+    };
+
+    // The record of a finished workgroup.  Small batches (RES): the host does not wait for the kernel's completion
+    // signal but polls the records in its mapped result block — the done bit (flags & 4) is stored last, alone, behind a
+    // system-scope release fence issued by this ONE lane after the workgroup barrier that follows the stream stores
+    // (the release is cumulative: it covers what the other lanes stored before the barrier; every lane fencing for
+    // itself costs 4 us, and merely waiting for the stores' acknowledgements is not enough — tried, the host then
+    // sometimes sees the bit before the entries).
+    auto publish = [&](QueryOut o) {
+        if constexpr (RES) {
+            const uint32_t fl = o.flags;
+            o.flags = 0;
+            A.qout[wgi] = o;
+            __threadfence_system();                              // ONE lane's release covers the workgroup's stores (see the caller)
+            __hip_atomic_store(&A.qout[wgi].flags, fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            A.qout[wgi] = o;
+        }
+    };
     float qmin = 0.0f, qmax = 0.0f;
     uint32_t flags = 0;
     if (A.ftables) {
@@ -203,8 +310,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             const PartDesc& d = parts[assign[a]];
             mine += d.global_n ? d.start_n : 0u;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+        mine = q_wave_sum(mine);
         if (lane == 0) wcnt[wave] = mine;
         __syncthreads();
         uint32_t total_starts = 0;
@@ -214,6 +320,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
         float* __restrict__ gvals = A.fvals + (size_t)wgi * A.fcap;
         __syncthreads();
 
+        STAMP(2);
         const int wpp = ma >= kQWaves ? 1 : kQWaves / ma;        // waves per probe
         const int pstride = kQWaves / wpp;                       // probes in flight
         float* mytab = wtab + wave * (M * 16);
@@ -271,9 +378,10 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             }
             if (wpp > 1) __syncthreads();                        // the hand-over slot is reused by the next round
         }
+        STAMP(3);
+        prefetch();                                              // in flight under the select and the quantizer
         // qmin = min over ALL ma tables (db_query_4.cpp:258)
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) lmin = fminf(lmin, __shfl_xor(lmin, d, 64));
+        lmin = q_wave_min(lmin);
         if (lane == 0) redf[wave] = lmin;
         __threadfence_block();
         __syncthreads();
@@ -281,6 +389,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
 #pragma unroll
         for (int w = 1; w < kQWaves; ++w) qmin = fminf(qmin, redf[w]);
 
+        STAMP(4);
         // ---- R-th smallest of the pre-scan values = tmp_bh.max() (db_query_4.cpp:259); FLT_MAX if fewer than R ----
         const uint32_t n = s_nvals;
         if (n < R) {
@@ -295,19 +404,32 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
                 const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (lo + 8));
                 for (uint32_t i = tid; i < n; i += kQWG) {
                     const uint32_t key = q_fkey(in_lds ? vals[i] : gvals[i]);
-                    if ((key & himask) == prefix) atomicAdd(&hist[(key >> lo) & 0xffu], 1u);
+                    if ((key & himask) == prefix) {
+                        // the first digit of float keys (sign + 7 exponent bits) puts almost every value into two or
+                        // three bins: lanes that share the leading lane's digit add ONE count per wave
+                        const uint32_t dg = (key >> lo) & 0xffu;
+                        bool counted = false;
+#pragma unroll
+                        for (int it = 0; it < 3; ++it) {
+                            if (!counted) {
+                                const uint32_t lead = q_uni(dg);
+                                if (dg == lead) {
+                                    const uint64_t same = __builtin_amdgcn_ballot_w64(true);
+                                    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u)) == 0)
+                                        atomicAdd(&hist[lead], (uint32_t)__popcll(same));
+                                    counted = true;
+                                }
+                            }
+                        }
+                        if (!counted) atomicAdd(&hist[dg], 1u);
+                    }
                 }
                 __syncthreads();
                 if (tid < 64) {                                  // wave 0: 4 bins per lane, pick the digit holding rank k
                     const uint32_t k = s_k;
                     const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
                     const uint32_t sum4 = c0 + c1 + c2 + c3;
-                    uint32_t incl = sum4;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t o = __shfl_up(incl, d, 64);
-                        if (tid >= (uint32_t)d) incl += o;
-                    }
+                    const uint32_t incl = q_wave_incl_sum(sum4);
                     const uint32_t excl = incl - sum4;
                     if (incl >= k && excl < k) {                 // exactly one lane
                         uint32_t run = excl, digit = 4 * tid;
@@ -325,6 +447,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             }
             qmax = q_funkey(s_prefix);
         }
+        STAMP(5);
         // ---- 2. qmin / clamp / QuantizerMAX (db_query_4.cpp:258-284, 37-71) ----
         if (qmin < 0) { qmin = 0; flags |= 2u; }
         if (qmax > 1e30f) flags |= 1u;
@@ -339,11 +462,16 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             else if (v >= qmax) o = 127;
             else o = (int8_t)(int)(A.quant_mode == 0 ? (v - qmin) / delta : (v - qmin) * scale);
             qt_all[i] = o;
+            if constexpr (RES) {                                 // the first probed partition's table: straight into LDS as well
+                if (resident && i / (M * 16) == a_res) tq[i % (M * 16)] = (unsigned char)o;
+            }
         }
         __threadfence_block();
         __syncthreads();
         if (tid < 256) hist[tid] = 0;                            // becomes the value histogram of the scan
         __syncthreads();
+    } else {
+        prefetch();
     }
 
     if (flags & 1u) {                                            // the reference prints a warning and exits: no scan
@@ -351,7 +479,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             QueryOut o;
             o.count = 0; o.reps = 0; o.flags = flags | 4u; o.out_off = (uint32_t)((size_t)wgi * A.cap);
             o.qmin = qmin; o.qmax = qmax; o.pad[0] = o.pad[1] = 0;
-            A.qout[wgi] = o;
+            publish(o);
         }
         return;
     }
@@ -370,8 +498,6 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     // (assign slot, position) with a bitonic network in the LDS the tables no longer need, expands the padding-lane
     // replays and writes the ordered stream.  Exactness does not depend on how the waves interleave: the bound of an
     // epoch is fixed before its first code is tested, and the order is restored by the sort.
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(1))) u32x4* gvec_t;
     constexpr int kRounds = U;                                   // loads per lane in flight
     constexpr uint32_t kEpochVec = 32768;                        // longest epoch (vectors): bounds how stale a bound gets
     uint32_t* hist_done = misc;                                  // [128] candidates of the finished epochs, by value
@@ -424,11 +550,12 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             V += (eff_n(n_, cb_) + CPL - 1) / CPL;
             cb_ += n_;
         }
+    } else if (RES) {
+        V = V_top;
     } else {
         uint32_t vmine = 0;
         for (int a_ = tid; a_ < ma; a_ += kQWG) vmine += (parts[assign[a_]].n + CPL - 1) / CPL;
-#pragma unroll
-        for (int dlt = 32; dlt >= 1; dlt >>= 1) vmine += __shfl_xor(vmine, dlt, 64);
+        vmine = q_wave_sum(vmine);
         if (lane == 0) wcnt[wave] = vmine;
         q_lds_barrier();
 #pragma unroll
@@ -438,7 +565,6 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     // Every workgroup walks the first block [0, B) to tighten its bound (only workgroup 0 emits from it), then its own
     // chunk of the rest.  The bound a workgroup uses for a code is the R-th smallest value of candidates from the
     // first block and from its own chunk before that code: a subset of the code's scan-order prefix, hence valid.
-    constexpr uint32_t kFirstBlock = 4096;
     const uint64_t B = MULTI ? min(V, (uint64_t)kFirstBlock) : 0;
     const uint64_t chunk = MULTI ? ((V - B + G - 1) / G + 63) / 64 * 64 : V;
     const uint64_t my_lo = min(V, B + (uint64_t)g * chunk), my_hi = min(V, my_lo + chunk);
@@ -448,10 +574,100 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
     int tables_of = -1;                                          // probe whose pair tables are in LDS
     if (tid == 0) s_dirty = 0;
     q_lds_barrier();
+    STAMP(7);
+    uint64_t lo1 = my_lo;                                        // where pass 1 of the plain walk starts
+    if constexpr (RES) {
+        if (resident) {
+            // the walk's first epochs, from the registers loaded at kernel entry: same epoch rule (a code is tested
+            // against the bound of the FINISHED epochs), tile t of the partition belongs to wave t mod 16
+            if (!A.ftables) {                                    // (float path: the quantizer staged this table already)
+                if (tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] = table_word(a_res);
+                q_lds_barrier();
+            }
+            write_tables();
+            q_lds_barrier();
+            tables_of = a_res;
+            STAMP(8);
+            const uint32_t dup_pos = d_res.first_pos + d_res.n == d_res.global_n ? d_res.n - 1u : 0xffffffffu;
+            const uint32_t dup_reps = (16u - d_res.global_n % 16u) % 16u;
+            const uint32_t key_base = d_res.key_base + d_res.first_pos;
+            auto proc = [&](const u32x4& v, uint32_t vec, bool do_emit) {
+                uint32_t dd[4] = {v.x, v.y, v.z, v.w};
+                // (opaque copy: keeps the compiler from hoisting the 16 lookup addresses of every resident vector
+                // out of the epoch loop, which would spill)
+                asm volatile("" : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]), "+v"(dd[3]));
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const uint32_t cv = min(q_pair_sum<M>(dd + c * DW, lane_lo, lane_hi), 127u);
+                    if (__builtin_expect(cv < bound, 0)) {
+                        const uint32_t p = vec * CPL + c;
+                        // one LDS atomic per wave, not per lane: while the bound is loose every code qualifies
+                        const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+                        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                        if (do_emit) {
+                            uint32_t base = 0;
+                            if (before == 0) base = atomicAdd(&s_ccount, (uint32_t)__popcll(act));
+                            const uint32_t slot = q_uni(base) + before;
+                            if (slot < A.ccap) {
+                                QCand qc;
+                                qc.key = d_res.labels ? d_res.labels[p] : key_base + p;
+                                qc.val_reps = cv | ((p == dup_pos ? dup_reps : 0u) << 8);
+                                qc.pos = p;
+                                qc.slot = (uint32_t)a_res;
+                                cands[slot] = qc;
+                            }
+                        } else if (before == 0) {
+                            atomicAdd(&s_dirty, 1u);
+                        }
+                        atomicAdd(&hist_cur[cv], 1u);
+                    }
+                }
+            };
+            auto end_epoch_r = [&]() {
+                q_lds_barrier();
+                const uint32_t cnt = s_ccount + s_dirty;
+                if (cnt != last_cnt && tid < 128) {
+                    hist_done[tid] += hist_cur[tid];
+                    hist_cur[tid] = 0;
+                }
+                q_lds_barrier();
+                if (cnt != last_cnt) {
+                    bound = q_uni(q_bound_from_hist(hist_done, R, lane));
+                    last_cnt = cnt;
+                }
+            };
+            for (uint32_t e_lo = 0; e_lo < kFirstBlock;) {       // the first block: bound only, unless this is workgroup 0
+                const uint32_t e_hi = e_lo + min(ramp, kFirstBlock - e_lo);
+                ramp *= 2u;
+#pragma unroll
+                for (int j = 0; j < (int)(kFirstBlock / kQWG); ++j) {
+                    const uint32_t vec = j * kQWG + tid;
+                    if (vec >= e_lo && vec < e_hi) proc(fb[j], vec, g == 0);
+                }
+                end_epoch_r();
+                e_lo = e_hi;
+            }
+            STAMP(9);
+#pragma unroll
+            for (int jj = 0; jj < (int)(kResident / kQWG); jj += 4) {    // this workgroup's chunk: epochs of 4096 vectors
+                if (res_lo + jj * kQWG < res_hi) {
+#pragma unroll
+                    for (int j = jj; j < jj + 4; ++j) {
+                        const uint32_t vec = res_lo + j * kQWG + tid;
+                        if (vec < res_hi) proc(cf[j], vec, true);
+                    }
+                    end_epoch_r();
+                }
+            }
+            STAMP(10);
+            ramp = max(ramp, 2u * kFirstBlock);
+            lo1 = max(my_lo, (uint64_t)res_hi);
+        }
+    }
     // pass 0: the first block [0, B) (bound only unless this is workgroup 0); pass 1: this workgroup's chunk.
     // (one loop body for both: inlining the walk twice doubles the register pressure of the hot loop)
-    for (int pass = (MULTI && B) ? 0 : 1; pass < 2; ++pass) {
-        const uint64_t lo = pass == 0 ? 0 : my_lo, hi = pass == 0 ? B : my_hi;
+    for (int pass = (MULTI && B && !(RES && resident)) ? 0 : ((RES && resident && lo1 >= my_hi) ? 2 : 1); pass < 2; ++pass) {
+        const uint64_t lo = pass == 0 ? 0 : lo1, hi = pass == 0 ? B : my_hi;
         const bool do_emit = pass == 1 || g == 0;
         uint64_t pbase = 0, cbase = 0;                           // vectors / codes of the scan order before partition a
         int a = HEAD ? 0 : next_part(-1);                        // (HEAD walks every slot: cbase counts empty-here partitions too)
@@ -641,10 +857,25 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             skey[i] = k;
         }
         q_lds_barrier();
+        STAMP(12);
         // bitonic network, wave-major ownership: wave w owns elements [w*chunk, (w+1)*chunk).  An exchange at distance
         // j < chunk stays inside one wave's elements and needs no workgroup barrier (LDS traffic of a wave is in order);
         // only the few steps with j >= chunk synchronise the workgroup: 10 barriers instead of 55 for 1024 elements.
+        constexpr uint32_t kRankSortMax = 512;
         const uint32_t chunk = max(64u, n2 / kQWaves);           // (fewer than 1024 elements: only the first n2/64 waves work)
+        if (ncand <= kRankSortMax) {
+            // few candidates (a small batch's workgroups): the network's ~n log^2 n dependent LDS round trips cost more
+            // than counting — entry e's place is the number of smaller keys (keys are distinct: they end in the index)
+            uint64_t* sorted = skey + kRankSortMax;              // (skey holds <= 512 entries here)
+            if (tid < ncand) {
+                const uint64_t mine = skey[tid];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < ncand; ++j) rank += skey[j] < mine ? 1u : 0u;   // same address in every lane: a broadcast read
+                sorted[rank] = mine;
+            }
+            q_lds_barrier();
+            if (tid < ncand) skey[tid] = sorted[tid];
+        } else
         for (uint32_t k = 2; k <= n2; k <<= 1)
             for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
                 const bool local = jj < chunk;
@@ -661,6 +892,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
                 else q_lds_barrier();
             }
         q_lds_barrier();
+        STAMP(13);
         // expand the padding-lane replays while writing: thread t owns sorted entries [4t, 4t+4)
         uint64_t pay[4];
         uint32_t mine = 0;
@@ -673,12 +905,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
                 mine += 1u + ((uint32_t)(pay[u] >> 40) & 15u);
             }
         }
-        uint32_t incl = mine;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const uint32_t o = __shfl_up(incl, dlt, 64);
-            if (lane >= (uint32_t)dlt) incl += o;
-        }
+        const uint32_t incl = q_wave_incl_sum(mine);
         if (lane == 63) wcnt[wave] = incl;
         q_lds_barrier();
         uint32_t wp = incl - mine;
@@ -698,7 +925,9 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
             }
         }
     }
+    STAMP(14);
     s_count = out_count;
+    if constexpr (RES) __syncthreads();                          // every lane's stream entries happen-before lane 0's release in publish()
     if (tid == 0) {
         QueryOut o;
         o.count = s_count;                                       // entries requested (replays included); > cap = overflow
@@ -708,15 +937,42 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A
         o.qmin = qmin;
         o.qmax = qmax;
         const uint64_t clk3 = __builtin_readcyclecounter();
+#ifdef QADC_STAMPS
+        if (blockIdx.x == 1) {
+            stamps[6] = clk1; stamps[11] = clk2; stamps[15] = clk3;
+            printf("STAMPS ncand=%u:", ncand);
+            for (int i_ = 1; i_ < 16; ++i_) printf(" %d:%llu", i_, (unsigned long long)(stamps[i_] - stamps[i_ - 1]));
+            printf("\n");
+        }
+#endif
         // phase clocks: pad[0] = (pre-scan + select + quantizer) >> 6 | (sort + ordered write) >> 6 << 16; pad[1] = scan >> 4
         o.pad[0] = (uint32_t)min((clk1 - clk0) >> 6, (uint64_t)0xffff) | ((uint32_t)min((clk3 - clk2) >> 6, (uint64_t)0xffff) << 16);
         o.pad[1] = (uint32_t)((clk2 - clk1) >> 4);
-        A.qout[wgi] = o;
+        publish(o);
         if (A.qstate_flags) {                                    // what replay_heap_lanes_kernel reads
             A.qstate_flags[4 * wgi + 0] = flags | 4u;
             A.qstate_flags[4 * wgi + 1] = s_count;
         }
     }
+}
+
+template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD>
+__global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A) {
+    scan_query_body<M, U, OCC, NT, MULTI, HEAD>(A);
+}
+
+// Small batches (G > 1): the same kernel with room for inline input behind its arguments (QueryKernelArgs::inline_input).
+template <int M, int U, int OCC, bool NT>
+__global__ __launch_bounds__(kQWG, OCC) void scan_query_inline_kernel(QueryKernelInline IA) {
+    QueryKernelArgs A = IA.a;
+    if (A.inline_input) {
+        // (read through the kernel-argument segment pointer: indexing IA.payload would copy the struct to scratch)
+        const unsigned char* ka = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(QueryKernelInline, payload);
+        A.assign = reinterpret_cast<const int32_t*>(ka);
+        A.parts = reinterpret_cast<const PartDesc*>(ka + A.inline_off_parts);
+        A.ftables = reinterpret_cast<float*>(const_cast<unsigned char*>(ka) + A.inline_off_tables);
+    }
+    scan_query_body<M, U, OCC, NT, true, false>(A);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -927,31 +1183,55 @@ static hipError_t launch_scan_query_nt(int nq, const QueryKernelArgs& args, hipS
     return hipGetLastError();
 }
 
+template <int M, int U, int OCC, bool NT>
+static hipError_t launch_scan_query_inline(int nq, const QueryKernelArgs& args, hipStream_t stream, const void* payload, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    static uint64_t done = 0;
+    const size_t lds = QCfg<M>::LDS_BYTES;
+    if (dev < 64 && !(done & (1ull << dev))) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_inline_kernel<M, U, OCC, NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done |= 1ull << dev;
+    }
+    QueryKernelInline ia;
+    ia.a = args;
+    ia.a.inline_input = payload ? 1u : 0u;
+    if (payload) std::memcpy(ia.payload, payload, bytes);
+    hipLaunchKernelGGL((scan_query_inline_kernel<M, U, OCC, NT>), dim3(nq * args.G), dim3(kQWG), lds, stream, ia);
+    return hipGetLastError();
+}
+
 template <int M, int U, int OCC>
-static hipError_t launch_scan_query_v(int nq, const QueryKernelArgs& args, hipStream_t stream) {
+static hipError_t launch_scan_query_v(int nq, const QueryKernelArgs& args, hipStream_t stream, const void* payload, size_t bytes) {
+    if (payload && (args.head_codes || args.G <= 1 || bytes > kInlineBytes)) return hipErrorInvalidValue;
     if (args.head_codes)
         return args.nontemporal ? launch_scan_query_nt<M, U, OCC, true, true, true>(nq, args, stream)
                                 : launch_scan_query_nt<M, U, OCC, false, true, true>(nq, args, stream);
-    if (args.G > 1)
-        return args.nontemporal ? launch_scan_query_nt<M, U, OCC, true, true>(nq, args, stream)
-                                : launch_scan_query_nt<M, U, OCC, false, true>(nq, args, stream);
+    if (args.G > 1)                                              // (small batches: one workgroup per CU at most, 128 VGPRs —
+                                                                 //  the walk's first 12 vectors per lane live in registers)
+        return args.nontemporal ? launch_scan_query_inline<M, U, 4, true>(nq, args, stream, payload, bytes)
+                                : launch_scan_query_inline<M, U, 4, false>(nq, args, stream, payload, bytes);
     return args.nontemporal ? launch_scan_query_nt<M, U, OCC, true, false>(nq, args, stream)
                             : launch_scan_query_nt<M, U, OCC, false, false>(nq, args, stream);
 }
 
 // variant = 64-vector tiles (16-byte loads per lane in flight) per wave and iteration: 0 -> 2 (default), 1 -> 3, 2 -> 4, 3 -> 6.
 // 16x4: two workgroups per CU (64 KiB of tables each); 32x4: one (128 KiB).
-hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& args, hipStream_t stream) {
+hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& args, hipStream_t stream,
+                             const void* inline_payload, size_t inline_bytes) {
     if (M == 16) {
-        if (variant == 1) return launch_scan_query_v<16, 3, QCfg<16>::OCC>(nq, args, stream);
-        if (variant == 2) return launch_scan_query_v<16, 4, QCfg<16>::OCC>(nq, args, stream);
-        if (variant == 3) return launch_scan_query_v<16, 6, 4>(nq, args, stream);   // one workgroup per CU, 128 VGPRs
-        return launch_scan_query_v<16, 2, QCfg<16>::OCC>(nq, args, stream);
+        if (variant == 1) return launch_scan_query_v<16, 3, QCfg<16>::OCC>(nq, args, stream, inline_payload, inline_bytes);
+        if (variant == 2) return launch_scan_query_v<16, 4, QCfg<16>::OCC>(nq, args, stream, inline_payload, inline_bytes);
+        if (variant == 3) return launch_scan_query_v<16, 6, 4>(nq, args, stream, inline_payload, inline_bytes);   // one workgroup per CU, 128 VGPRs
+        return launch_scan_query_v<16, 2, QCfg<16>::OCC>(nq, args, stream, inline_payload, inline_bytes);
     }
-    if (variant == 1) return launch_scan_query_v<32, 3, QCfg<32>::OCC>(nq, args, stream);
-    if (variant == 2) return launch_scan_query_v<32, 4, QCfg<32>::OCC>(nq, args, stream);
-    if (variant == 3) return launch_scan_query_v<32, 6, QCfg<32>::OCC>(nq, args, stream);
-    return launch_scan_query_v<32, 2, QCfg<32>::OCC>(nq, args, stream);
+    if (variant == 1) return launch_scan_query_v<32, 3, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
+    if (variant == 2) return launch_scan_query_v<32, 4, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
+    if (variant == 3) return launch_scan_query_v<32, 6, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
+    return launch_scan_query_v<32, 2, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
 }
 
 uint32_t replay_lanes_max_R() { return 288; }                    // R * 512 B of LDS per wave (<= 144 KiB)

@@ -13,14 +13,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "scanner_hip_demo")
 
 
-def build_demo():
+def _compile(src, exe):
+    """g++ -std=c++14 against the C-ABI library; written under a per-process name and renamed into place, so that
+    parallel test workers never execute (or overwrite) a half-linked binary."""
     libdir = os.path.join(ROOT, "quick-adc_amd")
     if not os.path.exists(os.path.join(libdir, "libqadc_hip.so")):
         import __graft_entry__
         __graft_entry__.build()
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror",
-                           os.path.join(ROOT, "tests", "cpp", "scanner_hip_demo.cpp"), "-o", EXE,
+    tmp = "%s.%d.tmp" % (exe, os.getpid())
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror", src, "-o", tmp,
                            "-L" + libdir, "-lqadc_hip", "-Wl,-rpath," + libdir])
+    os.replace(tmp, exe)
+
+
+
+def build_demo():
+    _compile(os.path.join(ROOT, "tests", "cpp", "scanner_hip_demo.cpp"), EXE)
 
 
 def test_scanner_hip_builds_as_cxx14():
@@ -86,13 +94,7 @@ DRIVER = os.path.join(ROOT, "tests", "cpp", "db_query_4_hip")
 
 
 def build_driver():
-    libdir = os.path.join(ROOT, "quick-adc_amd")
-    if not os.path.exists(os.path.join(libdir, "libqadc_hip.so")):
-        import __graft_entry__
-        __graft_entry__.build()
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror",
-                           os.path.join(ROOT, "tests", "cpp", "db_query_4_hip.cpp"), "-o", DRIVER,
-                           "-L" + libdir, "-lqadc_hip", "-Wl,-rpath," + libdir])
+    _compile(os.path.join(ROOT, "tests", "cpp", "db_query_4_hip.cpp"), DRIVER)
 
 
 def test_db_query_4_driver_builds_as_cxx14():
@@ -189,12 +191,7 @@ DIST_DEMO = os.path.join(ROOT, "tests", "cpp", "dist_demo")
 
 
 def build_dist_demo():
-    libdir = os.path.join(ROOT, "quick-adc_amd")
-    if not os.path.exists(os.path.join(libdir, "libqadc_hip.so")):
-        import __graft_entry__
-        __graft_entry__.build()
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "dist_demo.cpp"),
-                           "-o", DIST_DEMO, "-L" + libdir, "-lqadc_hip", "-Wl,-rpath," + libdir])
+    _compile(os.path.join(ROOT, "tests", "cpp", "dist_demo.cpp"), DIST_DEMO)
 
 
 def test_dist_demo_builds_as_cxx14():
