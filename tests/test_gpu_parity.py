@@ -1137,3 +1137,59 @@ def test_wgq_small_batches_split_a_query_over_several_workgroups(pyqadc, po, M, 
     assert heaps_equal(g1["heaps"][0], (w1["keys"], w1["values"]))
     idx.close()
     i2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 32])
+@pytest.mark.parametrize("inline,poll", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_wgq_lone_small_query_shortcuts_change_nothing(pyqadc, po, M, inline, poll):
+    """A lone small query takes three shortcuts: its input rides in the kernel arguments (wgq_inline), its first block
+    and the head of every workgroup's chunk are walked from registers loaded under the front, and the host reads its
+    completion from the mapped result block (wgq_poll).  Every combination, repeated with different tables on the same
+    slot (stale records / stale stream entries would show): heaps == oracle.  Shapes: a flat list whose first block and
+    chunks are fully register-resident, one whose chunks are longer than the resident part, one shorter than the
+    first block (plain walk), a sharded tail (padding-lane replays at the very end) and labels."""
+    rng = np.random.default_rng(900 + M + 2 * inline + poll)
+    keep, R = 0.05, 100                                        # (the shortest list still pre-scans more than R codes)
+    for n, labelled, split, split_codes in [(100000, False, 12, 8192), (400003, True, 6, 16384), (5000, False, 12, 1024),
+                                            (65536 + 7, True, 16, 4096)]:
+        codes = rand_codes(rng, n, M)
+        labels = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) if labelled else None
+        idx = pyqadc.Index(M)
+        idx.add_partitions([codes], [labels] if labelled else None)
+        idx.finalize(keep)
+        for k, v in (("wgq", 2), ("wgq_split", split), ("wgq_split_codes", split_codes), ("wgq_inline", inline), ("wgq_poll", poll)):
+            idx.set_option(k, v)
+        for rep in range(4):
+            t = float_tables(rng, 1, 1, M)
+            got = idx.query_scan(np.zeros((1, 1), np.int32), t.copy(), R, want_qtables=True)
+            want = po.query_scan(M, [codes], [labels] if labelled else None, keep, [0], t[0].copy(), R)
+            assert want["rc"] == 0 and np.array_equal(got["qtables"][0], want["qtables"])
+            assert heaps_equal(got["heaps"][0], (want["keys"], want["values"])), (n, rep)
+        idx.close()
+
+
+@pytest.mark.gpu
+def test_wgq_resident_walk_on_ivf_shapes(pyqadc, po):
+    """Small IVF batches: the register-resident start needs the first PROBED partition to hold the whole first block as
+    complete vectors; queries whose first probe is short, empty or ragged take the plain walk, in the same launch as
+    queries that qualify.  nq = 2 keeps the input inline (2 x 1 KiB tables would not fit with ma = 3: uploaded)."""
+    M, keep, R = 16, 0.02, 100
+    rng = np.random.default_rng(4242)
+    sizes = [9000, 0, 8191, 8192, 30011, 100, 24001]           # 8192 codes = exactly 4096 vectors: the smallest that qualifies
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(keep)
+    idx.set_option("wgq", 2)
+    idx.set_option("wgq_split_codes", 2048)
+    for assign in ([[3, 4, 6], [2, 4, 0]], [[1, 4, 5], [4, 3, 1]], [[0, 6, 4], [5, 0, 3]], [[6], [4]], [[3], [2]]):
+        a = np.array(assign, np.int32)
+        nq, ma = a.shape
+        t = float_tables(rng, nq, ma, M)
+        got = idx.query_scan(a, t.copy(), R)
+        for q in range(nq):
+            want = po.query_scan(M, parts, labels, keep, a[q], t[q].copy(), R)
+            assert want["rc"] == 0 and heaps_equal(got["heaps"][q], (want["keys"], want["values"])), (assign, q)
+    idx.close()
