@@ -296,6 +296,8 @@ typedef struct qadc_profile {
     uint64_t wgq_scan_cycles;  /* ... in the int8 scan */
     uint64_t wgq_sort_cycles;  /* ... and in the final candidate sort + ordered stream write */
     uint64_t head_launches;    /* level path: batches whose first bound levels were scanned by one head launch */
+    uint64_t group_launches;   /* large IVF batches that took the partition-major second phase ... */
+    uint64_t group_fallbacks;  /* ... and those of them whose candidate regions overflowed (redone on the level path) */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

@@ -158,6 +158,9 @@ struct Slot {
     DevBuf<float> d_ftables;            // float tables built on the device (qadc_search)
     DevBuf<int8_t> d_qtables;
     DevBuf<Cand> d_cands;
+    DevBuf<uint32_t> d_gplan;           // grouped second phase: [cnt K][fill K][goff K+1]
+    DevBuf<ScanItem> d_gitems;          // ... its device-planned ScanItem groups
+    bool wgq_grouped = false;           // the batch took the partition-major second phase
     DevBuf<float> d_fc;
 
     // one-workgroup-per-query path (qadc_query_kernel.hip): no planner, no levels, no sort
@@ -292,6 +295,8 @@ struct qadc_index {
     int front_dist = 1;    // early levels also for the multi-GPU loop's batches (pre-scan injected)
     uint32_t wgq_split_codes = 8192;    // a query is split over several workgroups only down to this many codes each
     int wgq_poll = 1;      // ... and its completion is read from the result block, not from the event
+    int wgq_group = 1;     // partition-major second phase for large IVF batches: 0 never, 1 auto, 2 whenever possible
+    int wgq_group_head = 4;   // ... after a head of this many probes per query (one workgroup per query)
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
     int head_early = 1;    // the head launch joins the front stream (under the previous batch's long levels)
     int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
@@ -1021,7 +1026,46 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         for (int i = 0; i < nsub; ++i) s.h_qout[i].flags = 0;
     A.inline_off_parts = (uint32_t)inl_off_parts;
     A.inline_off_tables = (uint32_t)inl_off_tables;
-    HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st, inl_bytes ? inl : nullptr, inl_bytes));
+    // Large IVF batches: a (query, probe) pair lands on a partition several other queries of the batch probe too.  The
+    // kernel then only walks the first probes of every query (head: front + a tight bound); the other pairs are
+    // regrouped by partition on the device and scanned 8 queries per pass (see launch_ivf_plan), and a third kernel
+    // orders every query's candidates into the stream layout the plain launch produces.
+    const int head_slots = std::min(idx->wgq_group_head, ma);
+    const size_t pairs = (size_t)nq * (size_t)(ma - head_slots);
+    const size_t nparts = idx->parts.size();
+    s.wgq_grouped = s.dev_replay && !s.dist_batch && G == 1 && pairs > 0 && nparts < (1u << 24) &&
+                    (idx->wgq_group == 2 || (idx->wgq_group == 1 && nq >= 256 && pairs >= 2 * nparts));
+    if (s.wgq_grouped) {
+        const size_t state_bytes = 64 + sizeof(QueryState) * (size_t)nq;
+        const size_t ngroups = ivf_max_groups(pairs, nparts);
+        if (ngroups * 8 >= (1ull << 31)) return fail(QADC_E_CAPACITY, "too many (query, probe) pairs for one batch");
+        HIPCHECK(s.d_state.ensure(state_bytes));
+        HIPCHECK(s.d_cands.ensure((size_t)nq * ccap));
+        HIPCHECK(s.d_gplan.ensure(3 * nparts + 1));
+        HIPCHECK(s.d_gitems.ensure(ngroups * 8));
+        s.d_hdr = reinterpret_cast<CandHeader*>(s.d_state.p);
+        s.d_qs = reinterpret_cast<QueryState*>(s.d_state.p + 64);
+        HIPCHECK(hipMemsetAsync(s.d_state.p, 0, state_bytes, st));
+        HIPCHECK(hipMemsetAsync(s.d_gplan.p, 0, sizeof(uint32_t) * (3 * nparts + 1), st));
+        HIPCHECK(hipMemsetAsync(s.d_gitems.p, 0, sizeof(ScanItem) * ngroups * 8, st));
+        launch_ivf_plan(A.assign, idx->d_partdesc.p, nq, ma, head_slots, (int)nparts, s.d_gplan.p, s.d_gplan.p + 2 * nparts,
+                        s.d_gplan.p + nparts, s.d_gitems.p, st);
+        QueryKernelArgs H = A;
+        H.head_codes = ~0ull;
+        H.head_slots = (uint32_t)head_slots;
+        H.qstates = s.d_qs;
+        H.cand_regions = s.d_cands.p;
+        H.cand_cap = ccap;
+        H.hdr = s.d_hdr;
+        H.G = 1;
+        HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));
+        const int wgs = (int)std::max<uint64_t>(1, ((uint64_t)idx->max_part_n + idx->mq_codes_per_wg - 1) / idx->mq_codes_per_wg);
+        launch_scan_i8_mq(M, s.d_gitems.p, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, ccap, (uint32_t)s.R, st);
+        HIPCHECK(launch_order_cands(s.d_qs, s.d_cands.p, ccap, ccap, nq, s.d_stream.p, cap, s.d_qout, s.d_qflags.p, st));
+        idx->prof.group_launches++;
+    } else {
+        HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st, inl_bytes ? inl : nullptr, inl_bytes));
+    }
     if (idx->profile) HIPCHECK(prof_event(s, st));
     if (s.dev_replay) {
         if (!alone) {
@@ -1211,6 +1255,8 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
             // some query emitted more candidates than a workgroup sorts in LDS (adversarial order, all-equal tables):
             // the level-structured path has the machinery for that (regrow, host sort) — run the batch through it
             idx->prof.regrows++;
+            if (s.wgq_grouped) idx->prof.group_fallbacks++;
+            s.wgq_grouped = false;
             s.wgq = false;
             s.wgq_G = 1;
             s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)s.nq * 8192u, 1ull << 30));
@@ -1449,6 +1495,7 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     if (const char* e = std::getenv("QADC_WGQ")) idx->wgq = std::atoi(e);   // test hook: force (2) / forbid (0) the one-workgroup-per-query path
     if (const char* e = std::getenv("QADC_WGQ_POLL")) idx->wgq_poll = std::atoi(e);     // test hooks for the lone-small-batch shortcuts
     if (const char* e = std::getenv("QADC_WGQ_INLINE")) idx->wgq_inline = std::atoi(e);
+    if (const char* e = std::getenv("QADC_WGQ_GROUP")) idx->wgq_group = std::max(0, std::min(std::atoi(e), 2));
     if (const char* e = std::getenv("QADC_HEAD_LEVEL")) idx->head_level = std::max(0, std::min(std::atoi(e), kMaxLevels - 1));   // test hook
     // The streaming launches fill every CU for milliseconds.  They go on the LOWEST-priority queue so that the
     // short work that must overlap them is dispatched as soon as a workgroup slot frees up instead of waiting for
@@ -1491,6 +1538,7 @@ int qadc_index_destroy(qadc_index* idx) {
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
         s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
         s.h_cands.release(); s.d_stream.release(); s.d_qflags.release(); s.d_fvals.release(); s.d_qcands.release(); s.h_fetch.release();
+        s.d_gplan.release(); s.d_gitems.release();
         if (s.ev_assign) (void)hipEventDestroy(s.ev_assign);
         s.d_queries.release(); s.d_assign.release(); s.d_cdist.release(); s.h_queries.release(); s.h_assign.release();
         if (s.ev_feed) (void)hipEventDestroy(s.ev_feed);
@@ -1746,6 +1794,8 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "overlap_front") idx->overlap_front = value != 0;
     else if (n == "head_early") idx->head_early = value != 0;
     else if (n == "wgq_inline") idx->wgq_inline = value != 0;
+    else if (n == "wgq_group") idx->wgq_group = (int)std::max(0.0, std::min(value, 2.0));
+    else if (n == "wgq_group_head") idx->wgq_group_head = (int)std::max(1.0, std::min(value, 4096.0));
     else if (n == "wgq_poll") idx->wgq_poll = value != 0;
     else if (n == "wgq_split_codes") idx->wgq_split_codes = (uint32_t)std::max(value, 1024.0);
     else if (n == "front_dist") idx->front_dist = value != 0;

@@ -2,6 +2,7 @@
 // Internal header (not part of the C-ABI; see include/qadc.h for that).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
 
 namespace qadc {
@@ -124,6 +125,7 @@ struct QueryKernelArgs {
     // head mode (level-structured path): scan only the first head_codes codes of every query's scan order with the int8
     // tables in `qtables`, emit Cand records / level-0 histogram counts like emit_candidate does (0 = normal mode)
     uint64_t head_codes;
+    uint32_t head_slots;     // head mode, other cut: walk the first head_slots probed partitions in full (head_codes = ~0)
     QueryState* qstates;
     Cand* cand_regions;      // [nq][cand_cap]
     uint32_t cand_cap;
@@ -147,6 +149,14 @@ size_t query_kernel_lds_bytes(int M);
 uint32_t query_kernel_lds_values(int M);       // pre-scan values a query may have before fvals is needed
 hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& args, hipStream_t stream,
                              const void* inline_payload = nullptr, size_t inline_bytes = 0);
+// Large IVF batches, partition-major second phase (qadc_query_kernel.hip): regroup the (query, probe) pairs of the
+// probes s0 .. ma-1 by partition into ScanItem groups of 8 for scan_i8_mq_kernel (d_cnt, d_fill: K zeroed counters;
+// d_goff: K + 1; d_items: zeroed, ivf_max_groups() * 8 entries), and order a query's Cand region into its push stream.
+inline size_t ivf_max_groups(size_t pairs, size_t K) { return pairs / 8 + std::min(pairs, K); }
+void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, int s0, int K, uint32_t* d_cnt,
+                     uint32_t* d_goff, uint32_t* d_fill, ScanItem* d_items, hipStream_t stream);
+hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uint32_t cand_cap, uint32_t ccap, int nq,
+                              uint64_t* d_stream, uint32_t cap, QueryOut* d_qout, uint32_t* d_qflags, hipStream_t stream);
 // kv_binheap push replay of the ordered streams, 64 queries per wave (one lane each); R <= replay_lanes_max_R().
 uint32_t replay_lanes_max_R();
 hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,

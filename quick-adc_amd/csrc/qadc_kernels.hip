@@ -396,6 +396,7 @@ __global__ __launch_bounds__(kMQWG, 4) void scan_i8_mq_kernel(
     const int nq = min(kMQ, nitems - first_item);            // queries of this group (>= 1)
     const ScanItem* __restrict__ its = items + first_item;
     const ScanItem it = its[0];                              // codes / n / pos0 / labels / key_base / dup_*: shared
+    if (it.n == 0) return;                                   // (device-planned launches are sized for the worst case: no such group)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     lds_base_is_zero();
 
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(kMQWG, 4) void scan_i8_mq_kernel(
 #pragma unroll
         for (int j = 0; j < kMQ; ++j) {
             uint16_t v = 0;
-            if (j < nq) v = (uint16_t)(uint8_t)qtables[(uint64_t)its[j].table * (M * 16) + e];
+            if (j < nq && its[j].n != 0) v = (uint16_t)(uint8_t)qtables[(uint64_t)its[j].table * (M * 16) + e];   // (n == 0: empty seat)
             row[j] = v;
         }
         *reinterpret_cast<u16x8*>(smem + e * 16) = row;     // little-endian: query j = field j&3 of u64 j>>2
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(kMQWG, 4) void scan_i8_mq_kernel(
     // ---- bounds: wave w computes queries w, w+4 (absent queries: 0 = nothing qualifies) ----
     for (int j = (int)wave; j < kMQ; j += kMQWG / 64) {
         uint32_t b = 0;
-        if (j < nq) b = prefix_bound_wave(qstates + its[j].query, its[j].order >> 16, R, lane);
+        if (j < nq && its[j].n != 0) b = prefix_bound_wave(qstates + its[j].query, its[j].order >> 16, R, lane);
         if (lane == 0) lbound[j] = b;
     }
     __syncthreads();

@@ -172,6 +172,96 @@ __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint
     return min((uint32_t)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(reached)), 127u);
 }
 
+// Orders one query's (one workgroup's) candidates by (assign slot, position) = scan order in LDS, expands the
+// padding-lane replays and writes the push stream: the tail of scan_query_kernel, and all of order_cands_kernel.
+// load(i) -> QCand of the i-th unordered candidate; needs ncand <= kQueryCandCap; returns the entries written
+// (replays included; entries beyond `cap` are counted, not stored).  Uses qsmem[0 .. 64 KiB) and wcnt[16].
+template <typename Load>
+__device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand, uint64_t* __restrict__ stream, uint32_t cap,
+                                                      uint32_t* wcnt, uint32_t tid, uint32_t lane, uint32_t wave) {
+    uint32_t out_count = 0;
+    uint64_t* skey = reinterpret_cast<uint64_t*>(qsmem);             // [n2] (slot << 44 | pos << 12 | index)
+    uint64_t* spay = reinterpret_cast<uint64_t*>(qsmem + 32768);     // [ncand] key | val << 32 | reps << 40 | slot << 48
+    uint32_t n2 = 64;
+    while (n2 < ncand) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += kQWG) {
+        uint64_t k = ~0ull;
+        if (i < ncand) {
+            const QCand c = load(i);
+            k = ((uint64_t)c.slot << 44) | ((uint64_t)c.pos << 12) | i;
+            spay[i] = (uint64_t)c.key | ((uint64_t)(c.val_reps & 0xfffu) << 32) | ((uint64_t)c.slot << 48);
+        }
+        skey[i] = k;
+    }
+    q_lds_barrier();
+    // bitonic network, wave-major ownership: wave w owns elements [w*chunk, (w+1)*chunk).  An exchange at distance
+    // j < chunk stays inside one wave's elements and needs no workgroup barrier (LDS traffic of a wave is in order);
+    // only the few steps with j >= chunk synchronise the workgroup: 10 barriers instead of 55 for 1024 elements.
+    constexpr uint32_t kRankSortMax = 512;
+    const uint32_t chunk = max(64u, n2 / kQWaves);           // (fewer than 1024 elements: only the first n2/64 waves work)
+    if (ncand <= kRankSortMax) {
+        // few candidates (a small batch's workgroups): the network's ~n log^2 n dependent LDS round trips cost more
+        // than counting — entry e's place is the number of smaller keys (keys are distinct: they end in the index)
+        uint64_t* sorted = skey + kRankSortMax;              // (skey holds <= 512 entries here)
+        if (tid < ncand) {
+            const uint64_t mine = skey[tid];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < ncand; ++j) rank += skey[j] < mine ? 1u : 0u;   // same address in every lane: a broadcast read
+            sorted[rank] = mine;
+        }
+        q_lds_barrier();
+        if (tid < ncand) skey[tid] = sorted[tid];
+    } else
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+        for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+            const bool local = jj < chunk;
+            if (!local) q_lds_barrier();
+            for (uint32_t r = 0; r < chunk; r += 64) {
+                const uint32_t i = wave * chunk + r + lane;
+                const uint32_t pi = i ^ jj;
+                if (i < n2 && pi > i) {
+                    const uint64_t x = skey[i], y = skey[pi];
+                    if ((x > y) == ((i & k) == 0)) { skey[i] = y; skey[pi] = x; }
+                }
+            }
+            if (local) q_wave_lds_sync();
+            else q_lds_barrier();
+        }
+    q_lds_barrier();
+    // expand the padding-lane replays while writing: thread t owns sorted entries [4t, 4t+4)
+    uint64_t pay[4];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t i = tid * 4u + u;
+        pay[u] = 0;
+        if (i < ncand) {
+            pay[u] = spay[skey[i] & 0xfffu];
+            mine += 1u + ((uint32_t)(pay[u] >> 40) & 15u);
+        }
+    }
+    const uint32_t incl = q_wave_incl_sum(mine);
+    if (lane == 63) wcnt[wave] = incl;
+    q_lds_barrier();
+    uint32_t wp = incl - mine;
+    for (uint32_t w = 0; w < kQWaves; ++w) {
+        const uint32_t c_ = wcnt[w];
+        if (w < wave) wp += c_;
+        out_count += c_;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t i = tid * 4u + u;
+        if (i < ncand) {
+            const uint32_t reps = 1u + ((uint32_t)(pay[u] >> 40) & 15u);
+            const uint64_t en = (pay[u] & 0xffffffffffull & ~(0xffull << 40)) | ((pay[u] >> 48) << 40);
+            for (uint32_t r = 0; r < reps; ++r, ++wp)
+                if (wp < cap) stream[wp] = en;
+        }
+    }
+    return out_count;
+}
+
 // OCC = waves per SIMD the register budget is sized for: 8 = two workgroups per CU (64 VGPRs), 4 = one (128 VGPRs).
 // NT = non-temporal code loads (lists that stream from HBM anyway); a database that fits the 256 MiB Infinity Cache
 // keeps the default policy and is re-read from the cache by every query.
@@ -475,6 +565,15 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     }
 
     if (flags & 1u) {                                            // the reference prints a warning and exits: no scan
+        if (HEAD) {
+            if (tid == 0 && g == 0) {
+                QueryState* qs = A.qstates + q;
+                qs->qmin = qmin;
+                qs->qmax = qmax;
+                qs->flags = flags & 3u;
+            }
+            return;
+        }
         if (tid == 0) {
             QueryOut o;
             o.count = 0; o.reps = 0; o.flags = flags | 4u; o.out_off = (uint32_t)((size_t)wgi * A.cap);
@@ -485,6 +584,8 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     }
 
     const uint64_t clk1 = __builtin_readcyclecounter();
+    // (HEAD with a slot limit: only the first head_slots probed partitions are walked; the front above covered all ma)
+    const int mas = (HEAD && A.head_slots) ? min(ma, (int)A.head_slots) : ma;
     // ---- 3. int8 scan in assign[] order: free-running waves, epochs, one in-workgroup sort at the end ----
     // The query's scan order is cut into EPOCHS: 64, 128, 256, ... vectors at the start (while the bound is loose),
     // then one epoch per probed partition (long partitions: one per kEpochVec vectors).  Inside an epoch the 16 waves
@@ -506,7 +607,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     QCand* __restrict__ cands = A.cands + (size_t)wgi * A.ccap;
     auto next_part = [&](int a_) {
         ++a_;
-        while (a_ < ma && q_uni(parts[assign[a_]].n) == 0) ++a_; // empty partition (db_query_4.cpp:291-293) / no local codes
+        while (a_ < mas && q_uni(parts[assign[a_]].n) == 0) ++a_; // empty partition (db_query_4.cpp:291-293) / no local codes
         return a_;
     };
     auto table_word = [&](int a_) -> uint32_t {
@@ -545,7 +646,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     uint64_t V = 0;
     if (HEAD) {
         uint64_t cb_ = 0;
-        for (int a_ = 0; a_ < ma && cb_ < A.head_codes; ++a_) {
+        for (int a_ = 0; a_ < mas && cb_ < A.head_codes; ++a_) {
             const uint32_t n_ = q_uni(parts[assign[a_]].n);
             V += (eff_n(n_, cb_) + CPL - 1) / CPL;
             cb_ += n_;
@@ -554,7 +655,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         V = V_top;
     } else {
         uint32_t vmine = 0;
-        for (int a_ = tid; a_ < ma; a_ += kQWG) vmine += (parts[assign[a_]].n + CPL - 1) / CPL;
+        for (int a_ = tid; a_ < mas; a_ += kQWG) vmine += (parts[assign[a_]].n + CPL - 1) / CPL;
         vmine = q_wave_sum(vmine);
         if (lane == 0) wcnt[wave] = vmine;
         q_lds_barrier();
@@ -671,7 +772,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         const bool do_emit = pass == 1 || g == 0;
         uint64_t pbase = 0, cbase = 0;                           // vectors / codes of the scan order before partition a
         int a = HEAD ? 0 : next_part(-1);                        // (HEAD walks every slot: cbase counts empty-here partitions too)
-        while (MULTI && a < ma) {                                // skip the partitions that end before lo
+        while (MULTI && a < mas) {                                // skip the partitions that end before lo
             const uint32_t n_ = q_uni(parts[assign[a]].n);
             const uint32_t nv = (eff_n(n_, cbase) + CPL - 1) / CPL;
             if (pbase + nv > lo) break;
@@ -679,7 +780,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
             cbase += n_;
             a = HEAD ? a + 1 : next_part(a);
         }
-        while (a < ma && (!MULTI || pbase < hi)) {
+        while (a < mas && (!MULTI || pbase < hi)) {
             UDesc d = q_load_desc(parts, (int)q_uni((uint32_t)assign[a]));
             const uint32_t n_full = d.n;
             if (HEAD) {
@@ -703,7 +804,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 tables_of = a;
             }
             const int a_next = HEAD ? a + 1 : next_part(a);
-            const bool more = !HEAD && a_next < ma && (!MULTI || pbase + nvec < hi);   // the walk continues in the next probed partition
+            const bool more = !HEAD && a_next < mas && (!MULTI || pbase + nvec < hi);   // the walk continues in the next probed partition
             const uint32_t tqv = more ? table_word(a_next) : 0u; // in flight during this partition's epochs
             const gvec_t src = (gvec_t)(uintptr_t)d.codes;
             const uint32_t dup_pos = (d.first_pos + n_full == d.global_n && n == n_full) ? n_full - 1u : 0xffffffffu;
@@ -834,7 +935,15 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
             a = a_next;
         }
     }
-    if (HEAD) return;                                            // the level path orders and reports
+    if (HEAD) {                                                  // the level path (or order_cands_kernel) orders and reports
+        if (A.ftables && tid == 0 && g == 0) {                   // front run here: its results travel in the QueryState
+            QueryState* qs = A.qstates + q;
+            qs->qmin = qmin;
+            qs->qmax = qmax;
+            qs->flags = flags & 3u;
+        }
+        return;
+    }
     // ---- 4. order the candidates: (assign slot, position) ascending = scan order ----
     const uint64_t clk2 = __builtin_readcyclecounter();
     __syncthreads();                                             // the candidate stores of every wave are complete
@@ -843,87 +952,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     if (ncand > A.ccap) {
         flags |= 32u;                                            // more candidates than the in-workgroup sort takes: host falls back
     } else if (ncand) {
-        uint64_t* skey = reinterpret_cast<uint64_t*>(qsmem);             // [n2] (slot << 44 | pos << 12 | index)
-        uint64_t* spay = reinterpret_cast<uint64_t*>(qsmem + 32768);     // [ncand] key | val << 32 | reps << 40 | slot << 48
-        uint32_t n2 = 64;
-        while (n2 < ncand) n2 <<= 1;
-        for (uint32_t i = tid; i < n2; i += kQWG) {
-            uint64_t k = ~0ull;
-            if (i < ncand) {
-                const QCand c = cands[i];
-                k = ((uint64_t)c.slot << 44) | ((uint64_t)c.pos << 12) | i;
-                spay[i] = (uint64_t)c.key | ((uint64_t)(c.val_reps & 0xfffu) << 32) | ((uint64_t)c.slot << 48);
-            }
-            skey[i] = k;
-        }
-        q_lds_barrier();
-        STAMP(12);
-        // bitonic network, wave-major ownership: wave w owns elements [w*chunk, (w+1)*chunk).  An exchange at distance
-        // j < chunk stays inside one wave's elements and needs no workgroup barrier (LDS traffic of a wave is in order);
-        // only the few steps with j >= chunk synchronise the workgroup: 10 barriers instead of 55 for 1024 elements.
-        constexpr uint32_t kRankSortMax = 512;
-        const uint32_t chunk = max(64u, n2 / kQWaves);           // (fewer than 1024 elements: only the first n2/64 waves work)
-        if (ncand <= kRankSortMax) {
-            // few candidates (a small batch's workgroups): the network's ~n log^2 n dependent LDS round trips cost more
-            // than counting — entry e's place is the number of smaller keys (keys are distinct: they end in the index)
-            uint64_t* sorted = skey + kRankSortMax;              // (skey holds <= 512 entries here)
-            if (tid < ncand) {
-                const uint64_t mine = skey[tid];
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < ncand; ++j) rank += skey[j] < mine ? 1u : 0u;   // same address in every lane: a broadcast read
-                sorted[rank] = mine;
-            }
-            q_lds_barrier();
-            if (tid < ncand) skey[tid] = sorted[tid];
-        } else
-        for (uint32_t k = 2; k <= n2; k <<= 1)
-            for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
-                const bool local = jj < chunk;
-                if (!local) q_lds_barrier();
-                for (uint32_t r = 0; r < chunk; r += 64) {
-                    const uint32_t i = wave * chunk + r + lane;
-                    const uint32_t pi = i ^ jj;
-                    if (i < n2 && pi > i) {
-                        const uint64_t x = skey[i], y = skey[pi];
-                        if ((x > y) == ((i & k) == 0)) { skey[i] = y; skey[pi] = x; }
-                    }
-                }
-                if (local) q_wave_lds_sync();
-                else q_lds_barrier();
-            }
-        q_lds_barrier();
-        STAMP(13);
-        // expand the padding-lane replays while writing: thread t owns sorted entries [4t, 4t+4)
-        uint64_t pay[4];
-        uint32_t mine = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = tid * 4u + u;
-            pay[u] = 0;
-            if (i < ncand) {
-                pay[u] = spay[skey[i] & 0xfffu];
-                mine += 1u + ((uint32_t)(pay[u] >> 40) & 15u);
-            }
-        }
-        const uint32_t incl = q_wave_incl_sum(mine);
-        if (lane == 63) wcnt[wave] = incl;
-        q_lds_barrier();
-        uint32_t wp = incl - mine;
-        for (uint32_t w = 0; w < kQWaves; ++w) {
-            const uint32_t c_ = wcnt[w];
-            if (w < wave) wp += c_;
-            out_count += c_;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = tid * 4u + u;
-            if (i < ncand) {
-                const uint32_t reps = 1u + ((uint32_t)(pay[u] >> 40) & 15u);
-                const uint64_t en = (pay[u] & 0xffffffffffull & ~(0xffull << 40)) | ((pay[u] >> 48) << 40);
-                for (uint32_t r = 0; r < reps; ++r, ++wp)
-                    if (wp < A.cap) stream[wp] = en;
-            }
-        }
+        out_count = q_order_and_write([&](uint32_t i) { return cands[i]; }, ncand, stream, A.cap, wcnt, tid, lane, wave);
     }
     STAMP(14);
     s_count = out_count;
@@ -973,6 +1002,121 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_inline_kernel(QueryKerne
         A.ftables = reinterpret_cast<float*>(const_cast<unsigned char*>(ka) + A.inline_off_tables);
     }
     scan_query_body<M, U, OCC, NT, true, false>(A);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large IVF batches, partition-major second phase.  A batch of 1024 queries x 32 probes lands ~8 times on each of
+// 4096 partitions: walking query by query reads (and looks up) every partition 8 times.  After the head launch
+// (scan_query_kernel in HEAD mode: front + the first head_slots probes of every query, which fixes a tight bound per
+// query) the remaining (query, probe) pairs are regrouped BY PARTITION on the device — count, offsets, scatter: three
+// small kernels, no host round trip — into groups of up to 8 pairs that share one pass of scan_i8_mq_kernel over the
+// partition (one LDS lookup serves 8 queries).  Every pair is bound level 1: its bound derives from the head's
+// candidates only, i.e. from codes that precede it in its query's scan order, whatever order the groups run in.
+// order_cands_kernel then restores scan order per query and hands the streams to replay_heap_lanes_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ivf_count_kernel(const int32_t* __restrict__ assign, const PartDesc* __restrict__ parts,
+                                                        int nq, int ma, int s0, uint32_t* __restrict__ cnt) {
+    const int per = ma - s0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * per) return;
+    const int q = i / per, a = s0 + i % per;
+    const int p = assign[(size_t)q * ma + a];
+    if (parts[p].n != 0) atomicAdd(&cnt[p], 1u);
+}
+
+// goff[p] = first group of partition p, goff[K] = groups in all; one workgroup
+__global__ __launch_bounds__(1024) void ivf_offsets_kernel(const uint32_t* __restrict__ cnt, int K, uint32_t* __restrict__ goff) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const int per = (K + 1023) / 1024;
+    const int lo = min(K, (int)tid * per), hi = min(K, lo + per);
+    uint32_t mine = 0;
+    for (int p = lo; p < hi; ++p) mine += (cnt[p] + 7u) / 8u;
+    const uint32_t incl = q_wave_incl_sum(mine);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - mine, total = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < wave) base += wsum[w];
+        total += wsum[w];
+    }
+    for (int p = lo; p < hi; ++p) {
+        goff[p] = base;
+        base += (cnt[p] + 7u) / 8u;
+    }
+    if (tid == 0) goff[K] = total;
+}
+
+// items must arrive zeroed: an item with n == 0 is an empty seat of its group (scan_i8_mq_kernel), a group whose first
+// seat is empty does not exist.  The seat order inside a partition is whatever the atomics give — the candidates are
+// ordered afterwards, so the result does not depend on it.
+__global__ __launch_bounds__(256) void ivf_scatter_kernel(const int32_t* __restrict__ assign, const PartDesc* __restrict__ parts,
+                                                          int nq, int ma, int s0, const uint32_t* __restrict__ goff,
+                                                          uint32_t* __restrict__ fill, ScanItem* __restrict__ items) {
+    const int per = ma - s0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * per) return;
+    const int q = i / per, a = s0 + i % per;
+    const int p = assign[(size_t)q * ma + a];
+    const PartDesc d = parts[p];
+    if (d.n == 0) return;
+    const uint32_t seat = atomicAdd(&fill[p], 1u);
+    ScanItem it;
+    it.codes = d.codes;
+    it.labels = d.labels;
+    it.n = d.n;
+    it.pos0 = 0;
+    it.key_base = d.key_base + d.first_pos;
+    it.table = (uint32_t)(q * ma + a);
+    it.query = (uint32_t)q;
+    it.order = (1u << 16) | (uint32_t)a;                         // bound level 1, assign slot a
+    it.dup_pos = d.first_pos + d.n == d.global_n ? d.n - 1u : 0xffffffffu;
+    it.dup_reps = (16u - d.global_n % 16u) % 16u;
+    items[(size_t)(goff[p] + seat / 8u) * 8u + seat % 8u] = it;
+}
+
+// One workgroup per query: the query's unordered Cand records (head + grouped pairs) -> ordered push stream in the
+// layout scan_query_kernel writes ([nq][cap] entries, QueryOut, {flags, entries} for the lane replay).
+__global__ __launch_bounds__(kQWG) void order_cands_kernel(const QueryState* __restrict__ qstates, const Cand* __restrict__ regions,
+                                                           uint32_t cand_cap, uint32_t ccap, uint64_t* __restrict__ stream,
+                                                           uint32_t cap, QueryOut* __restrict__ qout, uint32_t* __restrict__ qflags) {
+    __shared__ uint32_t wcnt[kQWaves];
+    const int q = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const QueryState* qs = qstates + q;
+    const uint32_t n = qs->count;
+    uint32_t flags = qs->flags & 3u, out_count = 0;
+    const Cand* __restrict__ region = regions + (size_t)q * cand_cap;
+    if (n > min(cand_cap, ccap)) {
+        flags |= 32u;                                            // more than the in-workgroup sort takes (or the region held): host falls back
+    } else if (n) {
+        out_count = q_order_and_write(
+            [&](uint32_t i) {
+                const Cand c = region[i];
+                QCand o;
+                o.key = c.key;
+                o.val_reps = (c.val & 0xffu) | (((c.order >> 20) & 15u) << 8);
+                o.pos = c.pos;
+                o.slot = c.order & 0x3fffu;
+                return o;
+            },
+            n, stream + (size_t)q * cap, cap, wcnt, tid, lane, wave);
+    }
+    if (tid == 0) {
+        QueryOut o;
+        o.count = out_count;
+        o.reps = 0;
+        o.flags = flags | 4u;
+        o.out_off = (uint32_t)((size_t)q * cap);
+        o.qmin = qs->qmin;
+        o.qmax = qs->qmax;
+        o.pad[0] = o.pad[1] = 0;
+        qout[q] = o;
+        if (qflags) {
+            qflags[4 * q + 0] = flags | 4u;
+            qflags[4 * q + 1] = out_count;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1232,6 +1376,32 @@ hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& 
     if (variant == 2) return launch_scan_query_v<32, 4, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
     if (variant == 3) return launch_scan_query_v<32, 6, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
     return launch_scan_query_v<32, 2, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
+}
+
+void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, int s0, int K, uint32_t* d_cnt,
+                     uint32_t* d_goff, uint32_t* d_fill, ScanItem* d_items, hipStream_t stream) {
+    const int pairs = nq * (ma - s0);
+    if (pairs <= 0) return;
+    hipLaunchKernelGGL(ivf_count_kernel, dim3((pairs + 255) / 256), dim3(256), 0, stream, d_assign, d_parts, nq, ma, s0, d_cnt);
+    hipLaunchKernelGGL(ivf_offsets_kernel, dim3(1), dim3(1024), 0, stream, d_cnt, K, d_goff);
+    hipLaunchKernelGGL(ivf_scatter_kernel, dim3((pairs + 255) / 256), dim3(256), 0, stream, d_assign, d_parts, nq, ma, s0, d_goff,
+                       d_fill, d_items);
+}
+
+hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uint32_t cand_cap, uint32_t ccap, int nq,
+                              uint64_t* d_stream, uint32_t cap, QueryOut* d_qout, uint32_t* d_qflags, hipStream_t stream) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    static uint64_t done = 0;
+    if (dev < 64 && !(done & (1ull << dev))) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&order_cands_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e != hipSuccess) return e;
+        done |= 1ull << dev;
+    }
+    hipLaunchKernelGGL(order_cands_kernel, dim3(nq), dim3(kQWG), 65536, stream, d_qs, d_regions, cand_cap, ccap, d_stream, cap,
+                       d_qout, d_qflags);
+    return hipGetLastError();
 }
 
 uint32_t replay_lanes_max_R() { return 288; }                    // R * 512 B of LDS per wave (<= 144 KiB)

@@ -43,7 +43,8 @@ class Profile(C.Structure):
                 ("host_heap_ms", C.c_double), ("host_sorted_queries", C.c_uint64), ("mq_launches", C.c_uint64),
                 ("pass_codes", C.c_uint64), ("wgq_launches", C.c_uint64), ("wgq_queries", C.c_uint64),
                 ("wgq_codes", C.c_uint64), ("wgq_ms", C.c_double), ("wgq_front_cycles", C.c_uint64),
-                ("wgq_scan_cycles", C.c_uint64), ("wgq_sort_cycles", C.c_uint64), ("head_launches", C.c_uint64)]
+                ("wgq_scan_cycles", C.c_uint64), ("wgq_sort_cycles", C.c_uint64), ("head_launches", C.c_uint64),
+                ("group_launches", C.c_uint64), ("group_fallbacks", C.c_uint64)]
 
 
 class QadcError(RuntimeError):

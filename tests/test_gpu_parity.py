@@ -1193,3 +1193,56 @@ def test_wgq_resident_walk_on_ivf_shapes(pyqadc, po):
             want = po.query_scan(M, parts, labels, keep, a[q], t[q].copy(), R)
             assert want["rc"] == 0 and heaps_equal(got["heaps"][q], (want["keys"], want["values"])), (assign, q)
     idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,nq,ma,head,big_first", [(16, 96, 8, 2, True), (16, 257, 12, 4, True), (32, 130, 6, 2, True),
+                                                    (16, 70, 5, 5, True), (16, 200, 16, 3, True), (16, 96, 8, 2, False)])
+def test_wgq_grouped_second_phase_matches_oracle(pyqadc, po, M, nq, ma, head, big_first):
+    """Large IVF batches walk only the first `head` probes of every query in the one-workgroup-per-query kernel; the
+    other (query, probe) pairs are regrouped by partition ON THE DEVICE and scanned 8 queries per pass, then every
+    query's candidates are ordered back into scan order.  Labelled partitions of very different sizes (empty, shorter
+    than a block, ragged), many queries per partition (groups of 8 with empty seats, partitions with several groups),
+    head == ma (no second phase at all): heaps == oracle for every query.  big_first = every query's first probe is a
+    long partition and later probes have larger distances (as residual tables do), so the head leaves a bound that
+    holds for the rest and the grouped result is what comes back.  Without it — short head, unrelated
+    random tables per probe — whole partitions fall below the head's bound, the candidate regions overflow and the
+    batch is redone on the level path (tested as well)."""
+    rng = np.random.default_rng(7000 + M + nq + ma)
+    sizes = [int(x) for x in rng.integers(1, 3000, 37)] + [0, 15, 16, 17, 40001, 0, 129, 30000, 25013, 36000]
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
+    keep, R = 0.05, 100
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(keep)
+    idx.set_option("wgq", 2)
+    idx.set_option("wgq_group", 2)
+    idx.set_option("wgq_group_head", head)
+    idx.set_option("profile", 1)
+    K = len(sizes)
+    big = [41, 44, 45, 46]
+    assign = np.stack([rng.permutation(K)[:ma] for _ in range(nq)]).astype(np.int32)
+    if big_first:
+        for q in range(nq):
+            b = big[q % 4]
+            assign[q] = [b] + [p for p in assign[q] if p != b][:ma - 1]
+    else:
+        assign[:, 0] = np.where(np.isin(assign[:, 0], [37, 42]), 40, assign[:, 0])   # (first probe never empty: enough starts for qmax)
+    assign[1] = assign[0]                                       # identical probe lists: shared groups all the way
+    tables = float_tables(rng, nq, ma, M)
+    if big_first:                                               # like real residual tables: farther centroids, larger distances
+        tables = np.ascontiguousarray(tables + np.float32(0.6) * np.arange(ma, dtype=np.float32)[None, :, None])
+    got = idx.query_scan(assign, tables.copy(), R, want_qtables=True)
+    prof = idx.profile()
+    assert prof["group_launches"] >= (1 if head < ma else 0)
+    if M == 16:                                                 # (the 32x4 case holds one candidate-heavy query: > 4096 entries on any path)
+        assert (prof["group_fallbacks"] > 0) == (not big_first)
+    for q in range(nq):
+        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
+        if want["rc"] != 0:
+            assert got["status"][q] == want["rc"]
+            continue
+        assert np.array_equal(got["qtables"][q], want["qtables"]), q
+        assert heaps_equal(got["heaps"][q], (want["keys"], want["values"])), q
+    idx.close()
