@@ -1074,6 +1074,8 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             // side streams alternately, so that a replay never waits for the previous batch's replay.
             if (!s.ev_scanned) HIPCHECK(hipEventCreateWithFlags(&s.ev_scanned, hipEventDisableTiming));
             HIPCHECK(hipEventRecord(s.ev_scanned, st));
+            // (a replay stream of its own per slot was tried: 1.2 -> 1.9 us per query at the IVF shape — more high-priority
+            // queues with long-running kernels get in the way of the front kernels' dispatch)
             st = ((&s - idx->slot) & 1) ? idx->front_stream : idx->sort_stream;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
         }

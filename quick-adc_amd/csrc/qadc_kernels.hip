@@ -9,6 +9,7 @@
 //
 // The op is a gather + byte add bound by HBM reads: no MFMA.
 #include "qadc_kernels.h"
+#include <cstdlib>
 
 #include <algorithm>
 #include <atomic>
@@ -1665,13 +1666,146 @@ __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restr
     }
 }
 
+// ---- large batches: the same arithmetic as two lean kernels ----
+// coarse_assign_kernel keeps a query group's K distances in registers (64 accumulators per lane at K = 4096) and reads
+// its centroid rows one row per lane.  Under the pipelined IVF batches that is the most expensive kernel of the front.
+// Here (1) coarse_dist_kernel computes [16 queries] x [256 centroids] distance tiles — centroid tiles staged through LDS
+// with 16-byte coalesced loads (the next tile's loads in flight), transposed so that lane k reads tile[d][k] without
+// bank conflicts, the 16 queries' components as LDS broadcasts, 16 accumulators per lane — into the [nq][K] scratch,
+// and (2) coarse_select_kernel picks the ma nearest per query.  Every (query, centroid) sum still accumulates
+// d = 0, 1, 2 ... in order, and the selection applies the same (distance, index) order: same assign[] bit for bit.
+constexpr int kCDQ = 16, kCDC = 32, kCDStride = 257;
+
+__device__ __forceinline__ uint32_t dpp_wave_min_u32(uint32_t x) {
+    uint32_t v = x;
+    const int id = -1;                                           // 0xffffffff: identity of min
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x113, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x114, 0xf, 0xe, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x118, 0xf, 0xc, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xa, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ __launch_bounds__(256) void coarse_dist_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
+                                                          int nq, int K, int dim, float* __restrict__ dist) {
+    __shared__ float tile[kCDC * kCDStride];                     // [d][centroid]
+    __shared__ __attribute__((aligned(16))) float qt[kCDC * kCDQ];   // [d][query]
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * 256, q0 = blockIdx.y * kCDQ;
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;           // this thread's float4s of a tile: rows lrow + 32p, columns lcol..lcol+3
+    float acc[kCDQ];
+#pragma unroll
+    for (int b = 0; b < kCDQ; ++b) acc[b] = 0.0f;
+    float4 pre[8];
+    float qpre[2];
+    auto fetch = [&](int d0) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int k = k0 + lrow + 32 * p, d = d0 + lcol;
+            pre[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (k < K && d < dim) pre[p] = *reinterpret_cast<const float4*>(coarse + (size_t)k * dim + d);   // (dim % 4 == 0)
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                            // the query chunk [16][32]: element (b, dd) = tid + 256 e
+            const int i = tid + 256 * e, b = i / kCDC, dd = i % kCDC;
+            const int q = min(q0 + b, nq - 1), d = d0 + dd;      // (a ragged last group repeats its last query)
+            qpre[e] = d < dim ? queries[(size_t)q * dim + d] : 0.0f;
+        }
+    };
+    fetch(0);
+    for (int d0 = 0; d0 < dim; d0 += kCDC) {
+        const int dcn = min(kCDC, dim - d0);
+        __syncthreads();                                         // the previous tile has been consumed
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int r = lrow + 32 * p;
+            tile[(lcol + 0) * kCDStride + r] = pre[p].x;
+            tile[(lcol + 1) * kCDStride + r] = pre[p].y;
+            tile[(lcol + 2) * kCDStride + r] = pre[p].z;
+            tile[(lcol + 3) * kCDStride + r] = pre[p].w;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = tid + 256 * e;
+            qt[(i % kCDC) * kCDQ + i / kCDC] = qpre[e];
+        }
+        __syncthreads();
+        if (d0 + kCDC < dim) fetch(d0 + kCDC);                   // in flight while this tile is consumed
+        for (int dd = 0; dd < dcn; ++dd) {
+            const float cv = tile[dd * kCDStride + tid];
+            float qv[kCDQ];
+#pragma unroll
+            for (int b4 = 0; b4 < kCDQ / 4; ++b4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(&qt[dd * kCDQ + 4 * b4]);   // same address in every lane: broadcast
+                qv[4 * b4] = t4.x; qv[4 * b4 + 1] = t4.y; qv[4 * b4 + 2] = t4.z; qv[4 * b4 + 3] = t4.w;
+            }
+#pragma unroll
+            for (int b = 0; b < kCDQ; ++b) {
+                const float t = qv[b] - cv;
+                acc[b] += t * t;
+            }
+        }
+    }
+    const int k = k0 + tid;
+    if (k < K)
+#pragma unroll
+        for (int b = 0; b < kCDQ; ++b)
+            if (q0 + b < nq) dist[(size_t)(q0 + b) * K + k] = acc[b];
+}
+
+// ma rounds of "smallest (distance, index) strictly after the previous pick" over a query's K distances (>= 0: their bit
+// patterns order like the values); one workgroup per query, KPT distances per lane in registers
+template <int KPT>
+__global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restrict__ dist, int K, int ma, int32_t* __restrict__ assign) {
+    __shared__ uint32_t rv[2][4], rk[2][4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    uint32_t mine[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int k = j * 256 + tid;
+        mine[j] = k < K ? __float_as_uint(dist[(size_t)q * K + k]) : 0xffffffffu;
+    }
+    uint32_t last_v = 0;
+    int last_k = -1, par = 0;
+    for (int a = 0; a < ma; ++a, par ^= 1) {
+        uint32_t bv = 0xffffffffu, bk = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t k = (uint32_t)(j * 256 + tid);
+            const uint32_t v = mine[j];
+            const bool after = v > last_v || (v == last_v && (int)k > last_k);
+            if (k < (uint32_t)K && after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
+        }
+        const uint32_t wv = dpp_wave_min_u32(bv);
+        const uint32_t wk = dpp_wave_min_u32(bv == wv ? bk : 0xffffffffu);
+        if ((tid & 63) == 0) { rv[par][tid >> 6] = wv; rk[par][tid >> 6] = wk; }
+        __syncthreads();                                         // (slots alternate: one barrier per round)
+        bv = rv[par][0];
+        bk = rk[par][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (rv[par][w] < bv || (rv[par][w] == bv && rk[par][w] < bk)) { bv = rv[par][w]; bk = rk[par][w]; }
+        last_v = bv;
+        last_k = (int)bk;
+        if (tid == 0) assign[(size_t)q * ma + a] = last_k;
+    }
+}
+
 void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
                           int32_t* d_assign, hipStream_t stream) {
     const int kpt = (K + 255) / 256;
     // large batches share every centroid row between 4 queries (registers: KPT x 4 distances per thread)
 #define QADC_CA(N, QB) hipLaunchKernelGGL((coarse_assign_kernel<N, QB>), dim3((nq + QB - 1) / QB), dim3(256), (size_t)QB * dim * sizeof(float), \
                                           stream, d_queries, d_coarse, nq, K, dim, ma, d_dist, d_assign)
-    if (nq >= 512) {
+    if (nq >= 256 && kpt <= 64 && ma <= K && dim % 4 == 0 && (reinterpret_cast<uintptr_t>(d_coarse) & 15) == 0 && d_dist) {
+        hipLaunchKernelGGL(coarse_dist_kernel, dim3(kpt, (nq + kCDQ - 1) / kCDQ), dim3(256), 0, stream, d_queries, d_coarse, nq, K, dim, d_dist);
+        if (kpt <= 4) hipLaunchKernelGGL(coarse_select_kernel<4>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
+        else if (kpt <= 16) hipLaunchKernelGGL(coarse_select_kernel<16>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
+        else hipLaunchKernelGGL(coarse_select_kernel<64>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
+    } else if (nq >= 512) {
         if (kpt <= 4) QADC_CA(4, 4);
         else if (kpt <= 16) QADC_CA(16, 4);
         else if (kpt <= 32) QADC_CA(32, 2);

@@ -1246,3 +1246,29 @@ def test_wgq_grouped_second_phase_matches_oracle(pyqadc, po, M, nq, ma, head, bi
         assert np.array_equal(got["qtables"][q], want["qtables"]), q
         assert heaps_equal(got["heaps"][q], (want["keys"], want["values"])), q
     idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,K,dim,ma", [(300, 700, 16, 9), (257, 4100, 48, 33), (1030, 256, 128, 16)])
+def test_coarse_assignment_of_large_batches_is_the_sequential_one(pyqadc, nq, K, dim, ma):
+    """Batches of >= 256 queries compute the coarse distances as [16 queries] x [256 centroids] tiles and select per
+    query in a second kernel; assign[] must be what the sequential host loop gives — squared L2 accumulated in
+    ascending d, the ma nearest in ascending (distance, index) order — including exact ties (duplicated centroids), a
+    ragged last query group, K not a multiple of 256 and dimensions that are not a multiple of the 32-wide tile."""
+    rng = np.random.default_rng(nq + K)
+    idx = pyqadc.Index(16)
+    idx.add_partitions([rand_codes(rng, 40, 16) for _ in range(K)])
+    idx.finalize(1.0)
+    idx.set_pq(rng.normal(size=(16, 16, dim // 16)).astype(np.float32))
+    coarse = rng.normal(size=(K, dim)).astype(np.float32)
+    coarse[5] = coarse[3]
+    coarse[K - 1] = coarse[K - 2]                               # exact ties, one of them in the last (partial) block
+    queries = rng.normal(size=(nq, dim)).astype(np.float32)
+    queries[7] = coarse[3]                                      # distance exactly 0, twice
+    idx.set_coarse(coarse)
+    got = idx.search(queries, ma, 30)["assign"]
+    for q in list(range(0, nq, 17)) + [7, nq - 1]:
+        d = _seq_sqdist(queries[q][None, :], coarse)
+        want = np.lexsort((np.arange(K), d))[:ma]
+        assert np.array_equal(got[q], want), q
+    idx.close()
