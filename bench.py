@@ -368,7 +368,7 @@ def ivf_leg(local_rank):
             nc += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
         return time.perf_counter() - t0, nc
 
-    steps, depth = 16, 3
+    steps, depth = 16, int(os.environ.get("QADC_BENCH_IVF_DEPTH", 4))          # all four submission slots of the C-ABI in use
     dt, ncodes = pipelined(qs, steps, depth)
     p = idx.profile()
     qs2 = [rng.normal(size=(2 * NQB, dim)).astype(np.float32) for _ in range(4)]       # and at twice the batch size

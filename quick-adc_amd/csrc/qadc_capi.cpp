@@ -296,6 +296,7 @@ struct qadc_index {
     int front_dist = 1;    // early levels also for the multi-GPU loop's batches (pre-scan injected)
     uint32_t wgq_split_codes = 8192;    // a query is split over several workgroups only down to this many codes each
     int wgq_poll = 1;      // ... and its completion is read from the result block, not from the event
+    int group_strikes = 0; // grouped batches whose candidate regions overflowed (data whose later probes fall below the head's bound)
     int wgq_group = 1;     // partition-major second phase for large IVF batches: 0 never, 1 auto, 2 whenever possible
     int wgq_group_head = 4;   // ... after a head of this many probes per query (one workgroup per query)
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
@@ -1035,7 +1036,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     const size_t pairs = (size_t)nq * (size_t)(ma - head_slots);
     const size_t nparts = idx->parts.size();
     s.wgq_grouped = s.dev_replay && !s.dist_batch && G == 1 && pairs > 0 && nparts < (1u << 24) &&
-                    (idx->wgq_group == 2 || (idx->wgq_group == 1 && nq >= 256 && pairs >= 2 * nparts));
+                    (idx->wgq_group == 2 || (idx->wgq_group == 1 && idx->group_strikes < 2 && nq >= 256 && pairs >= 2 * nparts));
     if (s.wgq_grouped) {
         const size_t state_bytes = 64 + sizeof(QueryState) * (size_t)nq;
         const size_t ngroups = ivf_max_groups(pairs, nparts);
@@ -1259,7 +1260,10 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
             // some query emitted more candidates than a workgroup sorts in LDS (adversarial order, all-equal tables):
             // the level-structured path has the machinery for that (regrow, host sort) — run the batch through it
             idx->prof.regrows++;
-            if (s.wgq_grouped) idx->prof.group_fallbacks++;
+            if (s.wgq_grouped) {
+                idx->prof.group_fallbacks++;
+                idx->group_strikes++;                            // (auto mode gives the second phase up after two such batches)
+            }
             s.wgq_grouped = false;
             s.wgq = false;
             s.wgq_G = 1;
@@ -1798,7 +1802,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "overlap_front") idx->overlap_front = value != 0;
     else if (n == "head_early") idx->head_early = value != 0;
     else if (n == "wgq_inline") idx->wgq_inline = value != 0;
-    else if (n == "wgq_group") idx->wgq_group = (int)std::max(0.0, std::min(value, 2.0));
+    else if (n == "wgq_group") { idx->wgq_group = (int)std::max(0.0, std::min(value, 2.0)); idx->group_strikes = 0; }
     else if (n == "wgq_group_head") idx->wgq_group_head = (int)std::max(1.0, std::min(value, 4096.0));
     else if (n == "wgq_poll") idx->wgq_poll = value != 0;
     else if (n == "wgq_split_codes") idx->wgq_split_codes = (uint32_t)std::max(value, 1024.0);
