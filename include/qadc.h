@@ -97,6 +97,8 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * "wgq_small_codes", "wgq_capacity", "wgq_cand_cap", "wgq_variant", "wgq_split" / "wgq_split_codes" (workgroups a
  * small batch spreads one query over / codes each keeps at least), "wgq_inline" (a lone small query's input rides
  * in the kernel arguments), "wgq_poll" (... and its completion is read from the mapped result block),
+ * "wgq_group" (large IVF batches: partition-major second phase; 0 never, 1 auto, 2 whenever possible),
+ * "wgq_group_head" (probes per query the one-workgroup-per-query head walks before it),
  * "head_level", "table_form", "dist_cap_entries", "dist_device_nq". */
 int qadc_set_option(qadc_index* idx, const char* name, double value);
 
