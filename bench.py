@@ -251,6 +251,9 @@ def pmc_traffic_in_run(M, N):
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__), "--pmc-leg"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            for line in r.stdout.decode(errors="replace").splitlines():      # the leg's own launch / code counters
+                if line.startswith("{") and "pmc_leg" in line:
+                    got["leg"] = json.loads(line)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode()[-300:])
@@ -267,8 +270,15 @@ def pmc_traffic_in_run(M, N):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     (fk, fl), (wk, wl) = got["FETCH_SIZE"], got["WRITE_SIZE"]
-    return {"bytes_per_launch": fk * 1024 * 2 / fl + wk * 1024 / wl, "launches": fl,
-            "fetch_kb_total": fk, "write_kb_total": wk}, "in-run rocprofv3 --pmc passes"
+    leg = got.get("leg")
+    if not leg or leg.get("scan_launches") != fl or not leg.get("scan_codes"):
+        return None, "the PMC leg's launch count (%s) does not match the counter file's (%d)" % (leg and leg.get("scan_launches"), fl)
+    # per launch like `achieved`, but the leg's launches are not the timed region's (sequential lone queries keep their
+    # short levels on the main stream): the comparable figure is bytes over the ALGORITHMIC bytes of the same launches
+    total = fk * 1024 * 2 + wk * 1024
+    alg_leg = float(leg["scan_codes"]) * (M // 2)
+    return {"bytes_per_launch_of_the_pmc_leg": total / fl, "launches": fl, "fetch_kb_total": fk, "write_kb_total": wk,
+            "algorithmic_bytes_of_those_launches": alg_leg, "traffic_over_algorithmic": total / alg_leg}, "in-run rocprofv3 --pmc passes"
 
 
 def pmc_traffic_from_profiles(M, N, alg_bytes_per_launch):
@@ -680,7 +690,7 @@ def main():
             sprof, sdt = single_query_leg(idx, M, N, pool, nsingle)
             alg = sprof["scan_codes"] * cs / max(sprof["scan_launches"], 1)
             if pmc is not None:
-                traffic, tsrc = pmc["bytes_per_launch"], pmc_src
+                traffic, tsrc = pmc["traffic_over_algorithmic"] * alg, pmc_src + " (ratio of the same launches x this region's bytes per launch)"
             else:
                 traffic, tsrc2 = pmc_traffic_from_profiles(M, N, alg)
                 tsrc = "%s; %s" % (pmc_src, tsrc2)
