@@ -48,7 +48,9 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
                 front_run_max=int(rng.choice([0, 4096, 8 << 20])), device_replay_nq=int(rng.choice([0, 1, 1])),
                 # one-workgroup-per-query path: workgroups per query, kernel variant, tiny stream / candidate capacities
                 wgq_split=int(rng.choice([1, 3, 8])), wgq_variant=int(rng.choice([0, 1, 2, 3])),
-                wgq_capacity=int(rng.choice([64, 4096])), wgq_cand_cap=int(rng.choice([64, 4096, 4096])))
+                wgq_capacity=int(rng.choice([64, 4096])), wgq_cand_cap=int(rng.choice([64, 4096, 4096])),
+                # partition-major second phase of device-replayed batches (with its overflow fallback), head length
+                wgq_group=int(rng.choice([0, 2, 2])), wgq_group_head=int(rng.choice([1, 2, 4])))
     for k, v in opts.items():
         idx.set_option(k, v)
     tables = float_tables(rng, nq, ma, M, scale=float(rng.choice([0.2, 1.0])))
