@@ -2356,9 +2356,8 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         d.h_src.p[q] = qs.out_off;
         d.h_src.p[nq + q] = ordered ? qs.count + qs.reps : 0u;
         d.h_src.p[2 * nq + q] = qs.flags;
-        if (!ordered && !(qs.flags & 1u))
-            return fail(QADC_E_CAPACITY, "a query was not ordered on the device (more than 16384 candidates): not supported by "
-                                         "the native merge; use the stream interface");
+        // (a query that was not ordered on the device — more than 16384 candidates — is not supported by the native merge;
+        // it is reported AFTER the gather, from the headers every rank sees, so that all ranks leave the collective alike)
     }
     if (extra_n) {
         HIPCHECK(d.h_extra.ensure(extra_n));
