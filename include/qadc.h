@@ -214,6 +214,22 @@ int qadc_pq_encode(int M, int dim, const float* codebooks, const void* d_vectors
 int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vectors, uint64_t n, uint8_t* codes,
                         int device_id);
 
+/* N4, the rest of the build path (host buffers in and out, any device).
+ * qadc_ivf_encode_host = the compute of index_db::add_vectors (databases.hpp:270-298) / flat_db::add_vectors (136-156):
+ *   nearest coarse centroid per vector (K > 0; squared L2 in ascending d, lowest index on ties — find_k_neighbors with
+ *   k = 1), residual, optional OPQ rotation rotated[r] = sum_c x[c] * rotation[r][c] (quantizers.hpp:289-301; rotation
+ *   [dim][dim] or NULL), PQ encode (quantizers.hpp:222-245).  assign_out [n] (nullable; untouched when K == 0),
+ *   codes [n][M/2].  The caller dispatches (assign, code, label = index + offset) to its partitions in vector order
+ *   like databases.hpp:291-297 (host/db_build.hpp does).
+ * qadc_kmeans_iterations_host = kmeans_fast_iterations_thread (databases.cpp:50-90): `iters` rounds of assign-to-nearest
+ *   + centroid = (sum of the members in ascending vector order) / count (an empty cluster becomes NaN like the
+ *   reference's 0/0); centroids [K][dim] in and out.  The reference seeds these iterations with two OpenCV
+ *   k-means++ iterations (databases.cpp:96-113) — third-party, not restated: the caller provides the seed. */
+int qadc_ivf_encode_host(int M, int dim, const float* codebooks, const float* rotation, int K, const float* coarse,
+                         const float* vectors, uint64_t n, int32_t* assign_out, uint8_t* codes, int device_id);
+int qadc_kmeans_iterations_host(const float* vectors, uint64_t n, int dim, int K, float* centroids, int iters,
+                                int32_t* assign_out, int device_id);
+
 /* Host-only helper (no GPU involved): push (keys[i], vals[i]), i = 0..n-1, in order into an empty
  * heap of capacity R with kv_binheap<unsigned,int8_t>::push semantics (binheap.hpp:75-116), after
  * an optional (0,127) sentinel (db_query_4.cpp:276), and return the heap arrays.  This is the

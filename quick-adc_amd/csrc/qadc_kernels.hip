@@ -1928,6 +1928,91 @@ void launch_pq_encode(const float* d_vectors, uint64_t n, int M, int dim, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Database build.  index_db::add_vectors (databases.hpp:270-298): nearest coarse centroid
+// (coarse_dist_kernel + coarse_select_kernel with ma = 1), then per vector the residual x - centroid and, for OPQ, the
+// rotation rotated[r] = sum_c x[c] * rotation[r][c] (quantizers.hpp:289-301) in sequential float sums — the same loops as
+// build_tables_kernel and host/query_driver.hpp — and pq_encode_kernel on the result.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void residual_rotate_kernel(const float* __restrict__ vectors, uint64_t n, int dim,
+                                                              const float* __restrict__ coarse, const int32_t* __restrict__ assign,
+                                                              const float* __restrict__ rotation, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    float* res = reinterpret_cast<float*>(dyn);                  // [dim] residual of this workgroup's vector
+    for (uint64_t v = blockIdx.x; v < n; v += gridDim.x) {
+        const float* __restrict__ x = vectors + v * dim;
+        const float* __restrict__ c = coarse ? coarse + (size_t)assign[v] * dim : nullptr;
+        __syncthreads();
+        for (int d = threadIdx.x; d < dim; d += 256) res[d] = c ? x[d] - c[d] : x[d];
+        __syncthreads();
+        for (int r = threadIdx.x; r < dim; r += 256) {
+            float o = res[r];
+            if (rotation) {
+                const float* __restrict__ row = rotation + (size_t)r * dim;
+                o = 0.0f;
+                for (int cc = 0; cc < dim; ++cc) o += res[cc] * row[cc];
+            }
+            out[v * dim + r] = o;
+        }
+    }
+}
+
+void launch_residual_rotate(const float* d_vectors, uint64_t n, int dim, const float* d_coarse, const int32_t* d_assign,
+                            const float* d_rotation, float* d_out, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(residual_rotate_kernel, dim3((unsigned)std::min<uint64_t>(n, 65536)), dim3(256), (size_t)dim * sizeof(float),
+                       stream, d_vectors, n, dim, d_coarse, d_assign, d_rotation, d_out);
+}
+
+// kmeans_fast_iterations_thread's centroid update (databases.cpp:67-88): centroid = (sum of its members, added in
+// ascending vector order) / member count; an empty cluster divides 0 by 0 like the reference does.  One workgroup per
+// centroid walks assign[] in order, compacts the members of every 256-vector chunk IN ORDER (ballot + prefix) and
+// lets its lanes (one per component) add them sequentially: the float sums are those of the sequential host loop.
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restrict__ vectors, uint64_t n, int dim,
+                                                            const int32_t* __restrict__ assign, float* __restrict__ centroids) {
+    __shared__ uint32_t members[256];
+    __shared__ uint32_t wcount[4];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kMaxPer = 8;                                   // components per lane (dim <= 2048)
+    float acc[kMaxPer];
+#pragma unroll
+    for (int j = 0; j < kMaxPer; ++j) acc[j] = 0.0f;
+    uint32_t count = 0;
+    for (uint64_t base = 0; base < n; base += 256) {
+        const uint64_t i = base + tid;
+        const bool mine = i < n && assign[i] == c;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+        if (lane == 0) wcount[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)), total = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) before += wcount[w];
+            total += wcount[w];
+        }
+        if (mine) members[before] = (uint32_t)(i - base);
+        __syncthreads();
+        for (uint32_t k = 0; k < total; ++k) {
+            const float* __restrict__ x = vectors + (base + members[k]) * dim;
+#pragma unroll
+            for (int j = 0; j < kMaxPer; ++j) {
+                const int d = tid + 256 * j;
+                if (d < dim) acc[j] += x[d];
+            }
+        }
+        count += total;
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxPer; ++j) {
+        const int d = tid + 256 * j;
+        if (d < dim) centroids[(size_t)c * dim + d] = acc[j] / (float)(int)count;
+    }
+}
+
+void launch_kmeans_update(const float* d_vectors, uint64_t n, int dim, int K, const int32_t* d_assign, float* d_centroids,
+                          hipStream_t stream) {
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(K), dim3(256), 0, stream, d_vectors, n, dim, d_assign, d_centroids);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic codes: word w (8 code bytes) = splitmix64(seed ^ splitmix64(w)), little endian.
 // Same function as orc_fill_codes in the oracle, so any sub-range is reproducible on the CPU.
 // ---------------------------------------------------------------------------------------------

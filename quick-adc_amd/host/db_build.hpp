@@ -1,0 +1,92 @@
+// Database build on the GPU — C++14, header only, calls the C-ABI (include/qadc.h).
+//
+//   add_vectors_hip(flat_database&, ...)   flat_db::add_vectors  (databases.hpp:136-156)
+//   add_vectors_hip(ivf_database&, ...)    index_db::add_vectors (databases.hpp:270-298): the device does the compute
+//                                          (nearest centroid, residual, OPQ rotation, PQ encode: qadc_ivf_encode_host),
+//                                          the host dispatches codes and labels to the partitions in vector order
+//                                          exactly like lines 291-297
+//   kmeans_fast_iterations(...)            CPU restatement of kmeans_fast_iterations_thread (databases.cpp:50-90), the
+//                                          definition the device version is tested against bit for bit
+//   learn_coarse_quantizer_hip(...)        learn_coarse_quantizer (databases.cpp:94-118) from a caller-provided seed:
+//                                          the reference seeds with two OpenCV k-means++ iterations (third-party, absent
+//                                          here), then runs kmeans_iter_max - 2 = 48 fast iterations — those run on the GPU
+// Chunked feeding (db_add.cpp:52-82 reads the base file chunk by chunk and calls add_vectors per chunk with the chunk's
+// offset) is the caller's loop around add_vectors_hip; labels = index in chunk + labels_offset, as there.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/qadc.h"
+#include "query_driver.hpp"
+
+namespace qadc {
+
+inline void add_vectors_hip(flat_database& db, const float* vecs, unsigned n, int device = 0) {
+    const pq4& pq = *db.pq;
+    db.codes.resize((size_t)(db.count + n) * pq.code_size());
+    if (qadc_ivf_encode_host(pq.sq_count, pq.dim, pq.centroids.data(), pq.rotation.empty() ? nullptr : pq.rotation.data(), 0,
+                             nullptr, vecs, n, nullptr, db.codes.data() + (size_t)db.count * pq.code_size(), device) != QADC_OK)
+        throw std::runtime_error(std::string("qadc_ivf_encode_host: ") + qadc_last_error());
+    db.count += n;
+}
+
+inline void add_vectors_hip(ivf_database& db, const float* vecs, unsigned n, unsigned labels_offset, int device = 0) {
+    const pq4& pq = *db.pq;
+    const size_t cs = (size_t)pq.code_size();
+    std::vector<std::int32_t> assign(n);
+    std::vector<std::uint8_t> codes((size_t)n * cs);
+    if (qadc_ivf_encode_host(pq.sq_count, pq.dim, pq.centroids.data(), pq.rotation.empty() ? nullptr : pq.rotation.data(),
+                             db.part_count, db.coarse.data(), vecs, n, assign.data(), codes.data(), device) != QADC_OK)
+        throw std::runtime_error(std::string("qadc_ivf_encode_host: ") + qadc_last_error());
+    for (unsigned i = 0; i < n; ++i) {                         // databases.hpp:291-297
+        const int p = assign[i];
+        db.partitions[p].insert(db.partitions[p].end(), codes.begin() + (size_t)i * cs, codes.begin() + (size_t)(i + 1) * cs);
+        db.labels[p].push_back(i + labels_offset);
+    }
+}
+
+// databases.cpp:50-90 on the host: assign every vector to its closest centroid (squared L2 accumulated in ascending d,
+// first minimum), then centroid = (sum of its members in vector order) / count.  An empty cluster divides 0 by 0.
+inline void kmeans_fast_iterations(const float* vecs, size_t n, int dim, int K, float* centroids, int iters, int* assign) {
+    std::vector<int> cnt((size_t)K);
+    for (int it = 0; it < iters; ++it) {
+        for (size_t i = 0; i < n; ++i) {
+            const float* x = vecs + i * dim;
+            int best = 0;
+            float bestd = std::numeric_limits<float>::max();
+            for (int k = 0; k < K; ++k) {
+                const float* c = centroids + (size_t)k * dim;
+                float s = 0;
+                for (int d = 0; d < dim; ++d) {
+                    const float t = x[d] - c[d];
+                    s += t * t;
+                }
+                if (s < bestd) { bestd = s; best = k; }
+            }
+            assign[i] = best;
+        }
+        std::fill(centroids, centroids + (size_t)K * dim, 0.0f);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (size_t i = 0; i < n; ++i) {
+            cnt[assign[i]]++;
+            float* c = centroids + (size_t)assign[i] * dim;
+            for (int d = 0; d < dim; ++d) c[d] += vecs[i * dim + d];
+        }
+        for (int k = 0; k < K; ++k)
+            for (int d = 0; d < dim; ++d) centroids[(size_t)k * dim + d] /= cnt[k];
+    }
+}
+
+constexpr int kmeans_iter_max = 50;                            // databases.cpp:92
+
+// `seed` [K][dim]: what the reference gets from cv::kmeans(KMEANS_PP_CENTERS, 2 iterations)
+inline std::vector<float> learn_coarse_quantizer_hip(const float* vecs, size_t n, int dim, int K, const float* seed,
+                                                     int device = 0) {
+    std::vector<float> centroids(seed, seed + (size_t)K * dim);
+    if (qadc_kmeans_iterations_host(vecs, n, dim, K, centroids.data(), kmeans_iter_max - 2, nullptr, device) != QADC_OK)
+        throw std::runtime_error(std::string("qadc_kmeans_iterations_host: ") + qadc_last_error());
+    return centroids;
+}
+
+}  // namespace qadc

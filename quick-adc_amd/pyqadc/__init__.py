@@ -30,7 +30,7 @@ SYMBOLS = [
     "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit", "qadc_prescan_submit",
     "qadc_prescan_collect", "qadc_query_scan_submit_prescanned",
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
-    "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
+    "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_kmeans_iterations_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
     "qadc_dist_unique_id", "qadc_dist_init", "qadc_dist_collect", "qadc_dist_shutdown", "qadc_dist_merge_blocks",
 ]
 
@@ -106,6 +106,8 @@ def lib():
         L.qadc_search_collect.argtypes = [C.c_void_p, C.c_int, u32p, i8p, i32p, i32p, i32p]
         L.qadc_pq_encode.argtypes = [C.c_int, C.c_int, f32p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.qadc_pq_encode_host.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_uint64, u8p, C.c_int]
+        L.qadc_ivf_encode_host.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_int, f32p, f32p, C.c_uint64, i32p, u8p, C.c_int]
+        L.qadc_kmeans_iterations_host.argtypes = [f32p, C.c_uint64, C.c_int, C.c_int, f32p, C.c_int, i32p, C.c_int]
         L.qadc_replay_i8.argtypes = [C.c_uint64, u32p, i8p, C.c_int, C.c_int, u32p, i8p, i32p]
         L.qadc_sort_keys_i8.argtypes = [C.c_int, u32p, i8p, u32p]
         L.qadc_merge_streams_i8.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, i32p, C.c_uint64, C.c_int,
@@ -188,6 +190,32 @@ def merge_streams_i8(gathered, world, nq, R, cap, ma, q_first, q_step, status, k
     st = None if status is None else np.ascontiguousarray(status, np.int32)
     _check(lib().qadc_merge_streams_i8(world, nq, R, cap, ma, _p(g, i32p), g.shape[1], q_first, q_step, _p(st, i32p),
                                        _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p)))
+
+
+def ivf_encode(codebooks, vectors, coarse=None, rotation=None, device=0):
+    """index_db::add_vectors' compute on the GPU: nearest coarse centroid, residual, optional OPQ rotation, PQ encode.
+    -> (assign int32 [n] or None for a flat database, codes uint8 [n][M/2])."""
+    cb = np.ascontiguousarray(codebooks, np.float32)
+    v = np.ascontiguousarray(vectors, np.float32)
+    M, dim, n = cb.shape[0], v.shape[1], v.shape[0]
+    co = None if coarse is None else np.ascontiguousarray(coarse, np.float32)
+    rot = None if rotation is None else np.ascontiguousarray(rotation, np.float32)
+    assert rot is None or rot.shape == (dim, dim)
+    K = 0 if co is None else co.shape[0]
+    assign = np.zeros(n, np.int32) if K else None
+    codes = np.zeros((n, M // 2), np.uint8)
+    _check(lib().qadc_ivf_encode_host(M, dim, _p(cb, f32p), _p(rot, f32p), K, _p(co, f32p), _p(v, f32p), n, _p(assign, i32p),
+                                      _p(codes, u8p), device))
+    return assign, codes
+
+
+def kmeans_iterations(vectors, centroids, iters, device=0):
+    """kmeans_fast_iterations_thread on the GPU: -> (centroids float32 [K][dim], assign int32 [n] of the last round)."""
+    v = np.ascontiguousarray(vectors, np.float32)
+    c = np.array(centroids, np.float32, order="C", copy=True)
+    assign = np.zeros(v.shape[0], np.int32)
+    _check(lib().qadc_kmeans_iterations_host(_p(v, f32p), v.shape[0], v.shape[1], c.shape[0], _p(c, f32p), iters, _p(assign, i32p), device))
+    return c, assign
 
 
 def pq_encode(codebooks, vectors, device=0):

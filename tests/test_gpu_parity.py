@@ -1272,3 +1272,47 @@ def test_coarse_assignment_of_large_batches_is_the_sequential_one(pyqadc, nq, K,
         want = np.lexsort((np.arange(K), d))[:ma]
         assert np.array_equal(got[q], want), q
     idx.close()
+
+
+@pytest.mark.gpu
+def test_ivf_encode_and_kmeans_iterations_match_numpy(pyqadc):
+    """N4 through ctypes: qadc_ivf_encode_host (nearest centroid, residual, OPQ rotation, PQ encode) and
+    qadc_kmeans_iterations_host against numpy evaluations of the same sequential loops."""
+    rng = np.random.default_rng(99)
+    M, dim, K, n = 16, 32, 50, 3000
+    cb = rng.normal(size=(M, 16, dim // M)).astype(np.float32)
+    coarse = rng.normal(size=(K, dim)).astype(np.float32)
+    rot = (rng.normal(size=(dim, dim)) * 0.3).astype(np.float32)
+    v = rng.normal(size=(n, dim)).astype(np.float32)
+    assign, codes = pyqadc.ivf_encode(cb, v, coarse=coarse, rotation=rot)
+    for i in list(range(0, n, 97)) + [n - 1]:
+        d = _seq_sqdist(v[i][None, :], coarse)
+        a = int(np.lexsort((np.arange(K), d))[0])
+        assert assign[i] == a
+        res = (v[i] - coarse[a]).astype(np.float32)
+        x = np.zeros(dim, np.float32)
+        for r in range(dim):
+            acc = np.float32(0)
+            for c in range(dim):
+                acc = np.float32(acc + np.float32(res[c] * rot[r, c]))
+            x[r] = acc
+        t = _seq_sqdist(x.reshape(M, 1, dim // M), cb)          # [M][16]
+        best = np.array([int(np.lexsort((np.arange(16), t[m]))[0]) for m in range(M)])
+        want = (best[0::2] | (best[1::2] << 4)).astype(np.uint8)
+        assert np.array_equal(codes[i], want), i
+    # flat database: no assignment, no residual
+    _, codes_flat = pyqadc.ivf_encode(cb, v[:100])
+    assert np.array_equal(codes_flat, pyqadc.pq_encode(cb, v[:100]))
+    # two k-means rounds from the first K vectors
+    cen, asg = pyqadc.kmeans_iterations(v, v[:K], 2)
+    c = v[:K].copy()
+    for _ in range(2):
+        a = np.array([int(np.lexsort((np.arange(K), _seq_sqdist(v[i][None, :], c)))[0]) for i in range(n)])
+        c = np.zeros_like(c)
+        cnt = np.zeros(K, np.int64)
+        for i in range(n):
+            c[a[i]] = (c[a[i]] + v[i]).astype(np.float32)
+            cnt[a[i]] += 1
+        with np.errstate(invalid="ignore", divide="ignore"):
+            c = (c / cnt[:, None].astype(np.float32)).astype(np.float32)
+    assert np.array_equal(asg, a) and np.array_equal(cen, c, equal_nan=True)

@@ -222,3 +222,23 @@ def test_dist_demo_world_1_equals_plain_scan(po, tmp_path):
             with np.errstate(over="ignore"):
                 acc = splitmix64(np.uint64(acc) ^ ((np.uint64(k) << np.uint64(8)) | np.uint64(np.uint8(v))))
     assert got == int(acc)
+
+
+DB_BUILD = os.path.join(ROOT, "tests", "cpp", "db_build_demo")
+
+
+def test_db_build_demo_builds_as_cxx14():
+    _compile(os.path.join(ROOT, "tests", "cpp", "db_build_demo.cpp"), DB_BUILD)
+    assert os.path.exists(DB_BUILD)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,dim,K,n,opq", [(16, 32, 37, 5000, 0), (32, 64, 300, 40000, 1), (16, 128, 1000, 70000, 0)])
+def test_gpu_database_build_equals_the_host_build(M, dim, K, n, opq):
+    """N4: host/db_build.hpp (index_db::add_vectors / flat_db::add_vectors compute and the k-means fast iterations on
+    the GPU, from C++14) against the sequential host loops: same partitions, codes, labels, centroids, bit for bit
+    (chunked adds with offsets, an exact centroid tie, OPQ rotation, batches on both sides of the 256-vector switch of
+    the coarse kernels)."""
+    _compile(os.path.join(ROOT, "tests", "cpp", "db_build_demo.cpp"), DB_BUILD)
+    out = subprocess.check_output([DB_BUILD, str(M), str(dim), str(K), str(n), str(opq)]).decode()
+    assert "ivf_partitions_differing 0 flat_differs 0 kmeans_differs 0" in out, out
