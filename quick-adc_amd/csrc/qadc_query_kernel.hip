@@ -604,6 +604,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     uint32_t* hist_done = misc;                                  // [128] candidates of the finished epochs, by value
     uint32_t* hist_cur = misc + 128;                             // [128] candidates of the running epoch
     uint32_t& s_ccount = misc[326];                              // candidates appended so far
+    uint32_t& s_hreps = misc[324];                               // (HEAD, one workgroup per query) padding-lane replays among them
     QCand* __restrict__ cands = A.cands + (size_t)wgi * A.ccap;
     auto next_part = [&](int a_) {
         ++a_;
@@ -632,7 +633,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     };
     const uint32_t lane_lo = (tid & 31u) * 4u, lane_hi = lane_lo | 0x10000u;
     if (tid < 256) misc[tid] = 0;                                // both histograms
-    if (tid == 0) s_ccount = 0;
+    if (tid == 0) { s_ccount = 0; s_hreps = 0; }
     // ---- how the query's scan order is shared by the G workgroups of the query (G = 1: everything is "mine") ----
     // total vectors of the probed partitions, in scan order
     // (HEAD: codes of a partition the head covers = the planner's cut of bound level k0 in that partition: everything if
@@ -811,7 +812,22 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
             const uint32_t dup_reps = (16u - d.global_n % 16u) % 16u;
             const uint32_t key_base = d.key_base + d.first_pos;
             auto emit = [&](uint32_t cv, uint32_t p) {           // rare: count (and append, unordered) one candidate
-                if (HEAD && do_emit) {                           // into the level path's structures (emit_candidate's twin)
+                if (HEAD && do_emit && G == 1) {
+                    // this workgroup is the only writer of the query's region: slots, replays and the histogram are
+                    // counted in LDS and published once, at the end (a global atomic per candidate — its return value
+                    // stalls the wave for a memory round trip — is what the shared-region form below pays)
+                    const uint32_t reps = p == dup_pos ? dup_reps : 0u;
+                    const uint32_t slot = atomicAdd(&s_ccount, 1u);
+                    if (slot < A.cand_cap) {
+                        Cand c_;
+                        c_.order = (uint32_t)a | (reps << 20);   // level 0, assign slot a
+                        c_.pos = p;
+                        c_.key = d.labels ? d.labels[p] : key_base + p;
+                        c_.val = cv;
+                        A.cand_regions[(size_t)q * A.cand_cap + slot] = c_;
+                    }
+                    if (reps) atomicAdd(&s_hreps, reps);
+                } else if (HEAD && do_emit) {                    // into the level path's structures (emit_candidate's twin)
                     QueryState* qs = A.qstates + q;
                     const uint32_t reps = p == dup_pos ? dup_reps : 0u;
                     const uint32_t slot = atomicAdd(&qs->count, 1u);
@@ -936,6 +952,16 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         }
     }
     if (HEAD) {                                                  // the level path (or order_cands_kernel) orders and reports
+        if (G == 1) {                                            // counts kept in LDS (see emit): published here
+            QueryState* qs = A.qstates + q;
+            q_lds_barrier();
+            if (tid < 128) qs->hist[tid] = hist_done[tid] + hist_cur[tid];
+            if (tid == 0) {
+                qs->count = s_ccount;
+                qs->reps = s_hreps;
+                if (s_ccount > A.cand_cap) atomicAdd(&A.hdr->overflow, s_ccount - A.cand_cap);
+            }
+        }
         if (A.ftables && tid == 0 && g == 0) {                   // front run here: its results travel in the QueryState
             QueryState* qs = A.qstates + q;
             qs->qmin = qmin;
