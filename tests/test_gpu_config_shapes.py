@@ -93,3 +93,44 @@ def test_c5_shape_ivf_32x4_dim96_nprobe64(pyqadc, po):
     assert int(res["status"].sum()) == 0
     _check(po, res, list(rng.choice(nq - 1, 31, replace=False)) + [nq - 1], queries, parts, labels, cb, coarse, M, ma, keep, R)
     idx.close()
+
+
+@pytest.mark.gpu
+def test_c3_full_size_the_bench_list_against_oracle(pyqadc, po):
+    """BASELINE configs[2] at FULL size — the very list bench.py's `ivf` leg times: 10^8 synthetic 16x4 codes in K = 4096
+    partitions (multinomial sizes, partition p = generator stream 1000 + p), nprobe 32, a 1024-query batch through
+    qadc_search (head + partition-major second phase).  The oracle only needs the probed partitions of the sampled
+    queries, which the CPU generator reproduces: 12 sampled queries must end in the oracle's heaps."""
+    M, K, MA, nq, dim, N, R, keep = 16, 4096, 32, 1024, 128, 100_000_000, 100, 0.01
+    rng = np.random.default_rng(0)
+    sizes = rng.multinomial(N, np.ones(K) / K)
+    idx = pyqadc.Index(M)
+    for p in range(K):
+        idx.add_partition_synthetic(int(sizes[p]), 1000 + p)
+    idx.finalize(keep)
+    cb = rng.normal(size=(M, 16, dim // M)).astype(np.float32)
+    coarse = rng.normal(size=(K, dim)).astype(np.float32)
+    idx.set_pq(cb)
+    idx.set_coarse(coarse)
+    idx.set_option("profile", 1)
+    queries = rng.normal(size=(nq, dim)).astype(np.float32)
+    res = idx.search(queries, MA, R)
+    prof = idx.profile()
+    import os
+    if os.environ.get("QADC_WGQ") != "0":                       # (the fixture also runs this test on the level-structured path)
+        assert prof["group_launches"] >= 1 and prof["group_fallbacks"] == 0   # the path bench.py measures, not a fallback
+    assert int(res["status"].sum()) == 0
+    ds = dim // M
+    for q in rng.choice(nq, 12, replace=False):
+        dist = _seq_sqdist(queries[q][None, :], coarse)
+        assign = np.lexsort((np.arange(K), dist))[:MA].astype(np.int32)
+        assert np.array_equal(res["assign"][q], assign), q
+        resid = (queries[q][None, :] - coarse[assign]).astype(np.float32)
+        tables = np.stack([_seq_expansion(resid[a].reshape(M, 1, ds), cb) for a in range(MA)])
+        probed = [po.fill_codes(0, int(sizes[p]), 1000 + int(p)).reshape(-1, M // 2) for p in assign]
+        want = po.query_scan(M, probed, None, keep, np.arange(MA, dtype=np.int32),
+                             np.ascontiguousarray(tables.reshape(MA, M * 16)), R)
+        assert want["rc"] == 0
+        sz = res["sizes"][q]
+        assert heaps_equal((res["keys"][q, :sz], res["values"][q, :sz]), (want["keys"], want["values"])), q
+    idx.close()
