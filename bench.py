@@ -22,6 +22,7 @@ ONE JSON line, several legs (SURVEY.md §8d keeps the two scan modes apart):
 * `roofline_32x4`: the same one-query-per-pass leg on 1B x 32x4 codes (16 B/code).
 * `ivf`: BASELINE configs[2] shape (100M codes in K=4096 labelled-free synthetic partitions, nprobe 32,
   1024-query pipelined batches through the device-side feeders).
+* `ivf_c5_one_gpu`: the same leg at BASELINE configs[4]'s shape on one GPU (1B x 32x4 codes, K=16384, 96-d, nprobe 64).
 * `latency_us_single_query`: synchronous single query on a 10^5-code list (README.md:327-330: 86 us).
 * `cpu_baseline`: the reference's own scan_avx_4<16> (oracle/_ref), 1 thread; `cpu_baseline_all_cores`:
   the same kernel on every physical core (C++ threads inside oracle/_ref, pinned, per-thread copies).
@@ -38,7 +39,7 @@ past 2^32 anyway) and the per-shard push streams are gathered once per batch and
 
 Environment overrides for quick runs: QADC_BENCH_CODES, QADC_BENCH_NQ, QADC_BENCH_M,
 QADC_BENCH_CPU_SECONDS (0 disables the CPU legs), QADC_BENCH_SINGLE_QUERIES, QADC_BENCH_PMC (0 = no
-in-run PMC child passes), QADC_BENCH_IVF_CODES (0 = no IVF leg), QADC_BENCH_32X4 (0 = no 32x4 leg),
+in-run PMC child passes), QADC_BENCH_IVF_CODES (0 = no IVF leg), QADC_BENCH_IVF_C5 (0 = no 1B x 32x4 IVF leg), QADC_BENCH_32X4 (0 = no 32x4 leg),
 QADC_BENCH_REAL_CODES (0 = no real-encode recall leg), QADC_BENCH_LATENCY (0 = no latency leg).
 """
 import argparse
@@ -342,17 +343,18 @@ def roofline_single(M, N, prof, dt, nqueries, traffic, traffic_src):
             "small_run_codes_not_event_timed": prof["small_codes"]}
 
 
-def ivf_leg(local_rank):
+def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000):
     """BASELINE configs[2] shape: 100M x 16x4 codes in K = 4096 ragged partitions, nprobe 32, R = 100, queries in
     (coarse assignment, residual tables, pre-scan, quantizer, scan, heap all on the GPU), 1024-query batches pipelined."""
     import pyqadc
-    M, K, MA, NQB, dim = 16, 4096, 32, 1024, 128
-    N = int(float(os.environ.get("QADC_BENCH_IVF_CODES", 1e8)))
+    NQB = 1024
+    if N is None:
+        N = int(float(os.environ.get("QADC_BENCH_IVF_CODES", 1e8)))
     rng = np.random.default_rng(0)
     sizes = rng.multinomial(N, np.ones(K) / K)
     idx = pyqadc.Index(M, local_rank)
     for p in range(K):
-        idx.add_partition_synthetic(int(sizes[p]), 1000 + p)
+        idx.add_partition_synthetic(int(sizes[p]), seed0 + p)
     idx.finalize(KEEP)
     cb = rng.normal(size=(M, 16, dim // M)).astype(np.float32)
     coarse = rng.normal(size=(K, dim)).astype(np.float32)
@@ -385,13 +387,13 @@ def ivf_leg(local_rank):
     dt2, _ = pipelined(qs2, 8, depth)
     idx.close()
     gbs = ncodes * (M // 2) / dt / 1e9
-    return {"workload": "IVF, %d x 16x4 codes in K=%d partitions (multinomial sizes), nprobe=%d, R=%d, keep=%.0f%%, "
-                        "%d-query batches, %d in flight, queries in -> heaps out (qadc_search)" % (N, K, MA, R, KEEP * 100, NQB, depth),
+    return {"workload": "IVF, %d x %dx4 codes (%d-d vectors) in K=%d partitions (multinomial sizes), nprobe=%d, R=%d, keep=%.0f%%, "
+                        "%d-query batches, %d in flight, queries in -> heaps out (qadc_search)" % (N, M, dim, K, MA, R, KEEP * 100, NQB, depth),
             "codes_per_sec": ncodes / dt, "us_per_query": dt * 1e6 / (steps * NQB), "queries_per_sec": steps * NQB / dt,
             "us_per_query_at_2048_query_batches": dt2 * 1e6 / (8 * 2 * NQB),
             "probed_codes_per_query": ncodes / (steps * NQB),
             "algorithmic_GBps": gbs,
-            "algorithmic_GBps_rule": "8 B x probed codes / wall time of the pipelined batches (whole path, not one kernel; "
+            "algorithmic_GBps_rule": "M/2 B x probed codes / wall time of the pipelined batches (whole path, not one kernel; "
                                      "NOT an HBM figure: the partition-major second phase reads a partition once for up to 8 queries)",
             "batches_through_partition_major_second_phase": int(p["group_launches"]), "of_them_redone_on_the_level_path": int(p["group_fallbacks"]),
             "host_ms_per_batch": {"plan": p["host_plan_ms"] / steps, "stream_assembly": p["host_replay_ms"] / steps,
@@ -776,6 +778,9 @@ def main():
             i32.close()
         if int(float(os.environ.get("QADC_BENCH_IVF_CODES", 1e8))) > 0:
             out["ivf"] = ivf_leg(local_rank)
+            if os.environ.get("QADC_BENCH_IVF_C5", "1") != "0" and N >= 1e9:
+                # BASELINE configs[4] on ONE GPU: 1B x 32x4 codes (16 GB), 96-d vectors, nprobe 64
+                out["ivf_c5_one_gpu"] = ivf_leg(local_rank, M=32, K=16384, MA=64, dim=96, N=int(1e9), seed0=7000)
         if os.environ.get("QADC_BENCH_LATENCY", "1") != "0":
             out["latency_us_single_query"] = latency_leg(local_rank)
         n_real = int(float(os.environ.get("QADC_BENCH_REAL_CODES", 1e7)))

@@ -134,3 +134,39 @@ def test_c3_full_size_the_bench_list_against_oracle(pyqadc, po):
         sz = res["sizes"][q]
         assert heaps_equal((res["keys"][q, :sz], res["values"][q, :sz]), (want["keys"], want["values"])), q
     idx.close()
+
+
+@pytest.mark.gpu
+def test_c5_full_size_1e9_codes_32x4_nprobe64_on_one_gpu(pyqadc, po):
+    """BASELINE configs[4] at FULL size on ONE GPU (16 GB of codes): 10^9 synthetic 32x4 codes in K = 16384 partitions,
+    96-d vectors (sq_dim 3), nprobe 64, a 1024-query batch through qadc_search; 6 sampled queries (3.9 M probed codes
+    each, regenerated on the CPU) must end in the oracle's heaps."""
+    M, K, MA, nq, dim, N, R, keep = 32, 16384, 64, 1024, 96, 1_000_000_000, 100, 0.01
+    rng = np.random.default_rng(5)
+    sizes = rng.multinomial(N, np.ones(K) / K)
+    idx = pyqadc.Index(M)
+    for p in range(K):
+        idx.add_partition_synthetic(int(sizes[p]), 7000 + p)
+    idx.finalize(keep)
+    cb = rng.normal(size=(M, 16, dim // M)).astype(np.float32)
+    coarse = rng.normal(size=(K, dim)).astype(np.float32)
+    idx.set_pq(cb)
+    idx.set_coarse(coarse)
+    queries = rng.normal(size=(nq, dim)).astype(np.float32)
+    res = idx.search(queries, MA, R)
+    assert int(res["status"].sum()) == 0
+    ds = dim // M
+    for q in rng.choice(nq, 6, replace=False):
+        dist = _seq_sqdist(queries[q][None, :], coarse)
+        assign = np.lexsort((np.arange(K), dist))[:MA].astype(np.int32)
+        assert np.array_equal(res["assign"][q], assign), q
+        resid = (queries[q][None, :] - coarse[assign]).astype(np.float32)
+        tables = np.stack([_seq_expansion(resid[a].reshape(M, 1, ds), cb) for a in range(MA)])
+        # a 32x4 code is 16 bytes = two words of the generator stream
+        probed = [po.fill_codes(0, 2 * int(sizes[p]), 7000 + int(p)).reshape(-1, M // 2) for p in assign]
+        want = po.query_scan(M, probed, None, keep, np.arange(MA, dtype=np.int32),
+                             np.ascontiguousarray(tables.reshape(MA, M * 16)), R)
+        assert want["rc"] == 0
+        sz = res["sizes"][q]
+        assert heaps_equal((res["keys"][q, :sz], res["values"][q, :sz]), (want["keys"], want["values"])), q
+    idx.close()
