@@ -286,6 +286,11 @@ int qadc_dist_shutdown(qadc_index* idx);
  * GPU check the multi-rank replay order.  sizes[q] = -1 when a block reports an overflow / unordered query. */
 int qadc_dist_merge_blocks(int device_id, int world, int nq, int ma, int R, const uint64_t* gathered, uint64_t block_words,
                            uint32_t* keys, int8_t* values, int32_t* sizes);
+/* The host half of the same merge (few-query batches: every rank replays its share of the queries between two
+ * all-gathers), executed for all `world` ranks in turn on the caller's thread — no GPU, no RCCL: the test hook of the
+ * code path 2/4/8-rank runs of 32-query batches take. */
+int qadc_dist_merge_blocks_host(int world, int nq, int ma, int R, const uint64_t* gathered, uint64_t block_words,
+                                uint32_t* keys, int8_t* values, int32_t* sizes);
 
 typedef struct qadc_profile {
     uint64_t scan_launches;   /* launches of the streaming int8 scan kernels (scan_i8_kernel, scan_i8_mq_kernel) */

@@ -2330,6 +2330,56 @@ int qadc_kmeans_iterations_host(const float* vectors, uint64_t n, int dim, int K
     return QADC_OK;
 }
 
+extern "C++" {
+namespace {
+// The host half of qadc_dist_collect for few-query batches: rank `rank` replays the queries q = rank, rank + world, ...
+// of the gathered blocks ([nq x {offset, count, flags, -} as u32][entries ...] per rank, `bw` words each) in GLOBAL scan
+// order — assign slot, then rank (= ascending code range), then position — through the reference's heap, sentinel first
+// (db_query_4.cpp:276).  myheaps: [ceil(nq / world)][R + 1] words, heap entries key | value << 32, then the size.
+void replay_my_share(const uint64_t* gathered, size_t bw, int world, int rank, int nq, int ma, int R, const int32_t* status,
+                     uint64_t* myheaps) {
+    const int per = (nq + world - 1) / world;
+    const size_t hw = (size_t)R + 1;
+    auto work = [&](int j0, int j1) {
+        kv_heap<uint32_t, int8_t> bh(R);
+        std::vector<uint32_t> cur(world), end(world);
+        for (int j = j0; j < j1; ++j) {
+            const int q = j * world + rank;
+            if (q >= nq || (status && status[q])) continue;
+            bh.reset();
+            bh.push(0, 127);
+            for (int g = 0; g < world; ++g) {
+                const uint32_t* h = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * bw) + 4 * (size_t)q;
+                cur[g] = h[0];
+                end[g] = h[0] + h[1];
+            }
+            for (int slot = 0; slot < ma; ++slot)
+                for (int g = 0; g < world; ++g) {
+                    const uint64_t* ent = gathered + (size_t)g * bw + 2 * (size_t)nq;
+                    while (cur[g] < end[g]) {                    // a rank scans its partitions in assign order: slots ascend
+                        const uint64_t e = ent[cur[g]];
+                        if (ma > 1 && (int)((e >> 40) & 0x3fffu) != slot) break;
+                        bh.push((uint32_t)e, (int8_t)(e >> 32));
+                        ++cur[g];
+                    }
+                }
+            uint64_t* o = myheaps + (size_t)j * hw;
+            for (int i = 0; i < bh.size(); ++i) o[i] = (uint64_t)bh.keys()[i] | ((uint64_t)(uint8_t)bh.values()[i] << 32);
+            o[R] = (uint64_t)bh.size();
+        }
+    };
+    const int nt = std::max(1, std::min<int>(std::min(per, 4), (int)std::thread::hardware_concurrency()));
+    if (nt == 1) {
+        work(0, per);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, per * t / nt, per * (t + 1) / nt);
+        for (auto& x : th) x.join();
+    }
+}
+}  // namespace
+}  // extern "C++"
+
 /* ---- native multi-GPU merge: one ncclAllGather per batch, device memory to device memory ---- */
 int qadc_dist_unique_id(uint8_t* id128) {
     if (!id128) return fail(QADC_E_ARG, "id is null");
@@ -2408,6 +2458,26 @@ int qadc_dist_merge_blocks(int device_id, int world, int nq, int ma, int R, cons
     return QADC_OK;
 }
 
+int qadc_dist_merge_blocks_host(int world, int nq, int ma, int R, const uint64_t* gathered, uint64_t block_words,
+                                uint32_t* keys, int8_t* values, int32_t* sizes) {
+    if (world < 1 || world > 16 || nq <= 0 || ma <= 0 || R <= 0 || !gathered || !sizes) return fail(QADC_E_ARG, "bad arguments");
+    // what the ranks of qadc_dist_collect do between their two all-gathers, rank by rank: every rank replays its share,
+    // the second gather concatenates the shares ([rank][ceil(nq / world)][R + 1]), every rank reads all heaps back
+    const int per = (nq + world - 1) / world;
+    const size_t hw = (size_t)R + 1;
+    std::vector<uint64_t> all((size_t)world * per * hw, 0);
+    for (int r = 0; r < world; ++r) replay_my_share(gathered, (size_t)block_words, world, r, nq, ma, R, nullptr, all.data() + (size_t)r * per * hw);
+    for (int q = 0; q < nq; ++q) {
+        const uint64_t* o = all.data() + ((size_t)(q % world) * per + q / world) * hw;
+        sizes[q] = (int32_t)o[R];
+        for (int i = 0; i < sizes[q]; ++i) {
+            if (keys) keys[(size_t)q * R + i] = (uint32_t)o[i];
+            if (values) values[(size_t)q * R + i] = (int8_t)(o[i] >> 32);
+        }
+    }
+    return QADC_OK;
+}
+
 int qadc_dist_shutdown(qadc_index* idx) {
     if (!idx || !idx->dist) return QADC_OK;
     (void)hipSetDevice(idx->device);
@@ -2453,11 +2523,14 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         // (a query that was not ordered on the device — more than 16384 candidates — is not supported by the native merge;
         // it is reported AFTER the gather, from the headers every rank sees, so that all ranks leave the collective alike)
     }
-    if (extra_n) {
-        HIPCHECK(d.h_extra.ensure(extra_n));
-        HIPCHECK(d.d_extra.ensure(extra_n));
-        std::memcpy(d.h_extra.p, extra, sizeof(float) * extra_n);
-    }
+    // Buffers are sized on the FIRST call for a payload of nq x R floats per rank (the sharded pre-scan's) whether or not
+    // this call carries one: the pinned allocations and the larger gather blocks a first payload would otherwise need
+    // cost milliseconds, and a pipeline's first batches typically come without payload.
+    const size_t extra_room = std::max<size_t>((size_t)extra_n, (size_t)nq * (size_t)R);
+    HIPCHECK(d.h_extra.ensure(extra_room));
+    HIPCHECK(d.d_extra.ensure(extra_room));
+    HIPCHECK(d.h_extra_all.ensure((size_t)world * extra_room));
+    if (extra_n) std::memcpy(d.h_extra.p, extra, sizeof(float) * extra_n);
     const size_t heaps_bytes = (sizeof(uint64_t) * (size_t)R + sizeof(uint32_t)) * (size_t)nq;
     HIPCHECK(d.h_out.ensure(heaps_bytes + 16, hipHostMallocMapped | hipHostMallocCoherent));
     if (d.h_out.p != d.h_out_mapped) {
@@ -2465,14 +2538,14 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         d.h_out_mapped = d.h_out.p;
     }
     HIPCHECK(d.h_hdr.ensure((size_t)world * nq * 4));
-    if (extra_n) HIPCHECK(d.h_extra_all.ensure((size_t)world * extra_n));
     hipStream_t st = d.stream;                               // the batch itself is complete (collect_common waited for it)
     uint64_t* h_heaps = reinterpret_cast<uint64_t*>(d.h_out.p);
     uint32_t* h_sizes = reinterpret_cast<uint32_t*>(d.h_out.p + sizeof(uint64_t) * (size_t)R * nq);
     for (int attempt = 0;; ++attempt) {
         const size_t bw = dist_block_words(nq, d.cap_entries, (uint32_t)extra_n);
-        HIPCHECK(d.d_block.ensure(bw));
-        HIPCHECK(d.d_gathered.ensure(bw * world));
+        const size_t bw_room = dist_block_words(nq, d.cap_entries, (uint32_t)extra_room);
+        HIPCHECK(d.d_block.ensure(bw_room));
+        HIPCHECK(d.d_gathered.ensure(bw_room * world));
         HIPCHECK(hipMemcpyAsync(d.d_src.p, d.h_src.p, sizeof(uint32_t) * 3 * nq, hipMemcpyHostToDevice, st));
         if (extra_n) HIPCHECK(hipMemcpyAsync(d.d_extra.p, d.h_extra.p, sizeof(float) * extra_n, hipMemcpyHostToDevice, st));
         HIPCHECK(launch_dist_pack(d.d_src.p, d.d_src.p + nq, d.d_src.p + 2 * nq, nq, s.d_stream.p, d.cap_entries,
@@ -2484,7 +2557,7 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
             HIPCHECK(launch_dist_merge_lanes(d.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, reinterpret_cast<uint64_t*>(d.d_out),
                                              reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq), st));
         else {
-            HIPCHECK(d.h_gathered.ensure(bw * world));
+            HIPCHECK(d.h_gathered.ensure(bw_room * world));
             HIPCHECK(hipMemcpyAsync(d.h_gathered.p, d.d_gathered.p, sizeof(uint64_t) * bw * world, hipMemcpyDeviceToHost, st));
         }
         // every rank's header (to size a retry identically everywhere) and extra payload come back with the heaps
@@ -2524,42 +2597,7 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         std::memset(d.h_myheaps.p, 0, sizeof(uint64_t) * (size_t)per * hw);
         {
             ScopedMs timer(idx->prof.host_heap_ms);
-            auto work = [&](int j0, int j1) {
-                kv_heap<uint32_t, int8_t> bh(R);
-                std::vector<uint32_t> cur(world), end(world);
-                for (int j = j0; j < j1; ++j) {
-                    const int q = j * world + d.rank;
-                    if (q >= nq || status[q]) continue;
-                    bh.reset();
-                    bh.push(0, 127);                             // db_query_4.cpp:276
-                    for (int g = 0; g < world; ++g) {
-                        const uint32_t* h = reinterpret_cast<const uint32_t*>(d.h_gathered.p + (size_t)g * bw) + 4 * (size_t)q;
-                        cur[g] = h[0];
-                        end[g] = h[0] + h[1];
-                    }
-                    for (int slot = 0; slot < s.ma; ++slot)
-                        for (int g = 0; g < world; ++g) {
-                            const uint64_t* ent = d.h_gathered.p + (size_t)g * bw + 2 * (size_t)nq;
-                            while (cur[g] < end[g]) {            // a rank scans its partitions in assign order: slots ascend
-                                const uint64_t e = ent[cur[g]];
-                                if (s.ma > 1 && (int)((e >> 40) & 0x3fffu) != slot) break;
-                                bh.push((uint32_t)e, (int8_t)(e >> 32));
-                                ++cur[g];
-                            }
-                        }
-                    uint64_t* o = d.h_myheaps.p + (size_t)j * hw;
-                    for (int i = 0; i < bh.size(); ++i) o[i] = (uint64_t)bh.keys()[i] | ((uint64_t)(uint8_t)bh.values()[i] << 32);
-                    o[R] = (uint64_t)bh.size();
-                }
-            };
-            const int nt = std::max(1, std::min<int>(std::min(per, 4), (int)std::thread::hardware_concurrency()));
-            if (nt == 1) {
-                work(0, per);
-            } else {
-                std::vector<std::thread> th;
-                for (int t = 0; t < nt; ++t) th.emplace_back(work, per * t / nt, per * (t + 1) / nt);
-                for (auto& x : th) x.join();
-            }
+            replay_my_share(d.h_gathered.p, bw, world, d.rank, nq, s.ma, R, status, d.h_myheaps.p);
         }
         HIPCHECK(hipMemcpyAsync(d.d_myheaps.p, d.h_myheaps.p, sizeof(uint64_t) * (size_t)per * hw, hipMemcpyHostToDevice, st));
         const int rc2 = d.AllGather(d.d_myheaps.p, d.d_allheaps.p, (size_t)per * hw, /*ncclUint64*/ 5, d.comm, st);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "qadc_prescan_collect", "qadc_query_scan_submit_prescanned",
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
     "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_kmeans_iterations_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
-    "qadc_dist_unique_id", "qadc_dist_init", "qadc_dist_collect", "qadc_dist_shutdown", "qadc_dist_merge_blocks",
+    "qadc_dist_unique_id", "qadc_dist_init", "qadc_dist_collect", "qadc_dist_shutdown", "qadc_dist_merge_blocks", "qadc_dist_merge_blocks_host",
 ]
 
 
@@ -119,6 +119,7 @@ def lib():
         L.qadc_dist_collect.argtypes = [C.c_void_p, C.c_int, u32p, i8p, i32p, i32p, f32p, C.c_int, f32p]
         L.qadc_dist_shutdown.argtypes = [C.c_void_p]
         L.qadc_dist_merge_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_uint64, u32p, i8p, i32p]
+        L.qadc_dist_merge_blocks_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_uint64, u32p, i8p, i32p]
         L.qadc_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.qadc_profile_reset.argtypes = [C.c_void_p]
         _lib = L
@@ -160,9 +161,10 @@ def dist_unique_id():
     return uid
 
 
-def dist_merge_blocks(streams, nq, ma, R, device=0):
+def dist_merge_blocks(streams, nq, ma, R, device=0, host=False):
     """streams[g] = dict(keys, vals, slots, offsets) of virtual rank g (Index.query_scan_shard_streams): assembles the
-    blocks qadc_dist_collect would gather and runs the device-side merge.  -> list of (keys, values) heaps."""
+    blocks qadc_dist_collect would gather and runs the device-side merge (host=True: the host-share replay the ranks
+    run for few-query batches, all ranks' shares in turn).  -> list of (keys, values) heaps."""
     world = len(streams)
     cap = max(int(st["offsets"][-1]) for st in streams) + 3
     bw = 2 * nq + cap
@@ -180,7 +182,10 @@ def dist_merge_blocks(streams, nq, ma, R, device=0):
     keys = np.zeros((nq, R), np.uint32)
     vals = np.zeros((nq, R), np.int8)
     sizes = np.zeros(nq, np.int32)
-    _check(lib().qadc_dist_merge_blocks(device, world, nq, ma, R, _p(g, u64p), bw, _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p)))
+    if host:
+        _check(lib().qadc_dist_merge_blocks_host(world, nq, ma, R, _p(g, u64p), bw, _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p)))
+    else:
+        _check(lib().qadc_dist_merge_blocks(device, world, nq, ma, R, _p(g, u64p), bw, _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p)))
     return [(keys[q, :sizes[q]].copy(), vals[q, :sizes[q]].copy()) for q in range(nq)]
 
 

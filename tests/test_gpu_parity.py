@@ -1049,10 +1049,14 @@ def test_dist_merge_kernel_on_virtual_ranks(pyqadc, po, M, world):
         streams.append(idx.query_scan_shard_streams(assign, tables.copy(), R))
         idx.close()
     got = pyqadc.dist_merge_blocks(streams, nq, ma, R)
+    # ... and the host half: the share replay the ranks of a few-query batch (bench.py's 32-query steps) run between
+    # their two all-gathers, all `world` shares in turn
+    got_host = pyqadc.dist_merge_blocks(streams, nq, ma, R, host=True)
     for q in range(nq):
         want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
         assert want["rc"] == 0
         assert heaps_equal(got[q], (want["keys"], want["values"])), q
+        assert heaps_equal(got_host[q], (want["keys"], want["values"])), q
 
 
 @pytest.mark.gpu
