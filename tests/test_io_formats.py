@@ -15,8 +15,12 @@ TOOL = os.path.join(ROOT, "tests", "cpp", "io_roundtrip")
 
 
 def build_tool():
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "io_roundtrip.cpp"),
-                           "-o", TOOL])
+    """host/qadc_io.hpp's test driver, built with AddressSanitizer + UndefinedBehaviorSanitizer (CPU code: the readers
+    parse untrusted files) — any report aborts the tool and fails the round-trip tests below."""
+    tmp = "%s.%d.tmp" % (TOOL, os.getpid())
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-g", "-Wall", "-Werror", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", os.path.join(ROOT, "tests", "cpp", "io_roundtrip.cpp"), "-o", tmp])
+    os.replace(tmp, TOOL)
 
 
 def run_tool(*args):
