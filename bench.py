@@ -618,9 +618,12 @@ def main():
 
         nb = min(LEAD, k)                                      # the first batches: one stand-alone gather for all
         pvs = []
-        for b in range(nb):
+        for b in range(min(nb, 2)):                            # (both pre-scan slots busy from the start)
             prescan(b)
+        for b in range(nb):
             pvs.append(idx.prescan_collect(b % 2))
+            if b + 2 < nb:
+                prescan(b + 2)
         g = sharded.gather_prescan(np.concatenate(pvs), cdev)
         for b in range(nb):
             idx.submit(b % 4, assign, tbs[b % 6], R, prescan=g[b * NQ:(b + 1) * NQ])
