@@ -286,6 +286,7 @@ struct qadc_index {
     uint32_t share_codes_per_wg = 1u << 20;
     int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
     int device_replay_nq = 64;           // batches of at least this many queries replay their streams on the device (0 = never)
+    int device_replay_alone_nq = 400;    // ... a batch with nothing else in flight (one-workgroup-per-query path): from this many
     uint64_t front_run_max = 2u << 20;   // leading levels whose runs are at most this long join the front (0 = none); they are
                                          // counted with the small launches, not event-timed.  125M x 32: 2 Mi -4 %, 8 Mi +1 %
     uint64_t front_min_batch = 0;        // ... in batches of at least this many (code, query) pairs
@@ -637,7 +638,11 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
 
     // state block: [CandHeader, 64 B][QueryState[nq]]; result block: [QueryOut[nq]][u64 entries[out_cap]]
     const size_t state_bytes = 64 + sizeof(QueryState) * (size_t)nq;
-    s.dev_replay = s.mode != 1 && idx->device_replay_nq > 0 && nq >= idx->device_replay_nq && s.R <= 4096;
+    bool lone = s.mode != 1;                                    // nothing else in flight: a synchronous call (see launch_wgq_batch)
+    for (int i = 0; i < kSlots; ++i) lone = lone && (&idx->slot[i] == &s || !idx->slot[i].busy);
+    lone = lone && !idx->pre_slot[0].busy && !idx->pre_slot[1].busy;
+    const int replay_from = lone ? std::max(idx->device_replay_nq, idx->device_replay_alone_nq) : idx->device_replay_nq;
+    s.dev_replay = s.mode != 1 && idx->device_replay_nq > 0 && nq >= replay_from && s.R <= 4096;
     const size_t off_heaps = sizeof(QueryOut) * (size_t)nq + sizeof(uint64_t) * (size_t)s.out_cap;
     const size_t heaps_bytes = s.dev_replay ? (sizeof(uint64_t) * (size_t)s.R + sizeof(uint32_t)) * (size_t)nq : 0;
     const size_t result_bytes = std::max(off_heaps + heaps_bytes, (sizeof(float) * (size_t)s.R + sizeof(uint32_t)) * (size_t)nq);
@@ -873,6 +878,9 @@ bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64
     if (idx->wgq == 0 || mode != 0 || ma > 4096 || R <= 0) return false;
     if (idx->wgq >= 2) return true;
     if (codes_per_query <= idx->wgq_small_codes) return true;
+    // an IVF batch (several partitions, several probes per query: the queries walk different codes) — the query kernel is
+    // ahead of the level path at every batch size (C3 shape, synchronous: 1 query 217 -> 175 us, 64 queries 0.85 -> 0.73 ms)
+    if (ma > 1 && idx->parts.size() > 1 && codes_per_query <= idx->wgq_max_codes) return true;
     return nq >= idx->wgq_min_nq && codes_per_query <= idx->wgq_max_codes;
 }
 
@@ -900,7 +908,15 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     // ---- result block in pinned, device-mapped host memory: [QueryOut[nq]][streams u64[nq][cap] unless they stay
     // on the device][heaps u64[nq][R]][sizes u32[nq]] ----
     const uint32_t cap = s.wgq_cap;
-    s.dev_replay = idx->device_replay_nq > 0 && nq >= idx->device_replay_nq && (uint32_t)s.R <= replay_lanes_max_R();
+    bool alone = true;
+    for (int i = 0; i < kSlots; ++i) alone = alone && (&idx->slot[i] == &s || !idx->slot[i].busy);
+    alone = alone && !idx->pre_slot[0].busy && !idx->pre_slot[1].busy;
+    // The lane-per-query replay takes ~1.3 ms whatever the batch size (one query's pushes are sequential): in a pipeline
+    // that latency hides under the next batches and the host stays free, but a batch submitted while nothing else is in
+    // flight — a synchronous call — is answered sooner by the host's threads up to a few hundred queries (C3 shape,
+    // synchronous: 64 queries 1.41 -> 0.87 ms, 256: 1.89 -> 1.44, 512: 2.26 vs 2.41)
+    const int replay_from = alone ? std::max(idx->device_replay_nq, idx->device_replay_alone_nq) : idx->device_replay_nq;
+    s.dev_replay = idx->device_replay_nq > 0 && nq >= replay_from && (uint32_t)s.R <= replay_lanes_max_R();
     s.dist_batch = idx->dist != nullptr;
     if (s.dist_batch) s.dev_replay = true;                   // streams stay on the device for the gather (qadc_dist_collect)
     // A batch too small to fill the GPU splits every query's scan order over G workgroups (each tightens its bound on
@@ -957,9 +973,6 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     const uint32_t ccap = std::min<uint32_t>(idx->wgq_cand_cap, kQueryCandCap);
     HIPCHECK(s.d_qcands.ensure((size_t)nsub * ccap));
 
-    bool alone = true;
-    for (int i = 0; i < kSlots; ++i) alone = alone && (&idx->slot[i] == &s || !idx->slot[i].busy);
-    alone = alone && !idx->pre_slot[0].busy && !idx->pre_slot[1].busy;
     hipStream_t st = idx->stream;
     // A lone small query (the synchronous single-query call): its input — which partitions, their descriptors, the
     // float tables — fits the kernel-argument segment and rides in the dispatch packet; no copy precedes the launch.
@@ -1802,6 +1815,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "overlap_front") idx->overlap_front = value != 0;
     else if (n == "head_early") idx->head_early = value != 0;
     else if (n == "wgq_inline") idx->wgq_inline = value != 0;
+    else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);
     else if (n == "wgq_group") { idx->wgq_group = (int)std::max(0.0, std::min(value, 2.0)); idx->group_strikes = 0; }
     else if (n == "wgq_group_head") idx->wgq_group_head = (int)std::max(1.0, std::min(value, 4096.0));
     else if (n == "wgq_poll") idx->wgq_poll = value != 0;

@@ -1666,7 +1666,7 @@ __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restr
     }
 }
 
-// ---- large batches: the same arithmetic as two lean kernels ----
+// ---- the same arithmetic as two lean kernels (what every batch with dim % 4 == 0 and K <= 16384 takes) ----
 // coarse_assign_kernel keeps a query group's K distances in registers (64 accumulators per lane at K = 4096) and reads
 // its centroid rows one row per lane.  Under the pipelined IVF batches that is the most expensive kernel of the front.
 // Here (1) coarse_dist_kernel computes [16 queries] x [256 centroids] distance tiles — centroid tiles staged through LDS
@@ -1800,7 +1800,8 @@ void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq,
     // large batches share every centroid row between 4 queries (registers: KPT x 4 distances per thread)
 #define QADC_CA(N, QB) hipLaunchKernelGGL((coarse_assign_kernel<N, QB>), dim3((nq + QB - 1) / QB), dim3(256), (size_t)QB * dim * sizeof(float), \
                                           stream, d_queries, d_coarse, nq, K, dim, ma, d_dist, d_assign)
-    if (nq >= 256 && kpt <= 64 && ma <= K && dim % 4 == 0 && (reinterpret_cast<uintptr_t>(d_coarse) & 15) == 0 && d_dist) {
+    // (any batch size: even one query — 15 of its group's 16 rows idle — is through sooner than with a row per lane)
+    if (kpt <= 64 && ma <= K && dim % 4 == 0 && (reinterpret_cast<uintptr_t>(d_coarse) & 15) == 0 && d_dist) {
         hipLaunchKernelGGL(coarse_dist_kernel, dim3(kpt, (nq + kCDQ - 1) / kCDQ), dim3(256), 0, stream, d_queries, d_coarse, nq, K, dim, d_dist);
         if (kpt <= 4) hipLaunchKernelGGL(coarse_select_kernel<4>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
         else if (kpt <= 16) hipLaunchKernelGGL(coarse_select_kernel<16>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);

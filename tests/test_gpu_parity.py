@@ -869,6 +869,7 @@ def test_wgq_device_replay_lanes_and_host_replay_agree(pyqadc, po, R):
     idx.add_partitions(parts, labels)
     idx.finalize(0.05)
     idx.set_option("wgq", 2)
+    idx.set_option("device_replay_alone_nq", 0)                 # (a synchronous call would otherwise replay on the host below 400 queries)
     assign = np.stack([rng.permutation(K)[:ma] for _ in range(nq)]).astype(np.int32)
     qt = rand_qtables(rng, (nq, ma), M, 9)
     got = idx.scan_i8(assign, qt, R)
@@ -1223,6 +1224,7 @@ def test_wgq_grouped_second_phase_matches_oracle(pyqadc, po, M, nq, ma, head, bi
     idx.set_option("wgq", 2)
     idx.set_option("wgq_group", 2)
     idx.set_option("wgq_group_head", head)
+    idx.set_option("device_replay_alone_nq", 0)                 # (the grouped phase needs the device replay; see the test above)
     idx.set_option("profile", 1)
     K = len(sizes)
     big = [41, 44, 45, 46]

@@ -1,0 +1,29 @@
+"""IVF at the C3 shape, synchronous batches of a few dozen to a few hundred queries: which path is faster?"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "quick-adc_amd"))
+import pyqadc
+M, K, MA, dim, N, R = 16, 4096, 32, 128, 100_000_000, 100
+rng = np.random.default_rng(0)
+sizes = rng.multinomial(N, np.ones(K) / K)
+idx = pyqadc.Index(M)
+for p in range(K):
+    idx.add_partition_synthetic(int(sizes[p]), 1000 + p)
+idx.finalize(0.01)
+idx.set_pq(rng.normal(size=(M, 16, dim // M)).astype(np.float32))
+idx.set_coarse(rng.normal(size=(K, dim)).astype(np.float32))
+for nq in (1, 4, 16, 32, 64, 128, 192, 256):
+    q = rng.normal(size=(nq, dim)).astype(np.float32)
+    out = []
+    for opts in ({"wgq": 1}, {"wgq": 0}, {"wgq": 2}):
+        for k, v in opts.items():
+            idx.set_option(k, v)
+        for _ in range(3):
+            idx.search(q, MA, R)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            idx.search(q, MA, R)
+        out.append((time.perf_counter() - t0) / 10 * 1e3)
+    print("nq %4d: auto %.3f ms  level path %.3f ms  query kernel %.3f ms   (us/query %.1f / %.1f / %.1f)" % (
+        nq, out[0], out[1], out[2], out[0] * 1e3 / nq, out[1] * 1e3 / nq, out[2] * 1e3 / nq))
