@@ -92,7 +92,8 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * launch the queries of a batch as L2-sharing siblings), "share_codes_per_wg", "mq" (8 queries per pass),
  * "mq_codes_per_wg", "mq_min_wgs", "mq_min_tiles", "prescan_mq", "overlap_front", "head_early", "front_run_max",
  * "front_min_batch", "front_dist" (kernel and launch tuning), "device_replay_nq" (batches of at least this many
- * queries replay their candidate streams through the heap on the device; 0 = always on the host), "replay_threads";
+ * queries replay their candidate streams through the heap on the device; 0 = always on the host),
+ * "device_replay_alone_nq" (... from this many when nothing else is in flight: a synchronous call), "replay_threads";
  * the one-workgroup-per-query path: "wgq" (0 never, 1 auto, 2 always), "wgq_min_nq", "wgq_max_codes",
  * "wgq_small_codes", "wgq_capacity", "wgq_cand_cap", "wgq_variant", "wgq_split" / "wgq_split_codes" (workgroups a
  * small batch spreads one query over / codes each keeps at least), "wgq_inline" (a lone small query's input rides
