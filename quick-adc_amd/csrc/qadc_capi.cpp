@@ -22,6 +22,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <thread>
@@ -114,6 +117,74 @@ struct LevelLaunch {
     uint64_t maxn;  // longest run of the launch
     bool early;     // launched on the front stream, under the previous batch's long levels: counted, not event-timed
     int ev = -1;    // index of the HIP event recorded before the launch (the next one follows it), -1 = not timed
+};
+
+// A few persistent host threads for the heap replay of a batch's queries (queries are independent; the caller still
+// drives the library from one thread).  Spawning threads per batch costs ~50 us each — as much as replaying a dozen
+// queries — so the workers are started once and woken per batch; the calling thread takes tasks too.
+class WorkerPool {
+  public:
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // runs f(t) for t = 0 .. tasks-1 on up to `threads` threads (this one included)
+    template <typename F>
+    void run(int tasks, int threads, F&& f) {
+        threads = std::max(1, std::min(threads, tasks));
+        if (threads == 1) {
+            for (int t = 0; t < tasks; ++t) f(t);
+            return;
+        }
+        while ((int)th_.size() < threads - 1) th_.emplace_back([this] { loop(); });
+        std::function<void(int)> fn = f;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn;
+            tasks_ = tasks;
+            next_.store(0);
+            helpers_ = threads - 1;
+            active_ = 0;
+            ++gen_;
+        }
+        cv_work_.notify_all();
+        for (int t; (t = next_.fetch_add(1)) < tasks;) fn(t);
+        std::unique_lock<std::mutex> lk(m_);
+        helpers_ = 0;                                           // no worker starts on this job any more
+        cv_done_.wait(lk, [this] { return active_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return stop_ || (gen_ != seen && helpers_ > 0); });
+            if (stop_) return;
+            seen = gen_;
+            --helpers_;
+            ++active_;
+            std::function<void(int)>* fn = job_;
+            const int tasks = tasks_;
+            lk.unlock();
+            for (int t; (t = next_.fetch_add(1)) < tasks;) (*fn)(t);
+            lk.lock();
+            if (--active_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::function<void(int)>* job_ = nullptr;
+    std::atomic<int> next_{0};
+    int tasks_ = 0, helpers_ = 0, active_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
 };
 
 struct Slot {
@@ -305,6 +376,7 @@ struct qadc_index {
     int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
     int replay_threads = 0;            // 0 = auto
+    WorkerPool pool;                   // host replay workers (started on first use)
     uint32_t small_vec_per_wg = 512;  // 16-byte vectors one small-run workgroup covers
     uint32_t small_run = 1u << 17;  // runs shorter than this use the small-run kernel
     int variant = 0x0d;    // kernel tuning variant (see launch_scan_i8): U=2, non-temporal loads, chunked tiles
@@ -1480,16 +1552,12 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
     // drives the library from one thread
     const uint64_t pushes = s.out_off[s.nq];
     int nt = idx->replay_threads > 0 ? idx->replay_threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 8);
-    nt = std::max(1, std::min(nt, s.nq / 16));
-    if (pushes < 50000) nt = 1;
-    if (nt == 1) {
-        work(0, s.nq);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t)
-            th.emplace_back(work, (int)((int64_t)s.nq * t / nt), (int)((int64_t)s.nq * (t + 1) / nt));
-        for (auto& x : th) x.join();
-    }
+    nt = std::max(1, std::min(nt, s.nq / 2));
+    if (pushes < 4000) nt = 1;                                 // (waking the workers costs about as much as 4 K pushes)
+    // tasks of a few queries each, handed out dynamically: candidate counts differ from query to query
+    const int per = std::max(1, s.nq / (nt * 4));
+    const int tasks = (s.nq + per - 1) / per;
+    idx->pool.run(tasks, nt, [&](int t) { work(t * per, std::min(s.nq, (t + 1) * per)); });
     return QADC_OK;
 }
 

@@ -15,15 +15,19 @@ idx.set_pq(rng.normal(size=(M, 16, dim // M)).astype(np.float32))
 idx.set_coarse(rng.normal(size=(K, dim)).astype(np.float32))
 for nq in (1, 4, 16, 32, 64, 128, 192, 256):
     q = rng.normal(size=(nq, dim)).astype(np.float32)
-    out = []
+    out, p90 = [], []
     for opts in ({"wgq": 1}, {"wgq": 0}, {"wgq": 2}):
         for k, v in opts.items():
             idx.set_option(k, v)
         for _ in range(3):
             idx.search(q, MA, R)
-        t0 = time.perf_counter()
-        for _ in range(10):
+        ts = []
+        for _ in range(40):
+            t0 = time.perf_counter()
             idx.search(q, MA, R)
-        out.append((time.perf_counter() - t0) / 10 * 1e3)
-    print("nq %4d: auto %.3f ms  level path %.3f ms  query kernel %.3f ms   (us/query %.1f / %.1f / %.1f)" % (
-        nq, out[0], out[1], out[2], out[0] * 1e3 / nq, out[1] * 1e3 / nq, out[2] * 1e3 / nq))
+            ts.append(time.perf_counter() - t0)
+        ts = np.sort(np.array(ts)) * 1e3
+        out.append(float(np.median(ts)))
+        p90.append(float(ts[36]))
+    print("nq %4d: auto %.3f ms  level path %.3f ms  query kernel %.3f ms   (p90 %.3f / %.3f / %.3f)" % (
+        nq, out[0], out[1], out[2], p90[0], p90[1], p90[2]))
