@@ -2419,7 +2419,7 @@ namespace {
 // order — assign slot, then rank (= ascending code range), then position — through the reference's heap, sentinel first
 // (db_query_4.cpp:276).  myheaps: [ceil(nq / world)][R + 1] words, heap entries key | value << 32, then the size.
 void replay_my_share(const uint64_t* gathered, size_t bw, int world, int rank, int nq, int ma, int R, const int32_t* status,
-                     uint64_t* myheaps) {
+                     uint64_t* myheaps, WorkerPool* pool) {
     const int per = (nq + world - 1) / world;
     const size_t hw = (size_t)R + 1;
     auto work = [&](int j0, int j1) {
@@ -2450,13 +2450,11 @@ void replay_my_share(const uint64_t* gathered, size_t bw, int world, int rank, i
             o[R] = (uint64_t)bh.size();
         }
     };
-    const int nt = std::max(1, std::min<int>(std::min(per, 4), (int)std::thread::hardware_concurrency()));
-    if (nt == 1) {
+    const int nt = std::max(1, std::min<int>(std::min(per, 8), (int)std::thread::hardware_concurrency()));
+    if (nt == 1 || !pool) {
         work(0, per);
     } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(work, per * t / nt, per * (t + 1) / nt);
-        for (auto& x : th) x.join();
+        pool->run(per, nt, [&](int j) { work(j, j + 1); });     // one query per task: their stream lengths differ
     }
 }
 }  // namespace
@@ -2548,7 +2546,8 @@ int qadc_dist_merge_blocks_host(int world, int nq, int ma, int R, const uint64_t
     const int per = (nq + world - 1) / world;
     const size_t hw = (size_t)R + 1;
     std::vector<uint64_t> all((size_t)world * per * hw, 0);
-    for (int r = 0; r < world; ++r) replay_my_share(gathered, (size_t)block_words, world, r, nq, ma, R, nullptr, all.data() + (size_t)r * per * hw);
+    for (int r = 0; r < world; ++r)
+        replay_my_share(gathered, (size_t)block_words, world, r, nq, ma, R, nullptr, all.data() + (size_t)r * per * hw, nullptr);
     for (int q = 0; q < nq; ++q) {
         const uint64_t* o = all.data() + ((size_t)(q % world) * per + q / world) * hw;
         sizes[q] = (int32_t)o[R];
@@ -2679,7 +2678,7 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         std::memset(d.h_myheaps.p, 0, sizeof(uint64_t) * (size_t)per * hw);
         {
             ScopedMs timer(idx->prof.host_heap_ms);
-            replay_my_share(d.h_gathered.p, bw, world, d.rank, nq, s.ma, R, status, d.h_myheaps.p);
+            replay_my_share(d.h_gathered.p, bw, world, d.rank, nq, s.ma, R, status, d.h_myheaps.p, &idx->pool);
         }
         HIPCHECK(hipMemcpyAsync(d.d_myheaps.p, d.h_myheaps.p, sizeof(uint64_t) * (size_t)per * hw, hipMemcpyHostToDevice, st));
         const int rc2 = d.AllGather(d.d_myheaps.p, d.d_allheaps.p, (size_t)per * hw, /*ncclUint64*/ 5, d.comm, st);
