@@ -357,7 +357,7 @@ struct qadc_index {
     uint32_t share_codes_per_wg = 1u << 20;
     int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
     int device_replay_nq = 64;           // batches of at least this many queries replay their streams on the device (0 = never)
-    int device_replay_alone_nq = 400;    // ... a batch with nothing else in flight (one-workgroup-per-query path): from this many
+    int device_replay_alone_nq = 512;    // ... a batch with nothing else in flight (a synchronous call): from this many
     uint64_t front_run_max = 2u << 20;   // leading levels whose runs are at most this long join the front (0 = none); they are
                                          // counted with the small launches, not event-timed.  125M x 32: 2 Mi -4 %, 8 Mi +1 %
     uint64_t front_min_batch = 0;        // ... in batches of at least this many (code, query) pairs

@@ -45,7 +45,7 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
                 prescan_sample=int(rng.choice([64, 4096, 65536])), level_base=int(rng.choice([64, 512, 4096])),
                 level_growth=int(rng.choice([2, 4, 8])), overlap_front=int(rng.integers(0, 2)),
                 prescan_mq=int(rng.integers(0, 2)),
-                front_run_max=int(rng.choice([0, 4096, 8 << 20])), device_replay_nq=int(rng.choice([0, 1, 1])), device_replay_alone_nq=int(rng.choice([0, 0, 400])),
+                front_run_max=int(rng.choice([0, 4096, 8 << 20])), device_replay_nq=int(rng.choice([0, 1, 1])), device_replay_alone_nq=int(rng.choice([0, 0, 512])),
                 # one-workgroup-per-query path: workgroups per query, kernel variant, tiny stream / candidate capacities
                 wgq_split=int(rng.choice([1, 3, 8])), wgq_variant=int(rng.choice([0, 1, 2, 3])),
                 wgq_capacity=int(rng.choice([64, 4096])), wgq_cand_cap=int(rng.choice([64, 4096, 4096])),

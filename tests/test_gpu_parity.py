@@ -869,7 +869,7 @@ def test_wgq_device_replay_lanes_and_host_replay_agree(pyqadc, po, R):
     idx.add_partitions(parts, labels)
     idx.finalize(0.05)
     idx.set_option("wgq", 2)
-    idx.set_option("device_replay_alone_nq", 0)                 # (a synchronous call would otherwise replay on the host below 400 queries)
+    idx.set_option("device_replay_alone_nq", 0)                 # (a synchronous call would otherwise replay on the host below 512 queries)
     assign = np.stack([rng.permutation(K)[:ma] for _ in range(nq)]).astype(np.int32)
     qt = rand_qtables(rng, (nq, ma), M, 9)
     got = idx.scan_i8(assign, qt, R)

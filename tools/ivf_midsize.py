@@ -13,10 +13,10 @@ for p in range(K):
 idx.finalize(0.01)
 idx.set_pq(rng.normal(size=(M, 16, dim // M)).astype(np.float32))
 idx.set_coarse(rng.normal(size=(K, dim)).astype(np.float32))
-for nq in (1, 4, 16, 32, 64, 128, 192, 256):
+for nq in [int(x) for x in os.environ.get('NQS', '1,4,16,32,64,128,192,256').split(',')]:
     q = rng.normal(size=(nq, dim)).astype(np.float32)
     out, p90 = [], []
-    for opts in ({"wgq": 1}, {"wgq": 0}, {"wgq": 2}):
+    for opts in ([{"device_replay_alone_nq": 400}, {"device_replay_alone_nq": 100000}, {"device_replay_alone_nq": 0}] if os.environ.get("REPLAY_AB") else [{"wgq": 1}, {"wgq": 0}, {"wgq": 2}]):
         for k, v in opts.items():
             idx.set_option(k, v)
         for _ in range(3):
