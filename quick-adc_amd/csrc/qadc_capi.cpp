@@ -1463,7 +1463,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
     // copy disjoint ranges (the block was just written by the GPU: a single thread reads it at ~9 GB/s).
     {
         const bool split = s.wgq && s.wgq_G > 1;
-        bool simple = true;
+        bool simple = true, skipped = false;
         uint64_t total = 0, ncand = 0;
         for (int q = 0; q < s.nq && simple; ++q) {
             s.out_off[q] = total;
@@ -1472,12 +1472,16 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
                 continue;
             }
             const QueryOut& qs = s.h_qout[q];
-            if (!need_stream && s.dev_replay && s.h_heap_sizes[q] != 0xffffffffu) continue;
+            if (!need_stream && s.dev_replay && s.h_heap_sizes[q] != 0xffffffffu) {   // heap already built on the device
+                skipped = true;
+                continue;
+            }
             if (qs.flags & 4u) total += (uint64_t)qs.count + qs.reps;
             else simple = false;
         }
         if (simple) {
             s.out_off[s.nq] = total;
+            s.skipped_streams = skipped;
             if (s.out_entries.size() < total) s.out_entries.resize(total);
             for (int q = 0; q < s.nq * (split ? s.wgq_G : 1); ++q) ncand += s.h_qout[q].count;
             idx->prof.candidates += ncand;
@@ -1492,8 +1496,6 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
                         }
                     } else if (s.out_off[q + 1] > s.out_off[q]) {
                         std::memcpy(dst, s.h_entries + s.h_qout[q].out_off, sizeof(uint64_t) * (s.out_off[q + 1] - s.out_off[q]));
-                    } else if (!need_stream && s.dev_replay && s.h_heap_sizes[q] != 0xffffffffu) {
-                        s.skipped_streams = true;                // (same value from every thread)
                     }
                 }
             };
