@@ -75,3 +75,15 @@ def test_unsupported_m_rejected(pyqadc):
     h = C.c_void_p()
     rc = pyqadc.lib().qadc_index_create(C.byref(h), 8, 0)
     assert rc == -1 and b"Supported configurations are: (16,4) (32,4)" in pyqadc.lib().qadc_last_error()
+
+
+def test_worker_pool_under_thread_sanitizer(tmp_path):
+    """host/worker_pool.hpp (the host replay's persistent threads): 4000 jobs of 1..37 tasks on 1..9 threads, built with
+    ThreadSanitizer — every task runs exactly once, results are visible after run(), no race report."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pool_tsan")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-g", "-fsanitize=thread", "-pthread", "-Wall", "-Werror",
+                           os.path.join(root, "tests", "cpp", "pool_test.cpp"), "-o", exe])
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b"pool ok" in p.stdout and b"ThreadSanitizer" not in p.stderr, p.stderr.decode()[-2000:]
