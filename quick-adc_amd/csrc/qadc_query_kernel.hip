@@ -1236,14 +1236,22 @@ __global__ __launch_bounds__(64) void replay_heap_lanes_kernel(const uint32_t* _
     if (flags & (1u | 32u)) n = 0;                              // qmax too high: the reference exits, no result / fallback pending
     const uint64_t* __restrict__ src = stream + (size_t)(have ? q : 0) * cap;
     if (have && !host_replay && !(flags & 1u)) h.push((uint64_t)127 << 32);   // the sentinel: key 0, value 127
-    // four entries per lane in flight: the stream of a lane is sequential in memory, 8 bytes at a time
-    for (uint32_t j = 0; j < n; j += 4) {
-        uint64_t e4[4];
+    // The stream of a lane is sequential in memory, 8 bytes at a time, a different cache line per lane: the next eight
+    // entries are requested BEFORE the current eight are pushed, so that their latency (a microsecond or two for 64
+    // scattered lines) passes under ~8 us of heap work instead of in front of it.
+    constexpr int kPF = 8;
+    uint64_t nxt[kPF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e4[u] = j + u < n ? src[j + u] & 0xffffffffffull : 0;
+    for (int u = 0; u < kPF; ++u) nxt[u] = (uint32_t)u < n ? src[u] : 0;
+    for (uint32_t j = 0; j < n; j += kPF) {
+        uint64_t cur[kPF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (j + u < n) h.push(e4[u]);
+        for (int u = 0; u < kPF; ++u) cur[u] = nxt[u] & 0xffffffffffull;
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) nxt[u] = j + kPF + u < n ? src[j + kPF + u] : 0;
+#pragma unroll
+        for (int u = 0; u < kPF; ++u)
+            if (j + u < n) h.push(cur[u]);
     }
     lane_heaps_out(h.hv, lane, h.size, host_replay, blockIdx.x * 64, nq, R, heaps, heap_sizes);
 }
