@@ -1182,23 +1182,24 @@ struct LaneHeap {
         // always sinks to the bottom).
         const bool accept = value < val_of(at(0));
         if (__builtin_amdgcn_ballot_w64(accept) == 0) return;
+        // Branch-free levels: both children are read from clamped slots whether they exist or not and the shifted child
+        // is stored either to the hole or to a scratch row (slot R) — a predicated read or store costs an exec-mask round
+        // trip with its scalar bookkeeping, which doubled the length of this dependent chain.
         bool sinking = accept;
         uint32_t i = 0;
         for (uint32_t lvl = 0; lvl < depth; ++lvl) {
             const uint32_t l = 2 * i + 1;
+            const uint64_t le = at(min(l, R - 1)), re = at(min(l + 1, R - 1));
             const bool has_l = sinking && l < size, has_r = sinking && l + 1 < size;
-            const uint64_t le = has_l ? at(l) : 0, re = has_r ? at(l + 1) : 0;
-            uint64_t ce = le;
-            uint32_t c = l;
-            if (has_r && val_of(re) > val_of(le)) { ce = re; c = l + 1; }
+            const bool right = has_r && val_of(re) > val_of(le); // the right child only if strictly greater
+            const uint64_t ce = right ? re : le;
+            const uint32_t c = right ? l + 1 : l;
             const bool down = has_l && val_of(ce) > value;       // stop at a child <= the value
-            if (down) {
-                at(i) = ce;
-                i = c;
-            }
+            at(down ? i : R) = ce;
+            i = down ? c : i;
             sinking = down;
         }
-        if (accept) at(i) = e;
+        at(accept ? i : R) = e;
     }
 };
 
@@ -1438,14 +1439,14 @@ hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uin
     return hipGetLastError();
 }
 
-uint32_t replay_lanes_max_R() { return 288; }                    // R * 512 B of LDS per wave (<= 144 KiB)
+uint32_t replay_lanes_max_R() { return 288; }                    // (R + 1) * 512 B of LDS per wave (<= 144.5 KiB): R slots + a scratch row
 
 static hipError_t lane_heap_lds_optin(const void* fn, uint64_t& done) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 64 && !(done & (1ull << dev))) {
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(replay_lanes_max_R() * 512));
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((replay_lanes_max_R() + 1) * 512));
         if (e != hipSuccess) return e;
         done |= 1ull << dev;
     }
@@ -1466,7 +1467,7 @@ hipError_t launch_dist_merge_lanes(const uint64_t* d_gathered, size_t block_word
     if (world > 16) return hipErrorInvalidValue;
     hipError_t e = lane_heap_lds_optin(reinterpret_cast<const void*>(&dist_merge_lanes_kernel), done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dist_merge_lanes_kernel, dim3((nq + 63) / 64), dim3(64), (size_t)R * 512, stream, d_gathered, block_words,
+    hipLaunchKernelGGL(dist_merge_lanes_kernel, dim3((nq + 63) / 64), dim3(64), ((size_t)R + 1) * 512, stream, d_gathered, block_words,
                        world, nq, ma, R, d_heaps, d_heap_sizes);
     return hipGetLastError();
 }
@@ -1479,11 +1480,11 @@ hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_
     static uint64_t done = 0;
     if (dev < 64 && !(done & (1ull << dev))) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&replay_heap_lanes_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(replay_lanes_max_R() * 512));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)((replay_lanes_max_R() + 1) * 512));
         if (e != hipSuccess) return e;
         done |= 1ull << dev;
     }
-    hipLaunchKernelGGL(replay_heap_lanes_kernel, dim3((nq + 63) / 64), dim3(64), (size_t)R * 512, stream, d_qflags, d_stream,
+    hipLaunchKernelGGL(replay_heap_lanes_kernel, dim3((nq + 63) / 64), dim3(64), ((size_t)R + 1) * 512, stream, d_qflags, d_stream,
                        cap, nq, R, d_heaps, d_heap_sizes);
     return hipGetLastError();
 }
