@@ -339,6 +339,20 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) u64x2* lds_row_t;
 
+// inclusive wave scan on the DPP path (row shifts + row broadcasts, 7 VALU operations) — __shfl_up goes through the LDS
+// crossbar, ~100 cycles per hop in a dependent chain of six
+__device__ __forceinline__ uint32_t dpp_wave_incl_sum(uint32_t x) {
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);   // row_shr:3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);   // row_shr:4, banks 1-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);   // row_shr:8, banks 2-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // wave-level prefix bound (no LDS, no barrier): lane l owns value bins 2l and 2l+1
 __device__ __forceinline__ uint32_t prefix_bound_wave(const QueryState* qs, int level, uint32_t R, uint32_t lane) {
     uint32_t c0 = 0, c1 = 0;
@@ -347,19 +361,12 @@ __device__ __forceinline__ uint32_t prefix_bound_wave(const QueryState* qs, int 
         c0 += h.x;
         c1 += h.y;
     }
-    uint32_t incl = c0 + c1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += o;
-    }
+    const uint32_t incl = dpp_wave_incl_sum(c0 + c1);
     const uint32_t excl = incl - (c0 + c1);
-    uint32_t b = 127;
-    if (excl + c0 >= R) b = 2 * lane;
-    else if (incl >= R) b = 2 * lane + 1;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) b = min(b, (uint32_t)__shfl_xor(b, d, 64));
-    return min(b, 127u);
+    const uint64_t reached = __builtin_amdgcn_ballot_w64(incl >= R);
+    if (reached == 0) return 127u;
+    const uint32_t b = excl + c0 >= R ? 2 * lane : 2 * lane + 1;   // (meaningful in the first lane that reaches R)
+    return min((uint32_t)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(reached)), 127u);
 }
 
 // (byte K of d) & mask in ONE VALU instruction (sub-dword operand select); the compiler finds this form for only a
