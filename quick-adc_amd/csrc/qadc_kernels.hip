@@ -94,6 +94,20 @@ __device__ __forceinline__ void build_pair_tables(const int8_t* __restrict__ qt)
     for (int r = 0; r < REPL / 4; ++r) reinterpret_cast<uint4*>(dst)[r] = w4;
 }
 
+// inclusive wave scan on the DPP path (row shifts + row broadcasts, 7 VALU operations) — __shfl_up goes through the LDS
+// crossbar, ~100 cycles per hop in a dependent chain of six
+__device__ __forceinline__ uint32_t dpp_wave_incl_sum(uint32_t x) {
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);   // row_shr:3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);   // row_shr:4, banks 1-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);   // row_shr:8, banks 2-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // bound = smallest v with #(emitted candidates of all earlier levels with value <= v) >= R, else 127.
 // Valid for every code of this level because those candidates all precede it in scan order.
 __device__ __forceinline__ uint32_t prefix_bound(const QueryState* qs, int level, uint32_t R, uint32_t* lds_hist,
@@ -107,19 +121,12 @@ __device__ __forceinline__ uint32_t prefix_bound(const QueryState* qs, int level
     __syncthreads();
     if (t < 64) {
         const uint32_t c0 = lds_hist[2 * t], c1 = lds_hist[2 * t + 1];
-        uint32_t incl = c0 + c1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (t >= d) incl += o;
-        }
+        const uint32_t incl = dpp_wave_incl_sum(c0 + c1);
         const uint32_t excl = incl - (c0 + c1);
-        uint32_t b = 127;
-        if (excl + c0 >= R) b = 2 * t;
-        else if (incl >= R) b = 2 * t + 1;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) b = min(b, (uint32_t)__shfl_xor(b, d, 64));
-        if (t == 0) *lds_bound = min(b, 127u);
+        const uint64_t reached = __builtin_amdgcn_ballot_w64(incl >= R);
+        uint32_t b = excl + c0 >= R ? 2 * t : 2 * t + 1;         // (meaningful in the first lane that reaches R)
+        b = reached ? min((uint32_t)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(reached ? reached : 1)), 127u) : 127u;
+        if (t == 0) *lds_bound = b;
     }
     __syncthreads();
     return *lds_bound;
@@ -338,20 +345,6 @@ typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) u64x2* lds_row_t;
-
-// inclusive wave scan on the DPP path (row shifts + row broadcasts, 7 VALU operations) — __shfl_up goes through the LDS
-// crossbar, ~100 cycles per hop in a dependent chain of six
-__device__ __forceinline__ uint32_t dpp_wave_incl_sum(uint32_t x) {
-    uint32_t v = x;
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);   // row_shr:3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);   // row_shr:4, banks 1-3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);   // row_shr:8, banks 2-3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-    return v;
-}
 
 // wave-level prefix bound (no LDS, no barrier): lane l owns value bins 2l and 2l+1
 __device__ __forceinline__ uint32_t prefix_bound_wave(const QueryState* qs, int level, uint32_t R, uint32_t lane) {
@@ -1484,12 +1477,7 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
         if (tid < 64) {                                    // wave 0: 4 bins per lane, inclusive scan, pick the digit
             const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
             const uint32_t mine = c0 + c1 + c2 + c3;
-            uint32_t incl = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d, 64);
-                if (tid >= d) incl += o;
-            }
+            const uint32_t incl = dpp_wave_incl_sum(mine);
             const uint32_t excl = incl - mine;
             if (incl >= k && excl < k) {                   // exactly one lane
                 uint32_t run = excl, digit = 4 * tid;
