@@ -363,34 +363,40 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000):
     for kv in filter(None, os.environ.get("QADC_BENCH_IVF_OPTS", "").split(",")):  # tuning experiments only
         idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     qs = [rng.normal(size=(NQB, dim)).astype(np.float32) for _ in range(4)]
-    def pipelined(batches, steps, depth=3):
+    def pipelined(batches, steps, depth=3, warm=True):
         for w in range(depth):                             # every slot used below sizes its buffers before the clock starts
             idx.search_submit(w, batches[w], MA, R)
         for w in range(depth):
             idx.search_collect(w)
-        idx.profile_reset()
+        if warm:                                           # ... and one untimed pass in the steady state of the loop below
+            pipelined(batches, 2 * depth, depth, warm=False)   # (runtime-side lazy growth under a full pipeline was seen to
+        idx.profile_reset()                                #  stall a first timed pass by tens of milliseconds)
         t0 = time.perf_counter()
         pend, nc = [], 0
+        stamps = []
         for s in range(steps):
+            stamps.append(time.perf_counter())
             idx.search_submit(s % depth, batches[s % 4], MA, R)
             pend.append(s % depth)
             if len(pend) == depth:
                 nc += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
+        if os.environ.get("QADC_BENCH_IVF_STEPLOG"):
+            print("ivf steps (ms):", [round((b - a) * 1e3, 2) for a, b in zip(stamps, stamps[1:])], file=sys.stderr)
         while pend:
             nc += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
         return time.perf_counter() - t0, nc
 
-    steps, depth = 16, int(os.environ.get("QADC_BENCH_IVF_DEPTH", 4))          # all four submission slots of the C-ABI in use
+    steps, depth = 48, int(os.environ.get("QADC_BENCH_IVF_DEPTH", 4))          # all four submission slots of the C-ABI in use
     dt, ncodes = pipelined(qs, steps, depth)
     p = idx.profile()
     qs2 = [rng.normal(size=(2 * NQB, dim)).astype(np.float32) for _ in range(4)]       # and at twice the batch size
-    dt2, _ = pipelined(qs2, 8, depth)
+    dt2, _ = pipelined(qs2, 24, depth)
     idx.close()
     gbs = ncodes * (M // 2) / dt / 1e9
     return {"workload": "IVF, %d x %dx4 codes (%d-d vectors) in K=%d partitions (multinomial sizes), nprobe=%d, R=%d, keep=%.0f%%, "
                         "%d-query batches, %d in flight, queries in -> heaps out (qadc_search)" % (N, M, dim, K, MA, R, KEEP * 100, NQB, depth),
             "codes_per_sec": ncodes / dt, "us_per_query": dt * 1e6 / (steps * NQB), "queries_per_sec": steps * NQB / dt,
-            "us_per_query_at_2048_query_batches": dt2 * 1e6 / (8 * 2 * NQB),
+            "us_per_query_at_2048_query_batches": dt2 * 1e6 / (24 * 2 * NQB),
             "probed_codes_per_query": ncodes / (steps * NQB),
             "algorithmic_GBps": gbs,
             "algorithmic_GBps_rule": "M/2 B x probed codes / wall time of the pipelined batches (whole path, not one kernel; "
@@ -511,6 +517,13 @@ def main():
     import torch.distributed as dist
     import pyqadc
     from pyqadc import sharded
+    # The interpreter's cyclic garbage collector stays off for the rest of the run: with torch loaded a full collection
+    # walks a few hundred thousand objects (~50 ms — sixty 1024-query IVF batches, or forty steps of a 1/8 shard), and
+    # when it fires depends on how many objects earlier legs allocated.  The loops below create no reference cycles.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Quick-ADC engine has no CPU path")
