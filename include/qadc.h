@@ -100,7 +100,7 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * in the kernel arguments), "wgq_poll" (... and its completion is read from the mapped result block),
  * "wgq_group" (large IVF batches: partition-major second phase; 0 never, 1 auto, 2 whenever possible),
  * "wgq_group_head" (probes per query the one-workgroup-per-query head walks before it),
- * "head_level", "table_form", "dist_cap_entries", "dist_device_nq". */
+ * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_inject_failure" (test hook). */
 int qadc_set_option(qadc_index* idx, const char* name, double value);
 
 /* Copy codes back (tests / checksums): partition `part`, codes [first, first+count). */
@@ -273,7 +273,12 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
  * so there is no second collective.  `extra` (optional, extra_n floats per rank) rides in the same all-gather and comes
  * back as extra_out[world][extra_n]: the multi-rank loop of bench.py ships the next batch's sharded pre-scan values
  * this way (qadc_prescan_submit).  RCCL is loaded with dlopen by qadc_dist_unique_id / qadc_dist_init; a single-GPU
- * user never loads it.  R <= 288 (the replay keeps 64 heaps per wave in LDS); world <= 16.
+ * user never loads it.  world <= 16.  Any R: the lane-per-query device replay holds R <= 288 (64 heaps per wave in LDS),
+ * larger heaps take the host-share replay.  A query some rank could not order on the device (> 16384 candidates) is
+ * sorted on that rank's host and shipped in the same gather.  A rank whose batch failed locally still takes part in the
+ * gather with a failure flag in its header, so every rank returns an error instead of one rank leaving the others
+ * blocked.  A batch submitted after qadc_dist_init may still be collected with the plain collect calls (host replay
+ * of this rank's streams only).
  *   rank 0:      qadc_dist_unique_id(id)  ... ship the 128 bytes to the other ranks by any means ...
  *   every rank:  qadc_dist_init(idx, rank, world, id);  then per batch  qadc_query_scan_submit(...); qadc_dist_collect(...) */
 #define QADC_DIST_ID_BYTES 128
@@ -282,6 +287,35 @@ int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128);
 int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
                       const float* extra, int extra_n, float* extra_out);
 int qadc_dist_shutdown(qadc_index* idx);
+/* The same merge over a caller-supplied all-gather instead of RCCL (no counterpart in the reference): `fn` gathers
+ * bytes_per_rank bytes of DEVICE memory from every rank into d_recv[world][bytes_per_rank] (rank order), is called with
+ * the producing work already enqueued on hip_stream, and must have completed (or be ordered on hip_stream) when it
+ * returns 0; any other return value fails the collect on this rank.  Every rank must call it the same number of times
+ * with the same size — qadc_dist_collect guarantees that, including on its retry and failure paths.  Uses: ranks that
+ * share one GPU (a single-GPU box exercising world > 1), hosts without librccl, MPI or other fabrics. */
+typedef int (*qadc_allgather_fn)(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* hip_stream);
+int qadc_dist_init_transport(qadc_index* idx, int rank, int world, qadc_allgather_fn fn, void* ctx);
+/* Built-in transport for qadc_dist_init_transport: host-staged all-gather through a POSIX shared-memory segment `name`
+ * ("/something", unique per run; rank 0 creates it, the others wait up to timeout_s seconds — 0 = 120 s — for it).
+ * slot_bytes = largest block a rank may contribute (a gather beyond it fails on every rank alike).  Barriers time out
+ * after timeout_s and poison the segment, so a missing rank turns into an error instead of a hang.
+ *   qadc_shm_transport_open(name, rank, world, slot_bytes, timeout_s, &ctx);
+ *   qadc_dist_init_transport(idx, rank, world, qadc_shm_transport_allgather, ctx);  ...  qadc_shm_transport_close(ctx);
+ * _allgather_host exchanges host buffers (no GPU): the CPU-side test of the protocol. */
+int qadc_shm_transport_open(const char* name, int rank, int world, uint64_t slot_bytes, double timeout_s, void** out_ctx);
+int qadc_shm_transport_allgather(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* hip_stream);
+int qadc_shm_transport_allgather_host(void* ctx, const void* send, void* recv, uint64_t bytes_per_rank);
+int qadc_shm_transport_close(void* ctx);
+const char* qadc_shm_transport_error(void);
+/* The probed partitions of the batch last collected from `slot` (qadc_search_submit computes assign[] on the GPU;
+ * qadc_dist_collect has no assign_out): assign_out [nq][ma]. */
+int qadc_slot_assign(qadc_index* idx, int slot, int32_t* assign_out);
+/* Size-balanced placement of whole partitions on `world` ranks (IVF option 1): partitions in descending
+ * size order, each to the currently lightest rank (ties: lowest rank).  owner_out[p] = rank of partition p.  A rank adds
+ * the partitions it owns in full and the others with local_n = 0 (starts replica only, qadc_index_add_partition_shard),
+ * so partition numbering — and assign[] — is the same on every rank and the merge order (assign slot, rank, position)
+ * degenerates to (assign slot, position).  Host-only. */
+int qadc_place_partitions(int part_count, const uint32_t* sizes, int world, int32_t* owner_out);
 /* The merge half of qadc_dist_collect on a caller-assembled gather result (host memory; `world` blocks of block_words
  * u64 each: [nq x {offset, count, flags, 0} as u32][entries = key | value << 32 | assign slot << 40]...): lets a single
  * GPU check the multi-rank replay order.  sizes[q] = -1 when a block reports an overflow / unordered query. */

@@ -156,6 +156,7 @@ struct Slot {
     DevBuf<uint64_t> d_stream;
     uint64_t* h_heaps = nullptr;
     uint32_t* h_heap_sizes = nullptr;
+    bool heaps_ready = false;           // a replay kernel ran for the batch: h_heaps / h_heap_sizes hold its result
     bool skipped_streams = false;       // collect_common left device-replayed queries' streams unassembled
     QueryOut* h_qout = nullptr;
     uint64_t* h_entries = nullptr;
@@ -227,6 +228,8 @@ struct DistState {
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     void* comm = nullptr;
+    qadc_allgather_fn user_fn = nullptr;                     // qadc_dist_init_transport: the caller's all-gather instead of RCCL
+    void* user_ctx = nullptr;
     hipStream_t stream = nullptr;                            // own high-priority stream: the merge of batch s must not queue
                                                              // behind the scan kernels of batches s+1.. on the main stream
     int rank = 0, world = 1;
@@ -234,6 +237,8 @@ struct DistState {
     DevBuf<uint64_t> d_block, d_gathered;
     DevBuf<uint32_t> d_src;                                  // [3][nq]: offset, count, flags of this rank's streams
     PinBuf<uint32_t> h_src;
+    DevBuf<uint64_t> d_fix;                                  // streams of the queries this rank had to order on the host
+    PinBuf<uint64_t> h_fix;
     DevBuf<float> d_extra;
     PinBuf<float> h_extra;
     PinBuf<unsigned char> h_out;                             // mapped: heaps u64[nq][R], sizes u32[nq]
@@ -249,6 +254,19 @@ struct DistState {
     DevBuf<uint64_t> d_myheaps, d_allheaps;
     PinBuf<uint64_t> h_allheaps;
     int device_nq = 256;                                     // batches of at least this many queries replay on the device
+    int inject_failure = 0;                                  // test hook: the next qadc_dist_collect of this rank fails locally
+    // One all-gather of `words` u64 per rank on `st`: RCCL (enqueued, stream-ordered) or the caller's transport
+    // (complete on return).  0 = ok; else the message is in `err`.
+    int gather(const void* d_send, void* d_recv, size_t words, hipStream_t st, std::string& err) {
+        if (user_fn) {
+            const int rc = user_fn(user_ctx, d_send, d_recv, (uint64_t)words * sizeof(uint64_t), st);
+            if (rc != 0) err = "the transport's all-gather failed (code " + std::to_string(rc) + ")";
+            return rc;
+        }
+        const int rc = AllGather(d_send, d_recv, words, /*ncclUint64*/ 5, comm, st);
+        if (rc != 0) err = std::string("ncclAllGather: ") + (GetErrorString ? GetErrorString(rc) : "error");
+        return rc;
+    }
 };
 
 int load_rccl(DistState& d, std::string& err) {
@@ -865,7 +883,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     }
     launch_sort_cands(s.d_qs, s.d_cands.p, s.cap_q, nq, s.d_qout, s.d_entries, s.out_cap, s.d_hdr, st,
                       dev_stream ? s.d_stream.p : nullptr);
-    if (s.dev_replay)
+    s.heaps_ready = s.dev_replay && !s.dist_batch;           // (a merge batch is replayed after the gather, not here)
+    if (s.heaps_ready)
         launch_replay_heap(s.d_qs, s.d_stream.p, s.out_cap, nq, (uint32_t)s.R,
                            reinterpret_cast<uint64_t*>(d_result + off_heaps),
                            reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq), st);
@@ -923,6 +942,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     const int replay_from = alone ? std::max(idx->device_replay_nq, idx->device_replay_alone_nq) : idx->device_replay_nq;
     s.dev_replay = idx->device_replay_nq > 0 && nq >= replay_from && (uint32_t)s.R <= replay_lanes_max_R();
     s.dist_batch = idx->dist != nullptr;
+    s.heaps_ready = s.dev_replay && !s.dist_batch;
     if (s.dist_batch) s.dev_replay = true;                   // streams stay on the device for the gather (qadc_dist_collect)
     // A batch too small to fill the GPU splits every query's scan order over G workgroups (each tightens its bound on
     // the query's first block, then scans its own chunk); the sub-streams are concatenated in workgroup order.
@@ -1053,7 +1073,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     const int head_slots = std::min(idx->wgq_group_head, ma);
     const size_t pairs = (size_t)nq * (size_t)(ma - head_slots);
     const size_t nparts = idx->parts.size();
-    s.wgq_grouped = s.dev_replay && !s.dist_batch && G == 1 && pairs > 0 && nparts < (1u << 24) &&
+    s.wgq_grouped = s.dev_replay && G == 1 && pairs > 0 && nparts < (1u << 24) &&
                     (idx->wgq_group == 2 || (idx->wgq_group == 1 && idx->group_strikes < 2 && nq >= 256 && pairs >= 2 * nparts));
     if (s.wgq_grouped) {
         const size_t state_bytes = 64 + sizeof(QueryState) * (size_t)nq;
@@ -1100,7 +1120,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             st = (idx->replay_seq++ & 1) ? idx->front_stream : idx->sort_stream;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
         }
-        if (!s.dist_batch)
+        if (s.heaps_ready)
         HIPCHECK(launch_replay_heap_lanes(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R,
                                           reinterpret_cast<uint64_t*>(d_result + off_heaps),
                                           reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq), st));
@@ -1236,12 +1256,16 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
 // Waits for the batch, regrows and re-runs on overflow, and lays the ordered candidate streams
 // (padding-lane replays expanded) out in s.out_*.  Queries the device could not sort (more than
 // kSortCap candidates) are sorted here.
-int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
+// from_dist: the caller is qadc_dist_collect, which consumes the ordered streams where they lie in device memory; a batch
+// submitted under the multi-GPU merge but collected by a plain collect call has no device-side heaps and, on the
+// one-workgroup-per-query path, no host copy of its streams: they are fetched and replayed on the host.
+int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool from_dist = false) {
     if (!idx) return fail(QADC_E_ARG, "null index");
     if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1, 2 or 3");
     Slot& s = idx->slot[slot_i];
     if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
     if (int rc = use_device(idx)) return rc;
+    if (s.dist_batch && !from_dist) need_stream = true;
     const uint32_t sort_limit_max = kSortCap;
     uint64_t total_sorted = 0;
     if (s.assign_on_device) {                                  // qadc_search: assign[] comes back for the caller (and the planner)
@@ -1374,13 +1398,14 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
     const auto t0 = std::chrono::steady_clock::now();
     s.out_off.assign((size_t)s.nq + 1, 0);                       // (out_entries keeps its size as a high-water mark: out_off[nq] is the length)
     s.skipped_streams = false;
-    if (s.wgq && s.dev_replay && !s.dist_batch) {
+    const bool streams_stay = s.dist_batch && from_dist;         // consumed in device memory by the gather's pack kernel
+    if (s.wgq && s.dev_replay && !streams_stay) {
         // the streams stayed in device memory; fetch them only if the caller wants them (or a query could not be
         // replayed on the device): one strided copy of the used part of every query's region
         bool need = need_stream;
         uint32_t max_count = 0;
         for (int q = 0; q < s.nq; ++q) {
-            need = need || s.h_heap_sizes[q] == 0xffffffffu;
+            need = need || (s.heaps_ready && s.h_heap_sizes[q] == 0xffffffffu);
             max_count = std::max(max_count, s.h_qout[q].count);
         }
         if (need && max_count) {
@@ -1405,7 +1430,8 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
                 continue;
             }
             const QueryOut& qs = s.h_qout[q];
-            if (!need_stream && s.dev_replay && s.h_heap_sizes[q] != 0xffffffffu) {   // heap already built on the device
+            if ((!need_stream && s.heaps_ready && s.h_heap_sizes[q] != 0xffffffffu) ||   // heap already built on the device
+                (streams_stay && (qs.flags & 4u))) {                                     // ... or the gather takes it from there
                 skipped = true;
                 continue;
             }
@@ -1455,7 +1481,8 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true) {
         const QueryOut& qs = s.h_qout[q];
         s.out_off[q] = s.out_entries.size();
         idx->prof.candidates += qs.count;
-        if (!need_stream && s.dev_replay && s.h_heap_sizes[q] != 0xffffffffu) {   // heap already built on the device
+        if ((!need_stream && s.heaps_ready && s.h_heap_sizes[q] != 0xffffffffu) ||   // heap already built on the device
+            (streams_stay && (qs.flags & 4u))) {
             s.skipped_streams = true;
             continue;
         }
@@ -1514,7 +1541,7 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
                 if (sizes) sizes[q] = 0;
                 continue;
             }
-            if (s.dev_replay && s.skipped_streams && s.h_heap_sizes[q] != 0xffffffffu) {   // replayed by replay_heap_kernel
+            if (s.heaps_ready && s.skipped_streams && s.h_heap_sizes[q] != 0xffffffffu) {   // replayed by replay_heap_kernel
                 const uint32_t sz = s.h_heap_sizes[q];
                 const uint64_t* hv = s.h_heaps + (size_t)q * s.R;
                 if (sizes) sizes[q] = (int32_t)sz;
@@ -1565,11 +1592,16 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     idx->M = M;
     idx->cs = M / 2;
     idx->device = device_id;
-    if (const char* e = std::getenv("QADC_WGQ")) idx->wgq = std::atoi(e);   // test hook: force (2) / forbid (0) the one-workgroup-per-query path
-    if (const char* e = std::getenv("QADC_WGQ_POLL")) idx->wgq_poll = std::atoi(e);     // test hooks for the lone-small-batch shortcuts
-    if (const char* e = std::getenv("QADC_WGQ_INLINE")) idx->wgq_inline = std::atoi(e);
-    if (const char* e = std::getenv("QADC_WGQ_GROUP")) idx->wgq_group = std::max(0, std::min(std::atoi(e), 2));
-    if (const char* e = std::getenv("QADC_HEAD_LEVEL")) idx->head_level = std::max(0, std::min(std::atoi(e), kMaxLevels - 1));   // test hook
+    // Test hooks (tests/conftest.py runs every parity test through every scan path this way).  They only apply when
+    // QADC_TEST_HOOKS=1 is set as well, so that a stray QADC_* variable in a deployment cannot change the scan path.
+    const char* hooks = std::getenv("QADC_TEST_HOOKS");
+    if (hooks && std::atoi(hooks) == 1) {
+        if (const char* e = std::getenv("QADC_WGQ")) idx->wgq = std::atoi(e);   // force (2) / forbid (0) the one-workgroup-per-query path
+        if (const char* e = std::getenv("QADC_WGQ_POLL")) idx->wgq_poll = std::atoi(e);     // the lone-small-batch shortcuts
+        if (const char* e = std::getenv("QADC_WGQ_INLINE")) idx->wgq_inline = std::atoi(e);
+        if (const char* e = std::getenv("QADC_WGQ_GROUP")) idx->wgq_group = std::max(0, std::min(std::atoi(e), 2));
+        if (const char* e = std::getenv("QADC_HEAD_LEVEL")) idx->head_level = std::max(0, std::min(std::atoi(e), kMaxLevels - 1));
+    }
     // The streaming launches fill every CU for milliseconds.  They go on the LOWEST-priority queue so that the
     // short work that must overlap them is dispatched as soon as a workgroup slot frees up instead of waiting for
     // the whole batch: the previous batch's candidate sort, the next batch's front (own streams, highest priority) and
@@ -1594,6 +1626,8 @@ int qadc_index_destroy(qadc_index* idx) {
     // a pre-scan (front stream) or an on-demand copy may still be in flight: drain all four streams before freeing
     for (hipStream_t st : {idx->stream, idx->front_stream, idx->copy_stream, idx->sort_stream})
         if (st) (void)hipStreamSynchronize(st);
+    (void)qadc_dist_shutdown(idx);      // drains the merge's stream and frees the communicator while the index's streams and
+                                        // the slot buffers the pack kernel reads are still alive
     for (auto& p : idx->parts) {
         if (p.own) {
             if (p.d_codes) (void)hipFree(p.d_codes);
@@ -1625,7 +1659,6 @@ int qadc_index_destroy(qadc_index* idx) {
     if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
     if (idx->front_stream) (void)hipStreamDestroy(idx->front_stream);
     if (idx->sort_stream) (void)hipStreamDestroy(idx->sort_stream);
-    (void)qadc_dist_shutdown(idx);
     delete idx;
     return QADC_OK;
 }
@@ -1897,6 +1930,10 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "dist_device_nq") {                         // batches of at least this many queries replay on the device
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
         idx->dist->device_nq = (int)std::max(1.0, value);
+    }
+    else if (n == "dist_inject_failure") {                    // test hook: this rank's next qadc_dist_collect fails before the gather
+        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
+        idx->dist->inject_failure = value != 0;
     }
     else if (n == "table_form") idx->table_form = std::max(0, std::min((int)value, 2));
     else if (n == "wgq_cand_cap") idx->wgq_cand_cap = (uint32_t)std::max(1.0, std::min(value, (double)kQueryCandCap));
@@ -2457,19 +2494,43 @@ int qadc_dist_unique_id(uint8_t* id128) {
     return QADC_OK;                                          // (the library handle stays loaded for the process)
 }
 
-int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
-    if (!idx || !id128 || world < 1 || world > 16 || rank < 0 || rank >= world) return fail(QADC_E_ARG, "need 0 <= rank < world <= 16");
+extern "C++" {
+namespace {
+// Releases a half-built DistState on every exit path of the init calls (communicator, stream).
+struct DistGuard {
+    std::unique_ptr<DistState> d;
+    ~DistGuard() {
+        if (!d) return;
+        if (d->stream) { (void)hipStreamSynchronize(d->stream); }
+        if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
+        if (d->stream) (void)hipStreamDestroy(d->stream);
+    }
+};
+int dist_init_checks(qadc_index* idx, int rank, int world) {
+    if (!idx || world < 1 || world > 16 || rank < 0 || rank >= world) return fail(QADC_E_ARG, "need 0 <= rank < world <= 16");
     if (idx->dist) return fail(QADC_E_STATE, "qadc_dist_init was already called");
     for (auto& sl : idx->slot)
         if (sl.busy) return fail(QADC_E_STATE, "collect every batch before qadc_dist_init");
-    if (int rc = use_device(idx)) return rc;
-    std::unique_ptr<DistState> d(new DistState());
+    return use_device(idx);
+}
+}  // namespace
+}  // extern "C++"
+
+int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
+    if (!id128) return fail(QADC_E_ARG, "id is null");
+    if (int rc = dist_init_checks(idx, rank, world)) return rc;
+    DistGuard g;
+    g.d.reset(new DistState());
+    DistState* d = g.d.get();
     std::string err;
     if (load_rccl(*d, err)) return fail(QADC_E_HIP, err);
     QadcNcclId id;
     std::memcpy(id.internal, id128, 128);
     const int rc = d->CommInitRank(&d->comm, world, id, rank);
-    if (rc != 0) return fail(QADC_E_HIP, std::string("ncclCommInitRank: ") + (d->GetErrorString ? d->GetErrorString(rc) : "error"));
+    if (rc != 0) {
+        d->comm = nullptr;
+        return fail(QADC_E_HIP, std::string("ncclCommInitRank: ") + (d->GetErrorString ? d->GetErrorString(rc) : "error"));
+    }
     d->rank = rank;
     d->world = world;
     int prio_least = 0, prio_greatest = 0;
@@ -2480,9 +2541,9 @@ int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
     {
         constexpr size_t kWords = 1 << 16;
         DevBuf<uint64_t> src, dst;
-        HIPCHECK(src.ensure(kWords));
-        HIPCHECK(dst.ensure(kWords * world));
-        hipError_t he = hipMemsetAsync(src.p, 0, sizeof(uint64_t) * kWords, d->stream);
+        hipError_t he = src.ensure(kWords);
+        if (he == hipSuccess) he = dst.ensure(kWords * world);
+        if (he == hipSuccess) he = hipMemsetAsync(src.p, 0, sizeof(uint64_t) * kWords, d->stream);
         int rc2 = 0;
         for (int i = 0; i < 16 && he == hipSuccess && rc2 == 0; ++i)
             rc2 = d->AllGather(src.p, dst.p, kWords, /*ncclUint64*/ 5, d->comm, d->stream);
@@ -2491,7 +2552,24 @@ int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
         if (rc2 != 0) return fail(QADC_E_HIP, std::string("ncclAllGather: ") + (d->GetErrorString ? d->GetErrorString(rc2) : "error"));
         HIPCHECK(he);
     }
-    idx->dist = d.release();
+    idx->dist = g.d.release();
+    return QADC_OK;
+}
+
+int qadc_dist_init_transport(qadc_index* idx, int rank, int world, qadc_allgather_fn fn, void* ctx) {
+    if (!fn) return fail(QADC_E_ARG, "the all-gather callback is null");
+    if (int rc = dist_init_checks(idx, rank, world)) return rc;
+    DistGuard g;
+    g.d.reset(new DistState());
+    DistState* d = g.d.get();
+    d->user_fn = fn;
+    d->user_ctx = ctx;
+    d->rank = rank;
+    d->world = world;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
+    idx->dist = g.d.release();
     return QADC_OK;
 }
 
@@ -2546,11 +2624,12 @@ int qadc_dist_merge_blocks_host(int world, int nq, int ma, int R, const uint64_t
 int qadc_dist_shutdown(qadc_index* idx) {
     if (!idx || !idx->dist) return QADC_OK;
     (void)hipSetDevice(idx->device);
-    (void)hipStreamSynchronize(idx->stream);
+    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     DistState* d = idx->dist;
     if (d->stream) (void)hipStreamSynchronize(d->stream);
-    if (d->comm) (void)d->CommDestroy(d->comm);
+    if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
     if (d->stream) (void)hipStreamDestroy(d->stream);
+    d->d_fix.release(); d->h_fix.release();
     d->d_block.release(); d->d_gathered.release(); d->d_src.release(); d->h_src.release(); d->d_extra.release();
     d->h_extra.release(); d->h_out.release(); d->h_hdr.release(); d->h_extra_all.release();
     d->h_gathered.release(); d->h_myheaps.release(); d->d_myheaps.release(); d->d_allheaps.release(); d->h_allheaps.release();
@@ -2566,27 +2645,63 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
     if (extra_n < 0 || (extra_n && (!extra || !extra_out))) return fail(QADC_E_ARG, "extra payload buffers missing");
     DistState& d = *idx->dist;
     Slot& s = idx->slot[slot];
-    if (s.busy && !s.dist_batch) return fail(QADC_E_STATE, "the batch was submitted before qadc_dist_init");
-    if ((uint32_t)s.R > replay_lanes_max_R()) return fail(QADC_E_ARG, "qadc_dist_collect needs R <= 288");
-    if (int rc = collect_common(idx, slot, /*need_stream=*/false)) return rc;
+    // caller errors — the same on every rank of a well-formed program — return before any rank enters the collective
+    if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
+    if (!s.dist_batch) return fail(QADC_E_STATE, "the batch was submitted before qadc_dist_init");
+    if (int rc = use_device(idx)) return rc;
     const int nq = s.nq, R = s.R, world = d.world;
+    // A failure of THIS rank's batch (candidate buffers that keep overflowing, a HIP error while re-running it) must not
+    // leave the other ranks blocked in the gather: the rank still contributes a block, with bit7 set in every header, and
+    // all ranks return the error after the gather.
+    int local_rc = collect_common(idx, slot, /*need_stream=*/false, /*from_dist=*/true);
+    std::string local_err = local_rc ? g_err : std::string();
+    if (d.inject_failure && !local_rc) {                      // test hook (option "dist_inject_failure")
+        d.inject_failure = 0;
+        local_rc = QADC_E_STATE;
+        local_err = "injected failure (test hook)";
+    }
     std::vector<int32_t> st_local;
     if (!status) {
         st_local.resize(nq);
         status = st_local.data();
     }
-    finish_float_outputs(idx, s, status, nullptr, nullptr);
+    if (!local_rc) finish_float_outputs(idx, s, status, nullptr, nullptr);
     // where this rank's ordered streams lie in device memory
     HIPCHECK(d.h_src.ensure(3 * (size_t)nq));
     HIPCHECK(d.d_src.ensure(3 * (size_t)nq));
+    uint64_t fix_total = 0;
+    for (int q = 0; q < nq && !local_rc; ++q) {
+        const uint32_t fl = s.h_qout[q].flags;
+        if (!(fl & 4u) && !(fl & 1u)) fix_total += s.out_off[q + 1] - s.out_off[q];   // ordered by collect_common on the host
+    }
+    if (fix_total >= (1ull << 31)) return fail(QADC_E_CAPACITY, "host-ordered streams exceed 2^31 entries");
+    if (fix_total) {
+        HIPCHECK(d.h_fix.ensure(fix_total));
+        HIPCHECK(d.d_fix.ensure(fix_total));
+    }
+    uint64_t fix_off = 0;
     for (int q = 0; q < nq; ++q) {
+        if (local_rc) {
+            d.h_src.p[q] = 0;
+            d.h_src.p[nq + q] = 0;
+            d.h_src.p[2 * nq + q] = 128u;
+            continue;
+        }
         const QueryOut& qs = s.h_qout[q];
         const bool ordered = (qs.flags & 4u) != 0;
         d.h_src.p[q] = qs.out_off;
         d.h_src.p[nq + q] = ordered ? qs.count + qs.reps : 0u;
-        d.h_src.p[2 * nq + q] = qs.flags;
-        // (a query that was not ordered on the device — more than 16384 candidates — is not supported by the native merge;
-        // it is reported AFTER the gather, from the headers every rank sees, so that all ranks leave the collective alike)
+        d.h_src.p[2 * nq + q] = qs.flags & 0x3fu;
+        if (!ordered && !(qs.flags & 1u)) {
+            // more candidates than the device sort takes (> 16384): collect_common sorted the query's raw region on the host;
+            // its stream travels in the same gather from a side buffer
+            const uint64_t n = s.out_off[q + 1] - s.out_off[q];
+            std::memcpy(d.h_fix.p + fix_off, s.out_entries.data() + s.out_off[q], sizeof(uint64_t) * n);
+            d.h_src.p[q] = (uint32_t)fix_off;
+            d.h_src.p[nq + q] = (uint32_t)n;
+            d.h_src.p[2 * nq + q] = (qs.flags & 0x3fu) | 4u | 256u;
+            fix_off += n;
+        }
     }
     // Buffers are sized on the FIRST call for a payload of nq x R floats per rank (the sharded pre-scan's) whether or not
     // this call carries one: the pinned allocations and the larger gather blocks a first payload would otherwise need
@@ -2606,6 +2721,9 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
     hipStream_t st = d.stream;                               // the batch itself is complete (collect_common waited for it)
     uint64_t* h_heaps = reinterpret_cast<uint64_t*>(d.h_out.p);
     uint32_t* h_sizes = reinterpret_cast<uint32_t*>(d.h_out.p + sizeof(uint64_t) * (size_t)R * nq);
+    // the lane-per-query device replay keeps 64 heaps per wave in LDS: R <= 288; larger heaps take the host share
+    const bool on_device = nq >= d.device_nq && (uint32_t)R <= replay_lanes_max_R();
+    std::string gerr;
     for (int attempt = 0;; ++attempt) {
         const size_t bw = dist_block_words(nq, d.cap_entries, (uint32_t)extra_n);
         const size_t bw_room = dist_block_words(nq, d.cap_entries, (uint32_t)extra_room);
@@ -2613,11 +2731,10 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         HIPCHECK(d.d_gathered.ensure(bw_room * world));
         HIPCHECK(hipMemcpyAsync(d.d_src.p, d.h_src.p, sizeof(uint32_t) * 3 * nq, hipMemcpyHostToDevice, st));
         if (extra_n) HIPCHECK(hipMemcpyAsync(d.d_extra.p, d.h_extra.p, sizeof(float) * extra_n, hipMemcpyHostToDevice, st));
-        HIPCHECK(launch_dist_pack(d.d_src.p, d.d_src.p + nq, d.d_src.p + 2 * nq, nq, s.d_stream.p, d.cap_entries,
+        if (fix_total) HIPCHECK(hipMemcpyAsync(d.d_fix.p, d.h_fix.p, sizeof(uint64_t) * fix_total, hipMemcpyHostToDevice, st));
+        HIPCHECK(launch_dist_pack(d.d_src.p, d.d_src.p + nq, d.d_src.p + 2 * nq, nq, s.d_stream.p, d.d_fix.p, d.cap_entries,
                                   extra_n ? d.d_extra.p : nullptr, (uint32_t)extra_n, d.d_block.p, st));
-        const int rc = d.AllGather(d.d_block.p, d.d_gathered.p, bw, /*ncclUint64*/ 5, d.comm, st);
-        if (rc != 0) return fail(QADC_E_HIP, std::string("ncclAllGather: ") + (d.GetErrorString ? d.GetErrorString(rc) : "error"));
-        const bool on_device = nq >= d.device_nq;
+        if (d.gather(d.d_block.p, d.d_gathered.p, bw, st, gerr)) return fail(QADC_E_HIP, gerr);
         if (on_device)
             HIPCHECK(launch_dist_merge_lanes(d.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, reinterpret_cast<uint64_t*>(d.d_out),
                                              reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq), st));
@@ -2634,17 +2751,25 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         HIPCHECK(hipStreamSynchronize(st));
         uint64_t need = 0;
         bool overflow = false, unordered = false;
+        int failed_rank = -1;
         for (int g = 0; g < world; ++g) {
             uint64_t tot = 0;
             for (int q = 0; q < nq; ++q) {
                 const uint32_t* h = d.h_hdr.p + ((size_t)g * nq + q) * 4;
                 tot += h[1];
                 overflow |= (h[2] & 64u) != 0;
-                unordered |= !(h[2] & 4u) && !(h[2] & 1u);
+                if ((h[2] & 128u) && failed_rank < 0) failed_rank = g;
+                unordered |= !(h[2] & 4u) && !(h[2] & 1u) && !(h[2] & 128u);
             }
             need = std::max(need, tot);
         }
-        if (unordered) return fail(QADC_E_CAPACITY, "a rank could not order a query on the device: not supported by the native merge");
+        // (every rank reads the same headers: the same branch is taken everywhere, no rank stays behind in a collective)
+        if (failed_rank >= 0) {
+            if (extra_n) std::memcpy(extra_out, d.h_extra_all.p, sizeof(float) * (size_t)world * extra_n);
+            return fail(local_rc ? local_rc : QADC_E_STATE,
+                        local_rc ? local_err : "rank " + std::to_string(failed_rank) + " failed before the gather (see its own error)");
+        }
+        if (unordered) return fail(QADC_E_STATE, "a rank shipped a query without ordering it");
         if (overflow) {
             if (attempt >= 2 || need >= (1ull << 31)) return fail(QADC_E_CAPACITY, "gather block overflow persists");
             d.cap_entries = (uint32_t)((need + need / 8 + 4095) / 4096 * 4096);   // the same on every rank: they all saw the same headers
@@ -2652,7 +2777,7 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
             continue;
         }
         if (on_device) break;
-        // ---- few queries: replay my share on the host (global scan order: assign slot, rank, position), share the heaps ----
+        // ---- few queries (or R > 288): replay my share on the host (global scan order: assign slot, rank, position), share the heaps ----
         const int per = (nq + world - 1) / world;
         const size_t hw = (size_t)R + 1;                       // words per query in the heap exchange
         HIPCHECK(d.h_myheaps.ensure((size_t)per * hw));
@@ -2665,8 +2790,7 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
             replay_my_share(d.h_gathered.p, bw, world, d.rank, nq, s.ma, R, status, d.h_myheaps.p, &idx->pool);
         }
         HIPCHECK(hipMemcpyAsync(d.d_myheaps.p, d.h_myheaps.p, sizeof(uint64_t) * (size_t)per * hw, hipMemcpyHostToDevice, st));
-        const int rc2 = d.AllGather(d.d_myheaps.p, d.d_allheaps.p, (size_t)per * hw, /*ncclUint64*/ 5, d.comm, st);
-        if (rc2 != 0) return fail(QADC_E_HIP, std::string("ncclAllGather: ") + (d.GetErrorString ? d.GetErrorString(rc2) : "error"));
+        if (d.gather(d.d_myheaps.p, d.d_allheaps.p, (size_t)per * hw, st, gerr)) return fail(QADC_E_HIP, gerr);
         HIPCHECK(hipMemcpyAsync(d.h_allheaps.p, d.d_allheaps.p, sizeof(uint64_t) * (size_t)per * hw * world, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
         for (int q = 0; q < nq; ++q) {
@@ -2687,6 +2811,31 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         }
     }
     if (extra_n) std::memcpy(extra_out, d.h_extra_all.p, sizeof(float) * (size_t)world * extra_n);
+    return QADC_OK;
+}
+
+int qadc_slot_assign(qadc_index* idx, int slot, int32_t* assign_out) {
+    if (!idx || slot < 0 || slot >= kSlots || !assign_out) return fail(QADC_E_ARG, "bad arguments");
+    const Slot& s = idx->slot[slot];
+    if (s.busy) return fail(QADC_E_STATE, "collect the batch first");
+    if (s.assign.size() != (size_t)s.nq * s.ma) return fail(QADC_E_STATE, "slot has held no batch");
+    std::memcpy(assign_out, s.assign.data(), sizeof(int32_t) * s.assign.size());
+    return QADC_OK;
+}
+
+int qadc_place_partitions(int part_count, const uint32_t* sizes, int world, int32_t* owner_out) {
+    if (part_count < 0 || world < 1 || (part_count && (!sizes || !owner_out))) return fail(QADC_E_ARG, "bad arguments");
+    std::vector<int> order(part_count);
+    for (int p = 0; p < part_count; ++p) order[p] = p;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sizes[a] > sizes[b]; });
+    std::vector<uint64_t> load(world, 0);
+    for (int p : order) {
+        int best = 0;
+        for (int r = 1; r < world; ++r)
+            if (load[r] < load[best]) best = r;
+        owner_out[p] = best;
+        load[best] += sizes[p];
+    }
     return QADC_OK;
 }
 

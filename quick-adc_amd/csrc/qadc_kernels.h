@@ -168,9 +168,10 @@ inline size_t dist_block_words(int nq, uint32_t cap_entries, uint32_t extra_n) {
     return 2 * (size_t)nq + cap_entries + (extra_n + 1) / 2;
 }
 // d_src_off/cnt/flags[q]: where query q's ordered stream starts inside d_stream, its entries, its QueryState flags.
+// flags bit8: the query's stream lies in d_fix (ordered on the host), not in d_stream.
 hipError_t launch_dist_pack(const uint32_t* d_src_off, const uint32_t* d_src_cnt, const uint32_t* d_src_flags, int nq,
-                            const uint64_t* d_stream, uint32_t cap_entries, const float* d_extra, uint32_t extra_n,
-                            uint64_t* d_block, hipStream_t stream);
+                            const uint64_t* d_stream, const uint64_t* d_fix, uint32_t cap_entries, const float* d_extra,
+                            uint32_t extra_n, uint64_t* d_block, hipStream_t stream);
 // world blocks -> heaps [nq][R] (key | value << 32) + sizes (0xffffffff: some rank's block overflowed / query not
 // ordered on a device: the caller regrows and repeats, or falls back).  world <= 16, R <= replay_lanes_max_R().
 hipError_t launch_dist_merge_lanes(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,

@@ -29,6 +29,7 @@
 // block of the scan order for their bound) and HEAD (the first launch of the level-structured path).  gfx950 only.
 #include "qadc_kernels.h"
 
+#include <atomic>
 #include <cfloat>
 #include <cstddef>
 #include <cstring>
@@ -1268,7 +1269,8 @@ __global__ __launch_bounds__(64) void replay_heap_lanes_kernel(const uint32_t* _
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dist_pack_kernel(const uint32_t* __restrict__ src_off, const uint32_t* __restrict__ src_cnt,
                                                         const uint32_t* __restrict__ src_flags, int nq,
-                                                        const uint64_t* __restrict__ stream, uint32_t cap_entries,
+                                                        const uint64_t* __restrict__ stream,
+                                                        const uint64_t* __restrict__ fix, uint32_t cap_entries,
                                                         const float* __restrict__ extra, uint32_t extra_n,
                                                         uint64_t* __restrict__ block) {
     __shared__ uint32_t red[4];
@@ -1292,11 +1294,13 @@ __global__ __launch_bounds__(256) void dist_pack_kernel(const uint32_t* __restri
     if (tid == 0) {
         hdr[4 * q + 0] = off;
         hdr[4 * q + 1] = n;
-        hdr[4 * q + 2] = src_flags[q] | (fits ? 0u : 64u);      // bit6: this rank's block was too small
+        hdr[4 * q + 2] = src_flags[q] | (fits ? 0u : 64u);      // bit6: this rank's block was too small (bit7, set by the
+                                                                // host: the rank's batch failed before the gather)
         hdr[4 * q + 3] = 0;
     }
     if (!fits) return;
-    const uint64_t* __restrict__ s = stream + src_off[q];
+    // bit8: the rank ordered this query on the host (more candidates than the device sort takes); its stream lies in `fix`
+    const uint64_t* __restrict__ s = ((src_flags[q] & 256u) ? fix : stream) + src_off[q];
     for (uint32_t i = tid; i < n; i += 256) ent[off + i] = s[i];
 }
 
@@ -1318,8 +1322,8 @@ __global__ __launch_bounds__(64) void dist_merge_lanes_kernel(const uint64_t* __
         end[g] = cur[g] + hdr[4 * q + 1];
         const uint32_t fl = hdr[4 * q + 2];
         if (fl & 1u) skip = true;                               // qmax too high (identical on every rank)
-        if (fl & 64u) overflow = true;
-        if (!(fl & 4u)) overflow = true;                        // a rank could not order this query on the device
+        if (fl & (64u | 128u)) overflow = true;                 // block too small / the rank's batch failed
+        if (!(fl & 4u)) overflow = true;                        // a rank could not order this query
     }
     if (overflow) skip = true;
     if (!skip) {
@@ -1341,40 +1345,39 @@ __global__ __launch_bounds__(64) void dist_merge_lanes_kernel(const uint64_t* __
 
 }  // namespace
 
+// Dynamic-LDS opt-in above the default limit, once per (kernel, device); safe from several host threads (one per index).
+static hipError_t dynamic_lds_optin(const void* fn, int bytes, std::atomic<uint64_t>& done_devices) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < 64;                   // (beyond 64 devices: ask every time, it is cheap)
+    const uint64_t bit = tracked ? 1ull << dev : 0;
+    if (tracked && (done_devices.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    if (tracked) done_devices.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+
 size_t query_kernel_lds_bytes(int M) { return M == 16 ? QCfg<16>::LDS_BYTES : QCfg<32>::LDS_BYTES; }
 uint32_t query_kernel_lds_values(int M) { return M == 16 ? QCfg<16>::FCAP : QCfg<32>::FCAP; }
 
 template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD = false>
 static hipError_t launch_scan_query_nt(int nq, const QueryKernelArgs& args, hipStream_t stream) {
-    // dynamic LDS above the default limit is opted into per (kernel, device)
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    static uint64_t done = 0;
+    static std::atomic<uint64_t> done{0};
     const size_t lds = QCfg<M>::LDS_BYTES;
-    if (dev < 64 && !(done & (1ull << dev))) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        done |= 1ull << dev;
-    }
+    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>), (int)lds, done);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>), dim3(nq * (MULTI ? args.G : 1)), dim3(kQWG), lds, stream, args);
     return hipGetLastError();
 }
 
 template <int M, int U, int OCC, bool NT>
 static hipError_t launch_scan_query_inline(int nq, const QueryKernelArgs& args, hipStream_t stream, const void* payload, size_t bytes) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    static uint64_t done = 0;
+    static std::atomic<uint64_t> done{0};
     const size_t lds = QCfg<M>::LDS_BYTES;
-    if (dev < 64 && !(done & (1ull << dev))) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_inline_kernel<M, U, OCC, NT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        done |= 1ull << dev;
-    }
+    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&scan_query_inline_kernel<M, U, OCC, NT>), (int)lds, done);
+    if (e != hipSuccess) return e;
     QueryKernelInline ia;
     ia.a = args;
     ia.a.inline_input = payload ? 1u : 0u;
@@ -1425,15 +1428,9 @@ void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, i
 
 hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uint32_t cand_cap, uint32_t ccap, int nq,
                               uint64_t* d_stream, uint32_t cap, QueryOut* d_qout, uint32_t* d_qflags, hipStream_t stream) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    static std::atomic<uint64_t> done{0};
+    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&order_cands_kernel), 65536, done);
     if (e != hipSuccess) return e;
-    static uint64_t done = 0;
-    if (dev < 64 && !(done & (1ull << dev))) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&order_cands_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        if (e != hipSuccess) return e;
-        done |= 1ull << dev;
-    }
     hipLaunchKernelGGL(order_cands_kernel, dim3(nq), dim3(kQWG), 65536, stream, d_qs, d_regions, cand_cap, ccap, d_stream, cap,
                        d_qout, d_qflags);
     return hipGetLastError();
@@ -1441,29 +1438,21 @@ hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uin
 
 uint32_t replay_lanes_max_R() { return 288; }                    // (R + 1) * 512 B of LDS per wave (<= 144.5 KiB): R slots + a scratch row
 
-static hipError_t lane_heap_lds_optin(const void* fn, uint64_t& done) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 64 && !(done & (1ull << dev))) {
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((replay_lanes_max_R() + 1) * 512));
-        if (e != hipSuccess) return e;
-        done |= 1ull << dev;
-    }
-    return hipSuccess;
+static hipError_t lane_heap_lds_optin(const void* fn, std::atomic<uint64_t>& done) {
+    return dynamic_lds_optin(fn, (int)((replay_lanes_max_R() + 1) * 512), done);
 }
 
 hipError_t launch_dist_pack(const uint32_t* d_src_off, const uint32_t* d_src_cnt, const uint32_t* d_src_flags, int nq,
-                            const uint64_t* d_stream, uint32_t cap_entries, const float* d_extra, uint32_t extra_n,
-                            uint64_t* d_block, hipStream_t stream) {
+                            const uint64_t* d_stream, const uint64_t* d_fix, uint32_t cap_entries, const float* d_extra,
+                            uint32_t extra_n, uint64_t* d_block, hipStream_t stream) {
     hipLaunchKernelGGL(dist_pack_kernel, dim3(nq + 1), dim3(256), 0, stream, d_src_off, d_src_cnt, d_src_flags, nq, d_stream,
-                       cap_entries, d_extra, extra_n, d_block);
+                       d_fix, cap_entries, d_extra, extra_n, d_block);
     return hipGetLastError();
 }
 
 hipError_t launch_dist_merge_lanes(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
                                    uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
-    static uint64_t done = 0;
+    static std::atomic<uint64_t> done{0};
     if (world > 16) return hipErrorInvalidValue;
     hipError_t e = lane_heap_lds_optin(reinterpret_cast<const void*>(&dist_merge_lanes_kernel), done);
     if (e != hipSuccess) return e;
@@ -1474,16 +1463,9 @@ hipError_t launch_dist_merge_lanes(const uint64_t* d_gathered, size_t block_word
 
 hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
                                     uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    static std::atomic<uint64_t> done{0};
+    const hipError_t e = lane_heap_lds_optin(reinterpret_cast<const void*>(&replay_heap_lanes_kernel), done);
     if (e != hipSuccess) return e;
-    static uint64_t done = 0;
-    if (dev < 64 && !(done & (1ull << dev))) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&replay_heap_lanes_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)((replay_lanes_max_R() + 1) * 512));
-        if (e != hipSuccess) return e;
-        done |= 1ull << dev;
-    }
     hipLaunchKernelGGL(replay_heap_lanes_kernel, dim3((nq + 63) / 64), dim3(64), ((size_t)R + 1) * 512, stream, d_qflags, d_stream,
                        cap, nq, R, d_heaps, d_heap_sizes);
     return hipGetLastError();

@@ -32,6 +32,8 @@ SYMBOLS = [
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
     "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_kmeans_iterations_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
     "qadc_dist_unique_id", "qadc_dist_init", "qadc_dist_collect", "qadc_dist_shutdown", "qadc_dist_merge_blocks", "qadc_dist_merge_blocks_host",
+    "qadc_dist_init_transport", "qadc_shm_transport_open", "qadc_shm_transport_allgather", "qadc_shm_transport_allgather_host",
+    "qadc_shm_transport_close", "qadc_shm_transport_error", "qadc_slot_assign", "qadc_place_partitions",
 ]
 
 
@@ -120,6 +122,14 @@ def lib():
         L.qadc_dist_shutdown.argtypes = [C.c_void_p]
         L.qadc_dist_merge_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_uint64, u32p, i8p, i32p]
         L.qadc_dist_merge_blocks_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_uint64, u32p, i8p, i32p]
+        L.qadc_dist_init_transport.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.qadc_shm_transport_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_double, C.POINTER(C.c_void_p)]
+        L.qadc_shm_transport_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.qadc_shm_transport_allgather_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.qadc_shm_transport_close.argtypes = [C.c_void_p]
+        L.qadc_shm_transport_error.restype = C.c_char_p
+        L.qadc_slot_assign.argtypes = [C.c_void_p, C.c_int, i32p]
+        L.qadc_place_partitions.argtypes = [C.c_int, u32p, C.c_int, i32p]
         L.qadc_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.qadc_profile_reset.argtypes = [C.c_void_p]
         _lib = L
@@ -159,6 +169,40 @@ def dist_unique_id():
     uid = np.zeros(128, np.uint8)
     _check(lib().qadc_dist_unique_id(_p(uid, u8p)))
     return uid
+
+
+class ShmTransport:
+    """The library's built-in host-staged all-gather over a POSIX shared-memory segment (qadc_shm_transport_*): the
+    transport of ranks that share one GPU or have no RCCL.  name: "/something", unique per run."""
+
+    def __init__(self, name, rank, world, slot_bytes=64 << 20, timeout_s=120.0):
+        self.rank, self.world = rank, world
+        self._ctx = C.c_void_p()
+        rc = lib().qadc_shm_transport_open(name.encode(), rank, world, slot_bytes, timeout_s, C.byref(self._ctx))
+        if rc != 0:
+            raise QadcError("qadc error %d: %s" % (rc, lib().qadc_shm_transport_error().decode()))
+
+    def allgather_host(self, arr):
+        """Host buffers only (no GPU): every rank's `arr` -> [world][...]."""
+        a = np.ascontiguousarray(arr)
+        out = np.zeros((self.world,) + a.shape, a.dtype)
+        rc = lib().qadc_shm_transport_allgather_host(self._ctx, a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), a.nbytes)
+        if rc != 0:
+            raise QadcError("qadc error %d: %s" % (rc, lib().qadc_shm_transport_error().decode()))
+        return out
+
+    def close(self):
+        if self._ctx:
+            lib().qadc_shm_transport_close(self._ctx)
+            self._ctx = C.c_void_p()
+
+
+def place_partitions(sizes, world):
+    """Size-balanced owner rank of every partition (qadc_place_partitions)."""
+    sz = np.ascontiguousarray(sizes, np.uint32)
+    owner = np.zeros(len(sz), np.int32)
+    _check(lib().qadc_place_partitions(len(sz), _p(sz, u32p), world, _p(owner, i32p)))
+    return owner
 
 
 def dist_merge_blocks(streams, nq, ma, R, device=0, host=False):
@@ -415,13 +459,29 @@ class Index:
         _check(lib().qadc_dist_init(self._h, rank, world, _p(uid, u8p)))
         self._dist_world = world
 
+    def dist_init_transport(self, transport):
+        """The merge over the library's shared-memory transport (ShmTransport) instead of RCCL."""
+        fn = C.cast(lib().qadc_shm_transport_allgather, C.c_void_p)
+        _check(lib().qadc_dist_init_transport(self._h, transport.rank, transport.world, fn, transport._ctx))
+        self._dist_world = transport.world
+        self._transport = transport
+
     def dist_shutdown(self):
         _check(lib().qadc_dist_shutdown(self._h))
+
+    def slot_assign(self, slot, nq, ma):
+        out = np.zeros((nq, ma), np.int32)
+        _check(lib().qadc_slot_assign(self._h, slot, _p(out, i32p)))
+        return out
 
     def dist_collect(self, slot, extra=None):
         """Replaces collect(): one ncclAllGather of the ranks' push streams + device-side replay in global scan order.
         Returns dict(keys, values, sizes, status[, extra = float32 [world][n]])."""
-        nq, R, tables, assign = self._pending.pop(slot)
+        if slot in getattr(self, "_spending", {}):          # a search_submit batch (queries in)
+            q, _, R = self._spending.pop(slot)
+            nq = q.shape[0]
+        else:
+            nq, R, tables, assign = self._pending.pop(slot)
         keys = np.zeros((nq, R), np.uint32)
         vals = np.zeros((nq, R), np.int8)
         sizes = np.zeros(nq, np.int32)

@@ -50,6 +50,7 @@ def pytest_generate_tests(metafunc):
 def scan_path(request, monkeypatch):
     mode = getattr(request, "param", None)
     if mode is not None:
+        monkeypatch.setenv("QADC_TEST_HOOKS", "1")         # (the library ignores the QADC_* hooks without it)
         monkeypatch.setenv("QADC_WGQ", "2" if mode == "wgq" else "0")
         # "levels_head": the first two bound levels of every query are scanned by one head launch of the query kernel
         monkeypatch.setenv("QADC_HEAD_LEVEL", "2" if mode == "levels_head" else "0")

@@ -3,8 +3,11 @@
 // generator as bench.py), submits the same query batch, and qadc_dist_collect gathers the ranks' push streams
 // with one ncclAllGather and replays them on the GPU — every rank prints the same heap checksum, which equals
 // the checksum of an unsharded scan of the list (world = 1).
-//   usage:  RANK=r WORLD_SIZE=w [LOCAL_RANK=d] dist_demo <id_file> <codes> <nq> [R]
+//   usage:  RANK=r WORLD_SIZE=w [LOCAL_RANK=d] dist_demo <id_file | shm:/name> <codes> <nq> [R]
 // Rank 0 writes the 128-byte RCCL id to <id_file>.tmp and renames it; the others wait for the file.
+// With "shm:/name" the ranks use the library's shared-memory transport instead of RCCL (qadc_dist_init_transport +
+// qadc_shm_transport_*): several ranks may then share one GPU (LOCAL_RANK=0 for all) — how a single-GPU box runs
+// world > 1 through the unmodified qadc_dist_collect.
 #include <unistd.h>
 
 #include <cstdint>
@@ -47,8 +50,15 @@ int main(int argc, char** argv) {
     const float keep = 0.01f;
     const std::uint64_t seed = 0x5EED0001ull;
 
+    const bool use_shm = id_file.compare(0, 4, "shm:") == 0;
     std::uint8_t id[QADC_DIST_ID_BYTES];
-    if (rank == 0) {
+    void* shm = nullptr;
+    if (use_shm) {
+        if (qadc_shm_transport_open(id_file.c_str() + 4, rank, world, 32u << 20, 90.0, &shm) != QADC_OK) {
+            std::fprintf(stderr, "qadc_shm_transport_open: %s\n", qadc_shm_transport_error());
+            return 3;
+        }
+    } else if (rank == 0) {
         CHECK(qadc_dist_unique_id(id));
         const std::string tmp = id_file + ".tmp";
         FILE* f = std::fopen(tmp.c_str(), "wb");
@@ -69,7 +79,8 @@ int main(int argc, char** argv) {
     CHECK(qadc_index_create(&idx, M, device));
     CHECK(qadc_index_add_partition_synthetic_shard(idx, N, first, local_n, seed, starts));
     CHECK(qadc_index_finalize(idx, keep));
-    CHECK(qadc_dist_init(idx, rank, world, id));
+    if (use_shm) CHECK(qadc_dist_init_transport(idx, rank, world, qadc_shm_transport_allgather, shm));
+    else CHECK(qadc_dist_init(idx, rank, world, id));
 
     std::vector<float> tables((std::size_t)nq * M * 16);
     for (std::size_t i = 0; i < tables.size(); ++i) tables[i] = (float)(splitmix64(977 + i) >> 40) * (1.0f / 16777216.0f) * 4.0f;
@@ -91,5 +102,6 @@ int main(int argc, char** argv) {
     std::printf("rank %d of %d: %d queries, heap checksum %016llx, extra payload %s\n", rank, world, nq, (unsigned long long)sum,
                 extra_ok ? "ok" : "BAD");
     CHECK(qadc_index_destroy(idx));
+    if (shm) qadc_shm_transport_close(shm);
     return extra_ok ? 0 : 4;
 }

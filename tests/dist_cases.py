@@ -1,0 +1,79 @@
+"""Seeded multi-rank cases shared by tests/dist_worker.py (one process per rank, all on ONE GPU) and
+tests/test_gpu_dist_multiproc.py (the parent: starts the ranks, computes the unsharded oracle answers).
+
+Every case is one database + one query batch + the options that steer the native merge (qadc_dist_collect) through a
+particular branch: host-share replay with a second gather, lane-per-query device replay, a forced regrow of the gather
+block, the extra payload, R above the lane replay's limit, a query the device cannot order, a rank that fails locally.
+"""
+import numpy as np
+
+from helpers import float_tables, rand_codes
+
+
+def shard_ranges(n, world, align=16):
+    """Contiguous ranges in rank order, every range but the last a multiple of 16 codes (pyqadc/sharded.py)."""
+    per = (n // world) // align * align
+    return [(r * per, (n - r * per) if r == world - 1 else per) for r in range(world)]
+
+
+def start_size(n, keep):
+    return min(n, max(1, int(np.float32(n) * np.float32(keep)))) if n else 0
+
+
+def build_case(name):
+    """-> dict(M, parts, labels, keep, R, assign, tables, options, index_options, placement, extra_n)."""
+    c = dict(name=name, keep=0.01, R=100, labels=None, options={}, index_options={}, placement="range", extra_n=0,
+             slots=(0,))
+    if name == "flat32":
+        # bench.py's multi-rank step in small: 32 queries over one flat list, host-share replay + second gather;
+        # the gather block starts far too small (every rank regrows alike), an extra payload rides along, two batches in flight
+        rng = np.random.default_rng(501)
+        c.update(M=16, parts=[rand_codes(rng, 400003, 16)], assign=np.zeros((32, 1), np.int32))
+        c["tables"] = float_tables(rng, 32, 1, 16)
+        c["options"] = {"dist_cap_entries": 64}
+        c["extra_n"] = 37
+        c["slots"] = (0, 1)
+    elif name in ("ivf_lanes", "ivf_whole"):
+        # >= 256 queries: the gathered streams are replayed on the GPU, one lane per query.  Ragged labelled partitions,
+        # an empty one, some too small for every rank to hold a piece, tie-heavy tables.
+        M = 16 if name == "ivf_lanes" else 32
+        rng = np.random.default_rng(502 + M)
+        sizes = [int(x) for x in rng.integers(50, 9000, 44)]
+        sizes[3], sizes[7], sizes[11], sizes[20] = 0, 16, 37, 1
+        parts = [rand_codes(rng, s, M) for s in sizes]
+        perm = rng.permutation(sum(sizes)).astype(np.uint32)
+        labels = list(np.split(perm, np.cumsum(sizes)[:-1]))
+        nq, ma = (300, 6) if name == "ivf_lanes" else (260, 9)
+        live = [p for p, s in enumerate(sizes) if s]
+        assign = np.stack([rng.choice(live, ma, replace=False) for _ in range(nq)]).astype(np.int32)
+        c.update(M=M, parts=parts, labels=labels, keep=0.05, assign=assign, tables=float_tables(rng, nq, ma, M, scale=0.3))
+        if name == "ivf_whole":
+            c["placement"] = "whole"                      # whole partitions per rank, size-balanced
+            c["index_options"] = {"wgq_group": 2, "wgq_group_head": 2}    # partition-major second phase under the merge
+    elif name == "big_r":
+        # R above the lane replay's 288: host-share replay whatever the batch size
+        rng = np.random.default_rng(503)
+        c.update(M=16, parts=[rand_codes(rng, 90001, 16)], assign=np.zeros((270, 1), np.int32), R=300)
+        c["tables"] = float_tables(rng, 270, 1, 16)
+        c["options"] = {"dist_device_nq": 1}
+    elif name == "unordered":
+        # query 0: constant float tables -> all-zero int8 tables; with one bound level over the whole list every code of
+        # every rank's range is emitted (> 16384 candidates per rank): the ranks order it on the host and ship it anyway
+        rng = np.random.default_rng(504)
+        c.update(M=16, parts=[rand_codes(rng, 300007, 16)], assign=np.zeros((3, 1), np.int32))
+        t = float_tables(rng, 3, 1, 16)
+        t[0] = 1.0
+        c["tables"] = t
+        c["index_options"] = {"wgq": 0, "head_level": 0, "level_base": 1 << 22}
+    elif name == "inject":
+        # the LAST rank's batch fails before the gather: every rank must return an error (no rank left in the
+        # collective), and the next batch must go through
+        rng = np.random.default_rng(505)
+        c.update(M=16, parts=[rand_codes(rng, 120001, 16)], assign=np.zeros((8, 1), np.int32))
+        c["tables"] = float_tables(rng, 8, 1, 16)
+    else:
+        raise KeyError(name)
+    return c
+
+
+CASES = ["flat32", "ivf_lanes", "ivf_whole", "big_r", "unordered", "inject"]

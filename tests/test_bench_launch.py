@@ -13,7 +13,7 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 def _env(**kw):
     env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "QADC_WGQ", "QADC_HEAD_LEVEL"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "QADC_WGQ", "QADC_HEAD_LEVEL", "QADC_TEST_HOOKS"):
         env.pop(k, None)
     env.update({k: str(v) for k, v in kw.items()})
     return env

@@ -1061,12 +1061,16 @@ def test_dist_merge_kernel_on_virtual_ranks(pyqadc, po, M, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["rccl", "shm"])
 @pytest.mark.parametrize("replay", ["host_share", "device_lanes"])
 @pytest.mark.parametrize("shape", ["flat_levels", "flat_small", "ivf"])
-def test_dist_collect_world_1_over_rccl(pyqadc, po, shape, replay):
-    """qadc_dist_init / qadc_dist_collect end to end with a world of ONE rank over real RCCL (all a 1-GPU box allows):
-    pack kernel -> ncclAllGather -> merge kernel -> heaps; the extra payload comes back; a deliberately tiny gather block
-    is regrown; results equal the plain collect of the same batches."""
+def test_dist_collect_world_1_over_rccl(pyqadc, po, shape, replay, transport):
+    """qadc_dist_init / qadc_dist_collect end to end with a world of ONE rank over real RCCL (all a 1-GPU box allows;
+    world > 1: tests/test_gpu_dist_multiproc.py) and over the shared-memory transport:
+    pack kernel -> all-gather -> merge kernel -> heaps; the extra payload comes back; a deliberately tiny gather block
+    is regrown; results equal the plain collect of the same batches — and a batch submitted AFTER qadc_dist_init may
+    still be collected by the plain calls (synchronous query_scan included): its streams are fetched and replayed on
+    the host."""
     rng = np.random.default_rng(len(shape))
     M, R, keep = 16, 100, 0.01
     if shape == "flat_levels":
@@ -1085,7 +1089,13 @@ def test_dist_collect_world_1_over_rccl(pyqadc, po, shape, replay):
     tables = float_tables(rng, nq, ma, M)
     idx.submit(0, assign, tables.copy(), R)
     plain = idx.collect(0)
-    idx.dist_init(0, 1, pyqadc.dist_unique_id())
+    tr = None
+    if transport == "rccl":
+        idx.dist_init(0, 1, pyqadc.dist_unique_id())
+    else:
+        import uuid
+        tr = pyqadc.ShmTransport("/qadc_w1_%s" % uuid.uuid4().hex[:10], 0, 1, slot_bytes=16 << 20)
+        idx.dist_init_transport(tr)
     extra = rng.random(37).astype(np.float32)
     # few-query batches replay their share of the gathered streams on the host and exchange heaps with a second,
     # tiny all-gather; large ones replay everything on the device, one lane per query: both must give the same heaps
@@ -1101,7 +1111,23 @@ def test_dist_collect_world_1_over_rccl(pyqadc, po, shape, replay):
             sz = plain["sizes"][q]
             assert np.array_equal(got["keys"][q, :sz], plain["keys"][q, :sz]) and np.array_equal(got["values"][q, :sz], plain["values"][q, :sz]), q
     assert idx.profile()["regrows"] >= 1
+    # plain collects of batches submitted under the merge: asynchronous pair and the synchronous call
+    idx.submit(2, assign, tables.copy(), R)
+    again = idx.collect(2)
+    sync = idx.query_scan(assign, tables.copy(), R)
+    stream = idx.query_scan_shard_streams(assign, tables.copy(), R)
+    assert np.array_equal(again["sizes"], plain["sizes"]) and np.array_equal(sync["sizes"], plain["sizes"])
+    for q in range(nq):
+        sz = plain["sizes"][q]
+        assert np.array_equal(again["keys"][q, :sz], plain["keys"][q, :sz]) and np.array_equal(again["values"][q, :sz], plain["values"][q, :sz]), q
+        assert np.array_equal(sync["keys"][q, :sz], plain["keys"][q, :sz]) and np.array_equal(sync["values"][q, :sz], plain["values"][q, :sz]), q
+        lo, hi = int(stream["offsets"][q]), int(stream["offsets"][q + 1])
+        if plain["status"][q] == 0:
+            assert heaps_equal(pyqadc.replay_i8(stream["keys"][lo:hi], stream["vals"][lo:hi], R, sentinel=True),
+                               (plain["keys"][q, :sz], plain["values"][q, :sz])), q
     idx.close()
+    if tr is not None:
+        tr.close()
 
 
 @pytest.mark.gpu

@@ -224,6 +224,45 @@ def test_dist_demo_world_1_equals_plain_scan(po, tmp_path):
     assert got == int(acc)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_dist_demo_several_ranks_on_one_gpu_equal_the_unsharded_scan(po, tmp_path, world):
+    """The same C++14 driver with world > 1: `world` processes on GPU 0, shards of one list, the library's shared-memory
+    transport in place of RCCL, the unmodified qadc_dist_collect (32-query batch: host-share replay + second gather).
+    Every rank prints the checksum of the unsharded oracle's heaps."""
+    import uuid
+    build_dist_demo()
+    n, nq, R, M = 500003, 32, 100, 16
+    name = "shm:/qadc_demo_%s" % uuid.uuid4().hex[:10]
+    procs = [subprocess.Popen([DIST_DEMO, name, str(n), str(nq), str(R)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0")) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=300)
+            assert p.returncode == 0, se.decode()[-800:]
+            outs.append(so.decode())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    codes = po.fill_codes(0, (n * 8 + 7) // 8, 0x5EED0001)[:n * 8].reshape(n, 8)
+    i = np.arange(nq * M * 16, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        tables = ((splitmix64(np.uint64(977) + i) >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0) * np.float32(4.0))
+    tables = tables.reshape(nq, M * 16)
+    acc = np.uint64(0)
+    for q in range(nq):
+        want = po.query_scan(M, [codes], None, 0.01, [0], np.ascontiguousarray(tables[q:q + 1].copy()), R)
+        assert want["rc"] == 0
+        for k, v in zip(want["keys"], want["values"]):
+            with np.errstate(over="ignore"):
+                acc = splitmix64(np.uint64(acc) ^ ((np.uint64(k) << np.uint64(8)) | np.uint64(np.uint8(v))))
+    for out in outs:
+        assert "extra payload ok" in out
+        assert int(out.split("heap checksum ")[1].split(",")[0], 16) == int(acc), out
+
+
 DB_BUILD = os.path.join(ROOT, "tests", "cpp", "db_build_demo")
 
 
