@@ -343,9 +343,15 @@ def roofline_single(M, N, prof, dt, nqueries, traffic, traffic_src):
             "small_run_codes_not_event_timed": prof["small_codes"]}
 
 
-def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000):
+def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=None):
     """BASELINE configs[2] shape: 100M x 16x4 codes in K = 4096 ragged partitions, nprobe 32, R = 100, queries in
-    (coarse assignment, residual tables, pre-scan, quantizer, scan, heap all on the GPU), 1024-query batches pipelined."""
+    (coarse assignment, residual tables, pre-scan, quantizer, scan, heap all on the GPU), 1024-query batches pipelined.
+    shard = None: the whole database on this GPU, qadc_search_submit / _collect.
+    shard = dict(rank, world, placement, init): this rank's part of it — placement "whole" = whole partitions per rank,
+    size-balanced (qadc_place_partitions), "range" = every partition range-split over the ranks; every rank holds the
+    starts of every partition (the pre-scan and hence qmax / the int8 tables need no exchange), submits the same query
+    batches, and qadc_dist_collect gathers the push streams (init(idx) sets the merge up: RCCL, or the loopback stand-in
+    of tools/ivf_shard_sizes.py)."""
     import pyqadc
     NQB = 1024
     if N is None:
@@ -353,24 +359,55 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000):
     rng = np.random.default_rng(0)
     sizes = rng.multinomial(N, np.ones(K) / K)
     idx = pyqadc.Index(M, local_rank)
-    for p in range(K):
-        idx.add_partition_synthetic(int(sizes[p]), seed0 + p)
+    local_codes = 0
+    if shard is None:
+        for p in range(K):
+            idx.add_partition_synthetic(int(sizes[p]), seed0 + p)
+        local_codes = int(sizes.sum())
+    else:
+        rank, world = shard["rank"], shard["world"]
+        owner = pyqadc.place_partitions(sizes, world) if shard["placement"] == "whole" else None
+        for p in range(K):
+            n = int(sizes[p])
+            if n == 0:
+                idx.add_partition_synthetic(0, seed0 + p)
+                continue
+            if owner is not None:
+                first, ln = (0, n) if owner[p] == rank else (0, 0)
+            else:
+                per = (n // world) // 16 * 16
+                first, ln = rank * per, (n - rank * per) if rank == world - 1 else per
+            idx.add_partition_synthetic_shard(n, first, ln, seed0 + p, max(1, int(np.float32(n) * np.float32(KEEP))))
+            local_codes += ln
     idx.finalize(KEEP)
     cb = rng.normal(size=(M, 16, dim // M)).astype(np.float32)
     coarse = rng.normal(size=(K, dim)).astype(np.float32)
     idx.set_pq(cb)
     idx.set_coarse(coarse)
+    if shard is not None:
+        shard["init"](idx)
     for kv in filter(None, os.environ.get("QADC_BENCH_IVF_OPTS", "").split(",")):  # tuning experiments only
         idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     qs = [rng.normal(size=(NQB, dim)).astype(np.float32) for _ in range(4)]
+
+    def collect(slot, nq):
+        """-> probed codes of the batch (whole database: every rank counts the same figure)."""
+        if shard is None:
+            return int(sizes[idx.search_collect(slot)["assign"]].sum())
+        idx.dist_collect(slot)
+        return int(sizes[idx.slot_assign(slot, nq, MA)].sum())
+
     def pipelined(batches, steps, depth=3, warm=True):
+        nqb = batches[0].shape[0]
         for w in range(depth):                             # every slot used below sizes its buffers before the clock starts
             idx.search_submit(w, batches[w], MA, R)
         for w in range(depth):
-            idx.search_collect(w)
+            collect(w, nqb)
         if warm:                                           # ... and one untimed pass in the steady state of the loop below
             pipelined(batches, 2 * depth, depth, warm=False)   # (runtime-side lazy growth under a full pipeline was seen to
         idx.profile_reset()                                #  stall a first timed pass by tens of milliseconds)
+        if shard is not None and shard.get("barrier"):
+            shard["barrier"]()
         t0 = time.perf_counter()
         pend, nc = [], 0
         stamps = []
@@ -379,11 +416,13 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000):
             idx.search_submit(s % depth, batches[s % 4], MA, R)
             pend.append(s % depth)
             if len(pend) == depth:
-                nc += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
+                nc += collect(pend.pop(0), nqb)
         if os.environ.get("QADC_BENCH_IVF_STEPLOG"):
             print("ivf steps (ms):", [round((b - a) * 1e3, 2) for a, b in zip(stamps, stamps[1:])], file=sys.stderr)
         while pend:
-            nc += int(sizes[idx.search_collect(pend.pop(0))["assign"]].sum())
+            nc += collect(pend.pop(0), nqb)
+        if shard is not None and shard.get("barrier"):
+            shard["barrier"]()
         return time.perf_counter() - t0, nc
 
     steps, depth = 48, int(os.environ.get("QADC_BENCH_IVF_DEPTH", 4))          # all four submission slots of the C-ABI in use
@@ -393,17 +432,22 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000):
     dt2, _ = pipelined(qs2, 24, depth)
     idx.close()
     gbs = ncodes * (M // 2) / dt / 1e9
-    return {"workload": "IVF, %d x %dx4 codes (%d-d vectors) in K=%d partitions (multinomial sizes), nprobe=%d, R=%d, keep=%.0f%%, "
-                        "%d-query batches, %d in flight, queries in -> heaps out (qadc_search)" % (N, M, dim, K, MA, R, KEEP * 100, NQB, depth),
-            "codes_per_sec": ncodes / dt, "us_per_query": dt * 1e6 / (steps * NQB), "queries_per_sec": steps * NQB / dt,
-            "us_per_query_at_2048_query_batches": dt2 * 1e6 / (24 * 2 * NQB),
-            "probed_codes_per_query": ncodes / (steps * NQB),
-            "algorithmic_GBps": gbs,
-            "algorithmic_GBps_rule": "M/2 B x probed codes / wall time of the pipelined batches (whole path, not one kernel; "
-                                     "NOT an HBM figure: the partition-major second phase reads a partition once for up to 8 queries)",
-            "batches_through_partition_major_second_phase": int(p["group_launches"]), "of_them_redone_on_the_level_path": int(p["group_fallbacks"]),
-            "host_ms_per_batch": {"plan": p["host_plan_ms"] / steps, "stream_assembly": p["host_replay_ms"] / steps,
-                                  "heap": p["host_heap_ms"] / steps}}
+    out = {"workload": "IVF, %d x %dx4 codes (%d-d vectors) in K=%d partitions (multinomial sizes), nprobe=%d, R=%d, keep=%.0f%%, "
+                       "%d-query batches, %d in flight, queries in -> heaps out (qadc_search)" % (N, M, dim, K, MA, R, KEEP * 100, NQB, depth),
+           "codes_per_sec": ncodes / dt, "us_per_query": dt * 1e6 / (steps * NQB), "queries_per_sec": steps * NQB / dt,
+           "ms_per_batch": dt * 1e3 / steps,
+           "us_per_query_at_2048_query_batches": dt2 * 1e6 / (24 * 2 * NQB),
+           "probed_codes_per_query": ncodes / (steps * NQB),
+           "algorithmic_GBps": gbs,
+           "algorithmic_GBps_rule": "M/2 B x probed codes / wall time of the pipelined batches (whole path, not one kernel; "
+                                    "NOT an HBM figure: the partition-major second phase reads a partition once for up to 8 queries)",
+           "batches_through_partition_major_second_phase": int(p["group_launches"]), "of_them_redone_on_the_level_path": int(p["group_fallbacks"]),
+           "host_ms_per_batch": {"plan": p["host_plan_ms"] / steps, "stream_assembly": p["host_replay_ms"] / steps,
+                                 "heap": p["host_heap_ms"] / steps}}
+    if shard is not None:
+        out.update({"rccl_ranks": shard["world"], "placement": shard["placement"], "codes_on_this_rank": local_codes,
+                    "merge": shard.get("merge", "native: qadc_dist_collect"), "candidates_per_query_this_rank": p["candidates"] / (steps * NQB)})
+    return out
 
 
 def latency_leg(local_rank):
@@ -461,6 +505,10 @@ def latency_leg(local_rank):
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves — as CHILD processes, from a parent
     that never touches the GPU (no exec of a GPU-initialised process) — and relay rank 0's JSON line."""
+    if under_profiler():
+        # a profiler's preloaded library has initialised the GPU in THIS process: spawning ranks from it is the forbidden
+        # exec-after-GPU-init on this pool.  Profile one rank (`rocprofv3 ... -- python3 bench.py`) or launch the ranks first.
+        raise SystemExit("bench.py: --gpus %d under a profiler: launch the ranks with torch.distributed.run and profile those" % args.gpus)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -562,20 +610,26 @@ def main():
     # ---- native RCCL merge inside the library (default for real multi-rank runs): rank 0's unique id travels over the
     # process group that is up already; any failure on any rank sends ALL ranks to the torch.distributed path ----
     native_dist = False
+
+    def native_init(ix):
+        """qadc_dist_init on every rank with rank 0's id (the ranks agreed beforehand that RCCL loads everywhere)."""
+        uid = torch.from_numpy(pyqadc.dist_unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
+        dist.broadcast(uid, 0)
+        ix.dist_init(rank, world, uid.cpu().numpy())
+
     if use_dist and backend == "nccl" and os.environ.get("QADC_BENCH_NATIVE_DIST", "1") != "0":
+        # agree on availability FIRST: a rank that cannot load librccl must not leave the others inside ncclCommInitRank
         ok = 1
         try:
-            uid = torch.from_numpy(pyqadc.dist_unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
-            dist.broadcast(uid, 0)
-            idx.dist_init(rank, world, uid.cpu().numpy())
+            pyqadc.dist_unique_id()                            # loads RCCL in this process (the id itself is only used on rank 0)
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("rank %d: native RCCL merge unavailable (%r), using the torch.distributed path\n" % (rank, e))
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         native_dist = bool(flag.item())
-        if ok and not native_dist:
-            idx.dist_shutdown()
+        if native_dist:
+            native_init(idx)
 
     rng = np.random.default_rng(1234)
     codebooks = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
@@ -779,6 +833,31 @@ def main():
         # the int8 tables of one bench batch, for the CPU legs (same tables on both sides)
         qt_cpu = idx.query_scan(assign, pool[0].copy(), R, want_qtables=True)["qtables"][:, 0]
     idx.close()
+    # ---- BASELINE configs[2] / configs[4] shapes on N ranks: every rank holds its part of the partitions, the same query
+    # batches go to every rank, qadc_dist_collect merges the push streams ----
+    if use_dist and int(float(os.environ.get("QADC_BENCH_IVF_CODES", 1e8))) > 0:
+        shm_tr = []
+
+        def shard_init(ix):
+            if native_dist:
+                return native_init(ix)
+            # no RCCL between these ranks (gloo test hook: the ranks share one GPU): the library's shared-memory transport
+            tr = pyqadc.ShmTransport("/qadc_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), len(shm_tr)), rank, world)
+            shm_tr.append(tr)
+            ix.dist_init_transport(tr)
+
+        shard = dict(rank=rank, world=world, placement=os.environ.get("QADC_BENCH_IVF_PLACEMENT", "whole"), init=shard_init,
+                     barrier=sync, merge="native: qadc_dist_collect over " + ("RCCL" if native_dist else "the shared-memory transport"))
+        ivf_n = ivf_leg(local_rank, shard=dict(shard))
+        ivf_c5_n = None
+        if os.environ.get("QADC_BENCH_IVF_C5", "1") != "0" and N >= 1e9:
+            ivf_c5_n = ivf_leg(local_rank, M=32, K=16384, MA=64, dim=96, N=int(1e9), seed0=7000, shard=dict(shard))
+        for tr in shm_tr:
+            tr.close()
+        if rank == 0:
+            out["ivf"] = ivf_n
+            if ivf_c5_n is not None:
+                out["ivf_c5"] = ivf_c5_n
     if rank == 0 and world == 1 and not use_dist:
         torch.cuda.synchronize()
         if os.environ.get("QADC_BENCH_32X4", "1") != "0" and M == 16:

@@ -72,6 +72,7 @@ int qadc_index_add_partition_synthetic(qadc_index* idx, uint32_t size, uint64_t 
  * code happens only on the rank that holds it. */
 int qadc_index_add_partition_shard(qadc_index* idx, const uint8_t* codes, const uint32_t* labels, uint32_t local_n,
                                    uint32_t global_n, uint32_t first_pos, const uint8_t* starts, uint32_t starts_count);
+/* (synthetic form: the partition's generator stream is `seed`; local_n == 0 keeps only the starts replica) */
 int qadc_index_add_partition_synthetic_shard(qadc_index* idx, uint32_t global_n, uint32_t first_pos, uint32_t local_n,
                                              uint64_t seed, uint32_t starts_count);
 
@@ -295,6 +296,11 @@ int qadc_dist_shutdown(qadc_index* idx);
  * share one GPU (a single-GPU box exercising world > 1), hosts without librccl, MPI or other fabrics. */
 typedef int (*qadc_allgather_fn)(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* hip_stream);
 int qadc_dist_init_transport(qadc_index* idx, int rank, int world, qadc_allgather_fn fn, void* ctx);
+/* Measurement aid: ONE process stands in for rank `rank` of `world` — the transport copies this rank's block into every
+ * slot of the gather, so the merge replays a world's worth of entries while only this rank's shard is scanned.  Results
+ * are NOT the database's answers (every stream counts `world` times); tools/ivf_shard_sizes.py times one of 8 ranks' step
+ * on one GPU this way. */
+int qadc_dist_init_loopback(qadc_index* idx, int rank, int world);
 /* Built-in transport for qadc_dist_init_transport: host-staged all-gather through a POSIX shared-memory segment `name`
  * ("/something", unique per run; rank 0 creates it, the others wait up to timeout_s seconds — 0 = 120 s — for it).
  * slot_bytes = largest block a rank may contribute (a gather beyond it fails on every rank alike).  Barriers time out

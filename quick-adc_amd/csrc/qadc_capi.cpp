@@ -1807,17 +1807,19 @@ int qadc_index_add_partition_shard(qadc_index* idx, const uint8_t* codes, const 
 
 int qadc_index_add_partition_synthetic_shard(qadc_index* idx, uint32_t global_n, uint32_t first_pos, uint32_t local_n,
                                              uint64_t seed, uint32_t starts_count) {
-    if (!idx || local_n == 0 || (uint64_t)first_pos + local_n > global_n) return fail(QADC_E_ARG, "bad shard range");
+    if (!idx || global_n == 0 || (uint64_t)first_pos + local_n > global_n) return fail(QADC_E_ARG, "bad shard range");
     if ((uint64_t)first_pos * idx->cs % 16 != 0) return fail(QADC_E_ARG, "first_pos must keep the shard 16-byte aligned");
     if (int rc = use_device(idx)) return rc;
     if (int rc = check_labels_mode(idx, false)) return rc;
     Part pt;
-    if (int rc = alloc_part(idx, pt, local_n, false)) return rc;
+    if (local_n) {                                              // (local_n == 0: only the partition's starts replica lives here)
+        if (int rc = alloc_part(idx, pt, local_n, false)) return rc;
+        launch_fill_codes(pt.d_codes, (uint64_t)first_pos * idx->cs / 8, ((uint64_t)local_n * idx->cs + 7) / 8, seed, idx->stream);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(idx->stream));
+    }
     pt.global_n = global_n;
     pt.first_pos = first_pos;
-    launch_fill_codes(pt.d_codes, (uint64_t)first_pos * idx->cs / 8, ((uint64_t)local_n * idx->cs + 7) / 8, seed, idx->stream);
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(idx->stream));
     if (int rc = attach_starts(idx, pt, nullptr, starts_count, seed, true)) return rc;
     idx->parts.push_back(pt);
     idx->finalized = false;
@@ -2554,6 +2556,25 @@ int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
     }
     idx->dist = g.d.release();
     return QADC_OK;
+}
+
+extern "C++" {
+namespace {
+// Measurement aid (qadc_dist_init_loopback): ONE rank stands in for a whole world — its block fills every slot of the
+// gather, so the merge replays `world` ranks' worth of entries while only this rank's shard is scanned.
+int loopback_allgather(void* ctx, const void* d_send, void* d_recv, uint64_t bytes, void* st) {
+    const int world = (int)reinterpret_cast<intptr_t>(ctx);
+    for (int g = 0; g < world; ++g)
+        if (hipMemcpyAsync(static_cast<unsigned char*>(d_recv) + (size_t)g * bytes, d_send, bytes, hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(st)) != hipSuccess)
+            return -1;
+    return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int qadc_dist_init_loopback(qadc_index* idx, int rank, int world) {
+    return qadc_dist_init_transport(idx, rank, world, loopback_allgather, reinterpret_cast<void*>((intptr_t)world));
 }
 
 int qadc_dist_init_transport(qadc_index* idx, int rank, int world, qadc_allgather_fn fn, void* ctx) {

@@ -585,8 +585,27 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     }
 
     const uint64_t clk1 = __builtin_readcyclecounter();
-    // (HEAD with a slot limit: only the first head_slots probed partitions are walked; the front above covered all ma)
-    const int mas = (HEAD && A.head_slots) ? min(ma, (int)A.head_slots) : ma;
+    // (HEAD with a slot limit: the walk ends with the head_slots-th probed partition that has codes HERE — on a multi-GPU
+    // shard a rank may hold nothing of a query's first probes, and the grouped second phase needs a bound from local
+    // candidates; ivf_count / ivf_scatter draw the same line.  The front above covered all ma.)
+    int mas = ma;
+    if (HEAD && A.head_slots) {
+        int seen = 0;
+        mas = ma;
+        for (int a0 = 0; a0 < ma; a0 += 64) {                    // every wave computes it for itself: lanes = slots
+            const int a_ = a0 + (int)lane;
+            const bool ne = a_ < ma && parts[assign[a_]].n != 0;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(ne);
+            const int cnt = __popcll(m);
+            if (seen + cnt >= (int)A.head_slots) {               // the head_slots-th non-empty slot lies in this chunk
+                uint64_t mm = m;
+                for (int k = seen + 1; k < (int)A.head_slots; ++k) mm &= mm - 1;   // drop the lower set bits
+                mas = a0 + (int)__builtin_ctzll(mm) + 1;
+                break;
+            }
+            seen += cnt;
+        }
+    }
     // ---- 3. int8 scan in assign[] order: free-running waves, epochs, one in-workgroup sort at the end ----
     // The query's scan order is cut into EPOCHS: 64, 128, 256, ... vectors at the start (while the bound is loose),
     // then one epoch per probed partition (long partitions: one per kEpochVec vectors).  Inside an epoch the 16 waves
@@ -1041,14 +1060,32 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_inline_kernel(QueryKerne
 // candidates only, i.e. from codes that precede it in its query's scan order, whatever order the groups run in.
 // order_cands_kernel then restores scan order per query and hands the streams to replay_heap_lanes_kernel.
 // ---------------------------------------------------------------------------------------------
+// One wave per query, lanes = assign slots.  A (query, probe) pair belongs to the second phase iff its partition has codes
+// here and at least `h` such probes precede it in the query's assign[] (those are the head's: scan_query_kernel, HEAD).
+template <typename F>
+__device__ __forceinline__ void ivf_for_grouped_pairs(const int32_t* __restrict__ assign_q, const PartDesc* __restrict__ parts,
+                                                      int ma, int h, uint32_t lane, F f) {
+    int seen = 0;
+    for (int a0 = 0; a0 < ma; a0 += 64) {
+        const int a = a0 + (int)lane;
+        int p = 0;
+        bool ne = false;
+        if (a < ma) {
+            p = assign_q[a];
+            ne = parts[p].n != 0;
+        }
+        const uint64_t m = __builtin_amdgcn_ballot_w64(ne);
+        const int before = seen + __popcll(m & ((1ull << lane) - 1ull));
+        if (ne && before >= h) f(a, p);
+        seen += __popcll(m);
+    }
+}
+
 __global__ __launch_bounds__(256) void ivf_count_kernel(const int32_t* __restrict__ assign, const PartDesc* __restrict__ parts,
                                                         int nq, int ma, int s0, uint32_t* __restrict__ cnt) {
-    const int per = ma - s0;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nq * per) return;
-    const int q = i / per, a = s0 + i % per;
-    const int p = assign[(size_t)q * ma + a];
-    if (parts[p].n != 0) atomicAdd(&cnt[p], 1u);
+    const int q = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (q >= nq) return;
+    ivf_for_grouped_pairs(assign + (size_t)q * ma, parts, ma, s0, threadIdx.x & 63u, [&](int, int p) { atomicAdd(&cnt[p], 1u); });
 }
 
 // goff[p] = first group of partition p, goff[K] = groups in all; one workgroup
@@ -1080,26 +1117,24 @@ __global__ __launch_bounds__(1024) void ivf_offsets_kernel(const uint32_t* __res
 __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int32_t* __restrict__ assign, const PartDesc* __restrict__ parts,
                                                           int nq, int ma, int s0, const uint32_t* __restrict__ goff,
                                                           uint32_t* __restrict__ fill, ScanItem* __restrict__ items) {
-    const int per = ma - s0;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nq * per) return;
-    const int q = i / per, a = s0 + i % per;
-    const int p = assign[(size_t)q * ma + a];
-    const PartDesc d = parts[p];
-    if (d.n == 0) return;
-    const uint32_t seat = atomicAdd(&fill[p], 1u);
-    ScanItem it;
-    it.codes = d.codes;
-    it.labels = d.labels;
-    it.n = d.n;
-    it.pos0 = 0;
-    it.key_base = d.key_base + d.first_pos;
-    it.table = (uint32_t)(q * ma + a);
-    it.query = (uint32_t)q;
-    it.order = (1u << 16) | (uint32_t)a;                         // bound level 1, assign slot a
-    it.dup_pos = d.first_pos + d.n == d.global_n ? d.n - 1u : 0xffffffffu;
-    it.dup_reps = (16u - d.global_n % 16u) % 16u;
-    items[(size_t)(goff[p] + seat / 8u) * 8u + seat % 8u] = it;
+    const int q = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (q >= nq) return;
+    ivf_for_grouped_pairs(assign + (size_t)q * ma, parts, ma, s0, threadIdx.x & 63u, [&](int a, int p) {
+        const PartDesc d = parts[p];
+        const uint32_t seat = atomicAdd(&fill[p], 1u);
+        ScanItem it;
+        it.codes = d.codes;
+        it.labels = d.labels;
+        it.n = d.n;
+        it.pos0 = 0;
+        it.key_base = d.key_base + d.first_pos;
+        it.table = (uint32_t)(q * ma + a);
+        it.query = (uint32_t)q;
+        it.order = (1u << 16) | (uint32_t)a;                     // bound level 1, assign slot a
+        it.dup_pos = d.first_pos + d.n == d.global_n ? d.n - 1u : 0xffffffffu;
+        it.dup_reps = (16u - d.global_n % 16u) % 16u;
+        items[(size_t)(goff[p] + seat / 8u) * 8u + seat % 8u] = it;
+    });
 }
 
 // One workgroup per query: the query's unordered Cand records (head + grouped pairs) -> ordered push stream in the
@@ -1418,11 +1453,10 @@ hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& 
 
 void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, int s0, int K, uint32_t* d_cnt,
                      uint32_t* d_goff, uint32_t* d_fill, ScanItem* d_items, hipStream_t stream) {
-    const int pairs = nq * (ma - s0);
-    if (pairs <= 0) return;
-    hipLaunchKernelGGL(ivf_count_kernel, dim3((pairs + 255) / 256), dim3(256), 0, stream, d_assign, d_parts, nq, ma, s0, d_cnt);
+    if (nq <= 0 || ma <= s0) return;
+    hipLaunchKernelGGL(ivf_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, d_assign, d_parts, nq, ma, s0, d_cnt);
     hipLaunchKernelGGL(ivf_offsets_kernel, dim3(1), dim3(1024), 0, stream, d_cnt, K, d_goff);
-    hipLaunchKernelGGL(ivf_scatter_kernel, dim3((pairs + 255) / 256), dim3(256), 0, stream, d_assign, d_parts, nq, ma, s0, d_goff,
+    hipLaunchKernelGGL(ivf_scatter_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, d_assign, d_parts, nq, ma, s0, d_goff,
                        d_fill, d_items);
 }
 

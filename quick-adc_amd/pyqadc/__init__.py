@@ -32,7 +32,7 @@ SYMBOLS = [
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
     "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_kmeans_iterations_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
     "qadc_dist_unique_id", "qadc_dist_init", "qadc_dist_collect", "qadc_dist_shutdown", "qadc_dist_merge_blocks", "qadc_dist_merge_blocks_host",
-    "qadc_dist_init_transport", "qadc_shm_transport_open", "qadc_shm_transport_allgather", "qadc_shm_transport_allgather_host",
+    "qadc_dist_init_transport", "qadc_dist_init_loopback", "qadc_shm_transport_open", "qadc_shm_transport_allgather", "qadc_shm_transport_allgather_host",
     "qadc_shm_transport_close", "qadc_shm_transport_error", "qadc_slot_assign", "qadc_place_partitions",
 ]
 
@@ -123,6 +123,7 @@ def lib():
         L.qadc_dist_merge_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_uint64, u32p, i8p, i32p]
         L.qadc_dist_merge_blocks_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_uint64, u32p, i8p, i32p]
         L.qadc_dist_init_transport.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.qadc_dist_init_loopback.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.qadc_shm_transport_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_double, C.POINTER(C.c_void_p)]
         L.qadc_shm_transport_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.qadc_shm_transport_allgather_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -465,6 +466,11 @@ class Index:
         _check(lib().qadc_dist_init_transport(self._h, transport.rank, transport.world, fn, transport._ctx))
         self._dist_world = transport.world
         self._transport = transport
+
+    def dist_init_loopback(self, rank, world):
+        """Measurement aid: this process stands in for rank `rank` of `world` (qadc_dist_init_loopback)."""
+        _check(lib().qadc_dist_init_loopback(self._h, rank, world))
+        self._dist_world = world
 
     def dist_shutdown(self):
         _check(lib().qadc_dist_shutdown(self._h))
