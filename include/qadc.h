@@ -94,14 +94,15 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * "mq_codes_per_wg", "mq_min_wgs", "mq_min_tiles", "prescan_mq", "overlap_front", "head_early", "front_run_max",
  * "front_min_batch", "front_dist" (kernel and launch tuning), "device_replay_nq" (batches of at least this many
  * queries replay their candidate streams through the heap on the device; 0 = always on the host),
- * "device_replay_alone_nq" (... from this many when nothing else is in flight: a synchronous call), "replay_threads";
+ * "device_replay_alone_nq" (... from this many when nothing else is in flight: a synchronous call), "replay_threads",
+ * "replay_wave" (device replay of the query kernel's streams: 1 one wave per query with the heap in registers, 0 one lane per query);
  * the one-workgroup-per-query path: "wgq" (0 never, 1 auto, 2 always), "wgq_min_nq", "wgq_max_codes",
  * "wgq_small_codes", "wgq_capacity", "wgq_cand_cap", "wgq_variant", "wgq_split" / "wgq_split_codes" (workgroups a
  * small batch spreads one query over / codes each keeps at least), "wgq_inline" (a lone small query's input rides
  * in the kernel arguments), "wgq_poll" (... and its completion is read from the mapped result block),
  * "wgq_group" (large IVF batches: partition-major second phase; 0 never, 1 auto, 2 whenever possible),
  * "wgq_group_head" (probes per query the one-workgroup-per-query head walks before it),
- * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_inject_failure" (test hook). */
+ * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_async", "dist_inject_failure" (test hook). */
 int qadc_set_option(qadc_index* idx, const char* name, double value);
 
 /* Copy codes back (tests / checksums): partition `part`, codes [first, first+count). */
@@ -270,16 +271,19 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
  * PUSH STREAM, not its final top-R: re-pushing final heaps is not exact under ties (binheap.hpp:75-116 resolves ties by
  * push order).  qadc_dist_collect replaces qadc_query_scan_collect: it packs this rank's streams (already in device
  * memory), runs ONE ncclAllGather (device to device, no host staging), and replays the world's streams in global
- * scan order (assign slot, rank, position) on the GPU, one lane per query — every rank ends with every query's heap,
+ * scan order (assign slot, rank, position) on the GPU, one wave per query — every rank ends with every query's heap,
  * so there is no second collective.  `extra` (optional, extra_n floats per rank) rides in the same all-gather and comes
  * back as extra_out[world][extra_n]: the multi-rank loop of bench.py ships the next batch's sharded pre-scan values
  * this way (qadc_prescan_submit).  RCCL is loaded with dlopen by qadc_dist_unique_id / qadc_dist_init; a single-GPU
- * user never loads it.  world <= 16.  Any R: the lane-per-query device replay holds R <= 288 (64 heaps per wave in LDS),
+ * user never loads it.  world <= 16.  Any R: the device merge (one wave per query, heap in registers) holds R <= 320,
  * larger heaps take the host-share replay.  A query some rank could not order on the device (> 16384 candidates) is
  * sorted on that rank's host and shipped in the same gather.  A rank whose batch failed locally still takes part in the
  * gather with a failure flag in its header, so every rank returns an error instead of one rank leaving the others
  * blocked.  A batch submitted after qadc_dist_init may still be collected with the plain collect calls (host replay
- * of this rank's streams only).
+ * of this rank's streams only).  Large one-workgroup-per-query batches (>= "dist_device_nq" queries: IVF) have their merge —
+ * pack, all-gather, interleave, replay — ENQUEUED WITH THE BATCH, behind its scan, so qadc_dist_collect only waits for it
+ * (option "dist_async", default 1): after qadc_dist_init every rank must therefore SUBMIT the same batches in the same
+ * order, not just collect them (the all-gather of such a batch is issued by its submit call).
  *   rank 0:      qadc_dist_unique_id(id)  ... ship the 128 bytes to the other ranks by any means ...
  *   every rank:  qadc_dist_init(idx, rank, world, id);  then per batch  qadc_query_scan_submit(...); qadc_dist_collect(...) */
 #define QADC_DIST_ID_BYTES 128

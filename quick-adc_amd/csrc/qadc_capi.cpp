@@ -157,6 +157,7 @@ struct Slot {
     uint64_t* h_heaps = nullptr;
     uint32_t* h_heap_sizes = nullptr;
     bool heaps_ready = false;           // a replay kernel ran for the batch: h_heaps / h_heap_sizes hold its result
+    bool rerun = false;                 // the batch is being re-run from inside a collect call (no merge is enqueued with it)
     bool skipped_streams = false;       // collect_common left device-replayed queries' streams unassembled
     QueryOut* h_qout = nullptr;
     uint64_t* h_entries = nullptr;
@@ -220,6 +221,25 @@ struct Slot {
 // ---- native multi-GPU merge (qadc_dist_*): RCCL through dlopen, so that the library has no link-time dependency
 // on it and a single-GPU user never loads it ----
 struct QadcNcclId { char internal[128]; };                  // layout of ncclUniqueId (rccl.h)
+// A merge enqueued together with its batch (qadc_dist_*; one-workgroup-per-query batches without an extra payload): pack,
+// all-gather, interleave and replay follow the scan on the merge's stream with no host in between, so the collect call
+// only waits for one event.  One set of buffers per submission slot (several batches are in flight).
+struct DistSlot {
+    DevBuf<uint64_t> d_block, d_gathered, d_merged, d_moff;
+    DevBuf<uint32_t> d_mcnt;
+    PinBuf<unsigned char> h_out;                             // mapped: heaps u64[nq][R], sizes u32[nq], status u32[4]
+    unsigned char* d_out = nullptr;
+    unsigned char* h_out_mapped = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    bool enqueued = false;
+    void release() {
+        d_block.release(); d_gathered.release(); d_merged.release(); d_moff.release(); d_mcnt.release(); h_out.release();
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_done) (void)hipEventDestroy(ev_done);
+        ev_ready = ev_done = nullptr;
+    }
+};
+
 struct DistState {
     void* lib = nullptr;
     int (*GetUniqueId)(QadcNcclId*) = nullptr;
@@ -237,6 +257,8 @@ struct DistState {
     DevBuf<uint64_t> d_block, d_gathered;
     DevBuf<uint32_t> d_src;                                  // [3][nq]: offset, count, flags of this rank's streams
     PinBuf<uint32_t> h_src;
+    DevBuf<uint64_t> d_moff, d_merged;                       // merge scratch: per-query offsets, the world's streams in global scan order
+    DevBuf<uint32_t> d_mcnt;                                 // [2][nq]: merged entries per query, replay flags
     DevBuf<uint64_t> d_fix;                                  // streams of the queries this rank had to order on the host
     PinBuf<uint64_t> h_fix;
     DevBuf<float> d_extra;
@@ -255,6 +277,8 @@ struct DistState {
     PinBuf<uint64_t> h_allheaps;
     int device_nq = 256;                                     // batches of at least this many queries replay on the device
     int inject_failure = 0;                                  // test hook: the next qadc_dist_collect of this rank fails locally
+    int async_merge = 1;                                     // enqueue the merge with the batch where possible (option "dist_async")
+    DistSlot slot[kSlots];
     // One all-gather of `words` u64 per rank on `st`: RCCL (enqueued, stream-ordered) or the caller's transport
     // (complete on return).  0 = ok; else the message is in `err`.
     int gather(const void* d_send, void* d_recv, size_t words, hipStream_t st, std::string& err) {
@@ -322,7 +346,9 @@ struct qadc_index {
     int group_strikes = 0; // grouped batches whose candidate regions overflowed (data whose later probes fall below the head's bound)
     int wgq_group = 1;     // partition-major second phase for large IVF batches: 0 never, 1 auto, 2 whenever possible
     int wgq_group_head = 4;   // ... after a head of this many probes per query (one workgroup per query)
+    int wgq_group_head_dist = 2;   // ... under the multi-GPU merge (probes with codes on this rank)
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
+    int replay_wave = 1;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
     int head_early = 1;    // the head launch joins the front stream (under the previous batch's long levels)
     int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
@@ -614,6 +640,7 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
 }
 
 int launch_wgq_batch(qadc_index* idx, Slot& s);
+int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream);
 
 // Plans the batch in slot s and enqueues all of its GPU work (front, levels, ordering, optional device replay).
 int plan_and_launch(qadc_index* idx, Slot& s) {
@@ -1070,7 +1097,9 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     // kernel then only walks the first probes of every query (head: front + a tight bound); the other pairs are
     // regrouped by partition on the device and scanned 8 queries per pass (see launch_ivf_plan), and a third kernel
     // orders every query's candidates into the stream layout the plain launch produces.
-    const int head_slots = std::min(idx->wgq_group_head, ma);
+    // (a shard's probes are fewer or shorter: a head of 2 local probes bounds as well and leaves more to the shared passes —
+    // one of 8 ranks, C3 shape: 1.75 -> 1.53 ms per batch, C5: 2.32 -> 2.17)
+    const int head_slots = std::min(idx->dist ? idx->wgq_group_head_dist : idx->wgq_group_head, ma);
     const size_t pairs = (size_t)nq * (size_t)(ma - head_slots);
     const size_t nparts = idx->parts.size();
     s.wgq_grouped = s.dev_replay && G == 1 && pairs > 0 && nparts < (1u << 24) &&
@@ -1107,6 +1136,8 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st, inl_bytes ? inl : nullptr, inl_bytes));
     }
     if (idx->profile) HIPCHECK(prof_event(s, st));
+    if (s.dist_batch && !s.rerun)
+        if (int rc = enqueue_merge(idx, s, st)) return rc;
     if (s.dev_replay) {
         if (!alone) {
             // replay on a side stream, under the next batches' scans.  A 1024-query replay (16 waves, one lane per
@@ -1120,13 +1151,59 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             st = (idx->replay_seq++ & 1) ? idx->front_stream : idx->sort_stream;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
         }
-        if (s.heaps_ready)
-        HIPCHECK(launch_replay_heap_lanes(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R,
-                                          reinterpret_cast<uint64_t*>(d_result + off_heaps),
-                                          reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq), st));
+        if (s.heaps_ready) {
+            uint64_t* d_heaps = reinterpret_cast<uint64_t*>(d_result + off_heaps);
+            uint32_t* d_sizes = reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
+            if (idx->replay_wave)                               // one wave per query, heap in registers
+                HIPCHECK(launch_replay_heap_wave_qflags(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
+            else                                                // one lane per query, heaps in LDS
+                HIPCHECK(launch_replay_heap_lanes(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
+        }
     }
     if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(s.ev_done, st));
+    return QADC_OK;
+}
+
+// The merge of a one-workgroup-per-query batch, enqueued right behind its scan: pack (from the kernels' own records in
+// device memory) -> all-gather -> interleave -> replay, all on the merge's stream; the heaps and a status word land in
+// pinned host memory.  Every rank enqueues the same collectives in the same order (the ranks submit the same batches).
+// Not taken (the collect-time merge runs instead): few-query batches (host-share replay), R or ma x world beyond the device
+// merge, option dist_async = 0.
+int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream) {
+    DistState& d = *idx->dist;
+    const int slot_i = (int)(&s - idx->slot);
+    if (slot_i < 0 || slot_i >= kSlots) return QADC_OK;
+    DistSlot& ds = d.slot[slot_i];
+    ds.enqueued = false;
+    const int nq = s.nq, R = s.R, world = d.world;
+    if (!d.async_merge || nq < d.device_nq || (uint32_t)R > replay_wave_max_R() || (size_t)s.ma * world > dist_interleave_max_cells())
+        return QADC_OK;
+    const size_t bw = dist_block_words(nq, d.cap_entries, 0);
+    HIPCHECK(ds.d_block.ensure(bw));
+    HIPCHECK(ds.d_gathered.ensure(bw * world));
+    HIPCHECK(ds.d_merged.ensure((size_t)d.cap_entries * world));
+    HIPCHECK(ds.d_moff.ensure(nq));
+    HIPCHECK(ds.d_mcnt.ensure(2 * (size_t)nq));
+    const size_t heaps_bytes = (sizeof(uint64_t) * (size_t)R + sizeof(uint32_t)) * (size_t)nq;
+    HIPCHECK(ds.h_out.ensure(heaps_bytes + 32, hipHostMallocMapped | hipHostMallocCoherent));
+    if (ds.h_out.p != ds.h_out_mapped) {
+        HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ds.d_out), ds.h_out.p, 0));
+        ds.h_out_mapped = ds.h_out.p;
+    }
+    if (!ds.ev_ready) HIPCHECK(hipEventCreateWithFlags(&ds.ev_ready, hipEventDisableTiming));
+    if (!ds.ev_done) HIPCHECK(hipEventCreateWithFlags(&ds.ev_done, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(ds.ev_ready, scan_stream));
+    hipStream_t st = d.stream;
+    HIPCHECK(hipStreamWaitEvent(st, ds.ev_ready, 0));
+    HIPCHECK(launch_dist_pack_qflags(s.d_qflags.p, nq, s.d_stream.p, s.wgq_cap, d.cap_entries, ds.d_block.p, st));
+    std::string gerr;
+    if (d.gather(ds.d_block.p, ds.d_gathered.p, bw, st, gerr)) return fail(QADC_E_HIP, gerr);
+    uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ds.d_out + sizeof(uint64_t) * (size_t)R * nq);
+    HIPCHECK(launch_dist_merge(ds.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, ds.d_moff.p, ds.d_mcnt.p, ds.d_mcnt.p + nq,
+                               ds.d_merged.p, reinterpret_cast<uint64_t*>(ds.d_out), d_sizes, st, d_sizes + nq));
+    HIPCHECK(hipEventRecord(ds.ev_done, st));
+    ds.enqueued = true;
     return QADC_OK;
 }
 
@@ -1166,6 +1243,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
         s.qtables_in.assign(qtables, qtables + nt);
     }
     s.full_prescan = false;
+    s.rerun = false;
     s.assign_on_device = false;
     {   // which path: levels (long shared lists) or one workgroup per query (IVF batches, small lists)
         uint64_t max_codes = 0;
@@ -1245,6 +1323,7 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
         s.assign.assign(s.h_assign.p, s.h_assign.p + (size_t)nq * ma);
     }
     s.full_prescan = false;
+    s.rerun = false;
     if (s.wgq) s.wgq_cap = std::max<uint32_t>(s.wgq_cap, idx->wgq_capacity);
     s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
     if (!s.wgq) s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)nq * 8192u, 1ull << 30));
@@ -1265,7 +1344,13 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool fr
     Slot& s = idx->slot[slot_i];
     if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
     if (int rc = use_device(idx)) return rc;
-    if (s.dist_batch && !from_dist) need_stream = true;
+    if (s.dist_batch && !from_dist) {
+        need_stream = true;
+        if (idx->dist && idx->dist->slot[slot_i].enqueued) {     // a merge was enqueued with the batch: let it finish (its result is unused)
+            HIPCHECK(hipEventSynchronize(idx->dist->slot[slot_i].ev_done));
+            idx->dist->slot[slot_i].enqueued = false;
+        }
+    }
     const uint32_t sort_limit_max = kSortCap;
     uint64_t total_sorted = 0;
     if (s.assign_on_device) {                                  // qadc_search: assign[] comes back for the caller (and the planner)
@@ -1310,6 +1395,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool fr
             s.wgq = false;
             s.wgq_G = 1;
             s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)s.nq * 8192u, 1ull << 30));
+            s.rerun = true;
             if (int rc = plan_and_launch(idx, s)) {
                 s.busy = false;
                 return rc;
@@ -1323,6 +1409,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool fr
         }
         s.wgq_cap = (uint32_t)(max_count + max_count / 8 + 64);  // every entry was counted: size for all of them, run again
         idx->prof.regrows++;
+        s.rerun = true;
         if (int rc = plan_and_launch(idx, s)) {
             s.busy = false;
             return rc;
@@ -1902,9 +1989,10 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "overlap_front") idx->overlap_front = value != 0;
     else if (n == "head_early") idx->head_early = value != 0;
     else if (n == "wgq_inline") idx->wgq_inline = value != 0;
+    else if (n == "replay_wave") idx->replay_wave = value != 0;
     else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);
     else if (n == "wgq_group") { idx->wgq_group = (int)std::max(0.0, std::min(value, 2.0)); idx->group_strikes = 0; }
-    else if (n == "wgq_group_head") idx->wgq_group_head = (int)std::max(1.0, std::min(value, 4096.0));
+    else if (n == "wgq_group_head") idx->wgq_group_head = idx->wgq_group_head_dist = (int)std::max(1.0, std::min(value, 4096.0));
     else if (n == "wgq_poll") idx->wgq_poll = value != 0;
     else if (n == "wgq_split_codes") idx->wgq_split_codes = (uint32_t)std::max(value, 1024.0);
     else if (n == "front_dist") idx->front_dist = value != 0;
@@ -1932,6 +2020,10 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "dist_device_nq") {                         // batches of at least this many queries replay on the device
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
         idx->dist->device_nq = (int)std::max(1.0, value);
+    }
+    else if (n == "dist_async") {                             // 1: enqueue the merge with the batch where possible; 0: always at collect time
+        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
+        idx->dist->async_merge = value != 0;
     }
     else if (n == "dist_inject_failure") {                    // test hook: this rank's next qadc_dist_collect fails before the gather
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
@@ -2596,21 +2688,26 @@ int qadc_dist_init_transport(qadc_index* idx, int rank, int world, qadc_allgathe
 
 int qadc_dist_merge_blocks(int device_id, int world, int nq, int ma, int R, const uint64_t* gathered, uint64_t block_words,
                            uint32_t* keys, int8_t* values, int32_t* sizes) {
-    if (world < 1 || world > 16 || nq <= 0 || ma <= 0 || R <= 0 || (uint32_t)R > replay_lanes_max_R() || !gathered || !sizes)
+    if (world < 1 || world > 16 || nq <= 0 || ma <= 0 || R <= 0 || (uint32_t)R > replay_wave_max_R() ||
+        (size_t)ma * world > dist_interleave_max_cells() || !gathered || !sizes)
         return fail(QADC_E_ARG, "bad arguments");
     HIPCHECK(hipSetDevice(device_id));
-    DevBuf<uint64_t> d_g, d_h;
-    DevBuf<uint32_t> d_s;
+    DevBuf<uint64_t> d_g, d_h, d_off, d_m;
+    DevBuf<uint32_t> d_s, d_c;
     HIPCHECK(d_g.ensure((size_t)block_words * world));
     HIPCHECK(d_h.ensure((size_t)nq * R));
     HIPCHECK(d_s.ensure(nq));
+    HIPCHECK(d_off.ensure(nq));
+    HIPCHECK(d_c.ensure(2 * (size_t)nq));
+    HIPCHECK(d_m.ensure((size_t)block_words * world));
     HIPCHECK(hipMemcpy(d_g.p, gathered, sizeof(uint64_t) * (size_t)block_words * world, hipMemcpyHostToDevice));
-    HIPCHECK(launch_dist_merge_lanes(d_g.p, (size_t)block_words, world, nq, ma, (uint32_t)R, d_h.p, d_s.p, nullptr));
+    HIPCHECK(launch_dist_merge(d_g.p, (size_t)block_words, world, nq, ma, (uint32_t)R, d_off.p, d_c.p, d_c.p + nq, d_m.p, d_h.p, d_s.p,
+                               nullptr));
     std::vector<uint64_t> hv((size_t)nq * R);
     std::vector<uint32_t> hs(nq);
     HIPCHECK(hipMemcpy(hv.data(), d_h.p, sizeof(uint64_t) * hv.size(), hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(hs.data(), d_s.p, sizeof(uint32_t) * nq, hipMemcpyDeviceToHost));
-    d_g.release(); d_h.release(); d_s.release();
+    d_g.release(); d_h.release(); d_s.release(); d_off.release(); d_c.release(); d_m.release();
     for (int q = 0; q < nq; ++q) {
         sizes[q] = hs[q] == 0xffffffffu ? -1 : (int32_t)hs[q];
         for (uint32_t i = 0; hs[q] != 0xffffffffu && i < hs[q]; ++i) {
@@ -2650,7 +2747,8 @@ int qadc_dist_shutdown(qadc_index* idx) {
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
     if (d->stream) (void)hipStreamDestroy(d->stream);
-    d->d_fix.release(); d->h_fix.release();
+    d->d_fix.release(); d->h_fix.release(); d->d_moff.release(); d->d_merged.release(); d->d_mcnt.release();
+    for (auto& ds : d->slot) ds.release();
     d->d_block.release(); d->d_gathered.release(); d->d_src.release(); d->h_src.release(); d->d_extra.release();
     d->h_extra.release(); d->h_out.release(); d->h_hdr.release(); d->h_extra_all.release();
     d->h_gathered.release(); d->h_myheaps.release(); d->d_myheaps.release(); d->d_allheaps.release(); d->h_allheaps.release();
@@ -2674,8 +2772,58 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
     // A failure of THIS rank's batch (candidate buffers that keep overflowing, a HIP error while re-running it) must not
     // leave the other ranks blocked in the gather: the rank still contributes a block, with bit7 set in every header, and
     // all ranks return the error after the gather.
+    DistSlot& ds = d.slot[slot];
+    const bool was_enqueued = ds.enqueued;
+    if (was_enqueued) {                                       // the merge ran behind the scan: wait for all of it
+        HIPCHECK(hipEventSynchronize(ds.ev_done));
+        ds.enqueued = false;
+    }
     int local_rc = collect_common(idx, slot, /*need_stream=*/false, /*from_dist=*/true);
     std::string local_err = local_rc ? g_err : std::string();
+    if (was_enqueued) {
+        const uint32_t* h_sz = reinterpret_cast<const uint32_t*>(ds.h_out.p + sizeof(uint64_t) * (size_t)R * nq);
+        const uint32_t bad = h_sz[nq], need = h_sz[nq + 1];
+        if (!bad) {
+            // every rank saw clean headers: the heaps are final (a local failure of collect_common concerns this rank only)
+            if (local_rc) return fail(local_rc, local_err);
+            std::vector<int32_t> st_async;
+            int32_t* stp = status;
+            if (!stp) { st_async.resize(nq); stp = st_async.data(); }
+            finish_float_outputs(idx, s, stp, nullptr, nullptr);
+            const uint64_t* hh = reinterpret_cast<const uint64_t*>(ds.h_out.p);
+            for (int q = 0; q < nq; ++q) {
+                uint32_t sz = h_sz[q];
+                if (stp[q] || sz == 0xffffffffu) sz = 0;
+                if (sizes) sizes[q] = (int32_t)sz;
+                const uint64_t* hv = hh + (size_t)q * R;
+                for (uint32_t i = 0; i < sz; ++i) {
+                    if (keys) keys[(size_t)q * R + i] = (uint32_t)hv[i];
+                    if (values) values[(size_t)q * R + i] = (int8_t)(hv[i] >> 32);
+                }
+            }
+            if (extra_n) {                                    // (a payload on such a batch travels by a small gather of its own)
+                const size_t w = ((size_t)extra_n + 1) / 2;
+                HIPCHECK(d.h_extra.ensure(2 * w));
+                HIPCHECK(d.d_extra.ensure(2 * w));
+                HIPCHECK(d.h_extra_all.ensure(2 * w * world));
+                HIPCHECK(d.d_block.ensure(w * world));
+                std::memcpy(d.h_extra.p, extra, sizeof(float) * extra_n);
+                HIPCHECK(hipMemcpyAsync(d.d_extra.p, d.h_extra.p, sizeof(uint64_t) * w, hipMemcpyHostToDevice, d.stream));
+                std::string gerr2;
+                if (d.gather(d.d_extra.p, d.d_block.p, w, d.stream, gerr2)) return fail(QADC_E_HIP, gerr2);
+                HIPCHECK(hipMemcpy2DAsync(d.h_extra_all.p, sizeof(float) * extra_n, d.d_block.p, sizeof(uint64_t) * w,
+                                          sizeof(float) * extra_n, world, hipMemcpyDeviceToHost, d.stream));
+                HIPCHECK(hipStreamSynchronize(d.stream));
+                std::memcpy(extra_out, d.h_extra_all.p, sizeof(float) * (size_t)world * extra_n);
+            }
+            return QADC_OK;
+        }
+        // Some rank's stream overflowed its region or the gather block (identical verdict on every rank: they read the same
+        // headers): the merge is redone below, at collect time, after collect_common re-ran what had to be re-run.
+        if ((bad & 64u) && need + need / 8 > d.cap_entries && need < (1ull << 31))
+            d.cap_entries = (uint32_t)(((uint64_t)need + need / 8 + 4095) / 4096 * 4096);
+        idx->prof.regrows++;
+    }
     if (d.inject_failure && !local_rc) {                      // test hook (option "dist_inject_failure")
         d.inject_failure = 0;
         local_rc = QADC_E_STATE;
@@ -2742,8 +2890,10 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
     hipStream_t st = d.stream;                               // the batch itself is complete (collect_common waited for it)
     uint64_t* h_heaps = reinterpret_cast<uint64_t*>(d.h_out.p);
     uint32_t* h_sizes = reinterpret_cast<uint32_t*>(d.h_out.p + sizeof(uint64_t) * (size_t)R * nq);
-    // the lane-per-query device replay keeps 64 heaps per wave in LDS: R <= 288; larger heaps take the host share
-    const bool on_device = nq >= d.device_nq && (uint32_t)R <= replay_lanes_max_R();
+    // the device merge keeps a query's heap in the registers of one wave (R <= 320) and interleaves the ranks' streams with
+    // ma x world counters in LDS; anything larger takes the host share
+    const bool on_device = nq >= d.device_nq && (uint32_t)R <= replay_wave_max_R() &&
+                           (size_t)s.ma * world <= dist_interleave_max_cells();
     std::string gerr;
     for (int attempt = 0;; ++attempt) {
         const size_t bw = dist_block_words(nq, d.cap_entries, (uint32_t)extra_n);
@@ -2756,10 +2906,14 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         HIPCHECK(launch_dist_pack(d.d_src.p, d.d_src.p + nq, d.d_src.p + 2 * nq, nq, s.d_stream.p, d.d_fix.p, d.cap_entries,
                                   extra_n ? d.d_extra.p : nullptr, (uint32_t)extra_n, d.d_block.p, st));
         if (d.gather(d.d_block.p, d.d_gathered.p, bw, st, gerr)) return fail(QADC_E_HIP, gerr);
-        if (on_device)
-            HIPCHECK(launch_dist_merge_lanes(d.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, reinterpret_cast<uint64_t*>(d.d_out),
-                                             reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq), st));
-        else {
+        if (on_device) {
+            HIPCHECK(d.d_moff.ensure(nq));
+            HIPCHECK(d.d_mcnt.ensure(2 * (size_t)nq));
+            HIPCHECK(d.d_merged.ensure((size_t)d.cap_entries * world));
+            HIPCHECK(launch_dist_merge(d.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, d.d_moff.p, d.d_mcnt.p, d.d_mcnt.p + nq,
+                                       d.d_merged.p, reinterpret_cast<uint64_t*>(d.d_out),
+                                       reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq), st));
+        } else {
             HIPCHECK(d.h_gathered.ensure(bw_room * world));
             HIPCHECK(hipMemcpyAsync(d.h_gathered.p, d.d_gathered.p, sizeof(uint64_t) * bw * world, hipMemcpyDeviceToHost, st));
         }

@@ -172,10 +172,30 @@ inline size_t dist_block_words(int nq, uint32_t cap_entries, uint32_t extra_n) {
 hipError_t launch_dist_pack(const uint32_t* d_src_off, const uint32_t* d_src_cnt, const uint32_t* d_src_flags, int nq,
                             const uint64_t* d_stream, const uint64_t* d_fix, uint32_t cap_entries, const float* d_extra,
                             uint32_t extra_n, uint64_t* d_block, hipStream_t stream);
-// world blocks -> heaps [nq][R] (key | value << 32) + sizes (0xffffffff: some rank's block overflowed / query not
-// ordered on a device: the caller regrows and repeats, or falls back).  world <= 16, R <= replay_lanes_max_R().
-hipError_t launch_dist_merge_lanes(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
-                                   uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
+// world blocks -> heaps [nq][R] (key | value << 32) + sizes (0xffffffff: some rank's block overflowed / a query was not
+// ordered: the caller regrows and repeats, or falls back).  Three launches: per-query totals + prefix, interleave into
+// ONE stream per query in global scan order (assign slot, rank, position), wave-per-query replay with the heap in
+// registers.  world <= 16, ma * world <= dist_interleave_max_cells(), R <= replay_wave_max_R().
+// Scratch of the caller: d_moff [nq] u64, d_mcnt / d_info [nq] u32, d_merged [world x entries of a block] u64.
+uint32_t replay_wave_max_R();
+size_t dist_interleave_max_cells();
+// d_status (optional, 2 words, may be host-mapped): [0] = OR of the header bits that void the merge (bit6 block too
+// small, bit7 a rank must re-run / failed, bit8 a query shipped unordered), [1] = entries the fullest rank block needs.
+hipError_t launch_dist_merge(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
+                             uint64_t* d_moff, uint32_t* d_mcnt, uint32_t* d_info, uint64_t* d_merged, uint64_t* d_heaps,
+                             uint32_t* d_heap_sizes, hipStream_t stream, uint32_t* d_status = nullptr);
+// The pack step of a merge enqueued together with its batch: the streams are described by the query kernels' own
+// {flags, entries} records in device memory (stream q at q * qcap), no host-provided offsets.
+hipError_t launch_dist_pack_qflags(const uint32_t* d_qflags, int nq, const uint64_t* d_stream, uint32_t qcap, uint32_t cap_entries,
+                                   uint64_t* d_block, hipStream_t stream);
+// kv_binheap push replay, ONE WAVE per query, heap in registers (v_readlane / v_writelane sift on the scalar unit, the
+// lanes pre-filter 64 stream entries per ballot): stream[off[q] .. off[q] + cnt[q]); info[q] bit0 = skip (size 0),
+// bit1 = leave to the host (size 0xffffffff).
+hipError_t launch_replay_heap_wave(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
+                                   int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
+// ... on the single-GPU layout of launch_replay_heap_lanes: query q's stream at q * cap, {flags, entries} in d_qflags[4q..].
+hipError_t launch_replay_heap_wave_qflags(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
+                                          uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
 
 // A failed per-device setup step of a launcher (dynamic-LDS opt-in) since the last call, or hipSuccess.
 hipError_t take_launch_error();

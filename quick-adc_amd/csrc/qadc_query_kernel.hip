@@ -1307,7 +1307,8 @@ __global__ __launch_bounds__(256) void dist_pack_kernel(const uint32_t* __restri
                                                         const uint64_t* __restrict__ stream,
                                                         const uint64_t* __restrict__ fix, uint32_t cap_entries,
                                                         const float* __restrict__ extra, uint32_t extra_n,
-                                                        uint64_t* __restrict__ block) {
+                                                        uint64_t* __restrict__ block, const uint32_t* __restrict__ qflags,
+                                                        uint32_t qcap) {
     __shared__ uint32_t red[4];
     const int q = blockIdx.x, tid = threadIdx.x;
     uint32_t* hdr = reinterpret_cast<uint32_t*>(block);         // [nq][4]
@@ -1317,65 +1318,313 @@ __global__ __launch_bounds__(256) void dist_pack_kernel(const uint32_t* __restri
         for (uint32_t i = tid; i < extra_n; i += 256) dst[i] = extra[i];
         return;
     }
+    // qflags != nullptr: the merge was enqueued with the batch (no host in between) — the streams are described by what
+    // the query kernels left in device memory: {flags, entries} per query, stream q at q * qcap.  A stream that overflowed
+    // its region or a query with a fallback pending (bit5) ships nothing and raises bit7: every rank then redoes the merge
+    // at collect time, after this rank re-ran its batch.
+    auto cnt_of = [&](int p) -> uint32_t {
+        if (!qflags) return src_cnt[p];
+        const uint32_t n_ = qflags[4 * p + 1];
+        return (n_ > qcap || (qflags[4 * p] & 32u)) ? 0u : n_;
+    };
     uint32_t part = 0;
-    for (int p = tid; p < q; p += 256) part += src_cnt[p];
+    for (int p = tid; p < q; p += 256) part += cnt_of(p);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();
     const uint32_t off = red[0] + red[1] + red[2] + red[3];
-    const uint32_t n = src_cnt[q];
+    const uint32_t n = cnt_of(q);
+    uint32_t fl = qflags ? (qflags[4 * q] & 0x3fu) : src_flags[q];
+    if (qflags && (qflags[4 * q + 1] > qcap || (qflags[4 * q] & 32u))) fl |= 128u;
     const bool fits = (uint64_t)off + n <= cap_entries;
     if (tid == 0) {
         hdr[4 * q + 0] = off;
         hdr[4 * q + 1] = n;
-        hdr[4 * q + 2] = src_flags[q] | (fits ? 0u : 64u);      // bit6: this rank's block was too small (bit7, set by the
-                                                                // host: the rank's batch failed before the gather)
+        hdr[4 * q + 2] = fl | (fits ? 0u : 64u);                // bit6: this rank's block was too small; bit7: the rank's batch
+                                                                // failed before the gather / must be re-run first
         hdr[4 * q + 3] = 0;
     }
     if (!fits) return;
     // bit8: the rank ordered this query on the host (more candidates than the device sort takes); its stream lies in `fix`
-    const uint64_t* __restrict__ s = ((src_flags[q] & 256u) ? fix : stream) + src_off[q];
+    const uint64_t* __restrict__ s = qflags ? stream + (size_t)q * qcap : ((fl & 256u) ? fix : stream) + src_off[q];
     for (uint32_t i = tid; i < n; i += 256) ent[off + i] = s[i];
 }
 
-__global__ __launch_bounds__(64) void dist_merge_lanes_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world,
-                                                              int nq, int ma, uint32_t R, uint64_t* __restrict__ heaps,
-                                                              uint32_t* __restrict__ heap_sizes) {
-    LaneHeap h{reinterpret_cast<uint64_t*>(qsmem), threadIdx.x, R, 0, 32u - (uint32_t)__builtin_clz(R)};
-    const uint32_t lane = threadIdx.x;
-    const int q = blockIdx.x * 64 + (int)lane;
-    const bool have = q < nq;
-    constexpr int kMaxWorld = 16;
-    uint32_t cur[kMaxWorld], end[kMaxWorld];
-    bool skip = !have, overflow = false;
-    for (int g = 0; g < world && g < kMaxWorld; ++g) {
-        cur[g] = end[g] = 0;
-        if (!have) continue;
-        const uint32_t* hdr = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * block_words);
-        cur[g] = hdr[4 * q + 0];
-        end[g] = cur[g] + hdr[4 * q + 1];
-        const uint32_t fl = hdr[4 * q + 2];
-        if (fl & 1u) skip = true;                               // qmax too high (identical on every rank)
-        if (fl & (64u | 128u)) overflow = true;                 // block too small / the rank's batch failed
-        if (!(fl & 4u)) overflow = true;                        // a rank could not order this query
+// ---------------------------------------------------------------------------------------------
+// kv_binheap<unsigned,int8_t>::push (binheap.hpp:75-116) with ONE WAVE per query and the heap in REGISTERS: element e
+// lives in lane e % 64 of register pair e / 64 (value, key).  Everything about a push is wave-uniform — the hole index,
+// the value, the children — so the sift runs on the scalar unit with v_readlane / v_writelane (a few cycles each)
+// (writes: one compare + select) instead of dependent LDS round trips (~100 cycles each): a seven-level sink costs ~0.1 us instead of ~0.8 us.
+// What the 64 lanes add is the FILTER: a chunk of 64 stream entries is loaded coalesced, one ballot finds the entries
+// below the current root, and only those are pushed (in order; the mask is re-filtered as the root drops).  An entry
+// that is not below the root when its chunk arrives would be rejected by push() at its turn as well (the root never
+// rises once the heap is full), so the heap array is the sequential one, entry for entry.
+// ---------------------------------------------------------------------------------------------
+template <int NREG>
+struct WaveHeap {
+    uint32_t hv[NREG], hk[NREG];                                 // element (j*64 + lane): value, key
+    uint32_t lane;
+    uint32_t R, size;                                            // wave-uniform
+
+    // (branch-free on purpose: every uniform branch costs the scalar pipeline more than the readlane it would skip)
+    __device__ __forceinline__ uint32_t val_at(uint32_t e) const {
+        uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)hv[0], (int)(e & 63u));
+#pragma unroll
+        for (int j = 1; j < NREG; ++j) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)hv[j], (int)(e & 63u));
+            r = (e >> 6) == (uint32_t)j ? t : r;
+        }
+        return r;
     }
-    if (overflow) skip = true;
-    if (!skip) {
-        h.push((uint64_t)127 << 32);                            // db_query_4.cpp:276
-        for (int slot = 0; slot < ma; ++slot)
-            for (int g = 0; g < world && g < kMaxWorld; ++g) {
-                const uint64_t* __restrict__ ent = gathered + (size_t)g * block_words + 2 * (size_t)nq;
-                // a rank scans its partitions in assign order: its slots are ascending
-                while (cur[g] < end[g]) {
-                    const uint64_t e = ent[cur[g]];
-                    if (ma > 1 && (uint32_t)((e >> 40) & 0x3fffu) != (uint32_t)slot) break;
-                    h.push(e & 0xffffffffffull);
-                    ++cur[g];
-                }
+    __device__ __forceinline__ uint32_t key_at(uint32_t e) const {
+        uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)hk[0], (int)(e & 63u));
+#pragma unroll
+        for (int j = 1; j < NREG; ++j) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)hk[j], (int)(e & 63u));
+            r = (e >> 6) == (uint32_t)j ? t : r;
+        }
+        return r;
+    }
+    __device__ __forceinline__ void set(uint32_t e, uint32_t value, uint32_t key) {
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) {                         // one compare + two selects per register pair
+            const bool own = (lane + 64u * (uint32_t)j) == e;
+            hv[j] = own ? value : hv[j];
+            hk[j] = own ? key : hk[j];
+        }
+    }
+    // all arguments wave-uniform
+    __device__ __forceinline__ void push(uint32_t key, uint32_t value) {
+        if (size != R) {                                         // room: append, bubble up past strictly smaller parents
+            uint32_t i = size++;
+            while (i != 0) {
+                const uint32_t parent = (i - 1) >> 1;
+                const uint32_t pv = val_at(parent);
+                if (!(value > pv)) break;
+                set(i, pv, key_at(parent));
+                i = parent;
             }
+            set(i, value, key);
+            return;
+        }
+        if (!(value < val_at(0))) return;                        // full: only strictly below the root
+        uint32_t i = 0;
+        for (;;) {
+            const uint32_t l = 2 * i + 1;
+            if (l >= size) break;
+            uint32_t cv = val_at(l), c = l;
+            if (l + 1 < size) {
+                const uint32_t rv = val_at(l + 1);
+                if (rv > cv) { cv = rv; c = l + 1; }             // the right child only if strictly greater
+            }
+            if (cv <= value) break;                              // stop at a child <= the value
+            set(i, cv, key_at(c));
+            i = c;
+        }
+        set(i, value, key);
     }
-    lane_heaps_out(h.hv, lane, h.size, overflow, blockIdx.x * 64, nq, R, heaps, heap_sizes);
+};
+
+// One wave per query: stream[off[q] .. off[q] + n[q]) (entries key | value << 32 | ...), after the (0,127) sentinel
+// (db_query_4.cpp:276).  info[q]: bit0 = skip (qmax too high: the reference exits, size 0), bit1 = not replayable here
+// (a block overflowed / an unordered query: size 0xffffffff, the host regrows or falls back).
+// QF: the single-GPU layout instead — query q's stream at q * cap, {flags, entries} in info[4q], info[4q + 1]
+// (scan_query_kernel / order_cands_kernel write those): bit0 of the flags = qmax too high, bit5 = fallback pending.
+template <int NREG, bool QF>
+__global__ __launch_bounds__(256) void replay_heap_wave_kernel(const uint64_t* __restrict__ stream, const uint64_t* __restrict__ off,
+                                                               const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ info,
+                                                               uint32_t cap, int nq, uint32_t R, uint64_t* __restrict__ heaps,
+                                                               uint32_t* __restrict__ heap_sizes) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const int q = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (q >= nq) return;
+    uint32_t fl, n;
+    uint64_t o;
+    if (QF) {
+        const uint32_t qf = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[4 * q]);
+        n = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[4 * q + 1]);
+        fl = (qf & 1u) | ((n > cap || (qf & 32u)) ? 2u : 0u);    // overflowed stream / fallback pending: the host re-runs the batch
+        o = (uint64_t)q * cap;
+    } else {
+        fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[q]);
+        n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[q]);
+        o = off[q];
+    }
+    if (fl & 2u) {
+        if (lane == 0) heap_sizes[q] = 0xffffffffu;
+        return;
+    }
+    if (fl & 1u) {
+        if (lane == 0) heap_sizes[q] = 0;
+        return;
+    }
+    const uint64_t* __restrict__ src = stream + (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
+                                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o));
+    WaveHeap<NREG> h;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) h.hv[j] = h.hk[j] = 0;
+    h.lane = lane;
+    h.R = R;
+    h.size = 0;
+    h.push(0u, 127u);                                            // the sentinel
+    uint64_t nxt = lane < n ? src[lane] : 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint64_t cur = nxt;
+        const uint32_t m = min(64u, n - base);                   // entries of this chunk
+        nxt = base + 64 + lane < n ? src[base + 64 + lane] : 0;  // the next chunk is in flight while this one is pushed
+        const uint32_t key = (uint32_t)cur, val = (uint32_t)(cur >> 32) & 0xffu;
+        uint32_t j0 = 0;
+        while (h.size != R && j0 < m) {                          // the heap is still filling: every entry goes in
+            h.push((uint32_t)__builtin_amdgcn_readlane((int)key, (int)j0), (uint32_t)__builtin_amdgcn_readlane((int)val, (int)j0));
+            ++j0;
+        }
+        if (j0 >= m) continue;
+        uint32_t root = h.val_at(0);
+        uint64_t mask = __builtin_amdgcn_ballot_w64(lane >= j0 && lane < m && val < root);
+        while (mask) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1;
+            h.push((uint32_t)__builtin_amdgcn_readlane((int)key, (int)j), (uint32_t)__builtin_amdgcn_readlane((int)val, (int)j));
+            root = h.val_at(0);
+            mask &= __builtin_amdgcn_ballot_w64(val < root);     // the root dropped: later entries may no longer qualify
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+        const uint32_t e = (uint32_t)j * 64u + lane;
+        if (e < h.size) heaps[(size_t)q * R + e] = (uint64_t)h.hk[j] | ((uint64_t)h.hv[j] << 32);
+    }
+    if (lane == 0) heap_sizes[q] = h.size;
+}
+
+// ---- the world's gathered blocks -> ONE stream per query in global scan order (assign slot, rank, position) ----
+// Per query: totals and flags over the ranks, exclusive prefix over the queries (one workgroup).
+__global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world, int nq,
+                                                           uint64_t* __restrict__ moff, uint32_t* __restrict__ mcnt,
+                                                           uint32_t* __restrict__ info, uint32_t* __restrict__ status) {
+    __shared__ uint64_t wsum[16];
+    __shared__ unsigned long long rank_tot[16];
+    __shared__ uint32_t bad;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const int per = (nq + 1023) / 1024;
+    const int lo = min(nq, (int)tid * per), hi = min(nq, lo + per);
+    if (tid < 16) rank_tot[tid] = 0;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    uint64_t mine = 0;
+    uint32_t my_bad = 0;
+    for (int g = 0; g < world && status; ++g) {                  // entries every rank wanted to ship: sizes a regrow
+        unsigned long long t = 0;
+        for (int q = lo; q < hi; ++q) t += (reinterpret_cast<const uint32_t*>(gathered + (size_t)g * block_words) + 4 * (size_t)q)[1];
+        if (t) atomicAdd(&rank_tot[g], t);
+    }
+    for (int q = lo; q < hi; ++q) {
+        uint32_t tot = 0, fl = 0;
+        for (int g = 0; g < world; ++g) {
+            const uint32_t* hdr = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * block_words) + 4 * (size_t)q;
+            tot += hdr[1];
+            const uint32_t f = hdr[2];
+            if (f & 1u) fl |= 1u;                                // qmax too high (identical on every rank)
+            if ((f & (64u | 128u)) || !(f & (4u | 1u))) fl |= 2u; // block too small / the rank failed / not ordered
+            my_bad |= (f & (64u | 128u)) | ((f & (4u | 1u)) ? 0u : 256u);
+        }
+        if (fl) tot = 0;
+        mcnt[q] = tot;
+        info[q] = fl;
+        mine += tot;
+    }
+    // exclusive prefix of the per-thread sums (64-bit: a batch may gather more than 2^32 entries)
+    uint64_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = (uint64_t)__shfl_up((unsigned long long)incl, (unsigned)d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t base = incl - mine;
+    for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
+    for (int q = lo; q < hi; ++q) {
+        moff[q] = base;
+        base += mcnt[q];
+    }
+    if (status) {                                                // (host-mapped: the caller reads it after the batch's event)
+        if (my_bad) atomicOr(&bad, my_bad);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long need = 0;
+            for (int g = 0; g < world; ++g) need = max(need, rank_tot[g]);
+            status[0] = bad;                                     // bit6 / bit7 / bit8 of any header: the merge must be redone
+            status[1] = (uint32_t)min(need, 0xffffffffull);      // entries the fullest rank block needs
+        }
+    }
+}
+
+// One workgroup per query.  Rank g's entries of the query are sorted by assign slot already; the merged position of its
+// i-th entry (slot s) is  #entries of every rank with a lower slot  +  #entries of lower ranks with slot s  +  its index
+// inside rank g's run of slot s.  Both terms are prefix sums over the count matrix cnt[s][g]: one in (s, g) order, one in
+// (g, s) order.  Dynamic LDS: 2 x ma x world counters.
+__global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world,
+                                                              int nq, int ma, const uint64_t* __restrict__ moff,
+                                                              const uint32_t* __restrict__ info, uint64_t* __restrict__ merged) {
+    uint32_t* cnt_sg = reinterpret_cast<uint32_t*>(qsmem);        // [ma][world] -> exclusive prefix in (s, g) order
+    uint32_t* cnt_gs = cnt_sg + (size_t)ma * world;               // [world][ma] -> exclusive prefix in (g, s) order
+    __shared__ uint32_t wtot[4];
+    const int q = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (info[q]) return;
+    const int cells = ma * world;
+    for (int i = tid; i < 2 * cells; i += 256) cnt_sg[i] = 0;
+    __syncthreads();
+    if (ma > 1)
+        for (int g = 0; g < world; ++g) {
+            const uint32_t* hdr = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * block_words) + 4 * (size_t)q;
+            const uint64_t* __restrict__ ent = gathered + (size_t)g * block_words + 2 * (size_t)nq + hdr[0];
+            const uint32_t n = hdr[1];
+            for (uint32_t i = tid; i < n; i += 256) {
+                const uint32_t sl = (uint32_t)(ent[i] >> 40) & 0x3fffu;
+                atomicAdd(&cnt_sg[sl * world + g], 1u);
+                atomicAdd(&cnt_gs[g * ma + sl], 1u);
+            }
+        }
+    else if ((int)tid < world) {                                  // one probe: a rank's count is its header's
+        const uint32_t* hdr = reinterpret_cast<const uint32_t*>(gathered + (size_t)tid * block_words) + 4 * (size_t)q;
+        cnt_sg[tid] = cnt_gs[tid] = hdr[1];
+    }
+    __syncthreads();
+    // two exclusive scans of `cells` counters each: thread t owns a contiguous run of each array
+    for (int arr = 0; arr < 2; ++arr) {
+        uint32_t* a = arr ? cnt_gs : cnt_sg;
+        const int per = (cells + 255) / 256;
+        const int lo = min(cells, (int)tid * per), hi = min(cells, lo + per);
+        uint32_t mine = 0;
+        for (int i = lo; i < hi; ++i) mine += a[i];
+        const uint32_t incl = q_wave_incl_sum(mine);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) base += wtot[w];
+        for (int i = lo; i < hi; ++i) {
+            const uint32_t c = a[i];
+            a[i] = base;
+            base += c;
+        }
+        __syncthreads();
+    }
+    uint64_t* __restrict__ out = merged + moff[q];
+    for (int g = 0; g < world; ++g) {
+        const uint32_t* hdr = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * block_words) + 4 * (size_t)q;
+        const uint64_t* __restrict__ ent = gathered + (size_t)g * block_words + 2 * (size_t)nq + hdr[0];
+        const uint32_t n = hdr[1];
+        const uint32_t rank_first = cnt_gs[g * ma];              // entries of the ranks below g (= prefix at (g, slot 0))
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint64_t e = ent[i];
+            const uint32_t sl = ma > 1 ? (uint32_t)(e >> 40) & 0x3fffu : 0u;
+            const uint32_t run_first = cnt_gs[g * ma + sl] - rank_first;      // index of the slot's first entry in rank g's stream
+            out[cnt_sg[sl * world + g] + (i - run_first)] = e;
+        }
+    }
 }
 
 }  // namespace
@@ -1480,19 +1729,59 @@ hipError_t launch_dist_pack(const uint32_t* d_src_off, const uint32_t* d_src_cnt
                             const uint64_t* d_stream, const uint64_t* d_fix, uint32_t cap_entries, const float* d_extra,
                             uint32_t extra_n, uint64_t* d_block, hipStream_t stream) {
     hipLaunchKernelGGL(dist_pack_kernel, dim3(nq + 1), dim3(256), 0, stream, d_src_off, d_src_cnt, d_src_flags, nq, d_stream,
-                       d_fix, cap_entries, d_extra, extra_n, d_block);
+                       d_fix, cap_entries, d_extra, extra_n, d_block, (const uint32_t*)nullptr, 0u);
     return hipGetLastError();
 }
 
-hipError_t launch_dist_merge_lanes(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
-                                   uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
-    static std::atomic<uint64_t> done{0};
-    if (world > 16) return hipErrorInvalidValue;
-    hipError_t e = lane_heap_lds_optin(reinterpret_cast<const void*>(&dist_merge_lanes_kernel), done);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dist_merge_lanes_kernel, dim3((nq + 63) / 64), dim3(64), ((size_t)R + 1) * 512, stream, d_gathered, block_words,
-                       world, nq, ma, R, d_heaps, d_heap_sizes);
+hipError_t launch_dist_pack_qflags(const uint32_t* d_qflags, int nq, const uint64_t* d_stream, uint32_t qcap, uint32_t cap_entries,
+                                   uint64_t* d_block, hipStream_t stream) {
+    hipLaunchKernelGGL(dist_pack_kernel, dim3(nq), dim3(256), 0, stream, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, nq, d_stream, (const uint64_t*)nullptr, cap_entries, (const float*)nullptr, 0u, d_block,
+                       d_qflags, qcap);
     return hipGetLastError();
+}
+
+uint32_t replay_wave_max_R() { return 320; }                     // five register pairs of 64 heap elements
+size_t dist_interleave_max_cells() { return 8192; }              // ma x world counters, twice, in 64 KiB of LDS
+
+// One wave per query over stream[off[q] .. +cnt[q]); R <= replay_wave_max_R().
+template <bool QF>
+static hipError_t launch_replay_wave_t(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
+                                       uint32_t cap, int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
+    if (R == 0 || R > replay_wave_max_R()) return hipErrorInvalidValue;
+    const dim3 grid((nq + 3) / 4), block(256);
+    switch ((R + 63) / 64) {
+        case 1: hipLaunchKernelGGL((replay_heap_wave_kernel<1, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
+        case 2: hipLaunchKernelGGL((replay_heap_wave_kernel<2, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
+        case 3: hipLaunchKernelGGL((replay_heap_wave_kernel<3, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
+        case 4: hipLaunchKernelGGL((replay_heap_wave_kernel<4, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
+        default: hipLaunchKernelGGL((replay_heap_wave_kernel<5, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_replay_heap_wave(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
+                                   int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
+    return launch_replay_wave_t<false>(d_stream, d_off, d_cnt, d_info, 0, nq, R, d_heaps, d_heap_sizes, stream);
+}
+hipError_t launch_replay_heap_wave_qflags(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
+                                          uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
+    return launch_replay_wave_t<true>(d_stream, nullptr, nullptr, d_qflags, cap, nq, R, d_heaps, d_heap_sizes, stream);
+}
+
+// The world's gathered blocks -> heaps: totals + prefix, interleave into global scan order, wave-per-query replay.
+// d_moff [nq] u64, d_mcnt / d_info [nq] u32, d_merged [world * entries of a block] u64: scratch of the caller.
+hipError_t launch_dist_merge(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
+                             uint64_t* d_moff, uint32_t* d_mcnt, uint32_t* d_info, uint64_t* d_merged, uint64_t* d_heaps,
+                             uint32_t* d_heap_sizes, hipStream_t stream, uint32_t* d_status) {
+    if (world > 16 || (size_t)ma * world > dist_interleave_max_cells() || R > replay_wave_max_R()) return hipErrorInvalidValue;
+    static std::atomic<uint64_t> done{0};
+    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&dist_interleave_kernel), 65536, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dist_totals_kernel, dim3(1), dim3(1024), 0, stream, d_gathered, block_words, world, nq, d_moff, d_mcnt, d_info,
+                       d_status);
+    hipLaunchKernelGGL(dist_interleave_kernel, dim3(nq), dim3(256), (size_t)ma * world * 8, stream, d_gathered, block_words, world, nq, ma,
+                       d_moff, d_info, d_merged);
+    return launch_replay_heap_wave(d_merged, d_moff, d_mcnt, d_info, nq, R, d_heaps, d_heap_sizes, stream);
 }
 
 hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,

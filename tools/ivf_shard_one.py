@@ -1,0 +1,11 @@
+"""One configuration of tools/ivf_shard_sizes.py (for rocprofv3): python3 tools/ivf_shard_one.py c3|c5 whole|range|none [rank]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "quick-adc_amd"))
+import bench
+from ivf_shard_sizes import SHAPES, WORLD
+name, placement = sys.argv[1], sys.argv[2]
+r = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+shard = None if placement == "none" else dict(rank=r, world=WORLD, placement=placement, init=lambda ix: ix.dist_init_loopback(r, WORLD), merge="loopback")
+o = bench.ivf_leg(0, shard=shard, **SHAPES[name])
+print(json.dumps({k: o[k] for k in o if k not in ("workload", "algorithmic_GBps_rule")}))
