@@ -846,7 +846,7 @@ def main():
             shm_tr.append(tr)
             ix.dist_init_transport(tr)
 
-        shard = dict(rank=rank, world=world, placement=os.environ.get("QADC_BENCH_IVF_PLACEMENT", "whole"), init=shard_init,
+        shard = dict(rank=rank, world=world, placement=os.environ.get("QADC_BENCH_IVF_PLACEMENT", "range"), init=shard_init,
                      barrier=sync, merge="native: qadc_dist_collect over " + ("RCCL" if native_dist else "the shared-memory transport"))
         ivf_n = ivf_leg(local_rank, shard=dict(shard))
         ivf_c5_n = None

@@ -70,6 +70,23 @@ def test_gpus_2_self_launch_runs_two_ranks_over_gloo_on_one_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("placement", ["range", "whole"])
+def test_gpus_2_ivf_legs_through_the_native_merge(placement):
+    """The N-rank line carries `ivf` (BASELINE configs[2] shape, shrunk) measured through qadc_search_submit +
+    qadc_dist_collect on every rank — here 2 ranks on one GPU over the shared-memory transport (RCCL needs a GPU per rank)."""
+    env = _env(QADC_BENCH_BACKEND="gloo", QADC_BENCH_ONE_GPU=1, QADC_BENCH_IVF_PLACEMENT=placement,
+               **dict(SMALL, QADC_BENCH_IVF_CODES=int(4e6), QADC_BENCH_CODES=int(1e7)))
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    ivf = line["ivf"]
+    assert ivf["rccl_ranks"] == 2 and ivf["placement"] == placement and ivf["us_per_query"] > 0
+    assert ivf["batches_through_partition_major_second_phase"] > 0 and ivf["of_them_redone_on_the_level_path"] == 0
+    assert "shared-memory" in ivf["merge"]
+
+
+@pytest.mark.gpu
 def test_single_gpu_line_keeps_the_two_modes_apart():
     env = _env(**dict(SMALL, QADC_BENCH_PMC=1, QADC_BENCH_IVF_CODES=int(4e6), QADC_BENCH_LATENCY=1, QADC_BENCH_32X4=1,
                       QADC_BENCH_SINGLE_QUERIES=8))
