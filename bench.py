@@ -598,7 +598,11 @@ def main():
             raise SystemExit("bench.py: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
     # ---- database: this rank's contiguous shard of the synthetic list + replica of the starts ----
-    first, local_n = sharded.shard_ranges(N, world)[rank]
+    # measurement hook (tools/dist_sizes3.sh): ONE process stands in for rank 0 of LOOP ranks — it holds 1/LOOP of the list,
+    # pre-scans 1/LOOP of the starts, and the loopback transport hands it LOOP copies of its own block to merge
+    LOOP = int(os.environ.get("QADC_BENCH_LOOPBACK_WORLD", 0)) if world == 1 and use_dist else 0
+    mworld = LOOP or world                                     # ranks the merge sees
+    first, local_n = sharded.shard_ranges(N, mworld)[rank]
     starts = max(1, int(np.float32(N) * np.float32(KEEP)))
     idx = pyqadc.Index(M, local_rank)
     idx.add_partition_synthetic_shard(N, first, local_n, SEED, starts)
@@ -628,8 +632,12 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         native_dist = bool(flag.item())
-        if native_dist:
+        if native_dist and LOOP:
+            idx.dist_init_loopback(0, LOOP)
+        elif native_dist:
             native_init(idx)
+        for kv in filter(None, os.environ.get("QADC_BENCH_DIST_OPTS", "").split(",")) if native_dist else ():   # tuning experiments only
+            idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 
     rng = np.random.default_rng(1234)
     codebooks = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
@@ -667,7 +675,7 @@ def main():
 
         def prescan(b):                                        # batch b's sliced pre-scan -> pre-slot b % 2
             tbs[b % 6] = pool[b % len(pool)].copy()
-            idx.prescan_submit(b % 2, assign, tbs[b % 6], R, rank, world)
+            idx.prescan_submit(b % 2, assign, tbs[b % 6], R, rank, mworld)
 
         def merge(slot_i, pv):
             """Finished batch -> (keys, vals, sizes[, gathered pre-scan values]).  Native: qadc_dist_collect — ONE
@@ -678,7 +686,7 @@ def main():
                 res3 = (out["keys"], out["values"], out["sizes"])
                 if pv is None:
                     return res3
-                g = out["extra"].reshape(world, NQ, -1)
+                g = out["extra"].reshape(mworld, NQ, -1)
                 return res3 + (np.ascontiguousarray(g.transpose(1, 0, 2)).reshape(NQ, -1),)
             res = idx.collect_candidates(slot_i)
             return sharded.merge_batch(res, NQ, R, res["status"], cdev, extra=pv)
@@ -692,6 +700,8 @@ def main():
             if b + 2 < nb:
                 prescan(b + 2)
         g = sharded.gather_prescan(np.concatenate(pvs), cdev)
+        if LOOP:
+            g = np.tile(g, (1, LOOP))
         for b in range(nb):
             idx.submit(b % 4, assign, tbs[b % 6], R, prescan=g[b * NQ:(b + 1) * NQ])
         if k > LEAD:
@@ -712,11 +722,21 @@ def main():
             if i + LEAD < k:
                 idx.submit((i + LEAD) % 4, assign, tbs[(i + LEAD) % 6], R, prescan=out[3])
             te = time.perf_counter()
+            if stamps is not None:
+                acc = run_steps_dist.acc = getattr(run_steps_dist, "acc", [0.0] * 5)
+                for j, v in enumerate((tb_ - ta, tc - tb_, td - tc, te - td)):
+                    acc[j] += v
+                acc[4] += 1
             if stamps is not None and te - ta > 5e-3 and rank == 0:
                 print("SLOW iter %d: prescan %.2f collect_pv %.2f merge %.2f submit %.2f ms" % (i, (tb_-ta)*1e3, (tc-tb_)*1e3, (td-tc)*1e3, (te-td)*1e3), file=sys.stderr)
         if stamps and rank == 0:                                # tuning aid: per-iteration host times of the loop
             d = np.diff(np.array(stamps)) * 1e3
+            acc = run_steps_dist.acc
             with open(os.environ["QADC_BENCH_STEP_LOG"], "a") as f:
+                f.write("host ms per iteration: prescan_submit %.3f prescan_collect %.3f merge %.3f submit %.3f (profile: host_heap %.3f plan %.3f)\n" % (
+                    acc[0] / acc[4] * 1e3, acc[1] / acc[4] * 1e3, acc[2] / acc[4] * 1e3, acc[3] / acc[4] * 1e3,
+                    idx.profile()["host_heap_ms"] / max(acc[4], 1), idx.profile()["host_plan_ms"] / max(acc[4], 1)))
+                run_steps_dist.acc = [0.0] * 5
                 f.write("steps %d: median %.3f ms, max %.3f at %d, >2x median: %s\n" % (
                     k, np.median(d), d.max(), int(d.argmax()), [(int(j), round(float(d[j]), 2)) for j in np.nonzero(d > 2 * np.median(d))[0]][:40]))
         return last

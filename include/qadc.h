@@ -320,6 +320,11 @@ const char* qadc_shm_transport_error(void);
 /* The probed partitions of the batch last collected from `slot` (qadc_search_submit computes assign[] on the GPU;
  * qadc_dist_collect has no assign_out): assign_out [nq][ma]. */
 int qadc_slot_assign(qadc_index* idx, int slot, int32_t* assign_out);
+/* The int8 tables (QuantizerMAX<int8_t> output, db_query_4.cpp:277-284) of queries [q_first, q_first + q_count) of the
+ * batch last collected from `slot`, [q_count][ma][M][16] — still resident on the GPU until the slot is submitted again.
+ * qadc_search builds its float tables on the device and returns no tables; this is how a caller (the parity tests: the
+ * reference's own scan_avx_4 on the same int8 tables) gets at them. */
+int qadc_slot_qtables(qadc_index* idx, int slot, int q_first, int q_count, int8_t* out);
 /* Size-balanced placement of whole partitions on `world` ranks (IVF option 1): partitions in descending
  * size order, each to the currently lightest rank (ties: lowest rank).  owner_out[p] = rank of partition p.  A rank adds
  * the partitions it owns in full and the others with local_n = 0 (starts replica only, qadc_index_add_partition_shard),

@@ -488,7 +488,7 @@ int orc_query_scan(int M, const uint8_t* const* all_parts, const uint32_t* const
         for (long i = 0; i < all; ++i) if (tables[i] < 0) tables[i] = 0;
     }
     *out_qmin = qmin; *out_qmax = qmax;
-    if (qmax > 1e30f) return 1;
+    if ((double)qmax > 1e30) return 1;                           /* db_query_4.cpp:271 compares the float with a double literal */
     orc_quantize_tables(tables, all, qmin, qmax, quant_mode, out_qtables);
     /* sentinel + scan of every probed partition IN FULL, in assign order (276, 287-308) */
     orc_heap_i8 h = { out_keys, out_vals, R, 0 };

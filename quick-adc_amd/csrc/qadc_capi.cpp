@@ -2998,6 +2998,19 @@ int qadc_slot_assign(qadc_index* idx, int slot, int32_t* assign_out) {
     return QADC_OK;
 }
 
+int qadc_slot_qtables(qadc_index* idx, int slot, int q_first, int q_count, int8_t* out) {
+    if (!idx || slot < 0 || slot >= kSlots || !out || q_first < 0 || q_count < 0) return fail(QADC_E_ARG, "bad arguments");
+    const Slot& s = idx->slot[slot];
+    if (s.busy) return fail(QADC_E_STATE, "collect the batch first");
+    if (!s.d_qt || s.nq <= 0) return fail(QADC_E_STATE, "slot has held no batch");
+    if ((int64_t)q_first + q_count > s.nq) return fail(QADC_E_ARG, "query range outside the batch");
+    if (int rc = use_device(idx)) return rc;
+    const size_t per_q = (size_t)s.ma * idx->M * 16;
+    HIPCHECK(hipMemcpyAsync(out, s.d_qt + (size_t)q_first * per_q, (size_t)q_count * per_q, hipMemcpyDeviceToHost, idx->copy_stream));
+    HIPCHECK(hipStreamSynchronize(idx->copy_stream));
+    return QADC_OK;
+}
+
 int qadc_place_partitions(int part_count, const uint32_t* sizes, int world, int32_t* owner_out) {
     if (part_count < 0 || world < 1 || (part_count && (!sizes || !owner_out))) return fail(QADC_E_ARG, "bad arguments");
     std::vector<int> order(part_count);

@@ -1407,7 +1407,7 @@ __device__ void quantize_query(int table_dim_all, float* __restrict__ tb, int8_t
     float qmin = red[0];
     uint32_t flags = 0;
     if (qmin < 0) { qmin = 0; flags |= 2u; }
-    if (qmax > 1e30f) flags |= 1u;
+    if ((double)qmax > 1e30) flags |= 1u;                       // (a double compare, as db_query_4.cpp:271: 1e30f itself is above 1e30)
     const float delta = (qmax - qmin) / 127;
     const float scale = 127.0f / (qmax - qmin);
     for (int i = t; i < table_dim_all; i += 1024) {

@@ -541,7 +541,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         STAMP(5);
         // ---- 2. qmin / clamp / QuantizerMAX (db_query_4.cpp:258-284, 37-71) ----
         if (qmin < 0) { qmin = 0; flags |= 2u; }
-        if (qmax > 1e30f) flags |= 1u;
+        if ((double)qmax > 1e30) flags |= 1u;                   // (a double compare, as db_query_4.cpp:271: 1e30f itself is above 1e30)
         const float delta = (qmax - qmin) / 127;
         const float scale = 127.0f / (qmax - qmin);
         const int all = ma * M * 16;

@@ -10,14 +10,19 @@
 //   learn_coarse_quantizer_hip(...)        learn_coarse_quantizer (databases.cpp:94-118) from a caller-provided seed:
 //                                          the reference seeds with two OpenCV k-means++ iterations (third-party, absent
 //                                          here), then runs kmeans_iter_max - 2 = 48 fast iterations — those run on the GPU
-// Chunked feeding (db_add.cpp:52-82 reads the base file chunk by chunk and calls add_vectors per chunk with the chunk's
-// offset) is the caller's loop around add_vectors_hip; labels = index in chunk + labels_offset, as there.
+//   db_add_hip(db, base_file, chunk_count) db_add's add_vectors (db_add.cpp:52-82): a reader thread (io::vectors_reader,
+//                                          vector_io.hpp:231-288) fills a two-chunk queue from the .fvecs/.bvecs file while
+//                                          this thread encodes the previous chunk on the GPU; labels = index in chunk + the
+//                                          chunk's offset, as there.
 #pragma once
 #include <stdexcept>
 #include <string>
 #include <vector>
 
+#include <thread>
+
 #include "../../include/qadc.h"
+#include "qadc_io.hpp"
 #include "query_driver.hpp"
 
 namespace qadc {
@@ -44,6 +49,43 @@ inline void add_vectors_hip(ivf_database& db, const float* vecs, unsigned n, uns
         db.partitions[p].insert(db.partitions[p].end(), codes.begin() + (size_t)i * cs, codes.begin() + (size_t)(i + 1) * cs);
         db.labels[p].push_back(i + labels_offset);
     }
+}
+
+inline void add_chunk_hip(flat_database& db, const io::vectors_chunk& c, int device) { add_vectors_hip(db, c.data.data(), c.count, device); }
+inline void add_chunk_hip(ivf_database& db, const io::vectors_chunk& c, int device) {
+    add_vectors_hip(db, c.data.data(), c.count, c.offset, device);
+}
+inline void add_chunk_cpu(flat_database& db, const io::vectors_chunk& c) { db.add_vectors(c.data.data(), c.count); }
+inline void add_chunk_cpu(ivf_database& db, const io::vectors_chunk& c) { db.add_vectors(c.data.data(), c.count, c.offset); }
+
+// db_add.cpp:52-82.  on_gpu = false runs the host loops instead (the definition the GPU build is compared with).
+// Returns the vectors added; throws with the reference's message if the reader fails (wrong dimension, unknown extension).
+template <typename Db>
+unsigned db_add_hip(Db& db, const char* base_filename, unsigned chunk_count = 1000000, int device = 0, bool on_gpu = true) {
+    io::vectors_reader reader(base_filename, chunk_count);
+    if (reader.dim() != db.pq->dim) throw std::runtime_error("base vectors and quantizer disagree on the dimension");
+    std::thread read_thread([&reader] { reader.run(); });
+    unsigned added = 0;
+    std::string error;
+    while (!reader.done()) {
+        io::vectors_chunk chunk = reader.get_chunk();
+        if (chunk.failed) {
+            error = chunk.error;
+            break;
+        }
+        if (error.empty()) {
+            try {
+                if (on_gpu) add_chunk_hip(db, chunk, device);
+                else add_chunk_cpu(db, chunk);
+                added += chunk.count;
+            } catch (const std::exception& e) {
+                error = e.what();                                // keep draining: the reader must not stay blocked on a full queue
+            }
+        }
+    }
+    read_thread.join();
+    if (!error.empty()) throw std::runtime_error(error);
+    return added;
 }
 
 // databases.cpp:50-90 on the host: assign every vector to its closest centroid (squared L2 accumulated in ascending d,

@@ -25,10 +25,14 @@
 // Errors throw std::runtime_error carrying the reference's message text; a CLI prints it and exits 1 like the
 // reference does.
 #pragma once
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <mutex>
+#include <queue>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -106,6 +110,126 @@ void save_vectors(const T* data, int dim, long count, const char* filename) {  /
         f.write(reinterpret_cast<const char*>(data + (size_t)i * dim), sizeof(T) * (size_t)dim);
     }
 }
+
+// ---- chunked reading on a thread of its own (vector_io.hpp:180-290) ----------------------------------------------
+// db_add (db_add.cpp:52-82) does not load the base file whole: a reader thread fills a bounded queue (two chunks of
+// wanted_chunk_count vectors) while the main thread encodes the previous chunk.  Same here; the chunk carries its offset
+// (= label of its first vector).
+template <typename T>
+class safe_bounded_queue {  // vector_io.hpp:189-229
+    std::mutex mutex_;
+    std::condition_variable not_empty_, not_full_;
+    std::queue<T> queue_;
+    std::size_t max_size_;
+
+public:
+    explicit safe_bounded_queue(int max_size) : max_size_((std::size_t)max_size) {}
+    bool empty() {
+        std::lock_guard<std::mutex> lock(mutex_);
+        return queue_.empty();
+    }
+    void push(T&& item) {
+        std::unique_lock<std::mutex> lock(mutex_);
+        not_full_.wait(lock, [this] { return queue_.size() < max_size_; });
+        queue_.push(std::move(item));
+        lock.unlock();
+        not_empty_.notify_one();
+    }
+    void pop(T& item) {
+        std::unique_lock<std::mutex> lock(mutex_);
+        not_empty_.wait(lock, [this] { return !queue_.empty(); });
+        item = std::move(queue_.front());
+        queue_.pop();
+        lock.unlock();
+        not_full_.notify_one();
+    }
+};
+
+struct vectors_chunk {  // vector_io.hpp:168-185
+    std::vector<float> data;
+    int dim = 0;
+    unsigned count = 0, offset = 0;
+    bool failed = false;         // the reader hit an error: `error` holds the reference's message
+    std::string error;
+};
+
+class vectors_reader {  // vector_io.hpp:231-288 + vectors_reader_by_extension (vector_io.cpp:60-91)
+public:
+    static constexpr int MAX_QUEUE_SIZE = 2;
+    vectors_reader(const char* filename, unsigned chunk_count = 1000000)
+        : queue_(MAX_QUEUE_SIZE), wanted_chunk_count_(chunk_count), filename_(filename) {
+        const char* ext = std::strrchr(filename, '.');
+        if (ext && !std::strcmp(ext, ".bvecs")) elem_ = 1;
+        else if (ext && !std::strcmp(ext, ".fvecs")) elem_ = 4;
+        else if (ext && !std::strcmp(ext, ".ivecs")) elem_ = -4;
+        else throw std::runtime_error(std::string("Could not load vectors from ") + filename +
+                                      "\nUnknown extension\nKnown extensions: .bvecs, .ivecs, .fvecs");
+        std::ifstream f;
+        open_or_throw(filename, f);
+        std::int32_t dim = 0;
+        f.read(reinterpret_cast<char*>(&dim), sizeof(dim));
+        if (!f || dim <= 0) throw std::runtime_error(std::string("Could not load vectors from ") + filename);
+        f.seekg(0, std::ifstream::end);
+        dim_ = dim;
+        count_ = (unsigned)((long)f.tellg() / ((long)dim * (elem_ < 0 ? 4 : elem_) + 4));
+        read_count_ = 0;
+    }
+    // the reader thread's body
+    void run() {
+        std::ifstream f;
+        try {
+            open_or_throw(filename_.c_str(), f);
+            const std::size_t esz = (std::size_t)(elem_ < 0 ? 4 : elem_);
+            std::vector<unsigned char> rec((std::size_t)dim_ * esz);
+            while (read_count_.load() != count_) {
+                vectors_chunk chunk;
+                chunk.dim = dim_;
+                chunk.count = std::min(wanted_chunk_count_, count_ - read_count_.load());
+                chunk.offset = read_count_.load();
+                chunk.data.resize((std::size_t)chunk.count * dim_);
+                for (unsigned i = 0; i < chunk.count; ++i) {
+                    std::int32_t d = 0;
+                    f.read(reinterpret_cast<char*>(&d), sizeof(d));
+                    if (!f || d != dim_) {
+                        std::ostringstream os;
+                        os << "Error while reading vectors.\nVector " << (chunk.offset + i) << " has " << d
+                           << " dimensions while other vectors have " << dim_ << " dimensions\nAll vectors must have the same number of dimensions";
+                        throw std::runtime_error(os.str());
+                    }
+                    f.read(reinterpret_cast<char*>(rec.data()), (std::streamsize)rec.size());
+                    float* o = chunk.data.data() + (std::size_t)i * dim_;
+                    if (elem_ == 1) for (int k = 0; k < dim_; ++k) o[k] = (float)rec[k];
+                    else if (elem_ == 4) std::memcpy(o, rec.data(), rec.size());
+                    else for (int k = 0; k < dim_; ++k) { std::int32_t v; std::memcpy(&v, rec.data() + 4 * k, 4); o[k] = (float)v; }
+                }
+                read_count_ += chunk.count;
+                queue_.push(std::move(chunk));
+            }
+        } catch (const std::exception& e) {
+            vectors_chunk bad;
+            bad.failed = true;
+            bad.error = e.what();
+            read_count_ = count_;
+            queue_.push(std::move(bad));
+        }
+    }
+    unsigned count() const { return count_; }
+    int dim() const { return dim_; }
+    bool done() { return read_count_.load() == count_ && queue_.empty(); }
+    vectors_chunk get_chunk() {
+        vectors_chunk c;
+        queue_.pop(c);
+        return c;
+    }
+
+private:
+    safe_bounded_queue<vectors_chunk> queue_;
+    unsigned wanted_chunk_count_;
+    int dim_ = 0, elem_ = 4;
+    unsigned count_ = 0;
+    std::atomic<unsigned> read_count_{0};
+    std::string filename_;
+};
 
 // ---- product quantizer files ------------------------------------------------------------------
 struct pq_data {

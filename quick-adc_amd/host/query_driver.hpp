@@ -59,6 +59,7 @@ struct pq4 {
     }
     int sq_dim() const { return dim / sq_count; }
     int code_size() const { return sq_count / 2; }
+    int table_dim() const { return sq_count * 16; }
     const float* centroid(int m, int c) const { return centroids.data() + ((size_t)m * 16 + c) * sq_dim(); }
 
     // tables[m][c] = ||x_m - centroid(m,c)||^2
@@ -127,8 +128,9 @@ struct pq4 {
     }
 };
 
-struct flat_database {
-    std::unique_ptr<pq4> pq;
+template <typename Pq>
+struct flat_database_t {                 // flat_db over any quantizer: pq4 here, pq_bytes (host/scanner_simple.hpp) for PQ 8x8
+    std::unique_ptr<Pq> pq;
     std::vector<std::uint8_t> codes;
     unsigned count = 0;
 
@@ -151,6 +153,7 @@ struct flat_database {
         }
     }
 };
+typedef flat_database_t<pq4> flat_database;
 
 struct ivf_database {
     std::unique_ptr<pq4> pq;
@@ -232,8 +235,8 @@ struct nns_engine {  // query_common.hpp:245-309
     std::vector<float> residuals, dists;
     std::vector<int> assign;
     nns_engine(Scanner& s, Db& d, int ma_)
-        : db(d), scanner(s), ma(ma_), table_dim(d.pq->sq_count * 16), residuals((size_t)ma_ * d.pq->dim),
-          dists((size_t)ma_ * d.pq->sq_count * 16), assign(ma_) {}
+        : db(d), scanner(s), ma(ma_), table_dim(d.pq->table_dim()), residuals((size_t)ma_ * d.pq->dim),
+          dists((size_t)ma_ * d.pq->table_dim()), assign(ma_) {}
     void prepare_database() { scanner.prepare_database(db); }
     template <typename Heap>
     void process_query(const float* query, Heap& bh, query_metrics& metrics) {
@@ -265,8 +268,8 @@ struct nns_engine_batch {
     std::vector<float> residuals, dists;
     std::vector<int> assign;
     nns_engine_batch(Scanner& s, Db& d, int ma_, int batch_, int r_)
-        : db(d), scanner(s), ma(ma_), batch(batch_), table_dim(d.pq->sq_count * 16), r(r_),
-          residuals((size_t)batch_ * ma_ * d.pq->dim), dists((size_t)batch_ * ma_ * d.pq->sq_count * 16),
+        : db(d), scanner(s), ma(ma_), batch(batch_), table_dim(d.pq->table_dim()), r(r_),
+          residuals((size_t)batch_ * ma_ * d.pq->dim), dists((size_t)batch_ * ma_ * d.pq->table_dim()),
           assign((size_t)batch_ * ma_) {}
     void prepare_database() { scanner.prepare_database(db); }
     template <typename Heap>
@@ -298,7 +301,8 @@ struct nns_engine_batch {
 };
 
 // query_common.hpp:330-368.  groundtruth[q] = id of the true nearest neighbour; recall@R counts the queries
-// whose true neighbour is among keys()[0..R) — read unsorted and up to R even if the heap is not full.
+// whose true neighbour is among the keys — read unsorted.  The reference reads keys()[0..R) even when the heap is not
+// full (uninitialised tail, warning at query_common.hpp:357-361); this driver deliberately reads only keys()[0..size()).
 template <typename Db, typename Scanner, typename Heap>
 inline void call_engine(nns_engine<Db, Scanner>& e, int q, const float* queries, int, int dim, Heap& bh, query_metrics& m) {
     e.process_query(queries + (size_t)q * dim, bh, m);
@@ -331,6 +335,10 @@ void process_queries(Engine& engine, const float* queries, int count, int dim, i
 inline void print_csv(std::ostream& os, int r, double recall, int ma, float keep, const query_metrics& m) {
     os << "r,recall,ma,adc_type,keep,index_us,rotate_us,table_us,scan_us" << std::endl;  // db_query_4.cpp:387-390
     os << r << "," << recall << "," << ma << ",qadc," << keep << "," << m << std::endl;
+}
+inline void print_csv_adc(std::ostream& os, int r, double recall, int ma, const query_metrics& m) {
+    os << "r,recall,ma,adc_type,index_us,rotate_us,table_us,scan_us" << std::endl;       // db_query.cpp:112-115
+    os << r << "," << recall << "," << ma << ",adc," << m << std::endl;
 }
 
 }  // namespace qadc

@@ -33,7 +33,7 @@ SYMBOLS = [
     "qadc_search_collect", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_kmeans_iterations_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
     "qadc_dist_unique_id", "qadc_dist_init", "qadc_dist_collect", "qadc_dist_shutdown", "qadc_dist_merge_blocks", "qadc_dist_merge_blocks_host",
     "qadc_dist_init_transport", "qadc_dist_init_loopback", "qadc_shm_transport_open", "qadc_shm_transport_allgather", "qadc_shm_transport_allgather_host",
-    "qadc_shm_transport_close", "qadc_shm_transport_error", "qadc_slot_assign", "qadc_place_partitions",
+    "qadc_shm_transport_close", "qadc_shm_transport_error", "qadc_slot_assign", "qadc_slot_qtables", "qadc_place_partitions",
 ]
 
 
@@ -130,6 +130,7 @@ def lib():
         L.qadc_shm_transport_close.argtypes = [C.c_void_p]
         L.qadc_shm_transport_error.restype = C.c_char_p
         L.qadc_slot_assign.argtypes = [C.c_void_p, C.c_int, i32p]
+        L.qadc_slot_qtables.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i8p]
         L.qadc_place_partitions.argtypes = [C.c_int, u32p, C.c_int, i32p]
         L.qadc_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.qadc_profile_reset.argtypes = [C.c_void_p]
@@ -474,6 +475,12 @@ class Index:
 
     def dist_shutdown(self):
         _check(lib().qadc_dist_shutdown(self._h))
+
+    def slot_qtables(self, slot, q_first, q_count, ma):
+        """int8 tables [q_count][ma][M][16] of the batch last collected from `slot` (qadc_slot_qtables)."""
+        out = np.zeros((q_count, ma, self.M, 16), np.int8)
+        _check(lib().qadc_slot_qtables(self._h, slot, q_first, q_count, _p(out, i8p)))
+        return out
 
     def slot_assign(self, slot, nq, ma):
         out = np.zeros((nq, ma), np.int32)

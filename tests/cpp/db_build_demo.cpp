@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 
 #include "../../quick-adc_amd/host/db_build.hpp"
 
@@ -57,6 +58,27 @@ int main(int argc, char** argv) {
         return 2;
     }
     const int km_bad = std::memcmp(c1.data(), c2.data(), sizeof(float) * c1.size()) != 0 || a1 != a2;
-    std::printf("ivf_partitions_differing %d flat_differs %d kmeans_differs %d\n", bad, flat_bad, km_bad);
-    return (bad || flat_bad || km_bad) ? 1 : 0;
+    // db_add's loop: the base vectors come from an .fvecs file through the reader thread + two-chunk queue, in chunks that
+    // do not divide n (db_add.cpp:52-82, vector_io.hpp:231-288); GPU build == host build == the in-memory build above
+    int stream_bad = 0;
+    if (argc > 6) {
+        const std::string file = std::string(argv[6]) + ".fvecs";
+        io::save_vectors(vecs.data(), dim, (long)n, file.c_str());
+        ivf_database sg(make_pq(), K, coarse), sc(make_pq(), K, coarse);
+        const unsigned chunk = n / 7 + 5;
+        const unsigned got_g = db_add_hip(sg, file.c_str(), chunk, 0, true), got_c = db_add_hip(sc, file.c_str(), chunk, 0, false);
+        stream_bad += got_g != n || got_c != n;
+        for (int p = 0; p < K; ++p)
+            stream_bad += sg.partitions[p] != cpu.partitions[p] || sg.labels[p] != cpu.labels[p] || sc.partitions[p] != cpu.partitions[p] ||
+                          sc.labels[p] != cpu.labels[p];
+        flat_database fs;
+        fs.pq = make_pq();
+        stream_bad += db_add_hip(fs, file.c_str(), chunk) != n || fs.codes != fc.codes;
+        bool threw = false;
+        try { db_add_hip(fs, (std::string(argv[6]) + ".nope").c_str()); } catch (const std::exception&) { threw = true; }
+        stream_bad += !threw;
+        std::remove(file.c_str());
+    }
+    std::printf("ivf_partitions_differing %d flat_differs %d kmeans_differs %d streamed_add_differs %d\n", bad, flat_bad, km_bad, stream_bad);
+    return (bad || flat_bad || km_bad || stream_bad) ? 1 : 0;
 }

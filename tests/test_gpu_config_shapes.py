@@ -133,6 +133,23 @@ def test_c3_full_size_the_bench_list_against_oracle(pyqadc, po):
         assert want["rc"] == 0
         sz = res["sizes"][q]
         assert heaps_equal((res["keys"][q, :sz], res["values"][q, :sz]), (want["keys"], want["values"])), q
+    # The integer half of ALL 1024 queries against the REFERENCE BUILD itself (oracle/_ref: the reference's scan_avx_4<16>,
+    # simd_scan.hpp:125-187, and interleave_partition_4, simd_layout.hpp:55-65): the device's own int8 tables, the probed
+    # partitions regenerated on the CPU and laid out by the reference, one shared heap per query in assign[] order.
+    # Budget: ~4 s to generate + interleave the 4096 partitions, ~1 s for 1024 x 0.78 M codes through the AVX2 kernel.
+    if po.have_ref():
+        inter = {}
+        qt_all = idx.slot_qtables(0, 0, nq, MA)
+        for q in range(nq):
+            assign = res["assign"][q]
+            for p in assign:
+                if int(p) not in inter:
+                    inter[int(p)] = po.ref_interleave(po.fill_codes(0, int(sizes[p]), 1000 + int(p)).reshape(-1, M // 2))
+            live = [a for a in range(MA) if sizes[assign[a]] > 0]
+            want = po.ref_scan_interleaved(M, [inter[int(assign[a])] for a in live], [int(sizes[assign[a]]) for a in live], None,
+                                           qt_all[q][live], R)
+            sz = res["sizes"][q]
+            assert heaps_equal((res["keys"][q, :sz], res["values"][q, :sz]), want), q
     idx.close()
 
 
@@ -169,4 +186,15 @@ def test_c5_full_size_1e9_codes_32x4_nprobe64_on_one_gpu(pyqadc, po):
         assert want["rc"] == 0
         sz = res["sizes"][q]
         assert heaps_equal((res["keys"][q, :sz], res["values"][q, :sz]), (want["keys"], want["values"])), q
+    # integer half against the reference build (scan_avx_4<32> on the device's int8 tables), 48 sampled queries of
+    # 3.9 M probed codes each; budget ~25 s (the probed partitions are regenerated per query: 64 x 1 MB)
+    if po.have_ref():
+        for q in rng.choice(nq, 48, replace=False):
+            assign = res["assign"][q]
+            qt = idx.slot_qtables(0, int(q), 1, MA)[0]
+            live = [a for a in range(MA) if sizes[assign[a]] > 0]
+            inter = [po.ref_interleave(po.fill_codes(0, 2 * int(sizes[assign[a]]), 7000 + int(assign[a])).reshape(-1, M // 2)) for a in live]
+            want = po.ref_scan_interleaved(M, inter, [int(sizes[assign[a]]) for a in live], None, qt[live], R)
+            sz = res["sizes"][q]
+            assert heaps_equal((res["keys"][q, :sz], res["values"][q, :sz]), want), q
     idx.close()

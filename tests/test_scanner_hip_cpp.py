@@ -21,7 +21,7 @@ def _compile(src, exe):
         import __graft_entry__
         __graft_entry__.build()
     tmp = "%s.%d.tmp" % (exe, os.getpid())
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror", src, "-o", tmp,
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-pthread", src, "-o", tmp,
                            "-L" + libdir, "-lqadc_hip", "-Wl,-rpath," + libdir])
     os.replace(tmp, exe)
 
@@ -273,11 +273,56 @@ def test_db_build_demo_builds_as_cxx14():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,dim,K,n,opq", [(16, 32, 37, 5000, 0), (32, 64, 300, 40000, 1), (16, 128, 1000, 70000, 0)])
-def test_gpu_database_build_equals_the_host_build(M, dim, K, n, opq):
+def test_gpu_database_build_equals_the_host_build(M, dim, K, n, opq, tmp_path):
     """N4: host/db_build.hpp (index_db::add_vectors / flat_db::add_vectors compute and the k-means fast iterations on
     the GPU, from C++14) against the sequential host loops: same partitions, codes, labels, centroids, bit for bit
     (chunked adds with offsets, an exact centroid tie, OPQ rotation, batches on both sides of the 256-vector switch of
     the coarse kernels)."""
     _compile(os.path.join(ROOT, "tests", "cpp", "db_build_demo.cpp"), DB_BUILD)
-    out = subprocess.check_output([DB_BUILD, str(M), str(dim), str(K), str(n), str(opq)]).decode()
-    assert "ivf_partitions_differing 0 flat_differs 0 kmeans_differs 0" in out, out
+    out = subprocess.check_output([DB_BUILD, str(M), str(dim), str(K), str(n), str(opq), str(tmp_path / "base")]).decode()
+    # (the last figure: db_add's streamed form — reader thread + two-chunk queue from an .fvecs file, db_add.cpp:52-82)
+    assert "ivf_partitions_differing 0 flat_differs 0 kmeans_differs 0 streamed_add_differs 0" in out, out
+
+
+DBQ_SIMPLE = os.path.join(ROOT, "tests", "cpp", "db_query_simple")
+
+
+@pytest.mark.parametrize("M,bits,batch", [(8, 8, 1), (16, 8, 1), (4, 8, 4), (16, 4, 1), (32, 4, 3)])
+def test_db_query_cpu_front_end_matches_the_oracle(po, tmp_path, M, bits, batch):
+    """BASELINE configs[0]: the reference's plain `db_query` path (scanner_simple, db_query.cpp:17-46; scan_standard /
+    scan_4, query_common.hpp:59-118) restated in host/scanner_simple.hpp and driven by the engines of
+    host/query_driver.hpp — CPU only.  The driver dumps its codes, the float tables each query was scanned with and
+    the resulting float heaps; the oracle's orc_scan_standard_u8 (whole-byte codes) or its float ADC values replayed
+    through the float heap (4-bit codes) must give the same arrays."""
+    _compile(os.path.join(ROOT, "tests", "cpp", "db_query_simple.cpp"), DBQ_SIMPLE)
+    dim, n, nq, R = 64, 6001, 7, 40
+    dump = str(tmp_path / "dump.bin")
+    out = subprocess.check_output([DBQ_SIMPLE, "-r", str(R), "-b", str(batch), str(M), str(bits), str(dim), str(n), str(nq), "11", dump]).decode()
+    lines = out.strip().split("\n")
+    assert lines[0] == "r,recall,ma,adc_type,index_us,rotate_us,table_us,scan_us"      # db_query.cpp:112-115
+    assert lines[1].split(",")[0] == str(R) and lines[1].split(",")[3] == "adc" and 0.0 <= float(lines[1].split(",")[1]) <= 1.0
+    raw = np.fromfile(dump, np.uint8)
+    hdr = raw[:24].view(np.int32)
+    assert list(hdr) == [M, bits, dim, n, nq, R]
+    cs = M * bits // 8
+    o = 24
+    codes = raw[o:o + n * cs].reshape(n, cs).copy()
+    o += n * cs
+    td = M * (1 << bits)
+    tables = raw[o:o + nq * td * 4].view(np.float32).reshape(nq, td).copy()
+    o += nq * td * 4
+    for q in range(nq):
+        size = int(raw[o:o + 4].view(np.int32)[0])
+        keys = raw[o + 4:o + 4 + 4 * size].view(np.uint32)
+        vals = raw[o + 4 + 4 * size:o + 4 + 8 * size].view(np.float32)
+        o += 4 + 8 * size
+        assert size == R
+        if bits == 8:
+            wk, wv = po.scan_standard_u8(M, [codes], None, tables[q].reshape(1, M, 256), R)
+        else:
+            cand = po.candidates_f32(M, codes, tables[q])          # scan_4's sums (query_common.hpp:72-80)
+            fmax = np.float32(np.finfo(np.float32).max)
+            sent = np.array([fmax - np.float32(t) for t in range(R)], np.float32)
+            wk, wv = po.heap_replay_f32(np.concatenate([np.zeros(R, np.uint32), np.arange(n, dtype=np.uint32)]),
+                                        np.concatenate([sent, cand]), R)
+        assert np.array_equal(keys, wk) and np.array_equal(vals, wv), q
