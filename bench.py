@@ -19,7 +19,9 @@ ONE JSON line, several legs (SURVEY.md §8d keeps the two scan modes apart):
   WRITE_SIZE; separate passes) collected IN THIS RUN by child processes that run the same
   one-query-per-pass leg (--pmc-leg); when rocprofv3 is not available the committed per-mode
   profile (profiles/r02_single_hbm_traffic.json) is used if its keys match, else null.
-* `roofline_32x4`: the same one-query-per-pass leg on 1B x 32x4 codes (16 B/code).
+* `roofline_32x4`: the same one-query-per-pass leg on 1B x 32x4 codes (16 B/code), with its own in-run PMC traffic.
+* `roofline_ivf` / `roofline_ivf_c5`: the launches of the IVF legs' partition-major second phase against their roofs
+  (grouped scan: LDS lookup rate; head: HBM), from a short profiled pass after the timed loops.
 * `ivf`: BASELINE configs[2] shape (100M codes in K=4096 labelled-free synthetic partitions, nprobe 32,
   1024-query pipelined batches through the device-side feeders).
 * `ivf_c5_one_gpu`: the same leg at BASELINE configs[4]'s shape on one GPU (1B x 32x4 codes, K=16384, 96-d, nprobe 64).
@@ -340,6 +342,7 @@ def roofline_single(M, N, prof, dt, nqueries, traffic, traffic_src):
             "algorithmic_bytes_per_launch": alg,
             "algorithmic_bytes_rule": "%d B per (code, query) (SURVEY.md 8d) x codes of the launch's bound level" % cs,
             "codes_per_sec_wall": float(N) * nqueries / dt, "ms_per_query_wall": dt * 1e3 / nqueries,
+            "region_wall_s": dt, "region_queries": nqueries,
             "small_run_codes_not_event_timed": prof["small_codes"]}
 
 
@@ -430,7 +433,36 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
     p = idx.profile()
     qs2 = [rng.normal(size=(2 * NQB, dim)).astype(np.float32) for _ in range(4)]       # and at twice the batch size
     dt2, _ = pipelined(qs2, 24, depth)
+    # a short pass with the library's HIP events on (they cost ~10 us of stream time each: not in the timed loops above):
+    # the launches of the partition-major second phase against THEIR roofs
+    idx.set_option("profile", 1)
+    dtp, _ = pipelined(qs, 16, depth, warm=False)
+    pp = idx.profile()
+    idx.set_option("profile", 0)
     idx.close()
+    roof = None
+    if pp["group_batches"]:
+        nb = pp["group_batches"]
+        lds_cycles = (pp["group_pass_codes8"] * M * 4 + pp["group_pass_codes4"] * M * 2) / 64.0
+        lds_rate = lds_cycles / (pp["group_scan_ms"] * 1e-3) / 1e9
+        head_gbs = pp["group_head_codes"] * (M // 2) / (pp["group_head_ms"] * 1e-3) / 1e9
+        roof = {"bound": "lds", "kernel": "scan_i8_mq_kernel<%d,2> over the (query, probe) pairs regrouped by partition" % M,
+                "achieved": lds_rate, "peak": LDS_PEAK_GCYC, "unit": "G LDS-array cycles/s", "frac": lds_rate / LDS_PEAK_GCYC,
+                "avg_launch_ms": pp["group_scan_ms"] / nb, "launches": nb,
+                "lds_cycles_rule": "codes read by 8-seat passes x %d lookups x 4 cycles / 64 lanes + codes read by 4-seat passes x %d x 2 / 64 "
+                                   "(a group of <= 4 pairs takes 8-byte rows); recounted from assign[] on the host" % (M, M),
+                "seat_fill": pp["group_pairs"] / max(pp["group_seats"], 1), "pairs_per_batch": pp["group_pairs"] / nb,
+                "codes_read_per_batch": (pp["group_pass_codes8"] + pp["group_pass_codes4"]) / nb,
+                "head": {"bound": "hbm", "kernel": "scan_query_kernel<%d, HEAD> (front: pre-scan, select, quantizer of all %d tables; then the "
+                                                   "first probes of every query, one workgroup per query)" % (M, MA),
+                         "achieved": head_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head_gbs / HBM_PEAK_GBS,
+                         "avg_launch_ms": pp["group_head_ms"] / nb,
+                         "algorithmic_bytes_per_launch": pp["group_head_codes"] * (M // 2) / nb,
+                         "note": "bytes = M/2 x codes of the head probes only; the launch also pre-scans the starts of all probes and "
+                                 "quantizes their tables, so frac understates the walk"},
+                "order_cands_avg_launch_ms": pp["group_order_ms"] / nb,
+                "timed_region": "%d profiled batches after the timed loops (HIP events on the library's stream around each launch); "
+                                "wall %.3f ms per batch in that pass" % (nb, dtp * 1e3 / 16)}
     gbs = ncodes * (M // 2) / dt / 1e9
     out = {"workload": "IVF, %d x %dx4 codes (%d-d vectors) in K=%d partitions (multinomial sizes), nprobe=%d, R=%d, keep=%.0f%%, "
                        "%d-query batches, %d in flight, queries in -> heaps out (qadc_search)" % (N, M, dim, K, MA, R, KEEP * 100, NQB, depth),
@@ -444,6 +476,8 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
            "batches_through_partition_major_second_phase": int(p["group_launches"]), "of_them_redone_on_the_level_path": int(p["group_fallbacks"]),
            "host_ms_per_batch": {"plan": p["host_plan_ms"] / steps, "stream_assembly": p["host_replay_ms"] / steps,
                                  "heap": p["host_heap_ms"] / steps}}
+    if roof is not None:
+        out["roofline"] = roof
     if shard is not None:
         out.update({"rccl_ranks": shard["world"], "placement": shard["placement"], "codes_on_this_rank": local_codes,
                     "merge": shard.get("merge", "native: qadc_dist_collect"), "candidates_per_query_this_rank": p["candidates"] / (steps * NQB)})
@@ -558,8 +592,11 @@ def main():
     # ---- in-run HBM traffic of the one-query-per-pass mode: child processes under rocprofv3, BEFORE this process
     # touches the GPU (single rank only) ----
     pmc, pmc_src = None, "skipped"
+    pmc32, pmc32_src = None, "skipped"
     if world == 1 and os.environ.get("QADC_BENCH_PMC", "1") != "0" and not os.environ.get("QADC_BENCH_FORCE_DIST"):
         pmc, pmc_src = pmc_traffic_in_run(M, N)
+        if os.environ.get("QADC_BENCH_32X4", "1") != "0" and M == 16:
+            pmc32, pmc32_src = pmc_traffic_in_run(32, N)
 
     import torch
     import torch.distributed as dist
@@ -889,13 +926,21 @@ def main():
             cb32 = rng.normal(size=(32, 16, 4)).astype(np.float32)
             pool32 = [make_tables(rng, cb32, 8)]
             p32, dt32 = single_query_leg(i32, 32, N, pool32, 24)
-            out["roofline_32x4"] = roofline_single(32, N, p32, dt32, 24, None, "not collected for this leg")
+            alg32 = p32["scan_codes"] * 16 / max(p32["scan_launches"], 1)
+            out["roofline_32x4"] = roofline_single(32, N, p32, dt32, 24, None if pmc32 is None else pmc32["traffic_over_algorithmic"] * alg32,
+                                                   pmc32_src + ("" if pmc32 is None else " (ratio of the same launches x this region's bytes per launch)"))
+            if pmc32 is not None:
+                out["roofline_32x4"]["pmc"] = pmc32
             i32.close()
         if int(float(os.environ.get("QADC_BENCH_IVF_CODES", 1e8))) > 0:
             out["ivf"] = ivf_leg(local_rank)
+            if "roofline" in out["ivf"]:
+                out["roofline_ivf"] = out["ivf"].pop("roofline")
             if os.environ.get("QADC_BENCH_IVF_C5", "1") != "0" and N >= 1e9:
                 # BASELINE configs[4] on ONE GPU: 1B x 32x4 codes (16 GB), 96-d vectors, nprobe 64
                 out["ivf_c5_one_gpu"] = ivf_leg(local_rank, M=32, K=16384, MA=64, dim=96, N=int(1e9), seed0=7000)
+                if "roofline" in out["ivf_c5_one_gpu"]:
+                    out["roofline_ivf_c5"] = out["ivf_c5_one_gpu"].pop("roofline")
         if os.environ.get("QADC_BENCH_LATENCY", "1") != "0":
             out["latency_us_single_query"] = latency_leg(local_rank)
         n_real = int(float(os.environ.get("QADC_BENCH_REAL_CODES", 1e7)))

@@ -91,11 +91,11 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * "cand_capacity" (candidate region entries per query), "level_base", "level_growth" (bound levels),
  * "prescan_sample", "small_run", "small_vec_per_wg", "wgs_per_item", "variant", "share_variant" (0 = never
  * launch the queries of a batch as L2-sharing siblings), "share_codes_per_wg", "mq" (8 queries per pass),
- * "mq_codes_per_wg", "mq_min_wgs", "mq_min_tiles", "prescan_mq", "overlap_front", "head_early", "front_run_max",
+ * "mq_codes_per_wg", "mq_min_wgs", "mq_min_tiles", "mq_narrow" (groups of at most 4 queries take the 4-seat form of that kernel), "prescan_mq", "overlap_front", "head_early", "front_run_max",
  * "front_min_batch", "front_dist" (kernel and launch tuning), "device_replay_nq" (batches of at least this many
  * queries replay their candidate streams through the heap on the device; 0 = always on the host),
  * "device_replay_alone_nq" (... from this many when nothing else is in flight: a synchronous call), "replay_threads",
- * "replay_wave" (device replay of the query kernel's streams: 1 one wave per query with the heap in registers, 0 one lane per query);
+ * "replay_wave" (device replay of the query kernel's streams: 0 one lane per query — default — 1 one wave per query with the heap in registers);
  * the one-workgroup-per-query path: "wgq" (0 never, 1 auto, 2 always), "wgq_min_nq", "wgq_max_codes",
  * "wgq_small_codes", "wgq_capacity", "wgq_cand_cap", "wgq_variant", "wgq_split" / "wgq_split_codes" (workgroups a
  * small batch spreads one query over / codes each keeps at least), "wgq_inline" (a lone small query's input rides
@@ -371,6 +371,16 @@ typedef struct qadc_profile {
     uint64_t head_launches;    /* level path: batches whose first bound levels were scanned by one head launch */
     uint64_t group_launches;   /* large IVF batches that took the partition-major second phase ... */
     uint64_t group_fallbacks;  /* ... and those of them whose candidate regions overflowed (redone on the level path) */
+    /* the partition-major second phase in detail (profile on): HIP-event times of its three launches and the work in them */
+    double group_head_ms;      /* scan_query_kernel in HEAD mode: front (pre-scan, select, quantizer) + the head probes */
+    double group_scan_ms;      /* scan_i8_mq_kernel over the regrouped (query, probe) pairs */
+    double group_order_ms;     /* order_cands_kernel */
+    uint64_t group_head_codes; /* codes the heads walked (algorithmic HBM bytes = codes * M/2) */
+    uint64_t group_pairs;      /* (query, probe) pairs of the second phase */
+    uint64_t group_seats;      /* seats of their groups (8 per group, 4 for a narrow remainder group): fill = pairs / seats */
+    uint64_t group_pass_codes8; /* codes read by 8-seat passes (LDS cycles = codes * M * 4 / 64) */
+    uint64_t group_pass_codes4; /* ... by 4-seat passes (LDS cycles = codes * M * 2 / 64) */
+    uint64_t group_batches;    /* batches the above figures cover */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

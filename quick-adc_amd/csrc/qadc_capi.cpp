@@ -167,6 +167,7 @@ struct Slot {
     DevBuf<uint32_t> d_gplan;           // grouped second phase: [cnt K][fill K][goff K+1]
     DevBuf<ScanItem> d_gitems;          // ... its device-planned ScanItem groups
     bool wgq_grouped = false;           // the batch took the partition-major second phase
+    int group_head_slots = 0;           // ... after a head of this many local probes per query
     DevBuf<float> d_fc;
 
     // one-workgroup-per-query path (qadc_query_kernel.hip): no planner, no levels, no sort
@@ -348,7 +349,10 @@ struct qadc_index {
     int wgq_group_head = 4;   // ... after a head of this many probes per query (one workgroup per query)
     int wgq_group_head_dist = 2;   // ... under the multi-GPU merge (probes with codes on this rank)
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
-    int replay_wave = 1;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
+    int mq_narrow = 1;     // multi-query groups whose upper four seats are empty run the 4-seat form of the kernel
+    int replay_wave = 0;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
+                           // (C3 shape, 1024-query batches: lanes 0.80-0.84 us per query, waves 0.93 — a thousand waves hold
+                           // slots the scan workgroups want; C5 shape: 5.18 vs 5.01.  The multi-GPU merge replays by waves.)
     int head_early = 1;    // the head launch joins the front stream (under the previous batch's long levels)
     int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
@@ -826,7 +830,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                                  s.cap_q, (uint32_t)s.R, str);
         else if (ll.mq)
             launch_scan_i8_mq(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q,
-                              (uint32_t)s.R, str);
+                              (uint32_t)s.R, str, idx->mq_narrow);
         else
             launch_scan_i8(M, ll.shared ? idx->share_variant : (variant & ~64), s.d_items + ll.first, ll.nitems, ll.wgs,
                            s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q, (uint32_t)s.R, str);
@@ -1127,10 +1131,17 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         H.cand_cap = ccap;
         H.hdr = s.d_hdr;
         H.G = 1;
+        // (profile: one event before and after each of the three launches — prof_ev[1..4]; ~10 us of stream time each)
+        if (idx->profile) HIPCHECK(prof_event(s, st));
         HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));
+        if (idx->profile) HIPCHECK(prof_event(s, st));
         const int wgs = (int)std::max<uint64_t>(1, ((uint64_t)idx->max_part_n + idx->mq_codes_per_wg - 1) / idx->mq_codes_per_wg);
-        launch_scan_i8_mq(M, s.d_gitems.p, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, ccap, (uint32_t)s.R, st);
+        launch_scan_i8_mq(M, s.d_gitems.p, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, ccap, (uint32_t)s.R, st,
+                          idx->mq_narrow);
+        if (idx->profile) HIPCHECK(prof_event(s, st));
         HIPCHECK(launch_order_cands(s.d_qs, s.d_cands.p, ccap, ccap, nq, s.d_stream.p, cap, s.d_qout, s.d_qflags.p, st));
+        if (idx->profile) HIPCHECK(prof_event(s, st));
+        s.group_head_slots = head_slots;
         idx->prof.group_launches++;
     } else {
         HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st, inl_bytes ? inl : nullptr, inl_bytes));
@@ -1447,8 +1458,43 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool fr
     s.busy = false;
     if (idx->profile && s.wgq) {
         float ms = 0;
-        if (s.prof_used >= 2) HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[0], s.prof_ev[1]));
+        if (s.prof_used >= 2) HIPCHECK(hipEventElapsedTime(&ms, s.prof_ev[0], s.prof_ev[s.prof_used - 1]));
         idx->prof.wgq_ms += ms;
+        if (s.wgq_grouped && s.prof_used >= 6) {                 // [0] start, [1..4] around head / grouped scan / ordering, [5] end
+            float a = 0, b = 0, c = 0;
+            HIPCHECK(hipEventElapsedTime(&a, s.prof_ev[1], s.prof_ev[2]));
+            HIPCHECK(hipEventElapsedTime(&b, s.prof_ev[2], s.prof_ev[3]));
+            HIPCHECK(hipEventElapsedTime(&c, s.prof_ev[3], s.prof_ev[4]));
+            idx->prof.group_head_ms += a;
+            idx->prof.group_scan_ms += b;
+            idx->prof.group_order_ms += c;
+            idx->prof.group_batches++;
+            // the work in those launches, recounted from assign[] the way the device draws the line (ivf_for_grouped_pairs)
+            std::vector<uint32_t> cnt(idx->parts.size(), 0);
+            for (int q = 0; q < s.nq; ++q) {
+                int seen = 0;
+                for (int a_ = 0; a_ < s.ma; ++a_) {
+                    const int p = s.assign[(size_t)q * s.ma + a_];
+                    const uint32_t n = idx->parts[p].n;
+                    if (!n) continue;
+                    if (seen < s.group_head_slots) idx->prof.group_head_codes += n;
+                    else cnt[p]++;
+                    ++seen;
+                }
+            }
+            for (size_t p = 0; p < cnt.size(); ++p) {
+                if (!cnt[p]) continue;
+                const uint64_t n = idx->parts[p].n, full = cnt[p] / 8, rem = cnt[p] % 8;
+                idx->prof.group_pairs += cnt[p];
+                idx->prof.group_pass_codes8 += full * n;
+                idx->prof.group_seats += full * 8;
+                if (rem) {
+                    const bool narrow = idx->mq_narrow && rem <= 4;
+                    (narrow ? idx->prof.group_pass_codes4 : idx->prof.group_pass_codes8) += n;
+                    idx->prof.group_seats += narrow ? 4 : 8;
+                }
+            }
+        }
         idx->prof.wgq_launches++;
         for (int q = 0; q < s.nq * s.wgq_G; ++q) {
             idx->prof.wgq_front_cycles += (uint64_t)(s.h_qout[q].pad[0] & 0xffffu) << 6;
@@ -1990,6 +2036,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "head_early") idx->head_early = value != 0;
     else if (n == "wgq_inline") idx->wgq_inline = value != 0;
     else if (n == "replay_wave") idx->replay_wave = value != 0;
+    else if (n == "mq_narrow") idx->mq_narrow = value != 0;
     else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);
     else if (n == "wgq_group") { idx->wgq_group = (int)std::max(0.0, std::min(value, 2.0)); idx->group_strikes = 0; }
     else if (n == "wgq_group_head") idx->wgq_group_head = idx->wgq_group_head_dist = (int)std::max(1.0, std::min(value, 4096.0));

@@ -374,55 +374,53 @@ __device__ __forceinline__ uint32_t byte_and(uint32_t d, uint32_t mask) {
     return r;
 }
 
-template <int M, int U>
-__global__ __launch_bounds__(kMQWG, 4) void scan_i8_mq_kernel(
-    const ScanItem* __restrict__ items, int nitems, const int8_t* __restrict__ qtables,
-    QueryState* __restrict__ qstates, CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap,
-    uint32_t R, uint32_t ngroups) {
-    constexpr int CS = M / 2, DW = M / 8, CPL = 16 / CS;
-    constexpr int TAB = M * 256;                 // bytes of the u16 row image; then u32 bound[8]
-    uint32_t* lbound = reinterpret_cast<uint32_t*>(smem + TAB);
-    // sibling-major decode over the query GROUPS (see scan_i8_kernel): groups that read the same tiles share an XCD
-    const uint32_t G = gridDim.x / ngroups;
-    uint32_t bx, grp;
-    if ((G & 7u) == 0) {
-        const uint32_t r = blockIdx.x >> 3;
-        grp = r % ngroups;
-        bx = (r / ngroups) * 8u + (blockIdx.x & 7u);
-    } else {
-        grp = blockIdx.x % ngroups;
-        bx = blockIdx.x / ngroups;
-    }
-    const int first_item = (int)grp * kMQ;
-    const int nq = min(kMQ, nitems - first_item);            // queries of this group (>= 1)
-    const ScanItem* __restrict__ its = items + first_item;
-    const ScanItem it = its[0];                              // codes / n / pos0 / labels / key_base / dup_*: shared
-    if (it.n == 0) return;                                   // (device-planned launches are sized for the worst case: no such group)
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    lds_base_is_zero();
+typedef uint64_t u64x1 __attribute__((ext_vector_type(1)));
+template <int NQ> struct MqRow;
+template <> struct MqRow<8> { typedef u64x2 type; };          // 8 queries: 16-byte rows, ds_read_b128
+template <> struct MqRow<4> { typedef u64x1 type; };          // 4 queries:  8-byte rows, ds_read_b64 (half the LDS cycles)
 
-    // ---- row image: thread -> (t, x); the 8 queries' entries widened to u16; absent queries read as 0 ----
+// One group's pass with NQ = 8 or 4 query seats.  A group whose live seats fit 4 (the remainder groups of the IVF second
+// phase: seats are filled from 0 upward) takes the 4-seat form: the same lookups return 8 bytes instead of 16, i.e. 4 LDS
+// cycles per (64 codes, nibble pair) instead of 8, and half the adds.
+template <int M, int U, int NQ>
+__device__ __forceinline__ void scan_mq_body(const ScanItem* __restrict__ its, const ScanItem& it, int nq, uint32_t bx, uint32_t G,
+                                             const int8_t* __restrict__ qtables, QueryState* __restrict__ qstates,
+                                             CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap, uint32_t R) {
+    constexpr int CS = M / 2, DW = M / 8, CPL = 16 / CS;
+    constexpr int ROWB = 2 * NQ, NW = NQ / 4;                    // bytes per row, u64 words per row
+    typedef typename MqRow<NQ>::type row_t;
+    typedef const __attribute__((address_space(3))) row_t* lds_rowq_t;
+    constexpr int TAB = M * 256;                                 // bytes reserved for the row image; then u32 bound[8]
+    uint32_t* lbound = reinterpret_cast<uint32_t*>(smem + TAB);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+
+    // ---- row image: thread -> (t, x); the queries' entries widened to u16; absent queries read as 0 ----
     for (int e = tid; e < M * 16; e += kMQWG) {
-        u16x8 row;
+        uint16_t row[NQ];
 #pragma unroll
-        for (int j = 0; j < kMQ; ++j) {
+        for (int j = 0; j < NQ; ++j) {
             uint16_t v = 0;
             if (j < nq && its[j].n != 0) v = (uint16_t)(uint8_t)qtables[(uint64_t)its[j].table * (M * 16) + e];   // (n == 0: empty seat)
             row[j] = v;
         }
-        *reinterpret_cast<u16x8*>(smem + e * 16) = row;     // little-endian: query j = field j&3 of u64 j>>2
+        uint64_t* dst = reinterpret_cast<uint64_t*>(smem + e * ROWB);   // little-endian: query j = field j&3 of u64 j>>2
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            dst[w] = (uint64_t)row[4 * w] | ((uint64_t)row[4 * w + 1] << 16) | ((uint64_t)row[4 * w + 2] << 32) | ((uint64_t)row[4 * w + 3] << 48);
     }
     // ---- bounds: wave w computes queries w, w+4 (absent queries: 0 = nothing qualifies) ----
-    for (int j = (int)wave; j < kMQ; j += kMQWG / 64) {
+    for (int j = (int)wave; j < NQ; j += kMQWG / 64) {
         uint32_t b = 0;
         if (j < nq && its[j].n != 0) b = prefix_bound_wave(qstates + its[j].query, its[j].order >> 16, R, lane);
         if (lane == 0) lbound[j] = b;
     }
     __syncthreads();
-    uint32_t bq[kMQ];
-    uint64_t bias[2] = {0, 0};                               // (0x8000 - bound) in every 16-bit field
+    uint32_t bq[NQ];
+    uint64_t bias[NW];                                           // (0x8000 - bound) in every 16-bit field
 #pragma unroll
-    for (int j = 0; j < kMQ; ++j) {
+    for (int w = 0; w < NW; ++w) bias[w] = 0;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
         bq[j] = __builtin_amdgcn_readfirstlane(lbound[j]);
         bias[j >> 2] |= (uint64_t)(0x8000u - bq[j]) << (16 * (j & 3));
     }
@@ -434,21 +432,23 @@ __global__ __launch_bounds__(kMQWG, 4) void scan_i8_mq_kernel(
     const uint32_t nvec = (n + CPL - 1) / CPL;
     const uint32_t ntiles = (nvec + kMQWG - 1) / kMQWG;
 
-    const uint32_t nib_mask = 0xf0u;
-    // sums of the 8 queries for one code (DW dwords at d)
-    auto code_sums = [&](const uint32_t* d) -> u64x2 {
-        u64x2 a = {0, 0};
+    // row offset = x * ROWB.  16-byte rows: the high nibble of byte k is (byte k) & 0xf0, the low one the same of d << 4;
+    // 8-byte rows: (d >> 1) & 0x78 and (d << 3) & 0x78 (the bits that cross a byte boundary fall outside the mask)
+    constexpr uint32_t nib_mask = NQ == 8 ? 0xf0u : 0x78u;
+    // sums of the NQ queries for one code (DW dwords at d)
+    auto code_sums = [&](const uint32_t* d) -> row_t {
+        row_t a = {};
 #pragma unroll
         for (int w = 0; w < DW; ++w) {
-            // row offset = x*16: the high nibble of byte k is (byte k) & 0xf0, the low one the same of d << 4
-            const uint32_t dl = d[w] << 4;
+            const uint32_t dl = NQ == 8 ? d[w] << 4 : d[w] << 3;
+            const uint32_t dh = NQ == 8 ? d[w] : d[w] >> 1;
 #define QADC_MQ_BYTE(k)                                                                                        \
             {                                                                                                  \
                 /* code byte b = 4w + k: sub-quantizer 2b takes the low nibble, 2b+1 the high one */           \
                 const int t0 = 2 * (4 * w + (k));                                                              \
-                const uint32_t xl = byte_and<(k)>(dl, nib_mask), xh = byte_and<(k)>(d[w], nib_mask);           \
-                a += *reinterpret_cast<lds_row_t>(static_cast<uintptr_t>(xl + t0 * 256));                      \
-                a += *reinterpret_cast<lds_row_t>(static_cast<uintptr_t>(xh + (t0 + 1) * 256));                \
+                const uint32_t xl = byte_and<(k)>(dl, nib_mask), xh = byte_and<(k)>(dh, nib_mask);             \
+                a += *reinterpret_cast<lds_rowq_t>(static_cast<uintptr_t>(xl + t0 * (16 * ROWB)));             \
+                a += *reinterpret_cast<lds_rowq_t>(static_cast<uintptr_t>(xh + (t0 + 1) * (16 * ROWB)));       \
             }
             QADC_MQ_BYTE(0) QADC_MQ_BYTE(1) QADC_MQ_BYTE(2) QADC_MQ_BYTE(3)
 #undef QADC_MQ_BYTE
@@ -471,32 +471,36 @@ __global__ __launch_bounds__(kMQWG, 4) void scan_i8_mq_kernel(
                 else e[u] = 0xffffffffu;
             }
         }
-        u64x2 sums[U * CPL];
-        uint64_t all0 = kTop, all1 = kTop;                       // stays kTop while no field is below its bound
+        row_t sums[U * CPL];
+        uint64_t all[NW];                                        // stays kTop while no field is below its bound
+#pragma unroll
+        for (int w = 0; w < NW; ++w) all[w] = kTop;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
-                const u64x2 a = code_sums(d + c * DW);
+                const row_t a = code_sums(d + c * DW);
                 sums[u * CPL + c] = a;
-                uint64_t t0 = a.x + bias[0], t1 = a.y + bias[1];     // field top bit: sum >= bound
-                if (!decltype(full)::value) {
-                    const bool live = e[u] != 0xffffffffu && e[u] * CPL + c < n;
-                    if (!live) { t0 = kTop; t1 = kTop; }
+                const bool live = decltype(full)::value || (e[u] != 0xffffffffu && e[u] * CPL + c < n);
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const uint64_t t = a[w] + bias[w];           // field top bit: sum >= bound
+                    all[w] &= live ? t : kTop;
                 }
-                all0 &= t0;
-                all1 &= t1;
             }
         }
-        if (__builtin_expect(((all0 & all1) & kTop) != kTop, 0)) {   // rare
+        uint64_t allw = all[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) allw &= all[w];
+        if (__builtin_expect((allw & kTop) != kTop, 0)) {        // rare
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     if (!decltype(full)::value && !(e[u] != 0xffffffffu && e[u] * CPL + c < n)) continue;
 #pragma unroll
-                    for (int j = 0; j < kMQ; ++j) {
+                    for (int j = 0; j < NQ; ++j) {
                         const uint32_t sj = (uint32_t)(sums[u * CPL + c][j >> 2] >> (16 * (j & 3))) & 0xffffu;
                         if (sj < bq[j]) {
                             const ScanItem* ij = its + j;
@@ -516,22 +520,53 @@ __global__ __launch_bounds__(kMQWG, 4) void scan_i8_mq_kernel(
     for (; t0 < ntiles; t0 += G * U) run(t0, part_t());
 }
 
+// (7 waves per SIMD asked for: each of the two bodies fits 68 VGPRs by itself; with less the allocator lets the pair grow to 104
+// and the occupancy the kernel's latency hiding was tuned for — 7 waves per SIMD — drops to 4)
+template <int M, int U>
+__global__ __launch_bounds__(kMQWG, 7) void scan_i8_mq_kernel(
+    const ScanItem* __restrict__ items, int nitems, const int8_t* __restrict__ qtables,
+    QueryState* __restrict__ qstates, CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap,
+    uint32_t R, uint32_t ngroups, int narrow) {
+    // sibling-major decode over the query GROUPS (see scan_i8_kernel): groups that read the same tiles share an XCD
+    const uint32_t G = gridDim.x / ngroups;
+    uint32_t bx, grp;
+    if ((G & 7u) == 0) {
+        const uint32_t r = blockIdx.x >> 3;
+        grp = r % ngroups;
+        bx = (r / ngroups) * 8u + (blockIdx.x & 7u);
+    } else {
+        grp = blockIdx.x % ngroups;
+        bx = blockIdx.x / ngroups;
+    }
+    const int first_item = (int)grp * kMQ;
+    const int nq = min(kMQ, nitems - first_item);            // queries of this group (>= 1)
+    const ScanItem* __restrict__ its = items + first_item;
+    const ScanItem it = its[0];                              // codes / n / pos0 / labels / key_base / dup_*: shared
+    if (it.n == 0) return;                                   // (device-planned launches are sized for the worst case: no such group)
+    lds_base_is_zero();
+    // seats 4..7 all empty (a remainder group of the IVF second phase; the last group of a flat batch): 4-seat form
+    bool upper = false;
+    for (int j = 4; j < nq; ++j) upper = upper || its[j].n != 0;
+    if (narrow && !upper) scan_mq_body<M, U, 4>(its, it, min(nq, 4), bx, G, qtables, qstates, hdr, out, cand_cap, R);
+    else scan_mq_body<M, U, 8>(its, it, nq, bx, G, qtables, qstates, hdr, out, cand_cap, R);
+}
+
 template <int M>
 static void launch_scan_mq_m(const ScanItem* d_items, int nitems, int wgs_per_group, const int8_t* d_qtables,
                              QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R,
-                             hipStream_t stream) {
+                             hipStream_t stream, int narrow) {
     const uint32_t ngroups = (uint32_t)(nitems + kMQ - 1) / kMQ;
     hipLaunchKernelGGL((scan_i8_mq_kernel<M, 2>), dim3(ngroups * (uint32_t)wgs_per_group), dim3(kMQWG), M * 256 + 64,
-                       stream, d_items, nitems, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, ngroups);
+                       stream, d_items, nitems, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, ngroups, narrow);
 }
 
 // Runs of the launch must all cover the same codes (same codes / n / pos0 / labels / key_base / dup_*): the
 // planner guarantees it.  Groups of up to 8 consecutive runs share one pass.
 void launch_scan_i8_mq(int M, const ScanItem* d_items, int nitems, int wgs_per_group, const int8_t* d_qtables,
                        QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R,
-                       hipStream_t stream) {
-    if (M == 16) launch_scan_mq_m<16>(d_items, nitems, wgs_per_group, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, stream);
-    else         launch_scan_mq_m<32>(d_items, nitems, wgs_per_group, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, stream);
+                       hipStream_t stream, int narrow) {
+    if (M == 16) launch_scan_mq_m<16>(d_items, nitems, wgs_per_group, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, stream, narrow);
+    else         launch_scan_mq_m<32>(d_items, nitems, wgs_per_group, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, stream, narrow);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1431,13 +1431,17 @@ struct WaveHeap {
 // (a block overflowed / an unordered query: size 0xffffffff, the host regrows or falls back).
 // QF: the single-GPU layout instead — query q's stream at q * cap, {flags, entries} in info[4q], info[4q + 1]
 // (scan_query_kernel / order_cands_kernel write those): bit0 of the flags = qmax too high, bit5 = fallback pending.
+// kReplayWaves queries per workgroup: the waves live for about a millisecond (a query's pushes are a dependent scalar
+// chain) and hold wave slots the scan kernels' 1024-thread workgroups need — packed 16 to a workgroup they tie up a
+// quarter of the CUs they would tie up four to a workgroup.
+constexpr int kReplayWaves = 16;
 template <int NREG, bool QF>
-__global__ __launch_bounds__(256) void replay_heap_wave_kernel(const uint64_t* __restrict__ stream, const uint64_t* __restrict__ off,
+__global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(const uint64_t* __restrict__ stream, const uint64_t* __restrict__ off,
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ info,
                                                                uint32_t cap, int nq, uint32_t R, uint64_t* __restrict__ heaps,
                                                                uint32_t* __restrict__ heap_sizes) {
     const uint32_t lane = threadIdx.x & 63u;
-    const int q = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const int q = (int)(blockIdx.x * (uint32_t)kReplayWaves + (threadIdx.x >> 6));
     if (q >= nq) return;
     uint32_t fl, n;
     uint64_t o;
@@ -1749,7 +1753,7 @@ template <bool QF>
 static hipError_t launch_replay_wave_t(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
                                        uint32_t cap, int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
     if (R == 0 || R > replay_wave_max_R()) return hipErrorInvalidValue;
-    const dim3 grid((nq + 3) / 4), block(256);
+    const dim3 grid((nq + kReplayWaves - 1) / kReplayWaves), block(kReplayWaves * 64);
     switch ((R + 63) / 64) {
         case 1: hipLaunchKernelGGL((replay_heap_wave_kernel<1, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
         case 2: hipLaunchKernelGGL((replay_heap_wave_kernel<2, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;

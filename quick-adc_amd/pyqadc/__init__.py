@@ -46,7 +46,10 @@ class Profile(C.Structure):
                 ("pass_codes", C.c_uint64), ("wgq_launches", C.c_uint64), ("wgq_queries", C.c_uint64),
                 ("wgq_codes", C.c_uint64), ("wgq_ms", C.c_double), ("wgq_front_cycles", C.c_uint64),
                 ("wgq_scan_cycles", C.c_uint64), ("wgq_sort_cycles", C.c_uint64), ("head_launches", C.c_uint64),
-                ("group_launches", C.c_uint64), ("group_fallbacks", C.c_uint64)]
+                ("group_launches", C.c_uint64), ("group_fallbacks", C.c_uint64),
+                ("group_head_ms", C.c_double), ("group_scan_ms", C.c_double), ("group_order_ms", C.c_double),
+                ("group_head_codes", C.c_uint64), ("group_pairs", C.c_uint64), ("group_seats", C.c_uint64),
+                ("group_pass_codes8", C.c_uint64), ("group_pass_codes4", C.c_uint64), ("group_batches", C.c_uint64)]
 
 
 class QadcError(RuntimeError):

@@ -100,6 +100,11 @@ def test_single_gpu_line_keeps_the_two_modes_apart():
     assert line["roofline_batched"]["bound"] == "lds" and 0 < line["roofline_batched"]["frac"] <= 1.0
     assert 0 < line["roofline_32x4"]["frac"] <= 1.0
     assert line["ivf"]["us_per_query"] > 0 and line["latency_us_single_query"]["value"] > 0
+    assert rf["region_queries"] == 8 and rf["region_wall_s"] > 0
+    assert rf["region_wall_s"] >= rf["launches"] * rf["avg_launch_ms"] * 1e-3 / 3     # (three batches in flight at most)
+    ri = line["roofline_ivf"]                                  # the IVF leg's own roofs: grouped scan vs LDS, head vs HBM
+    assert ri["bound"] == "lds" and 0 < ri["frac"] <= 1.0 and 0 < ri["seat_fill"] <= 1.0
+    assert ri["head"]["bound"] == "hbm" and 0 < ri["head"]["frac"] <= 1.0
     assert line["n_gpus"] == 1 and line["recall_at_100"] == 1.0
     # in-run PMC traffic: present when rocprofv3 exists on the box, and then close to the algorithmic bytes
     if rf["traffic"] is not None:
