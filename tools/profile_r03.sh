@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-3 evidence (GPU box, via gpurun): everything tools/profile_r02.sh collects (tag r03), plus
+#   - a kernel trace of ONLY the headline loop (roofline_batched.avg_launch_ms must be recomputable from it),
+#   - a kernel trace and PMC passes of ONLY the IVF leg at the BASELINE configs[2] shape (scan_query_kernel head,
+#     scan_i8_mq_kernel grouped phase: FETCH_SIZE / WRITE_SIZE in their own passes, then the SQ / GRBM set),
+#   - the plain bench line, the one-of-8-rank step times (flat: tools/dist_sizes3.sh, IVF: tools/ivf_shard_sizes.py).
+# Then: python3 tools/summarize_profile_r03.py   (copies the summaries into profiles/)
+TAG=r03
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+bash $R/tools/profile_r02.sh $TAG > $R/gpurun_out/profile_${TAG}_base.log 2>&1
+cd /tmp
+(
+export QADC_BENCH_CPU_SECONDS=0 QADC_BENCH_REAL_CODES=0 QADC_BENCH_SINGLE_QUERIES=0 QADC_BENCH_32X4=0 QADC_BENCH_IVF_CODES=0 QADC_BENCH_LATENCY=0 QADC_BENCH_PMC=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_batched_kt -- python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/prof_${TAG}_batched_kt.log 2>&1
+)
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_ivf_kt -- python3 $R/tools/ivf_shard_one.py c3 none > $R/gpurun_out/prof_${TAG}_ivf_kt.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/prof_${TAG}_ivf_$C -- python3 $R/tools/ivf_shard_one.py c3 none > $R/gpurun_out/prof_${TAG}_ivf_$C.log 2>&1
+done
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_${TAG}_ivf_sq -- python3 $R/tools/ivf_shard_one.py c3 none > $R/gpurun_out/prof_${TAG}_ivf_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_${TAG}_ivf_sq2 -- python3 $R/tools/ivf_shard_one.py c3 none > $R/gpurun_out/prof_${TAG}_ivf_sq2.log 2>&1
+cd $R
+python3 bench.py > gpurun_out/${TAG}_bench_plain.json 2> gpurun_out/${TAG}_bench_plain.err
+bash tools/dist_sizes3.sh > gpurun_out/${TAG}_shard_sizes.txt 2>&1
+python3 tools/ivf_shard_sizes.py c3 c5 > gpurun_out/${TAG}_ivf_shard_sizes.txt 2>&1
+tail -3 gpurun_out/${TAG}_shard_sizes.txt gpurun_out/${TAG}_ivf_shard_sizes.txt
