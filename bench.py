@@ -675,6 +675,13 @@ def main():
             native_init(idx)
         for kv in filter(None, os.environ.get("QADC_BENCH_DIST_OPTS", "").split(",")) if native_dist else ():   # tuning experiments only
             idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+    flat_tr = None
+    if use_dist and backend != "nccl" and os.environ.get("QADC_BENCH_NATIVE_DIST", "1") != "0":
+        # test hook (ranks sharing one GPU, no RCCL between them): the SAME native merge over the library's shared-memory
+        # transport, so that a 1-GPU box runs the multi-rank loop below exactly as an 8-GPU node does, collectives included
+        flat_tr = pyqadc.ShmTransport("/qadc_bench_%s_flat" % os.environ.get("MASTER_PORT", "0"), rank, world)
+        idx.dist_init_transport(flat_tr)
+        native_dist = True
 
     rng = np.random.default_rng(1234)
     codebooks = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
@@ -863,7 +870,8 @@ def main():
         out = {
             "metric": "pq_codes_scanned_per_sec", "value": total_codes / elapsed, "unit": "codes/s",
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 1,
-            "multi_gpu_merge": ("native: qadc_dist_collect (one ncclAllGather of device-resident push streams + device replay)"
+            "multi_gpu_merge": (("native: qadc_dist_collect (one ncclAllGather of device-resident push streams + device replay)"
+                                 if backend == "nccl" else "native: qadc_dist_collect over the shared-memory transport (test hook)")
                                 if native_dist else "pyqadc/sharded.py over torch.distributed (%s)" % backend) if use_dist else None,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
@@ -890,13 +898,15 @@ def main():
         # the int8 tables of one bench batch, for the CPU legs (same tables on both sides)
         qt_cpu = idx.query_scan(assign, pool[0].copy(), R, want_qtables=True)["qtables"][:, 0]
     idx.close()
+    if flat_tr is not None:
+        flat_tr.close()
     # ---- BASELINE configs[2] / configs[4] shapes on N ranks: every rank holds its part of the partitions, the same query
     # batches go to every rank, qadc_dist_collect merges the push streams ----
     if use_dist and int(float(os.environ.get("QADC_BENCH_IVF_CODES", 1e8))) > 0:
         shm_tr = []
 
         def shard_init(ix):
-            if native_dist:
+            if native_dist and backend == "nccl":
                 return native_init(ix)
             # no RCCL between these ranks (gloo test hook: the ranks share one GPU): the library's shared-memory transport
             tr = pyqadc.ShmTransport("/qadc_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), len(shm_tr)), rank, world)
@@ -904,7 +914,7 @@ def main():
             ix.dist_init_transport(tr)
 
         shard = dict(rank=rank, world=world, placement=os.environ.get("QADC_BENCH_IVF_PLACEMENT", "range"), init=shard_init,
-                     barrier=sync, merge="native: qadc_dist_collect over " + ("RCCL" if native_dist else "the shared-memory transport"))
+                     barrier=sync, merge="native: qadc_dist_collect over " + ("RCCL" if native_dist and backend == "nccl" else "the shared-memory transport"))
         ivf_n = ivf_leg(local_rank, shard=dict(shard))
         ivf_c5_n = None
         if os.environ.get("QADC_BENCH_IVF_C5", "1") != "0" and N >= 1e9:

@@ -58,13 +58,19 @@ SMALL = dict(QADC_BENCH_CODES=int(4e7), QADC_BENCH_CPU_SECONDS=0, QADC_BENCH_REA
 
 
 @pytest.mark.gpu
-def test_gpus_2_self_launch_runs_two_ranks_over_gloo_on_one_gpu():
-    env = _env(QADC_BENCH_BACKEND="gloo", QADC_BENCH_ONE_GPU=1, **SMALL)
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+@pytest.mark.parametrize("ranks,native", [(2, 1), (4, 1), (2, 0)])
+def test_gpus_n_self_launch_runs_the_multi_rank_loop_on_one_gpu(ranks, native):
+    """bench.py --gpus N end to end with N ranks on ONE GPU (gloo for the script's own barriers): the flat multi-rank loop —
+    sliced pre-scan, one gather per step carrying streams + the next pre-scan values, host-share replay, second gather —
+    through the library's NATIVE merge over the shared-memory transport (what an 8-GPU node runs over RCCL), and through
+    the older torch.distributed path."""
+    env = _env(QADC_BENCH_BACKEND="gloo", QADC_BENCH_ONE_GPU=1, QADC_BENCH_NATIVE_DIST=native, **SMALL)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(ranks), "--steps", "6", "--warmup", "2"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    assert line["n_gpus"] == ranks and line["rccl_ranks"] == ranks
+    assert line["multi_gpu_merge"].startswith("native" if native else "pyqadc/sharded.py")
     assert line["recall_at_100"] == 1.0
     assert line["roofline"]["frac"] is None           # the one-query-per-pass leg is an N=1 measurement
 
