@@ -12,7 +12,9 @@ bash $R/tools/profile_r02.sh $TAG > $R/gpurun_out/profile_${TAG}_base.log 2>&1
 cd /tmp
 (
 export QADC_BENCH_CPU_SECONDS=0 QADC_BENCH_REAL_CODES=0 QADC_BENCH_SINGLE_QUERIES=0 QADC_BENCH_32X4=0 QADC_BENCH_IVF_CODES=0 QADC_BENCH_LATENCY=0 QADC_BENCH_PMC=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_batched_kt -- python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/prof_${TAG}_batched_kt.log 2>&1
+# (front_run_max = 0: every multi-query launch stays on the main stream inside the event-timed groups, so the launches the
+#  bench line averages ARE the launches the kernel-stats CSV lists)
+QADC_BENCH_OPTS=front_run_max=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_batched_kt -- python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/prof_${TAG}_batched_kt.log 2>&1
 )
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_ivf_kt -- python3 $R/tools/ivf_shard_one.py c3 none > $R/gpurun_out/prof_${TAG}_ivf_kt.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -32,6 +32,8 @@ def one(pattern):
 
 shutil.copy(one("prof_%s_batched_kt/**/*_kernel_stats.csv" % TAG), os.path.join(P, "%s_batched_only_kernel_stats.csv" % TAG))
 shutil.copy(one("prof_%s_ivf_kt/**/*_kernel_stats.csv" % TAG), os.path.join(P, "%s_ivf_kernel_stats.csv" % TAG))
+open(os.path.join(P, "%s_batched_only_bench.json" % TAG), "w").write(
+    [l for l in open(os.path.join(G, "prof_%s_batched_kt.log" % TAG)) if l.startswith("{")][-1])
 for name in ("bench_plain.json", "shard_sizes.txt", "ivf_shard_sizes.txt"):
     src = os.path.join(G, "%s_%s" % (TAG, name))
     if os.path.exists(src):
