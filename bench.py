@@ -915,10 +915,30 @@ def main():
 
         shard = dict(rank=rank, world=world, placement=os.environ.get("QADC_BENCH_IVF_PLACEMENT", "range"), init=shard_init,
                      barrier=sync, merge="native: qadc_dist_collect over " + ("RCCL" if native_dist and backend == "nccl" else "the shared-memory transport"))
-        ivf_n = ivf_leg(local_rank, shard=dict(shard))
-        ivf_c5_n = None
-        if os.environ.get("QADC_BENCH_IVF_C5", "1") != "0" and N >= 1e9:
-            ivf_c5_n = ivf_leg(local_rank, M=32, K=16384, MA=64, dim=96, N=int(1e9), seed0=7000, shard=dict(shard))
+        # The headline above is measured; these extra legs must not be able to take it down with them.  A watchdog on
+        # EVERY rank: if the legs are not through in time (a collective that never completes), rank 0 prints the line without
+        # them and every rank leaves — a hung rank cannot be interrupted, only abandoned.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["ivf"] = {"error": "the multi-rank IVF legs did not finish within %s s; abandoned" % limit}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        limit = float(os.environ.get("QADC_BENCH_IVF_TIMEOUT", 420))
+        dog = threading.Timer(limit, give_up)
+        dog.daemon = True
+        dog.start()
+        ivf_n, ivf_c5_n = None, None
+        try:
+            ivf_n = ivf_leg(local_rank, shard=dict(shard))
+            if os.environ.get("QADC_BENCH_IVF_C5", "1") != "0" and N >= 1e9:
+                ivf_c5_n = ivf_leg(local_rank, M=32, K=16384, MA=64, dim=96, N=int(1e9), seed0=7000, shard=dict(shard))
+        except Exception as e:  # noqa: BLE001 — reported in the line, the headline stands
+            ivf_n = ivf_n or {"error": repr(e)}
+            sys.stderr.write("rank %d: multi-rank IVF leg failed: %r\n" % (rank, e))
+        dog.cancel()
         for tr in shm_tr:
             tr.close()
         if rank == 0:
