@@ -577,6 +577,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args)
 
+    line_printed = []                                          # (non-empty once rank 0 has printed the JSON line)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -921,7 +922,7 @@ def main():
         import threading
 
         def give_up():
-            if rank == 0:
+            if rank == 0 and not line_printed:
                 out["ivf"] = {"error": "the multi-rank IVF legs did not finish within %s s; abandoned" % limit}
                 print(json.dumps(out), flush=True)
             os._exit(0)
@@ -930,7 +931,7 @@ def main():
         dog = threading.Timer(limit, give_up)
         dog.daemon = True
         dog.start()
-        ivf_n, ivf_c5_n = None, None
+        ivf_n, ivf_c5_n, ivf_failed = None, None, False
         try:
             ivf_n = ivf_leg(local_rank, shard=dict(shard))
             if os.environ.get("QADC_BENCH_IVF_C5", "1") != "0" and N >= 1e9:
@@ -938,7 +939,9 @@ def main():
         except Exception as e:  # noqa: BLE001 — reported in the line, the headline stands
             ivf_n = ivf_n or {"error": repr(e)}
             sys.stderr.write("rank %d: multi-rank IVF leg failed: %r\n" % (rank, e))
-        dog.cancel()
+            ivf_failed = True                                  # (the other ranks may be stuck in a collective: the watchdog stays armed)
+        if not ivf_failed:
+            dog.cancel()
         for tr in shm_tr:
             tr.close()
         if rank == 0:
@@ -981,6 +984,7 @@ def main():
             out.update(cpu_extra_legs(M, N, qt_cpu, min(cpu_s, 6.0)))
     if rank == 0:
         print(json.dumps(out), flush=True)
+        line_printed.append(1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
