@@ -102,7 +102,7 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * in the kernel arguments), "wgq_poll" (... and its completion is read from the mapped result block),
  * "wgq_group" (large IVF batches: partition-major second phase; 0 never, 1 auto, 2 whenever possible),
  * "wgq_group_head" (probes per query the one-workgroup-per-query head walks before it),
- * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_async", "dist_inject_failure" (test hook). */
+ * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_async", "dist_shard_front", "dist_inject_failure" (test hook). */
 int qadc_set_option(qadc_index* idx, const char* name, double value);
 
 /* Copy codes back (tests / checksums): partition `part`, codes [first, first+count). */
@@ -283,7 +283,11 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
  * of this rank's streams only).  Large one-workgroup-per-query batches (>= "dist_device_nq" queries: IVF) have their merge —
  * pack, all-gather, interleave, replay — ENQUEUED WITH THE BATCH, behind its scan, so qadc_dist_collect only waits for it
  * (option "dist_async", default 1): after qadc_dist_init every rank must therefore SUBMIT the same batches in the same
- * order, not just collect them (the all-gather of such a batch is issued by its submit call).
+ * order, not just collect them (the all-gather of such a batch is issued by its submit call).  qadc_search batches of
+ * that kind also SHARD THEIR FRONT (option "dist_shard_front", default 1): what is per query rather than per code — coarse
+ * assignment, residual tables, pre-scan, select, quantizer — runs on rank r for queries [r * ceil(nq / world), ...) only, and
+ * one more all-gather (issued by the submit call as well) ships assign[], the int8 tables and (flags, qmin, qmax) of every
+ * query to every rank before the sharded scan.
  *   rank 0:      qadc_dist_unique_id(id)  ... ship the 128 bytes to the other ranks by any means ...
  *   every rank:  qadc_dist_init(idx, rank, world, id);  then per batch  qadc_query_scan_submit(...); qadc_dist_collect(...) */
 #define QADC_DIST_ID_BYTES 128

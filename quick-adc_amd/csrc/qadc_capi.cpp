@@ -158,6 +158,17 @@ struct Slot {
     uint32_t* h_heap_sizes = nullptr;
     bool heaps_ready = false;           // a replay kernel ran for the batch: h_heaps / h_heap_sizes hold its result
     bool rerun = false;                 // the batch is being re-run from inside a collect call (no merge is enqueued with it)
+    // Front sharded over the ranks of the multi-GPU merge (qadc_search batches): this rank ran feeders + pre-scan + quantizer
+    // for queries [front_q0, front_q0 + front_n) only; the int8 tables, assign[] and (flags, qmin, qmax) of ALL queries come
+    // from one all-gather and the scan takes them like an int8 batch.
+    bool front_sharded = false;
+    int front_q0 = 0, front_n = 0, front_per = 0;
+    DevBuf<unsigned char> d_fblock, d_fgathered;
+    DevBuf<uint32_t> d_front_all;       // [nq][4] gathered {flags, qmin, qmax, 0}
+    PinBuf<unsigned char> h_fmap;       // mapped: assign i32[nq][ma], then front u32[nq][4] (written by front_unpack_kernel)
+    unsigned char* d_fmap = nullptr;
+    unsigned char* h_fmap_mapped = nullptr;
+    hipEvent_t ev_fa = nullptr, ev_fb = nullptr;
     bool skipped_streams = false;       // collect_common left device-replayed queries' streams unassembled
     QueryOut* h_qout = nullptr;
     uint64_t* h_entries = nullptr;
@@ -279,6 +290,7 @@ struct DistState {
     int device_nq = 256;                                     // batches of at least this many queries replay on the device
     int inject_failure = 0;                                  // test hook: the next qadc_dist_collect of this rank fails locally
     int async_merge = 1;                                     // enqueue the merge with the batch where possible (option "dist_async")
+    int shard_front = 1;                                     // qadc_search batches: every rank runs the front of 1/world of the queries (option "dist_shard_front")
     DistSlot slot[kSlots];
     // One all-gather of `words` u64 per rank on `st`: RCCL (enqueued, stream-ordered) or the caller's transport
     // (complete on return).  0 = ok; else the message is in `err`.
@@ -669,7 +681,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     const size_t off_sitems = align16(off_items + nitems * sizeof(ScanItem));
     const size_t off_init = align16(off_sitems + (na + nb) * sizeof(StartItem));
     const size_t off_tables = align16(off_init + fc_init.size() * sizeof(uint32_t));
-    const size_t tables_bytes = s.float_path ? (s.device_tables ? 0 : nt * sizeof(float)) : nt;
+    const size_t tables_bytes = s.float_path ? (s.device_tables ? 0 : nt * sizeof(float)) : (s.front_sharded ? 0 : nt);
     const size_t off_inj = align16(off_tables + tables_bytes);
     const size_t inj_bytes = s.mode == 2 ? sizeof(float) * (size_t)nq * s.inj_n : 0;
     const size_t off_hassign = align16(off_inj + inj_bytes);  // assign[] for the head launch (it walks the partition table itself)
@@ -682,7 +694,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     if (nb) std::memcpy(s.h_in.p + off_sitems + na * sizeof(StartItem), sitems_b.data(), nb * sizeof(StartItem));
     std::memcpy(s.h_in.p + off_init, fc_init.data(), fc_init.size() * sizeof(uint32_t));
     if (s.float_path && !s.device_tables) std::memcpy(s.h_in.p + off_tables, s.tables, nt * sizeof(float));
-    if (!s.float_path) std::memcpy(s.h_in.p + off_tables, s.qtables_in.data(), nt);
+    if (!s.float_path && !s.front_sharded) std::memcpy(s.h_in.p + off_tables, s.qtables_in.data(), nt);
     if (inj_bytes) std::memcpy(s.h_in.p + off_inj, s.inj_vals.data(), inj_bytes);
     if (hassign_bytes) std::memcpy(s.h_in.p + off_hassign, s.assign.data(), hassign_bytes);
     s.d_items = reinterpret_cast<ScanItem*>(s.d_in.p + off_items);
@@ -814,7 +826,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                           idx->quant_mode, st);
         if (idx->profile) HIPCHECK(prof_event(s, st));
     } else {
-        s.d_qt = reinterpret_cast<const int8_t*>(s.d_in.p + off_tables);     // caller's int8 tables, as uploaded
+        s.d_qt = s.front_sharded ? s.d_qtables.p                             // (a sharded-front batch redone here: the gathered tables)
+                                 : reinterpret_cast<const int8_t*>(s.d_in.p + off_tables);     // caller's int8 tables, as uploaded
         if (idx->profile) { HIPCHECK(prof_event(s, st)); HIPCHECK(prof_event(s, st)); }
     }
 
@@ -1065,7 +1078,9 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     A.ma = ma;
     A.ftables = nullptr;
     A.qtables = s.d_qtables.p;
-    if (s.float_path) {
+    if (s.front_sharded) {
+        // (tables come out of the sharded front below)
+    } else if (s.float_path) {
         if (s.device_tables) {
             HIPCHECK(s.d_ftables.ensure(nt));
             HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
@@ -1077,6 +1092,56 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         }
     } else {
         A.qtables = reinterpret_cast<int8_t*>(s.d_in.p + off_tables);    // the caller's int8 tables, as uploaded
+    }
+    if (s.front_sharded) {
+        // ---- sharded front: this rank's share -> gather -> the whole batch as an int8 batch with device-resident inputs ----
+        DistState& d = *idx->dist;
+        const size_t tab = table_dim * (size_t)ma;
+        const size_t block = ((size_t)s.front_per * (tab + (size_t)ma * 4 + 16) + 15) & ~(size_t)15;
+        int32_t* d_assign_share = reinterpret_cast<int32_t*>(s.d_fblock.p + (size_t)s.front_per * tab);
+        uint32_t* d_front_share = reinterpret_cast<uint32_t*>(s.d_fblock.p + (size_t)s.front_per * (tab + (size_t)ma * 4));
+        if (!s.rerun) {                                          // (a re-run from inside collect reuses the gathered arrays)
+            HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
+            if (s.front_n) {
+                const size_t nt_share = (size_t)s.front_n * tab;
+                HIPCHECK(s.d_ftables.ensure(nt_share));
+                launch_build_tables(s.d_queries.p, idx->d_coarse.p, d_assign_share, idx->d_codebooks.p,
+                                    idx->has_rotation ? idx->d_rotation.p : nullptr, s.front_n, ma, M, idx->dim, table_expansion(idx, ma),
+                                    s.d_ftables.p, st);
+                QueryKernelArgs F{};
+                F.parts = idx->d_partdesc.p;
+                F.assign = d_assign_share;
+                F.ma = ma;
+                F.ftables = s.d_ftables.p;
+                F.qtables = reinterpret_cast<int8_t*>(s.d_fblock.p);
+                F.fvals = fcap ? s.d_fvals.p : nullptr;
+                F.fcap = (uint32_t)fcap;
+                F.R = (uint32_t)s.R;
+                F.quant_mode = idx->quant_mode;
+                F.head_codes = ~0ull;
+                F.head_slots = 1;
+                F.G = 1;
+                F.front_only = 1;
+                F.front_out = d_front_share;
+                HIPCHECK(launch_scan_query(M, idx->wgq_variant, s.front_n, F, st));
+            }
+            // the collectives of the merge live on ONE stream, in the order the host issues them (the same on every rank)
+            if (!s.ev_fa) HIPCHECK(hipEventCreateWithFlags(&s.ev_fa, hipEventDisableTiming));
+            if (!s.ev_fb) HIPCHECK(hipEventCreateWithFlags(&s.ev_fb, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(s.ev_fa, st));
+            HIPCHECK(hipStreamWaitEvent(d.stream, s.ev_fa, 0));
+            std::string gerr;
+            if (d.gather(s.d_fblock.p, s.d_fgathered.p, block / 8, d.stream, gerr)) return fail(QADC_E_HIP, gerr);
+            HIPCHECK(launch_front_unpack(s.d_fgathered.p, block, d.world, s.front_per, nq, ma, tab, s.d_qtables.p, s.d_assign.p,
+                                         s.d_front_all.p, reinterpret_cast<int32_t*>(s.d_fmap),
+                                         reinterpret_cast<uint32_t*>(s.d_fmap + (size_t)nq * ma * 4), d.stream));
+            HIPCHECK(hipEventRecord(s.ev_fb, d.stream));
+            HIPCHECK(hipStreamWaitEvent(st, s.ev_fb, 0));
+        }
+        A.assign = s.d_assign.p;
+        A.ftables = nullptr;                                     // from here on: an int8 batch
+        A.qtables = s.d_qtables.p;
+        A.front_in = s.d_front_all.p;
     }
     s.d_qt = A.qtables;
     A.fvals = fcap ? s.d_fvals.p : nullptr;
@@ -1255,6 +1320,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
     }
     s.full_prescan = false;
     s.rerun = false;
+    s.front_sharded = false;
     s.assign_on_device = false;
     {   // which path: levels (long shared lists) or one workgroup per query (IVF batches, small lists)
         uint64_t max_codes = 0;
@@ -1276,6 +1342,14 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
     if (int rc = plan_and_launch(idx, s)) return rc;
     s.busy = true;
     return QADC_OK;
+}
+
+// Whether launch_wgq_batch will send a batch of this shape through the partition-major second phase (same test as there).
+bool will_group(const qadc_index* idx, int nq, int ma, bool dev_replay) {
+    const int head_slots = std::min(idx->dist ? idx->wgq_group_head_dist : idx->wgq_group_head, ma);
+    const size_t pairs = (size_t)nq * (size_t)(ma - head_slots), nparts = idx->parts.size();
+    return dev_replay && pairs > 0 && nparts < (1u << 24) &&
+           (idx->wgq_group == 2 || (idx->wgq_group == 1 && idx->group_strikes < 2 && nq >= 256 && pairs >= 2 * nparts));
 }
 
 // N1: queries in.  Coarse assignment runs on the copy stream (so it does not queue behind the previous
@@ -1308,6 +1382,53 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
     HIPCHECK(s.d_assign.ensure((size_t)nq * ma));
     std::memcpy(s.h_queries.p, queries, sizeof(float) * (size_t)nq * dim);
     hipStream_t cs = idx->copy_stream;
+    // Under the multi-GPU merge every rank receives the same queries; what is per QUERY rather than per code — coarse
+    // assignment, residual tables, pre-scan, select, quantizer — is then split over the ranks: rank r does it for queries
+    // [r * per, (r + 1) * per) and one all-gather ships assign[] + int8 tables + (flags, qmin, qmax) to everybody
+    // (launch_wgq_batch).  Only for batches that take the one-workgroup-per-query head + partition-major second phase.
+    s.front_sharded = false;
+    {
+        const uint64_t est = idx->parts.empty() ? 0 : idx->total_codes / idx->parts.size() * (uint64_t)(idx->K ? ma : 1);
+        if (idx->dist && idx->dist->shard_front && idx->dist->world > 1 && idx->K && nq >= 2 * idx->dist->world &&
+            wgq_eligible(idx, nq, ma, R, 0, est) && will_group(idx, nq, ma, true)) {
+            s.front_sharded = true;
+            s.front_per = (nq + idx->dist->world - 1) / idx->dist->world;
+            s.front_q0 = std::min(nq, idx->dist->rank * s.front_per);
+            s.front_n = std::min(nq, s.front_q0 + s.front_per) - s.front_q0;
+        }
+    }
+    if (s.front_sharded) {
+        const size_t tab = (size_t)ma * idx->M * 16;
+        const size_t block = ((size_t)s.front_per * (tab + (size_t)ma * 4 + 16) + 15) & ~(size_t)15;   // [qtables][assign][front] of `per` queries
+        HIPCHECK(s.d_fblock.ensure(block));
+        HIPCHECK(s.d_fgathered.ensure(block * idx->dist->world));
+        HIPCHECK(s.d_front_all.ensure(4 * (size_t)nq));
+        HIPCHECK(s.h_fmap.ensure((size_t)nq * ma * 4 + (size_t)nq * 16, hipHostMallocMapped | hipHostMallocCoherent));
+        if (s.h_fmap.p != s.h_fmap_mapped) {
+            HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.d_fmap), s.h_fmap.p, 0));
+            s.h_fmap_mapped = s.h_fmap.p;
+        }
+        if (s.front_n) {
+            HIPCHECK(hipMemcpyAsync(s.d_queries.p, s.h_queries.p + (size_t)s.front_q0 * dim, sizeof(float) * (size_t)s.front_n * dim,
+                                    hipMemcpyHostToDevice, cs));
+            HIPCHECK(s.d_cdist.ensure((size_t)s.front_n * idx->K));
+            int32_t* d_assign_share = reinterpret_cast<int32_t*>(s.d_fblock.p + (size_t)s.front_per * tab);
+            launch_coarse_assign(s.d_queries.p, idx->d_coarse.p, s.front_n, idx->K, dim, ma, s.d_cdist.p, d_assign_share, cs);
+            HIPCHECK(hipGetLastError());
+        }
+        if (!s.ev_feed) HIPCHECK(hipEventCreateWithFlags(&s.ev_feed, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(s.ev_feed, cs));
+        s.wgq = true;
+        s.wgq_codes = idx->total_codes / idx->parts.size() * (uint64_t)ma;
+        s.assign_on_device = true;
+        s.full_prescan = false;
+        s.rerun = false;
+        s.wgq_cap = std::max<uint32_t>(s.wgq_cap, idx->wgq_capacity);
+        s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
+        if (int rc = plan_and_launch(idx, s)) return rc;
+        s.busy = true;
+        return QADC_OK;
+    }
     HIPCHECK(hipMemcpyAsync(s.d_queries.p, s.h_queries.p, sizeof(float) * (size_t)nq * dim, hipMemcpyHostToDevice, cs));
     if (idx->K) {
         HIPCHECK(s.d_cdist.ensure((size_t)nq * idx->K));
@@ -1365,8 +1486,14 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool fr
     const uint32_t sort_limit_max = kSortCap;
     uint64_t total_sorted = 0;
     if (s.assign_on_device) {                                  // qadc_search: assign[] comes back for the caller (and the planner)
-        HIPCHECK(hipEventSynchronize(s.ev_assign));
-        s.assign.assign(s.h_assign.p, s.h_assign.p + (size_t)s.nq * s.ma);
+        if (s.front_sharded) {                                   // gathered from the ranks; front_unpack_kernel stored it in mapped memory
+            HIPCHECK(hipEventSynchronize(s.ev_fb));
+            const int32_t* ha = reinterpret_cast<const int32_t*>(s.h_fmap.p);
+            s.assign.assign(ha, ha + (size_t)s.nq * s.ma);
+        } else {
+            HIPCHECK(hipEventSynchronize(s.ev_assign));
+            s.assign.assign(s.h_assign.p, s.h_assign.p + (size_t)s.nq * s.ma);
+        }
         s.assign_on_device = false;
     }
     for (int attempt = 0; s.wgq; ++attempt) {                  // one workgroup per query: per-query stream capacity only
@@ -1405,6 +1532,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool fr
             s.wgq_grouped = false;
             s.wgq = false;
             s.wgq_G = 1;
+            if (s.front_sharded) s.float_path = false;           // the level path takes the gathered int8 tables as they lie on the device
             s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)s.nq * 8192u, 1ull << 30));
             s.rerun = true;
             if (int rc = plan_and_launch(idx, s)) {
@@ -1652,7 +1780,13 @@ void finish_float_outputs(qadc_index* idx, Slot& s, int32_t* status, float* qmin
     const size_t per_q = (size_t)s.ma * idx->M * 16;
     const int stride = s.wgq ? s.wgq_G : 1;                      // (a query's workgroups report the same qmin / qmax / flags)
     for (int q = 0; q < s.nq; ++q) {
-        const QueryOut& qs = s.h_qout[(size_t)q * stride];
+        QueryOut qs = s.h_qout[(size_t)q * stride];
+        if (s.front_sharded) {                                   // the front ran on rank q / per: its verdict came with the gather
+            const uint32_t* fr = reinterpret_cast<const uint32_t*>(s.h_fmap.p + (size_t)s.nq * s.ma * 4) + 4 * (size_t)q;
+            qs.flags = (qs.flags & ~3u) | (fr[0] & 3u);
+            std::memcpy(&qs.qmin, &fr[1], 4);
+            std::memcpy(&qs.qmax, &fr[2], 4);
+        }
         if (status) status[q] = (qs.flags & 1u) ? 1 : 0;
         if (qmin) qmin[q] = qs.qmin;
         if (qmax) qmax[q] = qs.qmax;
@@ -1779,6 +1913,9 @@ int qadc_index_destroy(qadc_index* idx) {
         s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
         s.h_cands.release(); s.d_stream.release(); s.d_qflags.release(); s.d_fvals.release(); s.d_qcands.release(); s.h_fetch.release();
         s.d_gplan.release(); s.d_gitems.release();
+        s.d_fblock.release(); s.d_fgathered.release(); s.d_front_all.release(); s.h_fmap.release();
+        if (s.ev_fa) (void)hipEventDestroy(s.ev_fa);
+        if (s.ev_fb) (void)hipEventDestroy(s.ev_fb);
         if (s.ev_assign) (void)hipEventDestroy(s.ev_assign);
         s.d_queries.release(); s.d_assign.release(); s.d_cdist.release(); s.h_queries.release(); s.h_assign.release();
         if (s.ev_feed) (void)hipEventDestroy(s.ev_feed);
@@ -2071,6 +2208,10 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "dist_async") {                             // 1: enqueue the merge with the batch where possible; 0: always at collect time
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
         idx->dist->async_merge = value != 0;
+    }
+    else if (n == "dist_shard_front") {                       // 1: feeders + pre-scan + quantizer of a qadc_search batch are split over the ranks
+        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
+        idx->dist->shard_front = value != 0;
     }
     else if (n == "dist_inject_failure") {                    // test hook: this rank's next qadc_dist_collect fails before the gather
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");

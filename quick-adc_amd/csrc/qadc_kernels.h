@@ -137,6 +137,13 @@ struct QueryKernelArgs {
     // dispatch packet and no host-to-device copy precedes the launch.  payload = [i32 assign[nq*ma] = 0,1,2...]
     // [PartDesc[nq*ma] of the probed partitions, at inline_off_parts][float tables, at inline_off_tables].
     uint32_t inline_input, inline_off_parts, inline_off_tables;
+    // Front sharded over the ranks of a multi-GPU merge (HEAD instantiation only): rank r runs the front — pre-scan,
+    // select, qmin / clamp, quantizer — for ITS share of the queries with front_only set (results: qtables + front_out[q] =
+    // {flags & 3, qmin, qmax, 0}; no walk), the shares are all-gathered, and the head launch of the whole batch takes the
+    // gathered int8 tables with front_in seeding every query's flags / qmin / qmax.
+    uint32_t front_only;
+    uint32_t* front_out;
+    const uint32_t* front_in;
 };
 
 constexpr size_t kInlineBytes = 3072;            // kernel arguments are limited to 4 KiB
@@ -157,6 +164,11 @@ void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, i
                      uint32_t* d_goff, uint32_t* d_fill, ScanItem* d_items, hipStream_t stream);
 hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uint32_t cand_cap, uint32_t ccap, int nq,
                               uint64_t* d_stream, uint32_t cap, QueryOut* d_qout, uint32_t* d_qflags, hipStream_t stream);
+// Front shares of the ranks (gathered blocks of block_bytes each: [qtables per x tab][assign per x ma i32][front per x 4 u32])
+// -> the batch's arrays in query order; assign and front records also into host-mapped memory for the collect call.
+hipError_t launch_front_unpack(const unsigned char* d_gathered, size_t block_bytes, int world, int per, int nq, int ma, size_t tab,
+                               int8_t* d_qt, int32_t* d_assign, uint32_t* d_front, int32_t* h_assign, uint32_t* h_front,
+                               hipStream_t stream);
 // kv_binheap push replay of the ordered streams, 64 queries per wave (one lane each); R <= replay_lanes_max_R().
 uint32_t replay_lanes_max_R();
 hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,

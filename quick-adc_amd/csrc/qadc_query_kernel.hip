@@ -559,10 +559,25 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         }
         __threadfence_block();
         __syncthreads();
+        if (HEAD && A.front_only) {                              // this rank's share of a sharded front: no walk here
+            if (tid == 0 && g == 0) {
+                uint32_t* fo = A.front_out + 4 * (size_t)q;
+                fo[0] = flags & 3u;
+                fo[1] = __float_as_uint(qmin);
+                fo[2] = __float_as_uint(qmax);
+                fo[3] = 0;
+            }
+            return;
+        }
         if (tid < 256) hist[tid] = 0;                            // becomes the value histogram of the scan
         __syncthreads();
     } else {
         prefetch();
+        if (HEAD && A.front_in) {                                // the front ran on another rank: its verdict travels with the tables
+            flags = A.front_in[4 * (size_t)q] & 3u;
+            qmin = __uint_as_float(A.front_in[4 * (size_t)q + 1]);
+            qmax = __uint_as_float(A.front_in[4 * (size_t)q + 2]);
+        }
     }
 
     if (flags & 1u) {                                            // the reference prints a warning and exits: no scan
@@ -982,7 +997,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 if (s_ccount > A.cand_cap) atomicAdd(&A.hdr->overflow, s_ccount - A.cand_cap);
             }
         }
-        if (A.ftables && tid == 0 && g == 0) {                   // front run here: its results travel in the QueryState
+        if ((A.ftables || A.front_in) && tid == 0 && g == 0) {   // front run here (or gathered): its results travel in the QueryState
             QueryState* qs = A.qstates + q;
             qs->qmin = qmin;
             qs->qmax = qmax;
@@ -1502,6 +1517,30 @@ __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(con
     if (lane == 0) heap_sizes[q] = h.size;
 }
 
+// ---- sharded front: the ranks' shares -> the batch's arrays in query order ----
+__global__ __launch_bounds__(256) void front_unpack_kernel(const unsigned char* __restrict__ gathered, size_t block_bytes, int world, int per,
+                                                           int nq, int ma, size_t tab, int8_t* __restrict__ qt, int32_t* __restrict__ assign,
+                                                           uint32_t* __restrict__ front, int32_t* __restrict__ h_assign,
+                                                           uint32_t* __restrict__ h_front) {
+    const int q = blockIdx.x;                                    // one workgroup per query
+    const int r = q / per, i = q % per;
+    const unsigned char* blk = gathered + (size_t)r * block_bytes;
+    const uint4* src = reinterpret_cast<const uint4*>(blk + (size_t)i * tab);      // (tab is a multiple of 256 bytes)
+    uint4* dst = reinterpret_cast<uint4*>(qt + (size_t)q * tab);
+    for (size_t w = threadIdx.x; w < tab / 16; w += 256) dst[w] = src[w];
+    const int32_t* sa = reinterpret_cast<const int32_t*>(blk + (size_t)per * tab) + (size_t)i * ma;
+    for (int a = threadIdx.x; a < ma; a += 256) {
+        const int32_t v = sa[a];
+        assign[(size_t)q * ma + a] = v;
+        h_assign[(size_t)q * ma + a] = v;
+    }
+    const uint32_t* sf = reinterpret_cast<const uint32_t*>(blk + (size_t)per * tab + (size_t)per * ma * 4) + 4 * (size_t)i;
+    if (threadIdx.x < 4) {
+        front[4 * (size_t)q + threadIdx.x] = sf[threadIdx.x];
+        h_front[4 * (size_t)q + threadIdx.x] = sf[threadIdx.x];
+    }
+}
+
 // ---- the world's gathered blocks -> ONE stream per query in global scan order (assign slot, rank, position) ----
 // Per query: totals and flags over the ranks, exclusive prefix over the queries (one workgroup).
 __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world, int nq,
@@ -1742,6 +1781,14 @@ hipError_t launch_dist_pack_qflags(const uint32_t* d_qflags, int nq, const uint6
     hipLaunchKernelGGL(dist_pack_kernel, dim3(nq), dim3(256), 0, stream, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, nq, d_stream, (const uint64_t*)nullptr, cap_entries, (const float*)nullptr, 0u, d_block,
                        d_qflags, qcap);
+    return hipGetLastError();
+}
+
+hipError_t launch_front_unpack(const unsigned char* d_gathered, size_t block_bytes, int world, int per, int nq, int ma, size_t tab,
+                               int8_t* d_qt, int32_t* d_assign, uint32_t* d_front, int32_t* h_assign, uint32_t* h_front,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(front_unpack_kernel, dim3(nq), dim3(256), 0, stream, d_gathered, block_bytes, world, per, nq, ma, tab, d_qt,
+                       d_assign, d_front, h_assign, h_front);
     return hipGetLastError();
 }
 

@@ -65,6 +65,28 @@ def build_case(name):
         t[0] = 1.0
         c["tables"] = t
         c["index_options"] = {"wgq": 0, "head_level": 0, "level_base": 1 << 22}
+    elif name in ("ivf_search", "ivf_search_whole"):
+        # QUERIES in (qadc_search_submit): under the merge the front of the batch — coarse assignment, residual tables,
+        # pre-scan, quantizer — is itself sharded over the ranks and all-gathered before the sharded scan.  nq not a multiple
+        # of the world sizes (ragged last share), an exact tie between two coarse centroids, one query far from everything.
+        M = 16 if name == "ivf_search" else 32
+        rng = np.random.default_rng(506 + M)
+        K, dim, nq, ma = 40, 32, 277, 5
+        sizes = [int(x) for x in rng.integers(300, 6000, K)]
+        sizes[9] = 0
+        parts = [rand_codes(rng, s_, M) for s_ in sizes]
+        perm = rng.permutation(sum(sizes)).astype(np.uint32)
+        labels = list(np.split(perm, np.cumsum(sizes)[:-1]))
+        cb = rng.normal(size=(M, 16, dim // M)).astype(np.float32)
+        coarse = rng.normal(size=(K, dim)).astype(np.float32)
+        coarse[5] = coarse[3]
+        queries = rng.normal(size=(nq, dim)).astype(np.float32)
+        queries[17] *= 50.0
+        c.update(M=M, parts=parts, labels=labels, keep=0.05, codebooks=cb, coarse=coarse, queries=queries, search_ma=ma,
+                 assign=None, tables=None)
+        c["index_options"] = {"wgq_group": 2, "wgq_group_head": 2}
+        if name == "ivf_search_whole":
+            c["placement"] = "whole"
     elif name == "inject":
         # the LAST rank's batch fails before the gather: every rank must return an error (no rank left in the
         # collective), and the next batch must go through
@@ -76,4 +98,40 @@ def build_case(name):
     return c
 
 
-CASES = ["flat32", "ivf_lanes", "ivf_whole", "big_r", "unordered", "inject"]
+CASES = ["flat32", "ivf_lanes", "ivf_whole", "ivf_search", "ivf_search_whole", "big_r", "unordered", "inject"]
+
+
+def search_inputs(case):
+    """assign[] and float tables of a queries-in case, evaluated by the same sequential float loops as the device feeders
+    (and host/query_driver.hpp): squared L2 in ascending d, lowest index on ties; BLAS-expansion tables for ma > 1."""
+    q, coarse, cb, ma, M = case["queries"], case["coarse"], case["codebooks"], case["search_ma"], case["M"]
+    K, dim = coarse.shape
+    ds = dim // M
+
+    def sqdist(x, c_):
+        s_ = np.zeros(c_.shape[:-1], np.float32)
+        for d in range(c_.shape[-1]):
+            t = (x[..., d] - c_[..., d]).astype(np.float32)
+            s_ = (s_ + (t * t).astype(np.float32)).astype(np.float32)
+        return s_
+
+    def expansion(x, c_):
+        vn = np.zeros(np.broadcast_shapes(x.shape[:-1], c_.shape[:-1]), np.float32)
+        cn, dot = np.zeros_like(vn), np.zeros_like(vn)
+        for d in range(c_.shape[-1]):
+            xv, cv = x[..., d].astype(np.float32), c_[..., d].astype(np.float32)
+            vn = (vn + (xv * xv).astype(np.float32)).astype(np.float32)
+            cn = (cn + (cv * cv).astype(np.float32)).astype(np.float32)
+            dot = (dot + (xv * cv).astype(np.float32)).astype(np.float32)
+        return ((vn + cn).astype(np.float32) + (np.float32(-2.0) * dot).astype(np.float32)).astype(np.float32)
+
+    nq = q.shape[0]
+    assign = np.zeros((nq, ma), np.int32)
+    tables = np.zeros((nq, ma, M * 16), np.float32)
+    for i in range(nq):
+        dist = sqdist(q[i][None, :], coarse)
+        assign[i] = np.lexsort((np.arange(K), dist))[:ma]
+        resid = (q[i][None, :] - coarse[assign[i]]).astype(np.float32)
+        for a in range(ma):
+            tables[i, a] = expansion(resid[a].reshape(M, 1, ds), cb).reshape(-1)
+    return assign, tables

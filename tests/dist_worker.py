@@ -38,6 +38,9 @@ def build_index(case, rank, world):
         idx.add_partition_shard(codes[first:first + ln], first, n, labels=None if (lab is None or ln == 0) else lab[first:first + ln],
                                 starts=codes[:start_size(n, keep)])
     idx.finalize(keep)
+    if "queries" in case:
+        idx.set_pq(case["codebooks"])
+        idx.set_coarse(case["coarse"])
     for k, v in case["index_options"].items():
         idx.set_option(k, v)
     return idx
@@ -65,6 +68,24 @@ def run_case(name, rank, world, transport):
         except pyqadc.QadcError as e:
             out["inject_error"] = np.array([1])
             out["inject_message"] = np.frombuffer(str(e).encode()[:200].ljust(200), np.uint8)
+    if "queries" in case:                                  # queries in: two batches in flight, the second with the front unsharded
+        idx.search_submit(0, case["queries"], case["search_ma"], R)
+        idx.search_submit(1, case["queries"][::-1].copy(), case["search_ma"], R)
+        for s, rev in ((0, False), (1, True)):
+            got = idx.dist_collect(s)
+            for k in ("keys", "values", "sizes", "status"):
+                out["%s_slot%d" % (k, s)] = got[k][::-1].copy() if rev else got[k]
+            a = idx.slot_assign(s, case["queries"].shape[0], case["search_ma"])
+            out["assign_slot%d" % s] = a[::-1].copy() if rev else a
+        idx.set_option("dist_shard_front", 0)
+        idx.search_submit(2, case["queries"], case["search_ma"], R)
+        got = idx.dist_collect(2)
+        for k in ("keys", "values", "sizes", "status"):
+            out["%s_slot2" % k] = got[k]
+        out["assign_slot2"] = idx.slot_assign(2, case["queries"].shape[0], case["search_ma"])
+        out["group_launches"] = np.array([idx.profile()["group_launches"]])
+        idx.close()
+        return out
     for s in case["slots"]:                                # (two batches in flight where the case says so)
         idx.submit(s, case["assign"], case["tables"].copy(), R)
     for s in case["slots"]:

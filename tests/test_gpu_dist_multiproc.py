@@ -18,7 +18,7 @@ import uuid
 import numpy as np
 import pytest
 
-from dist_cases import CASES, build_case
+from dist_cases import CASES, build_case, search_inputs
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "dist_worker.py")
@@ -61,11 +61,16 @@ def test_native_merge_with_several_processes_on_one_gpu(po, world, tmp_path, sca
     res = run_world(world, names, tmp_path)
     for name in names:
         case = build_case(name)
+        if "queries" in case:                              # queries in: the oracle gets assign[] / tables from the same float loops
+            case["assign"], case["tables"] = search_inputs(case)
+            case["slots"] = (0, 1, 2)                      # sharded front (two in flight, the second reversed), then unsharded
         want = oracle_heaps(po, case)
         nq = case["assign"].shape[0]
         for r in range(world):
             d = res[r]
             for s in case["slots"]:
+                if "queries" in case:
+                    assert np.array_equal(d["%s.assign_slot%d" % (name, s)], case["assign"]), (name, r, s)
                 sizes, status = d["%s.sizes_slot%d" % (name, s)], d["%s.status_slot%d" % (name, s)]
                 keys, vals = d["%s.keys_slot%d" % (name, s)], d["%s.values_slot%d" % (name, s)]
                 for q in range(nq):
