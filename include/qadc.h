@@ -101,7 +101,8 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * small batch spreads one query over / codes each keeps at least), "wgq_inline" (a lone small query's input rides
  * in the kernel arguments), "wgq_poll" (... and its completion is read from the mapped result block),
  * "wgq_group" (large IVF batches: partition-major second phase; 0 never, 1 auto, 2 whenever possible),
- * "wgq_group_head" (probes per query the one-workgroup-per-query head walks before it),
+ * "wgq_group_head" (probes per query the one-workgroup-per-query head walks before it), "wgq_group_head_dist" (the same under the
+ * multi-GPU merge, counted in probes with codes on the rank),
  * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_async", "dist_shard_front", "dist_inject_failure" (test hook). */
 int qadc_set_option(qadc_index* idx, const char* name, double value);
 
@@ -385,6 +386,7 @@ typedef struct qadc_profile {
     uint64_t group_pass_codes8; /* codes read by 8-seat passes (LDS cycles = codes * M * 4 / 64) */
     uint64_t group_pass_codes4; /* ... by 4-seat passes (LDS cycles = codes * M * 2 / 64) */
     uint64_t group_batches;    /* batches the above figures cover */
+    uint64_t front_sharded_batches; /* multi-GPU: qadc_search batches whose front ran on 1/world of the queries per rank */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

@@ -242,13 +242,14 @@ struct DistSlot {
     PinBuf<unsigned char> h_out;                             // mapped: heaps u64[nq][R], sizes u32[nq], status u32[4]
     unsigned char* d_out = nullptr;
     unsigned char* h_out_mapped = nullptr;
-    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr, ev_gathered = nullptr;
     bool enqueued = false;
     void release() {
         d_block.release(); d_gathered.release(); d_merged.release(); d_moff.release(); d_mcnt.release(); h_out.release();
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_done) (void)hipEventDestroy(ev_done);
-        ev_ready = ev_done = nullptr;
+        if (ev_gathered) (void)hipEventDestroy(ev_gathered);
+        ev_ready = ev_done = ev_gathered = nullptr;
     }
 };
 
@@ -264,6 +265,8 @@ struct DistState {
     void* user_ctx = nullptr;
     hipStream_t stream = nullptr;                            // own high-priority stream: the merge of batch s must not queue
                                                              // behind the scan kernels of batches s+1.. on the main stream
+    hipStream_t merge_stream = nullptr;                      // interleave + replay of a merge enqueued with its batch: a millisecond of
+                                                             // latency that must not sit in front of the NEXT batch's collectives
     int rank = 0, world = 1;
     uint32_t cap_entries = 1u << 16;                         // entries per rank block; regrown (by every rank alike) on overflow
     DevBuf<uint64_t> d_block, d_gathered;
@@ -359,7 +362,7 @@ struct qadc_index {
     int group_strikes = 0; // grouped batches whose candidate regions overflowed (data whose later probes fall below the head's bound)
     int wgq_group = 1;     // partition-major second phase for large IVF batches: 0 never, 1 auto, 2 whenever possible
     int wgq_group_head = 4;   // ... after a head of this many probes per query (one workgroup per query)
-    int wgq_group_head_dist = 2;   // ... under the multi-GPU merge (probes with codes on this rank)
+    int wgq_group_head_dist = 4;   // ... under the multi-GPU merge (probes with codes on this rank; option "wgq_group_head_dist")
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
     int mq_narrow = 1;     // multi-query groups whose upper four seats are empty run the 4-seat form of the kernel
     int replay_wave = 0;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
@@ -1101,6 +1104,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         int32_t* d_assign_share = reinterpret_cast<int32_t*>(s.d_fblock.p + (size_t)s.front_per * tab);
         uint32_t* d_front_share = reinterpret_cast<uint32_t*>(s.d_fblock.p + (size_t)s.front_per * (tab + (size_t)ma * 4));
         if (!s.rerun) {                                          // (a re-run from inside collect reuses the gathered arrays)
+            idx->prof.front_sharded_batches++;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
             if (s.front_n) {
                 const size_t nt_share = (size_t)s.front_n * tab;
@@ -1166,8 +1170,9 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     // kernel then only walks the first probes of every query (head: front + a tight bound); the other pairs are
     // regrouped by partition on the device and scanned 8 queries per pass (see launch_ivf_plan), and a third kernel
     // orders every query's candidates into the stream layout the plain launch produces.
-    // (a shard's probes are fewer or shorter: a head of 2 local probes bounds as well and leaves more to the shared passes —
-    // one of 8 ranks, C3 shape: 1.75 -> 1.53 ms per batch, C5: 2.32 -> 2.17)
+    // (under the merge the head counts probes WITH CODES ON THIS RANK; its length is an option of its own: whole-partition
+    // placement is better off with 2 — one of 8 ranks, C5 shape: 1.53 vs 1.78 ms per batch — the range split with 4:
+    // 1.35 vs 1.52, and at 2048-query batches a head of 2 short pieces bounds too loosely and the batches fall back)
     const int head_slots = std::min(idx->dist ? idx->wgq_group_head_dist : idx->wgq_group_head, ma);
     const size_t pairs = (size_t)nq * (size_t)(ma - head_slots);
     const size_t nparts = idx->parts.size();
@@ -1275,10 +1280,16 @@ int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream) {
     HIPCHECK(launch_dist_pack_qflags(s.d_qflags.p, nq, s.d_stream.p, s.wgq_cap, d.cap_entries, ds.d_block.p, st));
     std::string gerr;
     if (d.gather(ds.d_block.p, ds.d_gathered.p, bw, st, gerr)) return fail(QADC_E_HIP, gerr);
+    // the collectives keep `st` to themselves (the next batch's front gather is issued right behind this one); the merge's
+    // compute — a millisecond of replay latency — goes to a stream of its own
+    if (!ds.ev_gathered) HIPCHECK(hipEventCreateWithFlags(&ds.ev_gathered, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(ds.ev_gathered, st));
+    hipStream_t ms = d.merge_stream ? d.merge_stream : st;
+    if (ms != st) HIPCHECK(hipStreamWaitEvent(ms, ds.ev_gathered, 0));
     uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ds.d_out + sizeof(uint64_t) * (size_t)R * nq);
     HIPCHECK(launch_dist_merge(ds.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, ds.d_moff.p, ds.d_mcnt.p, ds.d_mcnt.p + nq,
-                               ds.d_merged.p, reinterpret_cast<uint64_t*>(ds.d_out), d_sizes, st, d_sizes + nq));
-    HIPCHECK(hipEventRecord(ds.ev_done, st));
+                               ds.d_merged.p, reinterpret_cast<uint64_t*>(ds.d_out), d_sizes, ms, d_sizes + nq));
+    HIPCHECK(hipEventRecord(ds.ev_done, ms));
     ds.enqueued = true;
     return QADC_OK;
 }
@@ -2177,6 +2188,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);
     else if (n == "wgq_group") { idx->wgq_group = (int)std::max(0.0, std::min(value, 2.0)); idx->group_strikes = 0; }
     else if (n == "wgq_group_head") idx->wgq_group_head = idx->wgq_group_head_dist = (int)std::max(1.0, std::min(value, 4096.0));
+    else if (n == "wgq_group_head_dist") idx->wgq_group_head_dist = (int)std::max(1.0, std::min(value, 4096.0));
     else if (n == "wgq_poll") idx->wgq_poll = value != 0;
     else if (n == "wgq_split_codes") idx->wgq_split_codes = (uint32_t)std::max(value, 1024.0);
     else if (n == "front_dist") idx->front_dist = value != 0;
@@ -2784,8 +2796,10 @@ struct DistGuard {
     ~DistGuard() {
         if (!d) return;
         if (d->stream) { (void)hipStreamSynchronize(d->stream); }
+        if (d->merge_stream) { (void)hipStreamSynchronize(d->merge_stream); }
         if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
         if (d->stream) (void)hipStreamDestroy(d->stream);
+        if (d->merge_stream) (void)hipStreamDestroy(d->merge_stream);
     }
 };
 int dist_init_checks(qadc_index* idx, int rank, int world) {
@@ -2818,6 +2832,9 @@ int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
+    // (NORMAL priority on purpose: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
+    // queue as the collectives' stream the replay would still sit in front of the next batch's gather — seen in the trace)
+    HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream, hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
     // RCCL finishes setting up its channels lazily, inside the first collectives of a communicator (the very first
     // all-gather takes ~8 ms); a few throw-away gathers here keep that out of the first batches' collect calls.
     {
@@ -2870,6 +2887,9 @@ int qadc_dist_init_transport(qadc_index* idx, int rank, int world, qadc_allgathe
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
+    // (NORMAL priority on purpose: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
+    // queue as the collectives' stream the replay would still sit in front of the next batch's gather — seen in the trace)
+    HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream, hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
     idx->dist = g.d.release();
     return QADC_OK;
 }
@@ -2933,8 +2953,10 @@ int qadc_dist_shutdown(qadc_index* idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     DistState* d = idx->dist;
     if (d->stream) (void)hipStreamSynchronize(d->stream);
+    if (d->merge_stream) (void)hipStreamSynchronize(d->merge_stream);
     if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
     if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->merge_stream) (void)hipStreamDestroy(d->merge_stream);
     d->d_fix.release(); d->h_fix.release(); d->d_moff.release(); d->d_merged.release(); d->d_mcnt.release();
     for (auto& ds : d->slot) ds.release();
     d->d_block.release(); d->d_gathered.release(); d->d_src.release(); d->h_src.release(); d->d_extra.release();

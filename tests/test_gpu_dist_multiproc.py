@@ -91,6 +91,9 @@ def test_native_merge_with_several_processes_on_one_gpu(po, world, tmp_path, sca
             assert all(int(res[r]["unordered.host_sorted_queries"][0]) >= 1 for r in range(world))
         if name == "ivf_whole" and scan_path != "levels" and scan_path != "levels_head":
             assert all(int(res[r]["ivf_whole.group_launches"][0]) >= 1 for r in range(world))  # grouped second phase under the merge
+        if "queries" in case and scan_path == "wgq":
+            # slots 0 and 1 took the sharded front (every rank ran the front of 1/world of the queries), slot 2 did not
+            assert all(int(res[r]["%s.front_sharded_batches" % name][0]) == 2 for r in range(world))
         if name == "inject":
             # the failure of ONE rank reached every rank through the gathered headers
             assert all(int(res[r]["inject.inject_error"][0]) == 1 for r in range(world))
