@@ -244,6 +244,8 @@ struct DistSlot {
     unsigned char* h_out_mapped = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr, ev_gathered = nullptr;
     bool enqueued = false;
+    bool pending = false;                                    // scan enqueued, merge not yet: it is issued BEHIND the next batch's front
+    uint64_t seq = 0;                                        // gather (flush_merges), so that that gather never waits for this batch's scan
     void release() {
         d_block.release(); d_gathered.release(); d_merged.release(); d_moff.release(); d_mcnt.release(); h_out.release();
         if (ev_ready) (void)hipEventDestroy(ev_ready);
@@ -293,6 +295,7 @@ struct DistState {
     int device_nq = 256;                                     // batches of at least this many queries replay on the device
     int inject_failure = 0;                                  // test hook: the next qadc_dist_collect of this rank fails locally
     int async_merge = 1;                                     // enqueue the merge with the batch where possible (option "dist_async")
+    uint64_t next_seq = 1;
     int shard_front = 1;                                     // qadc_search batches: every rank runs the front of 1/world of the queries (option "dist_shard_front")
     DistSlot slot[kSlots];
     // One all-gather of `words` u64 per rank on `st`: RCCL (enqueued, stream-ordered) or the caller's transport
@@ -660,6 +663,7 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
 
 int launch_wgq_batch(qadc_index* idx, Slot& s);
 int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream);
+int flush_merges(qadc_index* idx, uint64_t upto);
 
 // Plans the batch in slot s and enqueues all of its GPU work (front, levels, ordering, optional device replay).
 int plan_and_launch(qadc_index* idx, Slot& s) {
@@ -1105,13 +1109,16 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         uint32_t* d_front_share = reinterpret_cast<uint32_t*>(s.d_fblock.p + (size_t)s.front_per * (tab + (size_t)ma * 4));
         if (!s.rerun) {                                          // (a re-run from inside collect reuses the gathered arrays)
             idx->prof.front_sharded_batches++;
-            HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
+            // The share's front runs on the FRONT stream, under the previous batch's scan (it depends on nothing that batch
+            // produces), and its gather is issued IN FRONT of that batch's merge gather (flush_merges below).
+            hipStream_t fs = alone ? st : idx->front_stream;
+            HIPCHECK(hipStreamWaitEvent(fs, s.ev_feed, 0));
             if (s.front_n) {
                 const size_t nt_share = (size_t)s.front_n * tab;
                 HIPCHECK(s.d_ftables.ensure(nt_share));
                 launch_build_tables(s.d_queries.p, idx->d_coarse.p, d_assign_share, idx->d_codebooks.p,
                                     idx->has_rotation ? idx->d_rotation.p : nullptr, s.front_n, ma, M, idx->dim, table_expansion(idx, ma),
-                                    s.d_ftables.p, st);
+                                    s.d_ftables.p, fs);
                 QueryKernelArgs F{};
                 F.parts = idx->d_partdesc.p;
                 F.assign = d_assign_share;
@@ -1127,12 +1134,12 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
                 F.G = 1;
                 F.front_only = 1;
                 F.front_out = d_front_share;
-                HIPCHECK(launch_scan_query(M, idx->wgq_variant, s.front_n, F, st));
+                HIPCHECK(launch_scan_query(M, idx->wgq_variant, s.front_n, F, fs));
             }
             // the collectives of the merge live on ONE stream, in the order the host issues them (the same on every rank)
             if (!s.ev_fa) HIPCHECK(hipEventCreateWithFlags(&s.ev_fa, hipEventDisableTiming));
             if (!s.ev_fb) HIPCHECK(hipEventCreateWithFlags(&s.ev_fb, hipEventDisableTiming));
-            HIPCHECK(hipEventRecord(s.ev_fa, st));
+            HIPCHECK(hipEventRecord(s.ev_fa, fs));
             HIPCHECK(hipStreamWaitEvent(d.stream, s.ev_fa, 0));
             std::string gerr;
             if (d.gather(s.d_fblock.p, s.d_fgathered.p, block / 8, d.stream, gerr)) return fail(QADC_E_HIP, gerr);
@@ -1141,6 +1148,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
                                          reinterpret_cast<uint32_t*>(s.d_fmap + (size_t)nq * ma * 4), d.stream));
             HIPCHECK(hipEventRecord(s.ev_fb, d.stream));
             HIPCHECK(hipStreamWaitEvent(st, s.ev_fb, 0));
+            if (int rc = flush_merges(idx, ~0ull)) return rc;   // the older batches' merges: behind this front gather
         }
         A.assign = s.d_assign.p;
         A.ftables = nullptr;                                     // from here on: an int8 batch
@@ -1246,20 +1254,22 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     return QADC_OK;
 }
 
-// The merge of a one-workgroup-per-query batch, enqueued right behind its scan: pack (from the kernels' own records in
-// device memory) -> all-gather -> interleave -> replay, all on the merge's stream; the heaps and a status word land in
-// pinned host memory.  Every rank enqueues the same collectives in the same order (the ranks submit the same batches).
+// The merge of a one-workgroup-per-query batch, enqueued behind its scan: pack (from the kernels' own records in
+// device memory) -> all-gather -> interleave -> replay; the collectives on the merge's stream, the compute on a stream
+// of its own; the heaps and a status word land in pinned host memory.  Every rank enqueues the same collectives in the
+// same order (the ranks submit and collect the same batches in the same order).
 // Not taken (the collect-time merge runs instead): few-query batches (host-share replay), R or ma x world beyond the device
 // merge, option dist_async = 0.
-int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream) {
+// Two steps.  enqueue_merge (at the end of the batch's launch) records where the scan ends and marks the merge PENDING;
+// flush_merges issues the pending merges in submission order.  A batch with a sharded front flushes the OLDER merges right
+// after issuing its own front gather: on the collectives' stream that gather then lies in front of the previous batch's
+// merge gather (which waits for that batch's scan), so a front that runs under the previous scan is not held up by it.
+int enqueue_merge_now(qadc_index* idx, Slot& s) {
     DistState& d = *idx->dist;
     const int slot_i = (int)(&s - idx->slot);
-    if (slot_i < 0 || slot_i >= kSlots) return QADC_OK;
     DistSlot& ds = d.slot[slot_i];
-    ds.enqueued = false;
+    ds.pending = false;
     const int nq = s.nq, R = s.R, world = d.world;
-    if (!d.async_merge || nq < d.device_nq || (uint32_t)R > replay_wave_max_R() || (size_t)s.ma * world > dist_interleave_max_cells())
-        return QADC_OK;
     const size_t bw = dist_block_words(nq, d.cap_entries, 0);
     HIPCHECK(ds.d_block.ensure(bw));
     HIPCHECK(ds.d_gathered.ensure(bw * world));
@@ -1272,9 +1282,7 @@ int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream) {
         HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ds.d_out), ds.h_out.p, 0));
         ds.h_out_mapped = ds.h_out.p;
     }
-    if (!ds.ev_ready) HIPCHECK(hipEventCreateWithFlags(&ds.ev_ready, hipEventDisableTiming));
     if (!ds.ev_done) HIPCHECK(hipEventCreateWithFlags(&ds.ev_done, hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(ds.ev_ready, scan_stream));
     hipStream_t st = d.stream;
     HIPCHECK(hipStreamWaitEvent(st, ds.ev_ready, 0));
     HIPCHECK(launch_dist_pack_qflags(s.d_qflags.p, nq, s.d_stream.p, s.wgq_cap, d.cap_entries, ds.d_block.p, st));
@@ -1291,6 +1299,37 @@ int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream) {
                                ds.d_merged.p, reinterpret_cast<uint64_t*>(ds.d_out), d_sizes, ms, d_sizes + nq));
     HIPCHECK(hipEventRecord(ds.ev_done, ms));
     ds.enqueued = true;
+    return QADC_OK;
+}
+
+// Issues the pending merges with seq <= upto, oldest first.
+int flush_merges(qadc_index* idx, uint64_t upto) {
+    if (!idx->dist) return QADC_OK;
+    DistState& d = *idx->dist;
+    for (;;) {
+        int best = -1;
+        for (int i = 0; i < kSlots; ++i)
+            if (d.slot[i].pending && d.slot[i].seq <= upto && (best < 0 || d.slot[i].seq < d.slot[best].seq)) best = i;
+        if (best < 0) return QADC_OK;
+        if (int rc = enqueue_merge_now(idx, idx->slot[best])) return rc;
+    }
+}
+
+int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream) {
+    DistState& d = *idx->dist;
+    const int slot_i = (int)(&s - idx->slot);
+    if (slot_i < 0 || slot_i >= kSlots) return QADC_OK;
+    DistSlot& ds = d.slot[slot_i];
+    ds.enqueued = false;
+    ds.pending = false;
+    const int nq = s.nq, R = s.R, world = d.world;
+    if (!d.async_merge || nq < d.device_nq || (uint32_t)R > replay_wave_max_R() || (size_t)s.ma * world > dist_interleave_max_cells())
+        return QADC_OK;
+    if (!ds.ev_ready) HIPCHECK(hipEventCreateWithFlags(&ds.ev_ready, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(ds.ev_ready, scan_stream));
+    ds.pending = true;
+    ds.seq = d.next_seq++;
+    if (!s.front_sharded) return flush_merges(idx, ds.seq);     // no front gather to let pass: issue it (and anything older) now
     return QADC_OK;
 }
 
@@ -1489,6 +1528,8 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool fr
     if (int rc = use_device(idx)) return rc;
     if (s.dist_batch && !from_dist) {
         need_stream = true;
+        if (idx->dist && idx->dist->slot[slot_i].pending)
+            if (int rc = flush_merges(idx, idx->dist->slot[slot_i].seq)) return rc;
         if (idx->dist && idx->dist->slot[slot_i].enqueued) {     // a merge was enqueued with the batch: let it finish (its result is unused)
             HIPCHECK(hipEventSynchronize(idx->dist->slot[slot_i].ev_done));
             idx->dist->slot[slot_i].enqueued = false;
@@ -2983,6 +3024,8 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
     // leave the other ranks blocked in the gather: the rank still contributes a block, with bit7 set in every header, and
     // all ranks return the error after the gather.
     DistSlot& ds = d.slot[slot];
+    if (ds.pending)
+        if (int rc = flush_merges(idx, ds.seq)) return rc;
     const bool was_enqueued = ds.enqueued;
     if (was_enqueued) {                                       // the merge ran behind the scan: wait for all of it
         HIPCHECK(hipEventSynchronize(ds.ev_done));

@@ -1824,6 +1824,133 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
     }
 }
 
+// The same selection for ma <= 256 without the ma dependent rounds: (1) the ma-th smallest key by a 4-pass MSD radix
+// select over the K distances (8 bits per pass, 256-bin histogram in LDS); (2) every key below it, and the needed number
+// of keys EQUAL to it with the smallest indices, collected into LDS; (3) one bitonic sort of those ma (key, index) pairs.
+// Result identical to the rounds above (ascending distance, lower index first on ties); K = 16384, ma = 64: 330 -> ~25 us
+// for a workgroup on its own, which is what a rank's share of a sharded front waits for.
+// More than 256 keys tied at the threshold (degenerate inputs) -> `slow` is set and the rounds run for that query.
+template <int KPT>
+__global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* __restrict__ dist, int K, int ma, int32_t* __restrict__ assign) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint64_t cand[256];
+    __shared__ uint32_t ties[256];
+    __shared__ uint32_t s_prefix, s_rank, s_nless, s_nties;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    uint32_t mine[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int k = j * 256 + tid;
+        mine[j] = k < K ? __float_as_uint(dist[(size_t)q * K + k]) : 0xffffffffu;
+    }
+    if (tid == 0) { s_prefix = 0; s_rank = (uint32_t)ma; s_nless = 0; s_nties = 0; }
+    for (int pass = 3; pass >= 0; --pass) {
+        hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix, sh = 8u * (uint32_t)pass;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t v = mine[j];
+            if (j * 256 + tid < K && (pass == 3 || (v >> (sh + 8u)) == prefix)) atomicAdd(&hist[(v >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {                                          // wave 0: 4 bins per lane, the digit that holds rank s_rank
+            const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const uint32_t sum4 = c0 + c1 + c2 + c3;
+            const uint32_t incl = dpp_wave_incl_sum(sum4), excl = incl - sum4;
+            const uint32_t r = s_rank;
+            if (incl >= r && excl < r) {                         // exactly one lane
+                uint32_t run = excl, digit = 4 * tid;
+                const uint32_t cs4[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if (run + cs4[jj] >= r) { digit = 4 * tid + jj; break; }
+                    run += cs4[jj];
+                }
+                s_prefix = (prefix << 8) | digit;
+                s_rank = r - run;                                // rank inside the chosen digit
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t T = s_prefix, need_ties = s_rank;            // need_ties keys equal to T complete the ma smallest
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const uint32_t v = mine[j], k = (uint32_t)(j * 256 + tid);
+        if (k >= (uint32_t)K) continue;
+        if (v < T) cand[atomicAdd(&s_nless, 1u)] = ((uint64_t)v << 32) | k;
+        else if (v == T) {
+            const uint32_t slot = atomicAdd(&s_nties, 1u);
+            if (slot < 256u) ties[slot] = k;
+        }
+    }
+    __syncthreads();
+    const uint32_t nless = s_nless, nties = s_nties;            // nless == ma - need_ties
+    if (nties > 256u) {                                          // degenerate: the rounds (same result), this workgroup only
+        uint32_t last_v = 0;
+        int last_k = -1;
+        __shared__ uint32_t rv[2][4], rk[2][4];
+        int par = 0;
+        for (int a = 0; a < ma; ++a, par ^= 1) {
+            uint32_t bv = 0xffffffffu, bk = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t k = (uint32_t)(j * 256 + tid), v = mine[j];
+                const bool after = v > last_v || (v == last_v && (int)k > last_k);
+                if (k < (uint32_t)K && after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
+            }
+            const uint32_t wv = dpp_wave_min_u32(bv);
+            const uint32_t wk = dpp_wave_min_u32(bv == wv ? bk : 0xffffffffu);
+            if ((tid & 63) == 0) { rv[par][tid >> 6] = wv; rk[par][tid >> 6] = wk; }
+            __syncthreads();
+            bv = rv[par][0];
+            bk = rk[par][0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+                if (rv[par][w] < bv || (rv[par][w] == bv && rk[par][w] < bk)) { bv = rv[par][w]; bk = rk[par][w]; }
+            last_v = bv;
+            last_k = (int)bk;
+            if (tid == 0) assign[(size_t)q * ma + a] = last_k;
+        }
+        return;
+    }
+    // ties: the need_ties smallest indices among them — sort the (<= 256) tie indices, append the first need_ties
+    uint64_t e = ~0ull;                                          // thread's element of the final sort: (key << 32 | index), padding = max
+    {
+        uint32_t t = (uint32_t)tid < nties ? ties[tid] : 0xffffffffu;
+        __syncthreads();
+        ties[tid] = t;
+        __syncthreads();
+        for (uint32_t size = 2; size <= 256; size <<= 1)
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                const uint32_t partner = (uint32_t)tid ^ stride;
+                if (partner > (uint32_t)tid) {
+                    const uint32_t a = ties[tid], b = ties[partner];
+                    const bool up = ((uint32_t)tid & size) == 0;
+                    if ((a > b) == up) { ties[tid] = b; ties[partner] = a; }
+                }
+                __syncthreads();
+            }
+        if ((uint32_t)tid < need_ties) cand[nless + tid] = ((uint64_t)T << 32) | ties[tid];
+        __syncthreads();
+    }
+    if (tid < ma) e = cand[tid];
+    __syncthreads();
+    cand[tid] = e;
+    __syncthreads();
+    for (uint32_t size = 2; size <= 256; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            const uint32_t partner = (uint32_t)tid ^ stride;
+            if (partner > (uint32_t)tid) {
+                const uint64_t a = cand[tid], b = cand[partner];
+                const bool up = ((uint32_t)tid & size) == 0;
+                if ((a > b) == up) { cand[tid] = b; cand[partner] = a; }
+            }
+            __syncthreads();
+        }
+    if (tid < ma) assign[(size_t)q * ma + tid] = (int32_t)(uint32_t)cand[tid];
+}
+
 void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
                           int32_t* d_assign, hipStream_t stream) {
     const int kpt = (K + 255) / 256;
@@ -1833,7 +1960,12 @@ void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq,
     // (any batch size: even one query — 15 of its group's 16 rows idle — is through sooner than with a row per lane)
     if (kpt <= 64 && ma <= K && dim % 4 == 0 && (reinterpret_cast<uintptr_t>(d_coarse) & 15) == 0 && d_dist) {
         hipLaunchKernelGGL(coarse_dist_kernel, dim3(kpt, (nq + kCDQ - 1) / kCDQ), dim3(256), 0, stream, d_queries, d_coarse, nq, K, dim, d_dist);
-        if (kpt <= 4) hipLaunchKernelGGL(coarse_select_kernel<4>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
+        if (ma <= 256 && ma >= 8) {                              // radix select + one sort (few probes: the rounds are as quick)
+            if (kpt <= 4) hipLaunchKernelGGL(coarse_select_radix_kernel<4>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
+            else if (kpt <= 16) hipLaunchKernelGGL(coarse_select_radix_kernel<16>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
+            else hipLaunchKernelGGL(coarse_select_radix_kernel<64>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
+        }
+        else if (kpt <= 4) hipLaunchKernelGGL(coarse_select_kernel<4>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
         else if (kpt <= 16) hipLaunchKernelGGL(coarse_select_kernel<16>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
         else hipLaunchKernelGGL(coarse_select_kernel<64>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
     } else if (nq >= 512) {

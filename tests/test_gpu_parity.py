@@ -1281,7 +1281,8 @@ def test_wgq_grouped_second_phase_matches_oracle(pyqadc, po, M, nq, ma, head, bi
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nq,K,dim,ma", [(300, 700, 16, 9), (257, 4100, 48, 33), (1030, 256, 128, 16)])
+@pytest.mark.parametrize("nq,K,dim,ma", [(300, 700, 16, 9), (257, 4100, 48, 33), (1030, 256, 128, 16), (70, 16384, 96, 64),
+                                         (33, 1500, 32, 200), (20, 900, 16, 8)])
 def test_coarse_assignment_of_large_batches_is_the_sequential_one(pyqadc, nq, K, dim, ma):
     """Batches of >= 256 queries compute the coarse distances as [16 queries] x [256 centroids] tiles and select per
     query in a second kernel; assign[] must be what the sequential host loop gives — squared L2 accumulated in
@@ -1297,6 +1298,13 @@ def test_coarse_assignment_of_large_batches_is_the_sequential_one(pyqadc, nq, K,
     coarse[K - 1] = coarse[K - 2]                               # exact ties, one of them in the last (partial) block
     queries = rng.normal(size=(nq, dim)).astype(np.float32)
     queries[7] = coarse[3]                                      # distance exactly 0, twice
+    if K >= 900:
+        # the selection's radix form (8 <= ma <= 256): many centroids tied exactly AT the ma-th distance of a query — more
+        # than the 256 it sorts in LDS (the degenerate path: rounds) for query 3, a handful for query 4
+        coarse[100:100 + 400] = coarse[99]
+        queries[3] = coarse[99] + np.float32(0.001)
+        coarse[600:600 + 5] = coarse[599]
+        queries[4] = coarse[599]
     idx.set_coarse(coarse)
     got = idx.search(queries, ma, 30)["assign"]
     for q in list(range(0, nq, 17)) + [7, nq - 1]:
