@@ -391,7 +391,7 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
         shard["init"](idx)
     for kv in filter(None, os.environ.get("QADC_BENCH_IVF_OPTS", "").split(",")):  # tuning experiments only
         idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
-    qs = [rng.normal(size=(NQB, dim)).astype(np.float32) for _ in range(4)]
+    qs = [rng.normal(size=(NQB, dim)).astype(np.float32) for _ in range(8)]
 
     def collect(slot, nq):
         """-> probed codes of the batch (whole database: every rank counts the same figure)."""
@@ -414,14 +414,19 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
         t0 = time.perf_counter()
         pend, nc = [], 0
         stamps = []
+        t_sub = t_col = 0.0
         for s in range(steps):
             stamps.append(time.perf_counter())
-            idx.search_submit(s % depth, batches[s % 4], MA, R)
+            idx.search_submit(s % depth, batches[s % len(batches)], MA, R)
+            t_sub += time.perf_counter() - stamps[-1]
             pend.append(s % depth)
             if len(pend) == depth:
+                tc = time.perf_counter()
                 nc += collect(pend.pop(0), nqb)
+                t_col += time.perf_counter() - tc
         if os.environ.get("QADC_BENCH_IVF_STEPLOG"):
             print("ivf steps (ms):", [round((b - a) * 1e3, 2) for a, b in zip(stamps, stamps[1:])], file=sys.stderr)
+            print("host ms per step: submit %.3f collect %.3f" % (t_sub * 1e3 / steps, t_col * 1e3 / steps), file=sys.stderr)
         while pend:
             nc += collect(pend.pop(0), nqb)
         if shard is not None and shard.get("barrier"):
@@ -431,7 +436,7 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
     steps, depth = 48, int(os.environ.get("QADC_BENCH_IVF_DEPTH", 4))          # all four submission slots of the C-ABI in use
     dt, ncodes = pipelined(qs, steps, depth)
     p = idx.profile()
-    qs2 = [rng.normal(size=(2 * NQB, dim)).astype(np.float32) for _ in range(4)]       # and at twice the batch size
+    qs2 = [rng.normal(size=(2 * NQB, dim)).astype(np.float32) for _ in range(8)]       # and at twice the batch size
     dt2, _ = pipelined(qs2, 24, depth)
     # a short pass with the library's HIP events on (they cost ~10 us of stream time each: not in the timed loops above):
     # the launches of the partition-major second phase against THEIR roofs

@@ -154,7 +154,7 @@ int qadc_scan_start(qadc_index* idx, int nq, int ma, const int32_t* assign, cons
 
 /* Asynchronous form of qadc_query_scan for throughput: submit enqueues all GPU work of a batch on the
  * index's streams and returns; collect waits for that batch, replays and fills the outputs.  slot is
- * 0..3 (up to four batches in flight: one being collected, one scanning, the others queued with their
+ * 0..7 (up to eight batches in flight: one being collected, one scanning, the others queued with their
  * pre-scan fronts running ahead); a slot must be collected before it is submitted again.  `tables` must stay valid until
  * collect (it is mutated then). */
 int qadc_query_scan_submit(qadc_index* idx, int slot, int nq, int ma, const int32_t* assign, float* tables, int R);

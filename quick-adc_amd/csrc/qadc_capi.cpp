@@ -105,7 +105,9 @@ struct Part {
     bool own = true;
 };
 
-constexpr int kSlots = 4;   // batches in flight: one being collected, one scanning, one or two queued behind it with their fronts running ahead
+constexpr int kSlots = 8;   // batches in flight: one being collected, one scanning, the others queued behind it with their fronts running
+                            // ahead.  Three or four cover every loop measured so far (deeper pipelines of the multi-GPU IVF loop — six,
+                            // eight batches — were tried and are no faster: its batches share the GPU, they do not wait for it)
 
 struct LevelLaunch {
     size_t first;   // first item
@@ -267,8 +269,9 @@ struct DistState {
     void* user_ctx = nullptr;
     hipStream_t stream = nullptr;                            // own high-priority stream: the merge of batch s must not queue
                                                              // behind the scan kernels of batches s+1.. on the main stream
-    hipStream_t merge_stream = nullptr;                      // interleave + replay of a merge enqueued with its batch: a millisecond of
-                                                             // latency that must not sit in front of the NEXT batch's collectives
+    hipStream_t merge_stream[kSlots] = {};                   // interleave + replay of a merge enqueued with its batch: a millisecond of
+                                                             // latency that must neither sit in front of the NEXT batch's collectives
+                                                             // nor behind the PREVIOUS batch's replay (one stream per slot)
     int rank = 0, world = 1;
     uint32_t cap_entries = 1u << 16;                         // entries per rank block; regrown (by every rank alike) on overflow
     DevBuf<uint64_t> d_block, d_gathered;
@@ -1292,7 +1295,7 @@ int enqueue_merge_now(qadc_index* idx, Slot& s) {
     // compute — a millisecond of replay latency — goes to a stream of its own
     if (!ds.ev_gathered) HIPCHECK(hipEventCreateWithFlags(&ds.ev_gathered, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(ds.ev_gathered, st));
-    hipStream_t ms = d.merge_stream ? d.merge_stream : st;
+    hipStream_t ms = d.merge_stream[slot_i] ? d.merge_stream[slot_i] : st;
     if (ms != st) HIPCHECK(hipStreamWaitEvent(ms, ds.ev_gathered, 0));
     uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ds.d_out + sizeof(uint64_t) * (size_t)R * nq);
     HIPCHECK(launch_dist_merge(ds.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, ds.d_moff.p, ds.d_mcnt.p, ds.d_mcnt.p + nq,
@@ -1337,7 +1340,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
                   const int8_t* qtables, int R, int mode = 0, int slice = 0, int nslices = 1,
                   const float* inj_vals = nullptr, int inj_n = 0) {
     if (!idx) return fail(QADC_E_ARG, "null index");
-    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1, 2 or 3");
+    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0 .. 7");
     if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
     if (nq <= 0 || ma <= 0 || R <= 0 || !assign) return fail(QADC_E_ARG, "nq, ma, R must be > 0 and assign non-null");
     if (nq >= (1 << 24)) return fail(QADC_E_ARG, "nq must be < 2^24");
@@ -1407,7 +1410,7 @@ bool will_group(const qadc_index* idx, int nq, int ma, bool dev_replay) {
 // on the GPU by the main stream.
 int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int ma, int R) {
     if (!idx || !queries) return fail(QADC_E_ARG, "null argument");
-    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1, 2 or 3");
+    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0 .. 7");
     if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
     if (idx->dim == 0) return fail(QADC_E_STATE, "qadc_index_set_pq has not been called");
     if (nq <= 0 || ma <= 0 || R <= 0) return fail(QADC_E_ARG, "nq, ma, R must be > 0");
@@ -1522,7 +1525,7 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
 // one-workgroup-per-query path, no host copy of its streams: they are fetched and replayed on the host.
 int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool from_dist = false) {
     if (!idx) return fail(QADC_E_ARG, "null index");
-    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1, 2 or 3");
+    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0 .. 7");
     Slot& s = idx->slot[slot_i];
     if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
     if (int rc = use_device(idx)) return rc;
@@ -1958,7 +1961,10 @@ int qadc_index_destroy(qadc_index* idx) {
     idx->d_rotation.release();
     idx->d_coarse.release();
     idx->d_partdesc.release();
-    Slot* all_slots[kSlots + 2] = {&idx->slot[0], &idx->slot[1], &idx->slot[2], &idx->slot[3], &idx->pre_slot[0], &idx->pre_slot[1]};
+    Slot* all_slots[kSlots + 2];
+    for (int i = 0; i < kSlots; ++i) all_slots[i] = &idx->slot[i];
+    all_slots[kSlots] = &idx->pre_slot[0];
+    all_slots[kSlots + 1] = &idx->pre_slot[1];
     for (Slot* sp : all_slots) {
         Slot& s = *sp;
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
@@ -2837,10 +2843,10 @@ struct DistGuard {
     ~DistGuard() {
         if (!d) return;
         if (d->stream) { (void)hipStreamSynchronize(d->stream); }
-        if (d->merge_stream) { (void)hipStreamSynchronize(d->merge_stream); }
+        for (hipStream_t m : d->merge_stream) if (m) { (void)hipStreamSynchronize(m); }
         if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
         if (d->stream) (void)hipStreamDestroy(d->stream);
-        if (d->merge_stream) (void)hipStreamDestroy(d->merge_stream);
+        for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamDestroy(m);
     }
 };
 int dist_init_checks(qadc_index* idx, int rank, int world) {
@@ -2875,7 +2881,8 @@ int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
     HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
     // (NORMAL priority on purpose: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
     // queue as the collectives' stream the replay would still sit in front of the next batch's gather — seen in the trace)
-    HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream, hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
+    for (int i = 0; i < kSlots; ++i)
+        HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream[i], hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
     // RCCL finishes setting up its channels lazily, inside the first collectives of a communicator (the very first
     // all-gather takes ~8 ms); a few throw-away gathers here keep that out of the first batches' collect calls.
     {
@@ -2930,7 +2937,8 @@ int qadc_dist_init_transport(qadc_index* idx, int rank, int world, qadc_allgathe
     HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
     // (NORMAL priority on purpose: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
     // queue as the collectives' stream the replay would still sit in front of the next batch's gather — seen in the trace)
-    HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream, hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
+    for (int i = 0; i < kSlots; ++i)
+        HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream[i], hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
     idx->dist = g.d.release();
     return QADC_OK;
 }
@@ -2994,10 +3002,10 @@ int qadc_dist_shutdown(qadc_index* idx) {
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     DistState* d = idx->dist;
     if (d->stream) (void)hipStreamSynchronize(d->stream);
-    if (d->merge_stream) (void)hipStreamSynchronize(d->merge_stream);
+    for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamSynchronize(m);
     if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
     if (d->stream) (void)hipStreamDestroy(d->stream);
-    if (d->merge_stream) (void)hipStreamDestroy(d->merge_stream);
+    for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamDestroy(m);
     d->d_fix.release(); d->h_fix.release(); d->d_moff.release(); d->d_merged.release(); d->d_mcnt.release();
     for (auto& ds : d->slot) ds.release();
     d->d_block.release(); d->d_gathered.release(); d->d_src.release(); d->h_src.release(); d->d_extra.release();
@@ -3011,7 +3019,7 @@ int qadc_dist_shutdown(qadc_index* idx) {
 int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
                       const float* extra, int extra_n, float* extra_out) {
     if (!idx || !idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
-    if (slot < 0 || slot >= kSlots) return fail(QADC_E_ARG, "slot must be 0, 1, 2 or 3");
+    if (slot < 0 || slot >= kSlots) return fail(QADC_E_ARG, "slot must be 0 .. 7");
     if (extra_n < 0 || (extra_n && (!extra || !extra_out))) return fail(QADC_E_ARG, "extra payload buffers missing");
     DistState& d = *idx->dist;
     Slot& s = idx->slot[slot];
