@@ -1,6 +1,6 @@
 """The native multi-GPU merge (qadc_dist_collect) with world > 1 — on ONE GPU.
 
-2, 4 and 8 PROCESSES (fresh children, one rank each, all on GPU 0) hold the shards of one database and run the unmodified
+2, 3, 4 and 8 PROCESSES (fresh children, one rank each, all on GPU 0) hold the shards of one database and run the unmodified
 qadc_dist_collect: pack kernel -> all-gather -> replay in global scan order (assign slot, rank, position).  The transport
 is the library's shared-memory all-gather (qadc_dist_init_transport + qadc_shm_transport_*) instead of RCCL, which needs one
 GPU per rank; everything around it — header protocol, identical regrow on every rank, host-share replay + second gather,
@@ -55,7 +55,7 @@ def oracle_heaps(po, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_native_merge_with_several_processes_on_one_gpu(po, world, tmp_path, scan_path):
     names = CASES
     res = run_world(world, names, tmp_path)
