@@ -65,12 +65,12 @@ def build_case(name):
         t[0] = 1.0
         c["tables"] = t
         c["index_options"] = {"wgq": 0, "head_level": 0, "level_base": 1 << 22}
-    elif name in ("ivf_search", "ivf_search_whole"):
+    elif name in ("ivf_search", "ivf_search_whole", "ivf_search_regrow", "ivf_search_fallback", "ivf_search_fewstarts"):
         # QUERIES in (qadc_search_submit): under the merge the front of the batch — coarse assignment, residual tables,
         # pre-scan, quantizer — is itself sharded over the ranks and all-gathered before the sharded scan.  nq not a multiple
         # of the world sizes (ragged last share), an exact tie between two coarse centroids, one query far from everything.
-        M = 16 if name == "ivf_search" else 32
-        rng = np.random.default_rng(506 + M)
+        M = 32 if name == "ivf_search_whole" else 16
+        rng = np.random.default_rng(506 + M + len(name))
         K, dim, nq, ma = 40, 32, 277, 5
         sizes = [int(x) for x in rng.integers(300, 6000, K)]
         sizes[9] = 0
@@ -87,6 +87,12 @@ def build_case(name):
         c["index_options"] = {"wgq_group": 2, "wgq_group_head": 2}
         if name == "ivf_search_whole":
             c["placement"] = "whole"
+        if name == "ivf_search_regrow":                    # stream regions far too small: the batch is re-run inside collect with the
+            c["index_options"]["wgq_capacity"] = 16        # gathered tables (no second front gather), every rank redoes the merge
+        if name == "ivf_search_fallback":                  # more candidates than the in-workgroup sort is allowed: the batch falls back to
+            c["index_options"]["wgq_cand_cap"] = 48        # the level path, which takes the gathered int8 tables as they lie on the device
+        if name == "ivf_search_fewstarts":                 # fewer than R - 1 starts per query: qmax too high (status 1) — the verdict of the
+            c["keep"] = 0.0004                             # rank that ran the query's front reaches every rank with the gather
     elif name == "inject":
         # the LAST rank's batch fails before the gather: every rank must return an error (no rank left in the
         # collective), and the next batch must go through
@@ -98,7 +104,8 @@ def build_case(name):
     return c
 
 
-CASES = ["flat32", "ivf_lanes", "ivf_whole", "ivf_search", "ivf_search_whole", "big_r", "unordered", "inject"]
+CASES = ["flat32", "ivf_lanes", "ivf_whole", "ivf_search", "ivf_search_whole", "ivf_search_regrow", "ivf_search_fallback",
+         "ivf_search_fewstarts", "big_r", "unordered", "inject"]
 
 
 def search_inputs(case):

@@ -85,6 +85,8 @@ def run_case(name, rank, world, transport):
         out["assign_slot2"] = idx.slot_assign(2, case["queries"].shape[0], case["search_ma"])
         out["group_launches"] = np.array([idx.profile()["group_launches"]])
         out["front_sharded_batches"] = np.array([idx.profile()["front_sharded_batches"]])
+        out["regrows"] = np.array([idx.profile()["regrows"]])
+        out["group_fallbacks"] = np.array([idx.profile()["group_fallbacks"]])
         idx.close()
         return out
     for s in case["slots"]:                                # (two batches in flight where the case says so)

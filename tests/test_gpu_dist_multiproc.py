@@ -91,9 +91,15 @@ def test_native_merge_with_several_processes_on_one_gpu(po, world, tmp_path, sca
             assert all(int(res[r]["unordered.host_sorted_queries"][0]) >= 1 for r in range(world))
         if name == "ivf_whole" and scan_path != "levels" and scan_path != "levels_head":
             assert all(int(res[r]["ivf_whole.group_launches"][0]) >= 1 for r in range(world))  # grouped second phase under the merge
+        if name == "ivf_search_fewstarts":
+            assert all(w["rc"] == 1 for w in want)             # (what the case is for)
         if "queries" in case and scan_path == "wgq":
             # slots 0 and 1 took the sharded front (every rank ran the front of 1/world of the queries), slot 2 did not
             assert all(int(res[r]["%s.front_sharded_batches" % name][0]) == 2 for r in range(world))
+        if name == "ivf_search_regrow" and scan_path == "wgq":
+            assert all(int(res[r]["%s.regrows" % name][0]) >= 1 for r in range(world))        # re-run inside collect, merge redone
+        if name == "ivf_search_fallback" and scan_path == "wgq":
+            assert all(int(res[r]["%s.group_fallbacks" % name][0]) >= 1 for r in range(world))   # level path on the gathered tables
         if name == "inject":
             # the failure of ONE rank reached every rank through the gathered headers
             assert all(int(res[r]["inject.inject_error"][0]) == 1 for r in range(world))
