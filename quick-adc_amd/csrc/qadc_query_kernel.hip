@@ -1313,9 +1313,11 @@ __global__ __launch_bounds__(64) void replay_heap_lanes_kernel(const uint32_t* _
 // superset of the pushes the sequential scan's heap accepts from that range, so replaying the streams in GLOBAL scan
 // order (assign slot, rank, position) reproduces the reference heap array for array.  Two kernels around ONE
 // ncclAllGather (host side: qadc_dist_collect):
-//   dist_pack_kernel       this rank's streams -> one contiguous block  [nq x {offset, count, flags, -}][entries][extra]
-//   dist_merge_lanes_kernel  the world's blocks -> heaps, one lane per query (every rank computes every heap:
-//                            there is no second collective)
+//   dist_pack_kernel        this rank's streams -> one contiguous block  [nq x {offset, count, flags, -}][entries][extra]
+//   dist_totals_kernel      per-query totals over the gathered blocks, flags, 64-bit prefix, a status word for the host
+//   dist_interleave_kernel  the world's streams of a query -> ONE stream in global scan order
+//   replay_heap_wave_kernel that stream -> the heap, one wave per query (every rank computes every heap: there is no
+//                           second collective)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dist_pack_kernel(const uint32_t* __restrict__ src_off, const uint32_t* __restrict__ src_cnt,
                                                         const uint32_t* __restrict__ src_flags, int nq,
