@@ -3,6 +3,7 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "quick-adc_amd"))
 import bench
+if os.environ.get('QADC_PROBE_R'): bench.R = int(os.environ['QADC_PROBE_R'])   # probe: how much of the step is replay latency
 from ivf_shard_sizes import SHAPES, WORLD
 name, placement = sys.argv[1], sys.argv[2]
 r = int(sys.argv[3]) if len(sys.argv) > 3 else 0
