@@ -371,9 +371,10 @@ struct qadc_index {
     int wgq_group_head_dist = 4;   // ... under the multi-GPU merge (probes with codes on this rank; option "wgq_group_head_dist")
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
     int mq_narrow = 1;     // multi-query groups whose upper four seats are empty run the 4-seat form of the kernel
-    int replay_wave = 0;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
-                           // (C3 shape, 1024-query batches: lanes 0.80-0.84 us per query, waves 0.93 — a thousand waves hold
-                           // slots the scan workgroups want; C5 shape: 5.18 vs 5.01.  The multi-GPU merge replays by waves.)
+    int replay_wave = 1;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
+                           // (C3 shape, 1024-query batches: lanes 0.78 us per query, waves 0.75; C5 shape: 4.83 vs 4.67 — since
+                           // the wave heap sifts all levels at once; with its element-by-element sift the waves lost,
+                           // 0.93 vs 0.80.  The multi-GPU merge replays by waves.)
     int head_early = 1;    // the head launch joins the front stream (under the previous batch's long levels)
     int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
@@ -1202,6 +1203,9 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         HIPCHECK(hipMemsetAsync(s.d_state.p, 0, state_bytes, st));
         HIPCHECK(hipMemsetAsync(s.d_gplan.p, 0, sizeof(uint32_t) * (3 * nparts + 1), st));
         HIPCHECK(hipMemsetAsync(s.d_gitems.p, 0, sizeof(ScanItem) * ngroups * 8, st));
+        // (tried: the plan — two clears + count / offsets / scatter, needed by the second phase only — on a stream of its own
+        // under the head launch: its workgroups then wait for head workgroups to retire and the second phase for them;
+        // C3 0.75 -> 1.05 us per query, one of 8 ranks 0.72 -> 1.51 ms per batch)
         launch_ivf_plan(A.assign, idx->d_partdesc.p, nq, ma, head_slots, (int)nparts, s.d_gplan.p, s.d_gplan.p + 2 * nparts,
                         s.d_gplan.p + nparts, s.d_gitems.p, st);
         QueryKernelArgs H = A;
@@ -1922,6 +1926,7 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
         if (const char* e = std::getenv("QADC_WGQ_POLL")) idx->wgq_poll = std::atoi(e);     // the lone-small-batch shortcuts
         if (const char* e = std::getenv("QADC_WGQ_INLINE")) idx->wgq_inline = std::atoi(e);
         if (const char* e = std::getenv("QADC_WGQ_GROUP")) idx->wgq_group = std::max(0, std::min(std::atoi(e), 2));
+        if (const char* e = std::getenv("QADC_REPLAY_WAVE")) idx->replay_wave = std::atoi(e) != 0;
         if (const char* e = std::getenv("QADC_HEAD_LEVEL")) idx->head_level = std::max(0, std::min(std::atoi(e), kMaxLevels - 1));
     }
     // The streaming launches fill every CU for milliseconds.  They go on the LOWEST-priority queue so that the

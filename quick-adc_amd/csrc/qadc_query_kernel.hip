@@ -1380,66 +1380,125 @@ __global__ __launch_bounds__(256) void dist_pack_kernel(const uint32_t* __restri
 // ---------------------------------------------------------------------------------------------
 template <int NREG>
 struct WaveHeap {
-    uint32_t hv[NREG], hk[NREG];                                 // element (j*64 + lane): value, key
+    // Heap element e lives at POSITION e + 1 (1-based: children of p are 2p and 2p + 1, siblings share an even/odd lane
+    // pair of one register); position p = lane p & 63 of register p >> 6.  Positions past `size` (and position 0) hold
+    // value 0: "a child that is not there" and "a child <= the value" then stop the sift the same way.
+    uint32_t hv[NREG], hk[NREG];
     uint32_t lane;
     uint32_t R, size;                                            // wave-uniform
+    static constexpr uint32_t kPos = (uint32_t)NREG * 64u;
 
-    // (branch-free on purpose: every uniform branch costs the scalar pipeline more than the readlane it would skip)
-    __device__ __forceinline__ uint32_t val_at(uint32_t e) const {
-        uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)hv[0], (int)(e & 63u));
+    __device__ __forceinline__ uint32_t val_at(uint32_t p) const {
+        uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)hv[0], (int)(p & 63u));
 #pragma unroll
         for (int j = 1; j < NREG; ++j) {
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)hv[j], (int)(e & 63u));
-            r = (e >> 6) == (uint32_t)j ? t : r;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)hv[j], (int)(p & 63u));
+            r = (p >> 6) == (uint32_t)j ? t : r;
         }
         return r;
     }
-    __device__ __forceinline__ uint32_t key_at(uint32_t e) const {
-        uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)hk[0], (int)(e & 63u));
+    __device__ __forceinline__ uint32_t key_at(uint32_t p) const {
+        uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)hk[0], (int)(p & 63u));
 #pragma unroll
         for (int j = 1; j < NREG; ++j) {
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)hk[j], (int)(e & 63u));
-            r = (e >> 6) == (uint32_t)j ? t : r;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)hk[j], (int)(p & 63u));
+            r = (p >> 6) == (uint32_t)j ? t : r;
         }
         return r;
     }
-    __device__ __forceinline__ void set(uint32_t e, uint32_t value, uint32_t key) {
+    __device__ __forceinline__ void set(uint32_t p, uint32_t value, uint32_t key) {
 #pragma unroll
         for (int j = 0; j < NREG; ++j) {                         // one compare + two selects per register pair
-            const bool own = (lane + 64u * (uint32_t)j) == e;
+            const bool own = (lane + 64u * (uint32_t)j) == p;
             hv[j] = own ? value : hv[j];
             hk[j] = own ? key : hk[j];
         }
     }
-    // all arguments wave-uniform
-    __device__ __forceinline__ void push(uint32_t key, uint32_t value) {
-        if (size != R) {                                         // room: append, bubble up past strictly smaller parents
-            uint32_t i = size++;
-            while (i != 0) {
-                const uint32_t parent = (i - 1) >> 1;
-                const uint32_t pv = val_at(parent);
-                if (!(value > pv)) break;
-                set(i, pv, key_at(parent));
-                i = parent;
-            }
-            set(i, value, key);
-            return;
+    __device__ __forceinline__ uint32_t root() const { return (uint32_t)__builtin_amdgcn_readlane((int)hv[0], 1); }
+
+    // all arguments wave-uniform.  Room left: append, bubble up past strictly smaller parents (R pushes per query: the
+    // element-by-element form is good enough).
+    __device__ __forceinline__ void append(uint32_t key, uint32_t value) {
+        uint32_t p = ++size;
+        while (p != 1) {
+            const uint32_t parent = p >> 1;
+            const uint32_t pv = val_at(parent);
+            if (!(value > pv)) break;
+            set(p, pv, key_at(parent));
+            p = parent;
         }
-        if (!(value < val_at(0))) return;                        // full: only strictly below the root
-        uint32_t i = 0;
-        for (;;) {
-            const uint32_t l = 2 * i + 1;
-            if (l >= size) break;
-            uint32_t cv = val_at(l), c = l;
-            if (l + 1 < size) {
-                const uint32_t rv = val_at(l + 1);
-                if (rv > cv) { cv = rv; c = l + 1; }             // the right child only if strictly greater
-            }
-            if (cv <= value) break;                              // stop at a child <= the value
-            set(i, cv, key_at(c));
-            i = c;
+        set(p, value, key);
+    }
+    // Full heap, value strictly below the root: the root goes, the value sinks (binheap.hpp:75-116 — the right child only
+    // if strictly greater, stop at a child <= the value).  Element by element this is a dependent chain of ~25
+    // readlane / scalar / select instructions per LEVEL (~2000 cycles per push at R = 100).  Here the 64 lanes decide
+    // all levels at once: every position works out whether it is the child its parent would descend to AND above the
+    // value (one DPP sibling exchange, two compares), one ballot per register turns that into bit masks, the path from
+    // the root is then ~8 scalar instructions per level on those masks, and every position on the path takes over its
+    // chosen child's element through ONE bpermute per register (issued before the walk: its latency passes under it).
+    __device__ __forceinline__ void sift(uint32_t key, uint32_t value) {
+        uint64_t T[NREG];
+        uint32_t tv[NREG], tk[NREG];
+        const uint32_t even = (lane & 1u) ^ 1u;
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) {
+            const uint32_t sv = (uint32_t)__builtin_amdgcn_mov_dpp((int)hv[j], 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]: the sibling
+            const uint32_t sk = (uint32_t)__builtin_amdgcn_mov_dpp((int)hk[j], 0xB1, 0xf, 0xf, false);
+            // the parent descends to the right child only if strictly greater: left (even lane) wins with >=, right with >
+            const bool take = hv[j] + even > sv && hv[j] > value;
+            T[j] = __builtin_amdgcn_ballot_w64(take);
+            tv[j] = take ? hv[j] : sv;                           // both lanes of a pair: the element the parent would take
+            tk[j] = take ? hk[j] : sk;
         }
-        set(i, value, key);
+        // position p of register j (2j < NREG) pulls from the pair (2p, 2p + 1): register 2j for lanes < 32, 2j + 1 above;
+        // the even lanes of the operand carry register 2j's pairs, the odd lanes register 2j + 1's (xor-and select: a
+        // select between two array elements is turned into a dynamically indexed load, and the arrays into LDS)
+        uint32_t gv[(NREG + 1) / 2], gk[(NREG + 1) / 2];
+        const int src = (int)(lane < 32u ? 8u * lane : 8u * (lane - 32u) + 4u);   // byte address of the source lane
+        const uint32_t oddmask = 0u - (lane & 1u);
+#pragma unroll
+        for (int j = 0; 2 * j < NREG; ++j) {
+            uint32_t zv = tv[2 * j], zk = tk[2 * j];
+            if (2 * j + 1 < NREG) {
+                zv ^= (zv ^ tv[2 * j + 1 < NREG ? 2 * j + 1 : 0]) & oddmask;
+                zk ^= (zk ^ tk[2 * j + 1 < NREG ? 2 * j + 1 : 0]) & oddmask;
+            }
+            gv[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)zv);
+            gk[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)zk);
+        }
+        // the walk: q at depth k has its children in registers (2 << k) >> 6 .. ((4 << k) - 1) >> 6 — static per level
+        uint32_t q = 1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if ((2u << k) >= kPos) break;                        // (compile time)
+            const uint32_t l = 2u * q;
+            if (((4u << k) > kPos) && l >= kPos) break;          // (only the last level can run past the registers)
+            const int clo = (int)((2u << k) >> 6), chi = (int)(min(kPos - 1u, (4u << k) - 1u) >> 6);
+            uint64_t t = T[clo];
+#pragma unroll
+            for (int j = clo + 1; j <= chi; ++j) t = (l >> 6) == (uint32_t)j ? T[j] : t;
+            const uint32_t pair = (uint32_t)(t >> (l & 63u)) & 3u;
+            if (pair == 0) break;
+            q = l + (pair >> 1);
+        }
+        // the path is q's ancestors: p is one (or q itself) iff q >> (depth(q) - depth(p)) == p — deeper p are > q and can
+        // not match whatever the shift; position 0 is kept out by its stand-in value
+        const uint32_t clzq = (uint32_t)__builtin_clz(q);
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) {
+            const uint32_t p = (j == 0 && lane == 0) ? 0xffffffffu : lane + 64u * (uint32_t)j;
+            const bool own = p == q;
+            if (2 * j < NREG) {
+                const bool onpath = (q >> (((uint32_t)__builtin_clz(p) - clzq) & 31u)) == p;
+                const uint32_t nv = own ? value : gv[j < (NREG + 1) / 2 ? j : 0];
+                const uint32_t nk = own ? key : gk[j < (NREG + 1) / 2 ? j : 0];
+                hv[j] = onpath ? nv : hv[j];
+                hk[j] = onpath ? nk : hk[j];
+            } else {
+                hv[j] = own ? value : hv[j];
+                hk[j] = own ? key : hk[j];
+            }
+        }
     }
 };
 
@@ -1451,7 +1510,7 @@ struct WaveHeap {
 // kReplayWaves queries per workgroup: the waves live for about a millisecond (a query's pushes are a dependent scalar
 // chain) and hold wave slots the scan kernels' 1024-thread workgroups need — packed 16 to a workgroup they tie up a
 // quarter of the CUs they would tie up four to a workgroup.
-constexpr int kReplayWaves = 16;
+constexpr int kReplayWaves = 16;                                 // (4 and 8 measured the same within noise)
 template <int NREG, bool QF>
 __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(const uint64_t* __restrict__ stream, const uint64_t* __restrict__ off,
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ info,
@@ -1488,7 +1547,7 @@ __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(con
     h.lane = lane;
     h.R = R;
     h.size = 0;
-    h.push(0u, 127u);                                            // the sentinel
+    h.append(0u, 127u);                                          // the sentinel
     uint64_t nxt = lane < n ? src[lane] : 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint64_t cur = nxt;
@@ -1497,24 +1556,24 @@ __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(con
         const uint32_t key = (uint32_t)cur, val = (uint32_t)(cur >> 32) & 0xffu;
         uint32_t j0 = 0;
         while (h.size != R && j0 < m) {                          // the heap is still filling: every entry goes in
-            h.push((uint32_t)__builtin_amdgcn_readlane((int)key, (int)j0), (uint32_t)__builtin_amdgcn_readlane((int)val, (int)j0));
+            h.append((uint32_t)__builtin_amdgcn_readlane((int)key, (int)j0), (uint32_t)__builtin_amdgcn_readlane((int)val, (int)j0));
             ++j0;
         }
         if (j0 >= m) continue;
-        uint32_t root = h.val_at(0);
+        uint32_t root = h.root();
         uint64_t mask = __builtin_amdgcn_ballot_w64(lane >= j0 && lane < m && val < root);
         while (mask) {
             const uint32_t j = (uint32_t)__builtin_ctzll(mask);
             mask &= mask - 1;
-            h.push((uint32_t)__builtin_amdgcn_readlane((int)key, (int)j), (uint32_t)__builtin_amdgcn_readlane((int)val, (int)j));
-            root = h.val_at(0);
+            h.sift((uint32_t)__builtin_amdgcn_readlane((int)key, (int)j), (uint32_t)__builtin_amdgcn_readlane((int)val, (int)j));
+            root = h.root();
             mask &= __builtin_amdgcn_ballot_w64(val < root);     // the root dropped: later entries may no longer qualify
         }
     }
 #pragma unroll
     for (int j = 0; j < NREG; ++j) {
-        const uint32_t e = (uint32_t)j * 64u + lane;
-        if (e < h.size) heaps[(size_t)q * R + e] = (uint64_t)h.hk[j] | ((uint64_t)h.hv[j] << 32);
+        const uint32_t p = (uint32_t)j * 64u + lane;             // element p - 1
+        if (p >= 1 && p <= h.size) heaps[(size_t)q * R + (p - 1)] = (uint64_t)h.hk[j] | ((uint64_t)h.hv[j] << 32);
     }
     if (lane == 0) heap_sizes[q] = h.size;
 }
@@ -1794,7 +1853,7 @@ hipError_t launch_front_unpack(const unsigned char* d_gathered, size_t block_byt
     return hipGetLastError();
 }
 
-uint32_t replay_wave_max_R() { return 320; }                     // five register pairs of 64 heap elements
+uint32_t replay_wave_max_R() { return 320; }                     // positions 1 .. R in up to six register pairs of 64
 size_t dist_interleave_max_cells() { return 8192; }              // ma x world counters, twice, in 64 KiB of LDS
 
 // One wave per query over stream[off[q] .. +cnt[q]); R <= replay_wave_max_R().
@@ -1803,12 +1862,13 @@ static hipError_t launch_replay_wave_t(const uint64_t* d_stream, const uint64_t*
                                        uint32_t cap, int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
     if (R == 0 || R > replay_wave_max_R()) return hipErrorInvalidValue;
     const dim3 grid((nq + kReplayWaves - 1) / kReplayWaves), block(kReplayWaves * 64);
-    switch ((R + 63) / 64) {
+    switch ((R + 64) / 64) {                                     // positions 1 .. R
         case 1: hipLaunchKernelGGL((replay_heap_wave_kernel<1, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
         case 2: hipLaunchKernelGGL((replay_heap_wave_kernel<2, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
         case 3: hipLaunchKernelGGL((replay_heap_wave_kernel<3, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
         case 4: hipLaunchKernelGGL((replay_heap_wave_kernel<4, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
-        default: hipLaunchKernelGGL((replay_heap_wave_kernel<5, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
+        case 5: hipLaunchKernelGGL((replay_heap_wave_kernel<5, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
+        default: hipLaunchKernelGGL((replay_heap_wave_kernel<6, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
     }
     return hipGetLastError();
 }

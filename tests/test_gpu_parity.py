@@ -1061,6 +1061,44 @@ def test_dist_merge_kernel_on_virtual_ranks(pyqadc, po, M, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R", [1, 2, 3, 31, 62, 63, 64, 65, 100, 126, 127, 128, 129, 190, 191, 192, 254, 255, 256, 300, 318, 319, 320])
+def test_wave_replay_kernel_against_the_heap_oracle(pyqadc, po, R):
+    """replay_heap_wave_kernel alone (through qadc_dist_merge_blocks with a world of one rank): arbitrary push streams —
+    empty, shorter than R, exactly R, long; constant, ascending, descending, two-valued and uniform values (ties at
+    every level of the heap) — end in the array kv_binheap::push leaves (binheap.hpp:75-116), for every register count
+    of the wave heap and the R values either side of each 64-position boundary."""
+    rng = np.random.default_rng(4000 + R)
+    lens = [0, 1, max(R - 2, 0), R - 1, R, R + 1, 2 * R + 3, 700, 3000, 6000]
+    kinds = ["uniform", "const", "asc", "desc", "two", "narrow", "sawtooth"]
+    keys, vals, offs = [], [], [0]
+    for n in lens:
+        for kind in kinds:
+            if kind == "uniform":
+                v = rng.integers(0, 128, n)
+            elif kind == "const":
+                v = np.full(n, 77)
+            elif kind == "asc":
+                v = np.sort(rng.integers(0, 128, n))
+            elif kind == "desc":
+                v = np.sort(rng.integers(0, 128, n))[::-1]
+            elif kind == "two":
+                v = rng.choice([40, 41], n)
+            elif kind == "narrow":
+                v = rng.integers(60, 64, n)
+            else:
+                v = 127 - (np.arange(n) % 128)
+            keys.append(rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32))
+            vals.append(v.astype(np.int8))
+            offs.append(offs[-1] + n)
+    nq = len(keys)
+    st = dict(keys=np.concatenate(keys), vals=np.concatenate(vals), slots=np.zeros(offs[-1], np.uint32), offsets=np.array(offs, np.int64))
+    got = pyqadc.dist_merge_blocks([st], nq, 1, R)
+    for q in range(nq):
+        want = po.heap_replay_i8(np.concatenate([[0], keys[q]]).astype(np.uint32), np.concatenate([[127], vals[q]]).astype(np.int8), R)
+        assert np.array_equal(got[q][0], want[0]) and np.array_equal(got[q][1], want[1]), (R, q, lens[q // len(kinds)], kinds[q % len(kinds)])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("transport", ["rccl", "shm"])
 @pytest.mark.parametrize("replay", ["host_share", "device_lanes"])
 @pytest.mark.parametrize("shape", ["flat_levels", "flat_small", "ivf"])
