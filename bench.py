@@ -721,11 +721,12 @@ def main():
         if k <= 0:
             return last
         tbs = {}
-        LEAD = 3                                               # batches in flight besides the one being collected
+        LEAD = int(os.environ.get("QADC_BENCH_LEAD", 3))       # batches in flight besides the one being collected (<= 7: 8 slots)
+        NS, NT = LEAD + 1, LEAD + 3                            # submission slots / table copies in rotation
 
         def prescan(b):                                        # batch b's sliced pre-scan -> pre-slot b % 2
-            tbs[b % 6] = pool[b % len(pool)].copy()
-            idx.prescan_submit(b % 2, assign, tbs[b % 6], R, rank, mworld)
+            tbs[b % NT] = pool[b % len(pool)].copy()
+            idx.prescan_submit(b % 2, assign, tbs[b % NT], R, rank, mworld)
 
         def merge(slot_i, pv):
             """Finished batch -> (keys, vals, sizes[, gathered pre-scan values]).  Native: qadc_dist_collect — ONE
@@ -753,7 +754,7 @@ def main():
         if LOOP:
             g = np.tile(g, (1, LOOP))
         for b in range(nb):
-            idx.submit(b % 4, assign, tbs[b % 6], R, prescan=g[b * NQ:(b + 1) * NQ])
+            idx.submit(b % NS, assign, tbs[b % NT], R, prescan=g[b * NQ:(b + 1) * NQ])
         if k > LEAD:
             prescan(LEAD)
         stamps = [] if os.environ.get("QADC_BENCH_STEP_LOG") else None
@@ -766,11 +767,11 @@ def main():
             tb_ = time.perf_counter()
             pv = idx.prescan_collect((i + LEAD) % 2) if i + LEAD < k else None   # batch i+LEAD's, enqueued an iteration ago
             tc = time.perf_counter()
-            out = merge(i % 4, pv)
+            out = merge(i % NS, pv)
             td = time.perf_counter()
             last = out[:3]
             if i + LEAD < k:
-                idx.submit((i + LEAD) % 4, assign, tbs[(i + LEAD) % 6], R, prescan=out[3])
+                idx.submit((i + LEAD) % NS, assign, tbs[(i + LEAD) % NT], R, prescan=out[3])
             te = time.perf_counter()
             if stamps is not None:
                 acc = run_steps_dist.acc = getattr(run_steps_dist, "acc", [0.0] * 5)

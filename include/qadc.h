@@ -281,7 +281,7 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
  * sorted on that rank's host and shipped in the same gather.  A rank whose batch failed locally still takes part in the
  * gather with a failure flag in its header, so every rank returns an error instead of one rank leaving the others
  * blocked.  A batch submitted after qadc_dist_init may still be collected with the plain collect calls (host replay
- * of this rank's streams only).  Large one-workgroup-per-query batches (>= "dist_device_nq" queries: IVF) have their merge —
+ * of this rank's streams only).  Large batches (>= "dist_device_nq" queries: IVF; on either scan path) have their merge —
  * pack, all-gather, interleave, replay — ENQUEUED WITH THE BATCH, behind its scan, so qadc_dist_collect only waits for it
  * (option "dist_async", default 1): after qadc_dist_init every rank must therefore SUBMIT the same batches in the same
  * order, not just collect them (the all-gather of such a batch is issued by its submit call).  qadc_search batches of
@@ -387,6 +387,7 @@ typedef struct qadc_profile {
     uint64_t group_pass_codes4; /* ... by 4-seat passes (LDS cycles = codes * M * 2 / 64) */
     uint64_t group_batches;    /* batches the above figures cover */
     uint64_t front_sharded_batches; /* multi-GPU: qadc_search batches whose front ran on 1/world of the queries per rank */
+    uint64_t dist_async_collects;   /* multi-GPU: qadc_dist_collect calls served by a merge enqueued with the batch (one event wait) */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

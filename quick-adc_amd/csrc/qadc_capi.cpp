@@ -241,6 +241,7 @@ struct QadcNcclId { char internal[128]; };                  // layout of ncclUni
 struct DistSlot {
     DevBuf<uint64_t> d_block, d_gathered, d_merged, d_moff;
     DevBuf<uint32_t> d_mcnt;
+    DevBuf<uint32_t> d_src;                                  // level-path batches: {offset, count, flags}[nq] of the ordered streams
     PinBuf<unsigned char> h_out;                             // mapped: heaps u64[nq][R], sizes u32[nq], status u32[4]
     unsigned char* d_out = nullptr;
     unsigned char* h_out_mapped = nullptr;
@@ -250,6 +251,7 @@ struct DistSlot {
     uint64_t seq = 0;                                        // gather (flush_merges), so that that gather never waits for this batch's scan
     void release() {
         d_block.release(); d_gathered.release(); d_merged.release(); d_moff.release(); d_mcnt.release(); h_out.release();
+        d_src.release();
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_done) (void)hipEventDestroy(ev_done);
         if (ev_gathered) (void)hipEventDestroy(ev_gathered);
@@ -282,6 +284,7 @@ struct DistState {
     DevBuf<uint64_t> d_fix;                                  // streams of the queries this rank had to order on the host
     PinBuf<uint64_t> h_fix;
     DevBuf<float> d_extra;
+    DevBuf<uint64_t> d_extra_all;                            // the payload of a batch whose merge was enqueued with it, gathered [world][w]
     PinBuf<float> h_extra;
     PinBuf<unsigned char> h_out;                             // mapped: heaps u64[nq][R], sizes u32[nq]
     unsigned char* d_out = nullptr;
@@ -945,6 +948,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                            reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq), st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(take_launch_error());
+    if (s.dist_batch && !s.rerun && s.mode != 1)
+        if (int rc = enqueue_merge(idx, s, st)) return rc;
 
     if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(s.ev_done, st));
@@ -1292,7 +1297,17 @@ int enqueue_merge_now(qadc_index* idx, Slot& s) {
     if (!ds.ev_done) HIPCHECK(hipEventCreateWithFlags(&ds.ev_done, hipEventDisableTiming));
     hipStream_t st = d.stream;
     HIPCHECK(hipStreamWaitEvent(st, ds.ev_ready, 0));
-    HIPCHECK(launch_dist_pack_qflags(s.d_qflags.p, nq, s.d_stream.p, s.wgq_cap, d.cap_entries, ds.d_block.p, st));
+    if (s.wgq) {
+        HIPCHECK(launch_dist_pack_qflags(s.d_qflags.p, nq, s.d_stream.p, s.wgq_cap, d.cap_entries, ds.d_block.p, st));
+    } else {
+        // level path: the ordering pass left {out_off, count, reps, flags} in the query states and the compact ordered
+        // streams in d_stream; whatever the collect call would have to redo first (a query the device did not order, an
+        // overflowed region / output / pre-scan buffer) raises bit7 and the merge is redone at collect time
+        HIPCHECK(ds.d_src.ensure(3 * (size_t)nq));
+        HIPCHECK(launch_dist_src_from_states(s.d_qs, nq, s.out_cap, ds.d_src.p, st));
+        HIPCHECK(launch_dist_pack(ds.d_src.p, ds.d_src.p + nq, ds.d_src.p + 2 * (size_t)nq, nq, s.d_stream.p, nullptr, d.cap_entries,
+                                  nullptr, 0, ds.d_block.p, st));
+    }
     std::string gerr;
     if (d.gather(ds.d_block.p, ds.d_gathered.p, bw, st, gerr)) return fail(QADC_E_HIP, gerr);
     // the collectives keep `st` to themselves (the next batch's front gather is issued right behind this one); the merge's
@@ -1330,6 +1345,11 @@ int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream) {
     ds.enqueued = false;
     ds.pending = false;
     const int nq = s.nq, R = s.R, world = d.world;
+    // (level-path batches as well: the ordering pass leaves what the pack needs in the query states.  Below dist_device_nq
+    // queries the merge stays at collect time, where the ranks replay shares on the host's otherwise idle cores: enqueuing
+    // such a batch's device merge — or just its pack, gather and copy-out — behind the scan was measured on bench.py's
+    // 32-query flat steps, one of 8 ranks: 1.61-1.65 ms per step against 1.22; interleave + replay kernels under the long
+    // scan launches take 1.5-1.9 ms per batch, the host 0.07)
     if (!d.async_merge || nq < d.device_nq || (uint32_t)R > replay_wave_max_R() || (size_t)s.ma * world > dist_interleave_max_cells())
         return QADC_OK;
     if (!ds.ev_ready) HIPCHECK(hipEventCreateWithFlags(&ds.ev_ready, hipEventDisableTiming));
@@ -1637,6 +1657,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool fr
         if (out_overflow) s.out_cap = (uint32_t)(total_sorted + total_sorted / 4 + 1024);
         if (prescan_overflow) s.full_prescan = true;   // adversarially ordered starts: pre-scan all of them unfiltered
         idx->prof.regrows++;
+        s.rerun = true;                                // (no merge is enqueued behind a re-run: the collect-time merge follows)
         if (int rc = plan_and_launch(idx, s)) {
             s.busy = false;
             return rc;
@@ -2914,11 +2935,7 @@ namespace {
 // gather, so the merge replays `world` ranks' worth of entries while only this rank's shard is scanned.
 int loopback_allgather(void* ctx, const void* d_send, void* d_recv, uint64_t bytes, void* st) {
     const int world = (int)reinterpret_cast<intptr_t>(ctx);
-    for (int g = 0; g < world; ++g)
-        if (hipMemcpyAsync(static_cast<unsigned char*>(d_recv) + (size_t)g * bytes, d_send, bytes, hipMemcpyDeviceToDevice,
-                           static_cast<hipStream_t>(st)) != hipSuccess)
-            return -1;
-    return 0;
+    return launch_replicate_block(d_send, d_recv, (size_t)(bytes / 8), world, static_cast<hipStream_t>(st)) == hipSuccess ? 0 : 1;
 }
 }  // namespace
 }  // extern "C++"
@@ -3013,7 +3030,7 @@ int qadc_dist_shutdown(qadc_index* idx) {
     for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamDestroy(m);
     d->d_fix.release(); d->h_fix.release(); d->d_moff.release(); d->d_merged.release(); d->d_mcnt.release();
     for (auto& ds : d->slot) ds.release();
-    d->d_block.release(); d->d_gathered.release(); d->d_src.release(); d->h_src.release(); d->d_extra.release();
+    d->d_block.release(); d->d_gathered.release(); d->d_src.release(); d->h_src.release(); d->d_extra.release(); d->d_extra_all.release();
     d->h_extra.release(); d->h_out.release(); d->h_hdr.release(); d->h_extra_all.release();
     d->h_gathered.release(); d->h_myheaps.release(); d->d_myheaps.release(); d->d_allheaps.release(); d->h_allheaps.release();
     delete d;
@@ -3052,6 +3069,7 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         if (!bad) {
             // every rank saw clean headers: the heaps are final (a local failure of collect_common concerns this rank only)
             if (local_rc) return fail(local_rc, local_err);
+            idx->prof.dist_async_collects++;
             std::vector<int32_t> st_async;
             int32_t* stp = status;
             if (!stp) { st_async.resize(nq); stp = st_async.data(); }
@@ -3072,12 +3090,12 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
                 HIPCHECK(d.h_extra.ensure(2 * w));
                 HIPCHECK(d.d_extra.ensure(2 * w));
                 HIPCHECK(d.h_extra_all.ensure(2 * w * world));
-                HIPCHECK(d.d_block.ensure(w * world));
+                HIPCHECK(d.d_extra_all.ensure(w * world));       // (not d_block: a later batch's merge may be using that)
                 std::memcpy(d.h_extra.p, extra, sizeof(float) * extra_n);
                 HIPCHECK(hipMemcpyAsync(d.d_extra.p, d.h_extra.p, sizeof(uint64_t) * w, hipMemcpyHostToDevice, d.stream));
                 std::string gerr2;
-                if (d.gather(d.d_extra.p, d.d_block.p, w, d.stream, gerr2)) return fail(QADC_E_HIP, gerr2);
-                HIPCHECK(hipMemcpy2DAsync(d.h_extra_all.p, sizeof(float) * extra_n, d.d_block.p, sizeof(uint64_t) * w,
+                if (d.gather(d.d_extra.p, d.d_extra_all.p, w, d.stream, gerr2)) return fail(QADC_E_HIP, gerr2);
+                HIPCHECK(hipMemcpy2DAsync(d.h_extra_all.p, sizeof(float) * extra_n, d.d_extra_all.p, sizeof(uint64_t) * w,
                                           sizeof(float) * extra_n, world, hipMemcpyDeviceToHost, d.stream));
                 HIPCHECK(hipStreamSynchronize(d.stream));
                 std::memcpy(extra_out, d.h_extra_all.p, sizeof(float) * (size_t)world * extra_n);

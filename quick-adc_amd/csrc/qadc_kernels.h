@@ -196,12 +196,17 @@ size_t dist_interleave_max_cells();
 hipError_t launch_dist_merge(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
                              uint64_t* d_moff, uint32_t* d_mcnt, uint32_t* d_info, uint64_t* d_merged, uint64_t* d_heaps,
                              uint32_t* d_heap_sizes, hipStream_t stream, uint32_t* d_status = nullptr);
+// The loopback stand-in for an all-gather (qadc_dist_init_loopback): the block into all `world` slots, one kernel.
+hipError_t launch_replicate_block(const void* d_src, void* d_dst, size_t words, int world, hipStream_t stream);
+// Level-path batches: {offset, count, flags}[nq] (the three arrays launch_dist_pack takes) from the query states the
+// ordering pass left; bit7 of the flags = the collect call must redo the merge.
+hipError_t launch_dist_src_from_states(const QueryState* d_qs, int nq, uint32_t out_cap, uint32_t* d_src, hipStream_t stream);
 // The pack step of a merge enqueued together with its batch: the streams are described by the query kernels' own
 // {flags, entries} records in device memory (stream q at q * qcap), no host-provided offsets.
 hipError_t launch_dist_pack_qflags(const uint32_t* d_qflags, int nq, const uint64_t* d_stream, uint32_t qcap, uint32_t cap_entries,
                                    uint64_t* d_block, hipStream_t stream);
-// kv_binheap push replay, ONE WAVE per query, heap in registers (v_readlane / v_writelane sift on the scalar unit, the
-// lanes pre-filter 64 stream entries per ballot): stream[off[q] .. off[q] + cnt[q]); info[q] bit0 = skip (size 0),
+// kv_binheap push replay, ONE WAVE per query, heap in registers (the lanes sift all levels of a push at once and
+// pre-filter 64 stream entries per ballot): stream[off[q] .. off[q] + cnt[q]); info[q] bit0 = skip (size 0),
 // bit1 = leave to the host (size 0xffffffff).
 hipError_t launch_replay_heap_wave(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
                                    int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);

@@ -1368,15 +1368,31 @@ __global__ __launch_bounds__(256) void dist_pack_kernel(const uint32_t* __restri
     for (uint32_t i = tid; i < n; i += 256) ent[off + i] = s[i];
 }
 
+// Level-path batches (sort_cands_kernel ordered the streams): {offset, count, flags}[nq] for dist_pack_kernel from the query
+// states, as qadc_dist_collect builds them on the host from the QueryOut records.  bit7 = "the collect call has work to do
+// before this rank's streams are final" (a query the device did not order, an overflowed output or pre-scan buffer): every
+// rank then redoes the merge at collect time.
+__global__ __launch_bounds__(256) void dist_src_from_states_kernel(const QueryState* __restrict__ qstates, int nq, uint32_t out_cap,
+                                                                   uint32_t* __restrict__ src) {
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        const QueryState* qs = qstates + q;
+        const uint32_t fl = qs->flags, n = qs->count + qs->reps, off = qs->out_off;
+        const bool skip = (fl & 1u) != 0, ordered = (fl & 4u) != 0;
+        const bool bad = (fl & 8u) != 0 || (!skip && (!ordered || (uint64_t)off + n > out_cap));
+        src[q] = (ordered && !bad) ? off : 0u;
+        src[nq + q] = (ordered && !bad && !skip) ? n : 0u;
+        src[2 * nq + q] = (fl & 0x3fu) | (bad ? 128u : 0u);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-// kv_binheap<unsigned,int8_t>::push (binheap.hpp:75-116) with ONE WAVE per query and the heap in REGISTERS: element e
-// lives in lane e % 64 of register pair e / 64 (value, key).  Everything about a push is wave-uniform — the hole index,
-// the value, the children — so the sift runs on the scalar unit with v_readlane / v_writelane (a few cycles each)
-// (writes: one compare + select) instead of dependent LDS round trips (~100 cycles each): a seven-level sink costs ~0.1 us instead of ~0.8 us.
-// What the 64 lanes add is the FILTER: a chunk of 64 stream entries is loaded coalesced, one ballot finds the entries
-// below the current root, and only those are pushed (in order; the mask is re-filtered as the root drops).  An entry
-// that is not below the root when its chunk arrives would be rejected by push() at its turn as well (the root never
-// rises once the heap is full), so the heap array is the sequential one, entry for entry.
+// kv_binheap<unsigned,int8_t>::push (binheap.hpp:75-116) with ONE WAVE per query and the heap in REGISTERS (value, key
+// register pairs; see WaveHeap).  Everything about a push is wave-uniform — the value, the path it sinks along — and the
+// 64 lanes work out all levels of a sink at once (WaveHeap::sift) instead of following it through dependent LDS round
+// trips.  The lanes also FILTER: a chunk of 64 stream entries is loaded coalesced, one ballot finds the entries below
+// the current root, and only those are pushed (in order; the mask is re-filtered as the root drops).  An entry that is
+// not below the root when its chunk arrives would be rejected by push() at its turn as well (the root never rises once
+// the heap is full), so the heap array is the sequential one, entry for entry.
 // ---------------------------------------------------------------------------------------------
 template <int NREG>
 struct WaveHeap {
@@ -1834,6 +1850,26 @@ hipError_t launch_dist_pack(const uint32_t* d_src_off, const uint32_t* d_src_cnt
                             uint32_t extra_n, uint64_t* d_block, hipStream_t stream) {
     hipLaunchKernelGGL(dist_pack_kernel, dim3(nq + 1), dim3(256), 0, stream, d_src_off, d_src_cnt, d_src_flags, nq, d_stream,
                        d_fix, cap_entries, d_extra, extra_n, d_block, (const uint32_t*)nullptr, 0u);
+    return hipGetLastError();
+}
+
+// qadc_dist_init_loopback's stand-in for the all-gather: ONE kernel (as a real all-gather is), the block into every slot
+__global__ __launch_bounds__(256) void replicate_block_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, size_t words,
+                                                              int world) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) {
+        const uint64_t v = src[i];
+        for (int g = 0; g < world; ++g) dst[(size_t)g * words + i] = v;
+    }
+}
+hipError_t launch_replicate_block(const void* d_src, void* d_dst, size_t words, int world, hipStream_t stream) {
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((words + 255) / 256, 64));   // (a collective's few workgroups)
+    hipLaunchKernelGGL(replicate_block_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const uint64_t*>(d_src),
+                       static_cast<uint64_t*>(d_dst), words, world);
+    return hipGetLastError();
+}
+
+hipError_t launch_dist_src_from_states(const QueryState* d_qs, int nq, uint32_t out_cap, uint32_t* d_src, hipStream_t stream) {
+    hipLaunchKernelGGL(dist_src_from_states_kernel, dim3(1), dim3(256), 0, stream, d_qs, nq, out_cap, d_src);
     return hipGetLastError();
 }
 

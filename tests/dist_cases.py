@@ -33,6 +33,7 @@ def build_case(name):
         c["options"] = {"dist_cap_entries": 64}
         c["extra_n"] = 37
         c["slots"] = (0, 1)
+        c["repeat"] = 2                                    # the second pass fits the regrown block: merges enqueued with the batches
     elif name in ("ivf_lanes", "ivf_whole"):
         # >= 256 queries: the gathered streams are replayed on the GPU, one lane per query.  Ragged labelled partitions,
         # an empty one, some too small for every rank to hold a piece, tie-heavy tables.
@@ -46,7 +47,7 @@ def build_case(name):
         nq, ma = (300, 6) if name == "ivf_lanes" else (260, 9)
         live = [p for p, s in enumerate(sizes) if s]
         assign = np.stack([rng.choice(live, ma, replace=False) for _ in range(nq)]).astype(np.int32)
-        c.update(M=M, parts=parts, labels=labels, keep=0.05, assign=assign, tables=float_tables(rng, nq, ma, M, scale=0.3))
+        c.update(M=M, parts=parts, labels=labels, keep=0.05, assign=assign, tables=float_tables(rng, nq, ma, M, scale=0.3), repeat=2)
         if name == "ivf_whole":
             c["placement"] = "whole"                      # whole partitions per rank, size-balanced
             c["index_options"] = {"wgq_group": 2, "wgq_group_head": 2}    # partition-major second phase under the merge
@@ -56,6 +57,7 @@ def build_case(name):
         c.update(M=16, parts=[rand_codes(rng, 90001, 16)], assign=np.zeros((270, 1), np.int32), R=300)
         c["tables"] = float_tables(rng, 270, 1, 16)
         c["options"] = {"dist_device_nq": 1}
+        c["repeat"] = 2
     elif name == "unordered":
         # query 0: constant float tables -> all-zero int8 tables; with one bound level over the whole list every code of
         # every rank's range is emitted (> 16384 candidates per rank): the ranks order it on the host and ship it anyway

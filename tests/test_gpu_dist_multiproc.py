@@ -89,6 +89,13 @@ def test_native_merge_with_several_processes_on_one_gpu(po, world, tmp_path, sca
                         assert np.array_equal(ex[g], np.arange(case["extra_n"], dtype=np.float32) + 1000.0 * g)
         if name == "flat32":
             assert all(int(res[r]["flat32.regrows"][0]) >= 1 for r in range(world))          # the 64-entry block was regrown everywhere
+            # (32 queries < dist_device_nq: merged at collect time, the ranks replaying shares on the host)
+            assert all(int(res[r]["flat32.dist_async_collects"][0]) == 0 for r in range(world))
+        if name in ("ivf_lanes", "big_r"):                 # second pass: merges enqueued with the batch, level path and query kernel alike
+            assert all(int(res[r]["%s.dist_async_collects" % name][0]) >= 1 for r in range(world)), \
+                (name, [int(res[r]["%s.dist_async_collects" % name][0]) for r in range(world)])
+        if name == "unordered":                            # a query the device could not order: every rank redid the merge at collect time
+            assert all(int(res[r]["unordered.dist_async_collects"][0]) == 0 for r in range(world))
         if name == "unordered":
             assert all(int(res[r]["unordered.host_sorted_queries"][0]) >= 1 for r in range(world))
         if name == "ivf_whole" and scan_path != "levels" and scan_path != "levels_head":

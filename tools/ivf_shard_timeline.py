@@ -1,5 +1,5 @@
 """Per-queue kernel timeline of a steady-state window of tools/ivf_shard_trace.sh's trace.
-usage: python tools/ivf_shard_timeline.py <dir> [window_ms=4.5] [replay_index=36]
+usage: python tools/ivf_shard_timeline.py <dir> [window_ms=4.5] [anchor_index=36] [anchor_kernel=replay_heap_wave]
 (bench.ivf_leg: 4 sizing + 8 warm + 48 timed 1024-query batches, then the 2048-query and the profiled passes)"""
 import csv, glob, os, sys
 d = sys.argv[1]
@@ -9,7 +9,8 @@ f = max(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), k
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the timed region = the densest run of replay kernels; take the window ending `back` ms before the last replay
-rep = [r for r in rows if "replay_heap_wave" in r["Kernel_Name"]]
+anchor = sys.argv[4] if len(sys.argv) > 4 else "replay_heap_wave"
+rep = [r for r in rows if anchor in r["Kernel_Name"]]
 t_beg = int(rep[first]["Start_Timestamp"])
 t_end = t_beg + int(win * 1e6)
 queues = {}

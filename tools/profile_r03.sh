@@ -26,4 +26,4 @@ cd $R
 python3 bench.py > gpurun_out/${TAG}_bench_plain.json 2> gpurun_out/${TAG}_bench_plain.err
 bash tools/dist_sizes3.sh > gpurun_out/${TAG}_shard_sizes.txt 2>&1
 python3 tools/ivf_shard_sizes.py c3 c5 > gpurun_out/${TAG}_ivf_shard_sizes.txt 2>&1
-tail -3 gpurun_out/${TAG}_shard_sizes.txt gpurun_out/${TAG}_ivf_shard_sizes.txt
+tail -n 3 gpurun_out/${TAG}_shard_sizes.txt gpurun_out/${TAG}_ivf_shard_sizes.txt
