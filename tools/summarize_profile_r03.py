@@ -58,7 +58,7 @@ def counters(kind, names):
 leg = json.loads([l for l in open(os.path.join(G, "prof_%s_ivf_kt.log" % TAG)) if l.startswith("{")][-1])
 names = {"scan_query_kernel": "head (front + first probes of every query, one workgroup per query)",
          "scan_i8_mq_kernel": "partition-major second phase (8 or 4 queries per pass)",
-         "replay_heap_lanes_kernel": "lane-per-query heap replay", "order_cands_kernel": "scan order per query"}
+         "replay_heap_wave_kernel": "wave-per-query heap replay", "order_cands_kernel": "scan order per query"}
 out = {"command": "python3 tools/ivf_shard_one.py c3 none  (bench.py's ivf leg alone: 100M x 16x4 codes, K = 4096, nprobe 32, 1024- and 2048-query batches)",
        "us_per_query_in_the_kernel_trace_run": leg["us_per_query"], "kernels": {}}
 f, w, sq, sq2 = (counters(k, names) for k in ("FETCH_SIZE", "WRITE_SIZE", "sq", "sq2"))
