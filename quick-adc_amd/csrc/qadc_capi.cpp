@@ -1000,7 +1000,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     // flight — a synchronous call — is answered sooner by the host's threads up to a few hundred queries (C3 shape,
     // synchronous: 64 queries 1.41 -> 0.87 ms, 256: 1.89 -> 1.44, 512: 2.26 vs 2.41)
     const int replay_from = alone ? std::max(idx->device_replay_nq, idx->device_replay_alone_nq) : idx->device_replay_nq;
-    s.dev_replay = idx->device_replay_nq > 0 && nq >= replay_from && (uint32_t)s.R <= replay_lanes_max_R();
+    s.dev_replay = idx->device_replay_nq > 0 && nq >= replay_from && (uint32_t)s.R <= (idx->replay_wave ? replay_wave_max_R() : replay_lanes_max_R());
     s.dist_batch = idx->dist != nullptr;
     s.heaps_ready = s.dev_replay && !s.dist_batch;
     if (s.dist_batch) s.dev_replay = true;                   // streams stay on the device for the gather (qadc_dist_collect)

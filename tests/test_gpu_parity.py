@@ -834,6 +834,31 @@ def test_wgq_stream_capacity_regrow_is_exact(pyqadc, po, M):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R", [100, 288, 289, 320, 321])
+def test_device_replay_of_a_query_kernel_batch_at_the_heap_sizes_around_its_limits(pyqadc, po, R):
+    """70 queries through the one-workgroup-per-query path with the heap replay on the device (>= 64 queries): R up to
+    the lane replay's 288 / the wave replay's 320 elements stays on the GPU, R = 321 is replayed on the host — heaps
+    equal the oracle's either way (the scan_path fixture runs this with both device replays)."""
+    rng = np.random.default_rng(900 + R)
+    M, nq = 16, 70
+    parts = [rand_codes(rng, n, M) for n in (30011, 4001, 9000)]
+    labels = [rng.permutation(1 << 20)[:len(p)].astype(np.uint32) for p in parts]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(0.05)
+    idx.set_option("wgq", 2)
+    assign = np.stack([rng.permutation(3)[:2] for _ in range(nq)]).astype(np.int32)
+    tables = float_tables(rng, nq, 2, M, scale=0.3)
+    res = idx.query_scan(assign, tables.copy(), R)
+    for q in range(nq):
+        want = po.query_scan(M, parts, labels, 0.05, assign[q], tables[q].copy(), R)
+        assert want["rc"] == res["status"][q]
+        if want["rc"] == 0:
+            assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), (R, q)
+    idx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,n,keep", [(16, 2000003, 0.01), (32, 1200001, 0.02)])
 def test_wgq_prescan_values_beyond_the_lds_budget(pyqadc, po, M, n, keep):
     """More starts than the kernel keeps in LDS (12288 / 8192 values): the values go through the global scratch and
