@@ -451,7 +451,7 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
         lds_cycles = (pp["group_pass_codes8"] * M * 4 + pp["group_pass_codes4"] * M * 2) / 64.0
         lds_rate = lds_cycles / (pp["group_scan_ms"] * 1e-3) / 1e9
         head_gbs = pp["group_head_codes"] * (M // 2) / (pp["group_head_ms"] * 1e-3) / 1e9
-        roof = {"bound": "lds", "kernel": "scan_i8_mq_kernel<%d,2> over the (query, probe) pairs regrouped by partition" % M,
+        roof = {"bound": "lds", "kernel": "scan_i8_mq_narrow_kernel<%d,2> (8- and 4-seat groups) over the (query, probe) pairs regrouped by partition" % M,
                 "achieved": lds_rate, "peak": LDS_PEAK_GCYC, "unit": "G LDS-array cycles/s", "frac": lds_rate / LDS_PEAK_GCYC,
                 "avg_launch_ms": pp["group_scan_ms"] / nb, "launches": nb,
                 "lds_cycles_rule": "codes read by 8-seat passes x %d lookups x 4 cycles / 64 lanes + codes read by 4-seat passes x %d x 2 / 64 "

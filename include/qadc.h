@@ -91,7 +91,7 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * "cand_capacity" (candidate region entries per query), "level_base", "level_growth" (bound levels),
  * "prescan_sample", "small_run", "small_vec_per_wg", "wgs_per_item", "variant", "share_variant" (0 = never
  * launch the queries of a batch as L2-sharing siblings), "share_codes_per_wg", "mq" (8 queries per pass),
- * "mq_codes_per_wg", "mq_min_wgs", "mq_min_tiles", "mq_narrow" (groups of at most 4 queries take the 4-seat form of that kernel), "prescan_mq", "overlap_front", "head_early", "front_run_max",
+ * "mq_codes_per_wg", "mq_min_wgs", "mq_min_tiles", "mq_narrow" (IVF second phase: groups of at most 4 queries take the 4-seat form of that kernel), "prescan_mq", "overlap_front", "head_early", "front_run_max",
  * "front_min_batch", "front_dist" (kernel and launch tuning), "device_replay_nq" (batches of at least this many
  * queries replay their candidate streams through the heap on the device; 0 = always on the host),
  * "device_replay_alone_nq" (... from this many when nothing else is in flight: a synchronous call), "replay_threads",

@@ -373,7 +373,7 @@ struct qadc_index {
     int wgq_group_head = 4;   // ... after a head of this many probes per query (one workgroup per query)
     int wgq_group_head_dist = 4;   // ... under the multi-GPU merge (probes with codes on this rank; option "wgq_group_head_dist")
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
-    int mq_narrow = 1;     // multi-query groups whose upper four seats are empty run the 4-seat form of the kernel
+    int mq_narrow = 1;     // IVF second phase: groups whose upper four seats are empty run the 4-seat form (the two-body build of the kernel)
     int replay_wave = 1;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
                            // (C3 shape, 1024-query batches: lanes 0.78 us per query, waves 0.75; C5 shape: 4.83 vs 4.67 — since
                            // the wave heap sifts all levels at once; with its element-by-element sift the waves lost,
@@ -857,7 +857,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                                  s.cap_q, (uint32_t)s.R, str);
         else if (ll.mq)
             launch_scan_i8_mq(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q,
-                              (uint32_t)s.R, str, idx->mq_narrow);
+                              (uint32_t)s.R, str, /*narrow=*/0);   // (the 8-seat build: see scan_i8_mq_kernel)
         else
             launch_scan_i8(M, ll.shared ? idx->share_variant : (variant & ~64), s.d_items + ll.first, ll.nitems, ll.wgs,
                            s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q, (uint32_t)s.R, str);

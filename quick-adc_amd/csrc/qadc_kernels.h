@@ -223,7 +223,9 @@ void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int
 
 // Multi-query streaming scan: groups of up to 8 consecutive runs (all over the same codes, one per query) share
 // ONE pass; wgs_per_group workgroups of 256 threads per group, sibling-major over the groups.
-// narrow != 0: a group whose seats 4..7 are empty takes the 4-seat form (8-byte rows, half the LDS cycles per lookup).
+// narrow != 0: the build in which a group whose seats 4..7 are empty takes the 4-seat form (8-byte rows, half the LDS cycles
+// per lookup) — for the IVF second phase; the flat list's bound levels take the 8-seat-only build (narrow = 0), which the
+// two-body build would slow by 5-8 %.
 void launch_scan_i8_mq(int M, const ScanItem* d_items, int nitems, int wgs_per_group, const int8_t* d_qtables,
                        QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cap_per_query, uint32_t R,
                        hipStream_t stream, int narrow = 1);

@@ -520,13 +520,16 @@ __device__ __forceinline__ void scan_mq_body(const ScanItem* __restrict__ its, c
     for (; t0 < ntiles; t0 += G * U) run(t0, part_t());
 }
 
-// (7 waves per SIMD asked for: each of the two bodies fits 68 VGPRs by itself; with less the allocator lets the pair grow to 104
-// and the occupancy the kernel's latency hiding was tuned for — 7 waves per SIMD — drops to 4)
-template <int M, int U>
-__global__ __launch_bounds__(kMQWG, 7) void scan_i8_mq_kernel(
-    const ScanItem* __restrict__ items, int nitems, const int8_t* __restrict__ qtables,
-    QueryState* __restrict__ qstates, CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap,
-    uint32_t R, uint32_t ngroups, int narrow) {
+// Two builds of the kernel.  NARROW = false: the 8-seat body alone — the flat list's bound levels (every group of a flat
+// batch is full but possibly the last).  NARROW = true: both bodies, a group whose seats 4..7 are empty taking the 4-seat
+// one — the IVF second phase, whose remainder groups are mostly narrow.  They are separate kernels on purpose: with both
+// bodies in it the register allocator lets the pair grow to 104 VGPRs unless 7 waves per SIMD are demanded, and demanded,
+// it fits the 8-seat body into 66 with a schedule that costs the FLAT path 5-8 % (1B step 7.77 -> 8.17 ms, 125 M-code
+// shard 1.12 -> 1.21 ms: measured against round 2's build on one box) for the 3 % the narrow form gives the IVF path.
+template <int M, int U, bool NARROW>
+__device__ __forceinline__ void scan_mq_kernel_body(const ScanItem* __restrict__ items, int nitems, const int8_t* __restrict__ qtables,
+                                                    QueryState* __restrict__ qstates, CandHeader* __restrict__ hdr, Cand* __restrict__ out,
+                                                    uint32_t cand_cap, uint32_t R, uint32_t ngroups) {
     // sibling-major decode over the query GROUPS (see scan_i8_kernel): groups that read the same tiles share an XCD
     const uint32_t G = gridDim.x / ngroups;
     uint32_t bx, grp;
@@ -544,11 +547,34 @@ __global__ __launch_bounds__(kMQWG, 7) void scan_i8_mq_kernel(
     const ScanItem it = its[0];                              // codes / n / pos0 / labels / key_base / dup_*: shared
     if (it.n == 0) return;                                   // (device-planned launches are sized for the worst case: no such group)
     lds_base_is_zero();
-    // seats 4..7 all empty (a remainder group of the IVF second phase; the last group of a flat batch): 4-seat form
-    bool upper = false;
-    for (int j = 4; j < nq; ++j) upper = upper || its[j].n != 0;
-    if (narrow && !upper) scan_mq_body<M, U, 4>(its, it, min(nq, 4), bx, G, qtables, qstates, hdr, out, cand_cap, R);
-    else scan_mq_body<M, U, 8>(its, it, nq, bx, G, qtables, qstates, hdr, out, cand_cap, R);
+    if (NARROW) {
+        // seats 4..7 all empty (a remainder group of the IVF second phase): 4-seat form
+        bool upper = false;
+        for (int j = 4; j < nq; ++j) upper = upper || its[j].n != 0;
+        if (!upper) {
+            scan_mq_body<M, U, 4>(its, it, min(nq, 4), bx, G, qtables, qstates, hdr, out, cand_cap, R);
+            return;
+        }
+    }
+    scan_mq_body<M, U, 8>(its, it, nq, bx, G, qtables, qstates, hdr, out, cand_cap, R);
+}
+
+template <int M, int U>
+__global__ __launch_bounds__(kMQWG) void scan_i8_mq_kernel(
+    const ScanItem* __restrict__ items, int nitems, const int8_t* __restrict__ qtables,
+    QueryState* __restrict__ qstates, CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap,
+    uint32_t R, uint32_t ngroups) {
+    scan_mq_kernel_body<M, U, false>(items, nitems, qtables, qstates, hdr, out, cand_cap, R, ngroups);
+}
+
+// (7 waves per SIMD asked for: each of the two bodies fits 68 VGPRs by itself; without the demand the occupancy the
+// kernel's latency hiding was tuned for — 7 waves per SIMD — drops to 4)
+template <int M, int U>
+__global__ __launch_bounds__(kMQWG, 7) void scan_i8_mq_narrow_kernel(
+    const ScanItem* __restrict__ items, int nitems, const int8_t* __restrict__ qtables,
+    QueryState* __restrict__ qstates, CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap,
+    uint32_t R, uint32_t ngroups) {
+    scan_mq_kernel_body<M, U, true>(items, nitems, qtables, qstates, hdr, out, cand_cap, R, ngroups);
 }
 
 template <int M>
@@ -556,8 +582,12 @@ static void launch_scan_mq_m(const ScanItem* d_items, int nitems, int wgs_per_gr
                              QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R,
                              hipStream_t stream, int narrow) {
     const uint32_t ngroups = (uint32_t)(nitems + kMQ - 1) / kMQ;
-    hipLaunchKernelGGL((scan_i8_mq_kernel<M, 2>), dim3(ngroups * (uint32_t)wgs_per_group), dim3(kMQWG), M * 256 + 64,
-                       stream, d_items, nitems, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, ngroups, narrow);
+    if (narrow)
+        hipLaunchKernelGGL((scan_i8_mq_narrow_kernel<M, 2>), dim3(ngroups * (uint32_t)wgs_per_group), dim3(kMQWG), M * 256 + 64,
+                           stream, d_items, nitems, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, ngroups);
+    else
+        hipLaunchKernelGGL((scan_i8_mq_kernel<M, 2>), dim3(ngroups * (uint32_t)wgs_per_group), dim3(kMQWG), M * 256 + 64,
+                           stream, d_items, nitems, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, ngroups);
 }
 
 // Runs of the launch must all cover the same codes (same codes / n / pos0 / labels / key_base / dup_*): the

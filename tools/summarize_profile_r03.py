@@ -5,7 +5,7 @@ summaries, the JSON line under the tracer), plus
   r03_batched_only_kernel_stats.csv  kernel stats of a run of ONLY the headline loop (25 steps): AverageNs of
                                      scan_i8_mq_kernel there is what roofline_batched.avg_launch_ms must agree with
   r03_ivf_kernel_stats.csv           kernel stats of ONLY the IVF leg at the BASELINE configs[2] shape (tools/ivf_shard_one.py c3 none)
-  r03_ivf_pmc_summary.json           PMC of the two kernels that bound that leg: scan_query_kernel (head) and scan_i8_mq_kernel
+  r03_ivf_pmc_summary.json           PMC of the two kernels that bound that leg: scan_query_kernel (head) and scan_i8_mq_narrow_kernel
                                      (partition-major second phase): HBM bytes (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024,
                                      MI355X_MICROARCH.md), LDS pipe, VALU issue, wave wait share
   r03_bench_plain.json, r03_shard_sizes.txt, r03_ivf_shard_sizes.txt
@@ -57,7 +57,7 @@ def counters(kind, names):
 
 leg = json.loads([l for l in open(os.path.join(G, "prof_%s_ivf_kt.log" % TAG)) if l.startswith("{")][-1])
 names = {"scan_query_kernel": "head (front + first probes of every query, one workgroup per query)",
-         "scan_i8_mq_kernel": "partition-major second phase (8 or 4 queries per pass)",
+         "scan_i8_mq_narrow_kernel": "partition-major second phase (8 or 4 queries per pass)",
          "replay_heap_wave_kernel": "wave-per-query heap replay", "order_cands_kernel": "scan order per query"}
 out = {"command": "python3 tools/ivf_shard_one.py c3 none  (bench.py's ivf leg alone: 100M x 16x4 codes, K = 4096, nprobe 32, 1024- and 2048-query batches)",
        "us_per_query_in_the_kernel_trace_run": leg["us_per_query"], "kernels": {}}
