@@ -942,10 +942,14 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     launch_sort_cands(s.d_qs, s.d_cands.p, s.cap_q, nq, s.d_qout, s.d_entries, s.out_cap, s.d_hdr, st,
                       dev_stream ? s.d_stream.p : nullptr);
     s.heaps_ready = s.dev_replay && !s.dist_batch;           // (a merge batch is replayed after the gather, not here)
-    if (s.heaps_ready)
-        launch_replay_heap(s.d_qs, s.d_stream.p, s.out_cap, nq, (uint32_t)s.R,
-                           reinterpret_cast<uint64_t*>(d_result + off_heaps),
-                           reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq), st);
+    if (s.heaps_ready) {
+        uint64_t* d_heaps = reinterpret_cast<uint64_t*>(d_result + off_heaps);
+        uint32_t* d_sizes = reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
+        if (idx->replay_wave && (uint32_t)s.R <= replay_wave_max_R())     // one wave per query, all lanes at work (heap in registers)
+            HIPCHECK(launch_replay_heap_wave_states(s.d_qs, s.d_stream.p, s.out_cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
+        else                                                              // one wave per query, lane 0 pushing into an LDS heap (any R)
+            launch_replay_heap(s.d_qs, s.d_stream.p, s.out_cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st);
+    }
     HIPCHECK(hipGetLastError());
     HIPCHECK(take_launch_error());
     if (s.dist_batch && !s.rerun && s.mode != 1)

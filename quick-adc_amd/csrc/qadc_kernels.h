@@ -211,6 +211,9 @@ hipError_t launch_dist_pack_qflags(const uint32_t* d_qflags, int nq, const uint6
 hipError_t launch_replay_heap_wave(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
                                    int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
 // ... on the single-GPU layout of launch_replay_heap_lanes: query q's stream at q * cap, {flags, entries} in d_qflags[4q..].
+// ... on the level path's layout: the compact ordered output of sort_cands_kernel, described by the query states.
+hipError_t launch_replay_heap_wave_states(const QueryState* d_qs, const uint64_t* d_stream, uint32_t out_cap, int nq, uint32_t R,
+                                          uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
 hipError_t launch_replay_heap_wave_qflags(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
                                           uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
 

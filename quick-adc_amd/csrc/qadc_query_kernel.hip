@@ -1527,7 +1527,7 @@ struct WaveHeap {
 // chain) and hold wave slots the scan kernels' 1024-thread workgroups need — packed 16 to a workgroup they tie up a
 // quarter of the CUs they would tie up four to a workgroup.
 constexpr int kReplayWaves = 16;                                 // (4 and 8 measured the same within noise)
-template <int NREG, bool QF>
+template <int NREG, int QF>
 __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(const uint64_t* __restrict__ stream, const uint64_t* __restrict__ off,
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ info,
                                                                uint32_t cap, int nq, uint32_t R, uint64_t* __restrict__ heaps,
@@ -1537,7 +1537,15 @@ __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(con
     if (q >= nq) return;
     uint32_t fl, n;
     uint64_t o;
-    if (QF) {
+    if (QF == 2) {
+        // the level path's layout: what sort_cands_kernel left in the query states (info = the QueryState array, cap = the
+        // capacity of the compact ordered output); not ordered on the device / past the output: the host replays
+        const QueryState* qs = reinterpret_cast<const QueryState*>(info) + q;
+        const uint32_t qf = (uint32_t)__builtin_amdgcn_readfirstlane((int)qs->flags);
+        n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qs->count + qs->reps));
+        o = (uint32_t)__builtin_amdgcn_readfirstlane((int)qs->out_off);
+        fl = (qf & 1u) | ((!(qf & 4u) || o + n > cap) ? 2u : 0u);
+    } else if (QF == 1) {
         const uint32_t qf = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[4 * q]);
         n = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[4 * q + 1]);
         fl = (qf & 1u) | ((n > cap || (qf & 32u)) ? 2u : 0u);    // overflowed stream / fallback pending: the host re-runs the batch
@@ -1893,7 +1901,7 @@ uint32_t replay_wave_max_R() { return 320; }                     // positions 1 
 size_t dist_interleave_max_cells() { return 8192; }              // ma x world counters, twice, in 64 KiB of LDS
 
 // One wave per query over stream[off[q] .. +cnt[q]); R <= replay_wave_max_R().
-template <bool QF>
+template <int QF>
 static hipError_t launch_replay_wave_t(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
                                        uint32_t cap, int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
     if (R == 0 || R > replay_wave_max_R()) return hipErrorInvalidValue;
@@ -1910,11 +1918,16 @@ static hipError_t launch_replay_wave_t(const uint64_t* d_stream, const uint64_t*
 }
 hipError_t launch_replay_heap_wave(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
                                    int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
-    return launch_replay_wave_t<false>(d_stream, d_off, d_cnt, d_info, 0, nq, R, d_heaps, d_heap_sizes, stream);
+    return launch_replay_wave_t<0>(d_stream, d_off, d_cnt, d_info, 0, nq, R, d_heaps, d_heap_sizes, stream);
 }
 hipError_t launch_replay_heap_wave_qflags(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
                                           uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
-    return launch_replay_wave_t<true>(d_stream, nullptr, nullptr, d_qflags, cap, nq, R, d_heaps, d_heap_sizes, stream);
+    return launch_replay_wave_t<1>(d_stream, nullptr, nullptr, d_qflags, cap, nq, R, d_heaps, d_heap_sizes, stream);
+}
+hipError_t launch_replay_heap_wave_states(const QueryState* d_qs, const uint64_t* d_stream, uint32_t out_cap, int nq, uint32_t R,
+                                          uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
+    return launch_replay_wave_t<2>(d_stream, nullptr, nullptr, reinterpret_cast<const uint32_t*>(d_qs), out_cap, nq, R, d_heaps,
+                                   d_heap_sizes, stream);
 }
 
 // The world's gathered blocks -> heaps: totals + prefix, interleave into global scan order, wave-per-query replay.
