@@ -360,7 +360,10 @@ struct qadc_index {
     int device_replay_alone_nq = 512;    // ... a batch with nothing else in flight (a synchronous call): from this many
     uint64_t front_run_max = 2u << 20;   // leading levels whose runs are at most this long join the front (0 = none); they are
                                          // counted with the small launches, not event-timed.  125M x 32: 2 Mi -4 %, 8 Mi +1 %
-    uint64_t front_min_batch = 0;        // ... in batches of at least this many (code, query) pairs
+    uint64_t front_min_batch = 3000000000ull;   // ... in batches of at least this many (code, query) pairs: under a last level
+                                         // of a few hundred microseconds the early levels hide; under a shorter one they only make the front
+                                         // stream the longest chain of the step (32 queries per step: 3e7 codes 0.42 -> 0.37 ms with
+                                         // everything on the main stream, 6e7 0.64 -> 0.62, 1.25e8 1.12 -> 1.14: tools/front_run_ab.sh)
     int prescan_mq = 1;                  // ... and so does the float pre-scan when every query pre-scans the same starts
     uint32_t mq_codes_per_wg = 1u << 16;
     uint32_t mq_min_wgs = 4096;          // workgroups a multi-query launch should have at least (2 rounds of the chip)
