@@ -1916,7 +1916,7 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
     // queries are independent: large batches (IVF) are replayed by a few host threads, the caller still
     // drives the library from one thread
     const uint64_t pushes = s.out_off[s.nq];
-    int nt = idx->replay_threads > 0 ? idx->replay_threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 8);
+    int nt = idx->replay_threads > 0 ? idx->replay_threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 16);   // (10M-code list, 32 queries per step: 8 -> 16 threads 0.260 -> 0.231 ms per step)
     nt = std::max(1, std::min(nt, s.nq / 2));
     if (pushes < 4000) nt = 1;                                 // (waking the workers costs about as much as 4 K pushes)
     // tasks of a few queries each, handed out dynamically: candidate counts differ from query to query
