@@ -97,7 +97,7 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * "device_replay_alone_nq" (... from this many when nothing else is in flight: a synchronous call), "replay_threads",
  * "replay_wave" (device replay of the query kernel's streams: 1 one wave per query with the heap in registers — default — 0 one lane per query, heaps in LDS);
  * the one-workgroup-per-query path: "wgq" (0 never, 1 auto, 2 always), "wgq_min_nq", "wgq_max_codes",
- * "wgq_small_codes", "wgq_capacity", "wgq_cand_cap", "wgq_variant", "wgq_split" / "wgq_split_codes" (workgroups a
+ * "wgq_small_codes", "wgq_capacity", "wgq_cand_cap", "wgq_group_cand_cap", "wgq_variant", "wgq_split" / "wgq_split_codes" (workgroups a
  * small batch spreads one query over / codes each keeps at least), "wgq_inline" (a lone small query's input rides
  * in the kernel arguments), "wgq_poll" (... and its completion is read from the mapped result block),
  * "wgq_group" (large IVF batches: partition-major second phase; 0 never, 1 auto, 2 whenever possible),

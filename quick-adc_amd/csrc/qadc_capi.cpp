@@ -373,7 +373,7 @@ struct qadc_index {
     int wgq_poll = 1;      // ... and its completion is read from the result block, not from the event
     int group_strikes = 0; // grouped batches whose candidate regions overflowed (data whose later probes fall below the head's bound)
     int wgq_group = 1;     // partition-major second phase for large IVF batches: 0 never, 1 auto, 2 whenever possible
-    int wgq_group_head = 4;   // ... after a head of this many probes per query (one workgroup per query)
+    int wgq_group_head = 3;   // ... after a head of this many probes per query (one workgroup per query; 4 until the ordering pass took 8192 candidates)
     int wgq_group_head_dist = 4;   // ... under the multi-GPU merge (probes with codes on this rank; option "wgq_group_head_dist")
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
     int mq_narrow = 1;     // IVF second phase: groups whose upper four seats are empty run the 4-seat form (the two-body build of the kernel)
@@ -402,6 +402,7 @@ struct qadc_index {
     int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
     int table_form = 2;                  // float tables of qadc_search: 0 direct, 1 BLAS expansion, 2 the reference's nns_engine rule
     uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)
+    uint32_t wgq_group_cand_cap = kOrderCandCap;   // ... of a batch with the partition-major second phase (option "wgq_group_cand_cap")
     DevBuf<PartDesc> d_partdesc;         // device partition table (qadc_index_finalize)
     std::vector<PartDesc> h_partdesc;    // its host copy (a lone small query carries the descriptors it needs in its launch)
     uint32_t max_start_n = 0;
@@ -1207,7 +1208,10 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         const size_t ngroups = ivf_max_groups(pairs, nparts);
         if (ngroups * 8 >= (1ull << 31)) return fail(QADC_E_CAPACITY, "too many (query, probe) pairs for one batch");
         HIPCHECK(s.d_state.ensure(state_bytes));
-        HIPCHECK(s.d_cands.ensure((size_t)nq * ccap));
+        // (the ordering pass of this path sorts up to kOrderCandCap candidates per query — twice what the query kernel's own tail
+        // takes; a cap the caller lowered — the tests' way to force the fallback — is honoured)
+        const uint32_t gcap = idx->wgq_cand_cap < kQueryCandCap ? idx->wgq_cand_cap : std::min<uint32_t>(idx->wgq_group_cand_cap, kOrderCandCap);
+        HIPCHECK(s.d_cands.ensure((size_t)nq * gcap));
         HIPCHECK(s.d_gplan.ensure(3 * nparts + 1));
         HIPCHECK(s.d_gitems.ensure(ngroups * 8));
         s.d_hdr = reinterpret_cast<CandHeader*>(s.d_state.p);
@@ -1225,7 +1229,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         H.head_slots = (uint32_t)head_slots;
         H.qstates = s.d_qs;
         H.cand_regions = s.d_cands.p;
-        H.cand_cap = ccap;
+        H.cand_cap = gcap;
         H.hdr = s.d_hdr;
         H.G = 1;
         // (profile: one event before and after each of the three launches — prof_ev[1..4]; ~10 us of stream time each)
@@ -1233,10 +1237,10 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
         const int wgs = (int)std::max<uint64_t>(1, ((uint64_t)idx->max_part_n + idx->mq_codes_per_wg - 1) / idx->mq_codes_per_wg);
-        launch_scan_i8_mq(M, s.d_gitems.p, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, ccap, (uint32_t)s.R, st,
+        launch_scan_i8_mq(M, s.d_gitems.p, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, gcap, (uint32_t)s.R, st,
                           idx->mq_narrow);
         if (idx->profile) HIPCHECK(prof_event(s, st));
-        HIPCHECK(launch_order_cands(s.d_qs, s.d_cands.p, ccap, ccap, nq, s.d_stream.p, cap, s.d_qout, s.d_qflags.p, st));
+        HIPCHECK(launch_order_cands(s.d_qs, s.d_cands.p, gcap, gcap, nq, s.d_stream.p, cap, s.d_qout, s.d_qflags.p, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
         s.group_head_slots = head_slots;
         idx->prof.group_launches++;
@@ -2310,6 +2314,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
         idx->dist->inject_failure = value != 0;
     }
     else if (n == "table_form") idx->table_form = std::max(0, std::min((int)value, 2));
+    else if (n == "wgq_group_cand_cap") idx->wgq_group_cand_cap = (uint32_t)std::max(64.0, std::min(value, (double)kOrderCandCap));
     else if (n == "wgq_cand_cap") idx->wgq_cand_cap = (uint32_t)std::max(1.0, std::min(value, (double)kQueryCandCap));
     else if (n == "wgq_min_nq") idx->wgq_min_nq = (int)std::max(value, 1.0);
     else if (n == "wgq_max_codes") idx->wgq_max_codes = (uint64_t)std::max(value, 0.0);

@@ -177,19 +177,21 @@ __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint
 // padding-lane replays and writes the push stream: the tail of scan_query_kernel, and all of order_cands_kernel.
 // load(i) -> QCand of the i-th unordered candidate; needs ncand <= kQueryCandCap; returns the entries written
 // (replays included; entries beyond `cap` are counted, not stored).  Uses qsmem[0 .. 64 KiB) and wcnt[16].
-template <typename Load>
+// LOGCAP: log2 of the most candidates taken — 12 inside scan_query_kernel (64 KiB of LDS), 13 in order_cands_kernel (128 KiB).
+template <int LOGCAP, typename Load>
 __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand, uint64_t* __restrict__ stream, uint32_t cap,
                                                       uint32_t* wcnt, uint32_t tid, uint32_t lane, uint32_t wave) {
     uint32_t out_count = 0;
-    uint64_t* skey = reinterpret_cast<uint64_t*>(qsmem);             // [n2] (slot << 44 | pos << 12 | index)
-    uint64_t* spay = reinterpret_cast<uint64_t*>(qsmem + 32768);     // [ncand] key | val << 32 | reps << 40 | slot << 48
+    constexpr uint32_t kCap = 1u << LOGCAP, kPer = kCap / kQWG;      // entries per thread in the write-out
+    uint64_t* skey = reinterpret_cast<uint64_t*>(qsmem);             // [n2] (slot << (32 + LOGCAP) | pos << LOGCAP | index)
+    uint64_t* spay = reinterpret_cast<uint64_t*>(qsmem + kCap * 8);  // [ncand] key | val << 32 | reps << 40 | slot << 48
     uint32_t n2 = 64;
     while (n2 < ncand) n2 <<= 1;
     for (uint32_t i = tid; i < n2; i += kQWG) {
         uint64_t k = ~0ull;
         if (i < ncand) {
             const QCand c = load(i);
-            k = ((uint64_t)c.slot << 44) | ((uint64_t)c.pos << 12) | i;
+            k = ((uint64_t)c.slot << (32 + LOGCAP)) | ((uint64_t)c.pos << LOGCAP) | i;
             spay[i] = (uint64_t)c.key | ((uint64_t)(c.val_reps & 0xfffu) << 32) | ((uint64_t)c.slot << 48);
         }
         skey[i] = k;
@@ -229,15 +231,15 @@ __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand,
             else q_lds_barrier();
         }
     q_lds_barrier();
-    // expand the padding-lane replays while writing: thread t owns sorted entries [4t, 4t+4)
-    uint64_t pay[4];
+    // expand the padding-lane replays while writing: thread t owns sorted entries [kPer * t, kPer * (t + 1))
+    uint64_t pay[kPer];
     uint32_t mine = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t i = tid * 4u + u;
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint32_t i = tid * kPer + u;
         pay[u] = 0;
         if (i < ncand) {
-            pay[u] = spay[skey[i] & 0xfffu];
+            pay[u] = spay[skey[i] & (kCap - 1u)];
             mine += 1u + ((uint32_t)(pay[u] >> 40) & 15u);
         }
     }
@@ -251,8 +253,8 @@ __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand,
         out_count += c_;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t i = tid * 4u + u;
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint32_t i = tid * kPer + u;
         if (i < ncand) {
             const uint32_t reps = 1u + ((uint32_t)(pay[u] >> 40) & 15u);
             const uint64_t en = (pay[u] & 0xffffffffffull & ~(0xffull << 40)) | ((pay[u] >> 48) << 40);
@@ -1013,7 +1015,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     if (ncand > A.ccap) {
         flags |= 32u;                                            // more candidates than the in-workgroup sort takes: host falls back
     } else if (ncand) {
-        out_count = q_order_and_write([&](uint32_t i) { return cands[i]; }, ncand, stream, A.cap, wcnt, tid, lane, wave);
+        out_count = q_order_and_write<12>([&](uint32_t i) { return cands[i]; }, ncand, stream, A.cap, wcnt, tid, lane, wave);
     }
     STAMP(14);
     s_count = out_count;
@@ -1167,7 +1169,7 @@ __global__ __launch_bounds__(kQWG) void order_cands_kernel(const QueryState* __r
     if (n > min(cand_cap, ccap)) {
         flags |= 32u;                                            // more than the in-workgroup sort takes (or the region held): host falls back
     } else if (n) {
-        out_count = q_order_and_write(
+        out_count = q_order_and_write<13>(
             [&](uint32_t i) {
                 const Cand c = region[i];
                 QCand o;
@@ -1840,9 +1842,9 @@ void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, i
 hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uint32_t cand_cap, uint32_t ccap, int nq,
                               uint64_t* d_stream, uint32_t cap, QueryOut* d_qout, uint32_t* d_qflags, hipStream_t stream) {
     static std::atomic<uint64_t> done{0};
-    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&order_cands_kernel), 65536, done);
+    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&order_cands_kernel), 2 * kOrderCandCap * 8, done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(order_cands_kernel, dim3(nq), dim3(kQWG), 65536, stream, d_qs, d_regions, cand_cap, ccap, d_stream, cap,
+    hipLaunchKernelGGL(order_cands_kernel, dim3(nq), dim3(kQWG), 2 * kOrderCandCap * 8, stream, d_qs, d_regions, cand_cap, ccap, d_stream, cap,
                        d_qout, d_qflags);
     return hipGetLastError();
 }

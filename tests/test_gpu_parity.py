@@ -834,6 +834,54 @@ def test_wgq_stream_capacity_regrow_is_exact(pyqadc, po, M):
 
 
 @pytest.mark.gpu
+def test_grouped_second_phase_orders_more_than_4096_candidates_per_query(pyqadc, po):
+    """Partition-major second phase with a deliberately loose bound (head of ONE small partition, then five probes of
+    9000 codes whose share below that bound runs into the thousands): some queries end up with 4097 .. 8192 candidates,
+    which the ordering pass of this path takes (order_cands_kernel: 128 KiB of LDS, 8 entries per thread) where the
+    query kernel's own tail stops at 4096 — no fallback, heaps equal the oracle's."""
+    rng = np.random.default_rng(4242)
+    M, nq, ma, R, keep = 16, 72, 6, 100, 0.05
+    sizes = [400] + [9000] * 11
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    labels = [rng.permutation(1 << 22)[:n].astype(np.uint32) for n in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(keep)
+    for k, v in (("wgq", 2), ("wgq_group", 2), ("wgq_group_head", 1), ("device_replay_alone_nq", 0), ("profile", 1)):
+        idx.set_option(k, v)                               # (device_replay_alone_nq: the grouped phase needs the device replay)
+    assign = np.stack([np.concatenate([[0], rng.permutation(np.arange(1, 12))[:ma - 1]]) for _ in range(nq)]).astype(np.int32)
+    tables = float_tables(rng, nq, ma, M, scale=1.0)
+    tables[:, 1:, :] *= np.float32(1.3)                    # (later probes mostly above the head's values: tuned so that no query passes 8192)
+    res = idx.query_scan(assign, tables.copy(), R)
+    pr = idx.profile()
+    assert pr["group_launches"] >= 1 and pr["group_fallbacks"] == 0, pr
+    estimate = []                                          # candidates per query under a bound drawn from the head alone
+    for q in range(nq):
+        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
+        assert want["rc"] == res["status"][q]
+        if want["rc"]:
+            continue
+        assert heaps_equal(res["heaps"][q], (want["keys"], want["values"])), q
+        qt = want["qtables"].reshape(ma, M * 16)
+        head = po.candidates_i8(M, parts[0], qt[0]).astype(np.int32)
+        hs = np.sort(head[head < 127])
+        bound = hs[R - 2] if len(hs) >= R - 1 else 127
+        estimate.append(int((head < 127).sum()) + sum(int((po.candidates_i8(M, parts[assign[q][a]], qt[a]).astype(np.int32) < bound).sum())
+                                                        for a in range(1, ma)))
+    assert max(estimate) > 5000 and sum(e > 4096 for e in estimate) >= 2, sorted(estimate)[-5:]   # (what the case is for)
+    # ... and with the ordering pass held to the query kernel's 4096 the same batch does fall back (and still ends right)
+    idx.set_option("wgq_group_cand_cap", 4096)
+    idx.profile_reset()
+    res2 = idx.query_scan(assign, tables.copy(), R)
+    assert idx.profile()["group_fallbacks"] >= 1
+    for q in range(nq):
+        assert res2["status"][q] == res["status"][q]
+        if res["status"][q] == 0:
+            assert heaps_equal(res2["heaps"][q], res["heaps"][q]), q
+    idx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R", [100, 288, 289, 320, 321])
 def test_device_replay_of_a_query_kernel_batch_at_the_heap_sizes_around_its_limits(pyqadc, po, R):
     """70 queries through the one-workgroup-per-query path with the heap replay on the device (>= 64 queries): R up to
