@@ -104,7 +104,7 @@ struct QCand {
     uint32_t slot;      // assign slot
 };
 constexpr uint32_t kQueryCandCap = 4096;   // candidates per query the in-workgroup sort takes (64 KiB of LDS)
-constexpr uint32_t kOrderCandCap = 8192;   // ... and order_cands_kernel, the ordering pass of the partition-major second phase (128 KiB)
+constexpr uint32_t kOrderCandCap = 8192;   // ... and order_cands_kernel, the ordering pass of the partition-major second phase (64 KiB of keys)
 
 struct QueryKernelArgs {
     const PartDesc* parts;

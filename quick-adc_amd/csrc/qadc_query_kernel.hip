@@ -177,8 +177,11 @@ __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint
 // padding-lane replays and writes the push stream: the tail of scan_query_kernel, and all of order_cands_kernel.
 // load(i) -> QCand of the i-th unordered candidate; needs ncand <= kQueryCandCap; returns the entries written
 // (replays included; entries beyond `cap` are counted, not stored).  Uses qsmem[0 .. 64 KiB) and wcnt[16].
-// LOGCAP: log2 of the most candidates taken — 12 inside scan_query_kernel (64 KiB of LDS), 13 in order_cands_kernel (128 KiB).
-template <int LOGCAP, typename Load>
+// LOGCAP: log2 of the most candidates taken — 12 inside scan_query_kernel, 13 in order_cands_kernel.
+// PAYLDS: the payloads wait in LDS beside the sort keys (64 KiB in all at LOGCAP 12); false: they are fetched again through
+// load() when the stream is written (order_cands_kernel: its candidates lie in global memory the second phase has just
+// written — L2 — and keys alone let two workgroups share a CU at 8192 candidates, where keys + payloads left room for one).
+template <int LOGCAP, bool PAYLDS, typename Load>
 __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand, uint64_t* __restrict__ stream, uint32_t cap,
                                                       uint32_t* wcnt, uint32_t tid, uint32_t lane, uint32_t wave) {
     uint32_t out_count = 0;
@@ -192,7 +195,7 @@ __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand,
         if (i < ncand) {
             const QCand c = load(i);
             k = ((uint64_t)c.slot << (32 + LOGCAP)) | ((uint64_t)c.pos << LOGCAP) | i;
-            spay[i] = (uint64_t)c.key | ((uint64_t)(c.val_reps & 0xfffu) << 32) | ((uint64_t)c.slot << 48);
+            if (PAYLDS) spay[i] = (uint64_t)c.key | ((uint64_t)(c.val_reps & 0xfffu) << 32) | ((uint64_t)c.slot << 48);
         }
         skey[i] = k;
     }
@@ -239,7 +242,12 @@ __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand,
         const uint32_t i = tid * kPer + u;
         pay[u] = 0;
         if (i < ncand) {
-            pay[u] = spay[skey[i] & (kCap - 1u)];
+            if (PAYLDS) {
+                pay[u] = spay[skey[i] & (kCap - 1u)];
+            } else {
+                const QCand c = load((uint32_t)skey[i] & (kCap - 1u));
+                pay[u] = (uint64_t)c.key | ((uint64_t)(c.val_reps & 0xfffu) << 32) | ((uint64_t)c.slot << 48);
+            }
             mine += 1u + ((uint32_t)(pay[u] >> 40) & 15u);
         }
     }
@@ -1015,7 +1023,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     if (ncand > A.ccap) {
         flags |= 32u;                                            // more candidates than the in-workgroup sort takes: host falls back
     } else if (ncand) {
-        out_count = q_order_and_write<12>([&](uint32_t i) { return cands[i]; }, ncand, stream, A.cap, wcnt, tid, lane, wave);
+        out_count = q_order_and_write<12, true>([&](uint32_t i) { return cands[i]; }, ncand, stream, A.cap, wcnt, tid, lane, wave);
     }
     STAMP(14);
     s_count = out_count;
@@ -1169,7 +1177,7 @@ __global__ __launch_bounds__(kQWG) void order_cands_kernel(const QueryState* __r
     if (n > min(cand_cap, ccap)) {
         flags |= 32u;                                            // more than the in-workgroup sort takes (or the region held): host falls back
     } else if (n) {
-        out_count = q_order_and_write<13>(
+        out_count = q_order_and_write<13, false>(
             [&](uint32_t i) {
                 const Cand c = region[i];
                 QCand o;
@@ -1842,9 +1850,9 @@ void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, i
 hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uint32_t cand_cap, uint32_t ccap, int nq,
                               uint64_t* d_stream, uint32_t cap, QueryOut* d_qout, uint32_t* d_qflags, hipStream_t stream) {
     static std::atomic<uint64_t> done{0};
-    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&order_cands_kernel), 2 * kOrderCandCap * 8, done);
+    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&order_cands_kernel), kOrderCandCap * 8, done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(order_cands_kernel, dim3(nq), dim3(kQWG), 2 * kOrderCandCap * 8, stream, d_qs, d_regions, cand_cap, ccap, d_stream, cap,
+    hipLaunchKernelGGL(order_cands_kernel, dim3(nq), dim3(kQWG), kOrderCandCap * 8, stream, d_qs, d_regions, cand_cap, ccap, d_stream, cap,
                        d_qout, d_qflags);
     return hipGetLastError();
 }
