@@ -837,7 +837,7 @@ def test_wgq_stream_capacity_regrow_is_exact(pyqadc, po, M):
 def test_grouped_second_phase_orders_more_than_4096_candidates_per_query(pyqadc, po):
     """Partition-major second phase with a deliberately loose bound (head of ONE small partition, then five probes of
     9000 codes whose share below that bound runs into the thousands): some queries end up with 4097 .. 8192 candidates,
-    which the ordering pass of this path takes (order_cands_kernel: 128 KiB of LDS, 8 entries per thread) where the
+    which the ordering pass of this path takes (order_cands_kernel: 8192 sort keys in LDS, 8 entries per thread) where the
     query kernel's own tail stops at 4096 — no fallback, heaps equal the oracle's."""
     rng = np.random.default_rng(4242)
     M, nq, ma, R, keep = 16, 72, 6, 100, 0.05
