@@ -1221,7 +1221,10 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         HIPCHECK(hipMemsetAsync(s.d_gitems.p, 0, sizeof(ScanItem) * ngroups * 8, st));
         // (tried: the plan — two clears + count / offsets / scatter, needed by the second phase only — on a stream of its own
         // under the head launch: its workgroups then wait for head workgroups to retire and the second phase for them;
-        // C3 0.75 -> 1.05 us per query, one of 8 ranks 0.72 -> 1.51 ms per batch)
+        // C3 0.75 -> 1.05 us per query, one of 8 ranks 0.72 -> 1.51 ms per batch.  Tried as well: table build, clears and
+        // plan of a qadc_search batch on the front stream, enqueued under the PREVIOUS batch's scan — ~100 us of the scan
+        // stream per batch to win, but the dozen small launches trickle through that scan so slowly that the next head
+        // ends up waiting for them: C3 0.75 -> 0.91 us per query, C5 4.63 -> 4.82.)
         launch_ivf_plan(A.assign, idx->d_partdesc.p, nq, ma, head_slots, (int)nparts, s.d_gplan.p, s.d_gplan.p + 2 * nparts,
                         s.d_gplan.p + nparts, s.d_gitems.p, st);
         QueryKernelArgs H = A;
