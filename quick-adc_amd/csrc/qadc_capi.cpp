@@ -177,8 +177,6 @@ struct Slot {
     DevBuf<float> d_ftables;            // float tables built on the device (qadc_search)
     DevBuf<int8_t> d_qtables;
     DevBuf<Cand> d_cands;
-    DevBuf<uint32_t> d_gplan;           // grouped second phase: [cnt K][fill K][goff K+1]
-    DevBuf<ScanItem> d_gitems;          // ... its device-planned ScanItem groups
     bool wgq_grouped = false;           // the batch took the partition-major second phase
     int group_head_slots = 0;           // ... after a head of this many local probes per query
     DevBuf<float> d_fc;
@@ -1207,26 +1205,29 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         const size_t state_bytes = 64 + sizeof(QueryState) * (size_t)nq;
         const size_t ngroups = ivf_max_groups(pairs, nparts);
         if (ngroups * 8 >= (1ull << 31)) return fail(QADC_E_CAPACITY, "too many (query, probe) pairs for one batch");
-        HIPCHECK(s.d_state.ensure(state_bytes));
+        // query states, plan counters and group items in ONE allocation: one clear instead of three (every launch between
+        // two batches' scans costs the scan stream ~10 us)
+        auto up256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t gplan_off = up256(state_bytes), gplan_bytes = sizeof(uint32_t) * (3 * nparts + 1);
+        const size_t gitems_off = up256(gplan_off + gplan_bytes), gitems_bytes = sizeof(ScanItem) * ngroups * 8;
+        HIPCHECK(s.d_state.ensure(gitems_off + gitems_bytes));
+        uint32_t* d_gplan = reinterpret_cast<uint32_t*>(s.d_state.p + gplan_off);
+        ScanItem* d_gitems = reinterpret_cast<ScanItem*>(s.d_state.p + gitems_off);
         // (the ordering pass of this path sorts up to kOrderCandCap candidates per query — twice what the query kernel's own tail
         // takes; a cap the caller lowered — the tests' way to force the fallback — is honoured)
         const uint32_t gcap = idx->wgq_cand_cap < kQueryCandCap ? idx->wgq_cand_cap : std::min<uint32_t>(idx->wgq_group_cand_cap, kOrderCandCap);
         HIPCHECK(s.d_cands.ensure((size_t)nq * gcap));
-        HIPCHECK(s.d_gplan.ensure(3 * nparts + 1));
-        HIPCHECK(s.d_gitems.ensure(ngroups * 8));
         s.d_hdr = reinterpret_cast<CandHeader*>(s.d_state.p);
         s.d_qs = reinterpret_cast<QueryState*>(s.d_state.p + 64);
-        HIPCHECK(hipMemsetAsync(s.d_state.p, 0, state_bytes, st));
-        HIPCHECK(hipMemsetAsync(s.d_gplan.p, 0, sizeof(uint32_t) * (3 * nparts + 1), st));
-        HIPCHECK(hipMemsetAsync(s.d_gitems.p, 0, sizeof(ScanItem) * ngroups * 8, st));
+        HIPCHECK(hipMemsetAsync(s.d_state.p, 0, gitems_off + gitems_bytes, st));
         // (tried: the plan — two clears + count / offsets / scatter, needed by the second phase only — on a stream of its own
         // under the head launch: its workgroups then wait for head workgroups to retire and the second phase for them;
         // C3 0.75 -> 1.05 us per query, one of 8 ranks 0.72 -> 1.51 ms per batch.  Tried as well: table build, clears and
         // plan of a qadc_search batch on the front stream, enqueued under the PREVIOUS batch's scan — ~100 us of the scan
         // stream per batch to win, but the dozen small launches trickle through that scan so slowly that the next head
         // ends up waiting for them: C3 0.75 -> 0.91 us per query, C5 4.63 -> 4.82.)
-        launch_ivf_plan(A.assign, idx->d_partdesc.p, nq, ma, head_slots, (int)nparts, s.d_gplan.p, s.d_gplan.p + 2 * nparts,
-                        s.d_gplan.p + nparts, s.d_gitems.p, st);
+        launch_ivf_plan(A.assign, idx->d_partdesc.p, nq, ma, head_slots, (int)nparts, d_gplan, d_gplan + 2 * nparts,
+                        d_gplan + nparts, d_gitems, st);
         QueryKernelArgs H = A;
         H.head_codes = ~0ull;
         H.head_slots = (uint32_t)head_slots;
@@ -1240,7 +1241,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
         const int wgs = (int)std::max<uint64_t>(1, ((uint64_t)idx->max_part_n + idx->mq_codes_per_wg - 1) / idx->mq_codes_per_wg);
-        launch_scan_i8_mq(M, s.d_gitems.p, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, gcap, (uint32_t)s.R, st,
+        launch_scan_i8_mq(M, d_gitems, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, gcap, (uint32_t)s.R, st,
                           idx->mq_narrow);
         if (idx->profile) HIPCHECK(prof_event(s, st));
         HIPCHECK(launch_order_cands(s.d_qs, s.d_cands.p, gcap, gcap, nq, s.d_stream.p, cap, s.d_qout, s.d_qflags.p, st));
@@ -2010,7 +2011,6 @@ int qadc_index_destroy(qadc_index* idx) {
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
         s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
         s.h_cands.release(); s.d_stream.release(); s.d_qflags.release(); s.d_fvals.release(); s.d_qcands.release(); s.h_fetch.release();
-        s.d_gplan.release(); s.d_gitems.release();
         s.d_fblock.release(); s.d_fgathered.release(); s.d_front_all.release(); s.h_fmap.release();
         if (s.ev_fa) (void)hipEventDestroy(s.ev_fa);
         if (s.ev_fb) (void)hipEventDestroy(s.ev_fb);
