@@ -337,9 +337,6 @@ int load_rccl(DistState& d, std::string& err) {
 struct qadc_index {
     int M = 16, cs = 8, device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream_n = nullptr;     // scans of one-workgroup-per-query batches under the multi-GPU merge: NORMAL priority, the
-                                        // merge streams' (interleave / replay kernels).  On the lowest-priority stream the short
-                                        // launches between two batches' scans waited behind replay waves.
     hipStream_t front_stream = nullptr; // a batch's pre-scan/quantize chain, under the previous batch's streaming launches
     hipStream_t copy_stream = nullptr;  // uploads and on-demand copies: issued where they depend on nothing (see plan_and_launch)
     uint32_t replay_seq = 0;            // device replays alternate between two side streams in submission order
@@ -377,7 +374,6 @@ struct qadc_index {
     int wgq_group_head = 3;   // ... after a head of this many probes per query (one workgroup per query; 4 until the ordering pass took 8192 candidates)
     int wgq_group_head_dist = 4;   // ... under the multi-GPU merge (probes with codes on this rank; option "wgq_group_head_dist")
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
-    int dist_scan_normal = 1; // (option "dist_scan_normal")
     int mq_narrow = 1;     // IVF second phase: groups whose upper four seats are empty run the 4-seat form (the two-body build of the kernel)
     int replay_wave = 1;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
                            // (C3 shape, 1024-query batches: lanes 0.78 us per query, waves 0.75; C5 shape: 4.83 vs 4.67 — since
@@ -1068,7 +1064,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     const uint32_t ccap = std::min<uint32_t>(idx->wgq_cand_cap, kQueryCandCap);
     HIPCHECK(s.d_qcands.ensure((size_t)nsub * ccap));
 
-    hipStream_t st = (idx->dist && idx->dist_scan_normal) ? idx->stream_n : idx->stream;
+    hipStream_t st = idx->stream;
     // A lone small query (the synchronous single-query call): its input — which partitions, their descriptors, the
     // float tables — fits the kernel-argument segment and rides in the dispatch packet; no copy precedes the launch.
     alignas(16) unsigned char inl[kInlineBytes];
@@ -1975,10 +1971,7 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     // the caller's own streams (the RCCL gather of the multi-GPU merge).
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    // (created FIRST: HIP maps streams to its few hardware queues by creation order, and the queue this one gets decides
-    // whether the merge streams created later by qadc_dist_init share it — see DistState)
-    hipError_t e = hipStreamCreateWithPriority(&idx->stream_n, hipStreamNonBlocking, (prio_least + prio_greatest) / 2);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&idx->stream, hipStreamNonBlocking, prio_least);
+    hipError_t e = hipStreamCreateWithPriority(&idx->stream, hipStreamNonBlocking, prio_least);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&idx->copy_stream, hipStreamNonBlocking, prio_greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&idx->sort_stream, hipStreamNonBlocking, prio_greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&idx->front_stream, hipStreamNonBlocking, prio_greatest);
@@ -1994,7 +1987,7 @@ int qadc_index_destroy(qadc_index* idx) {
     if (!idx) return QADC_OK;
     (void)hipSetDevice(idx->device);
     // a pre-scan (front stream) or an on-demand copy may still be in flight: drain all four streams before freeing
-    for (hipStream_t st : {idx->stream, idx->stream_n, idx->front_stream, idx->copy_stream, idx->sort_stream})
+    for (hipStream_t st : {idx->stream, idx->front_stream, idx->copy_stream, idx->sort_stream})
         if (st) (void)hipStreamSynchronize(st);
     (void)qadc_dist_shutdown(idx);      // drains the merge's stream and frees the communicator while the index's streams and
                                         // the slot buffers the pack kernel reads are still alive
@@ -2031,7 +2024,6 @@ int qadc_index_destroy(qadc_index* idx) {
         for (auto e : s.prof_ev) (void)hipEventDestroy(e);
     }
     (void)hipStreamDestroy(idx->stream);
-    if (idx->stream_n) (void)hipStreamDestroy(idx->stream_n);
     if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
     if (idx->front_stream) (void)hipStreamDestroy(idx->front_stream);
     if (idx->sort_stream) (void)hipStreamDestroy(idx->sort_stream);
@@ -2280,7 +2272,6 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "wgq_inline") idx->wgq_inline = value != 0;
     else if (n == "replay_wave") idx->replay_wave = value != 0;
     else if (n == "mq_narrow") idx->mq_narrow = value != 0;
-    else if (n == "dist_scan_normal") idx->dist_scan_normal = value != 0;
     else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);
     else if (n == "wgq_group") { idx->wgq_group = (int)std::max(0.0, std::min(value, 2.0)); idx->group_strikes = 0; }
     else if (n == "wgq_group_head") idx->wgq_group_head = idx->wgq_group_head_dist = (int)std::max(1.0, std::min(value, 4096.0));
@@ -3046,7 +3037,6 @@ int qadc_dist_shutdown(qadc_index* idx) {
     if (!idx || !idx->dist) return QADC_OK;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    if (idx->stream_n) (void)hipStreamSynchronize(idx->stream_n);
     DistState* d = idx->dist;
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamSynchronize(m);
