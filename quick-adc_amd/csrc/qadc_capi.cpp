@@ -2920,10 +2920,13 @@ int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
-    // (NORMAL priority on purpose: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
-    // queue as the collectives' stream the replay would still sit in front of the next batch's gather — seen in the trace)
+    // (NOT the collectives' priority: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
+    // queue as the collectives' stream a replay sat in front of the next batch's gather — seen in the trace.  And not ABOVE
+    // the scans either: at normal priority the interleave / replay waves held up the short launches between two batches'
+    // scans on the lowest-priority scan stream — one of 8 ranks, 1024-query batches, C5 shape 1.18 -> 1.10 ms, C3 0.70 ->
+    // 0.60 with the merges at the scans' own, lowest priority.)
     for (int i = 0; i < kSlots; ++i)
-        HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream[i], hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
+        HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream[i], hipStreamNonBlocking, prio_least));
     // RCCL finishes setting up its channels lazily, inside the first collectives of a communicator (the very first
     // all-gather takes ~8 ms); a few throw-away gathers here keep that out of the first batches' collect calls.
     {
@@ -2972,10 +2975,13 @@ int qadc_dist_init_transport(qadc_index* idx, int rank, int world, qadc_allgathe
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
-    // (NORMAL priority on purpose: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
-    // queue as the collectives' stream the replay would still sit in front of the next batch's gather — seen in the trace)
+    // (NOT the collectives' priority: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
+    // queue as the collectives' stream a replay sat in front of the next batch's gather — seen in the trace.  And not ABOVE
+    // the scans either: at normal priority the interleave / replay waves held up the short launches between two batches'
+    // scans on the lowest-priority scan stream — one of 8 ranks, 1024-query batches, C5 shape 1.18 -> 1.10 ms, C3 0.70 ->
+    // 0.60 with the merges at the scans' own, lowest priority.)
     for (int i = 0; i < kSlots; ++i)
-        HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream[i], hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
+        HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream[i], hipStreamNonBlocking, prio_least));
     idx->dist = g.d.release();
     return QADC_OK;
 }
