@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_SO = os.path.join(_HERE, "libqadc_oracle.so")
 _REF_SO = os.path.join(_HERE, "_ref", "libqadc_ref.so")
+_REF_IO_SO = os.path.join(_HERE, "_ref", "libqadc_ref_io.so")
 
 u8p = C.POINTER(C.c_uint8)
 i8p = C.POINTER(C.c_int8)
@@ -27,7 +28,7 @@ def build(force=False):
     if force or not os.path.exists(_ORACLE_SO) or \
             os.path.getmtime(_ORACLE_SO) < os.path.getmtime(os.path.join(_HERE, "qadc_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "libqadc_oracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_SO)):
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_SO) or not os.path.exists(_REF_IO_SO)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -357,3 +358,87 @@ def ref_heap_replay_f32(keys, vals, R):
     ref().qadc_ref_heap_replay_f32(C.c_long(len(keys)), _p(keys, u32p), _p(vals, f32p), R,
                                    _p(ok, u32p), _p(ov, f32p), C.byref(osz))
     return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+# ----------------------------------------------------------------------------- reference build: vecs I/O + recall rule
+# oracle/_ref/libqadc_ref_io.so = the reference's vector_io.cpp / vector_io.hpp / recall.hpp compiled as they are
+# (oracle/ref_io_harness.cpp).  Pins host/qadc_io.hpp's vecs side and host/query_driver.hpp's recall rule.
+_ref_io = None
+
+
+def have_ref_io():
+    return os.path.exists(_REF_IO_SO)
+
+
+def ref_io():
+    global _ref_io
+    if _ref_io is None:
+        _ref_io = C.CDLL(_REF_IO_SO)
+        _ref_io.qadc_ref_io_free.argtypes = [C.c_void_p]
+        _ref_io.qadc_ref_io_free.restype = None
+    return _ref_io
+
+
+def _ref_io_take(ptr, ctype, dim, count, dtype):
+    n = dim.value * count.value
+    out = np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dtype, copy=True).reshape(count.value, dim.value)
+    ref_io().qadc_ref_io_free(C.cast(ptr, C.c_void_p))
+    return out
+
+
+def ref_load_vectors(filename):
+    """load_vectors_by_extension (vector_io.cpp:40-58) -> float32 [count][dim].  Exits the process on bad input: probe
+    with ref_try_load first."""
+    ptr, dim, count = f32p(), C.c_int(0), C.c_long(0)
+    rc = ref_io().qadc_ref_io_load(filename.encode(), C.byref(ptr), C.byref(dim), C.byref(count))
+    assert rc == 0
+    return _ref_io_take(ptr, C.c_float, dim, count, np.float32)
+
+
+def ref_load_ivecs(filename):
+    """load_vectors<int> as recall_file reads its ground truth (recall.hpp:37-39) -> int32 [count][dim]."""
+    ptr, dim, count = i32p(), C.c_int(0), C.c_long(0)
+    rc = ref_io().qadc_ref_io_load_ivecs(filename.encode(), C.byref(ptr), C.byref(dim), C.byref(count))
+    assert rc == 0
+    return _ref_io_take(ptr, C.c_int32, dim, count, np.int32)
+
+
+def ref_save_vectors(filename, arr):
+    """save_vectors<T> (vector_io.hpp:153-166), T by dtype: float32 / uint8 / int32."""
+    a = np.ascontiguousarray(arr)
+    fn = {np.dtype(np.float32): ("qadc_ref_io_save_f32", f32p), np.dtype(np.uint8): ("qadc_ref_io_save_u8", u8p),
+          np.dtype(np.int32): ("qadc_ref_io_save_i32", i32p)}[a.dtype]
+    getattr(ref_io(), fn[0])(filename.encode(), _p(a, fn[1]), C.c_int(a.shape[1]), C.c_long(a.shape[0]))
+
+
+def ref_try_load(filename):
+    """-> (exit code, stderr text) of a child process calling load_vectors_by_extension: the reference reports errors by
+    message + std::exit(1)."""
+    buf = C.create_string_buffer(4096)
+    rc = ref_io().qadc_ref_io_try_load(filename.encode(), buf, 4096)
+    return rc, buf.value.decode(errors="replace")
+
+
+def ref_read_chunked(filename, chunk_count, max_vectors, max_dim):
+    """The reference's vectors_reader driven like db_add.cpp:52-82 -> (data [count][dim], [(offset, count), ...])."""
+    for _ in range(20):
+        out = np.zeros(max_vectors * max_dim, np.float32)
+        offs, cnts = np.zeros(4096, np.uint32), np.zeros(4096, np.uint32)
+        nch, dim, total = C.c_int(0), C.c_int(0), C.c_uint(0)
+        rc = ref_io().qadc_ref_io_read_chunked(filename.encode(), C.c_uint(chunk_count), _p(out, f32p), C.c_long(out.size),
+                                               _p(offs, u32p), _p(cnts, u32p), 4096, C.byref(nch), C.byref(dim), C.byref(total))
+        if rc == 2:          # the reference's own done() window (see the harness): the loop ended a chunk early; again
+            continue
+        assert rc == 0, rc
+        return (out[:total.value * dim.value].reshape(total.value, dim.value).copy(),
+                [(int(offs[i]), int(cnts[i])) for i in range(nch.value)])
+    raise AssertionError("the reference's chunked reader kept ending early")
+
+
+def ref_check_labels(gt_filename, keys, t):
+    """recall_file(gt).check_labels(q, keys[q], keys[q] + n, t) for every query (recall.hpp:46-54) -> int32 [nq]."""
+    k = np.ascontiguousarray(keys, np.uint32)
+    out = np.zeros(k.shape[0], np.int32)
+    rc = ref_io().qadc_ref_io_check_labels(gt_filename.encode(), k.shape[0], _p(k, u32p), k.shape[1], t, _p(out, i32p))
+    assert rc == 0
+    return out

@@ -9,443 +9,18 @@
 //
 // The product path never touches oracle/: if the HIP runtime or the GPU is missing every entry
 // point fails loudly with QADC_E_HIP.
-#include "../../include/qadc.h"
-
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cfloat>
-#include <cstddef>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <condition_variable>
-#include <functional>
-#include <mutex>
-#include <memory>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../host/qadc_heap.hpp"
-#include "../host/worker_pool.hpp"
-#include "qadc_kernels.h"
+#include "qadc_host.h"
 
 using namespace qadc;
+using namespace qadc::host;
 
-namespace {
-
+namespace qadc {
+namespace host {
 thread_local std::string g_err;
-
-int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
 }
-
-#define HIPCHECK(expr)                                                                                   \
-    do {                                                                                                 \
-        hipError_t e_ = (expr);                                                                          \
-        if (e_ != hipSuccess)                                                                            \
-            return fail(QADC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
-    } while (0)
-
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
-        if (e == hipSuccess) cap = n;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-template <typename T>
-struct PinBuf {
-    T* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t n, unsigned flags = hipHostMallocDefault) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T), flags);
-        if (e == hipSuccess) cap = n;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-struct Part {
-    uint8_t* d_codes = nullptr;    // row-major codes of the local range
-    uint32_t* d_labels = nullptr;  // labels of the local range (or null)
-    uint8_t* d_starts = nullptr;   // replica of the global partition's first codes (null: d_codes, first_pos == 0)
-    uint32_t n = 0;                // codes held here
-    uint32_t global_n = 0;         // codes of the whole partition (== n unless sharded)
-    uint32_t first_pos = 0;        // global position of local code 0
-    uint32_t starts_cap = 0;       // codes available for the pre-scan
-    uint32_t start_n = 0;
-    uint32_t key_base = 0;
-    bool own = true;
-};
-
-constexpr int kSlots = 8;   // batches in flight: one being collected, one scanning, the others queued behind it with their fronts running
-                            // ahead.  Three or four cover every loop measured so far (deeper pipelines of the multi-GPU IVF loop — six,
-                            // eight batches — were tried and are no faster: its batches share the GPU, they do not wait for it)
-
-struct LevelLaunch {
-    size_t first;   // first item
-    int nitems;
-    int wgs;
-    uint64_t codes;
-    bool small;     // small-run kernel (runs below idx->small_run codes)
-    bool shared;    // every run of the launch covers the same codes (one run per query): sibling-major launch
-    bool mq;        // ... and groups of 8 of them share one pass (scan_i8_mq_kernel)
-    uint64_t maxn;  // longest run of the launch
-    bool early;     // launched on the front stream, under the previous batch's long levels: counted, not event-timed
-    int ev = -1;    // index of the HIP event recorded before the launch (the next one follows it), -1 = not timed
-};
-
-struct Slot {
-    bool busy = false;
-    bool has_result = false;            // collected streams not yet handed to the caller (capacity retry)
-    bool float_path = false;
-    int nq = 0, ma = 0, R = 0;
-    float* tables = nullptr;            // caller's float tables (float path)
-    std::vector<int32_t> assign;
-    std::vector<int8_t> qtables_in;     // int8 path input copy
-    uint32_t cap_q = 0;                 // candidate region entries per query
-    uint32_t out_cap = 0;               // entries of the device-sorted output
-
-    // one upload block per batch: [ScanItem items][StartItem starts][u32 fc_init[2 nq]][float or int8 tables]
-    DevBuf<unsigned char> d_in;
-    PinBuf<unsigned char> h_in;
-    ScanItem* d_items = nullptr;
-    StartItem* d_sitems = nullptr;
-    uint32_t* d_fc_init = nullptr;
-    float* d_ftables_in = nullptr;      // float tables inside d_in (host-table path)
-    // one state block, cleared by ONE memset: [CandHeader (64 B)][QueryState[nq]]
-    DevBuf<unsigned char> d_state;
-    CandHeader* d_hdr = nullptr;
-    QueryState* d_qs = nullptr;
-    // one result block in pinned, device-mapped HOST memory: [QueryOut[nq]][u64 entries[out_cap]].  The ordering
-    // kernel stores into it directly; there is no result copy (see plan_and_launch)
-    PinBuf<unsigned char> h_result;
-    unsigned char* h_result_mapped = nullptr;   // the allocation d_result_mapped was looked up for
-    unsigned char* d_result_mapped = nullptr;
-    QueryOut* d_qout = nullptr;         // device-side addresses of h_qout / h_entries
-    uint64_t* d_entries = nullptr;
-    const int8_t* d_qt = nullptr;       // int8 tables the scan reads (d_qtables, or the uploaded ones)
-    // device-side heap replay (large batches): the ordered stream also stays in device memory, one wave per query
-    // pushes it through the reference's heap, and the host block receives [heaps u64[nq][R]][sizes u32[nq]] as well
-    bool dev_replay = false;
-    DevBuf<uint64_t> d_stream;
-    uint64_t* h_heaps = nullptr;
-    uint32_t* h_heap_sizes = nullptr;
-    bool heaps_ready = false;           // a replay kernel ran for the batch: h_heaps / h_heap_sizes hold its result
-    bool rerun = false;                 // the batch is being re-run from inside a collect call (no merge is enqueued with it)
-    // Front sharded over the ranks of the multi-GPU merge (qadc_search batches): this rank ran feeders + pre-scan + quantizer
-    // for queries [front_q0, front_q0 + front_n) only; the int8 tables, assign[] and (flags, qmin, qmax) of ALL queries come
-    // from one all-gather and the scan takes them like an int8 batch.
-    bool front_sharded = false;
-    int front_q0 = 0, front_n = 0, front_per = 0;
-    DevBuf<unsigned char> d_fblock, d_fgathered;
-    DevBuf<uint32_t> d_front_all;       // [nq][4] gathered {flags, qmin, qmax, 0}
-    PinBuf<unsigned char> h_fmap;       // mapped: assign i32[nq][ma], then front u32[nq][4] (written by front_unpack_kernel)
-    unsigned char* d_fmap = nullptr;
-    unsigned char* h_fmap_mapped = nullptr;
-    hipEvent_t ev_fa = nullptr, ev_fb = nullptr;
-    bool skipped_streams = false;       // collect_common left device-replayed queries' streams unassembled
-    QueryOut* h_qout = nullptr;
-    uint64_t* h_entries = nullptr;
-    DevBuf<float> d_ftables;            // float tables built on the device (qadc_search)
-    DevBuf<int8_t> d_qtables;
-    DevBuf<Cand> d_cands;
-    bool wgq_grouped = false;           // the batch took the partition-major second phase
-    int group_head_slots = 0;           // ... after a head of this many local probes per query
-    DevBuf<float> d_fc;
-
-    // one-workgroup-per-query path (qadc_query_kernel.hip): no planner, no levels, no sort
-    bool wgq = false;
-    bool dist_batch = false;            // launched with the native multi-GPU merge active: streams kept in device memory
-    uint32_t wgq_cap = 0;               // stream entries per query workgroup (regrown on overflow)
-    bool poll = false;                  // collect watches the workgroups' done bits instead of the completion event
-    int wgq_G = 1;                      // workgroups per query (small batches: the scan order of a query is split)
-    uint64_t wgq_codes = 0;             // codes a query probes (exact maximum, or an estimate) — sizes wgq_G
-    uint64_t head_codes = 0;            // level path: codes of every query's scan order covered by the head launch (0 = none)
-    uint64_t wgq_fcap = 0;              // pre-scan values per query in the global scratch (0 = they fit LDS)
-    DevBuf<uint32_t> d_qflags;          // [nq][4]: {flags, entries} for replay_heap_lanes_kernel
-    DevBuf<float> d_fvals;
-    DevBuf<QCand> d_qcands;             // unordered candidates of the query workgroups (scratch)
-    PinBuf<uint64_t> h_fetch;           // streams fetched on demand when they were left in device memory
-    bool assign_on_device = false;      // qadc_search: assign[] was produced on the GPU and copied back asynchronously
-    hipEvent_t ev_assign = nullptr;
-    bool full_prescan = false;          // survivor buffer overflowed: pre-scan everything unfiltered
-    // sharded pre-scan (multi-GPU): mode 1 = pre-scan ONLY, of slice pre_slice of pre_nslices of every probed
-    // partition's starts, exporting the R smallest values per query; mode 2 = a full batch whose pre-scan is
-    // replaced by the gathered values inj_vals[nq][inj_n] of all ranks
-    int mode = 0;
-    int pre_slice = 0, pre_nslices = 1;
-    std::vector<float> inj_vals;
-    uint32_t inj_n = 0;
-    float* h_export = nullptr;          // mode 1 results in the pinned result block: [nq][R] floats, then [nq] flags
-    uint32_t* h_export_flags = nullptr;
-    PinBuf<Cand> h_cands;               // host-sort fallback only
-    // device-side feeders (qadc_search): queries in, tables never leave the GPU
-    bool device_tables = false;
-    DevBuf<float> d_queries;
-    DevBuf<int32_t> d_assign;
-    DevBuf<float> d_cdist;
-    PinBuf<float> h_queries;
-    PinBuf<int32_t> h_assign;
-    hipEvent_t ev_feed = nullptr;
-
-    std::vector<LevelLaunch> launches;
-    uint64_t start_codes = 0;
-    hipEvent_t ev_done = nullptr;
-    hipEvent_t ev_front = nullptr;      // pre-scan + quantizer finished (front stream)
-    hipEvent_t ev_up = nullptr;         // this batch's upload finished (copy stream)
-    hipEvent_t ev_scanned = nullptr;    // last scan level finished (main stream)
-    std::vector<hipEvent_t> prof_ev;    // pairs: [2i] before, [2i+1] after; pair 0 = pre-scan chain
-    size_t prof_used = 0;
-
-    // collect() results: ordered candidate streams, entry = key | value << 32 | assign slot << 40
-    std::vector<uint64_t> out_entries;
-    std::vector<uint64_t> out_off;
-};
-
-// ---- native multi-GPU merge (qadc_dist_*): RCCL through dlopen, so that the library has no link-time dependency
-// on it and a single-GPU user never loads it ----
-struct QadcNcclId { char internal[128]; };                  // layout of ncclUniqueId (rccl.h)
-// A merge enqueued together with its batch (qadc_dist_*; one-workgroup-per-query batches without an extra payload): pack,
-// all-gather, interleave and replay follow the scan on the merge's stream with no host in between, so the collect call
-// only waits for one event.  One set of buffers per submission slot (several batches are in flight).
-struct DistSlot {
-    DevBuf<uint64_t> d_block, d_gathered, d_merged, d_moff;
-    DevBuf<uint32_t> d_mcnt;
-    DevBuf<uint32_t> d_src;                                  // level-path batches: {offset, count, flags}[nq] of the ordered streams
-    PinBuf<unsigned char> h_out;                             // mapped: heaps u64[nq][R], sizes u32[nq], status u32[4]
-    unsigned char* d_out = nullptr;
-    unsigned char* h_out_mapped = nullptr;
-    hipEvent_t ev_ready = nullptr, ev_done = nullptr, ev_gathered = nullptr;
-    bool enqueued = false;
-    bool pending = false;                                    // scan enqueued, merge not yet: it is issued BEHIND the next batch's front
-    uint64_t seq = 0;                                        // gather (flush_merges), so that that gather never waits for this batch's scan
-    void release() {
-        d_block.release(); d_gathered.release(); d_merged.release(); d_moff.release(); d_mcnt.release(); h_out.release();
-        d_src.release();
-        if (ev_ready) (void)hipEventDestroy(ev_ready);
-        if (ev_done) (void)hipEventDestroy(ev_done);
-        if (ev_gathered) (void)hipEventDestroy(ev_gathered);
-        ev_ready = ev_done = ev_gathered = nullptr;
-    }
-};
-
-struct DistState {
-    void* lib = nullptr;
-    int (*GetUniqueId)(QadcNcclId*) = nullptr;
-    int (*CommInitRank)(void**, int, QadcNcclId, int) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    void* comm = nullptr;
-    qadc_allgather_fn user_fn = nullptr;                     // qadc_dist_init_transport: the caller's all-gather instead of RCCL
-    void* user_ctx = nullptr;
-    hipStream_t stream = nullptr;                            // own high-priority stream: the merge of batch s must not queue
-                                                             // behind the scan kernels of batches s+1.. on the main stream
-    hipStream_t merge_stream[kSlots] = {};                   // interleave + replay of a merge enqueued with its batch: a millisecond of
-                                                             // latency that must neither sit in front of the NEXT batch's collectives
-                                                             // nor behind the PREVIOUS batch's replay (one stream per slot)
-    int rank = 0, world = 1;
-    uint32_t cap_entries = 1u << 16;                         // entries per rank block; regrown (by every rank alike) on overflow
-    DevBuf<uint64_t> d_block, d_gathered;
-    DevBuf<uint32_t> d_src;                                  // [3][nq]: offset, count, flags of this rank's streams
-    PinBuf<uint32_t> h_src;
-    DevBuf<uint64_t> d_moff, d_merged;                       // merge scratch: per-query offsets, the world's streams in global scan order
-    DevBuf<uint32_t> d_mcnt;                                 // [2][nq]: merged entries per query, replay flags
-    DevBuf<uint64_t> d_fix;                                  // streams of the queries this rank had to order on the host
-    PinBuf<uint64_t> h_fix;
-    DevBuf<float> d_extra;
-    DevBuf<uint64_t> d_extra_all;                            // the payload of a batch whose merge was enqueued with it, gathered [world][w]
-    PinBuf<float> h_extra;
-    PinBuf<unsigned char> h_out;                             // mapped: heaps u64[nq][R], sizes u32[nq]
-    unsigned char* d_out = nullptr;
-    unsigned char* h_out_mapped = nullptr;
-    PinBuf<uint32_t> h_hdr;                                  // gathered headers [world][nq][4]
-    PinBuf<float> h_extra_all;                               // gathered extra payload [world][extra_n]
-    // few-query batches: the gathered streams come back to the host, rank r replays queries q = r (mod world) there,
-    // and a second, tiny all-gather shares the heaps (a lane-per-query device replay of ~10^4 sequential pushes per
-    // query would take milliseconds when only a few dozen lanes have work)
-    PinBuf<uint64_t> h_gathered;
-    PinBuf<uint64_t> h_myheaps;                              // [per][R + 1]: heap entries, then the size
-    DevBuf<uint64_t> d_myheaps, d_allheaps;
-    PinBuf<uint64_t> h_allheaps;
-    int device_nq = 256;                                     // batches of at least this many queries replay on the device
-    int inject_failure = 0;                                  // test hook: the next qadc_dist_collect of this rank fails locally
-    int async_merge = 1;                                     // enqueue the merge with the batch where possible (option "dist_async")
-    uint64_t next_seq = 1;
-    int shard_front = 1;                                     // qadc_search batches: every rank runs the front of 1/world of the queries (option "dist_shard_front")
-    DistSlot slot[kSlots];
-    // One all-gather of `words` u64 per rank on `st`: RCCL (enqueued, stream-ordered) or the caller's transport
-    // (complete on return).  0 = ok; else the message is in `err`.
-    int gather(const void* d_send, void* d_recv, size_t words, hipStream_t st, std::string& err) {
-        if (user_fn) {
-            const int rc = user_fn(user_ctx, d_send, d_recv, (uint64_t)words * sizeof(uint64_t), st);
-            if (rc != 0) err = "the transport's all-gather failed (code " + std::to_string(rc) + ")";
-            return rc;
-        }
-        const int rc = AllGather(d_send, d_recv, words, /*ncclUint64*/ 5, comm, st);
-        if (rc != 0) err = std::string("ncclAllGather: ") + (GetErrorString ? GetErrorString(rc) : "error");
-        return rc;
-    }
-};
-
-int load_rccl(DistState& d, std::string& err) {
-    if (d.lib) return 0;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        d.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (d.lib) break;
-    }
-    if (!d.lib) { err = std::string("cannot load RCCL: ") + dlerror(); return -1; }
-    d.GetUniqueId = reinterpret_cast<int (*)(QadcNcclId*)>(dlsym(d.lib, "ncclGetUniqueId"));
-    d.CommInitRank = reinterpret_cast<int (*)(void**, int, QadcNcclId, int)>(dlsym(d.lib, "ncclCommInitRank"));
-    d.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(d.lib, "ncclAllGather"));
-    d.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(d.lib, "ncclCommDestroy"));
-    d.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(d.lib, "ncclGetErrorString"));
-    if (!d.GetUniqueId || !d.CommInitRank || !d.AllGather || !d.CommDestroy) { err = "RCCL lacks an expected symbol"; return -1; }
-    return 0;
 }
-
-}  // namespace
-
-struct qadc_index {
-    int M = 16, cs = 8, device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t front_stream = nullptr; // a batch's pre-scan/quantize chain, under the previous batch's streaming launches
-    hipStream_t copy_stream = nullptr;  // uploads and on-demand copies: issued where they depend on nothing (see plan_and_launch)
-    uint32_t replay_seq = 0;            // device replays alternate between two side streams in submission order
-    hipStream_t sort_stream = nullptr;  // candidate ordering of batch s (stores into pinned host memory) overlaps batch s+1
-    std::vector<Part> parts;
-    int labeled = -1;  // -1 unknown, 0 flat, 1 labels
-    bool finalized = false;
-    float keep = 0.01f;
-    // options
-    int quant_mode = 1;
-    uint32_t cand_capacity = kSortCap;  // candidate region entries per query
-    uint64_t level_base = 512;
-    uint64_t level_growth = 4;
-    int wgs_per_item = 0;  // 0 = auto
-    int share_variant = 0x41;            // streaming-kernel variant for shared launches: sibling-major, U=2, cached loads
-    uint32_t share_codes_per_wg = 1u << 20;
-    int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
-    int device_replay_nq = 64;           // batches of at least this many queries replay their streams on the device (0 = never)
-    int device_replay_alone_nq = 512;    // ... a batch with nothing else in flight (a synchronous call): from this many
-    uint64_t front_run_max = 2u << 20;   // leading levels whose runs are at most this long join the front (0 = none); they are
-                                         // counted with the small launches, not event-timed.  125M x 32: 2 Mi -4 %, 8 Mi +1 %
-    uint64_t front_min_batch = 3000000000ull;   // ... in batches of at least this many (code, query) pairs: under a last level
-                                         // of a few hundred microseconds the early levels hide; under a shorter one they only make the front
-                                         // stream the longest chain of the step (32 queries per step: 3e7 codes 0.42 -> 0.37 ms with
-                                         // everything on the main stream, 6e7 0.64 -> 0.62, 1.25e8 1.12 -> 1.14: tools/front_run_ab.sh)
-    int prescan_mq = 1;                  // ... and so does the float pre-scan when every query pre-scans the same starts
-    uint32_t mq_codes_per_wg = 1u << 16;
-    uint32_t mq_min_wgs = 4096;          // workgroups a multi-query launch should have at least (2 rounds of the chip)
-    uint32_t mq_min_tiles = 4;           // ... but never fewer than this many 4 KiB tiles per workgroup
-    int front_dist = 1;    // early levels also for the multi-GPU loop's batches (pre-scan injected)
-    uint32_t wgq_split_codes = 8192;    // a query is split over several workgroups only down to this many codes each
-    int wgq_poll = 1;      // ... and its completion is read from the result block, not from the event
-    int group_strikes = 0; // grouped batches whose candidate regions overflowed (data whose later probes fall below the head's bound)
-    int wgq_group = 1;     // partition-major second phase for large IVF batches: 0 never, 1 auto, 2 whenever possible
-    int wgq_group_head = 3;   // ... after a head of this many probes per query (one workgroup per query; 4 until the ordering pass took 8192 candidates)
-    int wgq_group_head_dist = 4;   // ... under the multi-GPU merge (probes with codes on this rank; option "wgq_group_head_dist")
-    int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
-    int mq_narrow = 1;     // IVF second phase: groups whose upper four seats are empty run the 4-seat form (the two-body build of the kernel)
-    int replay_wave = 1;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
-                           // (C3 shape, 1024-query batches: lanes 0.78 us per query, waves 0.75; C5 shape: 4.83 vs 4.67 — since
-                           // the wave heap sifts all levels at once; with its element-by-element sift the waves lost,
-                           // 0.93 vs 0.80.  The multi-GPU merge replays by waves.)
-    int head_early = 1;    // the head launch joins the front stream (under the previous batch's long levels)
-    int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
-    uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
-    int replay_threads = 0;            // 0 = auto
-    WorkerPool pool;                   // host replay workers (started on first use)
-    uint32_t small_vec_per_wg = 512;  // 16-byte vectors one small-run workgroup covers
-    uint32_t small_run = 1u << 17;  // runs shorter than this use the small-run kernel
-    int variant = 0x0d;    // kernel tuning variant (see launch_scan_i8): U=2, non-temporal loads, chunked tiles
-    // one workgroup per query (IVF batches, small lists): 0 = never, 1 = auto, 2 = whenever structurally possible
-    int wgq = 1;
-    int wgq_min_nq = 128;                // auto: batches of at least this many queries ...
-    uint64_t wgq_max_codes = 1ull << 24; //   ... probing at most this many codes per query (estimate), or
-    uint64_t wgq_small_codes = 1ull << 18;   // any batch probing at most this many codes per query
-    uint32_t wgq_capacity = 4096;        // stream entries per query to start with
-    int wgq_split = 12;                 // workgroups a small batch may spread one query's scan order over
-    int head_level = 5;                  // level path: bound levels 0..head_level-1 (the first 512 Ki codes of every query) are
-                                         // scanned by ONE launch of the query kernel in head mode instead of head_level dependent
-                                         // level launches (0 = off): -5 % per step on a 125M-code shard, neutral at 1B
-    int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
-    int table_form = 2;                  // float tables of qadc_search: 0 direct, 1 BLAS expansion, 2 the reference's nns_engine rule
-    uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)
-    uint32_t wgq_group_cand_cap = kOrderCandCap;   // ... of a batch with the partition-major second phase (option "wgq_group_cand_cap")
-    DevBuf<PartDesc> d_partdesc;         // device partition table (qadc_index_finalize)
-    std::vector<PartDesc> h_partdesc;    // its host copy (a lone small query carries the descriptors it needs in its launch)
-    uint32_t max_start_n = 0;
-    uint64_t total_codes = 0;
-    uint32_t max_part_n = 0;
-    bool profile = false;
-    // N1: host feeders on the device
-    int dim = 0;                 // vector dimension (0 = qadc_index_set_pq not called)
-    DevBuf<float> d_codebooks;   // [M][16][dim/M]
-    DevBuf<float> d_rotation;    // [dim][dim] OPQ rotation (empty = plain PQ)
-    bool has_rotation = false;
-    int K = 0;                   // coarse centroids (0 = flat)
-    DevBuf<float> d_coarse;      // [K][dim]
-    Slot slot[kSlots];
-    Slot pre_slot[2];                   // sharded pre-scan passes (mode 1): own buffers, so that one can run
-                                        // while slot[i] still holds an uncollected batch
-    qadc_profile prof{};
-    DistState* dist = nullptr;          // qadc_dist_init
-};
 
 namespace {
-
-// Which float-table form qadc_search builds (option "table_form"): 0 = direct ||x - c||^2 always
-// (compute_dists_single_simd_cg, distances.hpp:294-311), 1 = BLAS expansion always (nns_engine_batch,
-// query_common.hpp:194-213), 2 = the rule of nns_engine (query_common.hpp:292-297): direct for ma == 1, expansion otherwise.
-int table_expansion(const qadc_index* idx, int ma);
-
-int use_device(const qadc_index* idx) {
-    HIPCHECK(hipSetDevice(idx->device));
-    return QADC_OK;
-}
-
-int table_expansion(const qadc_index* idx, int ma) {
-    return idx->table_form == 1 || (idx->table_form == 2 && ma > 1);
-}
-
-hipError_t prof_event(Slot& s, hipStream_t st) {
-    if (s.prof_used == s.prof_ev.size()) {
-        hipEvent_t e;
-        hipError_t r = hipEventCreate(&e);
-        if (r != hipSuccess) return r;
-        s.prof_ev.push_back(e);
-    }
-    return hipEventRecord(s.prof_ev[s.prof_used++], st);
-}
 
 // Level boundaries in the concatenated scan position space of one query.
 void level_bounds(const qadc_index* idx, uint64_t* L) {
@@ -457,13 +32,6 @@ void level_bounds(const qadc_index* idx, uint64_t* L) {
     }
     L[kMaxLevels] = UINT64_MAX;
 }
-
-struct ScopedMs {
-    double& acc;
-    std::chrono::steady_clock::time_point t0;
-    explicit ScopedMs(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
-    ~ScopedMs() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
-};
 
 // What the planner hands to the launcher: the work items of a batch in upload order.
 struct BatchPlan {
@@ -670,9 +238,25 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
     return QADC_OK;
 }
 
-int launch_wgq_batch(qadc_index* idx, Slot& s);
-int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream);
-int flush_merges(qadc_index* idx, uint64_t upto);
+}  // namespace
+
+namespace qadc {
+namespace host {
+
+int use_device(const qadc_index* idx) {
+    HIPCHECK(hipSetDevice(idx->device));
+    return QADC_OK;
+}
+
+hipError_t prof_event(Slot& s, hipStream_t st) {
+    if (s.prof_used == s.prof_ev.size()) {
+        hipEvent_t e;
+        hipError_t r = hipEventCreate(&e);
+        if (r != hipSuccess) return r;
+        s.prof_ev.push_back(e);
+    }
+    return hipEventRecord(s.prof_ev[s.prof_used++], st);
+}
 
 // Plans the batch in slot s and enqueues all of its GPU work (front, levels, ordering, optional device replay).
 int plan_and_launch(qadc_index* idx, Slot& s) {
@@ -785,8 +369,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             HIPCHECK(s.d_ftables.ensure(nt));
             d_ft = s.d_ftables.p;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
-            launch_build_tables(s.d_queries.p, idx->K ? idx->d_coarse.p : nullptr, s.d_assign.p, idx->d_codebooks.p,
-                                idx->has_rotation ? idx->d_rotation.p : nullptr, nq, ma, M, idx->dim, table_expansion(idx, ma), d_ft, st);
+            launch_build_tables(s.d_queries.p, idx->feed.K ? idx->feed.d_coarse.p : nullptr, s.d_assign.p, idx->feed.d_codebooks.p,
+                                idx->feed.has_rotation ? idx->feed.d_rotation.p : nullptr, nq, ma, M, idx->feed.dim, table_expansion(idx, ma), d_ft, st);
         }
         HIPCHECK(s.d_fc.ensure((size_t)nq * fc_stride));
         if (idx->profile) HIPCHECK(prof_event(s, st));
@@ -961,419 +545,10 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     HIPCHECK(hipEventRecord(s.ev_done, st));
     return QADC_OK;
 }
+}  // namespace host
+}  // namespace qadc
 
-// Decides whether a batch takes the one-workgroup-per-query path.  codes_per_query: exact maximum when the host
-// knows assign[], an estimate (ma x mean partition size) when assign[] is produced on the GPU.
-bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64_t codes_per_query) {
-    if (idx->wgq == 0 || mode != 0 || ma > 4096 || R <= 0) return false;
-    if (idx->wgq >= 2) return true;
-    if (codes_per_query <= idx->wgq_small_codes) return true;
-    // an IVF batch (several partitions, several probes per query: the queries walk different codes) — the query kernel is
-    // ahead of the level path at every batch size (C3 shape, synchronous: 1 query 217 -> 175 us, 64 queries 0.85 -> 0.73 ms)
-    if (ma > 1 && idx->parts.size() > 1 && codes_per_query <= idx->wgq_max_codes) return true;
-    return nq >= idx->wgq_min_nq && codes_per_query <= idx->wgq_max_codes;
-}
-
-// One launch per batch: scan_query_kernel (one workgroup per query), then — for batches large enough to replay on
-// the device — replay_heap_lanes_kernel on the side stream.  No host planning: the kernel walks assign[] and the
-// device partition table itself.
-int launch_wgq_batch(qadc_index* idx, Slot& s) {
-    ScopedMs timer(idx->prof.host_plan_ms);
-    const int M = idx->M, nq = s.nq, ma = s.ma;
-    const size_t table_dim = (size_t)M * 16, nt = (size_t)nq * ma * table_dim;
-    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    s.launches.clear();
-    s.start_codes = 0;
-    // ---- upload block: [assign i32 nq*ma (host-assign path)][float or int8 tables (host-table path)] ----
-    const size_t assign_bytes = s.assign_on_device ? 0 : sizeof(int32_t) * (size_t)nq * ma;
-    const size_t off_tables = align16(assign_bytes);
-    const size_t tables_bytes = s.float_path ? (s.device_tables ? 0 : nt * sizeof(float)) : nt;
-    const size_t in_bytes = align16(off_tables + tables_bytes);
-    HIPCHECK(s.h_in.ensure(std::max<size_t>(in_bytes, 16)));
-    HIPCHECK(s.d_in.ensure(std::max<size_t>(in_bytes, 16)));
-    if (assign_bytes) std::memcpy(s.h_in.p, s.assign.data(), assign_bytes);
-    if (s.float_path && !s.device_tables) std::memcpy(s.h_in.p + off_tables, s.tables, nt * sizeof(float));
-    if (!s.float_path) std::memcpy(s.h_in.p + off_tables, s.qtables_in.data(), nt);
-
-    // ---- result block in pinned, device-mapped host memory: [QueryOut[nq]][streams u64[nq][cap] unless they stay
-    // on the device][heaps u64[nq][R]][sizes u32[nq]] ----
-    const uint32_t cap = s.wgq_cap;
-    bool alone = true;
-    for (int i = 0; i < kSlots; ++i) alone = alone && (&idx->slot[i] == &s || !idx->slot[i].busy);
-    alone = alone && !idx->pre_slot[0].busy && !idx->pre_slot[1].busy;
-    // The lane-per-query replay takes ~1.3 ms whatever the batch size (one query's pushes are sequential): in a pipeline
-    // that latency hides under the next batches and the host stays free, but a batch submitted while nothing else is in
-    // flight — a synchronous call — is answered sooner by the host's threads up to a few hundred queries (C3 shape,
-    // synchronous: 64 queries 1.41 -> 0.87 ms, 256: 1.89 -> 1.44, 512: 2.26 vs 2.41)
-    const int replay_from = alone ? std::max(idx->device_replay_nq, idx->device_replay_alone_nq) : idx->device_replay_nq;
-    s.dev_replay = idx->device_replay_nq > 0 && nq >= replay_from && (uint32_t)s.R <= (idx->replay_wave ? replay_wave_max_R() : replay_lanes_max_R());
-    s.dist_batch = idx->dist != nullptr;
-    s.heaps_ready = s.dev_replay && !s.dist_batch;
-    if (s.dist_batch) s.dev_replay = true;                   // streams stay on the device for the gather (qadc_dist_collect)
-    // A batch too small to fill the GPU splits every query's scan order over G workgroups (each tightens its bound on
-    // the query's first block, then scans its own chunk); the sub-streams are concatenated in workgroup order.
-    int G = 1;
-    if (!s.dev_replay && nq * 2 <= 256) {
-        G = std::min<int>(idx->wgq_split, 256 / nq);
-        G = (int)std::min<uint64_t>((uint64_t)G, s.wgq_codes / idx->wgq_split_codes);   // at least wgq_split_codes codes per workgroup
-        G = std::max(G, 1);
-    }
-    s.wgq_G = G;
-    const int nsub = nq * G;
-    const size_t stream_entries = (size_t)nsub * cap;
-    if (stream_entries >= (1ull << 32)) return fail(QADC_E_CAPACITY, "candidate stream capacity exceeds 2^32 entries");
-    s.out_cap = (uint32_t)stream_entries;
-    const size_t host_stream_bytes = s.dev_replay ? 0 : sizeof(uint64_t) * stream_entries;
-    const size_t off_heaps = sizeof(QueryOut) * (size_t)nsub + host_stream_bytes;
-    const size_t heaps_bytes = s.dev_replay ? (sizeof(uint64_t) * (size_t)s.R + sizeof(uint32_t)) * (size_t)nq : 0;
-    HIPCHECK(s.h_result.ensure(off_heaps + heaps_bytes + 16, hipHostMallocMapped | hipHostMallocCoherent));
-    if (s.h_result.p != s.h_result_mapped) {
-        HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.d_result_mapped), s.h_result.p, 0));
-        s.h_result_mapped = s.h_result.p;
-    }
-    unsigned char* d_result = s.d_result_mapped;
-    s.d_qout = reinterpret_cast<QueryOut*>(d_result);
-    s.h_qout = reinterpret_cast<QueryOut*>(s.h_result.p);
-    s.d_entries = reinterpret_cast<uint64_t*>(d_result + sizeof(QueryOut) * (size_t)nsub);
-    s.h_entries = reinterpret_cast<uint64_t*>(s.h_result.p + sizeof(QueryOut) * (size_t)nsub);
-    s.h_heaps = reinterpret_cast<uint64_t*>(s.h_result.p + off_heaps);
-    s.h_heap_sizes = reinterpret_cast<uint32_t*>(s.h_result.p + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
-    if (s.dev_replay) {
-        HIPCHECK(s.d_stream.ensure(stream_entries));
-        HIPCHECK(s.d_qflags.ensure((size_t)nq * 4));
-    }
-    HIPCHECK(s.d_qtables.ensure(nt));
-    // pre-scan values beyond the kernel's LDS budget go to a global scratch
-    uint64_t fcap = 0;
-    if (s.float_path) {
-        uint64_t worst = (uint64_t)ma * idx->max_start_n;
-        if (!s.assign_on_device) {
-            worst = 0;
-            for (int q = 0; q < nq; ++q) {
-                uint64_t t = 0;
-                for (int a = 0; a < ma; ++a) t += idx->parts[s.assign[(size_t)q * ma + a]].start_n;
-                worst = std::max(worst, t);
-            }
-        }
-        if (worst > query_kernel_lds_values(M)) fcap = worst;
-        for (int q = 0; q < nq && !s.assign_on_device; ++q)
-            for (int a = 0; a < ma; ++a) s.start_codes += idx->parts[s.assign[(size_t)q * ma + a]].start_n;
-    }
-    s.wgq_fcap = fcap;
-    if (fcap) HIPCHECK(s.d_fvals.ensure((size_t)nsub * fcap));
-    const uint32_t ccap = std::min<uint32_t>(idx->wgq_cand_cap, kQueryCandCap);
-    HIPCHECK(s.d_qcands.ensure((size_t)nsub * ccap));
-
-    hipStream_t st = idx->stream;
-    // A lone small query (the synchronous single-query call): its input — which partitions, their descriptors, the
-    // float tables — fits the kernel-argument segment and rides in the dispatch packet; no copy precedes the launch.
-    alignas(16) unsigned char inl[kInlineBytes];
-    size_t inl_bytes = 0, inl_off_parts = 0, inl_off_tables = 0;
-    if (alone && G > 1 && idx->wgq_inline && s.float_path && !s.device_tables && !s.assign_on_device) {
-        const size_t na = (size_t)nq * ma;
-        inl_off_parts = align16(sizeof(int32_t) * na);
-        inl_off_tables = align16(inl_off_parts + sizeof(PartDesc) * na);
-        const size_t total = inl_off_tables + nt * sizeof(float);
-        if (total <= kInlineBytes) {
-            for (size_t i = 0; i < na; ++i) {
-                reinterpret_cast<int32_t*>(inl)[i] = (int32_t)i;
-                std::memcpy(inl + inl_off_parts + sizeof(PartDesc) * i, &idx->h_partdesc[s.assign[i]], sizeof(PartDesc));
-            }
-            std::memcpy(inl + inl_off_tables, s.tables, nt * sizeof(float));
-            inl_bytes = total;
-        }
-    }
-    if (in_bytes && !inl_bytes) {
-        if (alone) {
-            HIPCHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, st));
-        } else {                                            // never queue a copy behind the previous batch's kernels
-            HIPCHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, idx->copy_stream));
-            if (!s.ev_up) HIPCHECK(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
-            HIPCHECK(hipEventRecord(s.ev_up, idx->copy_stream));
-            HIPCHECK(hipStreamWaitEvent(st, s.ev_up, 0));
-        }
-    }
-    s.prof_used = 0;
-    QueryKernelArgs A{};
-    A.parts = idx->d_partdesc.p;
-    A.assign = s.assign_on_device ? s.d_assign.p : reinterpret_cast<const int32_t*>(s.d_in.p);
-    A.ma = ma;
-    A.ftables = nullptr;
-    A.qtables = s.d_qtables.p;
-    if (s.front_sharded) {
-        // (tables come out of the sharded front below)
-    } else if (s.float_path) {
-        if (s.device_tables) {
-            HIPCHECK(s.d_ftables.ensure(nt));
-            HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
-            launch_build_tables(s.d_queries.p, idx->K ? idx->d_coarse.p : nullptr, s.d_assign.p, idx->d_codebooks.p,
-                                idx->has_rotation ? idx->d_rotation.p : nullptr, nq, ma, M, idx->dim, table_expansion(idx, ma), s.d_ftables.p, st);
-            A.ftables = s.d_ftables.p;
-        } else {
-            A.ftables = reinterpret_cast<float*>(s.d_in.p + off_tables);
-        }
-    } else {
-        A.qtables = reinterpret_cast<int8_t*>(s.d_in.p + off_tables);    // the caller's int8 tables, as uploaded
-    }
-    if (s.front_sharded) {
-        // ---- sharded front: this rank's share -> gather -> the whole batch as an int8 batch with device-resident inputs ----
-        DistState& d = *idx->dist;
-        const size_t tab = table_dim * (size_t)ma;
-        const size_t block = ((size_t)s.front_per * (tab + (size_t)ma * 4 + 16) + 15) & ~(size_t)15;
-        int32_t* d_assign_share = reinterpret_cast<int32_t*>(s.d_fblock.p + (size_t)s.front_per * tab);
-        uint32_t* d_front_share = reinterpret_cast<uint32_t*>(s.d_fblock.p + (size_t)s.front_per * (tab + (size_t)ma * 4));
-        if (!s.rerun) {                                          // (a re-run from inside collect reuses the gathered arrays)
-            idx->prof.front_sharded_batches++;
-            // The share's front runs on the FRONT stream, under the previous batch's scan (it depends on nothing that batch
-            // produces), and its gather is issued IN FRONT of that batch's merge gather (flush_merges below).
-            hipStream_t fs = alone ? st : idx->front_stream;
-            HIPCHECK(hipStreamWaitEvent(fs, s.ev_feed, 0));
-            if (s.front_n) {
-                const size_t nt_share = (size_t)s.front_n * tab;
-                HIPCHECK(s.d_ftables.ensure(nt_share));
-                launch_build_tables(s.d_queries.p, idx->d_coarse.p, d_assign_share, idx->d_codebooks.p,
-                                    idx->has_rotation ? idx->d_rotation.p : nullptr, s.front_n, ma, M, idx->dim, table_expansion(idx, ma),
-                                    s.d_ftables.p, fs);
-                QueryKernelArgs F{};
-                F.parts = idx->d_partdesc.p;
-                F.assign = d_assign_share;
-                F.ma = ma;
-                F.ftables = s.d_ftables.p;
-                F.qtables = reinterpret_cast<int8_t*>(s.d_fblock.p);
-                F.fvals = fcap ? s.d_fvals.p : nullptr;
-                F.fcap = (uint32_t)fcap;
-                F.R = (uint32_t)s.R;
-                F.quant_mode = idx->quant_mode;
-                F.head_codes = ~0ull;
-                F.head_slots = 1;
-                F.G = 1;
-                F.front_only = 1;
-                F.front_out = d_front_share;
-                HIPCHECK(launch_scan_query(M, idx->wgq_variant, s.front_n, F, fs));
-            }
-            // the collectives of the merge live on ONE stream, in the order the host issues them (the same on every rank)
-            if (!s.ev_fa) HIPCHECK(hipEventCreateWithFlags(&s.ev_fa, hipEventDisableTiming));
-            if (!s.ev_fb) HIPCHECK(hipEventCreateWithFlags(&s.ev_fb, hipEventDisableTiming));
-            HIPCHECK(hipEventRecord(s.ev_fa, fs));
-            HIPCHECK(hipStreamWaitEvent(d.stream, s.ev_fa, 0));
-            std::string gerr;
-            if (d.gather(s.d_fblock.p, s.d_fgathered.p, block / 8, d.stream, gerr)) return fail(QADC_E_HIP, gerr);
-            HIPCHECK(launch_front_unpack(s.d_fgathered.p, block, d.world, s.front_per, nq, ma, tab, s.d_qtables.p, s.d_assign.p,
-                                         s.d_front_all.p, reinterpret_cast<int32_t*>(s.d_fmap),
-                                         reinterpret_cast<uint32_t*>(s.d_fmap + (size_t)nq * ma * 4), d.stream));
-            HIPCHECK(hipEventRecord(s.ev_fb, d.stream));
-            HIPCHECK(hipStreamWaitEvent(st, s.ev_fb, 0));
-            if (int rc = flush_merges(idx, ~0ull)) return rc;   // the older batches' merges: behind this front gather
-        }
-        A.assign = s.d_assign.p;
-        A.ftables = nullptr;                                     // from here on: an int8 batch
-        A.qtables = s.d_qtables.p;
-        A.front_in = s.d_front_all.p;
-    }
-    s.d_qt = A.qtables;
-    A.fvals = fcap ? s.d_fvals.p : nullptr;
-    A.fcap = (uint32_t)fcap;
-    A.stream = s.dev_replay ? s.d_stream.p : s.d_entries;
-    A.cap = cap;
-    A.cands = s.d_qcands.p;
-    A.ccap = ccap;
-    A.qout = s.d_qout;
-    A.qstate_flags = s.dev_replay ? s.d_qflags.p : nullptr;
-    A.R = (uint32_t)s.R;
-    A.quant_mode = idx->quant_mode;
-    A.nontemporal = idx->total_codes * (uint64_t)idx->cs > (200ull << 20);   // (same rule as the level path)
-    A.G = G;
-    if (idx->profile) HIPCHECK(prof_event(s, st));
-    s.poll = alone && G > 1 && !s.dev_replay && !idx->profile && idx->wgq_poll;
-    if (s.poll)
-        for (int i = 0; i < nsub; ++i) s.h_qout[i].flags = 0;
-    A.inline_off_parts = (uint32_t)inl_off_parts;
-    A.inline_off_tables = (uint32_t)inl_off_tables;
-    // Large IVF batches: a (query, probe) pair lands on a partition several other queries of the batch probe too.  The
-    // kernel then only walks the first probes of every query (head: front + a tight bound); the other pairs are
-    // regrouped by partition on the device and scanned 8 queries per pass (see launch_ivf_plan), and a third kernel
-    // orders every query's candidates into the stream layout the plain launch produces.
-    // (under the merge the head counts probes WITH CODES ON THIS RANK; its length is an option of its own: whole-partition
-    // placement is better off with 2 — one of 8 ranks, C5 shape: 1.53 vs 1.78 ms per batch — the range split with 4:
-    // 1.35 vs 1.52, and at 2048-query batches a head of 2 short pieces bounds too loosely and the batches fall back)
-    const int head_slots = std::min(idx->dist ? idx->wgq_group_head_dist : idx->wgq_group_head, ma);
-    const size_t pairs = (size_t)nq * (size_t)(ma - head_slots);
-    const size_t nparts = idx->parts.size();
-    s.wgq_grouped = s.dev_replay && G == 1 && pairs > 0 && nparts < (1u << 24) &&
-                    (idx->wgq_group == 2 || (idx->wgq_group == 1 && idx->group_strikes < 2 && nq >= 256 && pairs >= 2 * nparts));
-    if (s.wgq_grouped) {
-        const size_t state_bytes = 64 + sizeof(QueryState) * (size_t)nq;
-        const size_t ngroups = ivf_max_groups(pairs, nparts);
-        if (ngroups * 8 >= (1ull << 31)) return fail(QADC_E_CAPACITY, "too many (query, probe) pairs for one batch");
-        // query states, plan counters and group items in ONE allocation: one clear instead of three (every launch between
-        // two batches' scans costs the scan stream ~10 us)
-        auto up256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
-        const size_t gplan_off = up256(state_bytes), gplan_bytes = sizeof(uint32_t) * (3 * nparts + 1);
-        const size_t gitems_off = up256(gplan_off + gplan_bytes), gitems_bytes = sizeof(ScanItem) * ngroups * 8;
-        HIPCHECK(s.d_state.ensure(gitems_off + gitems_bytes));
-        uint32_t* d_gplan = reinterpret_cast<uint32_t*>(s.d_state.p + gplan_off);
-        ScanItem* d_gitems = reinterpret_cast<ScanItem*>(s.d_state.p + gitems_off);
-        // (the ordering pass of this path sorts up to kOrderCandCap candidates per query — twice what the query kernel's own tail
-        // takes; a cap the caller lowered — the tests' way to force the fallback — is honoured)
-        const uint32_t gcap = idx->wgq_cand_cap < kQueryCandCap ? idx->wgq_cand_cap : std::min<uint32_t>(idx->wgq_group_cand_cap, kOrderCandCap);
-        HIPCHECK(s.d_cands.ensure((size_t)nq * gcap));
-        s.d_hdr = reinterpret_cast<CandHeader*>(s.d_state.p);
-        s.d_qs = reinterpret_cast<QueryState*>(s.d_state.p + 64);
-        HIPCHECK(hipMemsetAsync(s.d_state.p, 0, gitems_off + gitems_bytes, st));
-        // (tried: the plan — two clears + count / offsets / scatter, needed by the second phase only — on a stream of its own
-        // under the head launch: its workgroups then wait for head workgroups to retire and the second phase for them;
-        // C3 0.75 -> 1.05 us per query, one of 8 ranks 0.72 -> 1.51 ms per batch.  Tried as well: table build, clears and
-        // plan of a qadc_search batch on the front stream, enqueued under the PREVIOUS batch's scan — ~100 us of the scan
-        // stream per batch to win, but the dozen small launches trickle through that scan so slowly that the next head
-        // ends up waiting for them: C3 0.75 -> 0.91 us per query, C5 4.63 -> 4.82.)
-        launch_ivf_plan(A.assign, idx->d_partdesc.p, nq, ma, head_slots, (int)nparts, d_gplan, d_gplan + 2 * nparts,
-                        d_gplan + nparts, d_gitems, st);
-        QueryKernelArgs H = A;
-        H.head_codes = ~0ull;
-        H.head_slots = (uint32_t)head_slots;
-        H.qstates = s.d_qs;
-        H.cand_regions = s.d_cands.p;
-        H.cand_cap = gcap;
-        H.hdr = s.d_hdr;
-        H.G = 1;
-        // (profile: one event before and after each of the three launches — prof_ev[1..4]; ~10 us of stream time each)
-        if (idx->profile) HIPCHECK(prof_event(s, st));
-        HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));
-        if (idx->profile) HIPCHECK(prof_event(s, st));
-        const int wgs = (int)std::max<uint64_t>(1, ((uint64_t)idx->max_part_n + idx->mq_codes_per_wg - 1) / idx->mq_codes_per_wg);
-        launch_scan_i8_mq(M, d_gitems, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, gcap, (uint32_t)s.R, st,
-                          idx->mq_narrow);
-        if (idx->profile) HIPCHECK(prof_event(s, st));
-        HIPCHECK(launch_order_cands(s.d_qs, s.d_cands.p, gcap, gcap, nq, s.d_stream.p, cap, s.d_qout, s.d_qflags.p, st));
-        if (idx->profile) HIPCHECK(prof_event(s, st));
-        s.group_head_slots = head_slots;
-        idx->prof.group_launches++;
-    } else {
-        HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st, inl_bytes ? inl : nullptr, inl_bytes));
-    }
-    if (idx->profile) HIPCHECK(prof_event(s, st));
-    if (s.dist_batch && !s.rerun)
-        if (int rc = enqueue_merge(idx, s, st)) return rc;
-    if (s.dev_replay) {
-        if (!alone) {
-            // replay on a side stream, under the next batches' scans.  A 1024-query replay (16 waves, one lane per
-            // query, ~1.5 K dependent pushes each) lasts about as long as the batch's scan: consecutive batches use two
-            // side streams alternately, so that a replay never waits for the previous batch's replay.
-            if (!s.ev_scanned) HIPCHECK(hipEventCreateWithFlags(&s.ev_scanned, hipEventDisableTiming));
-            HIPCHECK(hipEventRecord(s.ev_scanned, st));
-            // Alternate by SUBMISSION order, not by slot: with three batches in flight slots 2 and 0 follow each other, and
-            // on one stream the second replay would wait out the first (every third batch lost 0.7 ms that way).
-            // (a replay stream of its own per slot was tried: 1.2 -> 1.9 us per query at the IVF shape)
-            st = (idx->replay_seq++ & 1) ? idx->front_stream : idx->sort_stream;
-            HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
-        }
-        if (s.heaps_ready) {
-            uint64_t* d_heaps = reinterpret_cast<uint64_t*>(d_result + off_heaps);
-            uint32_t* d_sizes = reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
-            if (idx->replay_wave)                               // one wave per query, heap in registers
-                HIPCHECK(launch_replay_heap_wave_qflags(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
-            else                                                // one lane per query, heaps in LDS
-                HIPCHECK(launch_replay_heap_lanes(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
-        }
-    }
-    if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(s.ev_done, st));
-    return QADC_OK;
-}
-
-// The merge of a one-workgroup-per-query batch, enqueued behind its scan: pack (from the kernels' own records in
-// device memory) -> all-gather -> interleave -> replay; the collectives on the merge's stream, the compute on a stream
-// of its own; the heaps and a status word land in pinned host memory.  Every rank enqueues the same collectives in the
-// same order (the ranks submit and collect the same batches in the same order).
-// Not taken (the collect-time merge runs instead): few-query batches (host-share replay), R or ma x world beyond the device
-// merge, option dist_async = 0.
-// Two steps.  enqueue_merge (at the end of the batch's launch) records where the scan ends and marks the merge PENDING;
-// flush_merges issues the pending merges in submission order.  A batch with a sharded front flushes the OLDER merges right
-// after issuing its own front gather: on the collectives' stream that gather then lies in front of the previous batch's
-// merge gather (which waits for that batch's scan), so a front that runs under the previous scan is not held up by it.
-int enqueue_merge_now(qadc_index* idx, Slot& s) {
-    DistState& d = *idx->dist;
-    const int slot_i = (int)(&s - idx->slot);
-    DistSlot& ds = d.slot[slot_i];
-    ds.pending = false;
-    const int nq = s.nq, R = s.R, world = d.world;
-    const size_t bw = dist_block_words(nq, d.cap_entries, 0);
-    HIPCHECK(ds.d_block.ensure(bw));
-    HIPCHECK(ds.d_gathered.ensure(bw * world));
-    HIPCHECK(ds.d_merged.ensure((size_t)d.cap_entries * world));
-    HIPCHECK(ds.d_moff.ensure(nq));
-    HIPCHECK(ds.d_mcnt.ensure(2 * (size_t)nq));
-    const size_t heaps_bytes = (sizeof(uint64_t) * (size_t)R + sizeof(uint32_t)) * (size_t)nq;
-    HIPCHECK(ds.h_out.ensure(heaps_bytes + 32, hipHostMallocMapped | hipHostMallocCoherent));
-    if (ds.h_out.p != ds.h_out_mapped) {
-        HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ds.d_out), ds.h_out.p, 0));
-        ds.h_out_mapped = ds.h_out.p;
-    }
-    if (!ds.ev_done) HIPCHECK(hipEventCreateWithFlags(&ds.ev_done, hipEventDisableTiming));
-    hipStream_t st = d.stream;
-    HIPCHECK(hipStreamWaitEvent(st, ds.ev_ready, 0));
-    if (s.wgq) {
-        HIPCHECK(launch_dist_pack_qflags(s.d_qflags.p, nq, s.d_stream.p, s.wgq_cap, d.cap_entries, ds.d_block.p, st));
-    } else {
-        // level path: the ordering pass left {out_off, count, reps, flags} in the query states and the compact ordered
-        // streams in d_stream; whatever the collect call would have to redo first (a query the device did not order, an
-        // overflowed region / output / pre-scan buffer) raises bit7 and the merge is redone at collect time
-        HIPCHECK(ds.d_src.ensure(3 * (size_t)nq));
-        HIPCHECK(launch_dist_src_from_states(s.d_qs, nq, s.out_cap, ds.d_src.p, st));
-        HIPCHECK(launch_dist_pack(ds.d_src.p, ds.d_src.p + nq, ds.d_src.p + 2 * (size_t)nq, nq, s.d_stream.p, nullptr, d.cap_entries,
-                                  nullptr, 0, ds.d_block.p, st));
-    }
-    std::string gerr;
-    if (d.gather(ds.d_block.p, ds.d_gathered.p, bw, st, gerr)) return fail(QADC_E_HIP, gerr);
-    // the collectives keep `st` to themselves (the next batch's front gather is issued right behind this one); the merge's
-    // compute — a millisecond of replay latency — goes to a stream of its own
-    if (!ds.ev_gathered) HIPCHECK(hipEventCreateWithFlags(&ds.ev_gathered, hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(ds.ev_gathered, st));
-    hipStream_t ms = d.merge_stream[slot_i] ? d.merge_stream[slot_i] : st;
-    if (ms != st) HIPCHECK(hipStreamWaitEvent(ms, ds.ev_gathered, 0));
-    uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ds.d_out + sizeof(uint64_t) * (size_t)R * nq);
-    HIPCHECK(launch_dist_merge(ds.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, ds.d_moff.p, ds.d_mcnt.p, ds.d_mcnt.p + nq,
-                               ds.d_merged.p, reinterpret_cast<uint64_t*>(ds.d_out), d_sizes, ms, d_sizes + nq));
-    HIPCHECK(hipEventRecord(ds.ev_done, ms));
-    ds.enqueued = true;
-    return QADC_OK;
-}
-
-// Issues the pending merges with seq <= upto, oldest first.
-int flush_merges(qadc_index* idx, uint64_t upto) {
-    if (!idx->dist) return QADC_OK;
-    DistState& d = *idx->dist;
-    for (;;) {
-        int best = -1;
-        for (int i = 0; i < kSlots; ++i)
-            if (d.slot[i].pending && d.slot[i].seq <= upto && (best < 0 || d.slot[i].seq < d.slot[best].seq)) best = i;
-        if (best < 0) return QADC_OK;
-        if (int rc = enqueue_merge_now(idx, idx->slot[best])) return rc;
-    }
-}
-
-int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream) {
-    DistState& d = *idx->dist;
-    const int slot_i = (int)(&s - idx->slot);
-    if (slot_i < 0 || slot_i >= kSlots) return QADC_OK;
-    DistSlot& ds = d.slot[slot_i];
-    ds.enqueued = false;
-    ds.pending = false;
-    const int nq = s.nq, R = s.R, world = d.world;
-    // (level-path batches as well: the ordering pass leaves what the pack needs in the query states.  Below dist_device_nq
-    // queries the merge stays at collect time, where the ranks replay shares on the host's otherwise idle cores: enqueuing
-    // such a batch's device merge — or just its pack, gather and copy-out — behind the scan was measured on bench.py's
-    // 32-query flat steps, one of 8 ranks: 1.61-1.65 ms per step against 1.22; interleave + replay kernels under the long
-    // scan launches take 1.5-1.9 ms per batch, the host 0.07)
-    if (!d.async_merge || nq < d.device_nq || (uint32_t)R > replay_wave_max_R() || (size_t)s.ma * world > dist_interleave_max_cells())
-        return QADC_OK;
-    if (!ds.ev_ready) HIPCHECK(hipEventCreateWithFlags(&ds.ev_ready, hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(ds.ev_ready, scan_stream));
-    ds.pending = true;
-    ds.seq = d.next_seq++;
-    if (!s.front_sharded) return flush_merges(idx, ds.seq);     // no front gather to let pass: issue it (and anything older) now
-    return QADC_OK;
-}
+namespace {
 
 int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* assign, float* tables,
                   const int8_t* qtables, int R, int mode = 0, int slice = 0, int nslices = 1,
@@ -1412,6 +587,7 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
     }
     s.full_prescan = false;
     s.rerun = false;
+    s.group_fell_back = false;
     s.front_sharded = false;
     s.assign_on_device = false;
     {   // which path: levels (long shared lists) or one workgroup per query (IVF batches, small lists)
@@ -1436,125 +612,10 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
     return QADC_OK;
 }
 
-// Whether launch_wgq_batch will send a batch of this shape through the partition-major second phase (same test as there).
-bool will_group(const qadc_index* idx, int nq, int ma, bool dev_replay) {
-    const int head_slots = std::min(idx->dist ? idx->wgq_group_head_dist : idx->wgq_group_head, ma);
-    const size_t pairs = (size_t)nq * (size_t)(ma - head_slots), nparts = idx->parts.size();
-    return dev_replay && pairs > 0 && nparts < (1u << 24) &&
-           (idx->wgq_group == 2 || (idx->wgq_group == 1 && idx->group_strikes < 2 && nq >= 256 && pairs >= 2 * nparts));
-}
+}  // namespace
 
-// N1: queries in.  Coarse assignment runs on the copy stream (so it does not queue behind the previous
-// batch's scan), the host reads assign[] back to plan the work items, residuals and float tables are built
-// on the GPU by the main stream.
-int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int ma, int R) {
-    if (!idx || !queries) return fail(QADC_E_ARG, "null argument");
-    if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0 .. 7");
-    if (!idx->finalized) return fail(QADC_E_STATE, "qadc_index_finalize has not been called");
-    if (idx->dim == 0) return fail(QADC_E_STATE, "qadc_index_set_pq has not been called");
-    if (nq <= 0 || ma <= 0 || R <= 0) return fail(QADC_E_ARG, "nq, ma, R must be > 0");
-    if (nq >= (1 << 24) || ma >= (1 << 14)) return fail(QADC_E_ARG, "nq must be < 2^24 and ma < 16384");
-    if (idx->K && (idx->K != (int)idx->parts.size() || ma > idx->K))
-        return fail(QADC_E_ARG, "coarse centroids must match the partitions one to one and ma <= K");
-    if (!idx->K && idx->parts.size() != 1) return fail(QADC_E_ARG, "a database without coarse centroids must be flat (1 partition)");
-    Slot& s = idx->slot[slot_i];
-    if (s.busy) return fail(QADC_E_STATE, "slot still holds an uncollected batch");
-    if (int rc = use_device(idx)) return rc;
-    s.mode = 0;
-    const int dim = idx->dim;
-    s.nq = nq;
-    s.ma = ma;
-    s.R = R;
-    s.float_path = true;
-    s.device_tables = true;
-    s.tables = nullptr;
-    HIPCHECK(s.h_queries.ensure((size_t)nq * dim));
-    HIPCHECK(s.d_queries.ensure((size_t)nq * dim));
-    HIPCHECK(s.h_assign.ensure((size_t)nq * ma));
-    HIPCHECK(s.d_assign.ensure((size_t)nq * ma));
-    std::memcpy(s.h_queries.p, queries, sizeof(float) * (size_t)nq * dim);
-    hipStream_t cs = idx->copy_stream;
-    // Under the multi-GPU merge every rank receives the same queries; what is per QUERY rather than per code — coarse
-    // assignment, residual tables, pre-scan, select, quantizer — is then split over the ranks: rank r does it for queries
-    // [r * per, (r + 1) * per) and one all-gather ships assign[] + int8 tables + (flags, qmin, qmax) to everybody
-    // (launch_wgq_batch).  Only for batches that take the one-workgroup-per-query head + partition-major second phase.
-    s.front_sharded = false;
-    {
-        const uint64_t est = idx->parts.empty() ? 0 : idx->total_codes / idx->parts.size() * (uint64_t)(idx->K ? ma : 1);
-        if (idx->dist && idx->dist->shard_front && idx->dist->world > 1 && idx->K && nq >= 2 * idx->dist->world &&
-            wgq_eligible(idx, nq, ma, R, 0, est) && will_group(idx, nq, ma, true)) {
-            s.front_sharded = true;
-            s.front_per = (nq + idx->dist->world - 1) / idx->dist->world;
-            s.front_q0 = std::min(nq, idx->dist->rank * s.front_per);
-            s.front_n = std::min(nq, s.front_q0 + s.front_per) - s.front_q0;
-        }
-    }
-    if (s.front_sharded) {
-        const size_t tab = (size_t)ma * idx->M * 16;
-        const size_t block = ((size_t)s.front_per * (tab + (size_t)ma * 4 + 16) + 15) & ~(size_t)15;   // [qtables][assign][front] of `per` queries
-        HIPCHECK(s.d_fblock.ensure(block));
-        HIPCHECK(s.d_fgathered.ensure(block * idx->dist->world));
-        HIPCHECK(s.d_front_all.ensure(4 * (size_t)nq));
-        HIPCHECK(s.h_fmap.ensure((size_t)nq * ma * 4 + (size_t)nq * 16, hipHostMallocMapped | hipHostMallocCoherent));
-        if (s.h_fmap.p != s.h_fmap_mapped) {
-            HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.d_fmap), s.h_fmap.p, 0));
-            s.h_fmap_mapped = s.h_fmap.p;
-        }
-        if (s.front_n) {
-            HIPCHECK(hipMemcpyAsync(s.d_queries.p, s.h_queries.p + (size_t)s.front_q0 * dim, sizeof(float) * (size_t)s.front_n * dim,
-                                    hipMemcpyHostToDevice, cs));
-            HIPCHECK(s.d_cdist.ensure((size_t)s.front_n * idx->K));
-            int32_t* d_assign_share = reinterpret_cast<int32_t*>(s.d_fblock.p + (size_t)s.front_per * tab);
-            launch_coarse_assign(s.d_queries.p, idx->d_coarse.p, s.front_n, idx->K, dim, ma, s.d_cdist.p, d_assign_share, cs);
-            HIPCHECK(hipGetLastError());
-        }
-        if (!s.ev_feed) HIPCHECK(hipEventCreateWithFlags(&s.ev_feed, hipEventDisableTiming));
-        HIPCHECK(hipEventRecord(s.ev_feed, cs));
-        s.wgq = true;
-        s.wgq_codes = idx->total_codes / idx->parts.size() * (uint64_t)ma;
-        s.assign_on_device = true;
-        s.full_prescan = false;
-        s.rerun = false;
-        s.wgq_cap = std::max<uint32_t>(s.wgq_cap, idx->wgq_capacity);
-        s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
-        if (int rc = plan_and_launch(idx, s)) return rc;
-        s.busy = true;
-        return QADC_OK;
-    }
-    HIPCHECK(hipMemcpyAsync(s.d_queries.p, s.h_queries.p, sizeof(float) * (size_t)nq * dim, hipMemcpyHostToDevice, cs));
-    if (idx->K) {
-        HIPCHECK(s.d_cdist.ensure((size_t)nq * idx->K));
-        launch_coarse_assign(s.d_queries.p, idx->d_coarse.p, nq, idx->K, dim, ma, s.d_cdist.p, s.d_assign.p, cs);
-        HIPCHECK(hipGetLastError());
-        if (!s.ev_feed) HIPCHECK(hipEventCreateWithFlags(&s.ev_feed, hipEventDisableTiming));
-        HIPCHECK(hipEventRecord(s.ev_feed, cs));             // the tables need assign[] on the device, not the copy below
-        HIPCHECK(hipMemcpyAsync(s.h_assign.p, s.d_assign.p, sizeof(int32_t) * (size_t)nq * ma, hipMemcpyDeviceToHost, cs));
-    } else {
-        HIPCHECK(hipMemsetAsync(s.d_assign.p, 0, sizeof(int32_t) * (size_t)nq * ma, cs));
-        std::memset(s.h_assign.p, 0, sizeof(int32_t) * (size_t)nq * ma);
-        if (!s.ev_feed) HIPCHECK(hipEventCreateWithFlags(&s.ev_feed, hipEventDisableTiming));
-        HIPCHECK(hipEventRecord(s.ev_feed, cs));
-    }
-    if (!s.ev_assign) HIPCHECK(hipEventCreateWithFlags(&s.ev_assign, hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(s.ev_assign, cs));
-    // one workgroup per query: the kernel reads assign[] on the device, the host only wants it back for the caller
-    const uint64_t est_codes = idx->parts.empty() ? 0 : idx->total_codes / idx->parts.size() * (uint64_t)(idx->K ? ma : 1);
-    s.wgq = wgq_eligible(idx, nq, ma, R, 0, est_codes);
-    s.wgq_codes = est_codes;
-    s.assign_on_device = s.wgq;
-    if (!s.wgq) {
-        HIPCHECK(hipStreamSynchronize(cs));                  // the planner needs assign[] on the host
-        s.assign.assign(s.h_assign.p, s.h_assign.p + (size_t)nq * ma);
-    }
-    s.full_prescan = false;
-    s.rerun = false;
-    if (s.wgq) s.wgq_cap = std::max<uint32_t>(s.wgq_cap, idx->wgq_capacity);
-    s.cap_q = std::max<uint32_t>(s.cap_q, idx->cand_capacity);
-    if (!s.wgq) s.out_cap = std::max<uint32_t>(s.out_cap, (uint32_t)std::min<uint64_t>((uint64_t)nq * 8192u, 1ull << 30));
-    if (int rc = plan_and_launch(idx, s)) return rc;
-    s.busy = true;
-    return QADC_OK;
-}
+namespace qadc {
+namespace host {
 
 // Waits for the batch, regrows and re-runs on overflow, and lays the ordered candidate streams
 // (padding-lane replays expanded) out in s.out_*.  Queries the device could not sort (more than
@@ -1562,7 +623,7 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
 // from_dist: the caller is qadc_dist_collect, which consumes the ordered streams where they lie in device memory; a batch
 // submitted under the multi-GPU merge but collected by a plain collect call has no device-side heaps and, on the
 // one-workgroup-per-query path, no host copy of its streams: they are fetched and replayed on the host.
-int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool from_dist = false) {
+int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist) {
     if (!idx) return fail(QADC_E_ARG, "null index");
     if (slot_i < 0 || slot_i >= kSlots) return fail(QADC_E_ARG, "slot must be 0 .. 7");
     Slot& s = idx->slot[slot_i];
@@ -1621,7 +682,11 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool fr
             idx->prof.regrows++;
             if (s.wgq_grouped) {
                 idx->prof.group_fallbacks++;
-                idx->group_strikes++;                            // (auto mode gives the second phase up after two such batches)
+                // (auto mode gives the second phase up after two such batches.  Under the multi-GPU merge that count decides
+                // whether the NEXT batches issue the sharded front's all-gather, so it must move on every rank alike: the
+                // strike travels in the gathered headers and qadc_dist_collect counts it, not this rank by itself)
+                if (idx->dist) s.group_fell_back = true;
+                else idx->group.strikes++;
             }
             s.wgq_grouped = false;
             s.wgq = false;
@@ -1712,7 +777,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream = true, bool fr
                 idx->prof.group_pass_codes8 += full * n;
                 idx->prof.group_seats += full * 8;
                 if (rem) {
-                    const bool narrow = idx->mq_narrow && rem <= 4;
+                    const bool narrow = idx->group.mq_narrow && rem <= 4;
                     (narrow ? idx->prof.group_pass_codes4 : idx->prof.group_pass_codes8) += n;
                     idx->prof.group_seats += narrow ? 4 : 8;
                 }
@@ -1933,8 +998,8 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
     idx->pool.run(tasks, nt, [&](int t) { work(t * per, std::min(s.nq, (t + 1) * per)); });
     return QADC_OK;
 }
-
-}  // namespace
+}  // namespace host
+}  // namespace qadc
 
 extern "C" {
 
@@ -1961,7 +1026,7 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
         if (const char* e = std::getenv("QADC_WGQ")) idx->wgq = std::atoi(e);   // force (2) / forbid (0) the one-workgroup-per-query path
         if (const char* e = std::getenv("QADC_WGQ_POLL")) idx->wgq_poll = std::atoi(e);     // the lone-small-batch shortcuts
         if (const char* e = std::getenv("QADC_WGQ_INLINE")) idx->wgq_inline = std::atoi(e);
-        if (const char* e = std::getenv("QADC_WGQ_GROUP")) idx->wgq_group = std::max(0, std::min(std::atoi(e), 2));
+        if (const char* e = std::getenv("QADC_WGQ_GROUP")) idx->group.mode = std::max(0, std::min(std::atoi(e), 2));
         if (const char* e = std::getenv("QADC_REPLAY_WAVE")) idx->replay_wave = std::atoi(e) != 0;
         if (const char* e = std::getenv("QADC_HEAD_LEVEL")) idx->head_level = std::max(0, std::min(std::atoi(e), kMaxLevels - 1));
     }
@@ -1998,9 +1063,9 @@ int qadc_index_destroy(qadc_index* idx) {
         }
         if (p.d_starts) (void)hipFree(p.d_starts);
     }
-    idx->d_codebooks.release();
-    idx->d_rotation.release();
-    idx->d_coarse.release();
+    idx->feed.d_codebooks.release();
+    idx->feed.d_rotation.release();
+    idx->feed.d_coarse.release();
     idx->d_partdesc.release();
     Slot* all_slots[kSlots + 2];
     for (int i = 0; i < kSlots; ++i) all_slots[i] = &idx->slot[i];
@@ -2228,6 +1293,7 @@ int qadc_index_finalize(qadc_index* idx, float keep) {
     pd.assign(idx->parts.size(), PartDesc{});
     idx->max_start_n = 0;
     idx->total_codes = 0;
+    idx->total_global_codes = 0;
     idx->max_part_n = 0;
     for (size_t i = 0; i < idx->parts.size(); ++i) {
         const Part& p = idx->parts[i];
@@ -2244,6 +1310,7 @@ int qadc_index_finalize(qadc_index* idx, float keep) {
         idx->max_start_n = std::max(idx->max_start_n, p.start_n);
         idx->max_part_n = std::max(idx->max_part_n, p.n);
         idx->total_codes += p.n;
+        idx->total_global_codes += p.global_n;
     }
     HIPCHECK(idx->d_partdesc.ensure(pd.size()));
     HIPCHECK(hipMemcpy(idx->d_partdesc.p, pd.data(), pd.size() * sizeof(PartDesc), hipMemcpyHostToDevice));
@@ -2271,11 +1338,11 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "head_early") idx->head_early = value != 0;
     else if (n == "wgq_inline") idx->wgq_inline = value != 0;
     else if (n == "replay_wave") idx->replay_wave = value != 0;
-    else if (n == "mq_narrow") idx->mq_narrow = value != 0;
+    else if (n == "mq_narrow") idx->group.mq_narrow = value != 0;
     else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);
-    else if (n == "wgq_group") { idx->wgq_group = (int)std::max(0.0, std::min(value, 2.0)); idx->group_strikes = 0; }
-    else if (n == "wgq_group_head") idx->wgq_group_head = idx->wgq_group_head_dist = (int)std::max(1.0, std::min(value, 4096.0));
-    else if (n == "wgq_group_head_dist") idx->wgq_group_head_dist = (int)std::max(1.0, std::min(value, 4096.0));
+    else if (n == "wgq_group") { idx->group.mode = (int)std::max(0.0, std::min(value, 2.0)); idx->group.strikes = 0; }
+    else if (n == "wgq_group_head") idx->group.head = idx->group.head_dist = (int)std::max(1.0, std::min(value, 4096.0));
+    else if (n == "wgq_group_head_dist") idx->group.head_dist = (int)std::max(1.0, std::min(value, 4096.0));
     else if (n == "wgq_poll") idx->wgq_poll = value != 0;
     else if (n == "wgq_split_codes") idx->wgq_split_codes = (uint32_t)std::max(value, 1024.0);
     else if (n == "front_dist") idx->front_dist = value != 0;
@@ -2316,8 +1383,8 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
         idx->dist->inject_failure = value != 0;
     }
-    else if (n == "table_form") idx->table_form = std::max(0, std::min((int)value, 2));
-    else if (n == "wgq_group_cand_cap") idx->wgq_group_cand_cap = (uint32_t)std::max(64.0, std::min(value, (double)kOrderCandCap));
+    else if (n == "table_form") idx->feed.table_form = std::max(0, std::min((int)value, 2));
+    else if (n == "wgq_group_cand_cap") idx->group.cand_cap = (uint32_t)std::max(64.0, std::min(value, (double)kOrderCandCap));
     else if (n == "wgq_cand_cap") idx->wgq_cand_cap = (uint32_t)std::max(1.0, std::min(value, (double)kQueryCandCap));
     else if (n == "wgq_min_nq") idx->wgq_min_nq = (int)std::max(value, 1.0);
     else if (n == "wgq_max_codes") idx->wgq_max_codes = (uint64_t)std::max(value, 0.0);
@@ -2518,66 +1585,6 @@ int qadc_sort_keys_i8(int size, const uint32_t* heap_keys, const int8_t* heap_va
     return QADC_OK;
 }
 
-// Host half of the multi-GPU merge (pyqadc/sharded.py): `gathered` holds, rank after rank, the int32 buffers the
-// ranks contributed to the all-gather: [nq counts][cap keys][ceil(cap/4) words of int8 values]
-// [only when ma > 1: ceil(cap/2) words of u16 assign slots][...].  Queries q_first, q_first + q_step, ... are replayed here in
-// global scan order (assign slot, rank, position) through the reference heap after the (0,127) sentinel.
-int qadc_merge_streams_i8(int world, int nq, int R, uint64_t cap, int ma, const int32_t* gathered, uint64_t buflen,
-                          int q_first, int q_step, const int32_t* status, uint32_t* keys, int8_t* vals, int32_t* sizes) {
-    if (world <= 0 || nq <= 0 || R <= 0 || ma <= 0 || !gathered || !keys || !vals || !sizes || q_step <= 0 || q_first < 0)
-        return fail(QADC_E_ARG, "bad arguments");
-    const uint64_t nv = (cap + 3) / 4, ns = ma > 1 ? (cap + 1) / 2 : 0;
-    if (buflen < (uint64_t)nq + cap + nv + ns) return fail(QADC_E_ARG, "gathered buffers shorter than their layout");
-    // entry offsets of every (rank, query)
-    std::vector<uint64_t> offs((size_t)world * (nq + 1), 0);
-    for (int g = 0; g < world; ++g) {
-        const int32_t* cnt = gathered + (uint64_t)g * buflen;
-        uint64_t* o = offs.data() + (size_t)g * (nq + 1);
-        for (int q = 0; q < nq; ++q) o[q + 1] = o[q] + (uint32_t)cnt[q];
-        if (o[nq] > cap) return fail(QADC_E_CAPACITY, "a rank's stream exceeds the gathered capacity");
-    }
-    std::vector<int> mine;
-    for (int q = q_first; q < nq; q += q_step) mine.push_back(q);
-    auto work = [&](size_t i0, size_t i1) {
-        kv_heap<uint32_t, int8_t> bh(R);
-        std::vector<uint64_t> cur(world);
-        for (size_t i = i0; i < i1; ++i) {
-            const int q = mine[i];
-            sizes[q] = 0;
-            if (status && status[q]) continue;
-            bh.reset();
-            bh.push(0, 127);                                     // db_query_4.cpp:276
-            for (int g = 0; g < world; ++g) cur[g] = offs[(size_t)g * (nq + 1) + q];
-            for (int slot = 0; slot < ma; ++slot)
-                for (int g = 0; g < world; ++g) {
-                    const int32_t* base = gathered + (uint64_t)g * buflen;
-                    const uint32_t* k = reinterpret_cast<const uint32_t*>(base + nq);
-                    const int8_t* v = reinterpret_cast<const int8_t*>(base + nq + cap);
-                    const uint16_t* sl = reinterpret_cast<const uint16_t*>(base + nq + cap + nv);
-                    const uint64_t end = offs[(size_t)g * (nq + 1) + q + 1];
-                    uint64_t& c = cur[g];
-                    // a rank scans its partitions in assign order: its slots are ascending
-                    while (c < end && (ma == 1 || sl[c] == (uint16_t)slot)) {
-                        bh.push(k[c], v[c]);
-                        ++c;
-                    }
-                }
-            sizes[q] = bh.size();
-            std::memcpy(keys + (size_t)q * R, bh.keys(), sizeof(uint32_t) * bh.size());
-            std::memcpy(vals + (size_t)q * R, bh.values(), bh.size());
-        }
-    };
-    const size_t nt = std::min<size_t>(std::min<size_t>(mine.size(), 4), std::max<unsigned>(std::thread::hardware_concurrency(), 1));
-    if (nt <= 1) {
-        work(0, mine.size());
-    } else {
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nt; ++t) th.emplace_back(work, mine.size() * t / nt, mine.size() * (t + 1) / nt);
-        for (auto& x : th) x.join();
-    }
-    return QADC_OK;
-}
-
 int qadc_candidates_i8(qadc_index* idx, int part, const int8_t* qtable, int8_t* out) {
     if (!idx || part < 0 || part >= (int)idx->parts.size() || !qtable || !out) return fail(QADC_E_ARG, "bad arguments");
     const Part& p = idx->parts[part];
@@ -2632,668 +1639,6 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
     return QADC_OK;
 }
 
-int qadc_index_set_pq(qadc_index* idx, int dim, const float* codebooks) {
-    if (!idx || !codebooks || dim <= 0 || dim % idx->M != 0) return fail(QADC_E_ARG, "dim must be a positive multiple of M");
-    if (int rc = use_device(idx)) return rc;
-    const size_t n = (size_t)idx->M * 16 * (dim / idx->M);
-    HIPCHECK(idx->d_codebooks.ensure(n));
-    HIPCHECK(hipMemcpy(idx->d_codebooks.p, codebooks, n * sizeof(float), hipMemcpyHostToDevice));
-    idx->dim = dim;
-    return QADC_OK;
-}
-
-int qadc_index_set_rotation(qadc_index* idx, const float* rotation) {
-    if (!idx) return fail(QADC_E_ARG, "null index");
-    if (idx->dim == 0) return fail(QADC_E_STATE, "call qadc_index_set_pq first");
-    if (!rotation) {
-        idx->has_rotation = false;
-        return QADC_OK;
-    }
-    if (int rc = use_device(idx)) return rc;
-    const size_t n = (size_t)idx->dim * idx->dim;
-    HIPCHECK(idx->d_rotation.ensure(n));
-    HIPCHECK(hipMemcpy(idx->d_rotation.p, rotation, n * sizeof(float), hipMemcpyHostToDevice));
-    idx->has_rotation = true;
-    return QADC_OK;
-}
-
-int qadc_index_set_coarse(qadc_index* idx, int K, const float* centroids) {
-    if (!idx || K <= 0 || !centroids) return fail(QADC_E_ARG, "bad arguments");
-    if (idx->dim == 0) return fail(QADC_E_STATE, "call qadc_index_set_pq first");
-    if (int rc = use_device(idx)) return rc;
-    HIPCHECK(idx->d_coarse.ensure((size_t)K * idx->dim));
-    HIPCHECK(hipMemcpy(idx->d_coarse.p, centroids, (size_t)K * idx->dim * sizeof(float), hipMemcpyHostToDevice));
-    idx->K = K;
-    return QADC_OK;
-}
-
-int qadc_search_submit(qadc_index* idx, int slot, int nq, const float* queries, int ma, int R) {
-    return search_submit(idx, slot, nq, queries, ma, R);
-}
-
-int qadc_search_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
-                        int32_t* assign_out) {
-    if (int rc = collect_common(idx, slot, /*need_stream=*/false)) return rc;
-    Slot& s = idx->slot[slot];
-    std::vector<int32_t> st_local;
-    if (!status) {
-        st_local.resize(s.nq);
-        status = st_local.data();
-    }
-    finish_float_outputs(idx, s, status, nullptr, nullptr);
-    if (assign_out) std::memcpy(assign_out, s.assign.data(), sizeof(int32_t) * s.assign.size());
-    return replay_outputs(idx, s, keys, values, sizes, status);
-}
-
-int qadc_search(qadc_index* idx, int nq, const float* queries, int ma, int R, uint32_t* keys, int8_t* values, int32_t* sizes,
-                int32_t* status, int32_t* assign_out) {
-    if (int rc = search_submit(idx, 0, nq, queries, ma, R)) return rc;
-    return qadc_search_collect(idx, 0, keys, values, sizes, status, assign_out);
-}
-
-int qadc_pq_encode(int M, int dim, const float* codebooks, const void* d_vectors, uint64_t n, void* d_codes, int device_id) {
-    if ((M != 16 && M != 32) || dim <= 0 || dim % M != 0 || !codebooks || (n && (!d_vectors || !d_codes)))
-        return fail(QADC_E_ARG, "bad arguments");
-    HIPCHECK(hipSetDevice(device_id));
-    const size_t ncb = (size_t)M * 16 * (dim / M);
-    float* d_cb = nullptr;
-    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_cb), ncb * sizeof(float)));
-    HIPCHECK(hipMemcpy(d_cb, codebooks, ncb * sizeof(float), hipMemcpyHostToDevice));
-    if (n) launch_pq_encode(static_cast<const float*>(d_vectors), n, M, dim, d_cb, static_cast<uint8_t*>(d_codes), nullptr);
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipDeviceSynchronize());
-    HIPCHECK(hipFree(d_cb));
-    return QADC_OK;
-}
-
-int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vectors, uint64_t n, uint8_t* codes, int device_id) {
-    if (!vectors || !codes) return fail(QADC_E_ARG, "bad arguments");
-    HIPCHECK(hipSetDevice(device_id));
-    float* d_v = nullptr;
-    uint8_t* d_c = nullptr;
-    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_v), std::max<size_t>(1, n * dim * sizeof(float))));
-    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_c), std::max<size_t>(1, n * (M / 2))));
-    HIPCHECK(hipMemcpy(d_v, vectors, n * dim * sizeof(float), hipMemcpyHostToDevice));
-    const int rc = qadc_pq_encode(M, dim, codebooks, d_v, n, d_c, device_id);
-    if (rc == QADC_OK) HIPCHECK(hipMemcpy(codes, d_c, n * (M / 2), hipMemcpyDeviceToHost));
-    HIPCHECK(hipFree(d_v));
-    HIPCHECK(hipFree(d_c));
-    return rc;
-}
-
-/* ---- database build (N4): index_db::add_vectors' compute and the k-means iterations, host buffers in and out ---- */
-extern "C++" {
-namespace {
-struct ScratchFree {                                           // hipFree on every exit path
-    std::vector<void*> p;
-    ~ScratchFree() { for (void* x : p) if (x) (void)hipFree(x); }
-    template <typename T> hipError_t alloc(T** out, size_t bytes) {
-        void* q = nullptr;
-        const hipError_t e = hipMalloc(&q, std::max<size_t>(bytes, 16));
-        if (e == hipSuccess) { p.push_back(q); *out = static_cast<T*>(q); }
-        return e;
-    }
-};
-constexpr uint64_t kBuildChunk = 32768;                        // vectors per pass (the distance scratch is chunk x K floats)
-
-// nearest centroid of every vector, chunk by chunk: the coarse kernels of qadc_search with ma = 1
-int assign_nearest(const float* d_vectors, uint64_t n, int dim, int K, const float* d_coarse, float* d_dist, int32_t* d_assign) {
-    for (uint64_t o = 0; o < n; o += kBuildChunk) {
-        const int cnt = (int)std::min<uint64_t>(kBuildChunk, n - o);
-        launch_coarse_assign(d_vectors + o * dim, d_coarse, cnt, K, dim, 1, d_dist, d_assign + o, nullptr);
-    }
-    HIPCHECK(hipGetLastError());
-    return QADC_OK;
-}
-}  // namespace
-}  // extern "C++"
-
-int qadc_ivf_encode_host(int M, int dim, const float* codebooks, const float* rotation, int K, const float* coarse,
-                         const float* vectors, uint64_t n, int32_t* assign_out, uint8_t* codes, int device_id) {
-    if ((M != 16 && M != 32) || dim <= 0 || dim % M != 0 || !codebooks || K < 0 || (K > 0 && !coarse) ||
-        (n && (!vectors || !codes)))
-        return fail(QADC_E_ARG, "bad arguments");
-    HIPCHECK(hipSetDevice(device_id));
-    ScratchFree mem;
-    const size_t ncb = (size_t)M * 16 * (dim / M);
-    float *d_cb = nullptr, *d_rot = nullptr, *d_coarse = nullptr, *d_v = nullptr, *d_x = nullptr, *d_dist = nullptr;
-    int32_t* d_assign = nullptr;
-    uint8_t* d_codes = nullptr;
-    HIPCHECK(mem.alloc(&d_cb, ncb * sizeof(float)));
-    HIPCHECK(hipMemcpy(d_cb, codebooks, ncb * sizeof(float), hipMemcpyHostToDevice));
-    if (rotation) {
-        HIPCHECK(mem.alloc(&d_rot, sizeof(float) * (size_t)dim * dim));
-        HIPCHECK(hipMemcpy(d_rot, rotation, sizeof(float) * (size_t)dim * dim, hipMemcpyHostToDevice));
-    }
-    if (K > 0) {
-        HIPCHECK(mem.alloc(&d_coarse, sizeof(float) * (size_t)K * dim));
-        HIPCHECK(hipMemcpy(d_coarse, coarse, sizeof(float) * (size_t)K * dim, hipMemcpyHostToDevice));
-        HIPCHECK(mem.alloc(&d_dist, sizeof(float) * (size_t)std::min<uint64_t>(kBuildChunk, std::max<uint64_t>(n, 1)) * K));
-        HIPCHECK(mem.alloc(&d_assign, sizeof(int32_t) * n));
-    }
-    HIPCHECK(mem.alloc(&d_v, sizeof(float) * n * dim));
-    HIPCHECK(mem.alloc(&d_codes, n * (size_t)(M / 2)));
-    HIPCHECK(hipMemcpy(d_v, vectors, sizeof(float) * n * dim, hipMemcpyHostToDevice));
-    const float* d_enc = d_v;
-    if (n && K > 0)
-        if (int rc = assign_nearest(d_v, n, dim, K, d_coarse, d_dist, d_assign)) return rc;
-    if (n && (K > 0 || rotation)) {
-        HIPCHECK(mem.alloc(&d_x, sizeof(float) * n * dim));
-        launch_residual_rotate(d_v, n, dim, d_coarse, d_assign, d_rot, d_x, nullptr);
-        d_enc = d_x;
-    }
-    if (n) launch_pq_encode(d_enc, n, M, dim, d_cb, d_codes, nullptr);
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipDeviceSynchronize());
-    HIPCHECK(hipMemcpy(codes, d_codes, n * (size_t)(M / 2), hipMemcpyDeviceToHost));
-    if (assign_out && K > 0) HIPCHECK(hipMemcpy(assign_out, d_assign, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    return QADC_OK;
-}
-
-int qadc_kmeans_iterations_host(const float* vectors, uint64_t n, int dim, int K, float* centroids, int iters, int32_t* assign_out,
-                                int device_id) {
-    if (!vectors || !centroids || n == 0 || dim <= 0 || dim > 2048 || K <= 0 || iters < 0) return fail(QADC_E_ARG, "bad arguments");
-    HIPCHECK(hipSetDevice(device_id));
-    ScratchFree mem;
-    float *d_v = nullptr, *d_c = nullptr, *d_dist = nullptr;
-    int32_t* d_assign = nullptr;
-    HIPCHECK(mem.alloc(&d_v, sizeof(float) * n * dim));
-    HIPCHECK(mem.alloc(&d_c, sizeof(float) * (size_t)K * dim));
-    HIPCHECK(mem.alloc(&d_dist, sizeof(float) * (size_t)std::min<uint64_t>(kBuildChunk, n) * K));
-    HIPCHECK(mem.alloc(&d_assign, sizeof(int32_t) * n));
-    HIPCHECK(hipMemcpy(d_v, vectors, sizeof(float) * n * dim, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(d_c, centroids, sizeof(float) * (size_t)K * dim, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemset(d_assign, 0, sizeof(int32_t) * n));
-    for (int it = 0; it < iters; ++it) {                       // databases.cpp:57-89
-        if (int rc = assign_nearest(d_v, n, dim, K, d_c, d_dist, d_assign)) return rc;
-        launch_kmeans_update(d_v, n, dim, K, d_assign, d_c, nullptr);
-    }
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipDeviceSynchronize());
-    HIPCHECK(hipMemcpy(centroids, d_c, sizeof(float) * (size_t)K * dim, hipMemcpyDeviceToHost));
-    if (assign_out) HIPCHECK(hipMemcpy(assign_out, d_assign, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    return QADC_OK;
-}
-
-extern "C++" {
-namespace {
-// The host half of qadc_dist_collect for few-query batches: rank `rank` replays the queries q = rank, rank + world, ...
-// of the gathered blocks ([nq x {offset, count, flags, -} as u32][entries ...] per rank, `bw` words each) in GLOBAL scan
-// order — assign slot, then rank (= ascending code range), then position — through the reference's heap, sentinel first
-// (db_query_4.cpp:276).  myheaps: [ceil(nq / world)][R + 1] words, heap entries key | value << 32, then the size.
-void replay_my_share(const uint64_t* gathered, size_t bw, int world, int rank, int nq, int ma, int R, const int32_t* status,
-                     uint64_t* myheaps, WorkerPool* pool) {
-    const int per = (nq + world - 1) / world;
-    const size_t hw = (size_t)R + 1;
-    auto work = [&](int j0, int j1) {
-        kv_heap<uint32_t, int8_t> bh(R);
-        std::vector<uint32_t> cur(world), end(world);
-        for (int j = j0; j < j1; ++j) {
-            const int q = j * world + rank;
-            if (q >= nq || (status && status[q])) continue;
-            bh.reset();
-            bh.push(0, 127);
-            for (int g = 0; g < world; ++g) {
-                const uint32_t* h = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * bw) + 4 * (size_t)q;
-                cur[g] = h[0];
-                end[g] = h[0] + h[1];
-            }
-            for (int slot = 0; slot < ma; ++slot)
-                for (int g = 0; g < world; ++g) {
-                    const uint64_t* ent = gathered + (size_t)g * bw + 2 * (size_t)nq;
-                    while (cur[g] < end[g]) {                    // a rank scans its partitions in assign order: slots ascend
-                        const uint64_t e = ent[cur[g]];
-                        if (ma > 1 && (int)((e >> 40) & 0x3fffu) != slot) break;
-                        bh.push((uint32_t)e, (int8_t)(e >> 32));
-                        ++cur[g];
-                    }
-                }
-            uint64_t* o = myheaps + (size_t)j * hw;
-            for (int i = 0; i < bh.size(); ++i) o[i] = (uint64_t)bh.keys()[i] | ((uint64_t)(uint8_t)bh.values()[i] << 32);
-            o[R] = (uint64_t)bh.size();
-        }
-    };
-    const int nt = std::max(1, std::min<int>(std::min(per, 8), (int)std::thread::hardware_concurrency()));
-    if (nt == 1 || !pool) {
-        work(0, per);
-    } else {
-        pool->run(per, nt, [&](int j) { work(j, j + 1); });     // one query per task: their stream lengths differ
-    }
-}
-}  // namespace
-}  // extern "C++"
-
-/* ---- native multi-GPU merge: one ncclAllGather per batch, device memory to device memory ---- */
-int qadc_dist_unique_id(uint8_t* id128) {
-    if (!id128) return fail(QADC_E_ARG, "id is null");
-    DistState tmp;
-    std::string err;
-    if (load_rccl(tmp, err)) return fail(QADC_E_HIP, err);
-    QadcNcclId id;
-    const int rc = tmp.GetUniqueId(&id);
-    if (rc != 0) return fail(QADC_E_HIP, std::string("ncclGetUniqueId: ") + (tmp.GetErrorString ? tmp.GetErrorString(rc) : "error"));
-    std::memcpy(id128, id.internal, 128);
-    return QADC_OK;                                          // (the library handle stays loaded for the process)
-}
-
-extern "C++" {
-namespace {
-// Releases a half-built DistState on every exit path of the init calls (communicator, stream).
-struct DistGuard {
-    std::unique_ptr<DistState> d;
-    ~DistGuard() {
-        if (!d) return;
-        if (d->stream) { (void)hipStreamSynchronize(d->stream); }
-        for (hipStream_t m : d->merge_stream) if (m) { (void)hipStreamSynchronize(m); }
-        if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
-        if (d->stream) (void)hipStreamDestroy(d->stream);
-        for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamDestroy(m);
-    }
-};
-int dist_init_checks(qadc_index* idx, int rank, int world) {
-    if (!idx || world < 1 || world > 16 || rank < 0 || rank >= world) return fail(QADC_E_ARG, "need 0 <= rank < world <= 16");
-    if (idx->dist) return fail(QADC_E_STATE, "qadc_dist_init was already called");
-    for (auto& sl : idx->slot)
-        if (sl.busy) return fail(QADC_E_STATE, "collect every batch before qadc_dist_init");
-    return use_device(idx);
-}
-}  // namespace
-}  // extern "C++"
-
-int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
-    if (!id128) return fail(QADC_E_ARG, "id is null");
-    if (int rc = dist_init_checks(idx, rank, world)) return rc;
-    DistGuard g;
-    g.d.reset(new DistState());
-    DistState* d = g.d.get();
-    std::string err;
-    if (load_rccl(*d, err)) return fail(QADC_E_HIP, err);
-    QadcNcclId id;
-    std::memcpy(id.internal, id128, 128);
-    const int rc = d->CommInitRank(&d->comm, world, id, rank);
-    if (rc != 0) {
-        d->comm = nullptr;
-        return fail(QADC_E_HIP, std::string("ncclCommInitRank: ") + (d->GetErrorString ? d->GetErrorString(rc) : "error"));
-    }
-    d->rank = rank;
-    d->world = world;
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
-    // (NOT the collectives' priority: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
-    // queue as the collectives' stream a replay sat in front of the next batch's gather — seen in the trace.  And not ABOVE
-    // the scans either: at normal priority the interleave / replay waves held up the short launches between two batches'
-    // scans on the lowest-priority scan stream — one of 8 ranks, 1024-query batches, C5 shape 1.18 -> 1.10 ms, C3 0.70 ->
-    // 0.60 with the merges at the scans' own, lowest priority.)
-    for (int i = 0; i < kSlots; ++i)
-        HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream[i], hipStreamNonBlocking, prio_least));
-    // RCCL finishes setting up its channels lazily, inside the first collectives of a communicator (the very first
-    // all-gather takes ~8 ms); a few throw-away gathers here keep that out of the first batches' collect calls.
-    {
-        constexpr size_t kWords = 1 << 16;
-        DevBuf<uint64_t> src, dst;
-        hipError_t he = src.ensure(kWords);
-        if (he == hipSuccess) he = dst.ensure(kWords * world);
-        if (he == hipSuccess) he = hipMemsetAsync(src.p, 0, sizeof(uint64_t) * kWords, d->stream);
-        int rc2 = 0;
-        for (int i = 0; i < 16 && he == hipSuccess && rc2 == 0; ++i)
-            rc2 = d->AllGather(src.p, dst.p, kWords, /*ncclUint64*/ 5, d->comm, d->stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(d->stream);
-        src.release(); dst.release();
-        if (rc2 != 0) return fail(QADC_E_HIP, std::string("ncclAllGather: ") + (d->GetErrorString ? d->GetErrorString(rc2) : "error"));
-        HIPCHECK(he);
-    }
-    idx->dist = g.d.release();
-    return QADC_OK;
-}
-
-extern "C++" {
-namespace {
-// Measurement aid (qadc_dist_init_loopback): ONE rank stands in for a whole world — its block fills every slot of the
-// gather, so the merge replays `world` ranks' worth of entries while only this rank's shard is scanned.
-int loopback_allgather(void* ctx, const void* d_send, void* d_recv, uint64_t bytes, void* st) {
-    const int world = (int)reinterpret_cast<intptr_t>(ctx);
-    return launch_replicate_block(d_send, d_recv, (size_t)(bytes / 8), world, static_cast<hipStream_t>(st)) == hipSuccess ? 0 : 1;
-}
-}  // namespace
-}  // extern "C++"
-
-int qadc_dist_init_loopback(qadc_index* idx, int rank, int world) {
-    return qadc_dist_init_transport(idx, rank, world, loopback_allgather, reinterpret_cast<void*>((intptr_t)world));
-}
-
-int qadc_dist_init_transport(qadc_index* idx, int rank, int world, qadc_allgather_fn fn, void* ctx) {
-    if (!fn) return fail(QADC_E_ARG, "the all-gather callback is null");
-    if (int rc = dist_init_checks(idx, rank, world)) return rc;
-    DistGuard g;
-    g.d.reset(new DistState());
-    DistState* d = g.d.get();
-    d->user_fn = fn;
-    d->user_ctx = ctx;
-    d->rank = rank;
-    d->world = world;
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
-    // (NOT the collectives' priority: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
-    // queue as the collectives' stream a replay sat in front of the next batch's gather — seen in the trace.  And not ABOVE
-    // the scans either: at normal priority the interleave / replay waves held up the short launches between two batches'
-    // scans on the lowest-priority scan stream — one of 8 ranks, 1024-query batches, C5 shape 1.18 -> 1.10 ms, C3 0.70 ->
-    // 0.60 with the merges at the scans' own, lowest priority.)
-    for (int i = 0; i < kSlots; ++i)
-        HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream[i], hipStreamNonBlocking, prio_least));
-    idx->dist = g.d.release();
-    return QADC_OK;
-}
-
-int qadc_dist_merge_blocks(int device_id, int world, int nq, int ma, int R, const uint64_t* gathered, uint64_t block_words,
-                           uint32_t* keys, int8_t* values, int32_t* sizes) {
-    if (world < 1 || world > 16 || nq <= 0 || ma <= 0 || R <= 0 || (uint32_t)R > replay_wave_max_R() ||
-        (size_t)ma * world > dist_interleave_max_cells() || !gathered || !sizes)
-        return fail(QADC_E_ARG, "bad arguments");
-    HIPCHECK(hipSetDevice(device_id));
-    DevBuf<uint64_t> d_g, d_h, d_off, d_m;
-    DevBuf<uint32_t> d_s, d_c;
-    HIPCHECK(d_g.ensure((size_t)block_words * world));
-    HIPCHECK(d_h.ensure((size_t)nq * R));
-    HIPCHECK(d_s.ensure(nq));
-    HIPCHECK(d_off.ensure(nq));
-    HIPCHECK(d_c.ensure(2 * (size_t)nq));
-    HIPCHECK(d_m.ensure((size_t)block_words * world));
-    HIPCHECK(hipMemcpy(d_g.p, gathered, sizeof(uint64_t) * (size_t)block_words * world, hipMemcpyHostToDevice));
-    HIPCHECK(launch_dist_merge(d_g.p, (size_t)block_words, world, nq, ma, (uint32_t)R, d_off.p, d_c.p, d_c.p + nq, d_m.p, d_h.p, d_s.p,
-                               nullptr));
-    std::vector<uint64_t> hv((size_t)nq * R);
-    std::vector<uint32_t> hs(nq);
-    HIPCHECK(hipMemcpy(hv.data(), d_h.p, sizeof(uint64_t) * hv.size(), hipMemcpyDeviceToHost));
-    HIPCHECK(hipMemcpy(hs.data(), d_s.p, sizeof(uint32_t) * nq, hipMemcpyDeviceToHost));
-    d_g.release(); d_h.release(); d_s.release(); d_off.release(); d_c.release(); d_m.release();
-    for (int q = 0; q < nq; ++q) {
-        sizes[q] = hs[q] == 0xffffffffu ? -1 : (int32_t)hs[q];
-        for (uint32_t i = 0; hs[q] != 0xffffffffu && i < hs[q]; ++i) {
-            if (keys) keys[(size_t)q * R + i] = (uint32_t)hv[(size_t)q * R + i];
-            if (values) values[(size_t)q * R + i] = (int8_t)(hv[(size_t)q * R + i] >> 32);
-        }
-    }
-    return QADC_OK;
-}
-
-int qadc_dist_merge_blocks_host(int world, int nq, int ma, int R, const uint64_t* gathered, uint64_t block_words,
-                                uint32_t* keys, int8_t* values, int32_t* sizes) {
-    if (world < 1 || world > 16 || nq <= 0 || ma <= 0 || R <= 0 || !gathered || !sizes) return fail(QADC_E_ARG, "bad arguments");
-    // what the ranks of qadc_dist_collect do between their two all-gathers, rank by rank: every rank replays its share,
-    // the second gather concatenates the shares ([rank][ceil(nq / world)][R + 1]), every rank reads all heaps back
-    const int per = (nq + world - 1) / world;
-    const size_t hw = (size_t)R + 1;
-    std::vector<uint64_t> all((size_t)world * per * hw, 0);
-    for (int r = 0; r < world; ++r)
-        replay_my_share(gathered, (size_t)block_words, world, r, nq, ma, R, nullptr, all.data() + (size_t)r * per * hw, nullptr);
-    for (int q = 0; q < nq; ++q) {
-        const uint64_t* o = all.data() + ((size_t)(q % world) * per + q / world) * hw;
-        sizes[q] = (int32_t)o[R];
-        for (int i = 0; i < sizes[q]; ++i) {
-            if (keys) keys[(size_t)q * R + i] = (uint32_t)o[i];
-            if (values) values[(size_t)q * R + i] = (int8_t)(o[i] >> 32);
-        }
-    }
-    return QADC_OK;
-}
-
-int qadc_dist_shutdown(qadc_index* idx) {
-    if (!idx || !idx->dist) return QADC_OK;
-    (void)hipSetDevice(idx->device);
-    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
-    DistState* d = idx->dist;
-    if (d->stream) (void)hipStreamSynchronize(d->stream);
-    for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamSynchronize(m);
-    if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
-    if (d->stream) (void)hipStreamDestroy(d->stream);
-    for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamDestroy(m);
-    d->d_fix.release(); d->h_fix.release(); d->d_moff.release(); d->d_merged.release(); d->d_mcnt.release();
-    for (auto& ds : d->slot) ds.release();
-    d->d_block.release(); d->d_gathered.release(); d->d_src.release(); d->h_src.release(); d->d_extra.release(); d->d_extra_all.release();
-    d->h_extra.release(); d->h_out.release(); d->h_hdr.release(); d->h_extra_all.release();
-    d->h_gathered.release(); d->h_myheaps.release(); d->d_myheaps.release(); d->d_allheaps.release(); d->h_allheaps.release();
-    delete d;
-    idx->dist = nullptr;
-    return QADC_OK;
-}
-
-int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values, int32_t* sizes, int32_t* status,
-                      const float* extra, int extra_n, float* extra_out) {
-    if (!idx || !idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
-    if (slot < 0 || slot >= kSlots) return fail(QADC_E_ARG, "slot must be 0 .. 7");
-    if (extra_n < 0 || (extra_n && (!extra || !extra_out))) return fail(QADC_E_ARG, "extra payload buffers missing");
-    DistState& d = *idx->dist;
-    Slot& s = idx->slot[slot];
-    // caller errors — the same on every rank of a well-formed program — return before any rank enters the collective
-    if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
-    if (!s.dist_batch) return fail(QADC_E_STATE, "the batch was submitted before qadc_dist_init");
-    if (int rc = use_device(idx)) return rc;
-    const int nq = s.nq, R = s.R, world = d.world;
-    // A failure of THIS rank's batch (candidate buffers that keep overflowing, a HIP error while re-running it) must not
-    // leave the other ranks blocked in the gather: the rank still contributes a block, with bit7 set in every header, and
-    // all ranks return the error after the gather.
-    DistSlot& ds = d.slot[slot];
-    if (ds.pending)
-        if (int rc = flush_merges(idx, ds.seq)) return rc;
-    const bool was_enqueued = ds.enqueued;
-    if (was_enqueued) {                                       // the merge ran behind the scan: wait for all of it
-        HIPCHECK(hipEventSynchronize(ds.ev_done));
-        ds.enqueued = false;
-    }
-    int local_rc = collect_common(idx, slot, /*need_stream=*/false, /*from_dist=*/true);
-    std::string local_err = local_rc ? g_err : std::string();
-    if (was_enqueued) {
-        const uint32_t* h_sz = reinterpret_cast<const uint32_t*>(ds.h_out.p + sizeof(uint64_t) * (size_t)R * nq);
-        const uint32_t bad = h_sz[nq], need = h_sz[nq + 1];
-        if (!bad) {
-            // every rank saw clean headers: the heaps are final (a local failure of collect_common concerns this rank only)
-            if (local_rc) return fail(local_rc, local_err);
-            idx->prof.dist_async_collects++;
-            std::vector<int32_t> st_async;
-            int32_t* stp = status;
-            if (!stp) { st_async.resize(nq); stp = st_async.data(); }
-            finish_float_outputs(idx, s, stp, nullptr, nullptr);
-            const uint64_t* hh = reinterpret_cast<const uint64_t*>(ds.h_out.p);
-            for (int q = 0; q < nq; ++q) {
-                uint32_t sz = h_sz[q];
-                if (stp[q] || sz == 0xffffffffu) sz = 0;
-                if (sizes) sizes[q] = (int32_t)sz;
-                const uint64_t* hv = hh + (size_t)q * R;
-                for (uint32_t i = 0; i < sz; ++i) {
-                    if (keys) keys[(size_t)q * R + i] = (uint32_t)hv[i];
-                    if (values) values[(size_t)q * R + i] = (int8_t)(hv[i] >> 32);
-                }
-            }
-            if (extra_n) {                                    // (a payload on such a batch travels by a small gather of its own)
-                const size_t w = ((size_t)extra_n + 1) / 2;
-                HIPCHECK(d.h_extra.ensure(2 * w));
-                HIPCHECK(d.d_extra.ensure(2 * w));
-                HIPCHECK(d.h_extra_all.ensure(2 * w * world));
-                HIPCHECK(d.d_extra_all.ensure(w * world));       // (not d_block: a later batch's merge may be using that)
-                std::memcpy(d.h_extra.p, extra, sizeof(float) * extra_n);
-                HIPCHECK(hipMemcpyAsync(d.d_extra.p, d.h_extra.p, sizeof(uint64_t) * w, hipMemcpyHostToDevice, d.stream));
-                std::string gerr2;
-                if (d.gather(d.d_extra.p, d.d_extra_all.p, w, d.stream, gerr2)) return fail(QADC_E_HIP, gerr2);
-                HIPCHECK(hipMemcpy2DAsync(d.h_extra_all.p, sizeof(float) * extra_n, d.d_extra_all.p, sizeof(uint64_t) * w,
-                                          sizeof(float) * extra_n, world, hipMemcpyDeviceToHost, d.stream));
-                HIPCHECK(hipStreamSynchronize(d.stream));
-                std::memcpy(extra_out, d.h_extra_all.p, sizeof(float) * (size_t)world * extra_n);
-            }
-            return QADC_OK;
-        }
-        // Some rank's stream overflowed its region or the gather block (identical verdict on every rank: they read the same
-        // headers): the merge is redone below, at collect time, after collect_common re-ran what had to be re-run.
-        if ((bad & 64u) && need + need / 8 > d.cap_entries && need < (1ull << 31))
-            d.cap_entries = (uint32_t)(((uint64_t)need + need / 8 + 4095) / 4096 * 4096);
-        idx->prof.regrows++;
-    }
-    if (d.inject_failure && !local_rc) {                      // test hook (option "dist_inject_failure")
-        d.inject_failure = 0;
-        local_rc = QADC_E_STATE;
-        local_err = "injected failure (test hook)";
-    }
-    std::vector<int32_t> st_local;
-    if (!status) {
-        st_local.resize(nq);
-        status = st_local.data();
-    }
-    if (!local_rc) finish_float_outputs(idx, s, status, nullptr, nullptr);
-    // where this rank's ordered streams lie in device memory
-    HIPCHECK(d.h_src.ensure(3 * (size_t)nq));
-    HIPCHECK(d.d_src.ensure(3 * (size_t)nq));
-    uint64_t fix_total = 0;
-    for (int q = 0; q < nq && !local_rc; ++q) {
-        const uint32_t fl = s.h_qout[q].flags;
-        if (!(fl & 4u) && !(fl & 1u)) fix_total += s.out_off[q + 1] - s.out_off[q];   // ordered by collect_common on the host
-    }
-    if (fix_total >= (1ull << 31)) return fail(QADC_E_CAPACITY, "host-ordered streams exceed 2^31 entries");
-    if (fix_total) {
-        HIPCHECK(d.h_fix.ensure(fix_total));
-        HIPCHECK(d.d_fix.ensure(fix_total));
-    }
-    uint64_t fix_off = 0;
-    for (int q = 0; q < nq; ++q) {
-        if (local_rc) {
-            d.h_src.p[q] = 0;
-            d.h_src.p[nq + q] = 0;
-            d.h_src.p[2 * nq + q] = 128u;
-            continue;
-        }
-        const QueryOut& qs = s.h_qout[q];
-        const bool ordered = (qs.flags & 4u) != 0;
-        d.h_src.p[q] = qs.out_off;
-        d.h_src.p[nq + q] = ordered ? qs.count + qs.reps : 0u;
-        d.h_src.p[2 * nq + q] = qs.flags & 0x3fu;
-        if (!ordered && !(qs.flags & 1u)) {
-            // more candidates than the device sort takes (> 16384): collect_common sorted the query's raw region on the host;
-            // its stream travels in the same gather from a side buffer
-            const uint64_t n = s.out_off[q + 1] - s.out_off[q];
-            std::memcpy(d.h_fix.p + fix_off, s.out_entries.data() + s.out_off[q], sizeof(uint64_t) * n);
-            d.h_src.p[q] = (uint32_t)fix_off;
-            d.h_src.p[nq + q] = (uint32_t)n;
-            d.h_src.p[2 * nq + q] = (qs.flags & 0x3fu) | 4u | 256u;
-            fix_off += n;
-        }
-    }
-    // Buffers are sized on the FIRST call for a payload of nq x R floats per rank (the sharded pre-scan's) whether or not
-    // this call carries one: the pinned allocations and the larger gather blocks a first payload would otherwise need
-    // cost milliseconds, and a pipeline's first batches typically come without payload.
-    const size_t extra_room = std::max<size_t>((size_t)extra_n, (size_t)nq * (size_t)R);
-    HIPCHECK(d.h_extra.ensure(extra_room));
-    HIPCHECK(d.d_extra.ensure(extra_room));
-    HIPCHECK(d.h_extra_all.ensure((size_t)world * extra_room));
-    if (extra_n) std::memcpy(d.h_extra.p, extra, sizeof(float) * extra_n);
-    const size_t heaps_bytes = (sizeof(uint64_t) * (size_t)R + sizeof(uint32_t)) * (size_t)nq;
-    HIPCHECK(d.h_out.ensure(heaps_bytes + 16, hipHostMallocMapped | hipHostMallocCoherent));
-    if (d.h_out.p != d.h_out_mapped) {
-        HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d.d_out), d.h_out.p, 0));
-        d.h_out_mapped = d.h_out.p;
-    }
-    HIPCHECK(d.h_hdr.ensure((size_t)world * nq * 4));
-    hipStream_t st = d.stream;                               // the batch itself is complete (collect_common waited for it)
-    uint64_t* h_heaps = reinterpret_cast<uint64_t*>(d.h_out.p);
-    uint32_t* h_sizes = reinterpret_cast<uint32_t*>(d.h_out.p + sizeof(uint64_t) * (size_t)R * nq);
-    // the device merge keeps a query's heap in the registers of one wave (R <= 320) and interleaves the ranks' streams with
-    // ma x world counters in LDS; anything larger takes the host share
-    const bool on_device = nq >= d.device_nq && (uint32_t)R <= replay_wave_max_R() &&
-                           (size_t)s.ma * world <= dist_interleave_max_cells();
-    std::string gerr;
-    for (int attempt = 0;; ++attempt) {
-        const size_t bw = dist_block_words(nq, d.cap_entries, (uint32_t)extra_n);
-        const size_t bw_room = dist_block_words(nq, d.cap_entries, (uint32_t)extra_room);
-        HIPCHECK(d.d_block.ensure(bw_room));
-        HIPCHECK(d.d_gathered.ensure(bw_room * world));
-        HIPCHECK(hipMemcpyAsync(d.d_src.p, d.h_src.p, sizeof(uint32_t) * 3 * nq, hipMemcpyHostToDevice, st));
-        if (extra_n) HIPCHECK(hipMemcpyAsync(d.d_extra.p, d.h_extra.p, sizeof(float) * extra_n, hipMemcpyHostToDevice, st));
-        if (fix_total) HIPCHECK(hipMemcpyAsync(d.d_fix.p, d.h_fix.p, sizeof(uint64_t) * fix_total, hipMemcpyHostToDevice, st));
-        HIPCHECK(launch_dist_pack(d.d_src.p, d.d_src.p + nq, d.d_src.p + 2 * nq, nq, s.d_stream.p, d.d_fix.p, d.cap_entries,
-                                  extra_n ? d.d_extra.p : nullptr, (uint32_t)extra_n, d.d_block.p, st));
-        if (d.gather(d.d_block.p, d.d_gathered.p, bw, st, gerr)) return fail(QADC_E_HIP, gerr);
-        if (on_device) {
-            HIPCHECK(d.d_moff.ensure(nq));
-            HIPCHECK(d.d_mcnt.ensure(2 * (size_t)nq));
-            HIPCHECK(d.d_merged.ensure((size_t)d.cap_entries * world));
-            HIPCHECK(launch_dist_merge(d.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, d.d_moff.p, d.d_mcnt.p, d.d_mcnt.p + nq,
-                                       d.d_merged.p, reinterpret_cast<uint64_t*>(d.d_out),
-                                       reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq), st));
-        } else {
-            HIPCHECK(d.h_gathered.ensure(bw_room * world));
-            HIPCHECK(hipMemcpyAsync(d.h_gathered.p, d.d_gathered.p, sizeof(uint64_t) * bw * world, hipMemcpyDeviceToHost, st));
-        }
-        // every rank's header (to size a retry identically everywhere) and extra payload come back with the heaps
-        HIPCHECK(hipMemcpy2DAsync(d.h_hdr.p, sizeof(uint32_t) * 4 * nq, d.d_gathered.p, sizeof(uint64_t) * bw,
-                                  sizeof(uint32_t) * 4 * nq, world, hipMemcpyDeviceToHost, st));
-        if (extra_n)
-            HIPCHECK(hipMemcpy2DAsync(d.h_extra_all.p, sizeof(float) * extra_n, d.d_gathered.p + 2 * (size_t)nq + d.cap_entries,
-                                      sizeof(uint64_t) * bw, sizeof(float) * extra_n, world, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
-        uint64_t need = 0;
-        bool overflow = false, unordered = false;
-        int failed_rank = -1;
-        for (int g = 0; g < world; ++g) {
-            uint64_t tot = 0;
-            for (int q = 0; q < nq; ++q) {
-                const uint32_t* h = d.h_hdr.p + ((size_t)g * nq + q) * 4;
-                tot += h[1];
-                overflow |= (h[2] & 64u) != 0;
-                if ((h[2] & 128u) && failed_rank < 0) failed_rank = g;
-                unordered |= !(h[2] & 4u) && !(h[2] & 1u) && !(h[2] & 128u);
-            }
-            need = std::max(need, tot);
-        }
-        // (every rank reads the same headers: the same branch is taken everywhere, no rank stays behind in a collective)
-        if (failed_rank >= 0) {
-            if (extra_n) std::memcpy(extra_out, d.h_extra_all.p, sizeof(float) * (size_t)world * extra_n);
-            return fail(local_rc ? local_rc : QADC_E_STATE,
-                        local_rc ? local_err : "rank " + std::to_string(failed_rank) + " failed before the gather (see its own error)");
-        }
-        if (unordered) return fail(QADC_E_STATE, "a rank shipped a query without ordering it");
-        if (overflow) {
-            if (attempt >= 2 || need >= (1ull << 31)) return fail(QADC_E_CAPACITY, "gather block overflow persists");
-            d.cap_entries = (uint32_t)((need + need / 8 + 4095) / 4096 * 4096);   // the same on every rank: they all saw the same headers
-            idx->prof.regrows++;
-            continue;
-        }
-        if (on_device) break;
-        // ---- few queries (or R > 288): replay my share on the host (global scan order: assign slot, rank, position), share the heaps ----
-        const int per = (nq + world - 1) / world;
-        const size_t hw = (size_t)R + 1;                       // words per query in the heap exchange
-        HIPCHECK(d.h_myheaps.ensure((size_t)per * hw));
-        HIPCHECK(d.d_myheaps.ensure((size_t)per * hw));
-        HIPCHECK(d.d_allheaps.ensure((size_t)per * hw * world));
-        HIPCHECK(d.h_allheaps.ensure((size_t)per * hw * world));
-        std::memset(d.h_myheaps.p, 0, sizeof(uint64_t) * (size_t)per * hw);
-        {
-            ScopedMs timer(idx->prof.host_heap_ms);
-            replay_my_share(d.h_gathered.p, bw, world, d.rank, nq, s.ma, R, status, d.h_myheaps.p, &idx->pool);
-        }
-        HIPCHECK(hipMemcpyAsync(d.d_myheaps.p, d.h_myheaps.p, sizeof(uint64_t) * (size_t)per * hw, hipMemcpyHostToDevice, st));
-        if (d.gather(d.d_myheaps.p, d.d_allheaps.p, (size_t)per * hw, st, gerr)) return fail(QADC_E_HIP, gerr);
-        HIPCHECK(hipMemcpyAsync(d.h_allheaps.p, d.d_allheaps.p, sizeof(uint64_t) * (size_t)per * hw * world, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
-        for (int q = 0; q < nq; ++q) {
-            const uint64_t* o = d.h_allheaps.p + ((size_t)(q % world) * per + q / world) * hw;
-            h_sizes[q] = (uint32_t)o[R];
-            std::memcpy(h_heaps + (size_t)q * R, o, sizeof(uint64_t) * (size_t)R);
-        }
-        break;
-    }
-    for (int q = 0; q < nq; ++q) {
-        uint32_t sz = h_sizes[q];
-        if (status[q] || sz == 0xffffffffu) sz = 0;
-        if (sizes) sizes[q] = (int32_t)sz;
-        const uint64_t* hv = h_heaps + (size_t)q * R;
-        for (uint32_t i = 0; i < sz; ++i) {
-            if (keys) keys[(size_t)q * R + i] = (uint32_t)hv[i];
-            if (values) values[(size_t)q * R + i] = (int8_t)(hv[i] >> 32);
-        }
-    }
-    if (extra_n) std::memcpy(extra_out, d.h_extra_all.p, sizeof(float) * (size_t)world * extra_n);
-    return QADC_OK;
-}
-
 int qadc_slot_assign(qadc_index* idx, int slot, int32_t* assign_out) {
     if (!idx || slot < 0 || slot >= kSlots || !assign_out) return fail(QADC_E_ARG, "bad arguments");
     const Slot& s = idx->slot[slot];
@@ -3313,22 +1658,6 @@ int qadc_slot_qtables(qadc_index* idx, int slot, int q_first, int q_count, int8_
     const size_t per_q = (size_t)s.ma * idx->M * 16;
     HIPCHECK(hipMemcpyAsync(out, s.d_qt + (size_t)q_first * per_q, (size_t)q_count * per_q, hipMemcpyDeviceToHost, idx->copy_stream));
     HIPCHECK(hipStreamSynchronize(idx->copy_stream));
-    return QADC_OK;
-}
-
-int qadc_place_partitions(int part_count, const uint32_t* sizes, int world, int32_t* owner_out) {
-    if (part_count < 0 || world < 1 || (part_count && (!sizes || !owner_out))) return fail(QADC_E_ARG, "bad arguments");
-    std::vector<int> order(part_count);
-    for (int p = 0; p < part_count; ++p) order[p] = p;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sizes[a] > sizes[b]; });
-    std::vector<uint64_t> load(world, 0);
-    for (int p : order) {
-        int best = 0;
-        for (int r = 1; r < world; ++r)
-            if (load[r] < load[best]) best = r;
-        owner_out[p] = best;
-        load[best] += sizes[p];
-    }
     return QADC_OK;
 }
 

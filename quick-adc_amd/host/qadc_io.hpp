@@ -172,7 +172,6 @@ public:
         f.seekg(0, std::ifstream::end);
         dim_ = dim;
         count_ = (unsigned)((long)f.tellg() / ((long)dim * (elem_ < 0 ? 4 : elem_) + 4));
-        read_count_ = 0;
     }
     // the reader thread's body
     void run() {
@@ -181,11 +180,15 @@ public:
             open_or_throw(filename_.c_str(), f);
             const std::size_t esz = (std::size_t)(elem_ < 0 ? 4 : elem_);
             std::vector<unsigned char> rec((std::size_t)dim_ * esz);
-            while (read_count_.load() != count_) {
+            // (the reference publishes its read count BEFORE the push, vector_io.hpp:231-288, and its done() reads that count:
+            // a consumer asking in between sees the count complete and the queue empty and leaves without the last chunk — or
+            // without the reader's error.  Here done() counts what the CONSUMER has taken out: no window on either side.)
+            unsigned read = 0;
+            while (read != count_) {
                 vectors_chunk chunk;
                 chunk.dim = dim_;
-                chunk.count = std::min(wanted_chunk_count_, count_ - read_count_.load());
-                chunk.offset = read_count_.load();
+                chunk.count = std::min(wanted_chunk_count_, count_ - read);
+                chunk.offset = read;
                 chunk.data.resize((std::size_t)chunk.count * dim_);
                 for (unsigned i = 0; i < chunk.count; ++i) {
                     std::int32_t d = 0;
@@ -202,23 +205,25 @@ public:
                     else if (elem_ == 4) std::memcpy(o, rec.data(), rec.size());
                     else for (int k = 0; k < dim_; ++k) { std::int32_t v; std::memcpy(&v, rec.data() + 4 * k, 4); o[k] = (float)v; }
                 }
-                read_count_ += chunk.count;
+                read += chunk.count;
                 queue_.push(std::move(chunk));
             }
         } catch (const std::exception& e) {
             vectors_chunk bad;
             bad.failed = true;
             bad.error = e.what();
-            read_count_ = count_;
             queue_.push(std::move(bad));
         }
     }
     unsigned count() const { return count_; }
     int dim() const { return dim_; }
-    bool done() { return read_count_.load() == count_ && queue_.empty(); }
+    // (consumer side, one thread: every vector was handed out, or the reader's error was)
+    bool done() const { return consumed_ == count_ || failed_; }
     vectors_chunk get_chunk() {
         vectors_chunk c;
         queue_.pop(c);
+        if (c.failed) failed_ = true;
+        else consumed_ += c.count;
         return c;
     }
 
@@ -227,7 +232,8 @@ private:
     unsigned wanted_chunk_count_;
     int dim_ = 0, elem_ = 4;
     unsigned count_ = 0;
-    std::atomic<unsigned> read_count_{0};
+    unsigned consumed_ = 0;              // vectors get_chunk() has handed out
+    bool failed_ = false;                // ... or the chunk carrying the reader's error
     std::string filename_;
 };
 

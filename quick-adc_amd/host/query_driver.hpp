@@ -313,6 +313,17 @@ inline void call_engine(nns_engine_batch<Db, Scanner>& e, int q, const float* qu
     e.process_query(q, queries, count, bh, m);
 }
 
+// recall_file::check_labels / all_in (recall.hpp:21-32, 46-54): 1 iff every one of the query's first t ground-truth ids is
+// among [first, last).  The ids are int (the .ivecs ground truth, recall.hpp:34-40), the keys unsigned: std::find compares
+// them as the reference's does (the id converted to unsigned).  Pinned to the reference's own recall.hpp compiled into
+// oracle/_ref (tests/test_io_formats.py).
+template <typename It>
+inline int check_labels(const int* groundtruth_query, int t, It first, It last) {
+    for (int i = 0; i < t; ++i)
+        if (std::find(first, last, groundtruth_query[i]) == last) return 0;
+    return 1;
+}
+
 template <typename Engine, typename Heap>
 void process_queries(Engine& engine, const float* queries, int count, int dim, int r, const unsigned* groundtruth,
                      query_metrics& total_metrics, double& total_recall) {
@@ -325,7 +336,8 @@ void process_queries(Engine& engine, const float* queries, int count, int dim, i
         call_engine(engine, q, queries, count, dim, bh, metrics);
         if (bh.size() != r) std::cerr << " WARNING: Binheap not full" << std::endl;
         const unsigned* k = bh.keys();
-        total_recall += std::find(k, k + bh.size(), groundtruth[q]) != k + bh.size() ? 1 : 0;
+        const int truth = (int)groundtruth[q];                   // t = 1 (query_common.hpp:347): the true nearest neighbour
+        total_recall += check_labels(&truth, 1, k, k + bh.size());
         total_metrics += metrics;
     }
     total_metrics /= count;

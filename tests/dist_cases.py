@@ -67,7 +67,8 @@ def build_case(name):
         t[0] = 1.0
         c["tables"] = t
         c["index_options"] = {"wgq": 0, "head_level": 0, "level_base": 1 << 22}
-    elif name in ("ivf_search", "ivf_search_whole", "ivf_search_regrow", "ivf_search_fallback", "ivf_search_fewstarts"):
+    elif name in ("ivf_search", "ivf_search_whole", "ivf_search_regrow", "ivf_search_fallback", "ivf_search_fewstarts",
+                  "ivf_search_onerank"):
         # QUERIES in (qadc_search_submit): under the merge the front of the batch — coarse assignment, residual tables,
         # pre-scan, quantizer — is itself sharded over the ranks and all-gathered before the sharded scan.  nq not a multiple
         # of the world sizes (ragged last share), an exact tie between two coarse centroids, one query far from everything.
@@ -93,6 +94,9 @@ def build_case(name):
             c["index_options"]["wgq_capacity"] = 16        # gathered tables (no second front gather), every rank redoes the merge
         if name == "ivf_search_fallback":                  # more candidates than the in-workgroup sort is allowed: the batch falls back to
             c["index_options"]["wgq_cand_cap"] = 48        # the level path, which takes the gathered int8 tables as they lie on the device
+        if name == "ivf_search_onerank":                   # AUTO grouping, and ONLY RANK 0 overflows (dist_worker.py lowers its cap): the two
+            c["index_options"]["wgq_group"] = 1            # strikes that end the second phase — and with it the front's all-gather — must be
+                                                           # counted on every rank, from the gathered headers
         if name == "ivf_search_fewstarts":                 # fewer than R - 1 starts per query: qmax too high (status 1) — the verdict of the
             c["keep"] = 0.0004                             # rank that ran the query's front reaches every rank with the gather
     elif name == "inject":
@@ -107,7 +111,7 @@ def build_case(name):
 
 
 CASES = ["flat32", "ivf_lanes", "ivf_whole", "ivf_search", "ivf_search_whole", "ivf_search_regrow", "ivf_search_fallback",
-         "ivf_search_fewstarts", "big_r", "unordered", "inject"]
+         "ivf_search_onerank", "ivf_search_fewstarts", "big_r", "unordered", "inject"]
 
 
 def search_inputs(case):

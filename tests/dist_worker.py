@@ -68,6 +68,8 @@ def run_case(name, rank, world, transport):
         except pyqadc.QadcError as e:
             out["inject_error"] = np.array([1])
             out["inject_message"] = np.frombuffer(str(e).encode()[:200].ljust(200), np.uint8)
+    if name == "ivf_search_onerank" and rank == 0:
+        idx.set_option("wgq_cand_cap", 48)                 # this rank's grouped batches overflow and fall back; the others' do not
     if "queries" in case:                                  # queries in: two batches in flight, the second with the front unsharded
         idx.search_submit(0, case["queries"], case["search_ma"], R)
         idx.search_submit(1, case["queries"][::-1].copy(), case["search_ma"], R)
@@ -77,7 +79,8 @@ def run_case(name, rank, world, transport):
                 out["%s_slot%d" % (k, s)] = got[k][::-1].copy() if rev else got[k]
             a = idx.slot_assign(s, case["queries"].shape[0], case["search_ma"])
             out["assign_slot%d" % s] = a[::-1].copy() if rev else a
-        idx.set_option("dist_shard_front", 0)
+        if name != "ivf_search_onerank":                   # (that case: the front stays sharded if the index still groups)
+            idx.set_option("dist_shard_front", 0)
         idx.search_submit(2, case["queries"], case["search_ma"], R)
         got = idx.dist_collect(2)
         for k in ("keys", "values", "sizes", "status"):

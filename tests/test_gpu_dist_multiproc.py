@@ -102,6 +102,13 @@ def test_native_merge_with_several_processes_on_one_gpu(po, world, tmp_path, sca
             assert all(int(res[r]["ivf_whole.group_launches"][0]) >= 1 for r in range(world))  # grouped second phase under the merge
         if name == "ivf_search_fewstarts":
             assert all(w["rc"] == 1 for w in want)             # (what the case is for)
+        if name == "ivf_search_onerank" and scan_path == "wgq":
+            # rank 0 alone fell back, twice (slots 0 and 1); every rank counted both strikes from the gathered headers, so slot 2
+            # neither grouped nor sharded its front on ANY rank (before: rank 0 stopped issuing the front's all-gather by itself)
+            assert int(res[0]["%s.group_fallbacks" % name][0]) == 2
+            assert all(int(res[r]["%s.group_fallbacks" % name][0]) == 0 for r in range(1, world))
+            assert all(int(res[r]["%s.group_launches" % name][0]) == 2 for r in range(world)), \
+                [int(res[r]["%s.group_launches" % name][0]) for r in range(world)]
         if "queries" in case and scan_path == "wgq":
             # slots 0 and 1 took the sharded front (every rank ran the front of 1/world of the queries), slot 2 did not
             assert all(int(res[r]["%s.front_sharded_batches" % name][0]) == 2 for r in range(world))

@@ -98,6 +98,148 @@ def test_database_archives_round_trip(tmp_path):
     assert rc == 1 and "truncated" in err
 
 
+def _need_ref_io(po):
+    if not po.have_ref_io():
+        pytest.skip("oracle/_ref/libqadc_ref_io.so not built (no /root/reference here and no prebuilt copy)")
+
+
+def test_vecs_files_against_the_reference_reader_and_writer(po, tmp_path):
+    """host/qadc_io.hpp's vecs side pinned to the reference's own vector_io.cpp / vector_io.hpp compiled
+    into oracle/_ref (vector_io.cpp:40-91, vector_io.hpp:69-166): files written by the REFERENCE's save_vectors are read by
+    our readers bit for bit, files written by OUR save_vectors are read by the reference's load_vectors_by_extension bit for
+    bit, both readers agree on a file with trailing garbage (count = size / record size) and on both error cases."""
+    _need_ref_io(po)
+    build_tool()
+    rng = np.random.default_rng(11)
+    data = {"fvecs": rng.normal(size=(41, 24)).astype(np.float32),
+            "bvecs": rng.integers(0, 256, (53, 128), dtype=np.uint8),
+            "ivecs": rng.integers(-(1 << 30), 1 << 30, (9, 100)).astype(np.int32)}
+    data["fvecs"][3, 5], data["fvecs"][4, 0], data["fvecs"][5, 1] = np.float32("nan"), np.float32("-inf"), np.float32(-0.0)
+    kind = {"fvecs": "f32", "bvecs": "u8", "ivecs": "i32"}
+    for ext, a in data.items():
+        by_ref, by_us = str(tmp_path / ("ref." + ext)), str(tmp_path / ("us." + ext))
+        # the reference's writer -> our reader (io_roundtrip vecs re-writes what it read as .fvecs)
+        po.ref_save_vectors(by_ref, a)
+        back = str(tmp_path / ("ref.%s.back.fvecs" % ext))
+        rc, out, err = run_tool("vecs", by_ref, back)
+        assert rc == 0 and out == "vecs dim=%d count=%d" % (a.shape[1], a.shape[0]), err
+        ours = np.fromfile(back, np.uint8).reshape(a.shape[0], 4 + 4 * a.shape[1])[:, 4:].copy().view(np.uint32)
+        theirs = po.ref_load_vectors(by_ref)                      # the reference reading its own file
+        assert np.array_equal(ours, theirs.view(np.uint32))       # bit for bit (NaN, -0.0 included)
+        assert np.array_equal(theirs.view(np.uint32), a.astype(np.float32).view(np.uint32))
+        # our writer -> the reference's reader; and both writers produce the same bytes
+        raw = str(tmp_path / ("raw." + ext))
+        a.tofile(raw)
+        rc, out, err = run_tool("save", kind[ext], raw, str(a.shape[1]), by_us)
+        assert rc == 0 and out == "saved dim=%d count=%d" % (a.shape[1], a.shape[0]), err
+        assert open(by_us, "rb").read() == open(by_ref, "rb").read()
+        assert po.ref_try_load(by_us)[0] == 0
+        assert np.array_equal(po.ref_load_vectors(by_us).view(np.uint32), a.astype(np.float32).view(np.uint32))
+        # the file format helper the other tests write their inputs with is the same format
+        iof.write_vecs(str(tmp_path / ("np." + ext)), a)
+        assert open(str(tmp_path / ("np." + ext)), "rb").read() == open(by_ref, "rb").read()
+    # ground truth as recall_file reads it (load_vectors<int>, recall.hpp:37-39) == load_ivecs
+    assert np.array_equal(po.ref_load_ivecs(str(tmp_path / "ref.ivecs")), data["ivecs"])
+    # trailing bytes shorter than a record: count_vectors truncates (vector_io.hpp:69-76) on both sides
+    tail = str(tmp_path / "tail.fvecs")
+    open(tail, "wb").write(open(str(tmp_path / "ref.fvecs"), "rb").read() + b"\x18\x00\x00\x00" + b"\x01" * 40)
+    rc, out, _ = run_tool("vecs", tail, str(tmp_path / "tail.out.fvecs"))
+    assert rc == 0 and out == "vecs dim=24 count=41" and po.ref_load_vectors(tail).shape == (41, 24)
+    # errors: both sides exit 1 with the same message lines (vector_io.cpp:20-38)
+    bad = str(tmp_path / "bad.bvecs")
+    raw = bytearray(open(str(tmp_path / "ref.bvecs"), "rb").read())
+    raw[(4 + 128) * 7:(4 + 128) * 7 + 4] = (127).to_bytes(4, "little")
+    open(bad, "wb").write(bytes(raw))
+    rc_ref, err_ref = po.ref_try_load(bad)
+    rc, _, err = run_tool("vecs", bad, str(tmp_path / "x"))
+    assert rc_ref == 1 and rc == 1
+    assert [l.strip() for l in err_ref.strip().splitlines()] == [l.strip() for l in err.strip().splitlines()] == [
+        "Error while reading vectors.", "Vector 7 has 127 dimensions while other vectors have 128 dimensions",
+        "All vectors must have the same number of dimensions"]
+    unk = str(tmp_path / "ref.fvecs") + ".txt"
+    open(unk, "wb").write(b"x")
+    rc_ref, err_ref = po.ref_try_load(unk)
+    rc, _, err = run_tool("vecs", unk, str(tmp_path / "x"))
+    assert rc_ref == 1 and rc == 1
+    assert [l.strip() for l in err_ref.strip().splitlines()] == [l.strip() for l in err.strip().splitlines()] == [
+        "Could not load vectors from " + unk, "Unknown extension", "Known extensions: .bvecs, .ivecs, .fvecs"]
+
+
+def test_chunked_reader_against_the_reference_reader(po, tmp_path):
+    """The reader thread behind db_add (vector_io.hpp:187-290, vector_io.cpp:60-91, consumed as in db_add.cpp:52-82): the same
+    chunk offsets / counts and the same floats as the reference's vectors_reader, for chunk sizes that divide the file, do not
+    divide it, exceed it and equal 1, on all three element types."""
+    _need_ref_io(po)
+    build_tool()
+    rng = np.random.default_rng(12)
+    files = {"c.fvecs": rng.normal(size=(103, 16)).astype(np.float32), "c.bvecs": rng.integers(0, 256, (64, 32), dtype=np.uint8),
+             "c.ivecs": rng.integers(-9, 9, (7, 5)).astype(np.int32)}
+    for name, a in files.items():
+        path = str(tmp_path / name)
+        po.ref_save_vectors(path, a)
+        for chunk in (1, 7, 16, 64, 1000):
+            if chunk == 1 and a.shape[0] > 64:
+                continue
+            want_data, want_chunks = po.ref_read_chunked(path, chunk, a.shape[0], a.shape[1])
+            out = str(tmp_path / (name + ".chunks"))
+            rc, txt, err = run_tool("chunks", path, str(chunk), out)
+            assert rc == 0, err
+            lines = txt.splitlines()
+            assert lines[-1] == "total dim=%d count=%d" % (a.shape[1], a.shape[0])
+            assert [tuple(int(x) for x in l.split()) for l in lines[:-1]] == want_chunks
+            got = np.fromfile(out, np.float32).reshape(a.shape)
+            assert np.array_equal(got.view(np.uint32), want_data.view(np.uint32))
+            assert np.array_equal(want_data, a.astype(np.float32))
+
+
+def test_recall_rule_against_the_reference_recall_file(po, tmp_path):
+    """A9: the recall column of process_queries<> = recall_file::check_labels(q, keys, keys + R, t = 1) (query_common.hpp:360-361,
+    recall.hpp:21-61), pinned to the reference's recall.hpp compiled into oracle/_ref — on key arrays as the heaps hold them:
+    unsorted, with duplicate keys (the padding-lane replays), with the surviving sentinel key 0 (which counts as label 0),
+    ids above 2^31 (int ground truth against unsigned keys) and t up to the ground truth's width."""
+    _need_ref_io(po)
+    build_tool()
+    rng = np.random.default_rng(13)
+    nq, R, T = 64, 100, 5
+    gt = rng.integers(0, 5000, (nq, T)).astype(np.int32)
+    keys = rng.integers(0, 5000, (nq, R)).astype(np.uint32)
+    for q in range(nq):
+        kind = q % 8
+        if kind == 0:                                            # the true neighbour is there, once
+            keys[q, rng.integers(0, R)] = gt[q, 0]
+        elif kind == 1:                                          # ... several times (padding-lane duplicates)
+            keys[q, rng.choice(R, 5, replace=False)] = gt[q, 0]
+        elif kind == 2:                                          # absent
+            keys[q][keys[q] == np.uint32(gt[q, 0])] = 7777
+        elif kind == 3:                                          # the true neighbour IS label 0 and only the sentinel's key 0 is there
+            gt[q, 0] = 0
+            keys[q] = rng.integers(1, 5000, R)
+            keys[q, 0] = 0
+        elif kind == 4:                                          # all T ground-truth ids present (t > 1 succeeds)
+            keys[q, rng.choice(R, T, replace=False)] = gt[q].astype(np.uint32)
+        elif kind == 5:                                          # id >= 2^31: int -1 in the file, 0xffffffff among the keys
+            gt[q, 0] = -1
+            keys[q, 17] = 0xFFFFFFFF
+        elif kind == 6:                                          # same id, key missing
+            gt[q, 0] = -2
+        # kind 7: whatever the draw says
+    gt_path, keys_path = str(tmp_path / "gt.ivecs"), str(tmp_path / "keys.bin")
+    po.ref_save_vectors(gt_path, gt)
+    keys.tofile(keys_path)
+    seen = set()
+    for t in (1, 2, T):
+        want = po.ref_check_labels(gt_path, keys, t)
+        rc, out, err = run_tool("recall", gt_path, keys_path, str(R), str(t))
+        assert rc == 0, err
+        assert [int(c) for c in out.strip()] == want.tolist(), t
+        seen |= set(want.tolist())
+        if t == 1:
+            assert want[0] == 1 and want[1] == 1 and want[2] == 0 and want[3] == 1 and want[5] == 1 and want[6] == 0
+        if t == T:
+            assert want[4] == 1
+    assert seen == {0, 1}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,opq,qext", [("flat", False, ".fvecs"), ("index", True, ".bvecs")])
 def test_reference_command_line_on_reference_files(po, tmp_path, kind, opq, qext):

@@ -75,3 +75,67 @@ def test_place_partitions_is_size_balanced_and_deterministic():
     assert load.max() - load.min() <= sizes.max()             # greedy longest-first: within one partition of each other
     assert np.array_equal(owner, pyqadc.place_partitions(sizes, 8))
     assert list(pyqadc.place_partitions([5, 9, 1, 7, 3, 3], 3)) == [2, 0, 2, 1, 2, 1]
+
+
+MISMATCH = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import pyqadc
+rank, name = int(sys.argv[1]), sys.argv[2]
+t = pyqadc.ShmTransport(name, rank, 2, slot_bytes=1 << 16, timeout_s=30)
+t.allgather_host(np.zeros(64, np.uint8))
+try:
+    t.allgather_host(np.zeros(64 if rank == 0 else 128, np.uint8))   # the ranks are in DIFFERENT collectives
+    raise SystemExit(5)
+except pyqadc.QadcError as e:
+    assert "collective mismatch" in str(e) or "aborted" in str(e), str(e)
+    print("mismatch" if "collective mismatch" in str(e) else "aborted")
+""" % os.path.join(ROOT, "quick-adc_amd")
+
+
+def test_ranks_in_different_collectives_fail_instead_of_exchanging_garbage():
+    """the transport used to copy bytes_per_rank out of every slot whatever the other ranks had put there."""
+    name = "/qadc_cpu_%s" % uuid.uuid4().hex[:12]
+    procs = [subprocess.Popen([sys.executable, "-c", MISMATCH, str(r), name], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(2)]
+    outs = []
+    try:
+        for r, p in enumerate(procs):
+            so, se = p.communicate(timeout=120)
+            assert p.returncode == 0, (r, se.decode()[-800:])
+            outs.append(so.strip())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        if os.path.exists("/dev/shm" + name):
+            os.unlink("/dev/shm" + name)
+    assert b"mismatch" in outs                                  # at least one rank names the mismatch; the other may see the poison first
+
+
+def test_a_stale_segment_of_a_crashed_run_is_not_joined():
+    """a segment left by a crashed run (full size, valid magic, same geometry, abort flag set) under the same
+    name: rank 1 arrives FIRST, must not join it, and meets rank 0 on the segment rank 0 creates afterwards."""
+    import struct
+    import time
+    name = "/qadc_cpu_%s" % uuid.uuid4().hex[:12]
+    world, slot = 2, 1 << 20
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    with open("/dev/shm" + name, "wb") as f:                   # ShmHeader: magic, arrived, generation, abort, world, creator_pid, slot_bytes
+        f.write(struct.pack("<6IQ", 0x51414443, 1, 7, 1, world, dead.pid, slot))
+        f.truncate(4096 + world * slot)
+    p1 = _spawn(1, world, name, 60)
+    time.sleep(1.0)
+    p0 = _spawn(0, world, name, 60)
+    try:
+        for r, p in ((0, p0), (1, p1)):
+            so, se = p.communicate(timeout=120)
+            assert p.returncode == 0 and so.strip() == b"ok", (r, se.decode()[-800:])
+    finally:
+        for p in (p0, p1):
+            if p.poll() is None:
+                p.kill()
+        if os.path.exists("/dev/shm" + name):
+            os.unlink("/dev/shm" + name)
