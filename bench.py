@@ -107,6 +107,55 @@ def cpu_baseline(M, n_total, qtables, seconds):
                                         if kind == "reference" else "scalar C port (oracle)")}
 
 
+def cpu_ivf_baseline(sample, seconds):
+    """The reference's CPU path beside an IVF leg: scan_avx_4<M> through qadc_ref_scan (oracle/_ref:
+    (0,127) sentinel, then every probed partition in assign[] order into ONE heap, db_query_4.cpp:276, 287-308) on the probed
+    partitions of the leg's own first queries — regenerated on the CPU from the partitions' generator streams, laid out by the
+    reference's interleave_partition_4 — with the DEVICE's int8 tables (qadc_slot_qtables), 1 thread.  The heaps are compared
+    with the GPU's while at it.  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from concurrent.futures import ThreadPoolExecutor
+    if not po.have_ref():
+        return {"error": "oracle/_ref not built"}
+    M, sizes, seed0 = sample["M"], sample["sizes"], sample["seed0"]
+    assign, qt = sample["assign"], sample["qtables"]
+    cs, nq = M // 2, assign.shape[0]
+    need = sorted(set(int(p) for p in assign.reshape(-1)))
+
+    def make(p):                                               # partition p: generator stream seed0 + p, words from 0 (ivf_leg)
+        n = int(sizes[p])
+        if n == 0:
+            return p, np.zeros(0, np.uint8)
+        codes = po.fill_codes(0, (n * cs + 7) // 8, seed0 + p)[:n * cs].reshape(n, cs)
+        return p, po.ref_interleave(codes)
+    model, cpus = po.host_topology()
+    t_gen = time.perf_counter()
+    with ThreadPoolExecutor(max(1, min(len(cpus), 16))) as ex:     # (data generation only; the timed scan below is one thread)
+        inter = dict(ex.map(make, need))
+    t_gen = time.perf_counter() - t_gen
+
+    def run(q):
+        parts = [inter[int(p)] for p in assign[q]]
+        return po.ref_scan_interleaved(M, parts, [int(sizes[int(p)]) for p in assign[q]], None, qt[q], R)
+    same = 0
+    for q in range(nq):
+        k, v = run(q)
+        n = int(sample["heap_sizes"][q])
+        same += int(np.array_equal(k, sample["keys"][q, :n]) and np.array_equal(v, sample["values"][q, :n]))
+    t0, done, codes_done = time.perf_counter(), 0, 0
+    while time.perf_counter() - t0 < seconds:
+        run(done % nq)
+        codes_done += int(sizes[assign[done % nq]].sum())
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": codes_done / dt, "unit": "codes/s", "cores": 1, "kind": "reference", "cpu_model": model,
+            "us_per_query": dt * 1e6 / done, "reference_heaps_equal": "%d/%d" % (same, nq),
+            "sample": "%d query scans in %.1f s cycling over the first %d queries of the leg's first batch: their %d probed partitions each "
+                      "(%d distinct partitions regenerated on the CPU in %.1f s, untimed), the device's int8 tables, one shared heap per query, "
+                      "scan_avx_4<%d> compiled from the reference, 1 thread" % (done, dt, nq, assign.shape[1], len(need), t_gen, M)}
+
+
 def cpu_extra_legs(M, n_total, qtables, seconds):
     """Two more CPU figures asked for by BASELINE.md §3 (reported, never the target):
     - the reference's AVX2 scan on ALL physical host cores, driven from C++ inside oracle/_ref (one pinned thread
@@ -433,6 +482,14 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
             shard["barrier"]()
         return time.perf_counter() - t0, nc
 
+    cpu_sample = None
+    if shard is None and float(os.environ.get("QADC_BENCH_CPU_SECONDS", 15)) > 0:
+        # (untimed) the first queries of the first batch once more, synchronously, with everything the CPU leg needs: assign[],
+        # the device's int8 tables, the heaps
+        NS = int(os.environ.get("QADC_BENCH_IVF_CPU_QUERIES", 32))
+        r0 = idx.search(qs[0], MA, R)
+        cpu_sample = dict(M=M, sizes=sizes, seed0=seed0, assign=r0["assign"][:NS].copy(), qtables=idx.slot_qtables(0, 0, NS, MA),
+                          keys=r0["keys"][:NS].copy(), values=r0["values"][:NS].copy(), heap_sizes=r0["sizes"][:NS].copy())
     steps, depth = 48, int(os.environ.get("QADC_BENCH_IVF_DEPTH", 4))          # all four submission slots of the C-ABI in use
     dt, ncodes = pipelined(qs, steps, depth)
     p = idx.profile()
@@ -483,9 +540,157 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
                                  "heap": p["host_heap_ms"] / steps}}
     if roof is not None:
         out["roofline"] = roof
+    if cpu_sample is not None:
+        out["_cpu_sample"] = cpu_sample
     if shard is not None:
         out.update({"rccl_ranks": shard["world"], "placement": shard["placement"], "codes_on_this_rank": local_codes,
                     "merge": shard.get("merge", "native: qadc_dist_collect"), "candidates_per_query_this_rank": p["candidates"] / (steps * NQB)})
+    return out
+
+
+def c2_leg(local_rank):
+    """BASELINE configs[1]: flat 10M x 16x4 (80 MB) on one GPU, both scan modes — 32-query steps (8 queries per pass, three
+    steps in flight) and ONE query per pass (the reference's mode), each in its own timed region.  The list is 80 MB: after
+    the first pass it is served from the 256 MiB Infinity Cache / L2, and one query is a dependent chain of a head launch and
+    two bound-level launches of a few microseconds of streaming each, so neither mode is HBM-bound here; `roofline_c2` reports
+    the achieved algorithmic GB/s against the HBM peak anyway and says what bounds it."""
+    import torch
+    import pyqadc
+    M, N, NQ = 16, int(float(os.environ.get("QADC_BENCH_C2_CODES", 1e7))), 32
+    idx = pyqadc.Index(M, local_rank)
+    idx.add_partition_synthetic(N, SEED + 2)
+    idx.finalize(KEEP)
+    rng = np.random.default_rng(4321)
+    cb = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
+    pool = [make_tables(rng, cb, NQ) for _ in range(4)]
+    assign = np.zeros((NQ, 1), np.int32)
+
+    def run(k):
+        pend = []
+        for s in range(k):
+            idx.submit(s % 3, assign, pool[s % len(pool)].copy(), R)
+            pend.append(s % 3)
+            if len(pend) == 3:
+                idx.collect(pend.pop(0))
+        while pend:
+            idx.collect(pend.pop(0))
+
+    steps = 300
+    run(12)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # one query per pass: HIP events around the streaming launches (front_run_max 0: all of them on the scan stream)
+    idx.set_option("profile", 1)
+    idx.set_option("front_run_max", 0)
+    nsingle = 256
+    sprof, sdt = single_query_leg(idx, M, N, pool, nsingle)
+    idx.close()
+    cs = M // 2
+    wall_gbs = float(N) * cs * nsingle / sdt / 1e9
+    kern_gbs = sprof["scan_codes"] * cs / (sprof["scan_ms"] * 1e-3) / 1e9 if sprof["scan_ms"] > 0 else 0.0
+    roof = {"bound": "hbm", "achieved": wall_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wall_gbs / HBM_PEAK_GBS, "traffic": None,
+            "achieved_rule": "%d B x %d codes x %d queries / wall time of the region (whole query path: pre-scan, selects, head, bound "
+                             "levels, ordering, host replay; three queries in flight)" % (cs, N, nsingle),
+            "ms_per_query_wall": sdt * 1e3 / nsingle, "codes_per_sec_wall": float(N) * nsingle / sdt,
+            "streaming_launches": {"kernel": "scan_i8_kernel<%d,2> over the bound levels past the head" % M, "launches": sprof["scan_launches"],
+                                   "avg_launch_ms": sprof["scan_ms"] / max(sprof["scan_launches"], 1), "GBps_inside_the_launches": kern_gbs,
+                                   "codes_event_timed": sprof["scan_codes"], "codes_in_head_and_small_launches": sprof["small_codes"]},
+            "what_bounds_it": "not HBM: the 80 MB list is re-read from the Infinity Cache (256 MiB) by every query, and a query is "
+                              "a dependent chain of short launches (pre-scan + selects, head over the first 512 Ki codes, two bound "
+                              "levels, ordering) — launch latency and the ramps of ~10 us kernels; the batched mode above amortises "
+                              "exactly that chain over 32 queries",
+            "mode": "one query per pass over the list (simd_scan.hpp:125-187 called once per query, db_query_4.cpp:287-308)"}
+    return {"workload": "flat DB, %d x %dx4 PQ codes (%d MB), R=%d, keep=%.0f%%: BASELINE configs[1]" % (N, M, N * cs // 1000000, R, KEEP * 100),
+            "batched": {"queries_per_step": NQ, "steps": steps, "ms_per_step": dt * 1e3 / steps, "codes_per_sec": float(N) * NQ * steps / dt,
+                        "mode": "32 queries per step share every pass over the codes (8 per pass), three steps in flight"},
+            "one_query_per_pass": {"codes_per_sec": float(N) * nsingle / sdt, "ms_per_query": sdt * 1e3 / nsingle, "queries": nsingle}}, roof
+
+
+def real_encode_recall_ivf(local_rank):
+    """Recall@R of the IVF path on REAL encodings at BASELINE configs[2]'s proportions: K = 4096 cells,
+    nprobe = 32 (0.8 % of the cells), clustered synthetic 128-d vectors; coarse centroids = sampled base vectors refined by two
+    k-means rounds on a sample (qadc_kmeans_iterations_host), residuals PQ-encoded on the GPU (qadc_ivf_encode_host), partitions
+    with labels = vector ids; queries through qadc_search; ground truth = exact float L2 nearest neighbour (torch, chunked).
+    `reference_heaps_equal`: the reference's scan_avx_4 over the probed partitions (labels, one shared heap) with the device's
+    int8 tables ends in the same heaps — this recall IS the reference path's recall on the same tables."""
+    import torch
+    import pyqadc
+    M, dim, K, MA, nq = 16, 128, 4096, 32, 256
+    n = int(float(os.environ.get("QADC_BENCH_REAL_IVF_CODES", 4e6)))
+    dev = torch.device("cuda", local_rank)
+    g = torch.Generator(device=dev).manual_seed(11)
+    C = max(2000, n // 300)
+    centres = torch.randn(C, dim, device=dev, generator=g) * 3
+    base = centres[torch.randint(0, C, (n,), device=dev, generator=g)] + torch.randn(n, dim, device=dev, generator=g)
+    queries = centres[torch.randint(0, C, (nq,), device=dev, generator=g)] + torch.randn(nq, dim, device=dev, generator=g)
+    best_d = torch.full((nq,), float("inf"), device=dev)
+    best_i = torch.zeros(nq, dtype=torch.long, device=dev)
+    for lo in range(0, n, 1 << 20):
+        d = torch.cdist(queries, base[lo:lo + (1 << 20)])
+        dmin, imin = d.min(dim=1)
+        upd = dmin < best_d
+        best_d = torch.where(upd, dmin, best_d)
+        best_i = torch.where(upd, imin + lo, best_i)
+    gt = best_i.cpu().numpy()
+    base_h = base.cpu().numpy()
+    qh = queries.cpu().numpy()
+    del base, queries, centres
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(21)
+    sample = base_h[rng.choice(n, min(n, 200000), replace=False)]
+    coarse, _ = pyqadc.kmeans_iterations(sample, sample[rng.choice(sample.shape[0], K, replace=False)], 2, local_rank)
+    coarse = np.where(np.isnan(coarse), sample[:K], coarse).astype(np.float32)      # (an empty cell keeps a sample point)
+    ds = dim // M
+    assign0, _ = pyqadc.ivf_encode(np.zeros((M, 16, ds), np.float32), sample[:50000], coarse=coarse, device=local_rank)
+    resid = sample[:50000] - coarse[assign0]
+    cb = np.stack([resid[rng.choice(resid.shape[0], 16, replace=False), m * ds:(m + 1) * ds] for m in range(M)]).astype(np.float32)
+    assign = np.zeros(n, np.int32)
+    codes = np.zeros((n, M // 2), np.uint8)
+    for lo in range(0, n, 1 << 20):                             # db_add's chunks (db_add.cpp:52-82)
+        a, c = pyqadc.ivf_encode(cb, base_h[lo:lo + (1 << 20)], coarse=coarse, device=local_rank)
+        assign[lo:lo + len(a)], codes[lo:lo + len(a)] = a, c
+    order = np.argsort(assign, kind="stable")                   # vector order inside a partition = id order (databases.hpp:291-297)
+    bounds = np.searchsorted(assign[order], np.arange(K + 1))
+    parts = [codes[order[bounds[k]:bounds[k + 1]]] for k in range(K)]
+    labels = [order[bounds[k]:bounds[k + 1]].astype(np.uint32) for k in range(K)]
+    idx = pyqadc.Index(M, local_rank)
+    idx.add_partitions(parts, labels)
+    idx.finalize(KEEP)
+    idx.set_pq(cb)
+    idx.set_coarse(coarse)
+    res = idx.search(qh, MA, R)
+    hits = sum(int(gt[q] in set(res["keys"][q][:res["sizes"][q]].tolist())) for q in range(nq))
+    probed = float(np.mean([sum(parts[p].shape[0] for p in res["assign"][q]) for q in range(nq)]))
+    out = {"value": hits / nq, "codes": n, "queries": nq, "K": K, "nprobe": MA, "probed_codes_per_query": probed,
+           "queries_with_status_1": int((res["status"] != 0).sum()),
+           "data": "synthetic 128-d vectors, %d clusters (3*N(0,1) centres + N(0,1)); coarse centroids: %d sampled vectors + 2 k-means "
+                   "rounds on a 200 K sample; codebooks = sampled residual sub-vectors; residuals PQ %dx4 encoded on the GPU; labels = "
+                   "vector ids; ground truth = exact float L2 NN" % (C, K, M)}
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    if po.have_ref() and float(os.environ.get("QADC_BENCH_CPU_SECONDS", 15)) > 0:
+        NS = 64
+        qt = idx.slot_qtables(0, 0, NS, MA)
+        inter = {}
+        same, hits_ref = 0, 0
+        for q in range(NS):
+            if res["status"][q]:
+                same += 1                                       # (the reference would have exited; nothing to compare)
+                continue
+            ps = [int(p) for p in res["assign"][q]]
+            for p in ps:
+                if p not in inter:
+                    inter[p] = po.ref_interleave(parts[p]) if parts[p].shape[0] else np.zeros(0, np.uint8)
+            k, v = po.ref_scan_interleaved(M, [inter[p] for p in ps], [parts[p].shape[0] for p in ps], [labels[p] for p in ps], qt[q], R)
+            sz = int(res["sizes"][q])
+            same += int(np.array_equal(k, res["keys"][q, :sz]) and np.array_equal(v, res["values"][q, :sz]))
+            hits_ref += int(gt[q] in set(k.tolist()))
+        out["reference_heaps_equal"] = "%d/%d" % (same, NS)
+        out["reference_recall_at_100_first_%d" % NS] = hits_ref / NS
+    idx.close()
     return out
 
 
@@ -583,6 +788,8 @@ def main():
         return self_launch(args)
 
     line_printed = []                                          # (non-empty once rank 0 has printed the JSON line)
+    import threading
+    print_lock = threading.Lock()                              # the line is printed once: by main(), or by the watchdog of the N-rank legs
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -682,10 +889,16 @@ def main():
         for kv in filter(None, os.environ.get("QADC_BENCH_DIST_OPTS", "").split(",")) if native_dist else ():   # tuning experiments only
             idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     flat_tr = None
+    run_nonce = os.environ.get("MASTER_PORT", "0")
     if use_dist and backend != "nccl" and os.environ.get("QADC_BENCH_NATIVE_DIST", "1") != "0":
         # test hook (ranks sharing one GPU, no RCCL between them): the SAME native merge over the library's shared-memory
         # transport, so that a 1-GPU box runs the multi-rank loop below exactly as an 8-GPU node does, collectives included
-        flat_tr = pyqadc.ShmTransport("/qadc_bench_%s_flat" % os.environ.get("MASTER_PORT", "0"), rank, world)
+        # (segment names carry a per-run nonce agreed over the process group: a rerun on the same port after a crash must not
+        # meet the crashed run's segment)
+        nonce_t = torch.tensor([int.from_bytes(os.urandom(4), "little") & 0x7fffffff if rank == 0 else 0], dtype=torch.int64)
+        dist.broadcast(nonce_t, 0)
+        run_nonce = "%s_%08x" % (os.environ.get("MASTER_PORT", "0"), int(nonce_t.item()))
+        flat_tr = pyqadc.ShmTransport("/qadc_bench_%s_flat" % run_nonce, rank, world)
         idx.dist_init_transport(flat_tr)
         native_dist = True
 
@@ -891,6 +1104,9 @@ def main():
                        "codes": N, "M": M, "R": R, "keep": KEEP, "queries_per_step": NQ,
                        "parallelism": "shard%d" % world},
             "recall_at_100": recall,
+            # the north-star figure next to `value`: ONE query per pass over the same list (the mode `roofline` prices against HBM);
+            # `value` is the batched mode (8 queries per pass, priced against the LDS roof in `roofline_batched`)
+            "value_one_query_per_pass": single["codes_per_sec_wall"] if single is not None else None,
             "roofline": single if single is not None else
             {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
              "note": "the one-query-per-pass leg runs on a single rank only (N=1 line)"},
@@ -916,7 +1132,7 @@ def main():
             if native_dist and backend == "nccl":
                 return native_init(ix)
             # no RCCL between these ranks (gloo test hook: the ranks share one GPU): the library's shared-memory transport
-            tr = pyqadc.ShmTransport("/qadc_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), len(shm_tr)), rank, world)
+            tr = pyqadc.ShmTransport("/qadc_bench_%s_%d" % (run_nonce, len(shm_tr)), rank, world)
             shm_tr.append(tr)
             ix.dist_init_transport(tr)
 
@@ -925,13 +1141,15 @@ def main():
         # The headline above is measured; these extra legs must not be able to take it down with them.  A watchdog on
         # EVERY rank: if the legs are not through in time (a collective that never completes), rank 0 prints the line without
         # them and every rank leaves — a hung rank cannot be interrupted, only abandoned.
-        import threading
-
         def give_up():
-            if rank == 0 and not line_printed:
-                out["ivf"] = {"error": "the multi-rank IVF legs did not finish within %s s; abandoned" % limit}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            # a hung collective cannot be interrupted, only abandoned — and the abandonment must be VISIBLE to the launcher: rank 0
+            # prints the line (headline + the error) if the main thread has not, then every rank exits non-zero
+            with print_lock:
+                if rank == 0 and not line_printed:
+                    out["ivf"] = {"error": "the multi-rank IVF legs did not finish within %s s; abandoned, exit code 3" % limit}
+                    print(json.dumps(out), flush=True)
+                    line_printed.append(1)
+                os._exit(3)
 
         limit = float(os.environ.get("QADC_BENCH_IVF_TIMEOUT", 420))
         dog = threading.Timer(limit, give_up)
@@ -951,11 +1169,16 @@ def main():
         for tr in shm_tr:
             tr.close()
         if rank == 0:
+            if isinstance(ivf_n, dict) and "error" not in ivf_n:
+                ivf_n["scaling_note"] = ("BASELINE configs[2] is a ONE-GPU configuration (100M codes, 0.8 ms per 1024-query batch on one "
+                                         "GPU): a rank's batch is fixed costs (front, launches, merge), it is not expected to scale with "
+                                         "the ranks; configs[4] (`ivf_c5`) is the multi-GPU IVF configuration")
             out["ivf"] = ivf_n
             if ivf_c5_n is not None:
                 out["ivf_c5"] = ivf_c5_n
     if rank == 0 and world == 1 and not use_dist:
         torch.cuda.synchronize()
+        qt32_cpu = None
         if os.environ.get("QADC_BENCH_32X4", "1") != "0" and M == 16:
             i32 = pyqadc.Index(32, local_rank)
             i32.add_partition_synthetic_shard(N, 0, N, SEED, starts)
@@ -970,27 +1193,44 @@ def main():
                                                    pmc32_src + ("" if pmc32 is None else " (ratio of the same launches x this region's bytes per launch)"))
             if pmc32 is not None:
                 out["roofline_32x4"]["pmc"] = pmc32
+            if cpu_s > 0:
+                qt32_cpu = i32.query_scan(np.zeros((8, 1), np.int32), pool32[0].copy(), R, want_qtables=True)["qtables"][:, 0]
             i32.close()
+        cpu_samples = {}
         if int(float(os.environ.get("QADC_BENCH_IVF_CODES", 1e8))) > 0:
             out["ivf"] = ivf_leg(local_rank)
+            cpu_samples["cpu_baseline_ivf"] = out["ivf"].pop("_cpu_sample", None)
             if "roofline" in out["ivf"]:
                 out["roofline_ivf"] = out["ivf"].pop("roofline")
             if os.environ.get("QADC_BENCH_IVF_C5", "1") != "0" and N >= 1e9:
                 # BASELINE configs[4] on ONE GPU: 1B x 32x4 codes (16 GB), 96-d vectors, nprobe 64
                 out["ivf_c5_one_gpu"] = ivf_leg(local_rank, M=32, K=16384, MA=64, dim=96, N=int(1e9), seed0=7000)
+                cpu_samples["cpu_baseline_ivf_c5"] = out["ivf_c5_one_gpu"].pop("_cpu_sample", None)
                 if "roofline" in out["ivf_c5_one_gpu"]:
                     out["roofline_ivf_c5"] = out["ivf_c5_one_gpu"].pop("roofline")
+        if os.environ.get("QADC_BENCH_C2", "1") != "0":
+            out["c2"], out["roofline_c2"] = c2_leg(local_rank)         # BASELINE configs[1]: flat 10M x 16x4, both modes
         if os.environ.get("QADC_BENCH_LATENCY", "1") != "0":
             out["latency_us_single_query"] = latency_leg(local_rank)
         n_real = int(float(os.environ.get("QADC_BENCH_REAL_CODES", 1e7)))
         if n_real > 0:
             out["recall_at_100_real_encode"] = real_encode_recall(M, n_real, 64, local_rank)
+            if int(float(os.environ.get("QADC_BENCH_REAL_IVF_CODES", 4e6))) > 0:
+                out["recall_at_100_real_encode_ivf"] = real_encode_recall_ivf(local_rank)
         if cpu_s > 0:
             out["cpu_baseline"] = cpu_baseline(M, N, qt_cpu, cpu_s)
             out.update(cpu_extra_legs(M, N, qt_cpu, min(cpu_s, 6.0)))
+            # the reference's CPU path beside the other legs (1 thread each, bounded): 32x4 flat, and the IVF legs' own queries
+            if qt32_cpu is not None:
+                out["cpu_baseline_32x4"] = cpu_baseline(32, N, qt32_cpu, min(cpu_s, 4.0))
+            for key, smp in cpu_samples.items():
+                if smp is not None:
+                    out[key] = cpu_ivf_baseline(smp, min(cpu_s, 3.0))
     if rank == 0:
-        print(json.dumps(out), flush=True)
-        line_printed.append(1)
+        with print_lock:
+            if not line_printed:
+                print(json.dumps(out), flush=True)
+                line_printed.append(1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

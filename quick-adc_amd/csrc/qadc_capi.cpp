@@ -1001,6 +1001,138 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
 }  // namespace host
 }  // namespace qadc
 
+namespace {
+
+// ---- the streams of an index ----------------------------------------------------------------------------------------------
+// The streaming launches fill every CU for milliseconds.  They go on the LOWEST-priority stream so that the short work that
+// must overlap them is dispatched as soon as a workgroup slot frees up instead of waiting for the whole batch: the previous
+// batch's candidate ordering, the next batch's front (own streams, highest priority), the collectives of the multi-GPU merge.
+//
+// What was measured about streams (round 4; tools/stream_order_ab*.sh, profiles/r04_stream_order.txt):
+//  * every HIP stream created here gets a hardware queue of its own (the runtime keeps at most four per priority,
+//    GPU_MAX_HW_QUEUES), the queues take hardware slots in creation order, and slot i is served by compute pipe i mod 4;
+//  * queues on one pipe are served in turn, whatever their priority: a dispatch that waits for free CUs — anything launched
+//    beside a long scan — holds up the other queues of its pipe.  So what matters is WHICH streams share a pipe:
+//        pipe 0: S scan stream (lowest priority), W its normal-priority alternative (option "wgq_stream"; never busy together)
+//        pipe 1: C copy / coarse assignment, L the merge's collectives         (both highest priority, both short)
+//        pipe 2: O ordering pass + replays of single-GPU batches, M the merge's interleave + replay (O idles under the merge)
+//        pipe 3: F the next batch's front — alone: it decides when the next scan can start
+//    One of 8 ranks' batch (loopback stand-in) with this order against round 3's (the merge's nine streams created at
+//    qadc_dist_init, one merge stream per slot): C3 shape 0.84 -> 0.51-0.53 ms, C5 1.26 -> 0.89-0.90.  With the front on the
+//    scan stream's pipe, or on a merge stream's: 0.78-0.83 / 1.20-1.23.  More merge streams only put one of them on the
+//    front's or the scan's pipe (C5 shape: 1 stream 0.89 ms, 2: 0.93, 3: 1.06);
+//  * the layout a process gets is only the one above for the FIRST set of streams it creates: an index created after another
+//    one was destroyed — in either order of stream destruction — lands elsewhere (same shapes: 0.81 / 1.20 ms; the single-GPU
+//    C3 leg 0.75 -> 1.08 us per query; that was bench.py's IVF leg, the third index of its process).  Round 3's "figures
+//    depend on the process's history" was this.
+// Hence: ONE set of streams per process and device, created back to back in the order above by the first index on that
+// device, shared by every later index and never destroyed.  Indexes of one device that are driven at the same time share
+// these streams (stream order is then a superset of what each needs: correct, possibly serialised); the expected use is one
+// index at a time per GPU (include/qadc.h: one host thread drives one index, one process per GPU).
+struct StreamSet {
+    hipStream_t stream = nullptr, wgq = nullptr, copy = nullptr, sort = nullptr, front = nullptr, coll = nullptr;
+    hipStream_t merge[kMergeStreams] = {};
+    std::vector<hipStream_t> created;                           // creation order
+};
+std::mutex g_streams_mu;
+std::vector<std::pair<int, StreamSet*>> g_streams;              // (device, set): lives until the process ends
+
+// Creates the streams of `order` (tokens S W C O F L M0..; D / N / H = an idle dummy of the lowest / normal / highest
+// priority — measurement hook) back to back.  A token left out is not created and falls back on another stream.
+hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merge, bool merge_normal) {
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const int prio_normal = (prio_least + prio_greatest) / 2;
+    hipError_t e = hipSuccess;
+    for (size_t pos = 0; pos <= order.size() && e == hipSuccess;) {
+        const size_t comma = std::min(order.find(',', pos), order.size());
+        const std::string tok = order.substr(pos, comma - pos);
+        pos = comma + 1;
+        hipStream_t* dst = nullptr;
+        int prio = prio_greatest;
+        if (tok == "S") { dst = &ss.stream; prio = prio_least; }
+        else if (tok == "W") { dst = &ss.wgq; prio = prio_normal; }
+        else if (tok == "C") dst = &ss.copy;
+        else if (tok == "O") dst = &ss.sort;
+        else if (tok == "F") dst = &ss.front;
+        else if (tok == "L") dst = &ss.coll;
+        else if (tok.size() == 2 && tok[0] == 'M' && tok[1] >= '0' && tok[1] < '0' + kMergeStreams) {
+            if (tok[1] - '0' >= n_merge) continue;
+            dst = &ss.merge[tok[1] - '0'];
+            prio = merge_normal ? prio_normal : prio_least;
+        } else if (tok == "D" || tok == "N" || tok == "H") {
+            hipStream_t dummy = nullptr;
+            e = hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, tok == "D" ? prio_least : tok == "N" ? prio_normal : prio_greatest);
+            if (e == hipSuccess) ss.created.push_back(dummy);
+            continue;
+        } else continue;
+        if (*dst) continue;
+        e = hipStreamCreateWithPriority(dst, hipStreamNonBlocking, prio);
+        if (e == hipSuccess) ss.created.push_back(*dst);
+    }
+    if (e == hipSuccess && !ss.stream) {
+        e = hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, prio_least);
+        if (e == hipSuccess) ss.created.push_back(ss.stream);
+    }
+    if (e != hipSuccess) {
+        for (size_t i = ss.created.size(); i-- > 0;) (void)hipStreamDestroy(ss.created[i]);
+        ss = StreamSet();
+        return e;
+    }
+    for (hipStream_t* p : {&ss.wgq, &ss.copy, &ss.sort, &ss.front, &ss.coll})   // (left out by the hook: fall back on the scan stream)
+        if (!*p) *p = ss.stream;
+    for (int i = 0; i < kMergeStreams; ++i)
+        if (!ss.merge[i]) ss.merge[i] = ss.merge[0] ? ss.merge[0] : ss.stream;
+    return hipSuccess;
+}
+
+int attach_streams(qadc_index* idx, bool hooks) {
+    std::string order = "S,C,O,F,W,L,M0";
+    int n_merge = 1;
+    bool merge_normal = false, own = false;
+    if (hooks) {                                                // measurement hooks (tools/stream_order_ab*.sh): a set of the index's own
+        if (const char* e = std::getenv("QADC_STREAM_ORDER")) { order = e; own = true; n_merge = kMergeStreams; }
+        if (const char* e = std::getenv("QADC_MERGE_STREAMS")) { n_merge = std::max(1, std::min(std::atoi(e), kMergeStreams)); own = true; }
+        if (const char* e = std::getenv("QADC_MERGE_PRIO")) { merge_normal = std::atoi(e) != 0; own = true; }
+        if (const char* e = std::getenv("QADC_OWN_STREAMS")) own = own || std::atoi(e) != 0;
+        if (const char* e = std::getenv("QADC_WGQ_STREAM")) idx->wgq_stream_on = std::atoi(e) != 0;
+    }
+    StreamSet* ss = nullptr;
+    if (own) {
+        ss = new StreamSet();
+        const hipError_t e = create_stream_set(*ss, order, n_merge, merge_normal);
+        if (e != hipSuccess) {
+            delete ss;
+            return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        }
+        idx->own_streams = ss->created;                          // destroyed with the index
+    } else {
+        std::lock_guard<std::mutex> lock(g_streams_mu);
+        for (auto& ds : g_streams)
+            if (ds.first == idx->device) ss = ds.second;
+        if (!ss) {
+            ss = new StreamSet();
+            const hipError_t e = create_stream_set(*ss, order, n_merge, merge_normal);
+            if (e != hipSuccess) {
+                delete ss;
+                return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+            }
+            g_streams.emplace_back(idx->device, ss);
+        }
+    }
+    idx->stream = ss->stream;
+    idx->wgq_stream = ss->wgq;
+    idx->copy_stream = ss->copy;
+    idx->sort_stream = ss->sort;
+    idx->front_stream = ss->front;
+    idx->coll_stream = ss->coll;
+    for (int i = 0; i < kMergeStreams; ++i) idx->merge_streams[i] = ss->merge[i];
+    if (own) delete ss;
+    return QADC_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char* qadc_last_error(void) { return g_err.c_str(); }
@@ -1030,19 +1162,9 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
         if (const char* e = std::getenv("QADC_REPLAY_WAVE")) idx->replay_wave = std::atoi(e) != 0;
         if (const char* e = std::getenv("QADC_HEAD_LEVEL")) idx->head_level = std::max(0, std::min(std::atoi(e), kMaxLevels - 1));
     }
-    // The streaming launches fill every CU for milliseconds.  They go on the LOWEST-priority queue so that the
-    // short work that must overlap them is dispatched as soon as a workgroup slot frees up instead of waiting for
-    // the whole batch: the previous batch's candidate sort, the next batch's front (own streams, highest priority) and
-    // the caller's own streams (the RCCL gather of the multi-GPU merge).
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    hipError_t e = hipStreamCreateWithPriority(&idx->stream, hipStreamNonBlocking, prio_least);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&idx->copy_stream, hipStreamNonBlocking, prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&idx->sort_stream, hipStreamNonBlocking, prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&idx->front_stream, hipStreamNonBlocking, prio_greatest);
-    if (e != hipSuccess) {
+    if (int rc = attach_streams(idx, hooks && std::atoi(hooks) == 1)) {
         delete idx;
-        return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        return rc;
     }
     *out = idx;
     return QADC_OK;
@@ -1052,7 +1174,7 @@ int qadc_index_destroy(qadc_index* idx) {
     if (!idx) return QADC_OK;
     (void)hipSetDevice(idx->device);
     // a pre-scan (front stream) or an on-demand copy may still be in flight: drain all four streams before freeing
-    for (hipStream_t st : {idx->stream, idx->front_stream, idx->copy_stream, idx->sort_stream})
+    for (hipStream_t st : {idx->stream, idx->wgq_stream, idx->front_stream, idx->copy_stream, idx->sort_stream})
         if (st) (void)hipStreamSynchronize(st);
     (void)qadc_dist_shutdown(idx);      // drains the merge's stream and frees the communicator while the index's streams and
                                         // the slot buffers the pack kernel reads are still alive
@@ -1088,10 +1210,8 @@ int qadc_index_destroy(qadc_index* idx) {
         if (s.ev_scanned) (void)hipEventDestroy(s.ev_scanned);
         for (auto e : s.prof_ev) (void)hipEventDestroy(e);
     }
-    (void)hipStreamDestroy(idx->stream);
-    if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
-    if (idx->front_stream) (void)hipStreamDestroy(idx->front_stream);
-    if (idx->sort_stream) (void)hipStreamDestroy(idx->sort_stream);
+    // (the streams belong to the process — see attach_streams — unless a measurement hook gave this index a set of its own)
+    for (size_t i = idx->own_streams.size(); i-- > 0;) (void)hipStreamDestroy(idx->own_streams[i]);
     delete idx;
     return QADC_OK;
 }
@@ -1363,6 +1483,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
     else if (n == "wgq") idx->wgq = (int)value;
     else if (n == "wgq_variant") idx->wgq_variant = (int)value;
+    else if (n == "wgq_stream") idx->wgq_stream_on = value != 0;
     else if (n == "dist_cap_entries") {                       // entries per rank block of the native gather (test knob)
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
         idx->dist->cap_entries = (uint32_t)std::max(16.0, std::min(value, 1073741824.0));

@@ -75,7 +75,7 @@ int enqueue_merge_now(qadc_index* idx, Slot& s) {
     // compute — a millisecond of replay latency — goes to a stream of its own
     if (!ds.ev_gathered) HIPCHECK(hipEventCreateWithFlags(&ds.ev_gathered, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(ds.ev_gathered, st));
-    hipStream_t ms = d.merge_stream[slot_i] ? d.merge_stream[slot_i] : st;
+    hipStream_t ms = d.merge_stream[ds.seq % kMergeStreams] ? d.merge_stream[ds.seq % kMergeStreams] : st;
     if (ms != st) HIPCHECK(hipStreamWaitEvent(ms, ds.ev_gathered, 0));
     uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ds.d_out + sizeof(uint64_t) * (size_t)R * nq);
     HIPCHECK(launch_dist_merge(ds.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, ds.d_moff.p, ds.d_mcnt.p, ds.d_mcnt.p + nq,
@@ -255,9 +255,7 @@ struct DistGuard {
         if (!d) return;
         if (d->stream) { (void)hipStreamSynchronize(d->stream); }
         for (hipStream_t m : d->merge_stream) if (m) { (void)hipStreamSynchronize(m); }
-        if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
-        if (d->stream) (void)hipStreamDestroy(d->stream);
-        for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamDestroy(m);
+        if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);     // (the streams belong to the index)
     }
 };
 int dist_init_checks(qadc_index* idx, int rank, int world) {
@@ -287,16 +285,11 @@ int qadc_dist_init(qadc_index* idx, int rank, int world, const uint8_t* id128) {
     }
     d->rank = rank;
     d->world = world;
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
-    // (NOT the collectives' priority: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
-    // queue as the collectives' stream a replay sat in front of the next batch's gather — seen in the trace.  And not ABOVE
-    // the scans either: at normal priority the interleave / replay waves held up the short launches between two batches'
-    // scans on the lowest-priority scan stream — one of 8 ranks, 1024-query batches, C5 shape 1.18 -> 1.10 ms, C3 0.70 ->
-    // 0.60 with the merges at the scans' own, lowest priority.)
-    for (int i = 0; i < kSlots; ++i)
-        HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream[i], hipStreamNonBlocking, prio_least));
+    // the merge's streams were created with the index (qadc_index_create: one fixed order, a hardware queue each) — the
+    // collectives on the highest priority, interleave + replay at the scans' own lowest one: at normal priority their waves held
+    // up the short launches between two batches' scans (one of 8 ranks, C5 shape 1.18 -> 1.10 ms per batch, C3 0.70 -> 0.60)
+    d->stream = idx->coll_stream;
+    for (int i = 0; i < kMergeStreams; ++i) d->merge_stream[i] = idx->merge_streams[i];
     // RCCL finishes setting up its channels lazily, inside the first collectives of a communicator (the very first
     // all-gather takes ~8 ms); a few throw-away gathers here keep that out of the first batches' collect calls.
     {
@@ -342,16 +335,11 @@ int qadc_dist_init_transport(qadc_index* idx, int rank, int world, qadc_allgathe
     d->user_ctx = ctx;
     d->rank = rank;
     d->world = world;
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    HIPCHECK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_greatest));
-    // (NOT the collectives' priority: HIP multiplexes the streams of one priority over a few hardware queues, and on the same
-    // queue as the collectives' stream a replay sat in front of the next batch's gather — seen in the trace.  And not ABOVE
-    // the scans either: at normal priority the interleave / replay waves held up the short launches between two batches'
-    // scans on the lowest-priority scan stream — one of 8 ranks, 1024-query batches, C5 shape 1.18 -> 1.10 ms, C3 0.70 ->
-    // 0.60 with the merges at the scans' own, lowest priority.)
-    for (int i = 0; i < kSlots; ++i)
-        HIPCHECK(hipStreamCreateWithPriority(&d->merge_stream[i], hipStreamNonBlocking, prio_least));
+    // the merge's streams were created with the index (qadc_index_create: one fixed order, a hardware queue each) — the
+    // collectives on the highest priority, interleave + replay at the scans' own lowest one: at normal priority their waves held
+    // up the short launches between two batches' scans (one of 8 ranks, C5 shape 1.18 -> 1.10 ms per batch, C3 0.70 -> 0.60)
+    d->stream = idx->coll_stream;
+    for (int i = 0; i < kMergeStreams; ++i) d->merge_stream[i] = idx->merge_streams[i];
     idx->dist = g.d.release();
     return QADC_OK;
 }
@@ -413,12 +401,11 @@ int qadc_dist_shutdown(qadc_index* idx) {
     if (!idx || !idx->dist) return QADC_OK;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    if (idx->wgq_stream) (void)hipStreamSynchronize(idx->wgq_stream);
     DistState* d = idx->dist;
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamSynchronize(m);
-    if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);
-    if (d->stream) (void)hipStreamDestroy(d->stream);
-    for (hipStream_t m : d->merge_stream) if (m) (void)hipStreamDestroy(m);
+    if (d->comm && d->CommDestroy) (void)d->CommDestroy(d->comm);        // (the streams stay: they belong to the index)
     d->d_fix.release(); d->h_fix.release(); d->d_moff.release(); d->d_merged.release(); d->d_mcnt.release();
     for (auto& ds : d->slot) ds.release();
     d->d_block.release(); d->d_gathered.release(); d->d_src.release(); d->h_src.release(); d->d_extra.release(); d->d_extra_all.release();

@@ -100,6 +100,9 @@ struct Part {
     bool own = true;
 };
 
+constexpr int kMergeStreams = 3;   // streams the enqueued merges MAY rotate over (measurement hook); the default creates ONE:
+                                   // more merge streams than pipes to put them on only move a merge onto the front's or the
+                                   // scan's pipe (qadc_index_create) — one of 8 ranks, C5 shape: 1 stream 0.89 ms, 2: 0.93, 3: 1.06
 constexpr int kSlots = 8;   // batches in flight: one being collected, one scanning, the others queued behind it with their fronts running
                             // ahead.  Three or four cover every loop measured so far (deeper pipelines of the multi-GPU IVF loop — six,
                             // eight batches — were tried and are no faster: its batches share the GPU, they do not wait for it)
@@ -264,11 +267,12 @@ struct DistState {
     void* comm = nullptr;
     qadc_allgather_fn user_fn = nullptr;                     // qadc_dist_init_transport: the caller's all-gather instead of RCCL
     void* user_ctx = nullptr;
-    hipStream_t stream = nullptr;                            // own high-priority stream: the merge of batch s must not queue
-                                                             // behind the scan kernels of batches s+1.. on the main stream
-    hipStream_t merge_stream[kSlots] = {};                   // interleave + replay of a merge enqueued with its batch: a millisecond of
+    // (both BORROWED from the index, which creates every stream it will ever use in one fixed order — see qadc_index_create)
+    hipStream_t stream = nullptr;                            // the collectives' own high-priority stream: the merge of batch s must not
+                                                             // queue behind the scan kernels of batches s+1.. on the scan stream
+    hipStream_t merge_stream[kMergeStreams] = {};            // interleave + replay of a merge enqueued with its batch: a millisecond of
                                                              // latency that must neither sit in front of the NEXT batch's collectives
-                                                             // nor behind the PREVIOUS batch's replay (one stream per slot)
+                                                             // nor behind the PREVIOUS batch's replay (rotating, by merge sequence)
     int rank = 0, world = 1;
     uint32_t cap_entries = 1u << 16;                         // entries per rank block; regrown (by every rank alike) on overflow
     DevBuf<uint64_t> d_block, d_gathered;
@@ -342,7 +346,15 @@ using namespace qadc::host;   // (internal header: only the host-side translatio
 
 struct qadc_index {
     int M = 16, cs = 8, device = 0;
-    hipStream_t stream = nullptr;
+    // The streams belong to the PROCESS: one set per device, created in one fixed order by the first index on the device and
+    // shared by every later one (attach_streams in qadc_capi.cpp has the measurements: which compute pipe a stream's queue
+    // lands on decides what it can be blocked behind, and only the first set a process creates lands predictably).
+    hipStream_t stream = nullptr;       // scan stream of the level path (lowest priority)
+    hipStream_t wgq_stream = nullptr;   // scan stream of the one-workgroup-per-query batches when option "wgq_stream" says so (normal priority)
+    hipStream_t coll_stream = nullptr;  // the multi-GPU merge's collectives (highest priority; unused until qadc_dist_init)
+    hipStream_t merge_streams[kMergeStreams] = {};   // the merges' interleave + replay (lowest priority; unused until qadc_dist_init)
+    std::vector<hipStream_t> own_streams;   // only under a measurement hook: streams created for this index alone (destroyed with it)
+    int wgq_stream_on = 0;              // option "wgq_stream": 1 = query-kernel batches scan on wgq_stream instead of `stream`
     hipStream_t front_stream = nullptr; // a batch's pre-scan/quantize chain, under the previous batch's streaming launches
     hipStream_t copy_stream = nullptr;  // uploads and on-demand copies: issued where they depend on nothing (see plan_and_launch)
     uint32_t replay_seq = 0;            // device replays alternate between two side streams in submission order

@@ -119,7 +119,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     const uint32_t ccap = std::min<uint32_t>(idx->wgq_cand_cap, kQueryCandCap);
     HIPCHECK(s.d_qcands.ensure((size_t)nsub * ccap));
 
-    hipStream_t st = idx->stream;
+    hipStream_t st = idx->wgq_stream_on ? idx->wgq_stream : idx->stream;
     // A lone small query (the synchronous single-query call): its input — which partitions, their descriptors, the
     // float tables — fits the kernel-argument segment and rides in the dispatch packet; no copy precedes the launch.
     alignas(16) unsigned char inl[kInlineBytes];

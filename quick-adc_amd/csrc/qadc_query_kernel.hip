@@ -35,6 +35,10 @@
 #include <cstring>
 #include <type_traits>
 
+#ifndef QADC_WALK_PIPE
+#define QADC_WALK_PIPE 1
+#endif
+
 namespace qadc {
 
 namespace {
@@ -427,24 +431,57 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         float* mytab = wtab + wave * (M * 16);
         float lmin = FLT_MAX;
         const int pslot = (int)wave / wpp, sub = (int)wave % wpp;
+        // The pre-scan is LATENCY, not work: a wave's round used to be a chain of dependent memory round trips — assign[a],
+        // the partition descriptor, the probe's float table, then one 16-byte code load per 64 starts, each waited for before the
+        // next was issued (C5 shape: 4 rounds x ~12 round trips per wave; the front was half of the head launch).  Now the NEXT
+        // round's descriptor and table are fetched into registers while the current round's starts are evaluated (round_in),
+        // and the starts loop issues kPB code loads before it consumes the first.
+        constexpr int kTV = M * 16 / 64;                         // table floats per lane
+        constexpr int kPB = 4;                                   // start vectors in flight per lane
+        struct RoundIn {
+            float tv[kTV];
+            uint32_t sn;
+            const uint8_t* sc;
+            bool active;
+        };
+        auto round_in = [&](int a0) {
+            RoundIn r;
+            const int a = a0 + pslot;
+            r.active = pslot < pstride && a < ma;
+            r.sn = 0;
+            r.sc = nullptr;
+#pragma unroll
+            for (int k = 0; k < kTV; ++k) r.tv[k] = 0.0f;
+            if (r.active) {
+                const float* __restrict__ ft = ft_all + (size_t)a * (M * 16);
+#pragma unroll
+                for (int k = 0; k < kTV; ++k) r.tv[k] = ft[k * 64 + (int)lane];
+                const PartDesc& d = parts[assign[a]];
+                const uint32_t gn = d.global_n, st_n = d.start_n;
+                const uint8_t* st_p = d.starts;
+                const uint8_t* co_p = d.codes;
+                r.sn = gn ? st_n : 0u;
+                r.sc = st_p ? st_p : co_p;
+            }
+            return r;
+        };
+        RoundIn cur = round_in(0);
         // the loop bounds are workgroup-uniform (a wave without a probe idles through the barriers)
         for (int a0 = 0; a0 < ma; a0 += pstride) {
-            const int a = a0 + pslot;
-            const bool active = pslot < pstride && a < ma;
+            RoundIn nxt = round_in(a0 + pstride);                // (a0 + pstride >= ma: inactive, no loads)
+            const bool active = cur.active;
             uint32_t sn = 0, base = 0;
             const uint8_t* sc = nullptr;
             if (active) {
-                const float* __restrict__ ft = ft_all + (size_t)a * (M * 16);
                 q_wave_lds_sync();
-                for (int i = lane; i < M * 16; i += 64) {
-                    const float v = ft[i];
-                    mytab[i] = v;
-                    if (sub == 0) lmin = fminf(lmin, v);
+#pragma unroll
+                for (int k = 0; k < kTV; ++k) {
+                    mytab[k * 64 + (int)lane] = cur.tv[k];
+                    if (sub == 0) lmin = fminf(lmin, cur.tv[k]);
                 }
                 q_wave_lds_sync();
-                const PartDesc d = parts[assign[a]];
-                sn = d.global_n ? d.start_n : 0u;
-                sc = d.starts ? d.starts : d.codes;
+                sn = q_uni(cur.sn);
+                sc = reinterpret_cast<const uint8_t*>(q_uni64(reinterpret_cast<uint64_t>(cur.sc)));
                 if (sub == 0 && sn) {
                     if (lane == 0) base = atomicAdd(&s_nvals, sn);
                     base = __builtin_amdgcn_readfirstlane(base);
@@ -455,29 +492,45 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 __syncthreads();
                 if (active && sn) base = wcnt[16 + pslot];
             }
-            for (uint32_t i = (uint32_t)sub * 64u + lane; i < sn; i += 64u * (uint32_t)wpp) {
-                uint32_t dw[DW];
-                if constexpr (M == 16) {
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 v = ((const __attribute__((address_space(1))) u32x2*)(uintptr_t)sc)[i];
-                    dw[0] = v.x; dw[1] = v.y;
-                } else {
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 v = ((const __attribute__((address_space(1))) u32x4*)(uintptr_t)sc)[i];
-                    dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
-                }
-                // scan_4<M> order: byte by byte, low nibble then high nibble, accumulated from 0 (query_common.hpp:72-80)
-                float cand = 0.0f;
+            const uint32_t step = 64u * (uint32_t)wpp;
+            for (uint32_t i0 = (uint32_t)sub * 64u + lane; i0 < sn; i0 += step * kPB) {
+                uint32_t dwv[kPB][DW];
 #pragma unroll
-                for (int b = 0; b < CS; ++b) {
-                    const uint32_t byte = (dw[b >> 2] >> (8 * (b & 3))) & 0xffu;
-                    cand += mytab[(2 * b) * 16 + (byte & 15u)];
-                    cand += mytab[(2 * b + 1) * 16 + (byte >> 4)];
+                for (int u = 0; u < kPB; ++u) {
+                    const uint32_t i = i0 + (uint32_t)u * step;
+#pragma unroll
+                    for (int w_ = 0; w_ < DW; ++w_) dwv[u][w_] = 0;
+                    if (i < sn) {
+                        if constexpr (M == 16) {
+                            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                            const u32x2 v = ((const __attribute__((address_space(1))) u32x2*)(uintptr_t)sc)[i];
+                            dwv[u][0] = v.x; dwv[u][1] = v.y;
+                        } else {
+                            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                            const u32x4 v = ((const __attribute__((address_space(1))) u32x4*)(uintptr_t)sc)[i];
+                            dwv[u][0] = v.x; dwv[u][1] = v.y; dwv[u][2] = v.z; dwv[u][3] = v.w;
+                        }
+                    }
                 }
-                if (in_lds) vals[base + i] = cand;
-                else gvals[base + i] = cand;
+#pragma unroll
+                for (int u = 0; u < kPB; ++u) {
+                    const uint32_t i = i0 + (uint32_t)u * step;
+                    if (i < sn) {
+                        // scan_4<M> order: byte by byte, low nibble then high nibble, accumulated from 0 (query_common.hpp:72-80)
+                        float cand = 0.0f;
+#pragma unroll
+                        for (int b = 0; b < CS; ++b) {
+                            const uint32_t byte = (dwv[u][b >> 2] >> (8 * (b & 3))) & 0xffu;
+                            cand += mytab[(2 * b) * 16 + (byte & 15u)];
+                            cand += mytab[(2 * b + 1) * 16 + (byte >> 4)];
+                        }
+                        if (in_lds) vals[base + i] = cand;
+                        else gvals[base + i] = cand;
+                    }
+                }
             }
             if (wpp > 1) __syncthreads();                        // the hand-over slot is reused by the next round
+            cur = nxt;
         }
         STAMP(3);
         prefetch();                                              // in flight under the select and the quantizer
@@ -503,8 +556,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 __syncthreads();
                 const uint32_t prefix = s_prefix;
                 const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (lo + 8));
-                for (uint32_t i = tid; i < n; i += kQWG) {
-                    const uint32_t key = q_fkey(in_lds ? vals[i] : gvals[i]);
+                auto count_key = [&](uint32_t key) {
                     if ((key & himask) == prefix) {
                         // the first digit of float keys (sign + 7 exponent bits) puts almost every value into two or
                         // three bins: lanes that share the leading lane's digit add ONE count per wave
@@ -523,6 +575,24 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                             }
                         }
                         if (!counted) atomicAdd(&hist[dg], 1u);
+                    }
+                };
+                if (in_lds) {
+                    for (uint32_t i = tid; i < n; i += kQWG) count_key(q_fkey(vals[i]));
+                } else {
+                    // values in the global scratch (more starts than the LDS budget holds — the C5 shape: 39 K per query): eight
+                    // loads in flight per lane; one dependent load per iteration made this select 2/3 of that shape's front
+                    constexpr int kSB = 8;
+                    for (uint32_t i0 = tid; i0 < n; i0 += kQWG * kSB) {
+                        float fv[kSB];
+#pragma unroll
+                        for (int u = 0; u < kSB; ++u) {
+                            const uint32_t i = i0 + (uint32_t)u * kQWG;
+                            fv[u] = i < n ? gvals[i] : 0.0f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < kSB; ++u)
+                            if (i0 + (uint32_t)u * kQWG < n) count_key(q_fkey(fv[u]));
                     }
                 }
                 __syncthreads();
@@ -555,16 +625,29 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         const float delta = (qmax - qmin) / 127;
         const float scale = 127.0f / (qmax - qmin);
         const int all = ma * M * 16;
-        for (int i = tid; i < all; i += kQWG) {
-            float v = ft_all[i];
-            if (v < 0) { v = 0; if (G == 1) ft_all[i] = 0; }    // (G > 1: another workgroup may still pre-scan the unclamped tables)
-            int8_t o;
-            if (flags & 1u) o = 127;
-            else if (v >= qmax) o = 127;
-            else o = (int8_t)(int)(A.quant_mode == 0 ? (v - qmin) / delta : (v - qmin) * scale);
-            qt_all[i] = o;
-            if constexpr (RES) {                                 // the first probed partition's table: straight into LDS as well
-                if (resident && i / (M * 16) == a_res) tq[i % (M * 16)] = (unsigned char)o;
+        constexpr int kQB = 8;                                   // table entries in flight per lane (the clamp's store to the same
+                                                                 // array keeps the compiler from overlapping the loads by itself)
+        for (int i0 = tid; i0 < all; i0 += kQWG * kQB) {
+            float tv[kQB];
+#pragma unroll
+            for (int u = 0; u < kQB; ++u) {
+                const int i = i0 + u * kQWG;
+                tv[u] = i < all ? ft_all[i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kQB; ++u) {
+                const int i = i0 + u * kQWG;
+                if (i >= all) continue;
+                float v = tv[u];
+                if (v < 0) { v = 0; if (G == 1) ft_all[i] = 0; }    // (G > 1: another workgroup may still pre-scan the unclamped tables)
+                int8_t o;
+                if (flags & 1u) o = 127;
+                else if (v >= qmax) o = 127;
+                else o = (int8_t)(int)(A.quant_mode == 0 ? (v - qmin) / delta : (v - qmin) * scale);
+                qt_all[i] = o;
+                if constexpr (RES) {                             // the first probed partition's table: straight into LDS as well
+                    if (resident && i / (M * 16) == a_res) tq[i % (M * 16)] = (unsigned char)o;
+                }
             }
         }
         __threadfence_block();
@@ -645,6 +728,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     // replays and writes the ordered stream.  Exactness does not depend on how the waves interleave: the bound of an
     // epoch is fixed before its first code is tested, and the order is restored by the sort.
     constexpr int kRounds = U;                                   // loads per lane in flight
+    constexpr bool PIPE = QADC_WALK_PIPE;                        // (build-time A/B of the pipelined walk)
     constexpr uint32_t kEpochVec = 32768;                        // longest epoch (vectors): bounds how stale a bound gets
     uint32_t* hist_done = misc;                                  // [128] candidates of the finished epochs, by value
     uint32_t* hist_cur = misc + 128;                             // [128] candidates of the running epoch
@@ -660,21 +744,31 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         return tid < M * 4 ? reinterpret_cast<const uint32_t*>(qt_all + (size_t)a_ * (M * 16))[tid] : 0u;
     };
     auto write_tables = [&]() {                                  // replicated pair tables from the staged int8 table (layout: QCfg)
-        constexpr int PAIRS = (M / 8) * 256;                     // (code dword g, byte value x)
-        constexpr int TPP = kQWG / PAIRS;                        // threads per pair (16x4: 2, 32x4: 1)
-        constexpr int REPL = 32 / TPP;                           // bank replicas written per thread
-        const int pr = (int)tid / TPP, part = (int)tid % TPP;
-        const int g = pr >> 8, x = pr & 255;
+        // The image is written in ADDRESS order — thread t stores the 16-byte units t, t + 1024, ... — so a wave's
+        // ds_write_b128 covers 1 KiB contiguous: every bank once, no conflict.  (Round 3 gave a thread one (dword g, byte
+        // value x) pair and let it write that pair's 128-byte row by itself: the rows of a wave's lanes lie 256 bytes apart,
+        // i.e. in the SAME banks — a 32-way conflict on every store, ~4 K LDS cycles per 64 KiB image instead of ~256; the
+        // 15 % bank-conflict cycles the PMC pass of round 3 charged to this kernel.)
+        // A wave's units of iteration k belong to 8 (g, x) pairs, 8 lanes each; over all iterations the wave needs
+        // 8 * kIter pairs.  Lane l computes pair l's dword once; ds_bpermute hands it to the lanes that replicate it.
+        constexpr int kIter = C::TABLE_BYTES / 16 / kQWG;        // 16x4: 4, 32x4: 8 units per thread
         uint32_t w = 0;
+        {
+            const uint32_t pi = lane & (8u * kIter - 1u);        // (16x4: lanes 32..63 repeat 0..31)
+            const uint32_t k = pi >> 3, within = pi & 7u;
+            const uint32_t x = (k & 3u) * 64u + wave * 4u + (within >> 1);
+            const uint32_t g = (k >> 2) * 2u + (within & 1u);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int b = 4 * g + jj;
-            w |= ((uint32_t)tq[(2 * b) * 16 + (x & 15)] + (uint32_t)tq[(2 * b + 1) * 16 + (x >> 4)]) << (8 * jj);
+            for (int jj = 0; jj < 4; ++jj) {
+                const uint32_t b = 4u * g + jj;
+                w |= ((uint32_t)tq[(2 * b) * 16 + (x & 15u)] + (uint32_t)tq[(2 * b + 1) * 16 + (x >> 4)]) << (8 * jj);
+            }
         }
-        unsigned char* dst = qsmem + (g >> 1) * 65536 + x * 256 + (g & 1) * 128 + part * (REPL * 4);
-        const uint4 w4 = make_uint4(w, w, w, w);
 #pragma unroll
-        for (int r = 0; r < REPL / 4; ++r) reinterpret_cast<uint4*>(dst)[r] = w4;
+        for (int k = 0; k < kIter; ++k) {
+            const uint32_t wk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((k * 8u + (lane >> 3)) * 4u), (int)w);
+            *reinterpret_cast<uint4*>(qsmem + ((size_t)k * kQWG + tid) * 16) = make_uint4(wk, wk, wk, wk);
+        }
     };
     const uint32_t lane_lo = (tid & 31u) * 4u, lane_hi = lane_lo | 0x10000u;
     if (tid < 256) misc[tid] = 0;                                // both histograms
@@ -984,7 +1078,41 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                     }
                 };
                 uint32_t tl = wave;
-                for (; tl + (kRounds - 1) * kQWaves < full_tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, true>());
+                if constexpr (PIPE) {
+                    // software pipeline over the full tiles: the NEXT iteration's loads are issued before the current tiles are
+                    // summed, so a wave has loads in flight while it works the LDS pipe — without it the 16 (x 2 workgroups) waves of
+                    // a CU, which issued their loads together, get them back together, and the memory system idles while they all
+                    // look up (the head walk measured 3.6 TB/s of reads: about half of the time nothing was in flight)
+                    auto consume = [&](const u32x4 (&v)[kRounds], uint32_t tl_) {
+                        uint32_t cand[kRounds * CPL];
+                        const uint32_t best = sums_of(cand, v, t0, width, tl_, std::integral_constant<bool, true>());
+                        if (__builtin_expect(best < bound, 0)) {
+#pragma unroll
+                            for (int i = 0; i < kRounds; ++i)
+#pragma unroll
+                                for (int c = 0; c < CPL; ++c)
+                                    if (cand[i * CPL + c] < bound)
+                                        emit(cand[i * CPL + c], (t0 + (tl_ + (uint32_t)i * kQWaves) * 64u + lane) * CPL + c);
+                        }
+                    };
+                    if (tl + (kRounds - 1) * kQWaves < full_tiles) {
+                        u32x4 v[kRounds];
+                        load_tiles(v, t0, width, tl, std::integral_constant<bool, true>());
+                        for (;;) {
+                            const uint32_t tn = tl + kQWaves * kRounds;
+                            const bool more_full = tn + (kRounds - 1) * kQWaves < full_tiles;
+                            u32x4 nv[kRounds];
+                            if (more_full) load_tiles(nv, t0, width, tn, std::integral_constant<bool, true>());
+                            consume(v, tl);
+                            tl = tn;
+                            if (!more_full) break;
+#pragma unroll
+                            for (int i = 0; i < kRounds; ++i) v[i] = nv[i];
+                        }
+                    }
+                } else {
+                    for (; tl + (kRounds - 1) * kQWaves < full_tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, true>());
+                }
                 for (; tl < tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, false>());
                 t0 += width;
                 const bool sw = t0 >= t_end && more;
@@ -1012,6 +1140,11 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
             qs->qmin = qmin;
             qs->qmax = qmax;
             qs->flags = flags & 3u;
+            if (A.head_slots) {                                  // the IVF head: phase clocks for the profile (order_cands_kernel forwards
+                const uint64_t clk2 = __builtin_readcyclecounter();   // them; the select fields are idle on this path)
+                qs->sel_prefix = (uint32_t)min((clk1 - clk0) >> 6, (uint64_t)0xffff);
+                qs->sel_k = (uint32_t)((clk2 - clk1) >> 4);
+            }
         }
         return;
     }
@@ -1197,7 +1330,8 @@ __global__ __launch_bounds__(kQWG) void order_cands_kernel(const QueryState* __r
         o.out_off = (uint32_t)((size_t)q * cap);
         o.qmin = qs->qmin;
         o.qmax = qs->qmax;
-        o.pad[0] = o.pad[1] = 0;
+        o.pad[0] = qs->sel_prefix & 0xffffu;                     // the head's phase clocks (front >> 6, walk >> 4): scan_query_kernel, HEAD
+        o.pad[1] = qs->sel_k;
         qout[q] = o;
         if (qflags) {
             qflags[4 * q + 0] = flags | 4u;

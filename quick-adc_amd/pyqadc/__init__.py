@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libqadc_hip.so")
+if os.environ.get("QADC_TEST_HOOKS") == "1" and os.environ.get("QADC_LIB_PATH"):   # same-box A/B of two builds (tools/)
+    LIB_PATH = os.environ["QADC_LIB_PATH"]
 
 u8p = C.POINTER(C.c_uint8)
 i8p = C.POINTER(C.c_int8)

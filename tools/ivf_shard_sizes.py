@@ -12,6 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "quick-adc_amd"))
+os.environ.setdefault("QADC_BENCH_CPU_SECONDS", "0")   # (no CPU sample for these probes)
 import bench  # noqa: E402
 
 WORLD = int(os.environ.get("WORLD_EMU", 8))
