@@ -263,6 +263,9 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     if (s.wgq) return launch_wgq_batch(idx, s);
     ScopedMs timer(idx->prof.host_plan_ms);
     const int M = idx->M, cs = idx->cs, nq = s.nq, ma = s.ma;
+    // (tried, round 4: consecutive level-path batches alternating between two scan streams on the scan pipe, so that the first
+    // workgroups of batch s+1 fill the tail of batch s's last level — 125M-code shard 1.10-1.15 -> 1.15-1.35 ms per step, 1B
+    // 7.66 -> 7.72-7.76: the next batch's workgroups do not fill a tail, they compete with the current level for CUs)
     hipStream_t st = idx->stream;
     const size_t table_dim = (size_t)M * 16;
     BatchPlan plan;
@@ -1039,7 +1042,7 @@ std::vector<std::pair<int, StreamSet*>> g_streams;              // (device, set)
 
 // Creates the streams of `order` (tokens S W C O F L M0..; D / N / H = an idle dummy of the lowest / normal / highest
 // priority — measurement hook) back to back.  A token left out is not created and falls back on another stream.
-hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merge, bool merge_normal) {
+hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merge, bool merge_normal, bool w_low) {
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     const int prio_normal = (prio_least + prio_greatest) / 2;
@@ -1051,7 +1054,7 @@ hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merg
         hipStream_t* dst = nullptr;
         int prio = prio_greatest;
         if (tok == "S") { dst = &ss.stream; prio = prio_least; }
-        else if (tok == "W") { dst = &ss.wgq; prio = prio_normal; }
+        else if (tok == "W") { dst = &ss.wgq; prio = w_low ? prio_least : prio_normal; }
         else if (tok == "C") dst = &ss.copy;
         else if (tok == "O") dst = &ss.sort;
         else if (tok == "F") dst = &ss.front;
@@ -1089,8 +1092,9 @@ hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merg
 int attach_streams(qadc_index* idx, bool hooks) {
     std::string order = "S,C,O,F,W,L,M0";
     int n_merge = 1;
-    bool merge_normal = false, own = false;
-    if (hooks) {                                                // measurement hooks (tools/stream_order_ab*.sh): a set of the index's own
+    bool merge_normal = false, own = false, w_low = false;
+    if (hooks) {
+        if (const char* e = std::getenv("QADC_W_LOW")) { w_low = std::atoi(e) != 0; own = true; }                                                // measurement hooks (tools/stream_order_ab*.sh): a set of the index's own
         if (const char* e = std::getenv("QADC_STREAM_ORDER")) { order = e; own = true; n_merge = kMergeStreams; }
         if (const char* e = std::getenv("QADC_MERGE_STREAMS")) { n_merge = std::max(1, std::min(std::atoi(e), kMergeStreams)); own = true; }
         if (const char* e = std::getenv("QADC_MERGE_PRIO")) { merge_normal = std::atoi(e) != 0; own = true; }
@@ -1100,7 +1104,7 @@ int attach_streams(qadc_index* idx, bool hooks) {
     StreamSet* ss = nullptr;
     if (own) {
         ss = new StreamSet();
-        const hipError_t e = create_stream_set(*ss, order, n_merge, merge_normal);
+        const hipError_t e = create_stream_set(*ss, order, n_merge, merge_normal, w_low);
         if (e != hipSuccess) {
             delete ss;
             return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -1112,7 +1116,7 @@ int attach_streams(qadc_index* idx, bool hooks) {
             if (ds.first == idx->device) ss = ds.second;
         if (!ss) {
             ss = new StreamSet();
-            const hipError_t e = create_stream_set(*ss, order, n_merge, merge_normal);
+            const hipError_t e = create_stream_set(*ss, order, n_merge, merge_normal, w_low);
             if (e != hipSuccess) {
                 delete ss;
                 return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -1483,6 +1487,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
     else if (n == "wgq") idx->wgq = (int)value;
     else if (n == "wgq_variant") idx->wgq_variant = (int)value;
+    else if (n == "wgq_ramp_shift") idx->wgq_ramp_shift = (int)std::max(0.0, std::min(value, 4.0));
     else if (n == "wgq_stream") idx->wgq_stream_on = value != 0;
     else if (n == "dist_cap_entries") {                       // entries per rank block of the native gather (test knob)
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");

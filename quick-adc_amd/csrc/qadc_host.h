@@ -411,6 +411,7 @@ struct qadc_index {
                                          // scanned by ONE launch of the query kernel in head mode instead of head_level dependent
                                          // level launches (0 = off): -5 % per step on a 125M-code shard, neutral at 1B
     int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
+    int wgq_ramp_shift = 0;              // ramp epochs of the query kernel's walk grow by 2^shift (0 = default, doubling)
     uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)
     DevBuf<PartDesc> d_partdesc;         // device partition table (qadc_index_finalize)
     std::vector<PartDesc> h_partdesc;    // its host copy (a lone small query carries the descriptors it needs in its launch)

@@ -238,6 +238,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     A.quant_mode = idx->quant_mode;
     A.nontemporal = idx->total_codes * (uint64_t)idx->cs > (200ull << 20);   // (same rule as the level path)
     A.G = G;
+    A.ramp_shift = (uint32_t)idx->wgq_ramp_shift;
     if (idx->profile) HIPCHECK(prof_event(s, st));
     s.poll = alone && G > 1 && !s.dev_replay && !idx->profile && idx->wgq_poll;
     if (s.poll)

@@ -143,6 +143,7 @@ struct QueryKernelArgs {
     // {flags & 3, qmin, qmax, 0}; no walk), the shares are all-gathered, and the head launch of the whole batch takes the
     // gathered int8 tables with front_in seeding every query's flags / qmin / qmax.
     uint32_t front_only;
+    uint32_t ramp_shift;     // the ramp epochs of the walk grow by 2^ramp_shift (0 = the default: 1, i.e. doubling)
     uint32_t* front_out;
     const uint32_t* front_in;
 };

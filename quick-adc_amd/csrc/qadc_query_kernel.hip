@@ -1054,7 +1054,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 uint32_t width;
                 if (ramp < kEpochVec) {
                     width = min(ramp, rest);
-                    ramp *= 2u;
+                    ramp <<= (A.ramp_shift ? A.ramp_shift : 1u);
                 } else {
                     width = min(rest, kEpochVec);
                 }
