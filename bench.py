@@ -346,8 +346,8 @@ def pmc_traffic_from_profiles(M, N, alg_bytes_per_launch):
 
 
 # --------------------------------------------------------------------------------------------- GPU side legs
-def single_query_leg(idx, M, N, pool, nqueries):
-    """ONE query per pass (the reference's mode): `nqueries` sequential single-query batches, three in flight.
+def single_query_leg(idx, M, N, pool, nqueries, depth=3):
+    """ONE query per pass (the reference's mode): `nqueries` sequential single-query batches, `depth` (three) in flight.
     Returns the HIP-event profile of the streaming launches and the wall-clock rate."""
     import torch
     a1 = np.zeros((1, 1), np.int32)
@@ -356,14 +356,14 @@ def single_query_leg(idx, M, N, pool, nqueries):
     def run(k):
         pend = []
         for s in range(k):
-            idx.submit(s % 3, a1, tabs[s % len(tabs)].copy(), R)
-            pend.append(s % 3)
-            if len(pend) == 3:
+            idx.submit(s % depth, a1, tabs[s % len(tabs)].copy(), R)
+            pend.append(s % depth)
+            if len(pend) == depth:
                 idx.collect(pend.pop(0))
         while pend:
             idx.collect(pend.pop(0))
 
-    run(3)
+    run(2 * depth)
     idx.profile_reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -585,15 +585,15 @@ def c2_leg(local_rank):
     # one query per pass: HIP events around the streaming launches (front_run_max 0: all of them on the scan stream)
     idx.set_option("profile", 1)
     idx.set_option("front_run_max", 0)
-    nsingle = 256
-    sprof, sdt = single_query_leg(idx, M, N, pool, nsingle)
+    nsingle, depth1 = 512, int(os.environ.get("QADC_BENCH_C2_DEPTH", 8))     # (a query is a chain of ~10 short launches: eight in flight)
+    sprof, sdt = single_query_leg(idx, M, N, pool, nsingle, depth1)
     idx.close()
     cs = M // 2
     wall_gbs = float(N) * cs * nsingle / sdt / 1e9
     kern_gbs = sprof["scan_codes"] * cs / (sprof["scan_ms"] * 1e-3) / 1e9 if sprof["scan_ms"] > 0 else 0.0
     roof = {"bound": "hbm", "achieved": wall_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wall_gbs / HBM_PEAK_GBS, "traffic": None,
             "achieved_rule": "%d B x %d codes x %d queries / wall time of the region (whole query path: pre-scan, selects, head, bound "
-                             "levels, ordering, host replay; three queries in flight)" % (cs, N, nsingle),
+                             "levels, ordering, host replay; %d queries in flight)" % (cs, N, nsingle, depth1),
             "ms_per_query_wall": sdt * 1e3 / nsingle, "codes_per_sec_wall": float(N) * nsingle / sdt,
             "streaming_launches": {"kernel": "scan_i8_kernel<%d,2> over the bound levels past the head" % M, "launches": sprof["scan_launches"],
                                    "avg_launch_ms": sprof["scan_ms"] / max(sprof["scan_launches"], 1), "GBps_inside_the_launches": kern_gbs,
