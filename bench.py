@@ -25,9 +25,15 @@ ONE JSON line, several legs (SURVEY.md §8d keeps the two scan modes apart):
 * `ivf`: BASELINE configs[2] shape (100M codes in K=4096 labelled-free synthetic partitions, nprobe 32,
   1024-query pipelined batches through the device-side feeders).
 * `ivf_c5_one_gpu`: the same leg at BASELINE configs[4]'s shape on one GPU (1B x 32x4 codes, K=16384, 96-d, nprobe 64).
+* `c2` / `roofline_c2`: BASELINE configs[1] (flat 10M x 16x4), both modes: 32-query steps and one query per pass.
 * `latency_us_single_query`: synchronous single query on a 10^5-code list (README.md:327-330: 86 us).
+* `recall_at_100_real_encode` (flat, 10M) / `recall_at_100_real_encode_ivf` (K = 4096, nprobe 32): recall on REAL encodings against the
+  exact float L2 nearest neighbour, with `reference_heaps_equal` (the reference's scan_avx_4 on the same codes and int8 tables).
 * `cpu_baseline`: the reference's own scan_avx_4<16> (oracle/_ref), 1 thread; `cpu_baseline_all_cores`:
-  the same kernel on every physical core (C++ threads inside oracle/_ref, pinned, per-thread copies).
+  the same kernel on every physical core (C++ threads inside oracle/_ref, pinned, per-thread copies);
+  `cpu_baseline_32x4`: scan_avx_4<32> on the 32x4 list; `cpu_baseline_ivf` / `cpu_baseline_ivf_c5`: the reference's
+  scan over the probed partitions of the IVF legs' own first 32 queries with the device's int8 tables (1 thread each).
+* `value_one_query_per_pass` (top level): the north-star figure — one query per pass over the 1B list — next to `value`.
 
 With --gpus N and no WORLD_SIZE in the environment the script launches its own N ranks
 (torch.distributed.run, one per GPU, RCCL) BEFORE touching the GPU and relays rank 0's line; under
@@ -560,6 +566,8 @@ def c2_leg(local_rank):
     idx = pyqadc.Index(M, local_rank)
     idx.add_partition_synthetic(N, SEED + 2)
     idx.finalize(KEEP)
+    for kv in filter(None, os.environ.get("QADC_BENCH_C2_OPTS", "").split(",")):   # tuning experiments only
+        idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     rng = np.random.default_rng(4321)
     cb = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
     pool = [make_tables(rng, cb, NQ) for _ in range(4)]

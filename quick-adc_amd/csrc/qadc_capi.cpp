@@ -162,6 +162,9 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
     }
     size_t nitems = 0;
     for (auto& v : per_level) nitems += v.size();
+    uint64_t db_bytes_plan = 0;
+    for (auto& p : idx->parts) db_bytes_plan += (uint64_t)p.n * cs;
+    const bool db_small = db_bytes_plan <= (200ull << 20);
     std::vector<ScanItem>& all_items = plan.all_items;
     all_items.assign(nitems, ScanItem());
     s.launches.clear();
@@ -195,6 +198,10 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
             ll.early = false;
             ll.shared = !ll.small && same && cnt >= 2 && idx->share_variant != 0;
             ll.mq = ll.shared && idx->mq;
+            // (option "mq_single": a lone long run — one query over a list — through the multi-query kernel's 4-seat form with one
+            // seat taken instead of scan_i8_kernel: 256-thread workgroups with 4 KiB of tables instead of 1024-thread ones that each
+            // build a 64 KiB image; 1 = only for lists that fit the Infinity Cache, 2 = always)
+            if (!ll.small && cnt == 1 && idx->mq && idx->mq_single && (idx->mq_single >= 2 || db_small)) ll.mq = true;
             if (ll.mq) {
                 // 8 queries per pass (scan_i8_mq_kernel): 256-thread workgroups, ~64 Ki codes each, groups of 8
                 // queries as L2-sharing siblings
@@ -446,7 +453,8 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                                  s.cap_q, (uint32_t)s.R, str);
         else if (ll.mq)
             launch_scan_i8_mq(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q,
-                              (uint32_t)s.R, str, /*narrow=*/0);   // (the 8-seat build: see scan_i8_mq_kernel)
+                              (uint32_t)s.R, str, /*narrow=*/ll.nitems <= 4 ? idx->group.mq_narrow : 0);   // (8 queries per pass: the 8-seat
+                                                                   // build, see scan_i8_mq_kernel; <= 4 runs: the build with the 4-seat body)
         else
             launch_scan_i8(M, ll.shared ? idx->share_variant : (variant & ~64), s.d_items + ll.first, ll.nitems, ll.wgs,
                            s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q, (uint32_t)s.R, str);
@@ -1472,6 +1480,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "front_dist") idx->front_dist = value != 0;
     else if (n == "share_variant") idx->share_variant = (int)value;
     else if (n == "mq") idx->mq = value != 0;
+    else if (n == "mq_single") idx->mq_single = (int)std::max(0.0, std::min(value, 2.0));
     else if (n == "prescan_mq") idx->prescan_mq = value != 0;
     else if (n == "front_run_max") idx->front_run_max = (uint64_t)std::max(value, 0.0);
     else if (n == "device_replay_nq") idx->device_replay_nq = (int)std::max(value, 0.0);

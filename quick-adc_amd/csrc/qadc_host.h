@@ -372,6 +372,7 @@ struct qadc_index {
     int share_variant = 0x41;            // streaming-kernel variant for shared launches: sibling-major, U=2, cached loads
     uint32_t share_codes_per_wg = 1u << 20;
     int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
+    int mq_single = 0;                   // a lone long run takes that kernel's 4-seat form too (option "mq_single": 1 cached lists, 2 always)
     int device_replay_nq = 64;           // batches of at least this many queries replay their streams on the device (0 = never)
     int device_replay_alone_nq = 512;    // ... a batch with nothing else in flight (a synchronous call): from this many
     uint64_t front_run_max = 2u << 20;   // leading levels whose runs are at most this long join the front (0 = none); they are

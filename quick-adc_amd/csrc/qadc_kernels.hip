@@ -76,22 +76,31 @@ __device__ __forceinline__ void build_pair_tables(const int8_t* __restrict__ qt)
     if (t < M * 4) reinterpret_cast<uint32_t*>(smem + C::STAGE_OFF)[t] = reinterpret_cast<const uint32_t*>(qt)[t];
     __syncthreads();
     const unsigned char* T = smem + C::STAGE_OFF;
-    constexpr int PAIRS = (M / 8) * 256;                 // (group, x) pairs
-    constexpr int TPP = kWG / PAIRS;                     // threads per pair (M=16: 2, M=32: 1)
-    constexpr int REPL = 32 / TPP;                       // bank replicas written per thread
-    const int p = t / TPP, part = t % TPP;
-    const int g = p >> 8, x = p & 255;
+    // The image is written in ADDRESS order: thread t stores the 16-byte units t, t + kWG, ...; a wave's ds_write_b128 covers
+    // 1 KiB contiguous — every bank once.  (Until round 4 a thread wrote the 128-byte row of one (dword g, byte x) pair by
+    // itself: the rows of a wave's lanes lie 256 bytes apart, i.e. in the SAME banks — a 32-way conflict on every store,
+    // ~4 K LDS cycles per 64 KiB image instead of ~256.)  A wave's units of iteration k belong to 8 (g, x) pairs, 8 lanes each;
+    // lane l computes pair l's dword once and ds_bpermute hands it to the lanes that replicate it.
+    constexpr int kIter = C::TABLE_BYTES / 16 / kWG;     // 16x4: 4, 32x4: 8 units per thread
+    const uint32_t lane = (uint32_t)t & 63u, wave = (uint32_t)t >> 6;
     uint32_t w = 0;
+    {
+        const uint32_t pi = lane & (8u * kIter - 1u);    // (16x4: lanes 32..63 repeat 0..31)
+        const uint32_t k = pi >> 3, within = pi & 7u;
+        const uint32_t x = (k & 3u) * 64u + wave * 4u + (within >> 1);
+        const uint32_t g = (k >> 2) * 2u + (within & 1u);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int b = 4 * g + j;
-        const uint32_t v = (uint32_t)T[(2 * b) * 16 + (x & 15)] + (uint32_t)T[(2 * b + 1) * 16 + (x >> 4)];
-        w |= v << (8 * j);
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t b = 4u * g + j;
+            const uint32_t v = (uint32_t)T[(2 * b) * 16 + (x & 15u)] + (uint32_t)T[(2 * b + 1) * 16 + (x >> 4)];
+            w |= v << (8 * j);
+        }
     }
-    unsigned char* dst = smem + (g >> 1) * 65536 + x * 256 + (g & 1) * 128 + part * (REPL * 4);
-    const uint4 w4 = make_uint4(w, w, w, w);
 #pragma unroll
-    for (int r = 0; r < REPL / 4; ++r) reinterpret_cast<uint4*>(dst)[r] = w4;
+    for (int k = 0; k < kIter; ++k) {
+        const uint32_t wk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((k * 8u + (lane >> 3)) * 4u), (int)w);
+        *reinterpret_cast<uint4*>(smem + ((size_t)k * kWG + t) * 16) = make_uint4(wk, wk, wk, wk);
+    }
 }
 
 // inclusive wave scan on the DPP path (row shifts + row broadcasts, 7 VALU operations) — __shfl_up goes through the LDS
@@ -338,6 +347,9 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
 //
 // Exactness is untouched: the same integer sums, the same prefix bound per query, the same candidates.
 // ---------------------------------------------------------------------------------------------
+#ifndef QADC_MQ_PIPE
+#define QADC_MQ_PIPE 1             // (build-time A/B: software-pipelined loads in the IVF second phase's build of the kernel)
+#endif
 constexpr int kMQ = 8;          // queries per pass
 constexpr int kMQWG = 256;      // threads per workgroup
 
@@ -382,7 +394,7 @@ template <> struct MqRow<4> { typedef u64x1 type; };          // 4 queries:  8-b
 // One group's pass with NQ = 8 or 4 query seats.  A group whose live seats fit 4 (the remainder groups of the IVF second
 // phase: seats are filled from 0 upward) takes the 4-seat form: the same lookups return 8 bytes instead of 16, i.e. 4 LDS
 // cycles per (64 codes, nibble pair) instead of 8, and half the adds.
-template <int M, int U, int NQ>
+template <int M, int U, int NQ, bool PIPE>
 __device__ __forceinline__ void scan_mq_body(const ScanItem* __restrict__ its, const ScanItem& it, int nq, uint32_t bx, uint32_t G,
                                              const int8_t* __restrict__ qtables, QueryState* __restrict__ qstates,
                                              CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap, uint32_t R) {
@@ -516,7 +528,69 @@ __device__ __forceinline__ void scan_mq_body(const ScanItem* __restrict__ its, c
     using part_t = std::integral_constant<bool, false>;
     const uint32_t tiles_full = (n / CPL) / kMQWG;           // tiles whose every lane holds CPL complete codes
     uint32_t t0 = bx;
-    for (; t0 + (U - 1) * G < tiles_full; t0 += G * U) run(t0, full_t());
+    if constexpr (PIPE) {
+        // software pipeline over the full tiles (the IVF second phase: runs of a few 10^4 codes that come from HBM, one or two
+        // groups per partition): the next iteration's loads are issued before the current tiles are looked up, so a wave
+        // keeps loads in flight while it works the LDS pipe.  Without it a wave holds 2 KB in flight for ~3 us and then
+        // nothing while it computes: 28 waves x 2 KB per CU bound the launch below the LDS roof (C3 shape: 2.9 TB/s of reads)
+        auto consume = [&](const u32x4_t (&v)[U], uint32_t tt) {
+            row_t sums[U * CPL];
+            uint64_t all[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) all[w] = kTop;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const row_t a = code_sums(d + c * DW);
+                    sums[u * CPL + c] = a;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) all[w] &= a[w] + bias[w];
+                }
+            }
+            uint64_t allw = all[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) allw &= all[w];
+            if (__builtin_expect((allw & kTop) != kTop, 0)) {        // rare
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) {
+                            const uint32_t sj = (uint32_t)(sums[u * CPL + c][j >> 2] >> (16 * (j & 3))) & 0xffffu;
+                            if (sj < bq[j]) {
+                                const ScanItem* ij = its + j;
+                                emit_candidate(qstates + ij->query, hdr, out + (uint64_t)ij->query * cand_cap, cand_cap,
+                                               it.labels, it.key_base, ij->order, it.dup_pos, it.dup_reps,
+                                               it.pos0 + ((tt + u * G) * kMQWG + tid) * CPL + c, sj);
+                            }
+                        }
+            }
+        };
+        if (t0 + (U - 1) * G < tiles_full) {
+            u32x4_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = src[(t0 + u * G) * kMQWG + tid];
+            for (;;) {
+                const uint32_t tn = t0 + G * U;
+                const bool more_full = tn + (U - 1) * G < tiles_full;
+                u32x4_t nv[U];
+                if (more_full) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) nv[u] = src[(tn + u * G) * kMQWG + tid];
+                }
+                consume(v, t0);
+                t0 = tn;
+                if (!more_full) break;
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = nv[u];
+            }
+        }
+    } else {
+        for (; t0 + (U - 1) * G < tiles_full; t0 += G * U) run(t0, full_t());
+    }
     for (; t0 < ntiles; t0 += G * U) run(t0, part_t());
 }
 
@@ -552,11 +626,11 @@ __device__ __forceinline__ void scan_mq_kernel_body(const ScanItem* __restrict__
         bool upper = false;
         for (int j = 4; j < nq; ++j) upper = upper || its[j].n != 0;
         if (!upper) {
-            scan_mq_body<M, U, 4>(its, it, min(nq, 4), bx, G, qtables, qstates, hdr, out, cand_cap, R);
+            scan_mq_body<M, U, 4, QADC_MQ_PIPE != 0>(its, it, min(nq, 4), bx, G, qtables, qstates, hdr, out, cand_cap, R);
             return;
         }
     }
-    scan_mq_body<M, U, 8>(its, it, nq, bx, G, qtables, qstates, hdr, out, cand_cap, R);
+    scan_mq_body<M, U, 8, NARROW && QADC_MQ_PIPE != 0>(its, it, nq, bx, G, qtables, qstates, hdr, out, cand_cap, R);
 }
 
 template <int M, int U>
