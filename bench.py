@@ -506,6 +506,14 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
     idx.set_option("profile", 1)
     dtp, _ = pipelined(qs, 16, depth, warm=False)
     pp = idx.profile()
+    # ... and the same launches ALONE on the GPU (one batch at a time: nothing of another batch runs beside them) — the kernel's
+    # own duration, what `rocprofv3 --pmc` passes (which serialise kernels) see; the pipelined figures above include whatever
+    # the neighbouring batches' fronts, orderings and replays take from the launch
+    pa = None
+    if pp["group_batches"] and shard is None:
+        idx.profile_reset()
+        pipelined(qs, 8, 1, warm=False)
+        pa = idx.profile()
     idx.set_option("profile", 0)
     idx.close()
     roof = None
@@ -528,6 +536,13 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
                          "algorithmic_bytes_per_launch": pp["group_head_codes"] * (M // 2) / nb,
                          "note": "bytes = M/2 x codes of the head probes only; the launch also pre-scans the starts of all probes and "
                                  "quantizes their tables, so frac understates the walk"},
+                "launches_alone_on_the_gpu": None if not (pa and pa["group_batches"]) else {
+                    "what": "the same three launches with ONE batch in flight (8 batches): each kernel by itself, as a PMC pass sees it",
+                    "head_ms": pa["group_head_ms"] / pa["group_batches"], "grouped_scan_ms": pa["group_scan_ms"] / pa["group_batches"],
+                    "order_ms": pa["group_order_ms"] / pa["group_batches"],
+                    "head_frac_of_hbm": pa["group_head_codes"] * (M // 2) / (pa["group_head_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "grouped_scan_frac_of_lds": (pa["group_pass_codes8"] * M * 4 + pa["group_pass_codes4"] * M * 2) / 64.0
+                    / (pa["group_scan_ms"] * 1e-3) / 1e9 / LDS_PEAK_GCYC},
                 "order_cands_avg_launch_ms": pp["group_order_ms"] / nb,
                 "timed_region": "%d profiled batches after the timed loops (HIP events on the library's stream around each launch); "
                                 "wall %.3f ms per batch in that pass" % (nb, dtp * 1e3 / 16)}

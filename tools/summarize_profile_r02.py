@@ -22,7 +22,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-P = os.path.join(ROOT, "profiles")
+P = os.environ.get("QADC_PROFILES_OUT", os.path.join(ROOT, "profiles"))
 os.makedirs(P, exist_ok=True)
 
 

@@ -20,8 +20,10 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, P, TAG = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles"), (sys.argv[1] if len(sys.argv) > 1 else "r04")
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_profile_r02.py"), TAG], stdout=subprocess.DEVNULL)
+G, TAG = os.path.join(ROOT, "gpurun_out"), (sys.argv[1] if len(sys.argv) > 1 else "r04")
+P = os.environ.get("QADC_PROFILES_OUT", os.path.join(ROOT, "profiles"))   # (on the GPU box: a small directory under gpurun_out/ that travels back)
+os.makedirs(P, exist_ok=True)
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_profile_r02.py"), TAG], stdout=subprocess.DEVNULL, env=dict(os.environ))
 
 
 def one(pattern):
