@@ -420,19 +420,16 @@ def ref_try_load(filename):
 
 
 def ref_read_chunked(filename, chunk_count, max_vectors, max_dim):
-    """The reference's vectors_reader driven like db_add.cpp:52-82 -> (data [count][dim], [(offset, count), ...])."""
-    for _ in range(20):
-        out = np.zeros(max_vectors * max_dim, np.float32)
-        offs, cnts = np.zeros(4096, np.uint32), np.zeros(4096, np.uint32)
-        nch, dim, total = C.c_int(0), C.c_int(0), C.c_uint(0)
-        rc = ref_io().qadc_ref_io_read_chunked(filename.encode(), C.c_uint(chunk_count), _p(out, f32p), C.c_long(out.size),
-                                               _p(offs, u32p), _p(cnts, u32p), 4096, C.byref(nch), C.byref(dim), C.byref(total))
-        if rc == 2:          # the reference's own done() window (see the harness): the loop ended a chunk early; again
-            continue
-        assert rc == 0, rc
-        return (out[:total.value * dim.value].reshape(total.value, dim.value).copy(),
-                [(int(offs[i]), int(cnts[i])) for i in range(nch.value)])
-    raise AssertionError("the reference's chunked reader kept ending early")
+    """The reference's vectors_reader driven like db_add.cpp:52-82 -> (data [count][dim], [(offset, count), ...]).  (The harness
+    also collects what the reference's own loop leaves in the queue when its done() fires early: see ref_io_harness.cpp.)"""
+    out = np.zeros(max_vectors * max_dim, np.float32)
+    offs, cnts = np.zeros(4096, np.uint32), np.zeros(4096, np.uint32)
+    nch, dim, total, early = C.c_int(0), C.c_int(0), C.c_uint(0), C.c_int(0)
+    rc = ref_io().qadc_ref_io_read_chunked(filename.encode(), C.c_uint(chunk_count), _p(out, f32p), C.c_long(out.size),
+                                           _p(offs, u32p), _p(cnts, u32p), 4096, C.byref(nch), C.byref(dim), C.byref(total), C.byref(early))
+    assert rc == 0, rc
+    return (out[:total.value * dim.value].reshape(total.value, dim.value).copy(),
+            [(int(offs[i]), int(cnts[i])) for i in range(nch.value)])
 
 
 def ref_check_labels(gt_filename, keys, t):

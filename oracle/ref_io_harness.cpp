@@ -103,11 +103,14 @@ int qadc_ref_io_try_load(const char* filename, char* err, int err_cap) {
 // The chunked reader the way db_add.cpp:52-82 drives it: vectors_reader_by_extension (vector_io.cpp:60-91), run() on a
 // thread of its own, `while (!reader->done()) chunk = reader->get_chunk()`.  chunk_count replaces the constructor's
 // default of 1 000 000 (the factory passes none; the member is public).  out: all vectors in arrival order; offsets /
-// counts: per chunk.  Returns 0, or 2 if the loop ended before every vector arrived — the reference publishes its read
-// count before the push (vector_io.hpp:256-258), so done() can be seen true with the last chunk still outside the queue;
-// the caller repeats.
+// counts: per chunk.
+// The reference publishes its read count BEFORE the push (vector_io.hpp:256-258), so its done() can be seen true with the
+// last chunk still on its way into the queue and the loop above then ends a chunk early — under CPU load, with small
+// chunks, almost always.  What is pinned here is the READER (which chunks it cuts, what they hold), not that window: after
+// the loop the harness joins the reader thread and takes what is still in the (public) queue, in order; *early_exit says
+// whether the reference's own loop had ended early.
 int qadc_ref_io_read_chunked(const char* filename, unsigned chunk_count, float* out, long out_cap, unsigned* offsets,
-                             unsigned* counts, int max_chunks, int* nchunks, int* dim, unsigned* total) {
+                             unsigned* counts, int max_chunks, int* nchunks, int* dim, unsigned* total, int* early_exit) {
     std::unique_ptr<vectors_reader> reader = vectors_reader_by_extension(filename);
     reader->wanted_chunk_count_ = chunk_count;
     vectors_reader* rp = reader.get();
@@ -117,8 +120,7 @@ int qadc_ref_io_read_chunked(const char* filename, unsigned chunk_count, float* 
     long got = 0;
     int nc = 0;
     int rc = 0;
-    while (!reader->done()) {
-        vectors_chunk<float> chunk = reader->get_chunk();
+    auto take = [&](vectors_chunk<float>& chunk) {
         if (nc < max_chunks) {
             offsets[nc] = chunk.offset;
             counts[nc] = chunk.count;
@@ -128,8 +130,18 @@ int qadc_ref_io_read_chunked(const char* filename, unsigned chunk_count, float* 
         if (got + n <= out_cap) std::memcpy(out + got, chunk.data.get(), sizeof(float) * (size_t)n);
         else rc = -1;
         got += n;
+    };
+    while (!reader->done()) {
+        vectors_chunk<float> chunk = reader->get_chunk();
+        take(chunk);
     }
     th.join();
+    *early_exit = 0;
+    while (!reader->queue_.empty()) {                            // (the reader has exited: nothing is pushed any more)
+        vectors_chunk<float> chunk = reader->get_chunk();
+        take(chunk);
+        *early_exit = 1;
+    }
     *nchunks = nc;
     if (rc == 0 && got != (long)reader->count() * reader->dim()) rc = 2;
     return rc;
