@@ -74,10 +74,18 @@ __device__ __forceinline__ void q_lds_barrier() {
 // one dword = the four tables of a code dword, replicated over the 32 banks of a ds_read lane group; a lane reads
 // with bank = lane & 31.  64 KiB (16x4: two workgroups per CU) / 128 KiB (32x4: one).  The tables start at LDS
 // address 0 (absolute addressing spares an add per lookup) and OVERLAY the pre-scan's buffers, which are dead by then.
+// 32x4 (QADC_Q32_REPL16, round 4): the same image with SIXTEEN replicas — row x (256 B) = [dword 0: 16 replicas][dword 1]
+// [dword 2][dword 3], address x*256 + g*64 + (lane & 15)*4 + j — is 64 KiB instead of 128, so TWO workgroups share a CU
+// (32 waves instead of 16 to hide the walk's latencies behind) at the price of a 2-way bank conflict on every lookup
+// (lanes l and l + 16 of a 32-lane group share a replica): the walk is latency / issue bound, the LDS pipe 30 % busy.
+#ifndef QADC_Q32_REPL16
+#define QADC_Q32_REPL16 1
+#endif
 template <int M>
 struct QCfg {
     static constexpr int CS = M / 2, DW = M / 8, CPL = 16 / CS;
-    static constexpr int TABLE_BYTES = (M / 16) * 65536;
+    static constexpr bool R16 = M == 32 && QADC_Q32_REPL16 != 0;  // 16 replicas per dword, all four dwords in one 64 KiB region
+    static constexpr int TABLE_BYTES = R16 ? 65536 : (M / 16) * 65536;
     static constexpr int WTAB_BYTES = kQWaves * M * 16 * 4;      // float[16 waves][M*16] (pre-scan)
     static constexpr int FCAP = (TABLE_BYTES - WTAB_BYTES) / 4;  // pre-scan values kept in LDS: 12288 / 24576
     static constexpr int VALS_OFF = 0;                           // float[FCAP]        } pre-scan phase
@@ -86,7 +94,7 @@ struct QCfg {
     static constexpr int MISC_OFF = TABLE_BYTES + 512;
     // misc (u32 words): [0..255] radix histogram / [0..127] value histogram, then scalars
     static constexpr int LDS_BYTES = MISC_OFF + (256 + 64 + 64) * 4;
-    static constexpr int OCC = M == 16 ? 8 : 4;                  // waves per SIMD the register budget is sized for
+    static constexpr int OCC = (M == 16 || R16) ? 8 : 4;         // waves per SIMD the register budget is sized for
 };
 
 typedef const __attribute__((address_space(3))) unsigned char* q_lds_bytes_t;
@@ -98,9 +106,10 @@ __device__ __forceinline__ uint32_t q_pair_sum(const uint32_t* d, uint32_t lane_
     // all M/2 addresses first, then all M/2 reads, then the adds: the reads of a code (and, unrolled, of the codes
     // around it) are in flight together instead of waiting out one LDS latency per pair
     uint32_t a[M / 2], v[M / 2];
+    constexpr bool R16 = QCfg<M>::R16;                           // (then lane_lo = (lane & 15) * 4 and every dword lives in region 0)
 #pragma unroll
     for (int w = 0; w < M / 8; ++w) {
-        const uint32_t lo = (w >> 1) ? lane_hi : lane_lo;
+        const uint32_t lo = (!R16 && (w >> 1)) ? lane_hi : lane_lo;
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[w * 4 + k] = __builtin_amdgcn_perm(d[w], lo, 0x0c020000u | ((4u + k) << 8));
     }
@@ -108,7 +117,7 @@ __device__ __forceinline__ uint32_t q_pair_sum(const uint32_t* d, uint32_t lane_
     for (int w = 0; w < M / 8; ++w)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            v[w * 4 + k] = *reinterpret_cast<q_lds_bytes_t>(static_cast<uintptr_t>(a[w * 4 + k] + (w & 1) * 128 + k));
+            v[w * 4 + k] = *reinterpret_cast<q_lds_bytes_t>(static_cast<uintptr_t>(a[w * 4 + k] + (R16 ? w * 64 : (w & 1) * 128) + k));
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < M / 2; ++i) s += v[i];
@@ -751,13 +760,21 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         // 15 % bank-conflict cycles the PMC pass of round 3 charged to this kernel.)
         // A wave's units of iteration k belong to 8 (g, x) pairs, 8 lanes each; over all iterations the wave needs
         // 8 * kIter pairs.  Lane l computes pair l's dword once; ds_bpermute hands it to the lanes that replicate it.
-        constexpr int kIter = C::TABLE_BYTES / 16 / kQWG;        // 16x4: 4, 32x4: 8 units per thread
+        constexpr int kIter = C::TABLE_BYTES / 16 / kQWG;        // 16x4: 4, 32x4: 8 (4 with 16 replicas) units per thread
+        constexpr int kLPP = C::R16 ? 4 : 8;                     // lanes (16-byte units) per pair's row piece
+        constexpr int kPPI = 64 / kLPP;                          // pairs per wave and iteration
         uint32_t w = 0;
         {
-            const uint32_t pi = lane & (8u * kIter - 1u);        // (16x4: lanes 32..63 repeat 0..31)
-            const uint32_t k = pi >> 3, within = pi & 7u;
-            const uint32_t x = (k & 3u) * 64u + wave * 4u + (within >> 1);
-            const uint32_t g = (k >> 2) * 2u + (within & 1u);
+            const uint32_t pi = lane & (uint32_t)(kPPI * kIter - 1);   // (16x4: lanes 32..63 repeat 0..31)
+            const uint32_t k = pi / kPPI, within = pi % kPPI;
+            uint32_t x, g;
+            if (C::R16) {                                        // a wave-iteration = 1 KiB = rows x .. x+3, each [g0][g1][g2][g3]
+                x = k * 64u + wave * 4u + (within >> 2);
+                g = within & 3u;
+            } else {
+                x = (k & 3u) * 64u + wave * 4u + (within >> 1);
+                g = (k >> 2) * 2u + (within & 1u);
+            }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const uint32_t b = 4u * g + jj;
@@ -766,11 +783,11 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         }
 #pragma unroll
         for (int k = 0; k < kIter; ++k) {
-            const uint32_t wk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((k * 8u + (lane >> 3)) * 4u), (int)w);
+            const uint32_t wk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((k * kPPI + (lane / kLPP)) * 4u), (int)w);
             *reinterpret_cast<uint4*>(qsmem + ((size_t)k * kQWG + tid) * 16) = make_uint4(wk, wk, wk, wk);
         }
     };
-    const uint32_t lane_lo = (tid & 31u) * 4u, lane_hi = lane_lo | 0x10000u;
+    const uint32_t lane_lo = C::R16 ? (tid & 15u) * 4u : (tid & 31u) * 4u, lane_hi = lane_lo | 0x10000u;
     if (tid < 256) misc[tid] = 0;                                // both histograms
     if (tid == 0) { s_ccount = 0; s_hreps = 0; }
     // ---- how the query's scan order is shared by the G workgroups of the query (G = 1: everything is "mine") ----
@@ -1140,6 +1157,15 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
             qs->qmin = qmin;
             qs->qmax = qmax;
             qs->flags = flags & 3u;
+#ifdef QADC_STAMPS
+            if (blockIdx.x == 1) {
+                const uint64_t clk2s = __builtin_readcyclecounter();
+                printf("HEAD STAMPS: prologue %llu starts-known %llu prescan %llu qmin %llu select %llu quantize %llu walk %llu\n",
+                       (unsigned long long)(stamps[1] - clk0), (unsigned long long)(stamps[2] - stamps[1]), (unsigned long long)(stamps[3] - stamps[2]),
+                       (unsigned long long)(stamps[4] - stamps[3]), (unsigned long long)(stamps[5] - stamps[4]), (unsigned long long)(clk1 - stamps[5]),
+                       (unsigned long long)(clk2s - clk1));
+            }
+#endif
             if (A.head_slots) {                                  // the IVF head: phase clocks for the profile (order_cands_kernel forwards
                 const uint64_t clk2 = __builtin_readcyclecounter();   // them; the select fields are idle on this path)
                 qs->sel_prefix = (uint32_t)min((clk1 - clk0) >> 6, (uint64_t)0xffff);
