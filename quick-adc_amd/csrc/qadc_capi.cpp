@@ -1216,6 +1216,7 @@ int qadc_index_destroy(qadc_index* idx) {
         if (s.ev_assign) (void)hipEventDestroy(s.ev_assign);
         s.d_queries.release(); s.d_assign.release(); s.d_cdist.release(); s.h_queries.release(); s.h_assign.release();
         if (s.ev_feed) (void)hipEventDestroy(s.ev_feed);
+        if (s.ev_pre) (void)hipEventDestroy(s.ev_pre);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         if (s.ev_up) (void)hipEventDestroy(s.ev_up);
         if (s.ev_front) (void)hipEventDestroy(s.ev_front);
@@ -1496,6 +1497,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
     else if (n == "wgq") idx->wgq = (int)value;
     else if (n == "wgq_variant") idx->wgq_variant = (int)value;
+    else if (n == "plan_early") idx->plan_early = value != 0;
     else if (n == "wgq_ramp_shift") idx->wgq_ramp_shift = (int)std::max(0.0, std::min(value, 4.0));
     else if (n == "wgq_stream") idx->wgq_stream_on = value != 0;
     else if (n == "dist_cap_entries") {                       // entries per rank block of the native gather (test knob)

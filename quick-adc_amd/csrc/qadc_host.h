@@ -215,6 +215,7 @@ struct Slot {
     PinBuf<float> h_queries;
     PinBuf<int32_t> h_assign;
     hipEvent_t ev_feed = nullptr;
+    hipEvent_t ev_pre = nullptr;        // tables + state clear + partition-major plan done (enqueued off the scan stream: launch_wgq_batch)
 
     std::vector<LevelLaunch> launches;
     uint64_t start_codes = 0;
@@ -411,6 +412,7 @@ struct qadc_index {
     int head_level = 5;                  // level path: bound levels 0..head_level-1 (the first 512 Ki codes of every query) are
                                          // scanned by ONE launch of the query kernel in head mode instead of head_level dependent
                                          // level launches (0 = off): -5 % per step on a 125M-code shard, neutral at 1B
+    int plan_early = 1;                  // pipelined query-kernel batches: tables, state clear and plan off the scan stream (option "plan_early")
     int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
     int wgq_ramp_shift = 0;              // ramp epochs of the query kernel's walk grow by 2^shift (0 = default, doubling)
     uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)

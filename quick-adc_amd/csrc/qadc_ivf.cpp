@@ -149,6 +149,16 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         }
     }
     s.prof_used = 0;
+    // What a pipelined batch needs BEFORE its first scan launch but from nobody on the scan stream — the float tables (built
+    // from assign[], which the copy stream's coarse kernels produce), the state clear, the partition-major plan (count /
+    // offsets / scatter over assign[]) — is enqueued on the stream that produces assign[]: the copy stream, or the
+    // collectives' stream behind the unpack of a sharded front.  On the scan stream those ~6 short launches cost it ~0.1 ms
+    // per batch (C3 shape: a seventh of the batch) between the previous batch's ordering pass and this batch's head.
+    // (Round 3 tried the front stream for this and lost: it shared a pipe with the scan stream then, and carries every other
+    // replay — DESIGN.md section 5.)  option "plan_early"; a lone batch and a re-run keep everything on one stream.
+    const bool pre = idx->plan_early && !alone && !s.rerun;
+    hipStream_t pre_st = pre ? idx->copy_stream : st;
+    bool pre_used = false, flush_later = false;
     QueryKernelArgs A{};
     A.parts = idx->d_partdesc.p;
     A.assign = s.assign_on_device ? s.d_assign.p : reinterpret_cast<const int32_t*>(s.d_in.p);
@@ -160,9 +170,10 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     } else if (s.float_path) {
         if (s.device_tables) {
             HIPCHECK(s.d_ftables.ensure(nt));
-            HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
+            HIPCHECK(hipStreamWaitEvent(pre_st, s.ev_feed, 0));
             launch_build_tables(s.d_queries.p, idx->feed.K ? idx->feed.d_coarse.p : nullptr, s.d_assign.p, idx->feed.d_codebooks.p,
-                                idx->feed.has_rotation ? idx->feed.d_rotation.p : nullptr, nq, ma, M, idx->feed.dim, table_expansion(idx, ma), s.d_ftables.p, st);
+                                idx->feed.has_rotation ? idx->feed.d_rotation.p : nullptr, nq, ma, M, idx->feed.dim, table_expansion(idx, ma), s.d_ftables.p, pre_st);
+            pre_used = pre_st != st;
             A.ftables = s.d_ftables.p;
         } else {
             A.ftables = reinterpret_cast<float*>(s.d_in.p + off_tables);
@@ -218,7 +229,8 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
                                          reinterpret_cast<uint32_t*>(s.d_fmap + (size_t)nq * ma * 4), d.stream));
             HIPCHECK(hipEventRecord(s.ev_fb, d.stream));
             HIPCHECK(hipStreamWaitEvent(st, s.ev_fb, 0));
-            if (int rc = flush_merges(idx, ~0ull)) return rc;   // the older batches' merges: behind this front gather
+            if (pre) pre_st = d.stream;                          // (the plan follows the unpack on the collectives' stream)
+            flush_later = true;                                  // the older batches' merges: behind this front gather (and this plan)
         }
         A.assign = s.d_assign.p;
         A.ftables = nullptr;                                     // from here on: an int8 batch
@@ -275,7 +287,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         HIPCHECK(s.d_cands.ensure((size_t)nq * gcap));
         s.d_hdr = reinterpret_cast<CandHeader*>(s.d_state.p);
         s.d_qs = reinterpret_cast<QueryState*>(s.d_state.p + 64);
-        HIPCHECK(hipMemsetAsync(s.d_state.p, 0, gitems_off + gitems_bytes, st));
+        HIPCHECK(hipMemsetAsync(s.d_state.p, 0, gitems_off + gitems_bytes, pre_st));
         // (tried: the plan — two clears + count / offsets / scatter, needed by the second phase only — on a stream of its own
         // under the head launch: its workgroups then wait for head workgroups to retire and the second phase for them;
         // C3 0.75 -> 1.05 us per query, one of 8 ranks 0.72 -> 1.51 ms per batch.  Tried as well: table build, clears and
@@ -283,7 +295,18 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         // stream per batch to win, but the dozen small launches trickle through that scan so slowly that the next head
         // ends up waiting for them: C3 0.75 -> 0.91 us per query, C5 4.63 -> 4.82.)
         launch_ivf_plan(A.assign, idx->d_partdesc.p, nq, ma, head_slots, (int)nparts, d_gplan, d_gplan + 2 * nparts,
-                        d_gplan + nparts, d_gitems, st);
+                        d_gplan + nparts, d_gitems, pre_st);
+        pre_used = pre_used || pre_st != st;
+        if (pre_used) {
+            if (!s.ev_pre) HIPCHECK(hipEventCreateWithFlags(&s.ev_pre, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(s.ev_pre, pre_st));
+            HIPCHECK(hipStreamWaitEvent(st, s.ev_pre, 0));
+            pre_used = false;
+        }
+        if (flush_later) {
+            if (int rc = flush_merges(idx, ~0ull)) return rc;
+            flush_later = false;
+        }
         QueryKernelArgs H = A;
         H.head_codes = ~0ull;
         H.head_slots = (uint32_t)head_slots;
@@ -305,6 +328,13 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         s.group_head_slots = head_slots;
         idx->prof.group_launches++;
     } else {
+        if (pre_used) {                                          // (tables built on the copy stream, no plan)
+            if (!s.ev_pre) HIPCHECK(hipEventCreateWithFlags(&s.ev_pre, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(s.ev_pre, pre_st));
+            HIPCHECK(hipStreamWaitEvent(st, s.ev_pre, 0));
+        }
+        if (flush_later)
+            if (int rc = flush_merges(idx, ~0ull)) return rc;
         HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st, inl_bytes ? inl : nullptr, inl_bytes));
     }
     if (idx->profile) HIPCHECK(prof_event(s, st));
