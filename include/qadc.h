@@ -103,7 +103,13 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * "wgq_group" (large IVF batches: partition-major second phase; 0 never, 1 auto, 2 whenever possible),
  * "wgq_group_head" (probes per query the one-workgroup-per-query head walks before it), "wgq_group_head_dist" (the same under the
  * multi-GPU merge, counted in probes with codes on the rank),
- * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_async", "dist_shard_front", "dist_inject_failure" (test hook). */
+ * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_async", "dist_shard_front", "dist_inject_failure" (test hook),
+ * "plan_early" (pipelined query-kernel batches: float tables, state clear and partition-major plan run on the stream that produces
+ * assign[] instead of the scan stream; default 1), "wgq_stream" (query-kernel batches scan on the normal-priority alternative of the
+ * scan stream; default 0), "wgq_ramp_shift" (the walk's ramp epochs grow by 2^shift; default doubling), "mq_single" (a lone long
+ * run through the multi-query kernel's 4-seat form: 0 never — default —, 1 for lists that fit the Infinity Cache, 2 always).
+ * Streams: the library keeps ONE set of HIP streams per process and device, created by the first index on the device and shared
+ * by every later one. */
 int qadc_set_option(qadc_index* idx, const char* name, double value);
 
 /* Copy codes back (tests / checksums): partition `part`, codes [first, first+count). */
