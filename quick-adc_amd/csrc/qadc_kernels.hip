@@ -1870,16 +1870,22 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float* __restric
         if (d0 + kCDC < dim) fetch(d0 + kCDC);                   // in flight while this tile is consumed
         for (int dd = 0; dd < dcn; ++dd) {
             const float cv = tile[dd * kCDStride + tid];
-            float qv[kCDQ];
+            // two queries per instruction: v_pk_add_f32 (with the negated centroid component in both halves), v_pk_mul_f32,
+            // v_pk_add_f32 — each component is the IEEE result of the scalar operation, the sums stay sequential in d, so
+            // assign[] is unchanged bit for bit; 24 VALU instructions per step instead of 32 (the compiler packed the multiply
+            // and the add by itself, not the subtraction)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 cv2 = {cv, cv};
 #pragma unroll
             for (int b4 = 0; b4 < kCDQ / 4; ++b4) {
                 const float4 t4 = *reinterpret_cast<const float4*>(&qt[dd * kCDQ + 4 * b4]);   // same address in every lane: broadcast
-                qv[4 * b4] = t4.x; qv[4 * b4 + 1] = t4.y; qv[4 * b4 + 2] = t4.z; qv[4 * b4 + 3] = t4.w;
-            }
-#pragma unroll
-            for (int b = 0; b < kCDQ; ++b) {
-                const float t = qv[b] - cv;
-                acc[b] += t * t;
+                const f32x2 q01 = {t4.x, t4.y}, q23 = {t4.z, t4.w};
+                f32x2 t01, t23;                                  // q - cv as q + (-cv): the same IEEE result; (written out: the compiler
+                                                                 // scalarises a packed subtraction of a splat)
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t01) : "v"(q01), "v"(cv2));
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t23) : "v"(q23), "v"(cv2));
+                const f32x2 s01 = t01 * t01, s23 = t23 * t23;
+                acc[4 * b4] += s01.x; acc[4 * b4 + 1] += s01.y; acc[4 * b4 + 2] += s23.x; acc[4 * b4 + 3] += s23.y;
             }
         }
     }
