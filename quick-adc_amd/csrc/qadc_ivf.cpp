@@ -251,6 +251,8 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     A.nontemporal = idx->total_codes * (uint64_t)idx->cs > (200ull << 20);   // (same rule as the level path)
     A.G = G;
     A.ramp_shift = (uint32_t)idx->wgq_ramp_shift;
+    A.pos_bits = (idx->max_part_n ? 64u - (uint32_t)__builtin_clzll((unsigned long long)idx->max_part_n) : 0u) << 16 |
+                 (uint32_t)idx->order_bucket_max;
     if (idx->profile) HIPCHECK(prof_event(s, st));
     s.poll = alone && G > 1 && !s.dev_replay && !idx->profile && idx->wgq_poll;
     if (s.poll)
@@ -323,7 +325,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         launch_scan_i8_mq(M, d_gitems, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, gcap, (uint32_t)s.R, st,
                           idx->group.mq_narrow);
         if (idx->profile) HIPCHECK(prof_event(s, st));
-        HIPCHECK(launch_order_cands(s.d_qs, s.d_cands.p, gcap, gcap, nq, s.d_stream.p, cap, s.d_qout, s.d_qflags.p, st));
+        HIPCHECK(launch_order_cands(s.d_qs, s.d_cands.p, gcap, gcap, nq, s.d_stream.p, cap, s.d_qout, s.d_qflags.p, ma, A.pos_bits, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
         s.group_head_slots = head_slots;
         idx->prof.group_launches++;

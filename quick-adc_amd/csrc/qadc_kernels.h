@@ -143,6 +143,7 @@ struct QueryKernelArgs {
     // {flags & 3, qmin, qmax, 0}; no walk), the shares are all-gathered, and the head launch of the whole batch takes the
     // gathered int8 tables with front_in seeding every query's flags / qmin / qmax.
     uint32_t front_only;
+    uint32_t pos_bits;       // the ordering pass's bucket sort: bits of the longest partition's length << 16 | largest bucket it ranks
     uint32_t ramp_shift;     // the ramp epochs of the walk grow by 2^ramp_shift (0 = the default: 1, i.e. doubling)
     uint32_t* front_out;
     const uint32_t* front_in;
@@ -165,7 +166,7 @@ inline size_t ivf_max_groups(size_t pairs, size_t K) { return pairs / 8 + std::m
 void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, int s0, int K, uint32_t* d_cnt,
                      uint32_t* d_goff, uint32_t* d_fill, ScanItem* d_items, hipStream_t stream);
 hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uint32_t cand_cap, uint32_t ccap, int nq,
-                              uint64_t* d_stream, uint32_t cap, QueryOut* d_qout, uint32_t* d_qflags, hipStream_t stream);
+                              uint64_t* d_stream, uint32_t cap, QueryOut* d_qout, uint32_t* d_qflags, int ma, uint32_t pos_bits, hipStream_t stream);
 // Front shares of the ranks (gathered blocks of block_bytes each: [qtables per x tab][assign per x ma i32][front per x 4 u32])
 // -> the batch's arrays in query order; assign and front records also into host-mapped memory for the collect call.
 hipError_t launch_front_unpack(const unsigned char* d_gathered, size_t block_bytes, int world, int per, int nq, int ma, size_t tab,

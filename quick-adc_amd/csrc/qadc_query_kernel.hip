@@ -35,6 +35,10 @@
 #include <cstring>
 #include <type_traits>
 
+constexpr uint32_t kOrderBuckets = 1024;   // order_cands_kernel's bucket-sort scratch: (assign slots) x (up to 32 position sub-buckets)
+#ifndef QADC_BUCKET_SORT
+#define QADC_BUCKET_SORT 1   // 0: the ordering passes always run the bitonic network (A/B builds)
+#endif
 #ifndef QADC_WALK_PIPE
 #define QADC_WALK_PIPE 1
 #endif
@@ -194,9 +198,13 @@ __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint
 // PAYLDS: the payloads wait in LDS beside the sort keys (64 KiB in all at LOGCAP 12); false: they are fetched again through
 // load() when the stream is written (order_cands_kernel: its candidates lie in global memory the second phase has just
 // written — L2 — and keys alone let two workgroups share a CU at 8192 candidates, where keys + payloads left room for one).
+// scr / scr_slots / nslots / pos_bits: 2 x scr_slots + 1 words of LDS scratch, the number of assign slots and the bits of
+// the longest partition's length — for the BUCKET sort below (scr == nullptr: bitonic only).
 template <int LOGCAP, bool PAYLDS, typename Load>
 __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand, uint64_t* __restrict__ stream, uint32_t cap,
-                                                      uint32_t* wcnt, uint32_t tid, uint32_t lane, uint32_t wave) {
+                                                      uint32_t* wcnt, uint32_t tid, uint32_t lane, uint32_t wave,
+                                                      uint32_t* scr = nullptr, uint32_t scr_slots = 0, uint32_t nslots = 0,
+                                                      uint32_t pos_bits = 0, uint32_t bucket_max = 256) {
     uint32_t out_count = 0;
     constexpr uint32_t kCap = 1u << LOGCAP, kPer = kCap / kQWG;      // entries per thread in the write-out
     uint64_t* skey = reinterpret_cast<uint64_t*>(qsmem);             // [n2] (slot << (32 + LOGCAP) | pos << LOGCAP | index)
@@ -230,7 +238,79 @@ __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand,
         }
         q_lds_barrier();
         if (tid < ncand) skey[tid] = sorted[tid];
-    } else
+    } else {
+    // BUCKET sort (round 4): the network is 66 exchange steps at ~800 cycles for the 1.4 K candidates of a C3 query (~55 K
+    // of the pass's ~66 K cycles: phase stamps).  A query's candidates spread over a few dozen assign slots, and inside a
+    // slot their positions thin out like 1/pos (the heap's threshold tightens as the partition is walked): so a bucket =
+    // (slot, quarter-octave of the position above 2^(pos_bits-7)) holds a few dozen entries at most, and the bucket index
+    // is monotone in the key.  Count per bucket (LDS atomics), exclusive scan, scatter into the second half of the key
+    // array, then an entry's place inside its bucket is the number of smaller keys there (the lanes that share a bucket
+    // read them as broadcasts).  The keys are distinct (they end in the entry's index), so the order is the network's.
+    // Not taken — the network runs — when the candidates exceed half the key array or one bucket holds more than
+    // bucket_max entries (256; option "wgq_order_bucket_max" — the tests lower it to reach the fallback).
+    bool sorted_by_buckets = false;
+    if (QADC_BUCKET_SORT && scr && nslots != 0 && nslots * 2 <= scr_slots && ncand <= kCap / 2) {
+        uint32_t s_log = 5;                                      // sub-buckets per slot: 32, fewer when the scratch is short
+        while ((nslots << s_log) > scr_slots) --s_log;
+        const uint32_t nb = nslots << s_log;
+        const uint32_t lo = pos_bits > 7 ? pos_bits - 7 : 0;
+        auto bucket_of = [&](uint64_t k_) -> uint32_t {
+            const uint32_t slot = (uint32_t)(k_ >> (32 + LOGCAP));
+            const uint32_t p_ = (uint32_t)(k_ >> LOGCAP) >> lo;
+            uint32_t sub = 0;
+            if (p_) {
+                const uint32_t e = 31u - (uint32_t)__builtin_clz(p_);
+                sub = 1 + e * 4 + (e >= 2 ? (p_ >> (e - 2)) & 3u : (p_ << (2 - e)) & 3u);
+            }
+            sub = min(sub, 31u) >> (5 - s_log);
+            return min(slot, nslots - 1) * (1u << s_log) + sub;
+        };
+        uint32_t* cnt = scr;                                     // counts, then the scatter's cursors
+        uint32_t* base = scr + scr_slots;                        // nb + 1 bucket starts
+        for (uint32_t s_ = tid; s_ < nb; s_ += kQWG) cnt[s_] = 0;
+        q_lds_barrier();
+        for (uint32_t i = tid; i < ncand; i += kQWG) atomicAdd(&cnt[bucket_of(skey[i])], 1u);
+        q_lds_barrier();
+        if (wave == 0) {                                         // exclusive scan of the counts + the largest bucket
+            uint32_t run = 0, mx = 0;
+            for (uint32_t s0 = 0; s0 < nb; s0 += 64) {
+                const uint32_t c_ = s0 + lane < nb ? cnt[s0 + lane] : 0u;
+                const uint32_t incl = q_wave_incl_sum(c_);
+                if (s0 + lane < nb) {
+                    base[s0 + lane] = run + incl - c_;
+                    cnt[s0 + lane] = 0;
+                }
+                run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                mx = max(mx, c_);
+            }
+            mx = q_wave_scan_bits(mx, 0u, [](uint32_t a, uint32_t b) { return max(a, b); });
+            if (lane == 63) {
+                base[nb] = run;
+                wcnt[0] = mx;
+            }
+        }
+        q_lds_barrier();
+        sorted_by_buckets = wcnt[0] <= bucket_max;                    // (workgroup-uniform: read after the barrier)
+        q_lds_barrier();                                         // (wcnt is reused by the write-out below)
+        if (sorted_by_buckets) {
+            uint64_t* bkt = skey + kCap / 2;
+            for (uint32_t i = tid; i < ncand; i += kQWG) {
+                const uint64_t k_ = skey[i];
+                const uint32_t b_ = bucket_of(k_);
+                bkt[base[b_] + atomicAdd(&cnt[b_], 1u)] = k_;
+            }
+            q_lds_barrier();
+            for (uint32_t i = tid; i < ncand; i += kQWG) {
+                const uint64_t k_ = bkt[i];
+                const uint32_t b_ = bucket_of(k_);
+                const uint32_t b0 = base[b_], b1 = base[b_ + 1];
+                uint32_t rank = 0;
+                for (uint32_t j = b0; j < b1; ++j) rank += bkt[j] < k_ ? 1u : 0u;
+                skey[b0 + rank] = k_;
+            }
+        }
+    }
+    if (!sorted_by_buckets)
     for (uint32_t k = 2; k <= n2; k <<= 1)
         for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
             const bool local = jj < chunk;
@@ -246,6 +326,7 @@ __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand,
             if (local) q_wave_lds_sync();
             else q_lds_barrier();
         }
+    }
     q_lds_barrier();
     // expand the padding-lane replays while writing: thread t owns sorted entries [kPer * t, kPer * (t + 1))
     uint64_t pay[kPer];
@@ -1182,7 +1263,9 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     if (ncand > A.ccap) {
         flags |= 32u;                                            // more candidates than the in-workgroup sort takes: host falls back
     } else if (ncand) {
-        out_count = q_order_and_write<12, true>([&](uint32_t i) { return cands[i]; }, ncand, stream, A.cap, wcnt, tid, lane, wave);
+        // (bucket-sort scratch: the value histograms — misc[0..255] — are dead by now)
+        out_count = q_order_and_write<12, true>([&](uint32_t i) { return cands[i]; }, ncand, stream, A.cap, wcnt, tid, lane, wave,
+                                                misc, 127u, (uint32_t)ma, A.pos_bits >> 16, A.pos_bits & 0xffffu);
     }
     STAMP(14);
     s_count = out_count;
@@ -1325,8 +1408,10 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int32_t* __restr
 // layout scan_query_kernel writes ([nq][cap] entries, QueryOut, {flags, entries} for the lane replay).
 __global__ __launch_bounds__(kQWG) void order_cands_kernel(const QueryState* __restrict__ qstates, const Cand* __restrict__ regions,
                                                            uint32_t cand_cap, uint32_t ccap, uint64_t* __restrict__ stream,
-                                                           uint32_t cap, QueryOut* __restrict__ qout, uint32_t* __restrict__ qflags) {
+                                                           uint32_t cap, QueryOut* __restrict__ qout, uint32_t* __restrict__ qflags,
+                                                           uint32_t ma, uint32_t pos_bits) {
     __shared__ uint32_t wcnt[kQWaves];
+    __shared__ uint32_t bscr[2 * kOrderBuckets + 1];                 // bucket-sort scratch (q_order_and_write)
     const int q = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const QueryState* qs = qstates + q;
@@ -1346,7 +1431,7 @@ __global__ __launch_bounds__(kQWG) void order_cands_kernel(const QueryState* __r
                 o.slot = c.order & 0x3fffu;
                 return o;
             },
-            n, stream + (size_t)q * cap, cap, wcnt, tid, lane, wave);
+            n, stream + (size_t)q * cap, cap, wcnt, tid, lane, wave, bscr, kOrderBuckets, ma, pos_bits >> 16, pos_bits & 0xffffu);
     }
     if (tid == 0) {
         QueryOut o;
@@ -2008,12 +2093,12 @@ void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, i
 }
 
 hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uint32_t cand_cap, uint32_t ccap, int nq,
-                              uint64_t* d_stream, uint32_t cap, QueryOut* d_qout, uint32_t* d_qflags, hipStream_t stream) {
+                              uint64_t* d_stream, uint32_t cap, QueryOut* d_qout, uint32_t* d_qflags, int ma, uint32_t pos_bits, hipStream_t stream) {
     static std::atomic<uint64_t> done{0};
     const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&order_cands_kernel), kOrderCandCap * 8, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(order_cands_kernel, dim3(nq), dim3(kQWG), kOrderCandCap * 8, stream, d_qs, d_regions, cand_cap, ccap, d_stream, cap,
-                       d_qout, d_qflags);
+                       d_qout, d_qflags, (uint32_t)ma, pos_bits);
     return hipGetLastError();
 }
 

@@ -1392,6 +1392,46 @@ def test_wgq_grouped_second_phase_matches_oracle(pyqadc, po, M, nq, ma, head, bi
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("grouped", [True, False])
+@pytest.mark.parametrize("bucket_max", [256, 24, 3, 0])
+def test_ordering_pass_bucket_sort_and_its_bitonic_fallback_agree(pyqadc, po, grouped, bucket_max):
+    """The ordering pass (candidates back into scan order: assign slot, then position) sorts by (slot, position
+    quarter-octave) buckets and ranks inside a bucket by counting; a query with a bucket above `wgq_order_bucket_max`
+    takes the bitonic network instead.  256 = the default; 24 and 3 = some / nearly all queries fall back; 0 = every query
+    with a candidate does.  Same heaps as the oracle in every form — on the partition-major path's order_cands_kernel
+    (grouped) and in the query kernel's own tail — with partitions from empty to 40001 codes (positions from one bucket
+    to all 29 quarter-octaves) and ma = 12 slots."""
+    rng = np.random.default_rng(515)
+    M, nq, ma, R, keep = 16, 130, 12, 100, 0.05
+    sizes = [int(x) for x in rng.integers(1, 3000, 30)] + [0, 15, 17, 40001, 129, 30000, 25013, 36000]
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(keep)
+    for k, v in (("wgq", 2), ("wgq_group", 2 if grouped else 0), ("wgq_group_head", 3), ("device_replay_alone_nq", 0),
+                 ("profile", 1), ("wgq_order_bucket_max", bucket_max)):
+        idx.set_option(k, v)
+    K = len(sizes)
+    big = [33, 35, 36, 37]
+    assign = np.stack([rng.permutation(K)[:ma] for _ in range(nq)]).astype(np.int32)
+    for q in range(nq):
+        b = big[q % 4]
+        assign[q] = [b] + [p_ for p_ in assign[q] if p_ != b][:ma - 1]
+    tables = float_tables(rng, nq, ma, M)
+    tables = np.ascontiguousarray(tables + np.float32(0.6) * np.arange(ma, dtype=np.float32)[None, :, None])
+    got = idx.query_scan(assign, tables.copy(), R)
+    prof = idx.profile()
+    assert (prof["group_launches"] >= 1) == grouped and prof["group_fallbacks"] == 0, prof
+    for q in range(nq):
+        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
+        assert got["status"][q] == want["rc"]
+        if want["rc"] == 0:
+            assert heaps_equal(got["heaps"][q], (want["keys"], want["values"])), q
+    idx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nq,K,dim,ma", [(300, 700, 16, 9), (257, 4100, 48, 33), (1030, 256, 128, 16), (70, 16384, 96, 64),
                                          (33, 1500, 32, 200), (20, 900, 16, 8)])
 def test_coarse_assignment_of_large_batches_is_the_sequential_one(pyqadc, nq, K, dim, ma):
