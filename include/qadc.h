@@ -109,7 +109,8 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * scan stream; default 0), "wgq_ramp_shift" (the walk's ramp epochs grow by 2^shift; default doubling), "mq_single" (a lone long
  * run through the multi-query kernel's 4-seat form: 0 never — default —, 1 for lists that fit the Infinity Cache, 2 always),
  * "wgq_order_bucket_max" (the ordering pass sorts by (slot, position) buckets and ranks inside a bucket by counting; a query with
- * a bucket above this many entries takes the bitonic network; default 256, 0 = always the network).
+ * a bucket above this many entries takes the bitonic network; default 256, 0 = always the network), "wgq_select_rank" (the front's
+ * select draws its threshold from 64 sampled pre-scan values: 0 = the rank it computes itself, 1..64 = this rank — test hook).
  * Streams: the library keeps ONE set of HIP streams per process and device, created by the first index on the device and shared
  * by every later one. */
 int qadc_set_option(qadc_index* idx, const char* name, double value);

@@ -415,6 +415,7 @@ struct qadc_index {
     int plan_early = 1;                  // pipelined query-kernel batches: tables, state clear and plan off the scan stream (option "plan_early")
     int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
     int order_bucket_max = 256;          // largest bucket the ordering pass's bucket sort ranks by counting (option "wgq_order_bucket_max"; beyond: bitonic)
+    int select_rank = 0;                 // option "wgq_select_rank": 0 = auto (QueryKernelArgs::select_rank)
     int wgq_ramp_shift = 0;              // ramp epochs of the query kernel's walk grow by 2^shift (0 = default, doubling)
     uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)
     DevBuf<PartDesc> d_partdesc;         // device partition table (qadc_index_finalize)

@@ -251,6 +251,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     A.nontemporal = idx->total_codes * (uint64_t)idx->cs > (200ull << 20);   // (same rule as the level path)
     A.G = G;
     A.ramp_shift = (uint32_t)idx->wgq_ramp_shift;
+    A.select_rank = (uint32_t)idx->select_rank;
     A.pos_bits = (idx->max_part_n ? 64u - (uint32_t)__builtin_clzll((unsigned long long)idx->max_part_n) : 0u) << 16 |
                  (uint32_t)idx->order_bucket_max;
     if (idx->profile) HIPCHECK(prof_event(s, st));

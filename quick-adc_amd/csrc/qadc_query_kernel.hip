@@ -36,6 +36,12 @@
 #include <type_traits>
 
 constexpr uint32_t kOrderBuckets = 1024;   // order_cands_kernel's bucket-sort scratch: (assign slots) x (up to 32 position sub-buckets)
+#ifndef QADC_MERGE_WAVE_PRIO
+#define QADC_MERGE_WAVE_PRIO 3   // s_setprio of the replay / merge kernels' waves (0: off — A/B builds)
+#endif
+#ifndef QADC_SELECT_THRESHOLD
+#define QADC_SELECT_THRESHOLD 1   // 0: the front's select runs its radix passes only (A/B builds)
+#endif
 #ifndef QADC_BUCKET_SORT
 #define QADC_BUCKET_SORT 1   // 0: the ordering passes always run the bitonic network (A/B builds)
 #endif
@@ -390,6 +396,8 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     uint32_t& s_nvals = misc[320];
     uint32_t& s_prefix = misc[321];
     uint32_t& s_k = misc[322];
+    uint32_t& s_binc = misc[323];                // select: keys in the chosen digit's bin
+    uint32_t& s_sel = misc[328];                 // select: keys collected by the short cut
     uint32_t& s_count = misc[325];
     float* redf = reinterpret_cast<float*>(misc + 336);   // [16] per-wave minima
 
@@ -635,10 +643,78 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
 
         STAMP(4);
         // ---- R-th smallest of the pre-scan values = tmp_bh.max() (db_query_4.cpp:259); FLT_MAX if fewer than R ----
+        // A 4-pass radix select (8-bit digits, histogram in LDS), with two short cuts measured on the phase stamps of round 4
+        // (C3 shape, 7.8 K values: pass 5.6 K cycles, second pass 9 K — an LDS atomic per value on a handful of hot bins —;
+        // C5, 39 K values in the global scratch: 28 K / 44 K per pass, 18 K of it reading the values):
+        //  * THRESHOLD FIRST (n > 2048).  R is a percent or less of the values.  Wave 0 ranks 64 evenly spaced values in
+        //    registers; the m-th smallest of them (m = 1.5 x the R-th value's expected rank in such a sample, + 3) is a
+        //    threshold T some percent up the distribution.  ONE pass over the values keeps every key <= T (all of them:
+        //    ranks below T stay exact) in the dead per-wave table area, and the radix passes run over those few hundred
+        //    keys.  Fewer than R kept (an unlucky sample) or more than the area holds: the passes run over all values
+        //    (option "wgq_select_rank" = m, for the tests to reach both).
+        //  * once the chosen digit's bin holds <= 256 keys they are collected and ranked by counting.
+        // Either way the result is the exact R-th smallest key.
         const uint32_t n = s_nvals;
         if (n < R) {
             qmax = FLT_MAX;
         } else {
+            uint32_t* list = reinterpret_cast<uint32_t*>(qsmem + C::WTAB_OFF);
+            constexpr uint32_t kListCap = (uint32_t)C::WTAB_BYTES / 4u;
+            uint32_t nlist = 0;                                  // != 0: the passes read list[0 .. nlist)
+            // every value's key through f: the kept keys, the values in LDS, or the global scratch (more starts than the LDS
+            // budget holds — the C5 shape: eight loads in flight per lane; one dependent load per iteration made this select
+            // 2/3 of that shape's front)
+            auto for_each_key = [&](auto f) {
+                if (nlist) {
+                    for (uint32_t i = tid; i < nlist; i += kQWG) f(list[i]);
+                } else if (in_lds) {
+                    for (uint32_t i = tid; i < n; i += kQWG) f(q_fkey(vals[i]));
+                } else {
+                    constexpr int kSB = 8;
+                    for (uint32_t i0 = tid; i0 < n; i0 += kQWG * kSB) {
+                        float fv[kSB];
+#pragma unroll
+                        for (int u = 0; u < kSB; ++u) {
+                            const uint32_t i = i0 + (uint32_t)u * kQWG;
+                            fv[u] = i < n ? gvals[i] : 0.0f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < kSB; ++u)
+                            if (i0 + (uint32_t)u * kQWG < n) f(q_fkey(fv[u]));
+                    }
+                }
+            };
+            if (QADC_SELECT_THRESHOLD && n > 2048u) {
+                if (wave == 0) {
+                    const uint32_t i = (uint32_t)((uint64_t)lane * n / 64u);   // (evenly spaced: the values lie probe by probe, nearest centroid first)
+                    const uint32_t skey = q_fkey(in_lds ? vals[i] : gvals[i]);
+                    const uint32_t m = A.select_rank ? min(64u, A.select_rank) : min(64u, (uint32_t)((96ull * R + n - 1u) / n) + 3u);
+                    uint32_t less = 0, le = 0;
+#pragma unroll 8
+                    for (int j = 0; j < 64; ++j) {
+                        const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)skey, j);
+                        less += kj < skey ? 1u : 0u;
+                        le += kj <= skey ? 1u : 0u;
+                    }
+                    if (less < m && m <= le) s_prefix = skey;
+                    if (lane == 0) s_sel = 0;
+                }
+                __syncthreads();
+                const uint32_t T = s_prefix;
+                for_each_key([&](uint32_t key) {
+                    if (key <= T) {
+                        const uint64_t hits = __builtin_amdgcn_ballot_w64(true);
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+                        uint32_t base = 0;
+                        if (rank == 0) base = atomicAdd(&s_sel, (uint32_t)__popcll(hits));
+                        base = q_uni(base);
+                        if (base + rank < kListCap) list[base + rank] = key;
+                    }
+                });
+                __syncthreads();
+                const uint32_t c = s_sel;
+                if (c >= R && c <= kListCap) nlist = c;          // (workgroup-uniform)
+            }
             if (tid == 0) { s_prefix = 0; s_k = R; }
             for (int pass = 0; pass < 4; ++pass) {
                 const int lo = 24 - 8 * pass;
@@ -667,24 +743,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                         if (!counted) atomicAdd(&hist[dg], 1u);
                     }
                 };
-                if (in_lds) {
-                    for (uint32_t i = tid; i < n; i += kQWG) count_key(q_fkey(vals[i]));
-                } else {
-                    // values in the global scratch (more starts than the LDS budget holds — the C5 shape: 39 K per query): eight
-                    // loads in flight per lane; one dependent load per iteration made this select 2/3 of that shape's front
-                    constexpr int kSB = 8;
-                    for (uint32_t i0 = tid; i0 < n; i0 += kQWG * kSB) {
-                        float fv[kSB];
-#pragma unroll
-                        for (int u = 0; u < kSB; ++u) {
-                            const uint32_t i = i0 + (uint32_t)u * kQWG;
-                            fv[u] = i < n ? gvals[i] : 0.0f;
-                        }
-#pragma unroll
-                        for (int u = 0; u < kSB; ++u)
-                            if (i0 + (uint32_t)u * kQWG < n) count_key(q_fkey(fv[u]));
-                    }
-                }
+                for_each_key(count_key);
                 __syncthreads();
                 if (tid < 64) {                                  // wave 0: 4 bins per lane, pick the digit holding rank k
                     const uint32_t k = s_k;
@@ -702,9 +761,37 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                         }
                         s_prefix = prefix | (digit << lo);
                         s_k = k - run;
+                        s_binc = hist[digit];
                     }
+                    if (tid == 0) s_sel = 0;
                 }
                 __syncthreads();
+                if (pass < 3 && s_binc <= 256u) {                // the bin's keys into the histogram's words, ranked by counting
+                    const uint32_t prefix2 = s_prefix, k2 = s_k, mask2 = 0xffffffffu << lo;
+                    for_each_key([&](uint32_t key) {
+                        if ((key & mask2) == prefix2) hist[atomicAdd(&s_sel, 1u)] = key;
+                    });
+                    __syncthreads();
+                    const uint32_t c = s_sel;
+                    if (tid < c) {
+                        const uint32_t key = hist[tid];
+                        const uint4* h4 = reinterpret_cast<const uint4*>(hist);
+                        uint32_t less = 0, le = 0, j = 0;
+                        for (; j + 4 <= c; j += 4) {             // (four keys per LDS read: one dependent read per key made 256 keys 25 K cycles)
+                            const uint4 kk = h4[j >> 2];
+                            less += (kk.x < key ? 1u : 0u) + (kk.y < key ? 1u : 0u) + (kk.z < key ? 1u : 0u) + (kk.w < key ? 1u : 0u);
+                            le += (kk.x <= key ? 1u : 0u) + (kk.y <= key ? 1u : 0u) + (kk.z <= key ? 1u : 0u) + (kk.w <= key ? 1u : 0u);
+                        }
+                        for (; j < c; ++j) {
+                            const uint32_t kj = hist[j];
+                            less += kj < key ? 1u : 0u;
+                            le += kj <= key ? 1u : 0u;
+                        }
+                        if (less < k2 && k2 <= le) s_prefix = key;
+                    }
+                    __syncthreads();
+                    break;
+                }
             }
             qmax = q_funkey(s_prefix);
         }
@@ -1787,6 +1874,10 @@ __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(con
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ info,
                                                                uint32_t cap, int nq, uint32_t R, uint64_t* __restrict__ heaps,
                                                                uint32_t* __restrict__ heap_sizes) {
+    // A query's pushes are ONE dependent instruction chain: beside the scan kernels' waves (8 per SIMD, VALU-bound) the
+    // chain waits for its turn at the issue port at every step.  Raised wave priority gives it the port when it is ready;
+    // it is ready a few percent of the cycles, so the scans lose next to nothing.
+    if (QADC_MERGE_WAVE_PRIO) __builtin_amdgcn_s_setprio(QADC_MERGE_WAVE_PRIO);
     const uint32_t lane = threadIdx.x & 63u;
     const int q = (int)(blockIdx.x * (uint32_t)kReplayWaves + (threadIdx.x >> 6));
     if (q >= nq) return;
@@ -1889,6 +1980,7 @@ __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __res
     __shared__ uint64_t wsum[16];
     __shared__ unsigned long long rank_tot[16];
     __shared__ uint32_t bad;
+    if (QADC_MERGE_WAVE_PRIO) __builtin_amdgcn_s_setprio(QADC_MERGE_WAVE_PRIO);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const int per = (nq + 1023) / 1024;
     const int lo = min(nq, (int)tid * per), hi = min(nq, lo + per);
@@ -1954,6 +2046,7 @@ __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __
     uint32_t* cnt_sg = reinterpret_cast<uint32_t*>(qsmem);        // [ma][world] -> exclusive prefix in (s, g) order
     uint32_t* cnt_gs = cnt_sg + (size_t)ma * world;               // [world][ma] -> exclusive prefix in (g, s) order
     __shared__ uint32_t wtot[4];
+    if (QADC_MERGE_WAVE_PRIO) __builtin_amdgcn_s_setprio(QADC_MERGE_WAVE_PRIO);   // (latency chain on the merge stream: see replay_heap_wave_kernel)
     const int q = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (info[q]) return;

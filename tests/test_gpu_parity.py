@@ -928,6 +928,37 @@ def test_wgq_prescan_values_beyond_the_lds_budget(pyqadc, po, M, n, keep):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rank", [0, 1, 2, 40, 64])
+@pytest.mark.parametrize("M,sizes,keep,R", [(16, (60001, 90001, 8000, 70001), 0.02, 100), (32, (1200001,), 0.02, 100),
+                                           (16, (60001, 90001, 70001), 0.02, 1000), (16, (150001,), 0.02, 1)])
+def test_front_select_threshold_and_its_fallbacks_give_the_same_qmax(pyqadc, po, M, sizes, keep, R, rank):
+    """The front's select (R-th smallest pre-scan value = qmax) first keeps the keys below a threshold drawn from 64
+    sampled values and runs its radix passes over those.  rank 0 = the sample rank it computes itself; 1 / 2 = a threshold so
+    low that fewer than R keys are kept, 40 / 64 = so high that the kept keys exceed their LDS area (24 K values of the
+    32x4 case): both make the passes run over all values.  3 K .. 24 K values (LDS and global scratch), R = 1, 100 and 1000:
+    qmin, qmax, int8 tables and heaps equal the oracle's every time."""
+    rng = np.random.default_rng(77 + M + len(sizes) + R)
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts)
+    idx.finalize(keep)
+    idx.set_option("wgq", 2)
+    idx.set_option("wgq_select_rank", rank)
+    nq, ma = 3, len(sizes)
+    assign = np.stack([rng.permutation(len(sizes))[:ma] for _ in range(nq)]).astype(np.int32)
+    tables = float_tables(rng, nq, ma, M)
+    got = idx.query_scan(assign, tables.copy(), R, want_qtables=True)
+    for q in range(nq):
+        want = po.query_scan(M, parts, None, keep, assign[q], tables[q].copy(), R)
+        assert want["rc"] == got["status"][q]
+        assert got["qmax"][q] == np.float32(want["qmax"]) and got["qmin"][q] == np.float32(want["qmin"]), (q, got["qmax"][q], want["qmax"])
+        assert np.array_equal(got["qtables"][q], want["qtables"])
+        if want["rc"] == 0:
+            assert heaps_equal(got["heaps"][q], (want["keys"], want["values"])), q
+    idx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R", [1, 7, 100, 288, 289, 1000])
 def test_wgq_device_replay_lanes_and_host_replay_agree(pyqadc, po, R):
     """Batches of >= 64 queries replay on the device, one lane per query (replay_heap_lanes_kernel, R <= 288);
