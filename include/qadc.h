@@ -101,6 +101,7 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * small batch spreads one query over / codes each keeps at least), "wgq_inline" (a lone small query's input rides
  * in the kernel arguments), "wgq_poll" (... and its completion is read from the mapped result block),
  * "wgq_group" (large IVF batches: partition-major second phase; 0 never, 1 auto, 2 whenever possible),
+ * "wgq_group_codes_per_wg" (... whose groups take one workgroup per this many codes of the longest partition; default 16384),
  * "wgq_group_head" (probes per query the one-workgroup-per-query head walks before it), "wgq_group_head_dist" (the same under the
  * multi-GPU merge, counted in probes with codes on the rank),
  * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_async", "dist_shard_front", "dist_inject_failure" (test hook),

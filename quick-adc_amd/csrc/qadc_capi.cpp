@@ -1499,6 +1499,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "wgq_variant") idx->wgq_variant = (int)value;
     else if (n == "plan_early") idx->plan_early = value != 0;
     else if (n == "wgq_order_bucket_max") idx->order_bucket_max = (int)std::max(0.0, std::min(value, 4096.0));
+    else if (n == "wgq_group_codes_per_wg") idx->group.codes_per_wg = value <= 0 ? 0u : (uint32_t)std::max(value, 4096.0);
     else if (n == "wgq_select_rank") idx->select_rank = (int)std::max(0.0, std::min(value, 64.0));
     else if (n == "wgq_ramp_shift") idx->wgq_ramp_shift = (int)std::max(0.0, std::min(value, 4.0));
     else if (n == "wgq_stream") idx->wgq_stream_on = value != 0;

@@ -336,6 +336,7 @@ struct GroupState {
     int head = 3;          // ... after a head of this many probes per query (one workgroup per query; 4 until the ordering pass took 8192 candidates)
     int head_dist = 4;     // ... under the multi-GPU merge (probes with codes on this rank; option "wgq_group_head_dist")
     int mq_narrow = 1;     // groups whose upper four seats are empty run the 4-seat form (the two-body build of the kernel)
+    uint32_t codes_per_wg = 16384;   // codes of the longest partition per workgroup of a group (option "wgq_group_codes_per_wg"; 0 = mq_codes_per_wg)
     uint32_t cand_cap = kOrderCandCap;   // candidates per query of such a batch before it falls back (option "wgq_group_cand_cap")
 };
 

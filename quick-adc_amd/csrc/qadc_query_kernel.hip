@@ -36,9 +36,6 @@
 #include <type_traits>
 
 constexpr uint32_t kOrderBuckets = 1024;   // order_cands_kernel's bucket-sort scratch: (assign slots) x (up to 32 position sub-buckets)
-#ifndef QADC_MERGE_WAVE_PRIO
-#define QADC_MERGE_WAVE_PRIO 3   // s_setprio of the replay / merge kernels' waves (0: off — A/B builds)
-#endif
 #ifndef QADC_SELECT_THRESHOLD
 #define QADC_SELECT_THRESHOLD 1   // 0: the front's select runs its radix passes only (A/B builds)
 #endif
@@ -1874,10 +1871,8 @@ __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(con
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ info,
                                                                uint32_t cap, int nq, uint32_t R, uint64_t* __restrict__ heaps,
                                                                uint32_t* __restrict__ heap_sizes) {
-    // A query's pushes are ONE dependent instruction chain: beside the scan kernels' waves (8 per SIMD, VALU-bound) the
-    // chain waits for its turn at the issue port at every step.  Raised wave priority gives it the port when it is ready;
-    // it is ready a few percent of the cycles, so the scans lose next to nothing.
-    if (QADC_MERGE_WAVE_PRIO) __builtin_amdgcn_s_setprio(QADC_MERGE_WAVE_PRIO);
+    // (raised wave priority — s_setprio 3 here and in the two merge kernels — was measured in round 4: no change in one of 8
+    // ranks' batch; what the merge chain waits for beside the scans is not the issue port)
     const uint32_t lane = threadIdx.x & 63u;
     const int q = (int)(blockIdx.x * (uint32_t)kReplayWaves + (threadIdx.x >> 6));
     if (q >= nq) return;
@@ -1980,7 +1975,6 @@ __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __res
     __shared__ uint64_t wsum[16];
     __shared__ unsigned long long rank_tot[16];
     __shared__ uint32_t bad;
-    if (QADC_MERGE_WAVE_PRIO) __builtin_amdgcn_s_setprio(QADC_MERGE_WAVE_PRIO);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const int per = (nq + 1023) / 1024;
     const int lo = min(nq, (int)tid * per), hi = min(nq, lo + per);
@@ -2046,7 +2040,6 @@ __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __
     uint32_t* cnt_sg = reinterpret_cast<uint32_t*>(qsmem);        // [ma][world] -> exclusive prefix in (s, g) order
     uint32_t* cnt_gs = cnt_sg + (size_t)ma * world;               // [world][ma] -> exclusive prefix in (g, s) order
     __shared__ uint32_t wtot[4];
-    if (QADC_MERGE_WAVE_PRIO) __builtin_amdgcn_s_setprio(QADC_MERGE_WAVE_PRIO);   // (latency chain on the merge stream: see replay_heap_wave_kernel)
     const int q = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (info[q]) return;
