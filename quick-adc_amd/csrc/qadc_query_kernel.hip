@@ -131,6 +131,39 @@ __device__ __forceinline__ uint32_t q_pair_sum(const uint32_t* d, uint32_t lane_
     return s;
 }
 
+// The pre-scan's float ADC of one code (scan_4<M> order: byte by byte, low nibble then high nibble, accumulated from 0 —
+// query_common.hpp:72-80) against the wave's float table at absolute LDS address tb (256-byte aligned; table t at
+// tb + t*64).  Sixteen lookups are issued before the first add waits: the adds are a dependent chain by definition, the
+// reads need not be — one read waited for per add made a code 32 LDS round trips (C5 shape: the pre-scan was 107 K of the
+// front's 236 K cycles).  Addresses: the nibbles are masked four at a time, pre-multiplied by 4, and ONE v_perm_b32 per
+// lookup puts the byte under the table's address (the table index rides in the read's immediate offset).
+typedef const __attribute__((address_space(3))) float* q_lds_float_t;
+template <int M>
+__device__ __forceinline__ float q_prescan_sum(const uint32_t* d, uint32_t tb) {
+    constexpr int CS = M / 2;
+    float cand = 0.0f;
+#pragma unroll
+    for (int h = 0; h < CS; h += 8) {
+        float v[16];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const uint32_t dw = d[(h >> 2) + w];
+            const uint32_t dl = (dw << 2) & 0x3c3c3c3cu, dh = (dw >> 2) & 0x3c3c3c3cu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = h + 4 * w + k;                     // code byte: sub-quantizers 2b (low nibble) and 2b + 1
+                const uint32_t al = __builtin_amdgcn_perm(dl, tb, 0x03020104u + (uint32_t)k);
+                const uint32_t ah = __builtin_amdgcn_perm(dh, tb, 0x03020104u + (uint32_t)k);
+                v[8 * w + 2 * k] = *reinterpret_cast<q_lds_float_t>(static_cast<uintptr_t>(al + (2 * b) * 64));
+                v[8 * w + 2 * k + 1] = *reinterpret_cast<q_lds_float_t>(static_cast<uintptr_t>(ah + (2 * b + 1) * 64));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cand += v[j];
+    }
+    return cand;
+}
+
 // A partition descriptor whose fields are forced into scalar registers: the probed partition is the same for the
 // whole workgroup, but the compiler cannot prove that loads through assign[] are uniform.
 struct UDesc {
@@ -383,7 +416,7 @@ template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD>
 __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     using C = QCfg<M>;
     if (reinterpret_cast<uintptr_t>((q_lds_bytes_t)qsmem) != 0) __builtin_trap();   // the lookups use absolute LDS addresses
-    constexpr int CS = C::CS, DW = C::DW, CPL = C::CPL;
+    constexpr int DW = C::DW, CPL = C::CPL;
     float* vals = reinterpret_cast<float*>(qsmem + C::VALS_OFF);
     float* wtab = reinterpret_cast<float*>(qsmem + C::WTAB_OFF);
     unsigned char* tq = qsmem + C::TQ_OFF;
@@ -607,18 +640,12 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                         }
                     }
                 }
+                const uint32_t tb = (uint32_t)C::WTAB_OFF + wave * (uint32_t)(M * 16 * 4);   // mytab, as an absolute LDS address
 #pragma unroll
                 for (int u = 0; u < kPB; ++u) {
                     const uint32_t i = i0 + (uint32_t)u * step;
+                    const float cand = q_prescan_sum<M>(dwv[u], tb);   // (lanes past the starts sum code 0: not stored)
                     if (i < sn) {
-                        // scan_4<M> order: byte by byte, low nibble then high nibble, accumulated from 0 (query_common.hpp:72-80)
-                        float cand = 0.0f;
-#pragma unroll
-                        for (int b = 0; b < CS; ++b) {
-                            const uint32_t byte = (dwv[u][b >> 2] >> (8 * (b & 3))) & 0xffu;
-                            cand += mytab[(2 * b) * 16 + (byte & 15u)];
-                            cand += mytab[(2 * b + 1) * 16 + (byte >> 4)];
-                        }
                         if (in_lds) vals[base + i] = cand;
                         else gvals[base + i] = cand;
                     }
