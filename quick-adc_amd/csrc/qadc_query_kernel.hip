@@ -2010,25 +2010,45 @@ __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __res
     __syncthreads();
     uint64_t mine = 0;
     uint32_t my_bad = 0;
-    for (int g = 0; g < world && status; ++g) {                  // entries every rank wanted to ship: sizes a regrow
-        unsigned long long t = 0;
-        for (int q = lo; q < hi; ++q) t += (reinterpret_cast<const uint32_t*>(gathered + (size_t)g * block_words) + 4 * (size_t)q)[1];
-        if (t) atomicAdd(&rank_tot[g], t);
-    }
+    // (every rank's header of a query in ONE round trip — 16 bytes each, up to 16 ranks in flight: the loop used to wait for
+    //  each rank's two words in turn, twice: 16 dependent round trips made this one-workgroup kernel 40 us alone on the GPU)
+    unsigned long long rt[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) rt[g] = 0;
     for (int q = lo; q < hi; ++q) {
         uint32_t tot = 0, fl = 0;
-        for (int g = 0; g < world; ++g) {
-            const uint32_t* hdr = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * block_words) + 4 * (size_t)q;
-            tot += hdr[1];
-            const uint32_t f = hdr[2];
-            if (f & 1u) fl |= 1u;                                // qmax too high (identical on every rank)
-            if ((f & (64u | 128u)) || !(f & (4u | 1u))) fl |= 2u; // block too small / the rank failed / not ordered
-            my_bad |= (f & (64u | 128u)) | ((f & (4u | 1u)) ? 0u : 256u);
+        for (int g0 = 0; g0 < world; g0 += 16) {
+            uint32_t hc[16], hf[16];                             // header words 1 (entries) and 2 (flags); a block is 8-byte aligned
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                hc[u] = 0;
+                hf[u] = 4u;
+                if (g0 + u < world) {
+                    const uint64_t* hq = gathered + (size_t)(g0 + u) * block_words + 2 * (size_t)q;
+                    hc[u] = (uint32_t)(hq[0] >> 32);
+                    hf[u] = (uint32_t)hq[1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (g0 + u >= world) continue;
+                tot += hc[u];
+                if (g0 == 0) rt[u] += hc[u];
+                const uint32_t f = hf[u];
+                if (f & 1u) fl |= 1u;                            // qmax too high (identical on every rank)
+                if ((f & (64u | 128u)) || !(f & (4u | 1u))) fl |= 2u; // block too small / the rank failed / not ordered
+                my_bad |= (f & (64u | 128u)) | ((f & (4u | 1u)) ? 0u : 256u);
+            }
         }
         if (fl) tot = 0;
         mcnt[q] = tot;
         info[q] = fl;
         mine += tot;
+    }
+    if (status) {                                                // entries every rank wanted to ship: sizes a regrow
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+            if (g < world && rt[g]) atomicAdd(&rank_tot[g], rt[g]);
     }
     // exclusive prefix of the per-thread sums (64-bit: a batch may gather more than 2^32 entries)
     uint64_t incl = mine;
@@ -2073,18 +2093,46 @@ __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __
     const int cells = ma * world;
     for (int i = tid; i < 2 * cells; i += 256) cnt_sg[i] = 0;
     __syncthreads();
-    if (ma > 1)
+    if (ma > 1) {
+        // A rank's stream is in scan order, i.e. sorted by slot: a slot's count is the length of its RUN.  The lanes at a run's
+        // first and last entry store its bounds (plain LDS stores: a few dozen per rank); counting every entry with two LDS
+        // atomics — 64 lanes of a wave on the same counter, since neighbours share the slot — was most of this kernel
+        // (round 4: 90 -> 55 us per 1024-query batch of the C5 shape alone on the GPU).
         for (int g = 0; g < world; ++g) {
             const uint32_t* hdr = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * block_words) + 4 * (size_t)q;
             const uint64_t* __restrict__ ent = gathered + (size_t)g * block_words + 2 * (size_t)nq + hdr[0];
             const uint32_t n = hdr[1];
-            for (uint32_t i = tid; i < n; i += 256) {
-                const uint32_t sl = (uint32_t)(ent[i] >> 40) & 0x3fffu;
-                atomicAdd(&cnt_sg[sl * world + g], 1u);
-                atomicAdd(&cnt_gs[g * ma + sl], 1u);
+            constexpr int kIB = 4;                               // rows of 64 entries in flight per wave (one round trip, not four)
+            for (uint32_t i0 = wave * 64u; i0 < n; i0 += 256 * kIB) {   // (wave-uniform bounds: the shuffles need every lane)
+                uint32_t slv[kIB], pv[kIB], nx[kIB];
+#pragma unroll
+                for (int u = 0; u < kIB; ++u) {
+                    const uint32_t i = i0 + (uint32_t)u * 256u + lane;
+                    slv[u] = i < n ? (uint32_t)(ent[i] >> 40) & 0x3fffu : 0xffffffffu;
+                    pv[u] = nx[u] = 0xffffffffu;
+                    if (lane == 0 && i && i < n) pv[u] = (uint32_t)(ent[i - 1] >> 40) & 0x3fffu;
+                    if (lane == 63 && i + 1 < n) nx[u] = (uint32_t)(ent[i + 1] >> 40) & 0x3fffu;
+                }
+#pragma unroll
+                for (int u = 0; u < kIB; ++u) {
+                    const uint32_t i = i0 + (uint32_t)u * 256u + lane;
+                    const uint32_t sl = slv[u];
+                    uint32_t prev = (uint32_t)__shfl_up((int)sl, 1), next = (uint32_t)__shfl_down((int)sl, 1);
+                    if (lane == 0) prev = pv[u];
+                    if (lane == 63) next = nx[u];
+                    if (i < n && prev != sl) cnt_gs[g * ma + sl] = i;            // the run's first entry
+                    if (i < n && next != sl) cnt_sg[sl * world + g] = i + 1;     // one past its last
+                }
             }
         }
-    else if ((int)tid < world) {                                  // one probe: a rank's count is its header's
+        __syncthreads();
+        for (int c = tid; c < cells; c += 256) {                 // cell (g, s): count = end - first (both 0 where the slot is absent)
+            const int g = c / ma, s = c % ma;
+            const uint32_t cnt = cnt_sg[s * world + g] - cnt_gs[c];
+            cnt_gs[c] = cnt;
+            cnt_sg[s * world + g] = cnt;
+        }
+    } else if ((int)tid < world) {                                // one probe: a rank's count is its header's
         const uint32_t* hdr = reinterpret_cast<const uint32_t*>(gathered + (size_t)tid * block_words) + 4 * (size_t)q;
         cnt_sg[tid] = cnt_gs[tid] = hdr[1];
     }
@@ -2114,11 +2162,23 @@ __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __
         const uint64_t* __restrict__ ent = gathered + (size_t)g * block_words + 2 * (size_t)nq + hdr[0];
         const uint32_t n = hdr[1];
         const uint32_t rank_first = cnt_gs[g * ma];              // entries of the ranks below g (= prefix at (g, slot 0))
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint64_t e = ent[i];
-            const uint32_t sl = ma > 1 ? (uint32_t)(e >> 40) & 0x3fffu : 0u;
-            const uint32_t run_first = cnt_gs[g * ma + sl] - rank_first;      // index of the slot's first entry in rank g's stream
-            out[cnt_sg[sl * world + g] + (i - run_first)] = e;
+        constexpr int kOB = 4;                                   // entries in flight per lane
+        for (uint32_t i0 = tid; i0 < n; i0 += 256 * kOB) {
+            uint64_t ev[kOB];
+#pragma unroll
+            for (int u = 0; u < kOB; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * 256u;
+                ev[u] = i < n ? ent[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < kOB; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * 256u;
+                if (i >= n) continue;
+                const uint64_t e = ev[u];
+                const uint32_t sl = ma > 1 ? (uint32_t)(e >> 40) & 0x3fffu : 0u;
+                const uint32_t run_first = cnt_gs[g * ma + sl] - rank_first;  // index of the slot's first entry in rank g's stream
+                out[cnt_sg[sl * world + g] + (i - run_first)] = e;
+            }
         }
     }
 }
