@@ -36,6 +36,12 @@
 #include <type_traits>
 
 constexpr uint32_t kOrderBuckets = 1024;   // order_cands_kernel's bucket-sort scratch: (assign slots) x (up to 32 position sub-buckets)
+// Helper launches that run BESIDE the scan kernels (plan, merge, replay) use workgroups of 4 waves.  The partition-major scan
+// keeps 28 of a CU's 32 wave slots (256-thread workgroups, 7 waves per SIMD), so a 4-wave workgroup fits beside it at once;
+// a 1024-thread one waits until 16 slots of ONE CU are free together — and while it waits at the head of its queue nothing
+// else is dispatched there.  Round 4, same-box A/B on one of 8 ranks' IVF batch: replay 16 -> 4 waves per workgroup and the
+// one-workgroup totals kernel 1024 -> 256 threads: C3 0.52 -> 0.45 ms per batch, C5 0.81 -> 0.78 (profiles/r04_side_wg_ab.txt).
+constexpr int kSideWG = 256;
 #ifndef QADC_SELECT_THRESHOLD
 #define QADC_SELECT_THRESHOLD 1   // 0: the front's select runs its radix passes only (A/B builds)
 #endif
@@ -1467,10 +1473,11 @@ __global__ __launch_bounds__(256) void ivf_count_kernel(const int32_t* __restric
 }
 
 // goff[p] = first group of partition p, goff[K] = groups in all; one workgroup
-__global__ __launch_bounds__(1024) void ivf_offsets_kernel(const uint32_t* __restrict__ cnt, int K, uint32_t* __restrict__ goff) {
-    __shared__ uint32_t wsum[16];
+// (256 threads, like every helper launch that runs beside the scans: see kSideWG)
+__global__ __launch_bounds__(kSideWG) void ivf_offsets_kernel(const uint32_t* __restrict__ cnt, int K, uint32_t* __restrict__ goff) {
+    __shared__ uint32_t wsum[kSideWG / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const int per = (K + 1023) / 1024;
+    const int per = (K + kSideWG - 1) / kSideWG;
     const int lo = min(K, (int)tid * per), hi = min(K, lo + per);
     uint32_t mine = 0;
     for (int p = lo; p < hi; ++p) mine += (cnt[p] + 7u) / 8u;
@@ -1478,7 +1485,7 @@ __global__ __launch_bounds__(1024) void ivf_offsets_kernel(const uint32_t* __res
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint32_t base = incl - mine, total = 0;
-    for (uint32_t w = 0; w < 16; ++w) {
+    for (uint32_t w = 0; w < kSideWG / 64; ++w) {
         if (w < wave) base += wsum[w];
         total += wsum[w];
     }
@@ -1889,10 +1896,14 @@ struct WaveHeap {
 // (a block overflowed / an unordered query: size 0xffffffff, the host regrows or falls back).
 // QF: the single-GPU layout instead — query q's stream at q * cap, {flags, entries} in info[4q], info[4q + 1]
 // (scan_query_kernel / order_cands_kernel write those): bit0 of the flags = qmax too high, bit5 = fallback pending.
-// kReplayWaves queries per workgroup: the waves live for about a millisecond (a query's pushes are a dependent scalar
-// chain) and hold wave slots the scan kernels' 1024-thread workgroups need — packed 16 to a workgroup they tie up a
-// quarter of the CUs they would tie up four to a workgroup.
-constexpr int kReplayWaves = 16;                                 // (4 and 8 measured the same within noise)
+// kReplayWaves queries per workgroup.  The waves live for about half a millisecond (a query's pushes are a dependent scalar
+// chain) beside the scan kernels.  Round 3 packed 16 to a workgroup so that they tie up few CUs; but a 16-wave workgroup must
+// first FIND half a CU free, and beside the partition-major scan (28 of 32 wave slots taken, in 4-wave workgroups) it waits
+// for that at the head of its queue.  Four to a workgroup start at once in the slots that scan leaves free (see kSideWG).
+#ifndef QADC_REPLAY_WAVES
+#define QADC_REPLAY_WAVES 4
+#endif
+constexpr int kReplayWaves = QADC_REPLAY_WAVES;                  // (round 3 packed 16 to a workgroup; see kSideWG)
 template <int NREG, int QF>
 __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(const uint64_t* __restrict__ stream, const uint64_t* __restrict__ off,
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ info,
@@ -1996,6 +2007,10 @@ __global__ __launch_bounds__(256) void front_unpack_kernel(const unsigned char* 
 
 // ---- the world's gathered blocks -> ONE stream per query in global scan order (assign slot, rank, position) ----
 // Per query: totals and flags over the ranks, exclusive prefix over the queries (one workgroup).
+#ifndef QADC_TOTALS_THREADS
+#define QADC_TOTALS_THREADS 256
+#endif
+constexpr int kTotalsThreads = QADC_TOTALS_THREADS;
 __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world, int nq,
                                                            uint64_t* __restrict__ moff, uint32_t* __restrict__ mcnt,
                                                            uint32_t* __restrict__ info, uint32_t* __restrict__ status) {
@@ -2003,7 +2018,8 @@ __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __res
     __shared__ unsigned long long rank_tot[16];
     __shared__ uint32_t bad;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const int per = (nq + 1023) / 1024;
+    const int nthr = (int)blockDim.x;
+    const int per = (nq + nthr - 1) / nthr;
     const int lo = min(nq, (int)tid * per), hi = min(nq, lo + per);
     if (tid < 16) rank_tot[tid] = 0;
     if (tid == 0) bad = 0;
@@ -2260,7 +2276,7 @@ void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, i
                      uint32_t* d_goff, uint32_t* d_fill, ScanItem* d_items, hipStream_t stream) {
     if (nq <= 0 || ma <= s0) return;
     hipLaunchKernelGGL(ivf_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, d_assign, d_parts, nq, ma, s0, d_cnt);
-    hipLaunchKernelGGL(ivf_offsets_kernel, dim3(1), dim3(1024), 0, stream, d_cnt, K, d_goff);
+    hipLaunchKernelGGL(ivf_offsets_kernel, dim3(1), dim3(kSideWG), 0, stream, d_cnt, K, d_goff);
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, d_assign, d_parts, nq, ma, s0, d_goff,
                        d_fill, d_items);
 }
@@ -2367,7 +2383,7 @@ hipError_t launch_dist_merge(const uint64_t* d_gathered, size_t block_words, int
     static std::atomic<uint64_t> done{0};
     const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&dist_interleave_kernel), 65536, done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dist_totals_kernel, dim3(1), dim3(1024), 0, stream, d_gathered, block_words, world, nq, d_moff, d_mcnt, d_info,
+    hipLaunchKernelGGL(dist_totals_kernel, dim3(1), dim3(kTotalsThreads), 0, stream, d_gathered, block_words, world, nq, d_moff, d_mcnt, d_info,
                        d_status);
     hipLaunchKernelGGL(dist_interleave_kernel, dim3(nq), dim3(256), (size_t)ma * world * 8, stream, d_gathered, block_words, world, nq, ma,
                        d_moff, d_info, d_merged);
