@@ -1477,10 +1477,23 @@ __global__ __launch_bounds__(256) void ivf_count_kernel(const int32_t* __restric
 __global__ __launch_bounds__(kSideWG) void ivf_offsets_kernel(const uint32_t* __restrict__ cnt, int K, uint32_t* __restrict__ goff) {
     __shared__ uint32_t wsum[kSideWG / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const int per = (K + kSideWG - 1) / kSideWG;
+    const int per = ((K + kSideWG - 1) / kSideWG + 3) & ~3;      // a multiple of 4: the runs start 16-byte aligned if the arrays do
+    const bool vec = ((reinterpret_cast<uintptr_t>(cnt) | reinterpret_cast<uintptr_t>(goff)) & 15u) == 0;   // (goff = cnt + 2K: K even)
     const int lo = min(K, (int)tid * per), hi = min(K, lo + per);
     uint32_t mine = 0;
-    for (int p = lo; p < hi; ++p) mine += (cnt[p] + 7u) / 8u;
+    {
+        // (four counters per load, all of a thread's loads in flight: one dependent load per counter made this one-workgroup
+        //  launch — K / 256 = 64 counters per thread at the C5 shape — a chain of 64 round trips on the plan's critical path)
+        int p = lo;
+        for (; vec && p + 16 <= hi; p += 16) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(cnt + p + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mine += (v[u].x + 7u) / 8u + (v[u].y + 7u) / 8u + (v[u].z + 7u) / 8u + (v[u].w + 7u) / 8u;
+        }
+        for (; p < hi; ++p) mine += (cnt[p] + 7u) / 8u;
+    }
     const uint32_t incl = q_wave_incl_sum(mine);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -1489,9 +1502,26 @@ __global__ __launch_bounds__(kSideWG) void ivf_offsets_kernel(const uint32_t* __
         if (w < wave) base += wsum[w];
         total += wsum[w];
     }
-    for (int p = lo; p < hi; ++p) {
-        goff[p] = base;
-        base += (cnt[p] + 7u) / 8u;
+    {
+        int p = lo;
+        for (; vec && p + 16 <= hi; p += 16) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(cnt + p + 4 * u);   // (L2 hits: read a moment ago)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint4 o;
+                o.x = base; base += (v[u].x + 7u) / 8u;
+                o.y = base; base += (v[u].y + 7u) / 8u;
+                o.z = base; base += (v[u].z + 7u) / 8u;
+                o.w = base; base += (v[u].w + 7u) / 8u;
+                *reinterpret_cast<uint4*>(goff + p + 4 * u) = o;
+            }
+        }
+        for (; p < hi; ++p) {
+            goff[p] = base;
+            base += (cnt[p] + 7u) / 8u;
+        }
     }
     if (tid == 0) goff[K] = total;
 }
