@@ -1945,7 +1945,7 @@ __global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* _
     __shared__ uint32_t hist[256];
     __shared__ uint64_t cand[256];
     __shared__ uint32_t ties[256];
-    __shared__ uint32_t s_prefix, s_rank, s_nless, s_nties;
+    __shared__ uint32_t s_prefix, s_rank, s_nless, s_nties, s_kept, s_T0;
     const int q = blockIdx.x, tid = threadIdx.x;
     uint32_t mine[KPT];
 #pragma unroll
@@ -1953,7 +1953,36 @@ __global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* _
         const int k = j * 256 + tid;
         mine[j] = k < K ? __float_as_uint(dist[(size_t)q * K + k]) : 0xffffffffu;
     }
-    if (tid == 0) { s_prefix = 0; s_rank = (uint32_t)ma; s_nless = 0; s_nties = 0; }
+    if (tid == 0) { s_prefix = 0; s_rank = (uint32_t)ma; s_nless = 0; s_nties = 0; s_kept = 0; s_T0 = 0xffffffffu; }
+    __syncthreads();
+    // Threshold first (round 4, as in the query kernel's front select): ma is a percent or less of K, and counting ALL K
+    // distances into digit bins is one LDS atomic per value on one or two hot bins — 16384 serialized adds per pass at the C5
+    // shape.  Wave 0 ranks the first 64 distances (centroid order carries no distance order) and takes the m-th smallest,
+    // m = 1.5 x the ma-th value's expected rank among 64, + 3; only distances <= that take part in the passes (a few
+    // percent of K; the ma smallest are among them as long as at least ma are kept — counted; if not, no filter).
+    if (tid < 64) {
+        const uint32_t sk = mine[0];                             // (k = tid; 0xffffffff past K)
+        const uint32_t m = min(64u, (uint32_t)((96ull * (uint32_t)ma + (uint32_t)K - 1u) / (uint32_t)K) + 3u);
+        uint32_t less = 0, le = 0;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)sk, j);
+            less += kj < sk ? 1u : 0u;
+            le += kj <= sk ? 1u : 0u;
+        }
+        if (less < m && m <= le) s_T0 = sk;
+    }
+    __syncthreads();
+    uint32_t T0 = s_T0;
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) c += (j * 256 + tid < K && mine[j] <= T0) ? 1u : 0u;
+        c = dpp_wave_incl_sum(c);
+        if ((tid & 63) == 63) atomicAdd(&s_kept, c);
+    }
+    __syncthreads();
+    if (s_kept < (uint32_t)ma) T0 = 0xffffffffu;                 // (an unlucky sample: everything takes part, as before)
     for (int pass = 3; pass >= 0; --pass) {
         hist[tid] = 0;
         __syncthreads();
@@ -1961,7 +1990,18 @@ __global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* _
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const uint32_t v = mine[j];
-            if (j * 256 + tid < K && (pass == 3 || (v >> (sh + 8u)) == prefix)) atomicAdd(&hist[(v >> sh) & 255u], 1u);
+            if (j * 256 + tid < K && v <= T0 && (pass == 3 || (v >> (sh + 8u)) == prefix)) {
+                // the lanes that share the first lane's digit add ONE count (the top digits of distances are all but equal)
+                const uint32_t dg = (v >> sh) & 255u;
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)dg);
+                if (dg == lead) {
+                    const uint64_t same = __builtin_amdgcn_ballot_w64(true);
+                    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u)) == 0)
+                        atomicAdd(&hist[lead], (uint32_t)__popcll(same));
+                } else {
+                    atomicAdd(&hist[dg], 1u);
+                }
+            }
         }
         __syncthreads();
         if (tid < 64) {                                          // wave 0: 4 bins per lane, the digit that holds rank s_rank
