@@ -1943,7 +1943,7 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
 template <int KPT>
 __global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* __restrict__ dist, int K, int ma, int32_t* __restrict__ assign) {
     __shared__ uint32_t hist[256];
-    __shared__ uint64_t cand[256];
+    __shared__ __attribute__((aligned(16))) uint64_t cand[256];
     __shared__ uint32_t ties[256];
     __shared__ uint32_t s_prefix, s_rank, s_nless, s_nties, s_kept, s_T0;
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -2064,41 +2064,28 @@ __global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* _
         }
         return;
     }
-    // ties: the need_ties smallest indices among them — sort the (<= 256) tie indices, append the first need_ties
-    uint64_t e = ~0ull;                                          // thread's element of the final sort: (key << 32 | index), padding = max
-    {
-        uint32_t t = (uint32_t)tid < nties ? ties[tid] : 0xffffffffu;
-        __syncthreads();
-        ties[tid] = t;
-        __syncthreads();
-        for (uint32_t size = 2; size <= 256; size <<= 1)
-            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                const uint32_t partner = (uint32_t)tid ^ stride;
-                if (partner > (uint32_t)tid) {
-                    const uint32_t a = ties[tid], b = ties[partner];
-                    const bool up = ((uint32_t)tid & size) == 0;
-                    if ((a > b) == up) { ties[tid] = b; ties[partner] = a; }
-                }
-                __syncthreads();
-            }
-        if ((uint32_t)tid < need_ties) cand[nless + tid] = ((uint64_t)T << 32) | ties[tid];
-        __syncthreads();
+    // ties: the need_ties smallest indices among them; then the ma survivors in (distance, index) order.  Both by COUNTING — an
+    // entry's place is the number of smaller entries, read as LDS broadcasts (indices and keys are distinct) — instead of two
+    // 256-element bitonic networks: 72 barrier steps were most of this kernel (87 us alone on the GPU at the C5 shape for 67 MB of
+    // distances; round 4).
+    if ((uint32_t)tid < nties) {
+        const uint32_t mine_k = ties[tid];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nties; ++j) rank += ties[j] < mine_k ? 1u : 0u;
+        if (rank < need_ties) cand[nless + rank] = ((uint64_t)T << 32) | mine_k;
     }
-    if (tid < ma) e = cand[tid];
     __syncthreads();
-    cand[tid] = e;
-    __syncthreads();
-    for (uint32_t size = 2; size <= 256; size <<= 1)
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            const uint32_t partner = (uint32_t)tid ^ stride;
-            if (partner > (uint32_t)tid) {
-                const uint64_t a = cand[tid], b = cand[partner];
-                const bool up = ((uint32_t)tid & size) == 0;
-                if ((a > b) == up) { cand[tid] = b; cand[partner] = a; }
-            }
-            __syncthreads();
+    if (tid < ma) {
+        const uint64_t key = cand[tid];
+        uint32_t rank = 0;
+        int j = 0;
+        for (; j + 2 <= ma; j += 2) {                            // (two keys per LDS read)
+            const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&cand[j]);
+            rank += (kk.x < key ? 1u : 0u) + (kk.y < key ? 1u : 0u);
         }
-    if (tid < ma) assign[(size_t)q * ma + tid] = (int32_t)(uint32_t)cand[tid];
+        for (; j < ma; ++j) rank += cand[j] < key ? 1u : 0u;
+        assign[(size_t)q * ma + rank] = (int32_t)(uint32_t)key;
+    }
 }
 
 void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
@@ -2187,9 +2174,71 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restri
     }
 }
 
+// The same tables for kBTProbes probes of a query per workgroup (no OPQ rotation, sub-vectors of <= 8 components): a thread
+// keeps its table entry's codebook row in registers and walks the probes, whose residuals wait in LDS.  One workgroup per
+// (query, probe) is 65 K workgroups of 512 results each at the C5 shape — the launch was bound by workgroup dispatch and by
+// re-reading the codebook row per result (92 us alone on the GPU for 134 MB of tables; round 4: -> 8 K workgroups).
+// Entry for entry the arithmetic of build_tables_kernel: the same residual, the same sums in ascending d.
+constexpr int kBTProbes = 8;
+__global__ __launch_bounds__(256) void build_tables_multi_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
+                                                                 const int32_t* __restrict__ assign,
+                                                                 const float* __restrict__ codebooks, int ma, int M, int dim,
+                                                                 int expansion, float* __restrict__ ftables) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    float* res = reinterpret_cast<float*>(dyn);               // [kBTProbes][dim] residuals of this query's probes a0 ..
+    const int a0 = blockIdx.x * kBTProbes, qi = blockIdx.y, tid = threadIdx.x;
+    const int na = min(kBTProbes, ma - a0);
+    const int ds = dim / M;
+    for (int i = tid; i < na * dim; i += 256) {
+        const int a = i / dim, d = i - a * dim;
+        const float x = queries[(size_t)qi * dim + d];
+        res[i] = coarse ? x - coarse[(size_t)assign[(size_t)qi * ma + a0 + a] * dim + d] : x;
+    }
+    __syncthreads();
+    for (int e = tid; e < M * 16; e += 256) {
+        const int m = e >> 4;
+        float ce[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) ce[d] = d < ds ? codebooks[(size_t)e * ds + d] : 0.0f;
+        float cn = 0.0f;                                         // (expansion form: ||c||^2 does not depend on the probe)
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            if (d < ds) cn += ce[d] * ce[d];
+        for (int a = 0; a < na; ++a) {
+            const float* __restrict__ r = res + a * dim + m * ds;
+            float s = 0.0f;
+            if (expansion) {
+                float vn = 0.0f, dot = 0.0f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+                    if (d < ds) {
+                        const float v = r[d];
+                        vn += v * v;
+                        dot += v * ce[d];
+                    }
+                s = (vn + cn) + (-2.0f * dot);
+            } else {
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+                    if (d < ds) {
+                        const float t_ = r[d] - ce[d];
+                        s += t_ * t_;
+                    }
+            }
+            ftables[((size_t)qi * ma + a0 + a) * (M * 16) + e] = s;
+        }
+    }
+}
+
 void launch_build_tables(const float* d_queries, const float* d_coarse, const int32_t* d_assign, const float* d_codebooks,
                          const float* d_rotation, int nq, int ma, int M, int dim, int expansion, float* d_ftables,
                          hipStream_t stream) {
+    if (!d_rotation && dim / M <= 8 && ma > 1) {
+        hipLaunchKernelGGL(build_tables_multi_kernel, dim3((ma + kBTProbes - 1) / kBTProbes, nq), dim3(256),
+                           (size_t)kBTProbes * dim * sizeof(float), stream, d_queries, d_coarse, d_assign, d_codebooks, ma, M, dim,
+                           expansion, d_ftables);
+        return;
+    }
     hipLaunchKernelGGL(build_tables_kernel, dim3(ma, nq), dim3(256), 2 * dim * sizeof(float), stream, d_queries, d_coarse,
                        d_assign, d_codebooks, d_rotation, ma, M, dim, expansion, d_ftables);
 }
