@@ -2174,12 +2174,15 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restri
     }
 }
 
-// The same tables for kBTProbes probes of a query per workgroup (no OPQ rotation, sub-vectors of <= 8 components): a thread
+// The same tables for kBTProbes (16; 8 and 32 within 15 %) probes of a query per workgroup (no OPQ rotation, sub-vectors of <= 8 components): a thread
 // keeps its table entry's codebook row in registers and walks the probes, whose residuals wait in LDS.  One workgroup per
 // (query, probe) is 65 K workgroups of 512 results each at the C5 shape — the launch was bound by workgroup dispatch and by
 // re-reading the codebook row per result (92 us alone on the GPU for 134 MB of tables; round 4: -> 8 K workgroups).
 // Entry for entry the arithmetic of build_tables_kernel: the same residual, the same sums in ascending d.
-constexpr int kBTProbes = 8;
+#ifndef QADC_BT_PROBES
+#define QADC_BT_PROBES 16
+#endif
+constexpr int kBTProbes = QADC_BT_PROBES;
 __global__ __launch_bounds__(256) void build_tables_multi_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
                                                                  const int32_t* __restrict__ assign,
                                                                  const float* __restrict__ codebooks, int ma, int M, int dim,
