@@ -1165,6 +1165,52 @@ def test_dist_merge_kernel_on_virtual_ranks(pyqadc, po, M, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,ma,seed", [(8, 64, 1), (5, 37, 2), (16, 9, 3), (2, 200, 4)])
+def test_dist_interleave_run_bounds_on_synthetic_streams(pyqadc, world, ma, seed):
+    """dist_interleave_kernel derives every (rank, slot) count from the BOUNDS of the slot's run in the rank's stream (a
+    stream is sorted by slot) — the lanes at a run's first and last entry, neighbours compared by shuffle, rows of 64 entries,
+    four rows in flight.  Synthetic streams that lean on exactly that: runs of one entry, runs that start or end on a row
+    boundary (i = 63 / 64 / 255 / 256 / 1023 / 1024), slots missing on some ranks, empty streams, streams of a single
+    run, up to 3000 entries per rank and query.  The device merge must give what the host-share replay (an independent
+    implementation: qadc_dist_merge_blocks_host) gives from the same blocks, heap array for heap array."""
+    rng = np.random.default_rng(9000 + seed)
+    nq, R = 19, 100
+    streams = []
+    for g in range(world):
+        keys, vals, slots, offsets = [], [], [], [0]
+        for q in range(nq):
+            kind = (q + g) % 6
+            if kind == 0:
+                lens = np.zeros(ma, np.int64)                                   # an empty stream
+            elif kind == 1:
+                lens = np.zeros(ma, np.int64)
+                lens[rng.integers(ma)] = int(rng.choice([1, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025]))   # one run
+            elif kind == 2:
+                lens = np.ones(ma, np.int64)                                    # every run a single entry
+                lens[rng.random(ma) < 0.3] = 0
+            else:
+                lens = rng.integers(0, 2 * (3000 // ma) + 2, ma)
+                lens[rng.random(ma) < 0.25] = 0
+                # pad the first runs so that later ones start exactly on row boundaries
+                for target in (64, 256, 1024):
+                    c = np.cumsum(lens)
+                    j = int(np.searchsorted(c, target))
+                    if j < ma and c[j] >= target and lens[j] > 0:
+                        lens[j] -= c[j] - target
+            n = int(lens.sum())
+            slots.append(np.repeat(np.arange(ma), lens))
+            keys.append(rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32))
+            vals.append(rng.integers(0, 127, n).astype(np.int8))
+            offsets.append(offsets[-1] + n)
+        streams.append(dict(keys=np.concatenate(keys), vals=np.concatenate(vals), slots=np.concatenate(slots).astype(np.uint32),
+                            offsets=np.asarray(offsets, np.uint64)))
+    got = pyqadc.dist_merge_blocks(streams, nq, ma, R)
+    want = pyqadc.dist_merge_blocks(streams, nq, ma, R, host=True)
+    for q in range(nq):
+        assert np.array_equal(got[q][0], want[q][0]) and np.array_equal(got[q][1], want[q][1]), q
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R", [1, 2, 3, 31, 62, 63, 64, 65, 100, 126, 127, 128, 129, 190, 191, 192, 254, 255, 256, 300, 318, 319, 320])
 def test_wave_replay_kernel_against_the_heap_oracle(pyqadc, po, R):
     """replay_heap_wave_kernel alone (through qadc_dist_merge_blocks with a world of one rank): arbitrary push streams —
