@@ -2142,8 +2142,8 @@ __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __
     if (ma > 1) {
         // A rank's stream is in scan order, i.e. sorted by slot: a slot's count is the length of its RUN.  The lanes at a run's
         // first and last entry store its bounds (plain LDS stores: a few dozen per rank); counting every entry with two LDS
-        // atomics — 64 lanes of a wave on the same counter, since neighbours share the slot — was most of this kernel
-        // (round 4: 90 -> 55 us per 1024-query batch of the C5 shape alone on the GPU).
+        // atomics — 64 lanes of a wave on the same counter, since neighbours share the slot — serialised every one of them.
+        // (Round 4.  It did not move a rank's pipelined batch: beside the scans this launch waits for wave slots)
         for (int g = 0; g < world; ++g) {
             const uint32_t* hdr = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * block_words) + 4 * (size_t)q;
             const uint64_t* __restrict__ ent = gathered + (size_t)g * block_words + 2 * (size_t)nq + hdr[0];
