@@ -87,7 +87,9 @@ int qadc_index_partition_count(const qadc_index* idx);
 uint32_t qadc_index_partition_size(const qadc_index* idx, int part);
 uint32_t qadc_index_start_size(const qadc_index* idx, int part);
 
-/* Tunables: "quant_mode" (1 = as compiled by the reference's flags, 0 = source level), "profile" (0/1),
+/* Tunables: "quant_mode" (1 = as compiled by the reference's flags, 0 = source level), "sum_mode" (grouping of the float
+ * sums of the pre-scan [scan_4, query_common.hpp:72-80] and of the direct table form [fmanorm, distances.hpp:60-76]:
+ * 1 = as the reference binary adds them — it is built with -ffast-math, CMakeLists.txt:7 —, 0 = source order), "profile" (0/1),
  * "cand_capacity" (candidate region entries per query), "level_base", "level_growth" (bound levels),
  * "prescan_sample", "small_run", "small_vec_per_wg", "wgs_per_item", "variant", "share_variant" (0 = never
  * launch the queries of a batch as L2-sharing siblings), "share_codes_per_wg", "mq" (8 queries per pass),

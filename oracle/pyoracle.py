@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_SO = os.path.join(_HERE, "libqadc_oracle.so")
 _REF_SO = os.path.join(_HERE, "_ref", "libqadc_ref.so")
 _REF_IO_SO = os.path.join(_HERE, "_ref", "libqadc_ref_io.so")
+_REF_FLOAT_SO = os.path.join(_HERE, "_ref", "libqadc_ref_float.so")
 
 u8p = C.POINTER(C.c_uint8)
 i8p = C.POINTER(C.c_int8)
@@ -30,6 +31,8 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "libqadc_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_SO) or not os.path.exists(_REF_IO_SO)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_FLOAT_SO)):
+        subprocess.check_call(["make", "-C", _HERE, "ref_float"], stdout=subprocess.DEVNULL)
 
 
 def _p(a, t):
@@ -195,21 +198,34 @@ def candidates_i8(M, codes, qt):
     return out
 
 
-def candidates_f32(M, codes, dists):
+def candidates_f32(M, codes, dists, sum_mode=1):
     codes = np.ascontiguousarray(codes, np.uint8)
     dists = np.ascontiguousarray(dists, np.float32)
     out = np.zeros(codes.shape[0], np.float32)
-    lib().orc_candidates_f32(M, _p(codes, u8p), C.c_long(codes.shape[0]), _p(dists, f32p), _p(out, f32p))
+    lib().orc_candidates_f32_mode(M, _p(codes, u8p), C.c_long(codes.shape[0]), _p(dists, f32p), sum_mode, _p(out, f32p))
     return out
 
 
-def scan_standard_u8(NSQ, parts, labels, tables, R):
+def scan4_start(M, parts, labels, tables, R, sum_mode=1):
+    """query_scan_start alone: push(0, FLT_MAX) + scan_4<M> over each run with its table -> float heap (keys, values)."""
+    parts = [np.ascontiguousarray(p, np.uint8) for p in parts]
     sizes = np.array([p.shape[0] for p in parts], np.uint32)
     pa, keep1 = _ptr_array(parts, u8p)
     la, keep2 = _ptr_array(labels, u32p) if labels is not None else (None, None)
     tb = np.ascontiguousarray(tables, np.float32)
     ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.float32), C.c_int(0)
-    lib().orc_scan_standard_u8(NSQ, len(parts), pa, la, _p(sizes, u32p), _p(tb, f32p), R,
+    lib().orc_scan4_start(M, len(parts), pa, la, _p(sizes, u32p), _p(tb, f32p), R, sum_mode,
+                          _p(ok, u32p), _p(ov, f32p), C.byref(osz))
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def scan_standard_u8(NSQ, parts, labels, tables, R, sum_mode=1):
+    sizes = np.array([p.shape[0] for p in parts], np.uint32)
+    pa, keep1 = _ptr_array(parts, u8p)
+    la, keep2 = _ptr_array(labels, u32p) if labels is not None else (None, None)
+    tb = np.ascontiguousarray(tables, np.float32)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.float32), C.c_int(0)
+    lib().orc_scan_standard_u8(NSQ, len(parts), pa, la, _p(sizes, u32p), _p(tb, f32p), R, sum_mode,
                                _p(ok, u32p), _p(ov, f32p), C.byref(osz))
     return ok[:osz.value].copy(), ov[:osz.value].copy()
 
@@ -222,11 +238,21 @@ def quantize_tables(tables, qmin, qmax, mode=1):
     return out
 
 
+def tables_direct(centroids, vector, sum_mode=1):
+    """Direct table form (compute_dists_single_simd_cg): centroids [M][16][dsq], vector [M*dsq] -> [M*16] float32."""
+    cf = np.ascontiguousarray(centroids, np.float32)
+    M, _, dsq = cf.shape
+    v = np.ascontiguousarray(vector, np.float32)
+    out = np.zeros(M * 16, np.float32)
+    lib().orc_tables_direct(dsq, M, _p(cf, f32p), _p(v, f32p), sum_mode, _p(out, f32p))
+    return out
+
+
 def start_size(size, keep):
     return int(lib().orc_start_size(int(size), C.c_float(keep)))
 
 
-def query_scan(M, parts, labels, keep, assign, tables, R, quant_mode=1):
+def query_scan(M, parts, labels, keep, assign, tables, R, quant_mode=1, sum_mode=1):
     """Whole scanner_4::query_scan on row-major database partitions.  `tables` [ma][M*16] float32 is
     modified in place (negative clamp).  Returns dict(rc, qmin, qmax, qtables, keys, values)."""
     sizes = np.array([p.shape[0] for p in parts], np.uint32)
@@ -239,7 +265,7 @@ def query_scan(M, parts, labels, keep, assign, tables, R, quant_mode=1):
     qt = np.zeros((ma, M, 16), np.int8)
     ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.int8), C.c_int(0)
     rc = lib().orc_query_scan(M, pa, la, _p(sizes, u32p), C.c_float(keep), _p(assign, i32p), ma,
-                              _p(tables, f32p), R, quant_mode, C.byref(qmin), C.byref(qmax),
+                              _p(tables, f32p), R, quant_mode, sum_mode, C.byref(qmin), C.byref(qmax),
                               _p(qt, i8p), _p(ok, u32p), _p(ov, i8p), C.byref(osz))
     return dict(rc=rc, qmin=qmin.value, qmax=qmax.value, qtables=qt,
                 keys=ok[:osz.value].copy(), values=ov[:osz.value].copy())
@@ -439,3 +465,153 @@ def ref_check_labels(gt_filename, keys, t):
     rc = ref_io().qadc_ref_io_check_labels(gt_filename.encode(), k.shape[0], _p(k, u32p), k.shape[1], t, _p(out, i32p))
     assert rc == 0
     return out
+
+
+# ----------------------------------------------------------------------------- reference build: the float half
+# oracle/_ref/libqadc_ref_float.so = QuantizerMAX, scan_4, scanner_4 (whole), scanner_simple, base_pq, multiple_set_bits_4,
+# fmanorm / compute_dists_single_simd_cg and substract_vectors_from_unique compiled from line ranges of the reference's own
+# files (oracle/ref_extract.sh, oracle/ref_float_harness.cpp).  Pins rows A5 / A6 / A7 / A8 and the direct form of A10.
+_ref_float = None
+
+
+def have_ref_float():
+    return os.path.exists(_REF_FLOAT_SO)
+
+
+def ref_float():
+    global _ref_float
+    if _ref_float is None:
+        _ref_float = C.CDLL(_REF_FLOAT_SO)
+        _ref_float.qadc_reff_scanner4_create.restype = C.c_void_p
+    return _ref_float
+
+
+def reff_quantize_tables(tables, qmin, qmax):
+    """QuantizerMAX<int8_t>(qmin, qmax).quantize_tables as compiled here; tables [..., 16] float32."""
+    tb = np.ascontiguousarray(tables, np.float32)
+    assert tb.size % 16 == 0
+    out = np.zeros(tb.shape, np.int8)
+    ref_float().qadc_reff_quantize_tables(_p(tb, f32p), tb.size // 16, C.c_float(qmin), C.c_float(qmax), _p(out, i8p))
+    return out
+
+
+def reff_scan4_start(M, parts, labels, tables, R):
+    """push(0, FLT_MAX) + scan_4<M> over each run with its table -> float heap (keys, values); qmax = values[0]."""
+    parts = [np.ascontiguousarray(p, np.uint8) for p in parts]
+    sizes = np.array([p.shape[0] for p in parts], np.uint32)
+    pa, keep1 = _ptr_array(parts, u8p)
+    la, keep2 = _ptr_array(labels, u32p) if labels is not None else (None, None)
+    tb = np.ascontiguousarray(tables, np.float32)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.float32), C.c_int(0)
+    rc = ref_float().qadc_reff_scan4_start(M, len(parts), pa, la, _p(sizes, u32p), _p(tb, f32p), R,
+                                           _p(ok, u32p), _p(ov, f32p), C.byref(osz))
+    assert rc == 0
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def reff_scan_standard_u8(NSQ, parts, labels, tables, R):
+    """scanner_simple::query_scan (db_query.cpp:26-45) over an in-memory database -> float heap."""
+    parts = [np.ascontiguousarray(p, np.uint8) for p in parts]
+    sizes = np.array([p.shape[0] for p in parts], np.uint32)
+    pa, keep1 = _ptr_array(parts, u8p)
+    la, keep2 = _ptr_array(labels, u32p) if labels is not None else (None, None)
+    tb = np.ascontiguousarray(tables, np.float32)
+    ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.float32), C.c_int(0)
+    rc = ref_float().qadc_reff_scan_standard_u8(NSQ, len(parts), pa, la, _p(sizes, u32p), _p(tb, f32p), R,
+                                                _p(ok, u32p), _p(ov, f32p), C.byref(osz))
+    assert rc == 0
+    return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+
+def reff_pack4(assign, M):
+    assign = np.ascontiguousarray(assign, np.int32)
+    n = assign.shape[0]
+    codes = np.zeros((n, M // 2), np.uint8)
+    ref_float().qadc_reff_pack4(_p(assign, i32p), C.c_long(n), M, _p(codes, u8p))
+    return codes
+
+
+def reff_tables_direct(centroids, vector):
+    """compute_dists_single_simd_cg<DSQ>: centroids [M][16][DSQ], vector [M*DSQ] -> [M*16] float32."""
+    cf = np.ascontiguousarray(centroids, np.float32)
+    M, _, dsq = cf.shape
+    v = np.ascontiguousarray(vector, np.float32)
+    out = np.zeros(M * 16, np.float32)
+    rc = ref_float().qadc_reff_tables_direct(dsq, M, _p(cf, f32p), _p(v, f32p), _p(out, f32p))
+    assert rc == 0, "the reference's dispatch has no case for sq_dim %d" % dsq
+    return out
+
+
+def reff_substract_from_unique(vector, base_vectors, assign):
+    v = np.ascontiguousarray(vector, np.float32)
+    b = np.ascontiguousarray(base_vectors, np.float32)
+    a = np.ascontiguousarray(assign, np.int32)
+    out = np.zeros((len(a), len(v)), np.float32)
+    ref_float().qadc_reff_substract_from_unique(_p(v, f32p), len(v), _p(b, f32p), _p(a, i32p), len(a), _p(out, f32p))
+    return out
+
+
+class RefScanner4:
+    """The reference's scanner_4, whole (db_query_4.cpp:73-310), over row-major partitions held in memory."""
+
+    def __init__(self, M, parts, labels, keep):
+        self.M = M
+        parts = [np.ascontiguousarray(p, np.uint8).reshape(-1, M // 2) for p in parts]
+        self.nparts = len(parts)
+        sizes = np.array([p.shape[0] for p in parts], np.uint32)
+        pa, keep1 = _ptr_array(parts, u8p)
+        la, keep2 = _ptr_array(labels, u32p) if labels is not None else (None, None)
+        self._h = C.c_void_p(ref_float().qadc_reff_scanner4_create(M, C.c_float(keep), self.nparts, pa, la, _p(sizes, u32p)))
+        assert self._h
+
+    @staticmethod
+    def try_prepare(M, parts, labels, keep):
+        """exit status of prepare_database in a child process; labels: list with None entries allowed (mixed)."""
+        parts = [np.ascontiguousarray(p, np.uint8).reshape(-1, M // 2) for p in parts]
+        sizes = np.array([p.shape[0] for p in parts], np.uint32)
+        pa, keep1 = _ptr_array(parts, u8p)
+        la = None
+        if labels is not None:
+            keep2 = [None if l is None else np.ascontiguousarray(l, np.uint32) for l in labels]
+            la = (u32p * len(keep2))(*[None if l is None else _p(l, u32p) for l in keep2])
+        return ref_float().qadc_reff_scanner4_try_prepare(M, C.c_float(keep), len(parts), pa, la, _p(sizes, u32p))
+
+    def close(self):
+        if self._h:
+            ref_float().qadc_reff_scanner4_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def sizes(self):
+        st, ps, hl = np.zeros(self.nparts, np.uint32), np.zeros(self.nparts, np.uint32), C.c_int(0)
+        ref_float().qadc_reff_scanner4_sizes(self._h, _p(st, u32p), _p(ps, u32p), C.byref(hl))
+        return st, ps, bool(hl.value)
+
+    def query_start(self, assign, tables, R):
+        a = np.ascontiguousarray(assign, np.int32)
+        tb = np.ascontiguousarray(tables, np.float32)
+        ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.float32), C.c_int(0)
+        ref_float().qadc_reff_scanner4_query_start(self._h, _p(a, i32p), len(a), _p(tb, f32p), R,
+                                                   _p(ok, u32p), _p(ov, f32p), C.byref(osz))
+        return ok[:osz.value].copy(), ov[:osz.value].copy()
+
+    def try_query(self, assign, tables, R):
+        a = np.ascontiguousarray(assign, np.int32)
+        tb = np.ascontiguousarray(tables, np.float32)
+        return ref_float().qadc_reff_scanner4_try_query(self._h, _p(a, i32p), len(a), _p(tb, f32p), R)
+
+    def query_scan(self, assign, tables, R, want_sorted=False):
+        """`tables` float32 [ma][M*16], C-contiguous, modified in place (negative clamp).  EXITS the process if
+        qmax > 1e30: call try_query first where that can happen."""
+        a = np.ascontiguousarray(assign, np.int32)
+        assert tables.dtype == np.float32 and tables.flags.c_contiguous
+        ok, ov, osz = np.zeros(R, np.uint32), np.zeros(R, np.int8), C.c_int(0)
+        sk = np.zeros(R, np.uint32)
+        ref_float().qadc_reff_scanner4_query_scan(self._h, _p(a, i32p), len(a), _p(tables, f32p), R,
+                                                  _p(ok, u32p), _p(ov, i8p), C.byref(osz),
+                                                  _p(sk, u32p) if want_sorted else None)
+        if want_sorted:
+            return ok[:osz.value].copy(), ov[:osz.value].copy(), sk[:osz.value].copy()
+        return ok[:osz.value].copy(), ov[:osz.value].copy()

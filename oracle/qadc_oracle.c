@@ -12,11 +12,19 @@
  *       PINNED — checked entry-by-entry against the reference's own kernels compiled
  *       from /root/reference into oracle/_ref/libqadc_ref.so (tests/test_oracle_vs_ref.py)
  *       and against the committed fixtures in tests/golden/ generated from that build.
- *   - float start scan, QuantizerMAX, query_scan glue (orc_scan4_f32, orc_quantize_tables,
- *       orc_query_scan): PARITY UNPINNED.  Their translation unit (db_query_4.cpp /
- *       query_common.hpp) needs Cereal, cblas and OpenCV headers that this image lacks,
- *       so it cannot be compiled here without stand-ins; they are restated from the
- *       source text plus the as-compiled behaviour recorded in SURVEY.md §8 row A5.
+ *   - float start scan, QuantizerMAX, query_scan glue, start sizes, the direct table form, scan_standard, the 4-bit
+ *       packer (orc_scan4_start, orc_candidates_f32, orc_quantize_tables, orc_query_scan, orc_start_size,
+ *       orc_tables_direct, orc_scan_standard_u8, orc_pack4):
+ *       PINNED — checked bit for bit against the reference's own scanner_4 (whole), QuantizerMAX, scan_4,
+ *       scan_standard, fmanorm / compute_dists_single_simd_cg and multiple_set_bits_4, compiled with the reference's
+ *       flags from line ranges of its files into oracle/_ref/libqadc_ref_float.so (oracle/ref_extract.sh,
+ *       oracle/ref_float_harness.cpp; tests/test_oracle_float_ref.py: 10^4 random queries, 1.6 M quantizer entries,
+ *       every sq_dim of the reference's dispatch) and against tests/golden/ref_query_scan_cases.npz generated from
+ *       that build (oracle/gen_golden_float.py).  The reference is built with -ffast-math, so "as the source reads"
+ *       and "as the binary computes" differ in the grouping of float sums; where they do, mode 1 (the default) is the
+ *       binary's and mode 0 the source's.
+ *   - NOT pinned (third-party arithmetic absent from this image): the BLAS-expansion table form and find_k_neighbors
+ *       (OpenBLAS cblas_sgemm, distances.hpp:151-183, neighbors.cpp:30-76), cv::kmeans — not restated here at all.
  *
  * Build: strict IEEE (no -ffast-math) so every float expression evaluates exactly as
  * written here.
@@ -25,6 +33,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <math.h>
 
 /* ------------------------------------------------------------------------------------------
  * kv_binheap<unsigned, T>::push  — binheap.hpp:75-116
@@ -366,21 +375,53 @@ void orc_candidates_i8(int M, const uint8_t* codes, long n, const int8_t* qt, in
 }
 
 /* ------------------------------------------------------------------------------------------
- * scan_4<NSQ> — query_common.hpp:59-90.  Float ADC on row-major 4-bit codes; the sum is
- * accumulated sequentially from 0: byte by byte, low nibble then high nibble (72-80);
- * push iff cand < min, min refreshed after every push (81-88).
+ * scan_4<NSQ> — query_common.hpp:59-90.  Float ADC on row-major 4-bit codes; push iff
+ * cand < min, min refreshed after every push (81-88).  The SOURCE accumulates sequentially
+ * from 0, byte by byte, low nibble then high nibble (72-80); the reference is built with
+ * -ffast-math, which lets the compiler re-associate that sum, and it does.
+ *
+ * sum_mode 1 (default) = the association of the reference AS COMPILED HERE (g++ 11.4,
+ *   -O3 -ffast-math; same with -march=native and with the explicit ISA list), read off the
+ *   disassembly of the stand-alone scan_4<16> / scan_4<32> instances in
+ *   oracle/_ref/libqadc_ref_float.so and pinned to that binary by tests/test_oracle_float_ref.py.
+ *   With L_b = dists[(2b)*16 + lo(byte b)], H_b = dists[(2b+1)*16 + hi(byte b)]:
+ *     A = (H2+L3)+(H3+L4)   B = (H0+L1)+(H1+L2)   C = (H5+L6)+(H4+L5)   D = (H6+L7)+(H7+L0)
+ *     s = ((A+B)+C)+D                                   bytes 0..7 (all of NSQ=16)
+ *     s = s + ((L_{b+1}+H_{b+1}) + (L_b+H_b))           b = 8, 10, 12, 14   (NSQ=32 only)
+ *   (IEEE addition is commutative, so only the grouping matters.)
+ * sum_mode 0 = source order.
  * ---------------------------------------------------------------------------------------- */
-static void scan4_f32(orc_heap_f32* h, int M, const uint8_t* codes, const uint32_t* labels,
-                      uint32_t count, const float* dists) {
+static inline float adc4_f32(int M, const uint8_t* c, const float* dists, int sum_mode) {
     const int cs = M / 2;
-    float min = h->vals[0];
-    for (uint32_t i = 0; i < count; ++i) {
-        const uint8_t* c = codes + (long)i * cs;
+    if (sum_mode == 0) {
         float cand = 0;
         for (int b = 0; b < cs; ++b) {
             cand += dists[(2 * b) * 16 + (c[b] & 0xf)];
             cand += dists[(2 * b + 1) * 16 + ((c[b] & 0xf0) >> 4)];
         }
+        return cand;
+    }
+    float L[16], H[16];
+    for (int b = 0; b < cs; ++b) {
+        L[b] = dists[(2 * b) * 16 + (c[b] & 0xf)];
+        H[b] = dists[(2 * b + 1) * 16 + (c[b] >> 4)];
+    }
+    const float A = (H[2] + L[3]) + (H[3] + L[4]);
+    const float B = (H[0] + L[1]) + (H[1] + L[2]);
+    const float Cq = (H[5] + L[6]) + (H[4] + L[5]);
+    const float D = (H[6] + L[7]) + (H[7] + L[0]);
+    float s = ((A + B) + Cq) + D;
+    for (int b = 8; b < cs; b += 2)
+        s = s + ((L[b + 1] + H[b + 1]) + (L[b] + H[b]));
+    return s;
+}
+
+static void scan4_f32(orc_heap_f32* h, int M, const uint8_t* codes, const uint32_t* labels,
+                      uint32_t count, const float* dists, int sum_mode) {
+    const int cs = M / 2;
+    float min = h->vals[0];
+    for (uint32_t i = 0; i < count; ++i) {
+        const float cand = adc4_f32(M, codes + (long)i * cs, dists, sum_mode);
         if (cand < min) {
             orc_heap_f32_push(h, labels ? labels[i] : i, cand);
             min = h->vals[0];
@@ -388,26 +429,58 @@ static void scan4_f32(orc_heap_f32* h, int M, const uint8_t* codes, const uint32
     }
 }
 
-/* Per-code float ADC values with the same summation order (test helper). */
-void orc_candidates_f32(int M, const uint8_t* codes, long n, const float* dists, float* out) {
+/* Per-code float ADC values in either summation order (test helper). */
+void orc_candidates_f32_mode(int M, const uint8_t* codes, long n, const float* dists, int sum_mode, float* out) {
     const int cs = M / 2;
-    for (long i = 0; i < n; ++i) {
-        float cand = 0;
-        for (int b = 0; b < cs; ++b) {
-            cand += dists[(2 * b) * 16 + (codes[i * cs + b] & 0xf)];
-            cand += dists[(2 * b + 1) * 16 + (codes[i * cs + b] >> 4)];
-        }
-        out[i] = cand;
-    }
+    for (long i = 0; i < n; ++i) out[i] = adc4_f32(M, codes + i * cs, dists, sum_mode);
+}
+void orc_candidates_f32(int M, const uint8_t* codes, long n, const float* dists, float* out) {
+    orc_candidates_f32_mode(M, codes, n, dists, 1, out);
+}
+
+/* query_scan_start alone (db_query_4.cpp:230-242): push (0, FLT_MAX), then scan_4 over each run with its table. */
+int orc_scan4_start(int M, int nparts, const uint8_t* const* parts, const uint32_t* const* labels,
+                    const uint32_t* sizes, const float* tables, int R, int sum_mode,
+                    uint32_t* out_keys, float* out_vals, int* out_size) {
+    orc_heap_f32 h = { out_keys, out_vals, R, 0 };
+    orc_heap_f32_push(&h, 0, FLT_MAX);
+    for (int p = 0; p < nparts; ++p)
+        scan4_f32(&h, M, parts[p], labels ? labels[p] : NULL, sizes[p], tables + (long)p * M * 16, sum_mode);
+    *out_size = h.size;
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------
  * scan_standard<uint8_t,NSQ> — query_common.hpp:92-118 (BASELINE config 1: PQ 8x8 float ADC),
  * preceded by scanner_simple::query_scan's R sentinel pushes (db_query.cpp:32-34).
- * codes row-major [n][NSQ] bytes, dists [NSQ][256].
+ * codes row-major [n][NSQ] bytes, dists [NSQ][256].  The source adds t_m = dists[m*256 + code[m]]
+ * sequentially from 0; sum_mode 1 = the grouping of the reference as compiled here (same build and
+ * same pin as scan_4 above; instances NSQ = 4, 8, 16 exist in the reference, query_common.hpp:126-131):
+ *   NSQ 4:  (t1+t2) + (t3+t0)
+ *   NSQ 8:  ((t1+t2)+(t3+t4)) + ((t5+t6)+(t7+t0))
+ *   NSQ 16: ((A+B)+C)+D,  A = (t5+t6)+(t7+t8)  B = (t1+t2)+(t3+t4)  C = (t11+t12)+(t9+t10)  D = (t13+t14)+(t15+t0)
+ *           (the 16-term grouping of scan_4<16>, whose terms are L0,H0,L1,H1,...)
+ * sum_mode 0 (or another NSQ) = source order.
  * ---------------------------------------------------------------------------------------- */
+static inline float adc8_f32(int NSQ, const uint8_t* c, const float* dists, int sum_mode) {
+    float t[16] = {0};
+    if (sum_mode == 0 || !(NSQ == 4 || NSQ == 8 || NSQ == 16)) {
+        float cand = 0;
+        for (int m = 0; m < NSQ; ++m) cand += dists[m * 256 + c[m]];
+        return cand;
+    }
+    for (int m = 0; m < NSQ; ++m) t[m] = dists[m * 256 + c[m]];
+    if (NSQ == 4) return (t[1] + t[2]) + (t[3] + t[0]);
+    if (NSQ == 8) return ((t[1] + t[2]) + (t[3] + t[4])) + ((t[5] + t[6]) + (t[7] + t[0]));
+    const float A = (t[5] + t[6]) + (t[7] + t[8]);
+    const float B = (t[1] + t[2]) + (t[3] + t[4]);
+    const float Cq = (t[11] + t[12]) + (t[9] + t[10]);
+    const float D = (t[13] + t[14]) + (t[15] + t[0]);
+    return ((A + B) + Cq) + D;
+}
+
 int orc_scan_standard_u8(int NSQ, int nparts, const uint8_t* const* parts, const uint32_t* const* labels,
-                         const uint32_t* sizes, const float* tables, int R,
+                         const uint32_t* sizes, const float* tables, int R, int sum_mode,
                          uint32_t* out_keys, float* out_vals, int* out_size) {
     orc_heap_f32 h = { out_keys, out_vals, R, 0 };
     for (int t = 0; t < R; ++t) orc_heap_f32_push(&h, 0, FLT_MAX - (float)t);
@@ -416,9 +489,7 @@ int orc_scan_standard_u8(int NSQ, int nparts, const uint8_t* const* parts, const
         const uint32_t* lab = labels ? labels[p] : NULL;
         float min = h.vals[0];
         for (uint32_t i = 0; i < sizes[p]; ++i) {
-            const uint8_t* c = parts[p] + (long)i * NSQ;
-            float cand = 0;
-            for (int m = 0; m < NSQ; ++m) cand += dists[m * 256 + c[m]];
+            const float cand = adc8_f32(NSQ, parts[p] + (long)i * NSQ, dists, sum_mode);
             if (cand < min) {
                 orc_heap_f32_push(&h, lab ? lab[i] : i, cand);
                 min = h.vals[0];
@@ -447,6 +518,68 @@ void orc_quantize_tables(const float* tables, long count, float qmin, float qmax
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Direct table form: compute_dists_single_simd_cg<DSQ> -> fmanorm<DSQ/8, DSQ%8>(subvector, centroid)
+ * (distances.hpp:294-311, 60-76, 27-36).  centroids [M][16][dsq], vector [M*dsq], dists [M*16].
+ *
+ * sum_mode 1 = the reference AS COMPILED HERE (pinned to oracle/_ref/libqadc_ref_float.so for every
+ *   sq_dim of the reference's dispatch, distances.cpp:50-84, by tests/test_oracle_float_ref.py):
+ *     vector part  acc[j] = fma(d, d, acc[j]) per AVX lane j over the DSQ/8 blocks, d = x - c, acc from 0
+ *                  (the first fma is r(d*d) exactly), then reduceadd's tree:
+ *                  r[j] = acc[j] + acc[j+4] (j < 4);  (r[0] + r[2]) + (r[1] + r[3])
+ *     remainder    d = c - x, g++ -ffast-math -mfma pairs the scalar loop `norm += d*d` as
+ *                  p_k = fma(d_2k, d_2k, r(d_{2k+1} * d_{2k+1})) and groups
+ *                    REM 4 (sq_dim 4, 60):  (p0 + p1) + vec          (vec = 0 for sq_dim 4)
+ *                    REM 6 (sq_dim 30):     (vec + p2) + (p0 + p1)
+ *   Other remainders have no instance in the reference (sq_dim 3 of BASELINE configs[4] is not in its
+ *   dispatch): they take sum_mode 0's loop.  Returns 1 when the as-compiled form was used, else 0.
+ * sum_mode 0 = one sequential float loop s += (x - c)^2 in ascending d, no fused multiply-add (this
+ *   repository's own order from before the float half was pinned).
+ * ---------------------------------------------------------------------------------------- */
+static float tables_direct_seq(int dsq, const float* x, const float* c) {
+    float s = 0;
+    for (int d = 0; d < dsq; ++d) {
+        const float t = x[d] - c[d];
+        const float sq = t * t;
+        s = s + sq;
+    }
+    return s;
+}
+
+static float tables_direct_compiled(int dsq, const float* x, const float* c) {
+    const int blocks = dsq / 8, rem = dsq % 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < blocks; ++b)
+        for (int j = 0; j < 8; ++j) {
+            const float d = x[b * 8 + j] - c[b * 8 + j];
+            acc[j] = fmaf(d, d, acc[j]);
+        }
+    const float r0 = acc[0] + acc[4], r1 = acc[1] + acc[5], r2 = acc[2] + acc[6], r3 = acc[3] + acc[7];
+    const float vec = (r0 + r2) + (r1 + r3);
+    if (rem == 0) return vec;
+    float p[3] = {0, 0, 0};
+    for (int k = 0; k < rem / 2; ++k) {
+        const float d0 = c[blocks * 8 + 2 * k] - x[blocks * 8 + 2 * k];
+        const float d1 = c[blocks * 8 + 2 * k + 1] - x[blocks * 8 + 2 * k + 1];
+        const float sq1 = d1 * d1;
+        p[k] = fmaf(d0, d0, sq1);
+    }
+    if (rem == 4) return (p[0] + p[1]) + vec;
+    return (vec + p[2]) + (p[0] + p[1]);                      /* rem == 6 */
+}
+
+int orc_tables_direct(int dsq, int M, const float* centroids, const float* vector, int sum_mode, float* dists) {
+    const int rem = dsq % 8;
+    const int compiled = sum_mode != 0 && (rem == 0 || rem == 4 || rem == 6);
+    for (int m = 0; m < M; ++m)
+        for (int cent = 0; cent < 16; ++cent) {
+            const float* x = vector + (long)m * dsq;
+            const float* c = centroids + ((long)m * 16 + cent) * dsq;
+            dists[m * 16 + cent] = compiled ? tables_direct_compiled(dsq, x, c) : tables_direct_seq(dsq, x, c);
+        }
+    return compiled;
+}
+
 /* starts size — db_query_4.cpp:125-126: max(1u, unsigned(size * keep)), product in float. */
 uint32_t orc_start_size(uint32_t size, float keep) {
     if (size == 0) return 0;
@@ -463,7 +596,7 @@ uint32_t orc_start_size(uint32_t size, float keep) {
  * ---------------------------------------------------------------------------------------- */
 int orc_query_scan(int M, const uint8_t* const* all_parts, const uint32_t* const* all_labels,
                    const uint32_t* all_sizes, float keep, const int32_t* assign, int ma,
-                   float* tables, int R, int quant_mode,
+                   float* tables, int R, int quant_mode, int sum_mode,
                    float* out_qmin, float* out_qmax, int8_t* out_qtables,
                    uint32_t* out_keys, int8_t* out_vals, int* out_size) {
     const int table_dim = M * 16;
@@ -475,7 +608,7 @@ int orc_query_scan(int M, const uint8_t* const* all_parts, const uint32_t* const
     for (int a = 0; a < ma; ++a) {
         const int p = assign[a];
         const uint32_t s = orc_start_size(all_sizes[p], keep);
-        scan4_f32(&th, M, all_parts[p], all_labels ? all_labels[p] : NULL, s, tables + (long)a * table_dim);
+        scan4_f32(&th, M, all_parts[p], all_labels ? all_labels[p] : NULL, s, tables + (long)a * table_dim, sum_mode);
     }
     float qmax = th.vals[0];
     free(tk); free(tv);

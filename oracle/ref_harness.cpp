@@ -13,7 +13,8 @@
 // No stand-in headers or libraries are involved: these three headers need only
 // <immintrin.h> and the STL.  db_query_4.cpp (scanner_4, QuantizerMAX) and
 // query_common.hpp (scan_4) pull in Cereal/cblas/OpenCV through databases.hpp and
-// are therefore NOT buildable here; they are restated in qadc_oracle.c.
+// do not compile as whole files; the functions of theirs that are on the path are
+// compiled from line ranges of those files by ref_float_harness.cpp (libqadc_ref_float.so).
 //
 // What the harness itself adds (and nothing more): the call sequence of
 // scanner_4::query_scan's integer half (db_query_4.cpp:276, 287-308):

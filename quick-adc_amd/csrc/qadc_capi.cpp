@@ -380,7 +380,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
             d_ft = s.d_ftables.p;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_feed, 0));
             launch_build_tables(s.d_queries.p, idx->feed.K ? idx->feed.d_coarse.p : nullptr, s.d_assign.p, idx->feed.d_codebooks.p,
-                                idx->feed.has_rotation ? idx->feed.d_rotation.p : nullptr, nq, ma, M, idx->feed.dim, table_expansion(idx, ma), d_ft, st);
+                                idx->feed.has_rotation ? idx->feed.d_rotation.p : nullptr, nq, ma, M, idx->feed.dim, table_expansion(idx, ma), idx->sum_mode, d_ft, st);
         }
         HIPCHECK(s.d_fc.ensure((size_t)nq * fc_stride));
         if (idx->profile) HIPCHECK(prof_event(s, st));
@@ -401,10 +401,10 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         };
         auto start_scan = [&](const std::vector<StartItem>& v, const StartItem* d_v) {
             if (shared_items(v))
-                launch_start_scan_mq(M, d_v, (int)v.size(), std::min(2 * wgs_for(v), 1024), d_ft, s.d_fc.p, fc_stride, s.d_fc_init,
+                launch_start_scan_mq(M, idx->sum_mode, d_v, (int)v.size(), std::min(2 * wgs_for(v), 1024), d_ft, s.d_fc.p, fc_stride, s.d_fc_init,
                                      s.d_qs, st);
             else
-                launch_start_scan_f32(M, d_v, (int)v.size(), wgs_for(v), d_ft, s.d_fc.p, fc_stride, s.d_fc_init, s.d_qs, st);
+                launch_start_scan_f32(M, idx->sum_mode, d_v, (int)v.size(), wgs_for(v), d_ft, s.d_fc.p, fc_stride, s.d_fc_init, s.d_qs, st);
         };
         if (na) start_scan(sitems_a, s.d_sitems);
         if (nb) {
@@ -1229,6 +1229,9 @@ int qadc_index_destroy(qadc_index* idx) {
     return QADC_OK;
 }
 
+// has_labels is what partition 0 hands out, EVEN IF IT IS EMPTY (compute_sizes, db_query_4.cpp:105-110); every non-empty
+// partition must then agree (118-124).  An index_db whose partition 0 is empty returns a null labels pointer for it
+// (an empty std::vector's data()), so the reference refuses such a database: same here, same message.
 static int check_labels_mode(qadc_index* idx, bool has_labels) {
     if (idx->labeled < 0) idx->labeled = has_labels ? 1 : 0;
     if ((idx->labeled == 1) != has_labels)
@@ -1255,6 +1258,7 @@ int qadc_index_add_partitions(qadc_index* idx, int part_count, const uint8_t* co
         Part pt;
         const bool has_labels = labels != nullptr && labels[p] != nullptr;
         if (sizes[p] == 0) {  // "Warning: Partition i is empty" (db_query_4.cpp:113-116)
+            if (idx->parts.empty() && idx->labeled < 0) idx->labeled = has_labels ? 1 : 0;
             idx->parts.push_back(pt);
             continue;
         }
@@ -1275,6 +1279,7 @@ int qadc_index_add_partition_interleaved(qadc_index* idx, const uint8_t* interle
     if (int rc = use_device(idx)) return rc;
     Part pt;
     if (size == 0) {
+        if (idx->parts.empty() && idx->labeled < 0) idx->labeled = labels != nullptr ? 1 : 0;
         idx->parts.push_back(pt);
         return QADC_OK;
     }
@@ -1297,6 +1302,7 @@ int qadc_index_add_partition_device(qadc_index* idx, const void* d_codes, const 
     if (!idx || (size && !d_codes)) return fail(QADC_E_ARG, "bad arguments");
     if ((reinterpret_cast<uintptr_t>(d_codes) & 15u) != 0) return fail(QADC_E_ARG, "d_codes must be 16-byte aligned");
     Part pt;
+    if (!size && idx->parts.empty() && idx->labeled < 0) idx->labeled = d_labels != nullptr ? 1 : 0;
     if (size) {
         if (int rc = check_labels_mode(idx, d_labels != nullptr)) return rc;
         pt.d_codes = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_codes));
@@ -1463,6 +1469,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     if (!idx || !name) return fail(QADC_E_ARG, "bad arguments");
     const std::string n(name);
     if (n == "quant_mode") idx->quant_mode = value != 0 ? 1 : 0;
+    else if (n == "sum_mode") idx->sum_mode = value != 0 ? 1 : 0;
     else if (n == "cand_capacity") idx->cand_capacity = (uint32_t)std::max(16.0, std::min(value, 2147483648.0 - 1));
     else if (n == "level_base") idx->level_base = (uint64_t)std::max(16.0, value);
     else if (n == "level_growth") idx->level_growth = (uint64_t)std::max(2.0, value);
@@ -1758,7 +1765,7 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
     HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_v), blocks * sizeof(float)));
     HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_p), blocks * sizeof(uint32_t)));
     HIPCHECK(hipMemcpyAsync(d_t, table, idx->M * 16 * sizeof(float), hipMemcpyHostToDevice, idx->stream));
-    launch_float_top1(idx->M, p.d_codes, p.n, d_t, d_v, d_p, blocks, idx->stream);
+    launch_float_top1(idx->M, idx->sum_mode, p.d_codes, p.n, d_t, d_v, d_p, blocks, idx->stream);
     HIPCHECK(hipGetLastError());
     std::vector<float> hv(blocks);
     std::vector<uint32_t> hp(blocks);

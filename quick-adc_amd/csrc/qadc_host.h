@@ -367,6 +367,7 @@ struct qadc_index {
     float keep = 0.01f;
     // options
     int quant_mode = 1;
+    int sum_mode = 1;                   // grouping of the float pre-scan's adds (qadc_float_sum.h): 1 = as the reference is compiled
     uint32_t cand_capacity = kSortCap;  // candidate region entries per query
     uint64_t level_base = 512;
     uint64_t level_growth = 4;

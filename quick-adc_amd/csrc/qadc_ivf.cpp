@@ -172,7 +172,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             HIPCHECK(s.d_ftables.ensure(nt));
             HIPCHECK(hipStreamWaitEvent(pre_st, s.ev_feed, 0));
             launch_build_tables(s.d_queries.p, idx->feed.K ? idx->feed.d_coarse.p : nullptr, s.d_assign.p, idx->feed.d_codebooks.p,
-                                idx->feed.has_rotation ? idx->feed.d_rotation.p : nullptr, nq, ma, M, idx->feed.dim, table_expansion(idx, ma), s.d_ftables.p, pre_st);
+                                idx->feed.has_rotation ? idx->feed.d_rotation.p : nullptr, nq, ma, M, idx->feed.dim, table_expansion(idx, ma), idx->sum_mode, s.d_ftables.p, pre_st);
             pre_used = pre_st != st;
             A.ftables = s.d_ftables.p;
         } else {
@@ -199,7 +199,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
                 HIPCHECK(s.d_ftables.ensure(nt_share));
                 launch_build_tables(s.d_queries.p, idx->feed.d_coarse.p, d_assign_share, idx->feed.d_codebooks.p,
                                     idx->feed.has_rotation ? idx->feed.d_rotation.p : nullptr, s.front_n, ma, M, idx->feed.dim, table_expansion(idx, ma),
-                                    s.d_ftables.p, fs);
+                                    idx->sum_mode, s.d_ftables.p, fs);
                 QueryKernelArgs F{};
                 F.parts = idx->d_partdesc.p;
                 F.assign = d_assign_share;
@@ -210,6 +210,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
                 F.fcap = (uint32_t)fcap;
                 F.R = (uint32_t)s.R;
                 F.quant_mode = idx->quant_mode;
+                F.sum_mode = idx->sum_mode;
                 F.head_codes = ~0ull;
                 F.head_slots = 1;
                 F.G = 1;
@@ -248,6 +249,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     A.qstate_flags = s.dev_replay ? s.d_qflags.p : nullptr;
     A.R = (uint32_t)s.R;
     A.quant_mode = idx->quant_mode;
+    A.sum_mode = idx->sum_mode;
     A.nontemporal = idx->total_codes * (uint64_t)idx->cs > (200ull << 20);   // (same rule as the level path)
     A.G = G;
     A.ramp_shift = (uint32_t)idx->wgq_ramp_shift;

@@ -122,6 +122,7 @@ struct QueryKernelArgs {
     uint32_t* qstate_flags;  // optional [nq][4]: {flags, entries} for replay_heap_lanes_kernel, or nullptr
     uint32_t R;
     int quant_mode;
+    int sum_mode;            // grouping of the float pre-scan's adds: 1 = as the reference is compiled, 0 = source order (qadc_float_sum.h)
     int nontemporal;         // non-temporal code loads (database larger than the Infinity Cache)
     // head mode (level-structured path): scan only the first head_codes codes of every query's scan order with the int8
     // tables in `qtables`, emit Cand records / level-0 histogram counts like emit_candidate does (0 = normal mode)
@@ -259,17 +260,18 @@ void launch_replay_heap(const QueryState* d_qs, const uint64_t* d_entries, uint3
                         uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
 
 // d_fc_init[2q] = values of query q written unfiltered (phase A), d_fc_init[2q+1] = capacity of its buffer.
-void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item,
+// sum_mode: grouping of the float adds (qadc_float_sum.h): 1 = as the reference is compiled, 0 = source order.
+void launch_start_scan_f32(int M, int sum_mode, const StartItem* d_items, int nitems, int wgs_per_item,
                            const float* d_ftables, float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init,
                            QueryState* d_qs, hipStream_t stream);
 
 // Multi-query form: groups of up to 8 consecutive items that share codes / n / out_off / filter (one per query)
 // are evaluated in one pass; values bit-identical to launch_start_scan_f32.
-void launch_start_scan_mq(int M, const StartItem* d_items, int nitems, int wgs_per_group, const float* d_ftables, float* d_fc,
+void launch_start_scan_mq(int M, int sum_mode, const StartItem* d_items, int nitems, int wgs_per_group, const float* d_ftables, float* d_fc,
                           uint64_t fc_stride, const uint32_t* d_fc_init, QueryState* d_qs, hipStream_t stream);
 
 // Per-block (min float ADC distance, lowest position) over a whole partition; host reduces the blocks.
-void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,
+void launch_float_top1(int M, int sum_mode, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,
                        int blocks, hipStream_t stream);
 
 // ---- host feeders on the device --------------------------------------------------
@@ -283,14 +285,16 @@ void launch_kmeans_update(const float* d_vectors, uint64_t n, int dim, int K, co
 void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
                           int32_t* d_assign, hipStream_t stream);
 // Residual + per-query distance tables (compute_dists_single_simd_cg's result, distances.hpp:294-311):
-// tables[q][a][m][c] = sum_d ((x - centroid[assign])[m*ds+d] - codebook[m][c][d])^2, d ascending.
+// tables[q][a][m][c] = sum_d ((x - centroid[assign])[m*ds+d] - codebook[m][c][d])^2; sum_mode 1: added like the
+// reference's fmanorm as compiled (AVX lanes + fused multiply-add + reduceadd tree: direct_sqdist in qadc_kernels.hip),
+// sum_mode 0: one sequential sum in ascending d.
 // d_coarse == nullptr (flat DB): residual = query.  d_rotation != nullptr (OPQ): the residual is rotated first,
 // rotated[r] = sum_c x[c] * rotation[r][c]  (opq::rotate_multiple_vectors, quantizers.hpp:289-301).
 // expansion != 0: the BLAS-expansion form (||v||^2 + ||c||^2) - 2 v.c of compute_cross_dists_blas
 // (distances.hpp:151-183, 277-292) — what the reference evaluates for ma > 1 and in batch mode; may yield negatives.
 void launch_build_tables(const float* d_queries, const float* d_coarse, const int32_t* d_assign, const float* d_codebooks,
-                         const float* d_rotation, int nq, int ma, int M, int dim, int expansion, float* d_ftables,
-                         hipStream_t stream);
+                         const float* d_rotation, int nq, int ma, int M, int dim, int expansion, int sum_mode,
+                         float* d_ftables, hipStream_t stream);
 
 // R-th smallest of each query's stored float values (one workgroup per query) -> QueryState::qmax
 // (FLT_MAX if fewer than R values).  max_passes < 4: upper bound only (survivor filter of the pre-scan).

@@ -9,6 +9,7 @@
 //
 // The op is a gather + byte add bound by HBM reads: no MFMA.
 #include "qadc_kernels.h"
+#include "qadc_float_sum.h"
 #include <cstdlib>
 
 #include <algorithm>
@@ -1175,8 +1176,8 @@ void launch_candidates_i8(int M, const uint8_t* d_codes, uint64_t n, const int8_
 }
 
 // ---------------------------------------------------------------------------------------------
-// float pre-scan of the "starts" (scan_4<M>, query_common.hpp:59-90): cand accumulated
-// sequentially from 0, byte by byte, low nibble then high nibble — same IEEE adds, same order.
+// float pre-scan of the "starts" (scan_4<M>, query_common.hpp:59-90): the same IEEE adds in the grouping
+// sum_mode names (qadc_float_sum.h): 1 = the reference as compiled with its -ffast-math, 0 = source order.
 // The 16 lanes-distinct entries of one table sit in 16 consecutive LDS dwords, so every lookup
 // instruction (all lanes in the same table) is bank-conflict-free without replication.
 // ---------------------------------------------------------------------------------------------
@@ -1188,7 +1189,7 @@ __device__ __forceinline__ float funkey(uint32_t k) {
     return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
 }
 
-template <int M>
+template <int M, int SM>
 __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __restrict__ items,
                                                              const float* __restrict__ ftables, float* __restrict__ fc,
                                                              uint64_t fc_stride, const uint32_t* __restrict__ fc_init,
@@ -1210,7 +1211,7 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
     constexpr int DW = M / 8;
     uint32_t kmin = 0xffffffffu, kmax = 0u;
     const uint32_t stride = gridDim.x * 256;
-    // two codes per lane and iteration: two independent (sequential-order) float sums in flight
+    // two codes per lane and iteration: two independent float sums in flight
     for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < it.n; i0 += 2 * stride) {
         uint32_t d[2][DW];
         bool live[2];
@@ -1233,16 +1234,18 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
                 }
             }
         }
-        // scan_4<M> order: byte by byte, low nibble then high nibble, accumulated from 0 (query_common.hpp:72-80)
-        float cand[2] = {0.0f, 0.0f};
+        // scan_4<M>'s sum (query_common.hpp:72-80) in the grouping SM names
+        float cand[2];
 #pragma unroll
-        for (int b = 0; b < M / 2; ++b) {
+        for (int u = 0; u < 2; ++u) {
+            float v[M];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int b = 0; b < M / 2; ++b) {
                 const uint32_t byte = (d[u][b >> 2] >> (8 * (b & 3))) & 0xffu;
-                cand[u] += tab[(2 * b) * 16 + (byte & 15u)];
-                cand[u] += tab[(2 * b + 1) * 16 + (byte >> 4)];
+                v[2 * b] = tab[(2 * b) * 16 + (byte & 15u)];
+                v[2 * b + 1] = tab[(2 * b + 1) * 16 + (byte >> 4)];
             }
+            cand[u] = adc_sum_code<M>(v, SM, 0.0f);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1297,18 +1300,28 @@ __global__ __launch_bounds__(256) void start_scan_f32_kernel(const StartItem* __
 // Multi-query float pre-scan: the same sums for up to 8 queries in ONE pass over the starts (the float twin of
 // scan_i8_mq_kernel).  LDS row (t, half, x) = { T_q[t][x] : q = 4*half .. 4*half+3 } = 16 bytes at
 // t*512 + half*256 + x*16: two ds_read_b128 per code nibble, each conflict-free without replication (the 16 rows
-// of a (t, half) block tile the 64 banks once; equal rows broadcast).  Every query's sum is still accumulated
-// sequentially from 0 in scan_4's order (low nibble, then high nibble, byte by byte) — v_pk_add_f32 adds two
-// queries per instruction with the rounding of v_add_f32 — so the values are bit-identical to the one-query
-// kernel's.  Items of a group share codes / n / out_off / filter and differ in table / query.
-template <int M>
+// of a (t, half) block tile the 64 banks once; equal rows broadcast).  Every query's sum is grouped exactly as in
+// the one-query kernel (SM: qadc_float_sum.h) — v_pk_add_f32 adds two queries per instruction with the rounding of
+// v_add_f32 — so the values are bit-identical to that kernel's.  The as-compiled grouping is evaluated in a
+// streaming order (pair sums as soon as both operands are loaded) so that at most six 8-query rows are live.
+// Items of a group share codes / n / out_off / filter and differ in table / query.
+typedef float fq_f32x4 __attribute__((ext_vector_type(4)));
+struct FQ8 {                                                 // one value per query of the group
+    fq_f32x4 lo, hi;
+};
+__device__ __forceinline__ FQ8 operator+(const FQ8& a, const FQ8& b) { return FQ8{a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ FQ8 fq_row(uint32_t off) {
+    typedef const __attribute__((address_space(3))) fq_f32x4* lds_frow_t;
+    const fq_f32x4 lo = *reinterpret_cast<lds_frow_t>(static_cast<uintptr_t>(off));
+    const fq_f32x4 hi = *reinterpret_cast<lds_frow_t>(static_cast<uintptr_t>(off + 256));
+    return FQ8{lo, hi};
+}
+template <int M, int SM>
 __global__ __launch_bounds__(256) void start_scan_mq_kernel(const StartItem* __restrict__ items, int nitems,
                                                             const float* __restrict__ ftables, float* __restrict__ fc,
                                                             uint64_t fc_stride, const uint32_t* __restrict__ fc_init,
                                                             QueryState* __restrict__ qstates) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef const __attribute__((address_space(3))) f32x4* lds_frow_t;
     constexpr int kStageQ = 512;                             // survivors staged in LDS per query and workgroup
     constexpr int TAB = M * 512;
     float* stage = reinterpret_cast<float*>(smem + TAB);                 // [8][kStageQ]
@@ -1351,32 +1364,44 @@ __global__ __launch_bounds__(256) void start_scan_mq_kernel(const StartItem* __r
             const u32x4_t v = ((const __attribute__((address_space(1))) u32x4_t*)(uintptr_t)it.codes)[i];
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        // scan_4<M> order: byte by byte, low nibble then high nibble, accumulated from 0 (query_common.hpp:72-80)
-        f32x2 c01 = {0.0f, 0.0f}, c23 = {0.0f, 0.0f}, c45 = {0.0f, 0.0f}, c67 = {0.0f, 0.0f};
-#pragma unroll
-        for (int w = 0; w < DW; ++w) {
-            const uint32_t dl = d[w] << 4;
-#define QADC_FMQ_ADD(off)                                                                    \
-            {                                                                                 \
-                const f32x4 lo = *reinterpret_cast<lds_frow_t>(static_cast<uintptr_t>(off));         \
-                const f32x4 hi = *reinterpret_cast<lds_frow_t>(static_cast<uintptr_t>((off) + 256)); \
-                c01 += f32x2{lo.x, lo.y};                                                     \
-                c23 += f32x2{lo.z, lo.w};                                                     \
-                c45 += f32x2{hi.x, hi.y};                                                     \
-                c67 += f32x2{hi.z, hi.w};                                                     \
+        // scan_4<M>'s sum (query_common.hpp:72-80) for the 8 queries at once, in the grouping SM names
+#define QADC_FQ_L(w, k) fq_row(byte_and<(k)>(d[w] << 4, nib_mask) + (2 * (4 * (w) + (k))) * 512)
+#define QADC_FQ_H(w, k) fq_row(byte_and<(k)>(d[w], nib_mask) + (2 * (4 * (w) + (k)) + 1) * 512)
+        FQ8 s8;
+        if constexpr (SM == 0) {
+            s8 = FQ8{f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+#define QADC_FQ_BYTE(w, k) s8 = s8 + QADC_FQ_L(w, k); s8 = s8 + QADC_FQ_H(w, k);
+#define QADC_FQ_WORD(w) QADC_FQ_BYTE(w, 0) QADC_FQ_BYTE(w, 1) QADC_FQ_BYTE(w, 2) QADC_FQ_BYTE(w, 3)
+            QADC_FQ_WORD(0) QADC_FQ_WORD(1)
+            if constexpr (M == 32) { QADC_FQ_WORD(2) QADC_FQ_WORD(3) }
+#undef QADC_FQ_WORD
+#undef QADC_FQ_BYTE
+        } else {
+            // A = (H2+L3)+(H3+L4), B = (H0+L1)+(H1+L2), C = (H5+L6)+(H4+L5), D = (H6+L7)+(H7+L0); s = ((A+B)+C)+D
+            const FQ8 l0 = QADC_FQ_L(0, 0);
+            FQ8 hp = QADC_FQ_H(0, 0);
+            const FQ8 p0 = hp + QADC_FQ_L(0, 1); hp = QADC_FQ_H(0, 1);
+            const FQ8 p1 = hp + QADC_FQ_L(0, 2); hp = QADC_FQ_H(0, 2);
+            const FQ8 qb = p0 + p1;
+            const FQ8 p2 = hp + QADC_FQ_L(0, 3); hp = QADC_FQ_H(0, 3);
+            const FQ8 p3 = hp + QADC_FQ_L(1, 0); hp = QADC_FQ_H(1, 0);
+            s8 = (p2 + p3) + qb;
+            const FQ8 p4 = hp + QADC_FQ_L(1, 1); hp = QADC_FQ_H(1, 1);
+            const FQ8 p5 = hp + QADC_FQ_L(1, 2); hp = QADC_FQ_H(1, 2);
+            s8 = s8 + (p5 + p4);
+            const FQ8 p6 = hp + QADC_FQ_L(1, 3); hp = QADC_FQ_H(1, 3);
+            const FQ8 p7 = hp + l0;
+            s8 = s8 + (p6 + p7);
+            if constexpr (M == 32) {
+                // s = s + ((L_{b+1}+H_{b+1}) + (L_b+H_b)), b = 8, 10, 12, 14
+#define QADC_FQ_PAIR(w, k) s8 = s8 + ((QADC_FQ_L(w, (k) + 1) + QADC_FQ_H(w, (k) + 1)) + (QADC_FQ_L(w, k) + QADC_FQ_H(w, k)));
+                QADC_FQ_PAIR(2, 0) QADC_FQ_PAIR(2, 2) QADC_FQ_PAIR(3, 0) QADC_FQ_PAIR(3, 2)
+#undef QADC_FQ_PAIR
             }
-#define QADC_FMQ_BYTE(k)                                                                      \
-            {                                                                                 \
-                const int t0 = 2 * (4 * w + (k));                                             \
-                const uint32_t xl = byte_and<(k)>(dl, nib_mask), xh = byte_and<(k)>(d[w], nib_mask); \
-                QADC_FMQ_ADD(xl + t0 * 512)                                                   \
-                QADC_FMQ_ADD(xh + (t0 + 1) * 512)                                             \
-            }
-            QADC_FMQ_BYTE(0) QADC_FMQ_BYTE(1) QADC_FMQ_BYTE(2) QADC_FMQ_BYTE(3)
-#undef QADC_FMQ_BYTE
-#undef QADC_FMQ_ADD
         }
-        const float cand[kMQ] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y};
+#undef QADC_FQ_L
+#undef QADC_FQ_H
+        const float cand[kMQ] = {s8.lo.x, s8.lo.y, s8.lo.z, s8.lo.w, s8.hi.x, s8.hi.y, s8.hi.z, s8.hi.w};
         if (!it.filter) {
 #pragma unroll
             for (int j = 0; j < kMQ; ++j) {
@@ -1447,21 +1472,23 @@ __global__ __launch_bounds__(256) void start_scan_mq_kernel(const StartItem* __r
 }
 
 // groups of up to 8 consecutive items share codes / n / out_off / filter (the planner guarantees it)
-void launch_start_scan_mq(int M, const StartItem* d_items, int nitems, int wgs_per_group, const float* d_ftables, float* d_fc,
+void launch_start_scan_mq(int M, int sum_mode, const StartItem* d_items, int nitems, int wgs_per_group, const float* d_ftables, float* d_fc,
                           uint64_t fc_stride, const uint32_t* d_fc_init, QueryState* d_qs, hipStream_t stream) {
     const dim3 grid(wgs_per_group, (nitems + kMQ - 1) / kMQ), block(256);
     const size_t lds = (size_t)M * 512 + kMQ * 512 * 4 + 2 * kMQ * 4 + 64 * 4;
-    if (M == 16) hipLaunchKernelGGL(start_scan_mq_kernel<16>, grid, block, lds, stream, d_items, nitems, d_ftables, d_fc, fc_stride, d_fc_init, d_qs);
-    else         hipLaunchKernelGGL(start_scan_mq_kernel<32>, grid, block, lds, stream, d_items, nitems, d_ftables, d_fc, fc_stride, d_fc_init, d_qs);
+#define QADC_SSM(MM, SS) hipLaunchKernelGGL((start_scan_mq_kernel<MM, SS>), grid, block, lds, stream, d_items, nitems, d_ftables, d_fc, fc_stride, d_fc_init, d_qs)
+    if (M == 16) { if (sum_mode) QADC_SSM(16, 1); else QADC_SSM(16, 0); }
+    else         { if (sum_mode) QADC_SSM(32, 1); else QADC_SSM(32, 0); }
+#undef QADC_SSM
 }
 
 // Exact float-ADC nearest code of a partition (smallest distance, lowest position on ties):
 // the ground truth Recall@R is measured against when float ground truth over the raw vectors is
-// not available.  Same summation order as scan_4<M>.
+// not available.  Same sum as scan_4<M>, in the grouping sum_mode names (qadc_float_sum.h).
 template <int M>
 __global__ __launch_bounds__(256) void float_top1_kernel(const uint8_t* __restrict__ codes, uint32_t n,
                                                          const float* __restrict__ ftable, float* __restrict__ out_val,
-                                                         uint32_t* __restrict__ out_pos) {
+                                                         uint32_t* __restrict__ out_pos, int sum_mode) {
     __shared__ float tab[M * 16];
     __shared__ float rv[256];
     __shared__ uint32_t rp[256];
@@ -1479,13 +1506,14 @@ __global__ __launch_bounds__(256) void float_top1_kernel(const uint8_t* __restri
             const uint4 v = reinterpret_cast<const uint4*>(codes)[i];
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        float cand = 0.0f;
+        float v[M];
 #pragma unroll
         for (int b = 0; b < M / 2; ++b) {
             const uint32_t byte = (d[b >> 2] >> (8 * (b & 3))) & 0xffu;
-            cand += tab[(2 * b) * 16 + (byte & 15u)];
-            cand += tab[(2 * b + 1) * 16 + (byte >> 4)];
+            v[2 * b] = tab[(2 * b) * 16 + (byte & 15u)];
+            v[2 * b + 1] = tab[(2 * b + 1) * 16 + (byte >> 4)];
         }
+        const float cand = adc_sum_code<M>(v, sum_mode, 0.0f);
         if (cand < best) { best = cand; bpos = i; }   // i ascends per thread: first minimum kept
     }
     rv[threadIdx.x] = best;
@@ -1505,17 +1533,19 @@ __global__ __launch_bounds__(256) void float_top1_kernel(const uint8_t* __restri
     if (threadIdx.x == 0) { out_val[blockIdx.x] = rv[0]; out_pos[blockIdx.x] = rp[0]; }
 }
 
-void launch_float_top1(int M, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,
+void launch_float_top1(int M, int sum_mode, const uint8_t* d_codes, uint32_t n, const float* d_ftable, float* d_val, uint32_t* d_pos,
                        int blocks, hipStream_t stream) {
-    if (M == 16) hipLaunchKernelGGL(float_top1_kernel<16>, dim3(blocks), dim3(256), 0, stream, d_codes, n, d_ftable, d_val, d_pos);
-    else         hipLaunchKernelGGL(float_top1_kernel<32>, dim3(blocks), dim3(256), 0, stream, d_codes, n, d_ftable, d_val, d_pos);
+    if (M == 16) hipLaunchKernelGGL(float_top1_kernel<16>, dim3(blocks), dim3(256), 0, stream, d_codes, n, d_ftable, d_val, d_pos, sum_mode);
+    else         hipLaunchKernelGGL(float_top1_kernel<32>, dim3(blocks), dim3(256), 0, stream, d_codes, n, d_ftable, d_val, d_pos, sum_mode);
 }
 
-void launch_start_scan_f32(int M, const StartItem* d_items, int nitems, int wgs_per_item, const float* d_ftables,
+void launch_start_scan_f32(int M, int sum_mode, const StartItem* d_items, int nitems, int wgs_per_item, const float* d_ftables,
                            float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init, QueryState* d_qs, hipStream_t stream) {
     const dim3 grid(wgs_per_item, nitems), block(256);
-    if (M == 16) hipLaunchKernelGGL(start_scan_f32_kernel<16>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride, d_fc_init, d_qs);
-    else         hipLaunchKernelGGL(start_scan_f32_kernel<32>, grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride, d_fc_init, d_qs);
+#define QADC_SSF(MM, SS) hipLaunchKernelGGL((start_scan_f32_kernel<MM, SS>), grid, block, 0, stream, d_items, d_ftables, d_fc, fc_stride, d_fc_init, d_qs)
+    if (M == 16) { if (sum_mode) QADC_SSF(16, 1); else QADC_SSF(16, 0); }
+    else         { if (sum_mode) QADC_SSF(32, 1); else QADC_SSF(32, 0); }
+#undef QADC_SSF
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2119,11 +2149,54 @@ void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq,
 #undef QADC_CA
 }
 
+// ||x - c||^2 over ds components as the reference's direct table form adds it: fmanorm<ds/8, ds%8> called by
+// compute_dists_single_simd_cg (distances.hpp:60-76, 294-311) AS COMPILED with the reference's flags (pinned to that
+// build through the oracle's orc_tables_direct; host twin: host/float_sum.hpp sqdist):
+//   per AVX lane j: acc[j] = fma(d, d, acc[j]) over the ds/8 blocks, d = x - c;  reduceadd's tree acc[j] + acc[j+4],
+//   then (r0 + r2) + (r1 + r3);  the scalar remainder is paired p_k = fma(d_2k, d_2k, r(d_2k+1^2)), d = c - x:
+//   REM 4 -> (p0 + p1) + vec,  REM 6 -> (vec + p2) + (p0 + p1).
+// sum_mode 0, or a remainder the reference has no instance of (sq_dim 3 of BASELINE configs[4]; its dispatch is
+// distances.cpp:50-84): one sequential sum in ascending d.  X / C: anything indexable by int (pointer or register array).
+template <typename X, typename C>
+__device__ __forceinline__ float direct_sqdist(const X& x, const C& c, int ds, int sum_mode) {
+    const int blocks = ds >> 3, rem = ds & 7;
+    if (sum_mode == 0 || !(rem == 0 || rem == 4 || rem == 6)) {
+        float s = 0.0f;
+        for (int d = 0; d < ds; ++d) {
+            const float t = x[d] - c[d];
+            s += t * t;
+        }
+        return s;
+    }
+    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int b = 0; b < blocks; ++b) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = x[b * 8 + j] - c[b * 8 + j];
+            acc[j] = __fmaf_rn(d, d, acc[j]);
+        }
+    }
+    const float r0 = acc[0] + acc[4], r1 = acc[1] + acc[5], r2 = acc[2] + acc[6], r3 = acc[3] + acc[7];
+    const float vec = (r0 + r2) + (r1 + r3);
+    if (rem == 0) return vec;
+    float p[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (2 * k < rem) {
+            const float d0 = c[blocks * 8 + 2 * k] - x[blocks * 8 + 2 * k];
+            const float d1 = c[blocks * 8 + 2 * k + 1] - x[blocks * 8 + 2 * k + 1];
+            p[k] = __fmaf_rn(d0, d0, d1 * d1);
+        }
+    }
+    if (rem == 4) return (p[0] + p[1]) + vec;
+    return (vec + p[2]) + (p[0] + p[1]);
+}
+
 __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
                                                            const int32_t* __restrict__ assign,
                                                            const float* __restrict__ codebooks,
                                                            const float* __restrict__ rotation, int ma, int M, int dim,
-                                                           int expansion, float* __restrict__ ftables) {
+                                                           int expansion, int sum_mode, float* __restrict__ ftables) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     float* res = reinterpret_cast<float*>(dyn);               // [dim] residual of this (query, probe)
     float* tmp = res + dim;                                   // [dim] un-rotated residual (OPQ only)
@@ -2165,10 +2238,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restri
             }
             s = (vn + cn) + (-2.0f * dot);
         } else {
-            for (int d = 0; d < ds; ++d) {
-                const float t = res[m * ds + d] - ce[d];
-                s += t * t;
-            }
+            s = direct_sqdist(res + m * ds, ce, ds, sum_mode);
         }
         out[e] = s;
     }
@@ -2178,7 +2248,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restri
 // keeps its table entry's codebook row in registers and walks the probes, whose residuals wait in LDS.  One workgroup per
 // (query, probe) is 65 K workgroups of 512 results each at the C5 shape — the launch was bound by workgroup dispatch and by
 // re-reading the codebook row per result (92 us alone on the GPU for 134 MB of tables; round 4: -> 8 K workgroups).
-// Entry for entry the arithmetic of build_tables_kernel: the same residual, the same sums in ascending d.
+// Entry for entry the arithmetic of build_tables_kernel: the same residual, the same sums in the same grouping.
 #ifndef QADC_BT_PROBES
 #define QADC_BT_PROBES 16
 #endif
@@ -2186,7 +2256,7 @@ constexpr int kBTProbes = QADC_BT_PROBES;
 __global__ __launch_bounds__(256) void build_tables_multi_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
                                                                  const int32_t* __restrict__ assign,
                                                                  const float* __restrict__ codebooks, int ma, int M, int dim,
-                                                                 int expansion, float* __restrict__ ftables) {
+                                                                 int expansion, int sum_mode, float* __restrict__ ftables) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     float* res = reinterpret_cast<float*>(dyn);               // [kBTProbes][dim] residuals of this query's probes a0 ..
     const int a0 = blockIdx.x * kBTProbes, qi = blockIdx.y, tid = threadIdx.x;
@@ -2220,9 +2290,13 @@ __global__ __launch_bounds__(256) void build_tables_multi_kernel(const float* __
                         dot += v * ce[d];
                     }
                 s = (vn + cn) + (-2.0f * dot);
+            } else if (ds == 8) {
+                s = direct_sqdist(r, ce, 8, sum_mode);               // (constant ds: the block loop unrolls over the registers)
+            } else if (ds == 4) {
+                s = direct_sqdist(r, ce, 4, sum_mode);
             } else {
 #pragma unroll
-                for (int d = 0; d < 8; ++d)
+                for (int d = 0; d < 8; ++d)                          // other ds <= 8: no instance in the reference — sequential
                     if (d < ds) {
                         const float t_ = r[d] - ce[d];
                         s += t_ * t_;
@@ -2234,16 +2308,16 @@ __global__ __launch_bounds__(256) void build_tables_multi_kernel(const float* __
 }
 
 void launch_build_tables(const float* d_queries, const float* d_coarse, const int32_t* d_assign, const float* d_codebooks,
-                         const float* d_rotation, int nq, int ma, int M, int dim, int expansion, float* d_ftables,
+                         const float* d_rotation, int nq, int ma, int M, int dim, int expansion, int sum_mode, float* d_ftables,
                          hipStream_t stream) {
     if (!d_rotation && dim / M <= 8 && ma > 1) {
         hipLaunchKernelGGL(build_tables_multi_kernel, dim3((ma + kBTProbes - 1) / kBTProbes, nq), dim3(256),
                            (size_t)kBTProbes * dim * sizeof(float), stream, d_queries, d_coarse, d_assign, d_codebooks, ma, M, dim,
-                           expansion, d_ftables);
+                           expansion, sum_mode, d_ftables);
         return;
     }
     hipLaunchKernelGGL(build_tables_kernel, dim3(ma, nq), dim3(256), 2 * dim * sizeof(float), stream, d_queries, d_coarse,
-                       d_assign, d_codebooks, d_rotation, ma, M, dim, expansion, d_ftables);
+                       d_assign, d_codebooks, d_rotation, ma, M, dim, expansion, sum_mode, d_ftables);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -28,6 +28,7 @@
 // Variants of the same kernel: MULTI (a small batch spreads each query over G workgroups, which share the first
 // block of the scan order for their bound) and HEAD (the first launch of the level-structured path).  gfx950 only.
 #include "qadc_kernels.h"
+#include "qadc_float_sum.h"
 
 #include <atomic>
 #include <cfloat>
@@ -137,15 +138,15 @@ __device__ __forceinline__ uint32_t q_pair_sum(const uint32_t* d, uint32_t lane_
     return s;
 }
 
-// The pre-scan's float ADC of one code (scan_4<M> order: byte by byte, low nibble then high nibble, accumulated from 0 —
-// query_common.hpp:72-80) against the wave's float table at absolute LDS address tb (256-byte aligned; table t at
-// tb + t*64).  Sixteen lookups are issued before the first add waits: the adds are a dependent chain by definition, the
-// reads need not be — one read waited for per add made a code 32 LDS round trips (C5 shape: the pre-scan was 107 K of the
-// front's 236 K cycles).  Addresses: the nibbles are masked four at a time, pre-multiplied by 4, and ONE v_perm_b32 per
-// lookup puts the byte under the table's address (the table index rides in the read's immediate offset).
+// The pre-scan's float ADC of one code (scan_4<M>, query_common.hpp:59-90; the grouping of the adds is sum_mode's — 1 = as
+// the reference is compiled, 0 = source order: qadc_float_sum.h) against the wave's float table at absolute LDS address tb
+// (256-byte aligned; table t at tb + t*64).  Sixteen lookups are issued before the first add waits: one read waited for
+// per add made a code 32 LDS round trips (C5 shape: the pre-scan was 107 K of the front's 236 K cycles).  Addresses: the
+// nibbles are masked four at a time, pre-multiplied by 4, and ONE v_perm_b32 per lookup puts the byte under the table's
+// address (the table index rides in the read's immediate offset).
 typedef const __attribute__((address_space(3))) float* q_lds_float_t;
 template <int M>
-__device__ __forceinline__ float q_prescan_sum(const uint32_t* d, uint32_t tb) {
+__device__ __forceinline__ float q_prescan_sum(const uint32_t* d, uint32_t tb, int sum_mode) {
     constexpr int CS = M / 2;
     float cand = 0.0f;
 #pragma unroll
@@ -164,8 +165,9 @@ __device__ __forceinline__ float q_prescan_sum(const uint32_t* d, uint32_t tb) {
                 v[8 * w + 2 * k + 1] = *reinterpret_cast<q_lds_float_t>(static_cast<uintptr_t>(ah + (2 * b + 1) * 64));
             }
         }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) cand += v[j];
+        if (sum_mode == 0) cand = adc_sum8_source(cand, v);
+        else if (h == 0)   cand = adc_sum8_compiled_first(v);
+        else               cand = adc_sum8_compiled_next(cand, v);
     }
     return cand;
 }
@@ -563,6 +565,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         const int wpp = ma >= kQWaves ? 1 : kQWaves / ma;        // waves per probe
         const int pstride = kQWaves / wpp;                       // probes in flight
         float* mytab = wtab + wave * (M * 16);
+        const int sum_mode = A.sum_mode;                         // grouping of the float adds (qadc_float_sum.h)
         float lmin = FLT_MAX;
         const int pslot = (int)wave / wpp, sub = (int)wave % wpp;
         // The pre-scan is LATENCY, not work: a wave's round used to be a chain of dependent memory round trips — assign[a],
@@ -650,7 +653,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
 #pragma unroll
                 for (int u = 0; u < kPB; ++u) {
                     const uint32_t i = i0 + (uint32_t)u * step;
-                    const float cand = q_prescan_sum<M>(dwv[u], tb);   // (lanes past the starts sum code 0: not stored)
+                    const float cand = q_prescan_sum<M>(dwv[u], tb, sum_mode);   // (lanes past the starts sum code 0: not stored)
                     if (i < sn) {
                         if (in_lds) vals[base + i] = cand;
                         else gvals[base + i] = cand;

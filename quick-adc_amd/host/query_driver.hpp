@@ -12,8 +12,9 @@
 //                  with the four phase timers (query_common.hpp:245-309)
 //   process_queries  fresh heap per query, recall = true nearest neighbour among the R returned keys,
 //                  averaged metrics (query_common.hpp:330-368) and the CSV line of db_query_4.cpp:387-390
-// Float results of these feeders are NOT pinned against the reference (its versions go through
-// OpenBLAS / AVX kernels); the scan below them is, and it receives whatever tables they produce.
+// The direct table form (ma == 1: pq4::tables_direct) adds like the reference's AVX/FMA kernel as compiled
+// (host/float_sum.hpp, pinned to the reference build by the oracle's tests).  The BLAS-expansion form, the OPQ
+// rotation and the coarse assignment go through OpenBLAS in the reference and are NOT pinned (sequential sums here).
 #pragma once
 #include <sys/time.h>
 
@@ -24,6 +25,8 @@
 #include <limits>
 #include <memory>
 #include <vector>
+
+#include "float_sum.hpp"
 
 namespace qadc {
 
@@ -62,7 +65,9 @@ struct pq4 {
     int table_dim() const { return sq_count * 16; }
     const float* centroid(int m, int c) const { return centroids.data() + ((size_t)m * 16 + c) * sq_dim(); }
 
-    // tables[m][c] = ||x_m - centroid(m,c)||^2
+    // tables[m][c] = ||x_m - centroid(m,c)||^2, one sequential sum in ascending d: the encoder's distances (the
+    // reference encodes through find_k_neighbors' BLAS products, neighbors.cpp:30-76 — unpinned; the device encoder adds
+    // in this order)
     void tables(const float* x, float* out) const {
         const int ds = sq_dim();
         for (int m = 0; m < sq_count; ++m)
@@ -75,6 +80,14 @@ struct pq4 {
                 }
                 out[m * 16 + c] = s;
             }
+    }
+
+    // The direct ("single") form the query path uses for ma == 1: compute_dists_single_simd_cg -> fmanorm
+    // (distances.hpp:294-311, 60-76), in the reference's as-compiled grouping (float_sum.hpp).
+    void tables_direct(const float* x, float* out) const {
+        const int ds = sq_dim();
+        for (int m = 0; m < sq_count; ++m)
+            for (int c = 0; c < 16; ++c) out[m * 16 + c] = sqdist(x + m * ds, centroid(m, c), ds);
     }
 
     // The BLAS-expansion form of `count` vectors' tables (compute_dists_multiple_blas_cg -> compute_cross_dists_blas,
@@ -245,7 +258,7 @@ struct nns_engine {  // query_common.hpp:245-309
         const std::uint64_t t1 = ustime();
         db.pq->rotate_multiple_vectors(residuals.data(), ma);   // query_common.hpp:206-207 (no-op for plain PQ)
         const std::uint64_t t2 = ustime();
-        if (ma == 1) db.pq->tables(residuals.data(), dists.data());       // "Optimized" single form (query_common.hpp:292-294)
+        if (ma == 1) db.pq->tables_direct(residuals.data(), dists.data());   // "Optimized" single form (query_common.hpp:292-294)
         else db.pq->tables_blas(residuals.data(), ma, dists.data());       // dist_mult_func_ (295-297)
         const std::uint64_t t3 = ustime();
         scanner.query_scan(residuals.data(), assign.data(), ma, dists.data(), table_dim, bh, metrics);

@@ -8,8 +8,9 @@
 //   scan_4f<N>          query_common.hpp:59-90: the same on row-major 4-bit codes (low nibble = even sub-quantizer)
 //   get_scan_func       query_common.hpp:120-146: the (sq_count, sq_bits) dispatch and its error text
 //   scanner_simple      db_query.cpp:17-46: R sentinel pushes FLT_MAX - t, then every probed partition in assign[] order
-// Float sums are sequential in the source's order (built without -ffast-math); the oracle's orc_scan_standard_u8 is the
-// checker (tests/test_scanner_hip_cpp.py).
+// Float sums take the grouping of the reference AS COMPILED with its -ffast-math (host/float_sum.hpp; float_sum_mode() = 0
+// gives the source order); this file itself is built without -ffast-math.  The oracle's orc_scan_standard_u8 /
+// orc_candidates_f32 / orc_tables_direct, pinned to the reference build, are the checkers (tests/test_scanner_hip_cpp.py).
 #pragma once
 #include <cstdint>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 #include <limits>
 #include <vector>
 
+#include "float_sum.hpp"
 #include "qadc_heap.hpp"
 
 namespace qadc {
@@ -31,8 +33,9 @@ void scan_standard(const std::uint8_t* pqcodes_, const unsigned* labels, const u
     float min = bh.max();
     for (unsigned i = 0; i < pqcodes_count; ++i) {
         const T* const code = pqcodes + (std::size_t)i * NSQ;
-        float candidate = 0;
-        for (int sq = 0; sq < NSQ; ++sq) candidate += dists[sq * NCENT + code[sq]];
+        float t[NSQ];
+        for (int sq = 0; sq < NSQ; ++sq) t[sq] = dists[sq * NCENT + code[sq]];
+        const float candidate = adc_sum<NSQ>(t);
         if (candidate < min) {
             bh.push(labels != nullptr ? labels[i] : i, candidate);
             min = bh.max();
@@ -46,11 +49,12 @@ void scan_4f(const std::uint8_t* pqcodes, const unsigned* labels, const unsigned
     float min = bh.max();
     for (unsigned i = 0; i < pqcodes_count; ++i) {
         const std::uint8_t* const code = pqcodes + (std::size_t)i * (NSQ / 2);
-        float candidate = 0;
+        float t[NSQ];
         for (int b = 0; b < NSQ / 2; ++b) {                      // byte b: low nibble = sub-quantizer 2b, high nibble = 2b + 1
-            candidate += dists[(2 * b) * 16 + (code[b] & 0xf)];
-            candidate += dists[(2 * b + 1) * 16 + (code[b] >> 4)];
+            t[2 * b] = dists[(2 * b) * 16 + (code[b] & 0xf)];
+            t[2 * b + 1] = dists[(2 * b + 1) * 16 + (code[b] >> 4)];
         }
+        const float candidate = adc_sum<NSQ>(t);
         if (candidate < min) {
             bh.push(labels != nullptr ? labels[i] : i, candidate);
             min = bh.max();
@@ -86,19 +90,12 @@ struct pq_bytes {
     int table_dim() const { return sq_count * ncent(); }
     const float* centroid(int m, int c) const { return centroids.data() + ((std::size_t)m * ncent() + c) * sq_dim(); }
     void rotate_multiple_vectors(float*, int) const {}           // plain PQ (quantizers.hpp:189-195)
-    void tables(const float* x, float* out) const {              // ||x_m - c||^2, d ascending
+    void tables(const float* x, float* out) const {              // ||x_m - c||^2 as fmanorm adds it (float_sum.hpp)
         const int ds = sq_dim(), nc = ncent();
         for (int m = 0; m < sq_count; ++m)
-            for (int c = 0; c < nc; ++c) {
-                const float* ce = centroid(m, c);
-                float s = 0;
-                for (int d = 0; d < ds; ++d) {
-                    const float t = x[m * ds + d] - ce[d];
-                    s += t * t;
-                }
-                out[m * nc + c] = s;
-            }
+            for (int c = 0; c < nc; ++c) out[m * nc + c] = sqdist(x + m * ds, centroid(m, c), ds);
     }
+    void tables_direct(const float* x, float* out) const { tables(x, out); }   // the engine's name for the ma == 1 form
     void tables_blas(const float* vecs, int count, float* out) const {   // (||v||^2 + ||c||^2) - 2 v.c, distances.hpp:151-183
         const int ds = sq_dim(), nc = ncent();
         for (int v = 0; v < count; ++v)

@@ -318,8 +318,8 @@ class Index:
         ca = (u8p * len(codes))(*[_p(c, u8p) for c in codes])
         la = None
         if labels is not None:
-            labels = [np.ascontiguousarray(l, np.uint32) for l in labels]
-            la = (u32p * len(labels))(*[_p(l, u32p) for l in labels])
+            labels = [None if l is None else np.ascontiguousarray(l, np.uint32) for l in labels]
+            la = (u32p * len(labels))(*[None if l is None else _p(l, u32p) for l in labels])
         _check(lib().qadc_index_add_partitions(self._h, len(codes), ca, la, _p(sizes, u32p)))
 
     def add_partition_interleaved(self, inter, size, labels=None):

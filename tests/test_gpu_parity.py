@@ -391,7 +391,9 @@ def test_search_with_device_side_feeders(pyqadc, po, M, K, ma, opq, form):
         idx.set_rotation(rot)
     queries = rng.normal(size=(nq, dim)).astype(np.float32)
     idx.set_option("table_form", form)      # 0 direct, 1 BLAS expansion, 2 (default) nns_engine's rule: expansion iff ma > 1
-    table_fn = _seq_expansion if (form == 1 or (form == 2 and ma > 1)) else _seq_sqdist
+    # direct form: added like the reference's fmanorm as compiled (oracle's orc_tables_direct, pinned to the reference build)
+    direct_fn = lambda r, cb_: po.tables_direct(cb_, r.reshape(-1)).reshape(M, 16)
+    table_fn = _seq_expansion if (form == 1 or (form == 2 and ma > 1)) else direct_fn
     res = idx.search(queries, ma, R)
     for q in range(nq):
         if K:

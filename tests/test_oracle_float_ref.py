@@ -1,0 +1,257 @@
+"""CPU: the FLOAT half of the oracle (oracle/qadc_oracle.c: scan_4's sum, QuantizerMAX, the query_scan glue, start sizes,
+the direct table form, scan_standard, the 4-bit packer) against
+
+  * tests/golden/ref_query_scan_cases.npz — outputs of the reference's own scanner_4 / QuantizerMAX / scan_4 / scan_avx_4
+    as compiled by oracle/Makefile (generator: oracle/gen_golden_float.py); runs everywhere, and
+  * the live build oracle/_ref/libqadc_ref_float.so (line ranges of the reference's files compiled with its flags,
+    oracle/ref_extract.sh + oracle/ref_float_harness.cpp) on seeded random inputs; skipped where that build is absent.
+
+SURVEY.md section 8 rows A5 / A6 / A7 / A8 / A10 (direct form) and (c).  Everything compared is bit-exact: float heaps entry by
+entry (so qmax = values[0]), int8 tables, int8 heaps, start sizes, exit statuses."""
+import numpy as np
+import pytest
+
+import golden_cases
+from helpers import rand_codes
+
+FMAX = np.finfo(np.float32).max
+
+
+@pytest.fixture(scope="module")
+def g():
+    return golden_cases.load_query_scan()
+
+
+def _need_ref_float(po):
+    if not po.have_ref_float():
+        pytest.skip("oracle/_ref/libqadc_ref_float.so not built (no /root/reference here)")
+
+
+def rand_tables(rng, ma, M, negatives=False):
+    """[ma][M*16] float32: squared distances of N(0,1) sub-vectors at a random scale, optionally a few small negatives."""
+    q = rng.normal(size=(ma, M, 1, 8)).astype(np.float32)
+    c = rng.normal(size=(1, M, 16, 8)).astype(np.float32)
+    t = ((q - c) ** 2).sum(-1).astype(np.float32) * np.float32(rng.choice([1e-3, 1.0, 1.0, 37.5, 1e4]))
+    if negatives:
+        t = np.where(rng.random(t.shape) < 0.02, -np.float32(0.01) * t, t).astype(np.float32)
+    return np.ascontiguousarray(t.reshape(ma, M * 16), np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ golden (runs everywhere)
+def test_query_scan_matches_reference_golden(po, g):
+    n = nexit = 0
+    for c in golden_cases.query_scan_cases(g, po):
+        M, R, assign = c["M"], c["R"], c["assign"]
+        for a, p in enumerate(assign):
+            assert po.start_size(c["parts"][p].shape[0], c["keep"]) == c["starts"][a], c["cid"]
+        tb = c["tables"].copy()
+        o = po.query_scan(M, c["parts"], c["labels"], c["keep"], assign, tb, R)
+        assert o["rc"] == c["exit"], c["cid"]
+        assert np.float32(o["qmax"]) == c["qmax"] and np.float32(o["qmin"]) == c["qmin"], c["cid"]
+        if c["exit"]:
+            nexit += 1
+            continue
+        assert np.array_equal(o["qtables"], c["qt"]), c["cid"]
+        assert np.array_equal(o["keys"], c["keys"]) and np.array_equal(o["values"], c["vals"]), c["cid"]
+        assert np.array_equal(po.sort_keys_i8(o["keys"], o["values"]), c["sorted"]), c["cid"]
+        assert np.array_equal(tb, np.where(c["tables"] < 0, np.float32(0), c["tables"])), c["cid"]   # the in-place clamp
+        if "fcand" in c:
+            p0 = c["parts"][assign[0]]
+            assert np.array_equal(po.candidates_f32(M, p0[:c["starts"][0]], c["tables"][0]), c["fcand"]), c["cid"]
+            assert np.array_equal(po.candidates_i8(M, p0, c["qt"][0]), c["cand"]), c["cid"]
+        n += 1
+    assert n >= 20 and nexit >= 3
+
+
+def test_source_order_sum_is_not_what_the_reference_binary_computes(po, g):
+    """The pin is not vacuous: scan_4's sum in SOURCE order (sum_mode 0) disagrees with the reference as compiled on these
+    fixtures (its -ffast-math re-associates the sum) — in the per-code values and in qmax."""
+    dcand = dqmax = 0
+    for c in golden_cases.query_scan_cases(g, po):
+        if "fcand" in c:
+            p0 = c["parts"][c["assign"][0]]
+            seq = po.candidates_f32(c["M"], p0[:c["starts"][0]], c["tables"][0], sum_mode=0)
+            dcand += int((seq != c["fcand"]).sum())
+        if c["exit"] == 0:
+            o = po.query_scan(c["M"], c["parts"], c["labels"], c["keep"], c["assign"], c["tables"].copy(), c["R"], sum_mode=0)
+            dqmax += int(np.float32(o["qmax"]) != c["qmax"])
+    assert dcand > 0 and dqmax > 0
+
+
+# ------------------------------------------------------------------------------------------------ live reference build
+@pytest.mark.parametrize("M", [16, 32])
+def test_scan4_start_heap_matches_the_reference_as_compiled(po, M):
+    """A7: push(0, FLT_MAX) + scan_4<M> over 1..4 runs, each with its own table: the WHOLE float heap, entry by entry."""
+    _need_ref_float(po)
+    rng = np.random.default_rng(700 + M)
+    for t in range(400):
+        nparts = int(rng.integers(1, 5))
+        parts = [rand_codes(rng, int(rng.integers(1, 3000)), M) for _ in range(nparts)]
+        labels = None
+        if t % 3 == 0:
+            labels = [rng.integers(0, 2 ** 32, p.shape[0], dtype=np.uint64).astype(np.uint32) for p in parts]
+        tables = rand_tables(rng, nparts, M, negatives=(t % 4 == 1))
+        R = int(rng.choice([1, 10, 100, 1000]))
+        rk, rv = po.reff_scan4_start(M, parts, labels, tables, R)
+        ok, ov = po.scan4_start(M, parts, labels, tables, R)
+        assert np.array_equal(rk, ok) and np.array_equal(rv, ov), t
+
+
+def test_quantizer_matches_the_reference_as_compiled(po):
+    """A5: QuantizerMAX<int8_t>::quantize_tables on 1.6 M entries: random, exactly on bucket edges (k * delta + qmin and its
+    float neighbours), at / above qmax, and with qmin > 0."""
+    _need_ref_float(po)
+    rng = np.random.default_rng(55)
+    total = 0
+    for t in range(100):
+        qmin = np.float32(0) if t % 2 == 0 else np.float32(rng.random() * 3)
+        qmax = np.float32(qmin + np.float32(rng.choice([1e-3, 0.5, 7.25, 127.0, 3e4])) * np.float32(0.5 + rng.random()))
+        vals = (qmin + rng.random(16000).astype(np.float32) * np.float32(1.1) * (qmax - qmin)).astype(np.float32)
+        k = rng.integers(0, 128, 4000).astype(np.float32)
+        edge = (qmin + k * ((qmax - qmin) / np.float32(127))).astype(np.float32)
+        edges = np.concatenate([edge, np.nextafter(edge, np.float32(np.inf)), np.nextafter(edge, np.float32(-np.inf))])
+        edges = np.maximum(edges, qmin).astype(np.float32)       # the caller never hands values below qmin (it is the min)
+        allv = np.concatenate([vals, edges[:15984], np.array([qmax, np.nextafter(qmax, np.float32(0)), qmin] * 5 + [qmax], np.float32)])
+        allv = np.ascontiguousarray(allv[:(allv.size // 16) * 16].reshape(-1, 16))
+        want = po.reff_quantize_tables(allv, float(qmin), float(qmax))
+        got = po.quantize_tables(allv, float(qmin), float(qmax), mode=1)
+        assert np.array_equal(want, got), t
+        assert want.min() >= 0
+        total += allv.size
+    assert total >= 1_500_000
+
+
+@pytest.mark.parametrize("M", [16, 32])
+def test_query_scan_whole_matches_the_reference_as_compiled(po, M):
+    """A6 / A8: the reference's scanner_4, WHOLE (prepare_database + query_scan as compiled), against orc_query_scan on
+    5 000 random queries per M — flat and IVF with labels, keep 1 % / 0.2 % / larger, ragged and empty partitions, negative
+    table entries: start sizes, qmax (the float heap of query_scan_start), int8 tables (QuantizerMAX of the build on the
+    clamped tables) and the final int8 heap."""
+    _need_ref_float(po)
+    rng = np.random.default_rng(9100 + M)
+    nq = 0
+    for db in range(20):
+        ivf = db % 2 == 1
+        if ivf:
+            K = int(rng.integers(4, 12))
+            sizes = [int(s) for s in rng.integers(0, 9000, K)]
+            sizes[int(rng.integers(1, K))] = 0                       # (an empty partition 0 is refused: see the exit paths' test)
+            sizes[0] = max(sizes[0], 1)
+            keep = np.float32(rng.choice([0.01, 0.02, 0.05]))
+            perm = rng.permutation(sum(sizes)).astype(np.uint32) + 3
+            labels = list(np.split(perm, np.cumsum(sizes)[:-1]))
+        else:
+            sizes = [int(rng.integers(20000, 70000))]
+            keep = np.float32(rng.choice([0.01, 0.002 if sizes[0] > 55000 else 0.01, 0.1]))
+            labels = None
+        parts = [rand_codes(rng, s, M) for s in sizes]
+        sc = po.RefScanner4(M, parts, labels, keep)
+        starts, psizes, has_labels = sc.sizes()
+        assert list(psizes) == sizes and has_labels == ivf
+        assert [po.start_size(s, keep) for s in sizes] == list(starts)
+        for q in range(250):
+            ma = int(rng.integers(2, min(8, len(sizes)) + 1)) if ivf else 1
+            assign = rng.permutation(len(sizes))[:ma].astype(np.int32)
+            R = 100 if q % 5 else int(rng.choice([10, 50, 100]))
+            if int(starts[assign].sum()) < R:
+                continue                                             # qmax = FLT_MAX: the exit path has its own test
+            tables = rand_tables(rng, ma, M, negatives=(q % 3 == 0))
+            fk, fv = sc.query_start(assign, tables, R)
+            assert fv[0] < FMAX
+            want = po.query_scan(M, parts, labels, keep, assign, tables.copy(), R)
+            assert want["rc"] == 0 and np.float32(want["qmax"]) == fv[0], (db, q)
+            tb = tables.copy()
+            hk, hv = sc.query_scan(assign, tb, R)
+            assert np.array_equal(hk, want["keys"]) and np.array_equal(hv, want["values"]), (db, q)
+            if q % 10 == 0:
+                qt = po.reff_quantize_tables(tb.reshape(ma, M, 16), want["qmin"], float(fv[0]))
+                assert np.array_equal(qt, want["qtables"]), (db, q)
+            nq += 1
+        sc.close()
+    assert nq >= 4500
+
+
+def test_reference_exit_paths(po):
+    """qmax > 1e30 (fewer than R starts: heap not full, or only the sentinel evicted...) -> the reference prints its warning
+    and exit(1)s (db_query_4.cpp:271-274); mixed labelled / unlabelled partitions -> exit(1) in prepare_database (118-124)."""
+    _need_ref_float(po)
+    rng = np.random.default_rng(8)
+    codes = rand_codes(rng, 1000, 16)
+    tables = rand_tables(rng, 1, 16)
+    for s, code in ((1, 1), (98, 1), (99, 1), (100, 0), (101, 0)):
+        keep = np.float32((s + 0.5) / 1000)
+        sc = po.RefScanner4(16, [codes], None, keep)
+        assert sc.sizes()[0][0] == s == po.start_size(1000, keep)
+        assert sc.try_query([0], tables, 100) == code
+        assert po.query_scan(16, [codes], None, keep, [0], tables.copy(), 100)["rc"] == code
+        sc.close()
+    a, b = rand_codes(rng, 50, 16), rand_codes(rng, 60, 16)
+    la, lb = np.arange(50, dtype=np.uint32), np.arange(60, dtype=np.uint32)
+    assert po.RefScanner4.try_prepare(16, [a, b], [la, lb], 0.5) == 0
+    assert po.RefScanner4.try_prepare(16, [a, b], None, 0.5) == 0
+    assert po.RefScanner4.try_prepare(16, [a, b], [la, None], 0.5) == 1
+    assert po.RefScanner4.try_prepare(16, [a, b], [None, lb], 0.5) == 1
+    # has_labels is read off partition 0 even when it is EMPTY (compute_sizes, 105-110), and index_db hands out an empty
+    # std::vector's data() = nullptr for it (databases.hpp:237-243): a labelled database whose partition 0 is empty is refused
+    e = np.zeros((0, 8), np.uint8)
+    assert po.RefScanner4.try_prepare(16, [e, a, b], [None, la, lb], 0.5) == 1
+    assert po.RefScanner4.try_prepare(16, [a, e, b], [la, None, lb], 0.5) == 0
+
+
+def test_start_sizes_match_the_reference_as_compiled(po):
+    """A8: starts_sizes = max(1u, unsigned(size * keep)), the product evaluated in float (db_query_4.cpp:125-126), at sizes
+    where size * keep lands on or next to an integer."""
+    _need_ref_float(po)
+    sizes = [1, 2, 99, 100, 101, 199, 200, 1000, 4999, 5000, 5001, 65535, 65536, 100000, 300000, 1000003, 2000000]
+    parts = [np.zeros((s, 8), np.uint8) for s in sizes]
+    for keep in (0.01, 0.002, 0.0005, 0.1, 0.3, 1.0 / 3.0, 0.999, 1.0):
+        sc = po.RefScanner4(16, parts, None, np.float32(keep))
+        starts = sc.sizes()[0]
+        assert [po.start_size(s, np.float32(keep)) for s in sizes] == list(starts), keep
+        sc.close()
+
+
+def test_direct_tables_match_the_reference_as_compiled(po):
+    """A10 (direct form): compute_dists_single_simd_cg<DSQ> -> fmanorm for every sq_dim of the reference's dispatch
+    (distances.cpp:50-84); and sq_dims it has no instance of are refused by it (ours take the sequential loop)."""
+    _need_ref_float(po)
+    rng = np.random.default_rng(31)
+    for dsq in (4, 8, 16, 30, 32, 48, 60, 64, 96, 120, 128, 192, 240, 256):
+        for t in range(12):
+            M = int(rng.choice([16, 32]))
+            scale = np.float32(rng.choice([0.01, 1.0, 100.0]))
+            cb = (rng.normal(size=(M, 16, dsq)) * scale).astype(np.float32)
+            x = (rng.normal(size=M * dsq) * scale).astype(np.float32)
+            if t == 0:
+                x[:dsq] = cb[0, 3]                                   # an exact zero distance
+            assert np.array_equal(po.reff_tables_direct(cb, x), po.tables_direct(cb, x, sum_mode=1)), (dsq, t)
+    with pytest.raises(AssertionError):
+        po.reff_tables_direct(np.zeros((32, 16, 3), np.float32), np.zeros(96, np.float32))
+
+
+@pytest.mark.parametrize("NSQ", [4, 8, 16])
+def test_scan_standard_matches_the_reference_as_compiled(po, NSQ):
+    """BASELINE configs[0]: scanner_simple::query_scan (db_query.cpp:26-45) with scan_standard<uint8_t,NSQ>."""
+    _need_ref_float(po)
+    rng = np.random.default_rng(NSQ)
+    for t in range(60):
+        nparts = 1 + t % 3
+        parts = [rng.integers(0, 256, (int(rng.integers(1, 4000)), NSQ), dtype=np.uint8) for _ in range(nparts)]
+        labels = None if t % 2 else [rng.integers(0, 2 ** 31, p.shape[0]).astype(np.uint32) for p in parts]
+        tb = (rng.random((nparts, NSQ * 256), dtype=np.float32) * np.float32(rng.choice([1, 100]))).astype(np.float32)
+        R = int(rng.choice([10, 100]))
+        rk, rv = po.reff_scan_standard_u8(NSQ, parts, labels, tb, R)
+        ok, ov = po.scan_standard_u8(NSQ, parts, labels, tb, R)
+        assert np.array_equal(rk, ok) and np.array_equal(rv, ov), t
+
+
+def test_pack4_and_residuals_match_the_reference(po):
+    _need_ref_float(po)
+    rng = np.random.default_rng(2)
+    for M in (16, 32):
+        assign = rng.integers(0, 16, (501, M)).astype(np.int32)
+        assert np.array_equal(po.reff_pack4(assign, M), po.pack4(assign, M))
+    v = rng.normal(size=96).astype(np.float32)
+    base = rng.normal(size=(40, 96)).astype(np.float32)
+    a = rng.permutation(40)[:7].astype(np.int32)
+    assert np.array_equal(po.reff_substract_from_unique(v, base, a), (v[None, :] - base[a]).astype(np.float32))

@@ -112,11 +112,18 @@ def test_scan_standard_8x8(po):
     rng = np.random.default_rng(2)
     codes = rng.integers(0, 256, (5000, 8), dtype=np.uint8)
     tables = rng.random((1, 8, 256)).astype(np.float32)
-    keys, vals = po.scan_standard_u8(8, [codes], None, tables, 100)
     d = tables[0][np.arange(8)[None, :], codes].astype(np.float32)
+    # sum_mode 0: the source's sequential sum (query_common.hpp:106-108)
+    keys, vals = po.scan_standard_u8(8, [codes], None, tables, 100, sum_mode=0)
     s = np.zeros(5000, np.float32)
     for m in range(8):
         s = (s + d[:, m]).astype(np.float32)
+    assert len(keys) == 100 and np.array_equal(np.sort(vals), np.sort(s)[:100])
+    # sum_mode 1 (default): the grouping of the reference as compiled, ((t1+t2)+(t3+t4)) + ((t5+t6)+(t7+t0))
+    # (pinned to the reference build in tests/test_oracle_float_ref.py)
+    keys, vals = po.scan_standard_u8(8, [codes], None, tables, 100)
+    t = [d[:, m] for m in range(8)]
+    s = ((t[1] + t[2]) + (t[3] + t[4])) + ((t[5] + t[6]) + (t[7] + t[0]))
     assert len(keys) == 100 and np.array_equal(np.sort(vals), np.sort(s)[:100])
 
 
