@@ -7,18 +7,20 @@ quantizer, int8 scan of every code, candidate replay).
 
 ONE JSON line, several legs (SURVEY.md §8d keeps the two scan modes apart):
 
-* headline `value` / `ms_per_step` (the timed region of the contract): a step = one batch of
-  NQ = 32 queries (the reference's documented `-b32`, README.md:275-330) launched as L2-sharing
-  siblings, 8 queries per pass — the codes cross the HBM interface about once per LAUNCH.  That
-  mode is LDS-bound; its kernel is described by `roofline_batched` (bound "lds").
-* `roofline` (bound "hbm", frac <= 1): ONE QUERY PER PASS over the same list — what the reference's
-  scan_avx_4 does (simd_scan.hpp:125-187, one call per query at db_query_4.cpp:287-308): every
-  query streams all 8 GB from HBM by itself (scan_i8_kernel<M,2,nt,chunk>), timed with HIP events
-  on the library's stream in its own region of `single_queries` sequential queries.
-  `roofline.traffic` = HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950,
-  WRITE_SIZE; separate passes) collected IN THIS RUN by child processes that run the same
-  one-query-per-pass leg (--pmc-leg); when rocprofv3 is not available the committed per-mode
-  profile (profiles/r02_single_hbm_traffic.json) is used if its keys match, else null.
+* headline `value` / `ms_per_step` / `roofline` (the timed region of the contract, ONE region for all three): the METRIC'S
+  MODE — ONE QUERY PER PASS over the list, what the reference's scan_avx_4 does (simd_scan.hpp:125-187, one call per query at
+  db_query_4.cpp:287-308).  A step = one batch of NQ = 32 queries (the reference's documented `-b32`, README.md:275-330), each
+  of which walks the whole list BY ITSELF (library options share_variant = 0, mq = 0: no sibling launch, no multi-query
+  pass; scan_i8_kernel<M,2,nt,chunk>): 8 B per (code, query) cross the HBM interface — `roofline.traffic` (rocprofv3 PMC
+  passes over the same kind of steps, collected IN THIS RUN by child processes, --pmc-leg; FETCH_SIZE x2 on gfx950, WRITE_SIZE,
+  separate passes) is within 2 % of the algorithmic bytes.  `roofline` (bound "hbm", frac <= 1) = algorithmic bytes of the
+  region's streaming launches / their HIP-event time on the library's stream.  With --gpus N the SAME mode runs on every rank
+  (its shard of the list, one gather per 32-query step) and `roofline` is rank 0's shard (traffic null: no PMC child at N > 1).
+* `value_batched` / `ms_per_step_batched` / `roofline_batched` (reported SEPARATELY): the same 32-query
+  steps with the queries launched as L2-sharing siblings, 8 queries per pass (scan_i8_mq_kernel) — the codes cross the HBM
+  interface about once per LAUNCH, the kernel is LDS-bound (bound "lds"); timed in its own region after the headline's.
+* `roofline_one_query_per_call`: the strictest reading of the reference's mode — sequential single-query batches (three in
+  flight), 7 bound-level launches per query — in its own short region; `value_one_query_per_call` is its wall-clock rate.
 * `roofline_32x4`: the same one-query-per-pass leg on 1B x 32x4 codes (16 B/code), with its own in-run PMC traffic.
 * `roofline_ivf` / `roofline_ivf_c5`: the launches of the IVF legs' partition-major second phase against their roofs
   (grouped scan: LDS lookup rate; head: HBM), from a short profiled pass after the timed loops.
@@ -33,7 +35,6 @@ ONE JSON line, several legs (SURVEY.md §8d keeps the two scan modes apart):
   the same kernel on every physical core (C++ threads inside oracle/_ref, pinned, per-thread copies);
   `cpu_baseline_32x4`: scan_avx_4<32> on the 32x4 list; `cpu_baseline_ivf` / `cpu_baseline_ivf_c5`: the reference's
   scan over the probed partitions of the IVF legs' own first 32 queries with the device's int8 tables (1 thread each).
-* `value_one_query_per_pass` (top level): the north-star figure — one query per pass over the 1B list — next to `value`.
 
 With --gpus N and no WORLD_SIZE in the environment the script launches its own N ranks
 (torch.distributed.run, one per GPU, RCCL) BEFORE touching the GPU and relays rank 0's line; under
@@ -46,7 +47,8 @@ past 2^32 anyway) and the per-shard push streams are gathered once per batch and
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Environment overrides for quick runs: QADC_BENCH_CODES, QADC_BENCH_NQ, QADC_BENCH_M,
-QADC_BENCH_CPU_SECONDS (0 disables the CPU legs), QADC_BENCH_SINGLE_QUERIES, QADC_BENCH_PMC (0 = no
+QADC_BENCH_CPU_SECONDS (0 disables the CPU legs), QADC_BENCH_SINGLE_QUERIES (0 = no one-query-per-call leg), QADC_BENCH_BATCHED
+(0 = no batched-mode leg), QADC_BENCH_PMC (0 = no
 in-run PMC child passes), QADC_BENCH_IVF_CODES (0 = no IVF leg), QADC_BENCH_IVF_C5 (0 = no 1B x 32x4 IVF leg), QADC_BENCH_32X4 (0 = no 32x4 leg),
 QADC_BENCH_REAL_CODES (0 = no real-encode recall leg), QADC_BENCH_LATENCY (0 = no latency leg).
 """
@@ -70,6 +72,17 @@ sys.path.insert(0, os.path.join(ROOT, "quick-adc_amd"))
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 LDS_PEAK_GCYC = 256 * 2.4  # LDS-array cycles per second: 256 CUs x 2.4 GHz nominal (same guide)
 R, KEEP, SEED = 100, 0.01, 0x5EED0001
+# the two scan modes of a 32-query step (library options):
+#   one query per pass (the metric's mode, the headline): no sibling launch, no multi-query pass — every query of the step walks
+#     the list by itself; front_run_max = 0 keeps every streaming launch on the main stream inside the HIP-event-timed groups
+#   batched: the library's defaults — queries of a step as L2-sharing siblings, 8 per pass
+MODE_ONE_QUERY_PER_PASS = dict(share_variant=0, mq=0, front_run_max=0)
+MODE_BATCHED = dict(share_variant=0x41, mq=1, front_run_max=2 << 20)
+
+
+def set_mode(idx, mode):
+    for k, v in mode.items():
+        idx.set_option(k, v)
 
 
 def make_tables(rng, codebooks, nq):
@@ -271,28 +284,30 @@ def under_profiler():
 
 
 def pmc_leg_main():
-    """Child process of the in-run PMC passes (runs under `rocprofv3 --pmc ...`): the one-query-per-pass leg only,
-    a few queries, no torch.  Prints the profile counters it needs as one JSON line."""
+    """Child process of the in-run PMC passes (runs under `rocprofv3 --pmc ...`): two steps of the headline's mode (NQ queries per
+    step, one query per pass), no torch.  Prints the profile counters it needs as one JSON line."""
     import pyqadc
     M = int(os.environ.get("QADC_BENCH_M", 16))
     N = int(float(os.environ.get("QADC_BENCH_CODES", 1e9)))
+    NQ = int(os.environ.get("QADC_BENCH_NQ", 32))
     idx = pyqadc.Index(M, 0)
     idx.add_partition_synthetic_shard(N, 0, N, SEED, max(1, int(np.float32(N) * np.float32(KEEP))))
     idx.finalize(KEEP)
     idx.set_option("profile", 1)
+    set_mode(idx, MODE_ONE_QUERY_PER_PASS)
     rng = np.random.default_rng(1234)
     codebooks = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
-    tb = make_tables(rng, codebooks, 4)
-    a1 = np.zeros((1, 1), np.int32)
-    for q in range(3):
-        idx.query_scan(a1, tb[q:q + 1].copy(), R)
+    tb = make_tables(rng, codebooks, NQ)
+    assign = np.zeros((NQ, 1), np.int32)
+    for _ in range(2):
+        idx.query_scan(assign, tb.copy(), R)
     p = idx.profile()
     print(json.dumps({"pmc_leg": True, "scan_launches": p["scan_launches"], "scan_codes": p["scan_codes"]}), flush=True)
     idx.close()
 
 
-def pmc_traffic_in_run(M, N):
-    """Runs the one-query-per-pass leg twice under rocprofv3 (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass,
+def pmc_traffic_in_run(M, N, nq_step):
+    """Runs two steps of the headline's mode (pmc_leg_main) twice under rocprofv3 (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass,
     MI355X_MICROARCH.md "rocprofv3 PMC slots") and returns HBM bytes per scan_i8_kernel launch, or (None, reason).
     FETCH_SIZE is in KB and counts half of a 16-B/lane streaming read on gfx950 (same guide, "HBM"): x 1024 x 2."""
     exe = shutil.which("rocprofv3")
@@ -301,7 +316,7 @@ def pmc_traffic_in_run(M, N):
     if under_profiler():
         return None, "bench.py itself runs under a profiler"
     tmp = tempfile.mkdtemp(prefix="qadc_pmc_")
-    env = dict(os.environ, TMPDIR="/tmp", QADC_BENCH_M=str(M), QADC_BENCH_CODES=str(N))
+    env = dict(os.environ, TMPDIR="/tmp", QADC_BENCH_M=str(M), QADC_BENCH_CODES=str(N), QADC_BENCH_NQ=str(nq_step))
     got = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -331,8 +346,8 @@ def pmc_traffic_in_run(M, N):
     leg = got.get("leg")
     if not leg or leg.get("scan_launches") != fl or not leg.get("scan_codes"):
         return None, "the PMC leg's launch count (%s) does not match the counter file's (%d)" % (leg and leg.get("scan_launches"), fl)
-    # per launch like `achieved`, but the leg's launches are not the timed region's (sequential lone queries keep their
-    # short levels on the main stream): the comparable figure is bytes over the ALGORITHMIC bytes of the same launches
+    # per launch like `achieved`; the leg runs 2 steps, the timed region K: the comparable figure is bytes over the
+    # ALGORITHMIC bytes of the same launches (same launch shapes in both)
     total = fk * 1024 * 2 + wk * 1024
     alg_leg = float(leg["scan_codes"]) * (M // 2)
     return {"bytes_per_launch_of_the_pmc_leg": total / fl, "launches": fl, "fetch_kb_total": fk, "write_kb_total": wk,
@@ -341,14 +356,14 @@ def pmc_traffic_in_run(M, N):
 
 def pmc_traffic_from_profiles(M, N, alg_bytes_per_launch):
     """Fallback: the committed one-query-per-pass PMC profile, only if it was taken on exactly this mode/config."""
-    f = os.path.join(ROOT, "profiles", "r02_single_hbm_traffic.json")
+    f = os.path.join(ROOT, "profiles", "r05_headline_hbm_traffic.json")
     if not os.path.exists(f):
         return None, "no in-run PMC pass and no committed profile"
     pj = json.load(open(f))
-    if pj.get("mode") != "single" or pj.get("codes") != N or pj.get("M") != M:
+    if pj.get("mode") != "one_query_per_pass_batch32" or pj.get("codes") != N or pj.get("M") != M:
         return None, "committed PMC profile is for another mode/config (%s, %s codes, M=%s)" % (
             pj.get("mode"), pj.get("codes"), pj.get("M"))
-    return pj["traffic_over_algorithmic"] * alg_bytes_per_launch, "profiles/r02_single_hbm_traffic.json (ratio x this run's bytes)"
+    return pj["traffic_over_algorithmic"] * alg_bytes_per_launch, "profiles/r05_headline_hbm_traffic.json (ratio x this run's bytes)"
 
 
 # --------------------------------------------------------------------------------------------- GPU side legs
@@ -379,7 +394,36 @@ def single_query_leg(idx, M, N, pool, nqueries, depth=3):
     return idx.profile(), dt
 
 
-def roofline_single(M, N, prof, dt, nqueries, traffic, traffic_src):
+def one_pass_batch_leg(idx, pool, steps, warm=2, depth=3):
+    """The headline's mode on another list: `steps` pipelined steps of len(pool[0]) queries, every query walking the list by
+    itself (MODE_ONE_QUERY_PER_PASS).  Returns the HIP-event profile of the streaming launches and the wall time."""
+    import torch
+    nq = pool[0].shape[0]
+    assign = np.zeros((nq, 1), np.int32)
+    set_mode(idx, MODE_ONE_QUERY_PER_PASS)
+
+    def run(k):
+        pend = []
+        for s in range(k):
+            idx.submit(s % depth, assign, pool[s % len(pool)].copy(), R)
+            pend.append(s % depth)
+            if len(pend) == depth:
+                idx.collect(pend.pop(0))
+        while pend:
+            idx.collect(pend.pop(0))
+
+    run(warm)
+    idx.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    return idx.profile(), time.perf_counter() - t0
+
+
+def roofline_single(M, N, prof, dt, nqueries, traffic, traffic_src, region=None):
+    """HBM roofline object of a one-query-per-pass region from the library's HIP-event profile of its streaming launches.
+    region = None: sequential single-query batches (one query per CALL); else the text that describes the timed region."""
     cs = M // 2
     scan_ms = prof["scan_ms"]
     launches = max(prof["scan_launches"], 1)
@@ -391,8 +435,8 @@ def roofline_single(M, N, prof, dt, nqueries, traffic, traffic_src):
             "kernel": "scan_i8_kernel<%d,2,nt,chunk>" % M,
             "mode": "one query per pass over the whole list (simd_scan.hpp:125-187 called once per query, "
                     "db_query_4.cpp:287-308): every query streams the list from HBM by itself",
-            "timed_region": "%d sequential single-query batches (three in flight), HIP events around every run of "
-                            "consecutive streaming launches on the library's stream" % nqueries,
+            "timed_region": region or ("%d sequential single-query batches (three in flight), HIP events around every run of "
+                                       "consecutive streaming launches on the library's stream" % nqueries),
             "launches": prof["scan_launches"], "avg_launch_ms": scan_ms / launches,
             "algorithmic_bytes_per_launch": alg,
             "algorithmic_bytes_rule": "%d B per (code, query) (SURVEY.md 8d) x codes of the launch's bound level" % cs,
@@ -830,9 +874,9 @@ def main():
     pmc, pmc_src = None, "skipped"
     pmc32, pmc32_src = None, "skipped"
     if world == 1 and os.environ.get("QADC_BENCH_PMC", "1") != "0" and not os.environ.get("QADC_BENCH_FORCE_DIST"):
-        pmc, pmc_src = pmc_traffic_in_run(M, N)
+        pmc, pmc_src = pmc_traffic_in_run(M, N, NQ)
         if os.environ.get("QADC_BENCH_32X4", "1") != "0" and M == 16:
-            pmc32, pmc32_src = pmc_traffic_in_run(32, N)
+            pmc32, pmc32_src = pmc_traffic_in_run(32, N, 8)
 
     import torch
     import torch.distributed as dist
@@ -881,6 +925,7 @@ def main():
     idx.add_partition_synthetic_shard(N, first, local_n, SEED, starts)
     idx.finalize(KEEP)
     idx.set_option("profile", 1)
+    set_mode(idx, MODE_ONE_QUERY_PER_PASS)                     # the headline's mode (the metric's: SURVEY.md 8d)
     for kv in filter(None, os.environ.get("QADC_BENCH_OPTS", "").split(",")):     # tuning experiments only
         idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 
@@ -1061,55 +1106,54 @@ def main():
         hits += int(key in set(keys[q].tolist()))
     recall = hits / NQ
 
-    # ---- the one-query-per-pass leg (SURVEY.md §8d roofline), single rank only ----
+    # ---- `roofline`: the headline's OWN timed region (one query per pass), this rank's shard; rank 0's goes in the line ----
+    alg = prof["scan_codes"] * cs / max(prof["scan_launches"], 1)
+    if pmc is not None:
+        traffic, tsrc = pmc["traffic_over_algorithmic"] * alg, pmc_src + " (ratio of the same kind of launches x this region's bytes per launch)"
+    elif world == 1 and not use_dist:
+        traffic, tsrc2 = pmc_traffic_from_profiles(M, N, alg)
+        tsrc = "%s; %s" % (pmc_src, tsrc2)
+    else:
+        traffic, tsrc = None, "no PMC child pass in a multi-rank run (the N=1 line carries it)"
+    headline_roof = roofline_single(
+        M, local_n, prof, elapsed, NQ * args.steps, traffic, tsrc,
+        region="the headline's timed region: %d steps of %d queries, every query walks %s by itself (no sibling launch, no "
+               "multi-query pass), three steps in flight; HIP events around every run of consecutive streaming launches on the "
+               "library's stream" % (args.steps, NQ, "the whole list" if mworld == 1 else "this rank's 1/%d shard of the list" % mworld))
+    headline_roof["kernel"] = "scan_i8_kernel<%d,2,nt,chunk> (%d queries per launch, one pass over the level's codes each)" % (M, NQ)
+    if mworld > 1:
+        headline_roof["shard"] = {"rank": rank, "of": mworld, "codes": local_n}
+    if pmc is not None:
+        headline_roof["pmc"] = pmc
+
+    # ---- the batched mode, reported separately: the same steps, queries as L2-sharing siblings, 8 per pass ----
+    batched_elapsed, bprof = None, None
+    if os.environ.get("QADC_BENCH_BATCHED", "1") != "0":
+        set_mode(idx, MODE_BATCHED)
+        run_steps(args.warmup)
+        idx.profile_reset()
+        sync()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        sync()
+        batched_elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([batched_elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            batched_elapsed = float(t.item())
+        bprof = idx.profile()
+        set_mode(idx, MODE_ONE_QUERY_PER_PASS)
+
+    # ---- one query per CALL (sequential single-query batches): the strictest reading of the reference's mode, single rank only ----
     single = None
     if world == 1 and not use_dist:
         nsingle = int(os.environ.get("QADC_BENCH_SINGLE_QUERIES", 64))
         if nsingle > 0:
-            # every streaming launch of this leg on the main stream, inside the event-timed groups: the roofline figure
-            # then averages over exactly the launches `rocprofv3 --stats` lists for the kernel (the default would run
-            # the two shortest bound levels of a query on the front stream, counted but not event-timed)
-            idx.set_option("front_run_max", 0)
             sprof, sdt = single_query_leg(idx, M, N, pool, nsingle)
-            idx.set_option("front_run_max", 2 << 20)
-            alg = sprof["scan_codes"] * cs / max(sprof["scan_launches"], 1)
-            if pmc is not None:
-                traffic, tsrc = pmc["traffic_over_algorithmic"] * alg, pmc_src + " (ratio of the same launches x this region's bytes per launch)"
-            else:
-                traffic, tsrc2 = pmc_traffic_from_profiles(M, N, alg)
-                tsrc = "%s; %s" % (pmc_src, tsrc2)
-            single = roofline_single(M, N, sprof, sdt, nsingle, traffic, tsrc)
-            if pmc is not None:
-                single["pmc"] = pmc
+            single = roofline_single(M, N, sprof, sdt, nsingle, None, "not collected for this leg (the headline's PMC passes cover the same kernel)")
 
     if rank == 0:
         total_codes = float(N) * NQ * args.steps
-        scan_ms = prof["scan_ms"]
-        launches = max(prof["scan_launches"], 1)
-        avg_ms = scan_ms / launches
-        alg_bytes = prof["scan_codes"] * cs / launches
-        mq = prof["mq_launches"] > 0
-        # LDS-array cycles the launches need (MI355X_MICROARCH.md, LDS): multi-query kernel = one ds_read_b128 (4 cycles
-        # per 64 lanes) per code nibble and pass; single-query kernel = one ds_read_u8 (2 cycles) per code byte and query
-        lds_cycles = prof["pass_codes"] * (M * 4 if mq else (M // 2) * 2) / 64.0
-        lds_rate = lds_cycles / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        batched = {
-            "bound": "lds", "achieved": lds_rate, "peak": LDS_PEAK_GCYC, "unit": "G LDS-array cycles/s",
-            "frac": lds_rate / LDS_PEAK_GCYC,
-            "kernel": ("scan_i8_mq_kernel<%d,2> (8 queries per pass, %d passes per launch as L2-sharing siblings)"
-                       % (M, (NQ + 7) // 8)) if mq else "scan_i8_kernel<%d,2> (sibling-major launch)" % M,
-            "mode": "the headline's timed region: %d queries per step share every pass over the codes" % NQ,
-            "launches": prof["scan_launches"], "avg_launch_ms": avg_ms,
-            "lds_cycles_rule": "code reads of the launch x %d lookups x %d LDS cycles / 64 lanes "
-                               "(MI355X_MICROARCH.md LDS table); peak = 256 CUs x 2.4 GHz nominal — the PMC passes in "
-                               "profiles/ measure an effective clock of ~1.9-2.1 GHz under this load, i.e. the pipe is "
-                               "busier than frac says" % ((M, 4) if mq else (M // 2, 2)),
-            "code_reads_per_launch": prof["pass_codes"] / launches,
-            "pair_rate": {"value": prof["scan_codes"] / (scan_ms * 1e-3) if scan_ms > 0 else 0.0,
-                          "unit": "(code, query) pairs/s inside the timed launches"},
-            "hbm_note": "the queries of a launch share the codes through L2, so the HBM interface moves about 1/%d of "
-                        "%d B x (code, query) — see profiles/r02_batched_hbm_traffic.json; this mode is NOT priced "
-                        "against the HBM roofline (SURVEY.md 8d)" % (NQ, cs)}
         out = {
             "metric": "pq_codes_scanned_per_sec", "value": total_codes / elapsed, "unit": "codes/s",
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 1,
@@ -1119,26 +1163,54 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-            "config": {"workload": "flat DB, %d x %dx4 PQ codes (%d B/code), R=%d, keep=%.2f%%, sharded over %d GPU(s). "
-                                   "`value` = %d queries/step, every query scans the whole list, 8 queries per pass "
-                                   "(LDS-bound: `roofline_batched`).  `roofline` = the SAME list scanned ONE query per "
-                                   "pass (the reference's mode, HBM-bound), timed in its own region of this run"
+            "config": {"workload": "flat DB, %d x %dx4 PQ codes (%d B/code), R=%d, keep=%.2f%%, sharded over %d GPU(s); a step = "
+                                   "%d queries, ONE QUERY PER PASS: every query scans the whole list by itself (the reference's "
+                                   "mode, HBM-bound: `roofline` is this same timed region).  The multi-query-per-pass mode of the "
+                                   "same steps is reported separately as `value_batched` / `roofline_batched`"
                                    % (N, M, cs, R, KEEP * 100, world, NQ),
-                       "codes": N, "M": M, "R": R, "keep": KEEP, "queries_per_step": NQ,
+                       "codes": N, "M": M, "R": R, "keep": KEEP, "queries_per_step": NQ, "mode": "one query per pass",
                        "parallelism": "shard%d" % world},
             "recall_at_100": recall,
-            # the north-star figure next to `value`: ONE query per pass over the same list (the mode `roofline` prices against HBM);
-            # `value` is the batched mode (8 queries per pass, priced against the LDS roof in `roofline_batched`)
-            "value_one_query_per_pass": single["codes_per_sec_wall"] if single is not None else None,
-            "roofline": single if single is not None else
-            {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-             "note": "the one-query-per-pass leg runs on a single rank only (N=1 line)"},
-            "roofline_batched": batched,
+            "recall_note": "uniform random codes: the exact float-ADC nearest code is in the returned 100 for every query (near-vacuous); "
+                           "the credible figures are `recall_at_100_real_encode(_ivf)` with `reference_heaps_equal`",
+            "roofline": headline_roof,
             "phases": {"prescan_quantize_ms_per_step": prof["start_ms"] / args.steps,
-                       "scan_kernel_ms_per_step": scan_ms / args.steps,
+                       "scan_kernel_ms_per_step": prof["scan_ms"] / args.steps,
                        "host_sort_replay_ms_per_step": prof["host_replay_ms"] / args.steps,
                        "candidates_per_query": prof["candidates"] / (NQ * args.steps), "regrows": prof["regrows"]},
+            "multi_gpu_note": "no 8-GPU node was available to the builder: N > 1 has only run as N processes on ONE GPU over the "
+                              "shared-memory transport (tests) and with one rank over RCCL; no scaling curve was measured",
         }
+        if single is not None:
+            out["roofline_one_query_per_call"] = single
+            out["value_one_query_per_call"] = single["codes_per_sec_wall"]
+        if bprof is not None:
+            scan_ms = bprof["scan_ms"]
+            launches = max(bprof["scan_launches"], 1)
+            mq = bprof["mq_launches"] > 0
+            # LDS-array cycles the launches need (MI355X_MICROARCH.md, LDS): multi-query kernel = one ds_read_b128 (4 cycles
+            # per 64 lanes) per code nibble and pass; single-query kernel = one ds_read_u8 (2 cycles) per code byte and query
+            lds_cycles = bprof["pass_codes"] * (M * 4 if mq else (M // 2) * 2) / 64.0
+            lds_rate = lds_cycles / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+            out["value_batched"] = total_codes / batched_elapsed
+            out["ms_per_step_batched"] = batched_elapsed * 1e3 / args.steps
+            out["roofline_batched"] = {
+                "bound": "lds", "achieved": lds_rate, "peak": LDS_PEAK_GCYC, "unit": "G LDS-array cycles/s",
+                "frac": lds_rate / LDS_PEAK_GCYC,
+                "kernel": ("scan_i8_mq_kernel<%d,2> (8 queries per pass, %d passes per launch as L2-sharing siblings)"
+                           % (M, (NQ + 7) // 8)) if mq else "scan_i8_kernel<%d,2> (sibling-major launch)" % M,
+                "mode": "SURVEY.md 8f N2, its own timed region after the headline's: %d queries per step share every pass over the codes" % NQ,
+                "launches": bprof["scan_launches"], "avg_launch_ms": scan_ms / launches,
+                "lds_cycles_rule": "code reads of the launch x %d lookups x %d LDS cycles / 64 lanes "
+                                   "(MI355X_MICROARCH.md LDS table); peak = 256 CUs x 2.4 GHz nominal — the PMC passes in "
+                                   "profiles/ measure an effective clock of ~1.9-2.1 GHz under this load, i.e. the pipe is "
+                                   "busier than frac says" % ((M, 4) if mq else (M // 2, 2)),
+                "code_reads_per_launch": bprof["pass_codes"] / launches,
+                "pair_rate": {"value": bprof["scan_codes"] / (scan_ms * 1e-3) if scan_ms > 0 else 0.0,
+                              "unit": "(code, query) pairs/s inside the timed launches"},
+                "hbm_note": "the queries of a launch share the codes through L2, so the HBM interface moves about 1/%d of "
+                            "%d B x (code, query) — see profiles/r02_batched_hbm_traffic.json; this mode is NOT priced "
+                            "against the HBM roofline (SURVEY.md 8d)" % (NQ, cs)}
     cpu_s = float(os.environ.get("QADC_BENCH_CPU_SECONDS", 15))
     if rank == 0 and world == 1 and not use_dist and cpu_s > 0:
         # the int8 tables of one bench batch, for the CPU legs (same tables on both sides)
@@ -1207,17 +1279,19 @@ def main():
             i32.add_partition_synthetic_shard(N, 0, N, SEED, starts)
             i32.finalize(KEEP)
             i32.set_option("profile", 1)
-            i32.set_option("front_run_max", 0)                 # (as in the 16x4 leg: every streaming launch event-timed)
             cb32 = rng.normal(size=(32, 16, 4)).astype(np.float32)
-            pool32 = [make_tables(rng, cb32, 8)]
-            p32, dt32 = single_query_leg(i32, 32, N, pool32, 24)
+            NQ32, steps32 = 16, 3
+            pool32 = [make_tables(rng, cb32, NQ32)]
+            p32, dt32 = one_pass_batch_leg(i32, pool32, steps32, warm=1)         # the headline's mode on the 32x4 list
             alg32 = p32["scan_codes"] * 16 / max(p32["scan_launches"], 1)
-            out["roofline_32x4"] = roofline_single(32, N, p32, dt32, 24, None if pmc32 is None else pmc32["traffic_over_algorithmic"] * alg32,
-                                                   pmc32_src + ("" if pmc32 is None else " (ratio of the same launches x this region's bytes per launch)"))
+            out["roofline_32x4"] = roofline_single(32, N, p32, dt32, NQ32 * steps32, None if pmc32 is None else pmc32["traffic_over_algorithmic"] * alg32,
+                                                   pmc32_src + ("" if pmc32 is None else " (ratio of the same kind of launches x this region's bytes per launch)"),
+                                                   region="%d steps of %d queries, every query walks the whole list by itself (the headline's mode), three steps in "
+                                                          "flight; HIP events around every run of consecutive streaming launches" % (steps32, NQ32))
             if pmc32 is not None:
                 out["roofline_32x4"]["pmc"] = pmc32
             if cpu_s > 0:
-                qt32_cpu = i32.query_scan(np.zeros((8, 1), np.int32), pool32[0].copy(), R, want_qtables=True)["qtables"][:, 0]
+                qt32_cpu = i32.query_scan(np.zeros((8, 1), np.int32), pool32[0][:8].copy(), R, want_qtables=True)["qtables"][:, 0]
             i32.close()
         cpu_samples = {}
         if int(float(os.environ.get("QADC_BENCH_IVF_CODES", 1e8))) > 0:

@@ -72,7 +72,12 @@ def test_gpus_n_self_launch_runs_the_multi_rank_loop_on_one_gpu(ranks, native):
     assert line["n_gpus"] == ranks and line["rccl_ranks"] == ranks
     assert line["multi_gpu_merge"].startswith("native" if native else "pyqadc/sharded.py")
     assert line["recall_at_100"] == 1.0
-    assert line["roofline"]["frac"] is None           # the one-query-per-pass leg is an N=1 measurement
+    # the N-rank line carries the metric's mode too: rank 0's shard, one query per pass, priced against HBM (no PMC child at N > 1)
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1.0 and rf["traffic"] is None
+    assert rf["shard"] == {"rank": 0, "of": ranks, "codes": rf["shard"]["codes"]} and abs(rf["shard"]["codes"] - 4e7 / ranks) <= 64
+    assert line["config"]["mode"] == "one query per pass"
+    assert line["value_batched"] > 0 and line["roofline_batched"]["bound"] == "lds"
 
 
 @pytest.mark.gpu
@@ -103,11 +108,20 @@ def test_single_gpu_line_keeps_the_two_modes_apart():
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1.0 and "scan_i8_kernel<16,2,nt,chunk>" in rf["kernel"]
     assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-6)
+    # the headline triple comes from ONE timed region in the metric's mode: value = codes x queries / wall, the roofline's
+    # region is those same steps, and the algorithmic bytes of a step / ms_per_step stay under the HBM peak
+    assert line["config"]["mode"] == "one query per pass" and line["config"]["queries_per_step"] == 32
+    assert rf["region_queries"] == 32 * 3 and rf["region_wall_s"] == pytest.approx(line["ms_per_step"] * 3e-3, rel=1e-6)
+    assert line["value"] == pytest.approx(4e7 * 32 * 3 / rf["region_wall_s"], rel=1e-6)
+    assert 4e7 * 8 * 32 / (line["ms_per_step"] * 1e-3) / 1e9 <= rf["peak"]
+    assert rf["region_wall_s"] >= rf["launches"] * rf["avg_launch_ms"] * 1e-3 / 3     # (three steps in flight at most)
+    # the batched mode is a separate figure with its own roof; so is the one-query-per-CALL leg
     assert line["roofline_batched"]["bound"] == "lds" and 0 < line["roofline_batched"]["frac"] <= 1.0
+    assert line["value_batched"] > 0 and line["ms_per_step_batched"] > 0
+    rc = line["roofline_one_query_per_call"]
+    assert rc["bound"] == "hbm" and 0 < rc["frac"] <= 1.0 and rc["region_queries"] == 8
     assert 0 < line["roofline_32x4"]["frac"] <= 1.0
     assert line["ivf"]["us_per_query"] > 0 and line["latency_us_single_query"]["value"] > 0
-    assert rf["region_queries"] == 8 and rf["region_wall_s"] > 0
-    assert rf["region_wall_s"] >= rf["launches"] * rf["avg_launch_ms"] * 1e-3 / 3     # (three batches in flight at most)
     ri = line["roofline_ivf"]                                  # the IVF leg's own roofs: grouped scan vs LDS, head vs HBM
     assert ri["bound"] == "lds" and 0 < ri["frac"] <= 1.0 and 0 < ri["seat_fill"] <= 1.0
     assert ri["head"]["bound"] == "hbm" and 0 < ri["head"]["frac"] <= 1.0

@@ -50,15 +50,19 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
                 wgq_split=int(rng.choice([1, 3, 8])), wgq_variant=int(rng.choice([0, 1, 2, 3])),
                 wgq_capacity=int(rng.choice([64, 4096])), wgq_cand_cap=int(rng.choice([64, 4096, 4096])),
                 # partition-major second phase of device-replayed batches (with its overflow fallback), head length
-                wgq_group=int(rng.choice([0, 2, 2])), wgq_group_head=int(rng.choice([1, 2, 4])))
+                wgq_group=int(rng.choice([0, 2, 2])), wgq_group_head=int(rng.choice([1, 2, 4])),
+                # grouping of the float pre-scan's adds: the reference binary's (default) or the source's
+                sum_mode=int(rng.choice([1, 1, 0])))
     for k, v in opts.items():
         idx.set_option(k, v)
     tables = float_tables(rng, nq, ma, M, scale=float(rng.choice([0.2, 1.0])))
     if rng.integers(0, 2):
         tables = np.round(tables * 2) / 2                  # tie-heavy
+    if rng.integers(0, 4) == 0:                            # a few negative entries (BLAS-expansion tables): clamped in place
+        tables = np.where(rng.random(tables.shape) < 0.01, -np.float32(0.02) * tables, tables).astype(np.float32)
     res = idx.query_scan(assign, tables.copy(), R)
     for q in range(nq):
-        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
+        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R, sum_mode=opts["sum_mode"])
         if want["rc"] != 0:                                # the reference would exit: reported as status
             assert res["status"][q] == 1, (seed, q, opts)
             continue
