@@ -897,6 +897,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # The library's per-device stream set BEFORE any communicator exists (qadc_device_prepare): a communicator created first takes
+    # one of the runtime's four highest-priority queues and the set's streams then land on shared queues / pipes — one of 8 ranks'
+    # IVF batch measured 0.72 instead of 0.44 ms (C3) and 1.08 instead of 0.78 (C5): profiles/r05_queue_map_rccl.txt.  (torch's
+    # own HIP runtime has to be up first — tests/conftest.py — hence not earlier than this.)
+    torch.zeros(1, device=dev)
+    pyqadc.device_prepare(local_rank)
     cdev = dev if backend == "nccl" else torch.device("cpu")   # device of the collective buffers
     # QADC_BENCH_FORCE_DIST=1 takes the multi-rank code path (collectives included) even with one rank
     use_dist = world > 1 or bool(os.environ.get("QADC_BENCH_FORCE_DIST"))

@@ -37,6 +37,16 @@ const char* qadc_version(void);
  * [n][M/2] (one coalesced 16-byte load per lane); the 16-code block transpose is an AVX2 need.
  * ------------------------------------------------------------------------------------------- */
 
+/* Optional, idempotent: creates the library's per-device set of HIP streams NOW (the first qadc_index_create on the device does
+ * it otherwise).  The set — scan, copy, ordering, front, collectives, merge — is created once per process and device, back to
+ * back, because which hardware queue and compute pipe a stream lands on depends on the streams that exist already (DESIGN.md
+ * section 5).  Four of the seven are highest-priority streams and the runtime keeps at most four queues per priority: a process that
+ * creates a communicator (RCCL / torch.distributed "nccl": one more highest-priority stream) BEFORE the set measured a 40-60 %
+ * slower IVF batch (profiles/r05_queue_map_rccl.txt); created AFTER the set it costs nothing.  So: call this (or create the
+ * first index) right after the process selected its GPU and before it initialises any communicator.  No reference counterpart
+ * (the reference is single-process CPU code).  After hipDeviceReset() the set is rebuilt by the next call / index. */
+int qadc_device_prepare(int device_id);
+
 /* M = 16 or 32 sub-quantizers of 4 bits (get_simd_scan_func_epi8, db_query_4.cpp:22-35). */
 int qadc_index_create(qadc_index** out, int M, int device_id);
 int qadc_index_destroy(qadc_index* idx);

@@ -1097,6 +1097,30 @@ hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merg
     return hipSuccess;
 }
 
+// The per-device stream set of the process: found or created (the caller holds no lock).  A cached set whose streams the
+// runtime no longer knows (the application called hipDeviceReset between two indexes) is dropped and rebuilt.
+int shared_stream_set(int device, StreamSet** out) {
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    for (auto it = g_streams.begin(); it != g_streams.end(); ++it) {
+        if (it->first != device) continue;
+        const hipError_t q = hipStreamQuery(it->second->stream);
+        if (q == hipSuccess || q == hipErrorNotReady) { *out = it->second; return QADC_OK; }
+        (void)hipGetLastError();                                 // dead handles: forget them (they cannot be destroyed any more)
+        delete it->second;
+        g_streams.erase(it);
+        break;
+    }
+    StreamSet* ss = new StreamSet();
+    const hipError_t e = create_stream_set(*ss, "S,C,O,F,W,L,M0", 1, false, false);
+    if (e != hipSuccess) {
+        delete ss;
+        return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    g_streams.emplace_back(device, ss);
+    *out = ss;
+    return QADC_OK;
+}
+
 int attach_streams(qadc_index* idx, bool hooks) {
     std::string order = "S,C,O,F,W,L,M0";
     int n_merge = 1;
@@ -1119,18 +1143,7 @@ int attach_streams(qadc_index* idx, bool hooks) {
         }
         idx->own_streams = ss->created;                          // destroyed with the index
     } else {
-        std::lock_guard<std::mutex> lock(g_streams_mu);
-        for (auto& ds : g_streams)
-            if (ds.first == idx->device) ss = ds.second;
-        if (!ss) {
-            ss = new StreamSet();
-            const hipError_t e = create_stream_set(*ss, order, n_merge, merge_normal, w_low);
-            if (e != hipSuccess) {
-                delete ss;
-                return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
-            }
-            g_streams.emplace_back(idx->device, ss);
-        }
+        if (int rc = shared_stream_set(idx->device, &ss)) return rc;
     }
     idx->stream = ss->stream;
     idx->wgq_stream = ss->wgq;
@@ -1149,6 +1162,16 @@ extern "C" {
 
 const char* qadc_last_error(void) { return g_err.c_str(); }
 const char* qadc_version(void) { return "qadc-mi355x 0.1 (gfx950)"; }
+
+int qadc_device_prepare(int device_id) {
+    int ndev = 0;
+    HIPCHECK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(QADC_E_HIP, "no HIP device: the Quick-ADC engine has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(QADC_E_ARG, "device_id out of range");
+    HIPCHECK(hipSetDevice(device_id));
+    StreamSet* ss = nullptr;
+    return shared_stream_set(device_id, &ss);
+}
 
 int qadc_index_create(qadc_index** out, int M, int device_id) {
     if (!out) return fail(QADC_E_ARG, "out is null");

@@ -17,6 +17,35 @@ if _hist in ("destroyed", "alive"):
     _other.query_scan(np.zeros((1, 1), np.int32), np.random.default_rng(0).random((1, 1, 256)).astype(np.float32), 10)
     if _hist == "destroyed":
         _other.close()
+# a LIVE RCCL communicator in the process (round 5): does a communicator's own queues land on the scan's or the
+# front's compute pipe?  "torch_before" = torch.distributed's nccl group (torch's bundled RCCL), one all_reduce, BEFORE the library's
+# stream set exists; "lib_after" = the library's own dlopen-ed RCCL (qadc_dist_init, world 1) on a holder index, i.e. right AFTER
+# the stream set was created by that index; "lib_after_torch_before" = both.  The measured index then merges through the loopback
+# stand-in as always (a world-1 communicator cannot carry an 8-rank merge).
+_rccl = os.environ.get("QADC_PROBE_RCCL", "none")
+if "torch_cuda_only" in _rccl:                               # torch's HIP runtime up (null stream only), no communicator
+    import torch
+    torch.cuda.set_device(0); torch.zeros(1, device="cuda"); torch.cuda.synchronize()
+if "set_first" in _rccl:                                     # the library's stream set exists BEFORE torch creates its communicator
+    import torch
+    torch.cuda.set_device(0); torch.zeros(1, device="cuda"); torch.cuda.synchronize()
+    import pyqadc
+    pyqadc.device_prepare(0)                                 # (what bench.py does before dist.init_process_group)
+    _rccl += "_torch_before"
+if "torch_before" in _rccl:
+    import torch, torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _t = torch.ones(1 << 20, device="cuda"); dist.all_reduce(_t); dist.all_gather_into_tensor(torch.empty(1 << 20, device="cuda"), _t); torch.cuda.synchronize()
+if "lib_after" in _rccl:
+    import numpy as np, pyqadc
+    _holder = pyqadc.Index(16, 0)
+    _holder.add_partition_synthetic(100000, 1)
+    _holder.finalize(0.01)
+    _holder.dist_init(0, 1, pyqadc.dist_unique_id())
+    _holder.submit(0, np.zeros((4, 1), np.int32), np.random.default_rng(0).random((4, 1, 256)).astype(np.float32), 10)
+    _holder.dist_collect(0)                                  # one live all-gather through the communicator
 name, placement = sys.argv[1], sys.argv[2]
 r = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 shard = None if placement == "none" else dict(rank=r, world=WORLD, placement=placement, init=lambda ix: ix.dist_init_loopback(r, WORLD), merge="loopback")
