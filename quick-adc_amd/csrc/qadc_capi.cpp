@@ -644,6 +644,8 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
         need_stream = true;
         if (idx->dist && idx->dist->slot[slot_i].pending)
             if (int rc = flush_merges(idx, idx->dist->slot[slot_i].seq)) return rc;
+        if (idx->dist && idx->dist->slot[slot_i].pending_share)
+            if (int rc = flush_shares(idx, idx->dist->slot[slot_i].seq)) return rc;
         if (idx->dist && idx->dist->slot[slot_i].enqueued) {     // a merge was enqueued with the batch: let it finish (its result is unused)
             HIPCHECK(hipEventSynchronize(idx->dist->slot[slot_i].ev_done));
             idx->dist->slot[slot_i].enqueued = false;
@@ -1544,6 +1546,14 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "dist_async") {                             // 1: enqueue the merge with the batch where possible; 0: always at collect time
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
         idx->dist->async_merge = value != 0;
+    }
+    else if (n == "dist_shard_replay") {                      // 1: an enqueued merge replays this rank's share of the queries only (+ a heap gather)
+        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
+        idx->dist->shard_replay = value != 0;
+    }
+    else if (n == "dist_share_lag") {                         // the heap gather of merge s is issued behind the first gather of merge s + lag
+        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
+        idx->dist->share_lag = (int)std::max(0.0, std::min(value, 6.0));
     }
     else if (n == "dist_shard_front") {                       // 1: feeders + pre-scan + quantizer of a qadc_search batch are split over the ranks
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");

@@ -33,10 +33,21 @@ int load_rccl(DistState& d, std::string& err) {
 // same order (the ranks submit and collect the same batches in the same order).
 // Not taken (the collect-time merge runs instead): few-query batches (host-share replay), R or ma x world beyond the device
 // merge, option dist_async = 0.
+// The replay is sharded by query (option dist_shard_replay, world > 1): rank r interleaves and replays queries r, r + world, ...
+// only — 1/world of the waves, 1/world of the scattered bytes — and a second all-gather of the heap shares ((R + 1/2) words
+// per query) + dist_heaps_unpack_kernel put every rank's d_out in the state the unsharded replay leaves.  The replay is a
+// latency chain of ~0.4 ms; its share gather is therefore NOT issued right behind it on the collectives' stream (everything
+// later on that stream — the next batches' front and merge gathers — would wait for it) but behind the first gather of a
+// LATER merge (share_lag = 1 batch later; or at collect), when the chain is long over.  All of it in host program order, which
+// is the same on every rank, from rank-invariant state (sequence numbers, option values): the ranks issue the same collectives
+// in the same order.
 // Two steps.  enqueue_merge (at the end of the batch's launch) records where the scan ends and marks the merge PENDING;
 // flush_merges issues the pending merges in submission order.  A batch with a sharded front flushes the OLDER merges right
 // after issuing its own front gather: on the collectives' stream that gather then lies in front of the previous batch's
 // merge gather (which waits for that batch's scan), so a front that runs under the previous scan is not held up by it.
+// heap share of a rank: heaps u64[per][R], then sizes u32[per]
+static size_t share_words(int per, int R) { return (size_t)per * R + ((size_t)per + 1) / 2; }
+
 int enqueue_merge_now(qadc_index* idx, Slot& s) {
     DistState& d = *idx->dist;
     const int slot_i = (int)(&s - idx->slot);
@@ -78,11 +89,57 @@ int enqueue_merge_now(qadc_index* idx, Slot& s) {
     hipStream_t ms = d.merge_stream[ds.seq % kMergeStreams] ? d.merge_stream[ds.seq % kMergeStreams] : st;
     if (ms != st) HIPCHECK(hipStreamWaitEvent(ms, ds.ev_gathered, 0));
     uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ds.d_out + sizeof(uint64_t) * (size_t)R * nq);
+    if (d.shard_replay && world > 1) {
+        const int per = (nq + world - 1) / world;
+        const size_t sw = share_words(per, R);
+        HIPCHECK(ds.d_share.ensure(sw));
+        HIPCHECK(ds.d_shares.ensure(sw * world));
+        if (!ds.ev_replayed) HIPCHECK(hipEventCreateWithFlags(&ds.ev_replayed, hipEventDisableTiming));
+        // (a rank past the last query of a ragged batch replays fewer; the unpack never reads those heaps)
+        HIPCHECK(launch_dist_merge(ds.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, ds.d_moff.p, ds.d_mcnt.p, ds.d_mcnt.p + nq,
+                                   ds.d_merged.p, ds.d_share.p, reinterpret_cast<uint32_t*>(ds.d_share.p + (size_t)per * R), ms,
+                                   d_sizes + nq, d.rank, world));
+        HIPCHECK(hipEventRecord(ds.ev_replayed, ms));
+        ds.pending_share = true;
+        ds.share_nq = nq;
+        ds.share_R = R;
+        ds.enqueued = true;                                      // (ev_done is recorded by issue_share)
+        return QADC_OK;
+    }
     HIPCHECK(launch_dist_merge(ds.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, ds.d_moff.p, ds.d_mcnt.p, ds.d_mcnt.p + nq,
                                ds.d_merged.p, reinterpret_cast<uint64_t*>(ds.d_out), d_sizes, ms, d_sizes + nq));
     HIPCHECK(hipEventRecord(ds.ev_done, ms));
     ds.enqueued = true;
     return QADC_OK;
+}
+
+// The second half of a sharded replay: all-gather of the heap shares + unpack into the slot's mapped result block.
+int issue_share(qadc_index* idx, DistSlot& ds) {
+    DistState& d = *idx->dist;
+    ds.pending_share = false;
+    const int nq = ds.share_nq, R = ds.share_R, world = d.world;
+    const int per = (nq + world - 1) / world;
+    const size_t sw = share_words(per, R);
+    hipStream_t st = d.stream;
+    HIPCHECK(hipStreamWaitEvent(st, ds.ev_replayed, 0));
+    std::string gerr;
+    if (d.gather(ds.d_share.p, ds.d_shares.p, sw, st, gerr)) return fail(QADC_E_HIP, gerr);
+    uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ds.d_out + sizeof(uint64_t) * (size_t)R * nq);
+    HIPCHECK(launch_dist_heaps_unpack(ds.d_shares.p, sw, world, per, nq, (uint32_t)R, reinterpret_cast<uint64_t*>(ds.d_out), d_sizes, st));
+    HIPCHECK(hipEventRecord(ds.ev_done, st));
+    return QADC_OK;
+}
+
+// Issues the share gathers of the merges with seq <= upto, oldest first.
+int flush_shares(qadc_index* idx, uint64_t upto) {
+    DistState& d = *idx->dist;
+    for (;;) {
+        int best = -1;
+        for (int i = 0; i < kSlots; ++i)
+            if (d.slot[i].pending_share && d.slot[i].seq <= upto && (best < 0 || d.slot[i].seq < d.slot[best].seq)) best = i;
+        if (best < 0) return QADC_OK;
+        if (int rc = issue_share(idx, d.slot[best])) return rc;
+    }
 }
 
 // Issues the pending merges with seq <= upto, oldest first.
@@ -94,7 +151,11 @@ int flush_merges(qadc_index* idx, uint64_t upto) {
         for (int i = 0; i < kSlots; ++i)
             if (d.slot[i].pending && d.slot[i].seq <= upto && (best < 0 || d.slot[i].seq < d.slot[best].seq)) best = i;
         if (best < 0) return QADC_OK;
+        const uint64_t seq = d.slot[best].seq;
         if (int rc = enqueue_merge_now(idx, idx->slot[best])) return rc;
+        // the heap shares of the merges `share_lag` back: their replays are over by now, the gather does not hold up this stream
+        if (seq >= (uint64_t)d.share_lag)
+            if (int rc = flush_shares(idx, seq - (uint64_t)d.share_lag)) return rc;
     }
 }
 
@@ -434,6 +495,8 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
     DistSlot& ds = d.slot[slot];
     if (ds.pending)
         if (int rc = flush_merges(idx, ds.seq)) return rc;
+    if (ds.pending_share)                                     // (the batch is being collected before a later merge issued its share gather)
+        if (int rc = flush_shares(idx, ds.seq)) return rc;
     const bool was_enqueued = ds.enqueued;
     if (was_enqueued) {                                       // the merge ran behind the scan: wait for all of it
         HIPCHECK(hipEventSynchronize(ds.ev_done));

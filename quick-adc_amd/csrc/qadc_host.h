@@ -248,13 +248,20 @@ struct DistSlot {
     bool enqueued = false;
     bool pending = false;                                    // scan enqueued, merge not yet: it is issued BEHIND the next batch's front
     uint64_t seq = 0;                                        // gather (flush_merges), so that that gather never waits for this batch's scan
+    // replay sharded by query (option "dist_shard_replay"): this rank replayed queries rank, rank + world, ... into d_share; the shares'
+    // all-gather + unpack (`pending_share`) is issued behind a LATER merge's first gather, when the replay's latency chain is over
+    DevBuf<uint64_t> d_share, d_shares;
+    hipEvent_t ev_replayed = nullptr;
+    bool pending_share = false;
+    int share_nq = 0, share_R = 0;
     void release() {
         d_block.release(); d_gathered.release(); d_merged.release(); d_moff.release(); d_mcnt.release(); h_out.release();
-        d_src.release();
+        d_src.release(); d_share.release(); d_shares.release();
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_done) (void)hipEventDestroy(ev_done);
         if (ev_gathered) (void)hipEventDestroy(ev_gathered);
-        ev_ready = ev_done = ev_gathered = nullptr;
+        if (ev_replayed) (void)hipEventDestroy(ev_replayed);
+        ev_ready = ev_done = ev_gathered = ev_replayed = nullptr;
     }
 };
 
@@ -301,6 +308,9 @@ struct DistState {
     int device_nq = 256;                                     // batches of at least this many queries replay on the device
     int inject_failure = 0;                                  // test hook: the next qadc_dist_collect of this rank fails locally
     int async_merge = 1;                                     // enqueue the merge with the batch where possible (option "dist_async")
+    int shard_replay = 1;                                    // an enqueued merge replays only this rank's share of the queries; a second,
+                                                             // small all-gather shares the heaps (option "dist_shard_replay")
+    int share_lag = 1;                                       // ... issued behind the first gather of the merge `share_lag` batches later
     uint64_t next_seq = 1;
     int shard_front = 1;                                     // qadc_search batches: every rank runs the front of 1/world of the queries (option "dist_shard_front")
     DistSlot slot[kSlots];
@@ -464,6 +474,7 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
 int load_rccl(DistState& d, std::string& err);
 int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream);
 int flush_merges(qadc_index* idx, uint64_t upto);
+int flush_shares(qadc_index* idx, uint64_t upto);            // heap-share gathers of sharded replays (qadc_dist.cpp)
 
 }  // namespace host
 }  // namespace qadc

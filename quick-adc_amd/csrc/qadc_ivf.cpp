@@ -482,7 +482,11 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
     if (!s.ev_assign) HIPCHECK(hipEventCreateWithFlags(&s.ev_assign, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(s.ev_assign, cs));
     // one workgroup per query: the kernel reads assign[] on the device, the host only wants it back for the caller
-    const uint64_t est_codes = idx->parts.empty() ? 0 : idx->total_codes / idx->parts.size() * (uint64_t)(idx->feed.K ? ma : 1);
+    // (under the multi-GPU merge the estimate comes from the partitions' GLOBAL sizes, like the sharded front's above: the scan
+    // path — hence which kernels a later collective may be keyed on — must not depend on how many codes THIS rank happens to hold;
+    // qadc_host.h, "rank-invariant state")
+    const uint64_t est_total = idx->dist ? idx->total_global_codes : idx->total_codes;
+    const uint64_t est_codes = idx->parts.empty() ? 0 : est_total / idx->parts.size() * (uint64_t)(idx->feed.K ? ma : 1);
     s.wgq = wgq_eligible(idx, nq, ma, R, 0, est_codes);
     s.wgq_codes = est_codes;
     s.assign_on_device = s.wgq;

@@ -198,9 +198,16 @@ uint32_t replay_wave_max_R();
 size_t dist_interleave_max_cells();
 // d_status (optional, 2 words, may be host-mapped): [0] = OR of the header bits that void the merge (bit6 block too
 // small, bit7 a rank must re-run / failed, bit8 a query shipped unordered), [1] = entries the fullest rank block needs.
+// q0 / qstep: only queries q0, q0 + qstep, ... are interleaved and replayed, and their heaps / sizes are written DENSELY
+// (heap w = query q0 + w * qstep) — the share of a rank that splits the replay with its peers (q0 = rank, qstep = world; the
+// shares travel by a second, small all-gather and launch_dist_heaps_unpack puts them in query order).  Totals, prefix and the
+// status words always cover all nq queries (every rank must reach the same verdict).
 hipError_t launch_dist_merge(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
                              uint64_t* d_moff, uint32_t* d_mcnt, uint32_t* d_info, uint64_t* d_merged, uint64_t* d_heaps,
-                             uint32_t* d_heap_sizes, hipStream_t stream, uint32_t* d_status = nullptr);
+                             uint32_t* d_heap_sizes, hipStream_t stream, uint32_t* d_status = nullptr, int q0 = 0, int qstep = 1);
+// d_all = the gathered shares, `share_words` u64 each: heaps u64[per][R] then sizes u32[per]; rank r's j-th heap is query j * world + r.
+hipError_t launch_dist_heaps_unpack(const uint64_t* d_all, size_t share_words, int world, int per, int nq, uint32_t R, uint64_t* d_heaps,
+                                    uint32_t* d_sizes, hipStream_t stream);
 // The loopback stand-in for an all-gather (qadc_dist_init_loopback): the block into all `world` slots, one kernel.
 hipError_t launch_replicate_block(const void* d_src, void* d_dst, size_t words, int world, hipStream_t stream);
 // Level-path batches: {offset, count, flags}[nq] (the three arrays launch_dist_pack takes) from the query states the
@@ -213,8 +220,9 @@ hipError_t launch_dist_pack_qflags(const uint32_t* d_qflags, int nq, const uint6
 // kv_binheap push replay, ONE WAVE per query, heap in registers (the lanes sift all levels of a push at once and
 // pre-filter 64 stream entries per ballot): stream[off[q] .. off[q] + cnt[q]); info[q] bit0 = skip (size 0),
 // bit1 = leave to the host (size 0xffffffff).
+// (q0 / qstep: wave w replays query q0 + w * qstep and writes heap w — see launch_dist_merge)
 hipError_t launch_replay_heap_wave(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
-                                   int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
+                                   int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream, int q0 = 0, int qstep = 1);
 // ... on the single-GPU layout of launch_replay_heap_lanes: query q's stream at q * cap, {flags, entries} in d_qflags[4q..].
 // ... on the level path's layout: the compact ordered output of sort_cands_kernel, described by the query states.
 hipError_t launch_replay_heap_wave_states(const QueryState* d_qs, const uint64_t* d_stream, uint32_t out_cap, int nq, uint32_t R,

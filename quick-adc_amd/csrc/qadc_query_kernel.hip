@@ -1941,12 +1941,15 @@ template <int NREG, int QF>
 __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(const uint64_t* __restrict__ stream, const uint64_t* __restrict__ off,
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ info,
                                                                uint32_t cap, int nq, uint32_t R, uint64_t* __restrict__ heaps,
-                                                               uint32_t* __restrict__ heap_sizes) {
+                                                               uint32_t* __restrict__ heap_sizes, int q0, int qstep) {
     // (raised wave priority — s_setprio 3 here and in the two merge kernels — was measured in round 4: no change in one of 8
     // ranks' batch; what the merge chain waits for beside the scans is not the issue port)
     const uint32_t lane = threadIdx.x & 63u;
-    const int q = (int)(blockIdx.x * (uint32_t)kReplayWaves + (threadIdx.x >> 6));
-    if (q >= nq) return;
+    // wave w of the launch replays query q and writes heap w.  QF 0 (the multi-GPU merge): q = q0 + w * qstep — a rank that replays
+    // only ITS share of a batch's queries (q = rank, rank + world, ...) packs their heaps densely; elsewhere q = w.
+    const int w = (int)(blockIdx.x * (uint32_t)kReplayWaves + (threadIdx.x >> 6));
+    if (w >= nq) return;
+    const int q = QF == 0 ? q0 + w * qstep : w;
     uint32_t fl, n;
     uint64_t o;
     if (QF == 2) {
@@ -1968,11 +1971,11 @@ __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(con
         o = off[q];
     }
     if (fl & 2u) {
-        if (lane == 0) heap_sizes[q] = 0xffffffffu;
+        if (lane == 0) heap_sizes[w] = 0xffffffffu;
         return;
     }
     if (fl & 1u) {
-        if (lane == 0) heap_sizes[q] = 0;
+        if (lane == 0) heap_sizes[w] = 0;
         return;
     }
     const uint64_t* __restrict__ src = stream + (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
@@ -2009,9 +2012,22 @@ __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(con
 #pragma unroll
     for (int j = 0; j < NREG; ++j) {
         const uint32_t p = (uint32_t)j * 64u + lane;             // element p - 1
-        if (p >= 1 && p <= h.size) heaps[(size_t)q * R + (p - 1)] = (uint64_t)h.hk[j] | ((uint64_t)h.hv[j] << 32);
+        if (p >= 1 && p <= h.size) heaps[(size_t)w * R + (p - 1)] = (uint64_t)h.hk[j] | ((uint64_t)h.hv[j] << 32);
     }
-    if (lane == 0) heap_sizes[q] = h.size;
+    if (lane == 0) heap_sizes[w] = h.size;
+}
+
+// ---- sharded replay of the multi-GPU merge: the ranks' heap shares -> the batch's heaps in query order ----
+// Rank r replayed queries r, r + world, ...: share block = heaps u64[per][R], then sizes u32[per] (per = ceil(nq / world)).
+__global__ __launch_bounds__(256) void dist_heaps_unpack_kernel(const uint64_t* __restrict__ all, size_t share_words, int world, int per, int nq,
+                                                                uint32_t R, uint64_t* __restrict__ heaps, uint32_t* __restrict__ sizes) {
+    const int q = blockIdx.x;                                    // one workgroup per query
+    const int r = q % world, j = q / world;
+    const uint64_t* blk = all + (size_t)r * share_words;
+    const uint32_t sz = reinterpret_cast<const uint32_t*>(blk + (size_t)per * R)[j];
+    const uint32_t n = sz == 0xffffffffu ? 0u : min(sz, R);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) heaps[(size_t)q * R + i] = blk[(size_t)j * R + i];
+    if (threadIdx.x == 0) sizes[q] = sz;
 }
 
 // ---- sharded front: the ranks' shares -> the batch's arrays in query order ----
@@ -2132,11 +2148,11 @@ __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __res
 // (g, s) order.  Dynamic LDS: 2 x ma x world counters.
 __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world,
                                                               int nq, int ma, const uint64_t* __restrict__ moff,
-                                                              const uint32_t* __restrict__ info, uint64_t* __restrict__ merged) {
+                                                              const uint32_t* __restrict__ info, uint64_t* __restrict__ merged, int q0, int qstep) {
     uint32_t* cnt_sg = reinterpret_cast<uint32_t*>(qsmem);        // [ma][world] -> exclusive prefix in (s, g) order
     uint32_t* cnt_gs = cnt_sg + (size_t)ma * world;               // [world][ma] -> exclusive prefix in (g, s) order
     __shared__ uint32_t wtot[4];
-    const int q = blockIdx.x;
+    const int q = q0 + (int)blockIdx.x * qstep;                   // (a rank that merges only its share of the queries: rank, rank + world, ...)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (info[q]) return;
     const int cells = ma * world;
@@ -2380,22 +2396,23 @@ size_t dist_interleave_max_cells() { return 8192; }              // ma x world c
 // One wave per query over stream[off[q] .. +cnt[q]); R <= replay_wave_max_R().
 template <int QF>
 static hipError_t launch_replay_wave_t(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
-                                       uint32_t cap, int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
+                                       uint32_t cap, int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream,
+                                       int q0 = 0, int qstep = 1) {
     if (R == 0 || R > replay_wave_max_R()) return hipErrorInvalidValue;
     const dim3 grid((nq + kReplayWaves - 1) / kReplayWaves), block(kReplayWaves * 64);
     switch ((R + 64) / 64) {                                     // positions 1 .. R
-        case 1: hipLaunchKernelGGL((replay_heap_wave_kernel<1, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
-        case 2: hipLaunchKernelGGL((replay_heap_wave_kernel<2, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
-        case 3: hipLaunchKernelGGL((replay_heap_wave_kernel<3, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
-        case 4: hipLaunchKernelGGL((replay_heap_wave_kernel<4, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
-        case 5: hipLaunchKernelGGL((replay_heap_wave_kernel<5, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
-        default: hipLaunchKernelGGL((replay_heap_wave_kernel<6, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes); break;
+        case 1: hipLaunchKernelGGL((replay_heap_wave_kernel<1, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes, q0, qstep); break;
+        case 2: hipLaunchKernelGGL((replay_heap_wave_kernel<2, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes, q0, qstep); break;
+        case 3: hipLaunchKernelGGL((replay_heap_wave_kernel<3, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes, q0, qstep); break;
+        case 4: hipLaunchKernelGGL((replay_heap_wave_kernel<4, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes, q0, qstep); break;
+        case 5: hipLaunchKernelGGL((replay_heap_wave_kernel<5, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes, q0, qstep); break;
+        default: hipLaunchKernelGGL((replay_heap_wave_kernel<6, QF>), grid, block, 0, stream, d_stream, d_off, d_cnt, d_info, cap, nq, R, d_heaps, d_heap_sizes, q0, qstep); break;
     }
     return hipGetLastError();
 }
 hipError_t launch_replay_heap_wave(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
-                                   int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
-    return launch_replay_wave_t<0>(d_stream, d_off, d_cnt, d_info, 0, nq, R, d_heaps, d_heap_sizes, stream);
+                                   int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream, int q0, int qstep) {
+    return launch_replay_wave_t<0>(d_stream, d_off, d_cnt, d_info, 0, nq, R, d_heaps, d_heap_sizes, stream, q0, qstep);
 }
 hipError_t launch_replay_heap_wave_qflags(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
                                           uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
@@ -2411,16 +2428,24 @@ hipError_t launch_replay_heap_wave_states(const QueryState* d_qs, const uint64_t
 // d_moff [nq] u64, d_mcnt / d_info [nq] u32, d_merged [world * entries of a block] u64: scratch of the caller.
 hipError_t launch_dist_merge(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
                              uint64_t* d_moff, uint32_t* d_mcnt, uint32_t* d_info, uint64_t* d_merged, uint64_t* d_heaps,
-                             uint32_t* d_heap_sizes, hipStream_t stream, uint32_t* d_status) {
-    if (world > 16 || (size_t)ma * world > dist_interleave_max_cells() || R > replay_wave_max_R()) return hipErrorInvalidValue;
+                             uint32_t* d_heap_sizes, hipStream_t stream, uint32_t* d_status, int q0, int qstep) {
+    if (world > 16 || (size_t)ma * world > dist_interleave_max_cells() || R > replay_wave_max_R() || q0 < 0 || qstep < 1) return hipErrorInvalidValue;
+    const int nmine = q0 < nq ? (nq - q0 + qstep - 1) / qstep : 0;   // queries q0, q0 + qstep, ...: interleaved and replayed here
     static std::atomic<uint64_t> done{0};
     const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&dist_interleave_kernel), 65536, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(dist_totals_kernel, dim3(1), dim3(kTotalsThreads), 0, stream, d_gathered, block_words, world, nq, d_moff, d_mcnt, d_info,
                        d_status);
-    hipLaunchKernelGGL(dist_interleave_kernel, dim3(nq), dim3(256), (size_t)ma * world * 8, stream, d_gathered, block_words, world, nq, ma,
-                       d_moff, d_info, d_merged);
-    return launch_replay_heap_wave(d_merged, d_moff, d_mcnt, d_info, nq, R, d_heaps, d_heap_sizes, stream);
+    if (nmine == 0) return hipGetLastError();
+    hipLaunchKernelGGL(dist_interleave_kernel, dim3(nmine), dim3(256), (size_t)ma * world * 8, stream, d_gathered, block_words, world, nq, ma,
+                       d_moff, d_info, d_merged, q0, qstep);
+    return launch_replay_heap_wave(d_merged, d_moff, d_mcnt, d_info, nmine, R, d_heaps, d_heap_sizes, stream, q0, qstep);
+}
+
+hipError_t launch_dist_heaps_unpack(const uint64_t* d_all, size_t share_words, int world, int per, int nq, uint32_t R, uint64_t* d_heaps,
+                                    uint32_t* d_sizes, hipStream_t stream) {
+    hipLaunchKernelGGL(dist_heaps_unpack_kernel, dim3(nq), dim3(256), 0, stream, d_all, share_words, world, per, nq, R, d_heaps, d_sizes);
+    return hipGetLastError();
 }
 
 hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,

@@ -88,8 +88,14 @@ int shm_barrier(ShmTransport* t) {
         if (h->generation.load(std::memory_order_acquire) != gen) return QADC_OK;
         if (h->abort_flag.load(std::memory_order_acquire)) return shm_fail(QADC_E_STATE, "shm transport: another rank aborted");
         if ((spins & 255u) == 255u) {
-            if ((spins & 0xffffu) == 0xffffu && t->rank != 0 && !shm_same_segment(t))
+            if ((spins & 0xffffu) == 0xffffu && t->rank != 0 && !shm_same_segment(t)) {
+                // The name no longer leads here.  That is also what a FINISHED run looks like: rank 0 may have left this very
+                // barrier and unlinked the name (qadc_shm_transport_close) between this rank's generation load and the stat.
+                // So look at the barrier once more before calling it fatal: released or aborted wins over "replaced".
+                if (h->generation.load(std::memory_order_acquire) != gen) return QADC_OK;
+                if (h->abort_flag.load(std::memory_order_acquire)) return shm_fail(QADC_E_STATE, "shm transport: another rank aborted");
                 return shm_fail(QADC_E_STATE, "shm transport: the segment was replaced under this rank (it had joined a stale segment of an earlier run)");
+            }
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > t->timeout_s) {
                 h->abort_flag.store(1, std::memory_order_release);
                 return shm_fail(QADC_E_STATE, "shm transport: barrier timed out (a rank is missing or failed)");

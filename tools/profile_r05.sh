@@ -10,32 +10,35 @@
 TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
+# raw traces are hundreds of MB: they stay under /tmp on the box; only the summaries (gpurun_out/profiles_<tag>/) and the small logs travel back
+RAW=/tmp/qadc_prof_raw
+rm -rf $RAW; mkdir -p $RAW $R/gpurun_out
 cd /tmp
 OFF="QADC_BENCH_CPU_SECONDS=0 QADC_BENCH_REAL_CODES=0 QADC_BENCH_SINGLE_QUERIES=0 QADC_BENCH_32X4=0 QADC_BENCH_IVF_CODES=0 QADC_BENCH_LATENCY=0 QADC_BENCH_PMC=0 QADC_BENCH_C2=0"
 # (1)
 env $OFF true
-( export $OFF; rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_headline_kt -- python3 $R/bench.py --steps 20 --warmup 2 > $R/gpurun_out/prof_${TAG}_headline_kt.log 2>&1 )
+( export $OFF; rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/prof_${TAG}_headline_kt -- python3 $R/bench.py --steps 20 --warmup 2 > $RAW/prof_${TAG}_headline_kt.log 2>&1 )
 # (2)
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/prof_${TAG}_headline_$C -- python3 $R/bench.py --pmc-leg > $R/gpurun_out/prof_${TAG}_headline_$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $RAW/prof_${TAG}_headline_$C -- python3 $R/bench.py --pmc-leg > $RAW/prof_${TAG}_headline_$C.log 2>&1
 done
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_${TAG}_headline_sq -- python3 $R/bench.py --pmc-leg > $R/gpurun_out/prof_${TAG}_headline_sq.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_${TAG}_headline_sq2 -- python3 $R/bench.py --pmc-leg > $R/gpurun_out/prof_${TAG}_headline_sq2.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $RAW/prof_${TAG}_headline_sq -- python3 $R/bench.py --pmc-leg > $RAW/prof_${TAG}_headline_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $RAW/prof_${TAG}_headline_sq2 -- python3 $R/bench.py --pmc-leg > $RAW/prof_${TAG}_headline_sq2.log 2>&1
 # (4)
-QADC_BENCH_CPU_SECONDS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_kt -- python3 $R/bench.py --steps 5 --warmup 1 > $R/gpurun_out/prof_${TAG}_kt.log 2>&1
+QADC_BENCH_CPU_SECONDS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/prof_${TAG}_kt -- python3 $R/bench.py --steps 5 --warmup 1 > $RAW/prof_${TAG}_kt.log 2>&1
 # (5)
 for SH in c3 c5; do
   X=ivf; [ $SH = c5 ] && X=ivfc5
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${X}_kt -- python3 $R/tools/ivf_shard_one.py $SH none > $R/gpurun_out/prof_${TAG}_${X}_kt.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/prof_${TAG}_${X}_kt -- python3 $R/tools/ivf_shard_one.py $SH none > $RAW/prof_${TAG}_${X}_kt.log 2>&1
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/prof_${TAG}_${X}_$C -- python3 $R/tools/ivf_shard_one.py $SH none > $R/gpurun_out/prof_${TAG}_${X}_$C.log 2>&1
+    rocprofv3 --pmc $C --output-format csv -d $RAW/prof_${TAG}_${X}_$C -- python3 $R/tools/ivf_shard_one.py $SH none > $RAW/prof_${TAG}_${X}_$C.log 2>&1
   done
-  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_${TAG}_${X}_sq -- python3 $R/tools/ivf_shard_one.py $SH none > $R/gpurun_out/prof_${TAG}_${X}_sq.log 2>&1
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_${TAG}_${X}_sq2 -- python3 $R/tools/ivf_shard_one.py $SH none > $R/gpurun_out/prof_${TAG}_${X}_sq2.log 2>&1
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $RAW/prof_${TAG}_${X}_sq -- python3 $R/tools/ivf_shard_one.py $SH none > $RAW/prof_${TAG}_${X}_sq.log 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $RAW/prof_${TAG}_${X}_sq2 -- python3 $R/tools/ivf_shard_one.py $SH none > $RAW/prof_${TAG}_${X}_sq2.log 2>&1
 done
 cd $R
-python3 bench.py > gpurun_out/${TAG}_bench_plain.json 2> gpurun_out/${TAG}_bench_plain.err
-bash tools/dist_sizes_r05.sh > gpurun_out/${TAG}_shard_sizes.txt 2>&1
-QADC_TEST_HOOKS=1 bash tools/stream_order_ab3.sh > /dev/null 2>&1; cp gpurun_out/stream_order3.txt gpurun_out/${TAG}_ivf_shard_sizes.txt
-QADC_PROFILES_OUT=$R/gpurun_out/profiles_${TAG} python3 tools/summarize_profile_r05.py $TAG > gpurun_out/${TAG}_summary.log 2>&1
+python3 bench.py > $RAW/${TAG}_bench_plain.json 2> $RAW/${TAG}_bench_plain.err
+bash tools/dist_sizes_r05.sh > $RAW/${TAG}_shard_sizes.txt 2>&1
+QADC_TEST_HOOKS=1 bash tools/stream_order_ab3.sh > /dev/null 2>&1; cp gpurun_out/stream_order3.txt $RAW/${TAG}_ivf_shard_sizes.txt
+QADC_PROF_RAW=$RAW QADC_PROFILES_OUT=$R/gpurun_out/profiles_${TAG} python3 tools/summarize_profile_r05.py $TAG > gpurun_out/${TAG}_summary.log 2>&1
 tail -n 40 gpurun_out/${TAG}_summary.log

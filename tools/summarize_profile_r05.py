@@ -21,7 +21,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, TAG = os.path.join(ROOT, "gpurun_out"), (sys.argv[1] if len(sys.argv) > 1 else "r05")
+G, TAG = os.environ.get("QADC_PROF_RAW", os.path.join(ROOT, "gpurun_out")), (sys.argv[1] if len(sys.argv) > 1 else "r05")
 P = os.environ.get("QADC_PROFILES_OUT", os.path.join(ROOT, "profiles"))
 os.makedirs(P, exist_ok=True)
 
