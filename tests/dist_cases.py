@@ -51,6 +51,9 @@ def build_case(name):
         if name == "ivf_whole":
             c["placement"] = "whole"                      # whole partitions per rank, size-balanced
             c["index_options"] = {"wgq_group": 2, "wgq_group_head": 2}    # partition-major second phase under the merge
+            # every rank replays EVERY query of the enqueued merge (round 4's form); all other cases take the default: the replay
+            # sharded by query + a second all-gather of the heap shares (300 / 260 queries: ragged shares at 8, 3 and 7... ranks)
+            c["options"] = {"dist_shard_replay": 0}
     elif name == "big_r":
         # R above the lane replay's 288: host-share replay whatever the batch size
         rng = np.random.default_rng(503)
