@@ -420,8 +420,17 @@ int qadc_dist_merge_blocks(int device_id, int world, int nq, int ma, int R, cons
     HIPCHECK(d_c.ensure(2 * (size_t)nq));
     HIPCHECK(d_m.ensure((size_t)block_words * world));
     HIPCHECK(hipMemcpy(d_g.p, gathered, sizeof(uint64_t) * (size_t)block_words * world, hipMemcpyHostToDevice));
+    DevBuf<uint32_t> d_st;
+    HIPCHECK(d_st.ensure(4));
     HIPCHECK(launch_dist_merge(d_g.p, (size_t)block_words, world, nq, ma, (uint32_t)R, d_off.p, d_c.p, d_c.p + nq, d_m.p, d_h.p, d_s.p,
-                               nullptr));
+                               nullptr, d_st.p));
+    uint32_t st_words[4] = {0, 0, 0, 0};
+    HIPCHECK(hipMemcpy(st_words, d_st.p, sizeof(st_words), hipMemcpyDeviceToHost));
+    d_st.release();
+    if (st_words[2]) {
+        d_g.release(); d_h.release(); d_s.release(); d_off.release(); d_c.release(); d_m.release();
+        return fail(QADC_E_STATE, "multi-GPU merge: a rank's push stream is not grouped by assign slot");
+    }
     std::vector<uint64_t> hv((size_t)nq * R);
     std::vector<uint32_t> hs(nq);
     HIPCHECK(hipMemcpy(hv.data(), d_h.p, sizeof(uint64_t) * hv.size(), hipMemcpyDeviceToHost));
@@ -507,6 +516,8 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
     if (was_enqueued) {
         const uint32_t* h_sz = reinterpret_cast<const uint32_t*>(ds.h_out.p + sizeof(uint64_t) * (size_t)R * nq);
         const uint32_t bad = h_sz[nq], need = h_sz[nq + 1];
+        if (!bad && h_sz[nq + 2])                             // (raised by this rank's dist_interleave_kernel; every collective of the batch is behind us)
+            return fail(QADC_E_STATE, "multi-GPU merge: a rank's push stream is not grouped by assign slot");
         if (!bad) {
             // every rank saw clean headers: the heaps are final (a local failure of collect_common concerns this rank only — it
             // is returned AFTER the payload gather below, which the other ranks enter as well)
@@ -575,8 +586,16 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
         fix_total = 0;
     }
     if (fix_total) {
-        HIPCHECK(d.h_fix.ensure(fix_total));
-        HIPCHECK(d.d_fix.ensure(fix_total));
+        // (an allocation that fails HERE must not make this rank leave before the gather its peers are entering: it is a local
+        // failure like any other — bit7 in every header of this rank's block, the error returned after the gather)
+        hipError_t fe = d.h_fix.ensure(fix_total);
+        if (fe == hipSuccess) fe = d.d_fix.ensure(fix_total);
+        if (fe != hipSuccess) {
+            (void)hipGetLastError();
+            local_rc = QADC_E_HIP;
+            local_err = std::string("side buffer of the host-ordered streams: ") + hipGetErrorString(fe);
+            fix_total = 0;
+        }
     }
     uint64_t fix_off = 0;
     for (int q = 0; q < nq; ++q) {
@@ -611,7 +630,7 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
     HIPCHECK(d.h_extra_all.ensure((size_t)world * extra_room));
     if (extra_n) std::memcpy(d.h_extra.p, extra, sizeof(float) * extra_n);
     const size_t heaps_bytes = (sizeof(uint64_t) * (size_t)R + sizeof(uint32_t)) * (size_t)nq;
-    HIPCHECK(d.h_out.ensure(heaps_bytes + 16, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHECK(d.h_out.ensure(heaps_bytes + 32, hipHostMallocMapped | hipHostMallocCoherent));   // (+ the merge's status words)
     if (d.h_out.p != d.h_out_mapped) {
         HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d.d_out), d.h_out.p, 0));
         d.h_out_mapped = d.h_out.p;
@@ -642,7 +661,8 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
             HIPCHECK(d.d_merged.ensure((size_t)d.cap_entries * world));
             HIPCHECK(launch_dist_merge(d.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, d.d_moff.p, d.d_mcnt.p, d.d_mcnt.p + nq,
                                        d.d_merged.p, reinterpret_cast<uint64_t*>(d.d_out),
-                                       reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq), st));
+                                       reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq), st,
+                                       reinterpret_cast<uint32_t*>(d.d_out + sizeof(uint64_t) * (size_t)R * nq) + nq));
         } else {
             HIPCHECK(d.h_gathered.ensure(bw_room * world));
             HIPCHECK(hipMemcpyAsync(d.h_gathered.p, d.d_gathered.p, sizeof(uint64_t) * bw * world, hipMemcpyDeviceToHost, st));
@@ -686,7 +706,10 @@ int qadc_dist_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* values,
             idx->prof.regrows++;
             continue;
         }
-        if (on_device) break;
+        if (on_device) {
+            if (h_sizes[nq + 2]) return fail(QADC_E_STATE, "multi-GPU merge: a rank's push stream is not grouped by assign slot");
+            break;
+        }
         // ---- few queries (or R > 288): replay my share on the host (global scan order: assign slot, rank, position), share the heaps ----
         const int per = (nq + world - 1) / world;
         const size_t hw = (size_t)R + 1;                       // words per query in the heap exchange

@@ -196,8 +196,10 @@ hipError_t launch_dist_pack(const uint32_t* d_src_off, const uint32_t* d_src_cnt
 // Scratch of the caller: d_moff [nq] u64, d_mcnt / d_info [nq] u32, d_merged [world x entries of a block] u64.
 uint32_t replay_wave_max_R();
 size_t dist_interleave_max_cells();
-// d_status (optional, 2 words, may be host-mapped): [0] = OR of the header bits that void the merge (bit6 block too
-// small, bit7 a rank must re-run / failed, bit8 a query shipped unordered), [1] = entries the fullest rank block needs.
+// d_status (optional, 3 words, may be host-mapped): [0] = OR of the header bits that void the merge (bit6 block too
+// small, bit7 a rank must re-run / failed, bit8 a query shipped unordered), [1] = entries the fullest rank block needs,
+// [2] = 1 when a rank's stream of one of the queries interleaved HERE was not grouped by ascending assign slot (an invariant
+// of the ordering passes; the heaps of such a batch are not to be used).
 // q0 / qstep: only queries q0, q0 + qstep, ... are interleaved and replayed, and their heaps / sizes are written DENSELY
 // (heap w = query q0 + w * qstep) — the share of a rank that splits the replay with its peers (q0 = rank, qstep = world; the
 // shares travel by a second, small all-gather and launch_dist_heaps_unpack puts them in query order).  Totals, prefix and the

@@ -2138,6 +2138,7 @@ __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __res
             for (int g = 0; g < world; ++g) need = max(need, rank_tot[g]);
             status[0] = bad;                                     // bit6 / bit7 / bit8 of any header: the merge must be redone
             status[1] = (uint32_t)min(need, 0xffffffffull);      // entries the fullest rank block needs
+            status[2] = 0;                                       // set by dist_interleave_kernel: a stream not grouped by assign slot
         }
     }
 }
@@ -2148,7 +2149,8 @@ __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __res
 // (g, s) order.  Dynamic LDS: 2 x ma x world counters.
 __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world,
                                                               int nq, int ma, const uint64_t* __restrict__ moff,
-                                                              const uint32_t* __restrict__ info, uint64_t* __restrict__ merged, int q0, int qstep) {
+                                                              const uint32_t* __restrict__ info, uint64_t* __restrict__ merged, int q0, int qstep,
+                                                              uint32_t* __restrict__ status) {
     uint32_t* cnt_sg = reinterpret_cast<uint32_t*>(qsmem);        // [ma][world] -> exclusive prefix in (s, g) order
     uint32_t* cnt_gs = cnt_sg + (size_t)ma * world;               // [world][ma] -> exclusive prefix in (g, s) order
     __shared__ uint32_t wtot[4];
@@ -2185,8 +2187,16 @@ __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __
                     uint32_t prev = (uint32_t)__shfl_up((int)sl, 1), next = (uint32_t)__shfl_down((int)sl, 1);
                     if (lane == 0) prev = pv[u];
                     if (lane == 63) next = nx[u];
-                    if (i < n && prev != sl) cnt_gs[g * ma + sl] = i;            // the run's first entry
-                    if (i < n && next != sl) cnt_sg[sl * world + g] = i + 1;     // one past its last
+                    // The counts below come from run BOUNDS, so they are right only if a rank's stream is grouped by slot, slots
+                    // ascending and below ma — what the ordering passes guarantee.  A stream that is not (a future pack path, a
+                    // corrupted block) would scatter out of place: flag it (status[2]: the host fails the batch) and keep the
+                    // indices inside the count arrays.
+                    const bool live = i < n;
+                    const bool broken = live && (sl >= (uint32_t)ma || (prev != 0xffffffffu && prev > sl));
+                    if (broken && status) status[2] = 1u;
+                    if (live && sl >= (uint32_t)ma) continue;
+                    if (live && prev != sl) cnt_gs[g * ma + sl] = i;             // the run's first entry
+                    if (live && next != sl) cnt_sg[sl * world + g] = i + 1;      // one past its last
                 }
             }
         }
@@ -2240,7 +2250,7 @@ __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __
                 const uint32_t i = i0 + (uint32_t)u * 256u;
                 if (i >= n) continue;
                 const uint64_t e = ev[u];
-                const uint32_t sl = ma > 1 ? (uint32_t)(e >> 40) & 0x3fffu : 0u;
+                const uint32_t sl = ma > 1 ? min((uint32_t)(e >> 40) & 0x3fffu, (uint32_t)ma - 1u) : 0u;   // (clamped: see the guard above)
                 const uint32_t run_first = cnt_gs[g * ma + sl] - rank_first;  // index of the slot's first entry in rank g's stream
                 out[cnt_sg[sl * world + g] + (i - run_first)] = e;
             }
@@ -2438,7 +2448,7 @@ hipError_t launch_dist_merge(const uint64_t* d_gathered, size_t block_words, int
                        d_status);
     if (nmine == 0) return hipGetLastError();
     hipLaunchKernelGGL(dist_interleave_kernel, dim3(nmine), dim3(256), (size_t)ma * world * 8, stream, d_gathered, block_words, world, nq, ma,
-                       d_moff, d_info, d_merged, q0, qstep);
+                       d_moff, d_info, d_merged, q0, qstep, d_status);
     return launch_replay_heap_wave(d_merged, d_moff, d_mcnt, d_info, nmine, R, d_heaps, d_heap_sizes, stream, q0, qstep);
 }
 

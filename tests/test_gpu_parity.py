@@ -1210,6 +1210,23 @@ def test_dist_interleave_run_bounds_on_synthetic_streams(pyqadc, world, ma, seed
     want = pyqadc.dist_merge_blocks(streams, nq, ma, R, host=True)
     for q in range(nq):
         assert np.array_equal(got[q][0], want[q][0]) and np.array_equal(got[q][1], want[q][1]), q
+    # the run-bound counts assume a stream grouped by ASCENDING slot below ma: one that is not is refused, not scattered out of
+    # place — a slot run split in two, and a slot beyond ma
+    if ma > 1 and seed == 0:
+        for how in ("split_run", "slot_out_of_range"):
+            bad = [dict(st, slots=st["slots"].copy()) for st in streams]
+            g = next(g for g in range(world) if len(streams[g]["slots"]) > 8)
+            off = streams[g]["offsets"]
+            q = int(np.argmax(np.diff(off.astype(np.int64))))            # the rank's longest stream
+            a, b = int(off[q]), int(off[q + 1])
+            if how == "split_run":
+                if bad[g]["slots"][a] == bad[g]["slots"][b - 1]:
+                    continue                                              # (a single run: nothing to split)
+                bad[g]["slots"][b - 1] = bad[g]["slots"][a]               # the first slot comes back at the end
+            else:
+                bad[g]["slots"][b - 1] = ma                               # one past the probes
+            with pytest.raises(pyqadc.QadcError, match="not grouped by assign slot"):
+                pyqadc.dist_merge_blocks(bad, nq, ma, R)
 
 
 @pytest.mark.gpu
