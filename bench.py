@@ -566,6 +566,12 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
         lds_cycles = (pp["group_pass_codes8"] * M * 4 + pp["group_pass_codes4"] * M * 2) / 64.0
         lds_rate = lds_cycles / (pp["group_scan_ms"] * 1e-3) / 1e9
         head_gbs = pp["group_head_codes"] * (M // 2) / (pp["group_head_ms"] * 1e-3) / 1e9
+        # what the head LAUNCH has to read besides the head probes' codes (the front is part of the path: SURVEY.md 8 rows A5-A7): the
+        # starts of ALL probed partitions for the float pre-scan (max(1, size x keep) codes each: keep x the probed codes, to within
+        # the rounding of ~10^2-code start runs) and every probe's float table once
+        front_bytes_per_query = KEEP * (ncodes / (steps * NQB)) * (M // 2) + MA * M * 16 * 4
+        head_alg_incl = pp["group_head_codes"] * (M // 2) / nb + front_bytes_per_query * NQB
+        head_gbs_incl = head_alg_incl / (pp["group_head_ms"] / nb * 1e-3) / 1e9
         roof = {"bound": "lds", "kernel": "scan_i8_mq_narrow_kernel<%d,2> (8- and 4-seat groups) over the (query, probe) pairs regrouped by partition" % M,
                 "achieved": lds_rate, "peak": LDS_PEAK_GCYC, "unit": "G LDS-array cycles/s", "frac": lds_rate / LDS_PEAK_GCYC,
                 "avg_launch_ms": pp["group_scan_ms"] / nb, "launches": nb,
@@ -579,12 +585,20 @@ def ivf_leg(local_rank, M=16, K=4096, MA=32, dim=128, N=None, seed0=1000, shard=
                          "avg_launch_ms": pp["group_head_ms"] / nb,
                          "algorithmic_bytes_per_launch": pp["group_head_codes"] * (M // 2) / nb,
                          "note": "bytes = M/2 x codes of the head probes only; the launch also pre-scans the starts of all probes and "
-                                 "quantizes their tables, so frac understates the walk"},
+                                 "quantizes their tables, so frac understates the walk",
+                         "incl_front_reads": {
+                             "achieved": head_gbs_incl, "frac": head_gbs_incl / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": head_alg_incl,
+                             "rule": "head probes' codes + per query: keep x probed codes x M/2 B (the starts of all %d probes, read by the float "
+                                     "pre-scan: scan_4 over the starts, query_common.hpp:59-90) + %d float tables of %d B — the bytes the launch "
+                                     "cannot avoid reading; its PMC traffic (profiles/r05_ivf*_pmc_summary.json) also holds the value scratch "
+                                     "and the int8 tables it writes" % (MA, MA, M * 64)}},
                 "launches_alone_on_the_gpu": None if not (pa and pa["group_batches"]) else {
                     "what": "the same three launches with ONE batch in flight (8 batches): each kernel by itself, as a PMC pass sees it",
                     "head_ms": pa["group_head_ms"] / pa["group_batches"], "grouped_scan_ms": pa["group_scan_ms"] / pa["group_batches"],
                     "order_ms": pa["group_order_ms"] / pa["group_batches"],
                     "head_frac_of_hbm": pa["group_head_codes"] * (M // 2) / (pa["group_head_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "head_frac_of_hbm_incl_front_reads": (pa["group_head_codes"] * (M // 2) / pa["group_batches"] + front_bytes_per_query * NQB)
+                    / (pa["group_head_ms"] / pa["group_batches"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "grouped_scan_frac_of_lds": (pa["group_pass_codes8"] * M * 4 + pa["group_pass_codes4"] * M * 2) / 64.0
                     / (pa["group_scan_ms"] * 1e-3) / 1e9 / LDS_PEAK_GCYC},
                 "order_cands_avg_launch_ms": pp["group_order_ms"] / nb,
