@@ -255,3 +255,31 @@ def test_pack4_and_residuals_match_the_reference(po):
     base = rng.normal(size=(40, 96)).astype(np.float32)
     a = rng.permutation(40)[:7].astype(np.int32)
     assert np.array_equal(po.reff_substract_from_unique(v, base, a), (v[None, :] - base[a]).astype(np.float32))
+
+
+def test_extraction_refuses_a_drifted_reference(tmp_path):
+    """oracle/ref_extract.sh carries the sha256 of every line range it cuts out of the reference: one changed byte inside a
+    range stops the build instead of silently compiling something else; the untouched reference passes."""
+    import os
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("no /root/reference here")
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_extract.sh")
+    out = tmp_path / "out"
+    out.mkdir()
+    assert subprocess.run([script, ref, str(out)], stderr=subprocess.PIPE).returncode == 0
+    assert sorted(os.listdir(out))[0].startswith("x_") and len(os.listdir(out)) == 12
+    drift = tmp_path / "ref"
+    drift.mkdir()
+    for f in ("quantizers.hpp", "databases.hpp", "query_common.hpp", "db_query_4.cpp", "db_query.cpp", "distances.hpp", "databases.cpp"):
+        shutil.copy(os.path.join(ref, f), drift / f)
+    text = open(drift / "query_common.hpp").read()
+    assert text.count("candidate += dists[sq_i * NCENT + comp0];") == 1                  # (inside scan_4, query_common.hpp:59-90)
+    open(drift / "query_common.hpp", "w").write(text.replace("candidate += dists[sq_i * NCENT + comp0];",
+                                                              "candidate += dists[sq_i * NCENT + comp0] ;"))
+    out2 = tmp_path / "out2"
+    out2.mkdir()
+    r = subprocess.run([script, str(drift), str(out2)], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"the reference changed" in r.stderr
