@@ -640,6 +640,8 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
     Slot& s = idx->slot[slot_i];
     if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
     if (int rc = use_device(idx)) return rc;
+    if (s.replay_pending)                                     // (no later batch launched its head meanwhile: the replay goes out now)
+        if (int rc = issue_replay(idx, s, nullptr)) return rc;
     if (s.dist_batch && !from_dist) {
         need_stream = true;
         if (idx->dist && idx->dist->slot[slot_i].pending)
@@ -1246,6 +1248,7 @@ int qadc_index_destroy(qadc_index* idx) {
         if (s.ev_up) (void)hipEventDestroy(s.ev_up);
         if (s.ev_front) (void)hipEventDestroy(s.ev_front);
         if (s.ev_scanned) (void)hipEventDestroy(s.ev_scanned);
+        if (s.ev_head) (void)hipEventDestroy(s.ev_head);
         for (auto e : s.prof_ev) (void)hipEventDestroy(e);
     }
     // (the streams belong to the process — see attach_streams — unless a measurement hook gave this index a set of its own)
@@ -1503,6 +1506,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "head_early") idx->head_early = value != 0;
     else if (n == "wgq_inline") idx->wgq_inline = value != 0;
     else if (n == "replay_wave") idx->replay_wave = value != 0;
+    else if (n == "replay_defer") idx->replay_defer = value != 0;
     else if (n == "mq_narrow") idx->group.mq_narrow = value != 0;
     else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);
     else if (n == "wgq_group") { idx->group.mode = (int)std::max(0.0, std::min(value, 2.0)); idx->group.strikes = 0; }

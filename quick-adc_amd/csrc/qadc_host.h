@@ -223,6 +223,14 @@ struct Slot {
     hipEvent_t ev_front = nullptr;      // pre-scan + quantizer finished (front stream)
     hipEvent_t ev_up = nullptr;         // this batch's upload finished (copy stream)
     hipEvent_t ev_scanned = nullptr;    // last scan level finished (main stream)
+    // device replay of a partition-major batch deferred until the NEXT batch's head launch is through (option "replay_defer"):
+    // issued by that batch's launch, or by collect
+    bool replay_pending = false;
+    hipStream_t replay_stream = nullptr;
+    hipEvent_t ev_head = nullptr;       // this batch's head launch finished (scan stream)
+    uint64_t* rp_heaps = nullptr;
+    uint32_t* rp_sizes = nullptr;
+    uint32_t rp_cap = 0;
     std::vector<hipEvent_t> prof_ev;    // pairs: [2i] before, [2i+1] after; pair 0 = pre-scan chain
     size_t prof_used = 0;
 
@@ -402,6 +410,9 @@ struct qadc_index {
     uint32_t wgq_split_codes = 8192;    // a query is split over several workgroups only down to this many codes each
     int wgq_poll = 1;      // ... and its completion is read from the result block, not from the event
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
+    int replay_defer = 0;  // 1: the device replay of a partition-major batch waits for the NEXT batch's head launch.  Measured, round 5
+                           // (profiles/r05_replay_defer_ab.txt): C3 head 0.27 -> 0.215 ms but partition-major phase 0.31 -> 0.36 (batch
+                           // 0.666 -> 0.651 ms); C5 — whose head is HBM-bound and did not mind the replay — 4.13 -> 4.25.  Off.
     int replay_wave = 1;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
                            // (C3 shape, 1024-query batches: lanes 0.78 us per query, waves 0.75; C5 shape: 4.83 vs 4.67 — since
                            // the wave heap sifts all levels at once; with its element-by-element sift the waves lost,
@@ -469,6 +480,7 @@ int table_expansion(const qadc_index* idx, int ma);
 bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64_t codes_per_query);
 bool will_group(const qadc_index* idx, int nq, int ma, bool dev_replay);
 int launch_wgq_batch(qadc_index* idx, Slot& s);
+int issue_replay(qadc_index* idx, Slot& s, hipEvent_t after);   // a deferred device replay (launch_wgq_batch / collect_common)
 int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int ma, int R);
 // qadc_dist.cpp
 int load_rccl(DistState& d, std::string& err);

@@ -324,6 +324,21 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         if (idx->profile) HIPCHECK(prof_event(s, st));
         HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
+        // Option replay_defer (off by default).  At the C3 shape the head suffers from company: 1024-thread workgroups, latency-bound
+        // (waves parked ~70 %), two per CU only while all 32 wave slots of the CU are free — and the previous batch's replay, one wave
+        // per query spread over every CU for ~0.25 ms, starts exactly when this head does (kernel trace: head 0.285 ms in the
+        // pipeline against 0.173 alone, with the scan queue 98 % busy).  With the option the replays that wait are released here,
+        // behind the head, and run under the partition-major phase instead — which then pays for them (VALU issue 74-87 % busy):
+        // C3 -2 % per batch, C5 +3 % (profiles/r05_replay_defer_ab.txt).  The replay's ~0.05 ms of VALU work per batch lands somewhere.
+        bool waiting = false;
+        for (int i = 0; i < kSlots; ++i) waiting = waiting || (&idx->slot[i] != &s && idx->slot[i].replay_pending);
+        if (waiting) {
+            if (!s.ev_head) HIPCHECK(hipEventCreateWithFlags(&s.ev_head, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(s.ev_head, st));
+            for (int i = 0; i < kSlots; ++i)
+                if (&idx->slot[i] != &s && idx->slot[i].replay_pending)
+                    if (int rc = issue_replay(idx, idx->slot[i], s.ev_head)) return rc;
+        }
         // (workgroups per group: 16 K codes each.  One workgroup per partition — the multi-query scans' own 64 K — leaves the C3 shape's
         //  4.4 K groups 2.5 rounds of the GPU's 1792 resident workgroups, and the last round mostly empty: 0.335 -> 0.315 ms per
         //  batch at C3, 3.29 -> 3.18 at C5 with 16 K; 8 K the same, 4 K slower: a table build per 4 tile iterations)
@@ -362,6 +377,15 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             st = (idx->replay_seq++ & 1) ? idx->front_stream : idx->sort_stream;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
         }
+        if (s.heaps_ready && !alone && s.wgq_grouped && !s.dist_batch && idx->replay_defer) {
+            // deferred: released by the next partition-major batch's head launch (above), or by collect
+            s.replay_pending = true;
+            s.replay_stream = st;
+            s.rp_heaps = reinterpret_cast<uint64_t*>(d_result + off_heaps);
+            s.rp_sizes = reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
+            s.rp_cap = cap;
+            return QADC_OK;                                      // (ev_done is recorded behind the replay, by issue_replay)
+        }
         if (s.heaps_ready) {
             uint64_t* d_heaps = reinterpret_cast<uint64_t*>(d_result + off_heaps);
             uint32_t* d_sizes = reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
@@ -371,6 +395,20 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
                 HIPCHECK(launch_replay_heap_lanes(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
         }
     }
+    if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(s.ev_done, st));
+    return QADC_OK;
+}
+
+// A deferred device replay: on the side stream the batch was given, behind the batch's own scan and (if given) behind `after`.
+int issue_replay(qadc_index* idx, Slot& s, hipEvent_t after) {
+    s.replay_pending = false;
+    hipStream_t st = s.replay_stream;
+    if (after) HIPCHECK(hipStreamWaitEvent(st, after, 0));
+    if (idx->replay_wave)
+        HIPCHECK(launch_replay_heap_wave_qflags(s.d_qflags.p, s.d_stream.p, s.rp_cap, s.nq, (uint32_t)s.R, s.rp_heaps, s.rp_sizes, st));
+    else
+        HIPCHECK(launch_replay_heap_lanes(s.d_qflags.p, s.d_stream.p, s.rp_cap, s.nq, (uint32_t)s.R, s.rp_heaps, s.rp_sizes, st));
     if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(s.ev_done, st));
     return QADC_OK;

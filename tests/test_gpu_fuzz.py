@@ -52,7 +52,9 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
                 # partition-major second phase of device-replayed batches (with its overflow fallback), head length
                 wgq_group=int(rng.choice([0, 2, 2])), wgq_group_head=int(rng.choice([1, 2, 4])),
                 # grouping of the float pre-scan's adds: the reference binary's (default) or the source's
-                sum_mode=int(rng.choice([1, 1, 0])))
+                sum_mode=int(rng.choice([1, 1, 0])),
+                # device replay of a partition-major batch released by the next batch's head launch or by collect
+                replay_defer=int(rng.integers(0, 2)))
     for k, v in opts.items():
         idx.set_option(k, v)
     tables = float_tables(rng, nq, ma, M, scale=float(rng.choice([0.2, 1.0])))

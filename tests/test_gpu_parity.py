@@ -1488,6 +1488,57 @@ def test_wgq_grouped_second_phase_matches_oracle(pyqadc, po, M, nq, ma, head, bi
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 32])
+def test_deferred_replay_of_pipelined_partition_major_batches(pyqadc, po, M):
+    """Option replay_defer: the device replay of a partition-major batch is not enqueued with the batch but released behind
+    the head launch of the NEXT such batch — or by collect when no later batch came.  Five batches through three slots (the
+    first is alone on the GPU: replayed at once; the last has no successor: released by its collect; one is collected while its
+    successor is already in flight), changing batch sizes; heaps == oracle for every query, and the same with the option off."""
+    rng = np.random.default_rng(7100 + M)
+    sizes = [int(x) for x in rng.integers(200, 5000, 30)] + [0, 17, 40001, 30000]
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
+    keep, R, ma, K = 0.05, 100, 6, len(sizes)
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(keep)
+    for k, v in dict(wgq=2, wgq_group=2, wgq_group_head=2, device_replay_nq=1, device_replay_alone_nq=0).items():
+        idx.set_option(k, v)
+    batches = []
+    for nq in (70, 131, 64, 200, 97):
+        assign = np.stack([rng.permutation(K)[:ma] for _ in range(nq)]).astype(np.int32)
+        for q in range(nq):                                       # a long first probe, later probes farther away: the head's bound holds
+            b = (32, 33)[q % 2]
+            assign[q] = [b] + [p for p in assign[q] if p != b][:ma - 1]
+        tables = float_tables(rng, nq, ma, M)
+        tables = np.ascontiguousarray(tables + np.float32(0.6) * np.arange(ma, dtype=np.float32)[None, :, None])
+        batches.append((assign, tables))
+    for defer in (1, 0):
+        idx.set_option("replay_defer", defer)
+        idx.set_option("profile", 1)
+        idx.profile_reset()
+        res = [None] * len(batches)
+        idx.submit(0, batches[0][0], batches[0][1].copy(), R)
+        idx.submit(1, batches[1][0], batches[1][1].copy(), R)       # deferred: released by batch 2's head
+        idx.submit(2, batches[2][0], batches[2][1].copy(), R)       # deferred: released by batch 3's head
+        res[0] = idx.collect(0)
+        idx.submit(0, batches[3][0], batches[3][1].copy(), R)
+        res[1] = idx.collect(1)
+        res[2] = idx.collect(2)
+        idx.submit(1, batches[4][0], batches[4][1].copy(), R)       # deferred, no successor: released by its collect
+        res[3] = idx.collect(0)
+        res[4] = idx.collect(1)
+        assert idx.profile()["group_launches"] == len(batches) and idx.profile()["group_fallbacks"] == 0
+        for b, (assign, tables) in enumerate(batches):
+            for q in range(assign.shape[0]):
+                want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
+                assert want["rc"] == res[b]["status"][q] == 0
+                sz = res[b]["sizes"][q]
+                assert heaps_equal((res[b]["keys"][q, :sz], res[b]["values"][q, :sz]), (want["keys"], want["values"])), (defer, b, q)
+    idx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("grouped", [True, False])
 @pytest.mark.parametrize("bucket_max", [256, 24, 3, 0])
 def test_ordering_pass_bucket_sort_and_its_bitonic_fallback_agree(pyqadc, po, grouped, bucket_max):
