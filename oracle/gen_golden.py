@@ -15,8 +15,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import pyoracle as po  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
-                   "ref_scan_cases.npz")
+OUT = os.environ.get("QADC_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                                        "ref_scan_cases.npz")
 
 
 def synth_codes(n, M, seed):

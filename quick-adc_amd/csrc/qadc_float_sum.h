@@ -27,11 +27,12 @@ __device__ __forceinline__ T adc_sum8_source(T s, const T* v) {
     return s;
 }
 
+#define QADC_L(b) v[2 * (b)]
+#define QADC_H(b) v[2 * (b) + 1]
+
 // bytes 0..7: the result does not take an incoming sum (the compiled code has no "0 +")
 template <typename T>
 __device__ __forceinline__ T adc_sum8_compiled_first(const T* v) {
-#define QADC_L(b) v[2 * (b)]
-#define QADC_H(b) v[2 * (b) + 1]
     const T a = (QADC_H(2) + QADC_L(3)) + (QADC_H(3) + QADC_L(4));
     const T b = (QADC_H(0) + QADC_L(1)) + (QADC_H(1) + QADC_L(2));
     const T c = (QADC_H(5) + QADC_L(6)) + (QADC_H(4) + QADC_L(5));
@@ -45,9 +46,10 @@ __device__ __forceinline__ T adc_sum8_compiled_next(T s, const T* v) {
 #pragma unroll
     for (int b = 0; b < 8; b += 2) s = s + ((QADC_L(b + 1) + QADC_H(b + 1)) + (QADC_L(b) + QADC_H(b)));
     return s;
+}
+
 #undef QADC_L
 #undef QADC_H
-}
 
 // all CS = M/2 bytes: v[2b] = L_b, v[2b+1] = H_b
 template <int M, typename T>

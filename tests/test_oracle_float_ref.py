@@ -283,3 +283,21 @@ def test_extraction_refuses_a_drifted_reference(tmp_path):
     out2.mkdir()
     r = subprocess.run([script, str(drift), str(out2)], stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"the reference changed" in r.stderr
+
+
+@pytest.mark.parametrize("script,committed", [("gen_golden_float.py", "ref_query_scan_cases.npz"), ("gen_golden.py", "ref_scan_cases.npz")])
+def test_golden_fixtures_regenerate_from_the_reference_build(po, tmp_path, script, committed):
+    """The committed fixtures ARE what the generators produce from the reference build today: every array, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    if not (po.have_ref() and po.have_ref_float()):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / committed)
+    subprocess.check_call([sys.executable, os.path.join(root, "oracle", script)], env=dict(os.environ, QADC_GOLDEN_OUT=out),
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    a, b = np.load(out), np.load(os.path.join(root, "tests", "golden", committed))
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
