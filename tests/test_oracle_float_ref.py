@@ -275,10 +275,9 @@ def test_extraction_refuses_a_drifted_reference(tmp_path):
     drift.mkdir()
     for f in ("quantizers.hpp", "databases.hpp", "query_common.hpp", "db_query_4.cpp", "db_query.cpp", "distances.hpp", "databases.cpp"):
         shutil.copy(os.path.join(ref, f), drift / f)
-    text = open(drift / "query_common.hpp").read()
-    assert text.count("candidate += dists[sq_i * NCENT + comp0];") == 1                  # (inside scan_4, query_common.hpp:59-90)
-    open(drift / "query_common.hpp", "w").write(text.replace("candidate += dists[sq_i * NCENT + comp0];",
-                                                              "candidate += dists[sq_i * NCENT + comp0] ;"))
+    lines = open(drift / "query_common.hpp").read().split("\n")
+    lines[69] = lines[69] + " "                                    # one blank appended to line 70 (inside scan_4's range, 59-143)
+    open(drift / "query_common.hpp", "w").write("\n".join(lines))
     out2 = tmp_path / "out2"
     out2.mkdir()
     r = subprocess.run([script, str(drift), str(out2)], stderr=subprocess.PIPE)
