@@ -117,6 +117,10 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * "wgq_group_head" (probes per query the one-workgroup-per-query head walks before it), "wgq_group_head_dist" (the same under the
  * multi-GPU merge, counted in probes with codes on the rank),
  * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_async", "dist_shard_front", "dist_inject_failure" (test hook),
+ * "dist_shard_replay" (an enqueued multi-GPU merge replays only this rank's share of the queries — q = rank (mod world) — and a
+ * second, small all-gather shares the heaps; default 1), "dist_share_lag" (that gather is issued behind the first gather of the
+ * merge this many batches later; default 1), "replay_defer" (the device replay of a pipelined partition-major batch waits for the
+ * next batch's head launch; default 0: measured -2 % / +3 % at the two IVF configuration shapes),
  * "plan_early" (pipelined query-kernel batches: float tables, state clear and partition-major plan run on the stream that produces
  * assign[] instead of the scan stream; default 1), "wgq_stream" (query-kernel batches scan on the normal-priority alternative of the
  * scan stream; default 0), "wgq_ramp_shift" (the walk's ramp epochs grow by 2^shift; default doubling), "mq_single" (a lone long
@@ -294,8 +298,9 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
  * PUSH STREAM, not its final top-R: re-pushing final heaps is not exact under ties (binheap.hpp:75-116 resolves ties by
  * push order).  qadc_dist_collect replaces qadc_query_scan_collect: it packs this rank's streams (already in device
  * memory), runs ONE ncclAllGather (device to device, no host staging), and replays the world's streams in global
- * scan order (assign slot, rank, position) on the GPU, one wave per query — every rank ends with every query's heap,
- * so there is no second collective.  `extra` (optional, extra_n floats per rank) rides in the same all-gather and comes
+ * scan order (assign slot, rank, position) on the GPU, one wave per query — at collect time every rank replays every query
+ * (no second collective); a merge enqueued with its batch (below) shards the replay by query and shares the heaps with a
+ * second, small all-gather.  `extra` (optional, extra_n floats per rank) rides in the same all-gather and comes
  * back as extra_out[world][extra_n]: the multi-rank loop of bench.py ships the next batch's sharded pre-scan values
  * this way (qadc_prescan_submit).  RCCL is loaded with dlopen by qadc_dist_unique_id / qadc_dist_init; a single-GPU
  * user never loads it.  world <= 16.  Any R: the device merge (one wave per query, heap in registers) holds R <= 320,
@@ -306,8 +311,9 @@ int qadc_float_top1(qadc_index* idx, int part, const float* table, uint32_t* out
  * of this rank's streams only).  Large batches (>= "dist_device_nq" queries: IVF; on either scan path) have their merge —
  * pack, all-gather, interleave, replay — ENQUEUED WITH THE BATCH, behind its scan, so qadc_dist_collect only waits for it
  * (option "dist_async", default 1): after qadc_dist_init every rank must therefore SUBMIT the same batches in the same
- * order, not just collect them (the all-gather of such a batch is issued by its submit call).  qadc_search batches of
- * that kind also SHARD THEIR FRONT (option "dist_shard_front", default 1): what is per query rather than per code — coarse
+ * order, not just collect them (the all-gather of such a batch is issued by its submit call).  Such merges SHARD THEIR REPLAY
+ * (option "dist_shard_replay", default 1: rank r replays queries q = r (mod world); the heap shares' all-gather is issued by a later
+ * submit call, or by collect).  qadc_search batches of that kind also SHARD THEIR FRONT (option "dist_shard_front", default 1): what is per query rather than per code — coarse
  * assignment, residual tables, pre-scan, select, quantizer — runs on rank r for queries [r * ceil(nq / world), ...) only, and
  * one more all-gather (issued by the submit call as well) ships assign[], the int8 tables and (flags, qmin, qmax) of every
  * query to every rank before the sharded scan.
