@@ -1561,7 +1561,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     }
     else if (n == "dist_shard_front") {                       // 1: feeders + pre-scan + quantizer of a qadc_search batch are split over the ranks
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
-        idx->dist->shard_front = value != 0;
+        idx->dist->shard_front = value == 2 ? 2 : value != 0;      // (2: also with a world of one — measurement hook: the front as a launch of its own)
     }
     else if (n == "dist_inject_failure") {                    // test hook: this rank's next qadc_dist_collect fails before the gather
         if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");

@@ -463,7 +463,7 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
         // GLOBAL partition sizes (a rank's own total differs under whole-partition placement and for the last range), and the
         // strike count behind will_group moves only on gathered verdicts (qadc_dist_collect).
         const uint64_t est = idx->parts.empty() ? 0 : idx->total_global_codes / idx->parts.size() * (uint64_t)(idx->feed.K ? ma : 1);
-        if (idx->dist && idx->dist->shard_front && idx->dist->world > 1 && idx->feed.K && nq >= 2 * idx->dist->world &&
+        if (idx->dist && idx->dist->shard_front && (idx->dist->world > 1 || idx->dist->shard_front == 2) && idx->feed.K && nq >= 2 * idx->dist->world &&
             wgq_eligible(idx, nq, ma, R, 0, est) && will_group(idx, nq, ma, true)) {
             s.front_sharded = true;
             s.front_per = (nq + idx->dist->world - 1) / idx->dist->world;
