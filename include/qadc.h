@@ -120,7 +120,9 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * "dist_shard_replay" (an enqueued multi-GPU merge replays only this rank's share of the queries — q = rank (mod world) — and a
  * second, small all-gather shares the heaps; default 1), "dist_share_lag" (that gather is issued behind the first gather of the
  * merge this many batches later; default 1), "replay_defer" (the device replay of a pipelined partition-major batch waits for the
- * next batch's head launch; default 0: measured -2 % / +3 % at the two IVF configuration shapes),
+ * next batch's head launch; default 0: measured -2 % / +3 % at the two IVF configuration shapes), "front_tp" (partition-major
+ * batches run their front — float pre-scan of the starts, R-th smallest, quantizer — as three launches of small workgroups off the
+ * scan stream instead of inside the head launch),
  * "plan_early" (pipelined query-kernel batches: float tables, state clear and partition-major plan run on the stream that produces
  * assign[] instead of the scan stream; default 1), "wgq_stream" (query-kernel batches scan on the normal-priority alternative of the
  * scan stream; default 0), "wgq_ramp_shift" (the walk's ramp epochs grow by 2^shift; default doubling), "mq_single" (a lone long
@@ -416,6 +418,7 @@ typedef struct qadc_profile {
     uint64_t group_batches;    /* batches the above figures cover */
     uint64_t front_sharded_batches; /* multi-GPU: qadc_search batches whose front ran on 1/world of the queries per rank */
     uint64_t dist_async_collects;   /* multi-GPU: qadc_dist_collect calls served by a merge enqueued with the batch (one event wait) */
+    uint64_t front_tp_batches;      /* partition-major batches whose front ran as launches of its own (option "front_tp") */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

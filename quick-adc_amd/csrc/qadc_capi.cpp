@@ -1199,6 +1199,7 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
         if (const char* e = std::getenv("QADC_WGQ_INLINE")) idx->wgq_inline = std::atoi(e);
         if (const char* e = std::getenv("QADC_WGQ_GROUP")) idx->group.mode = std::max(0, std::min(std::atoi(e), 2));
         if (const char* e = std::getenv("QADC_REPLAY_WAVE")) idx->replay_wave = std::atoi(e) != 0;
+        if (const char* e = std::getenv("QADC_FRONT_TP")) idx->front_tp = std::atoi(e) != 0;
         if (const char* e = std::getenv("QADC_HEAD_LEVEL")) idx->head_level = std::max(0, std::min(std::atoi(e), kMaxLevels - 1));
     }
     if (int rc = attach_streams(idx, hooks && std::atoi(hooks) == 1)) {
@@ -1237,7 +1238,7 @@ int qadc_index_destroy(qadc_index* idx) {
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
         s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
         s.h_cands.release(); s.d_stream.release(); s.d_qflags.release(); s.d_fvals.release(); s.d_qcands.release(); s.h_fetch.release();
-        s.d_fblock.release(); s.d_fgathered.release(); s.d_front_all.release(); s.h_fmap.release();
+        s.d_fblock.release(); s.d_fgathered.release(); s.d_front_all.release(); s.h_fmap.release(); s.d_front_tp.release();
         if (s.ev_fa) (void)hipEventDestroy(s.ev_fa);
         if (s.ev_fb) (void)hipEventDestroy(s.ev_fb);
         if (s.ev_assign) (void)hipEventDestroy(s.ev_assign);
@@ -1507,6 +1508,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "wgq_inline") idx->wgq_inline = value != 0;
     else if (n == "replay_wave") idx->replay_wave = value != 0;
     else if (n == "replay_defer") idx->replay_defer = value != 0;
+    else if (n == "front_tp") idx->front_tp = value != 0;
     else if (n == "mq_narrow") idx->group.mq_narrow = value != 0;
     else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);
     else if (n == "wgq_group") { idx->group.mode = (int)std::max(0.0, std::min(value, 2.0)); idx->group.strikes = 0; }

@@ -222,6 +222,7 @@ struct Slot {
     hipEvent_t ev_done = nullptr;
     hipEvent_t ev_front = nullptr;      // pre-scan + quantizer finished (front stream)
     hipEvent_t ev_up = nullptr;         // this batch's upload finished (copy stream)
+    DevBuf<unsigned char> d_front_tp;   // throughput front of a partition-major batch: [StartItem nq*ma][fc_init 2nq][front records 4nq]
     hipEvent_t ev_scanned = nullptr;    // last scan level finished (main stream)
     // device replay of a partition-major batch deferred until the NEXT batch's head launch is through (option "replay_defer"):
     // issued by that batch's launch, or by collect
@@ -410,6 +411,8 @@ struct qadc_index {
     uint32_t wgq_split_codes = 8192;    // a query is split over several workgroups only down to this many codes each
     int wgq_poll = 1;      // ... and its completion is read from the result block, not from the event
     int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
+    int front_tp = 0;      // partition-major batches: the front (pre-scan, select, quantizer) as three launches of small workgroups off the
+                           // scan stream instead of inside the head (option "front_tp"; launch_wgq_batch)
     int replay_defer = 0;  // 1: the device replay of a partition-major batch waits for the NEXT batch's head launch.  Measured, round 5
                            // (profiles/r05_replay_defer_ab.txt): C3 head 0.27 -> 0.215 ms but partition-major phase 0.31 -> 0.36 (batch
                            // 0.666 -> 0.651 ms); C5 — whose head is HBM-bound and did not mind the replay — 4.13 -> 4.25.  Off.

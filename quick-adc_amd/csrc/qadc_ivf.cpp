@@ -302,6 +302,32 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         launch_ivf_plan(A.assign, idx->d_partdesc.p, nq, ma, head_slots, (int)nparts, d_gplan, d_gplan + 2 * nparts,
                         d_gplan + nparts, d_gitems, pre_st);
         pre_used = pre_used || pre_st != st;
+        // ---- throughput front (option "front_tp"): the batch's pre-scan, select and quantizer as THREE launches of small
+        // workgroups off the scan stream — one 256-thread workgroup per (query, probe) pair for scan_4 over the pair's starts
+        // (start_scan_f32_kernel, items built on the device from assign[]), one per query for the R-th smallest and the quantizer
+        // (select_kth_kernel<256>) — instead of inside the head, where the front is a third of a 1024-thread workgroup's life spent
+        // in dependent round trips (50 K of 170 K cycles at the C3 shape, 236 K of 656 K at C5) with a CU's wave slots held.
+        // The head then starts from int8 tables + {flags, qmin, qmax} like the head of a sharded front.
+        uint32_t* d_front_tp = nullptr;
+        if (idx->front_tp && A.ftables && !s.front_sharded) {
+            const uint64_t fstride = ((uint64_t)ma * idx->max_start_n + 3) & ~3ull;
+            if ((uint64_t)nq * fstride < (1ull << 31) && fstride < (1ull << 31)) {
+                auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+                const size_t off_init = up16(sizeof(StartItem) * (size_t)nq * ma);
+                const size_t off_front = up16(off_init + sizeof(uint32_t) * 2 * (size_t)nq);
+                HIPCHECK(s.d_front_tp.ensure(off_front + sizeof(uint32_t) * 4 * (size_t)nq));
+                HIPCHECK(s.d_fc.ensure((size_t)nq * fstride));
+                StartItem* d_sit = reinterpret_cast<StartItem*>(s.d_front_tp.p);
+                uint32_t* d_finit = reinterpret_cast<uint32_t*>(s.d_front_tp.p + off_init);
+                d_front_tp = reinterpret_cast<uint32_t*>(s.d_front_tp.p + off_front);
+                launch_ivf_front_items(A.assign, idx->d_partdesc.p, nq, ma, (uint32_t)fstride, d_sit, d_finit, pre_st);
+                launch_start_scan_f32(M, idx->sum_mode, d_sit, nq * ma, 1, A.ftables, s.d_fc.p, fstride, d_finit, s.d_qs, pre_st);
+                launch_select_kth(s.d_fc.p, fstride, d_finit, nq, (uint32_t)s.R, s.d_qs, 4, A.ftables, s.d_qtables.p, (int)(table_dim * ma),
+                                  idx->quant_mode, pre_st, nullptr, nullptr, d_front_tp, 1);
+                HIPCHECK(hipGetLastError());
+                idx->prof.front_tp_batches++;
+            }
+        }
         if (pre_used) {
             if (!s.ev_pre) HIPCHECK(hipEventCreateWithFlags(&s.ev_pre, hipEventDisableTiming));
             HIPCHECK(hipEventRecord(s.ev_pre, pre_st));
@@ -313,6 +339,11 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             flush_later = false;
         }
         QueryKernelArgs H = A;
+        if (d_front_tp) {                                        // the front ran as launches of its own (above): an int8 batch for the head
+            H.ftables = nullptr;
+            H.qtables = s.d_qtables.p;
+            H.front_in = d_front_tp;
+        }
         H.head_codes = ~0ull;
         H.head_slots = (uint32_t)head_slots;
         H.qstates = s.d_qs;

@@ -315,7 +315,15 @@ void launch_build_tables(const float* d_queries, const float* d_coarse, const in
 void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init, int nq, uint32_t R,
                        QueryState* d_qs, int max_passes, float* d_ftables, int8_t* d_qtables, int table_dim_all,
                        int quant_mode, hipStream_t stream, float* export_vals = nullptr,
-                       uint32_t* export_flags = nullptr);
+                       uint32_t* export_flags = nullptr, uint32_t* d_front_out = nullptr, int small_wg = 0);
+// d_front_out (optional): {flags & 3, qmin, qmax, 0} per query = the front_in record of scan_query_kernel's HEAD; small_wg:
+// 256-thread workgroups (a batch of many queries beside running scans) instead of 1024.
+
+// Pre-scan items of a queries-in batch, built on the device from assign[] and the partition table: one StartItem per
+// (query, probe) in assign order, out_off = prefix of the probes' start sizes; d_fc_init[2q] = starts of query q (<= cap),
+// d_fc_init[2q + 1] = cap.  launch_start_scan_f32 + launch_select_kth then are the query's front.
+void launch_ivf_front_items(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, uint32_t cap, StartItem* d_items,
+                            uint32_t* d_fc_init, hipStream_t stream);
 
 // Key range of d_vals[q][nvals] into QueryState::sel_nmin / sel_max (injected pre-scan values).
 void launch_prescan_minmax(const float* d_vals, uint32_t nvals, int nq, QueryState* d_qs, hipStream_t stream);

@@ -1562,14 +1562,15 @@ void launch_start_scan_f32(int M, int sum_mode, const StartItem* d_items, int ni
 // quant_mode 0 = source level: trunc((v-min)/delta), delta = (max-min)/127.
 // Strict IEEE float ops (build uses -ffp-contract=off, no fast-math), so results equal a CPU
 // evaluation of the same expressions.
+template <int BT>
 __device__ void quantize_query(int table_dim_all, float* __restrict__ tb, int8_t* __restrict__ qt, QueryState* qs,
-                               float qmax, int quant_mode, float* red /* [1024] LDS */) {
+                               float qmax, int quant_mode, float* red /* [BT] LDS */) {
     const int t = threadIdx.x;
     float m = FLT_MAX;
-    for (int i = t; i < table_dim_all; i += 1024) m = fminf(m, tb[i]);
+    for (int i = t; i < table_dim_all; i += BT) m = fminf(m, tb[i]);
     red[t] = m;
     __syncthreads();
-    for (int d = 512; d >= 1; d >>= 1) {
+    for (int d = BT / 2; d >= 1; d >>= 1) {
         if (t < d) red[t] = fminf(red[t], red[t + d]);
         __syncthreads();
     }
@@ -1579,7 +1580,7 @@ __device__ void quantize_query(int table_dim_all, float* __restrict__ tb, int8_t
     if ((double)qmax > 1e30) flags |= 1u;                       // (a double compare, as db_query_4.cpp:271: 1e30f itself is above 1e30)
     const float delta = (qmax - qmin) / 127;
     const float scale = 127.0f / (qmax - qmin);
-    for (int i = t; i < table_dim_all; i += 1024) {
+    for (int i = t; i < table_dim_all; i += BT) {
         float v = tb[i];
         if (v < 0) { v = 0; tb[i] = 0; }
         int8_t o;
@@ -1591,28 +1592,42 @@ __device__ void quantize_query(int table_dim_all, float* __restrict__ tb, int8_t
     if (t == 0) { qs->qmin = qmin; qs->flags |= flags; }   // keeps bit3 set by the pre-scan
 }
 
-__global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restrict__ fc, uint64_t fc_stride,
-                                                          const uint32_t* __restrict__ fc_init, uint32_t R,
-                                                          QueryState* __restrict__ qstates, int max_passes,
-                                                          float* __restrict__ ftables, int8_t* __restrict__ qtables,
-                                                          int table_dim_all, int quant_mode,
-                                                          float* __restrict__ export_vals,
-                                                          uint32_t* __restrict__ export_flags) {
+// BT threads per workgroup: 1024 for the level path's few queries with many values each; 256 for a batch of many queries
+// (the throughput front of a partition-major batch: a 16-wave workgroup would wait for half a CU beside the scans).
+// front_out (optional): {flags & 3, qmin, qmax, 0} per query, the record scan_query_kernel's HEAD takes as front_in.
+template <int BT>
+__global__ __launch_bounds__(BT) void select_kth_kernel(const float* __restrict__ fc, uint64_t fc_stride,
+                                                        const uint32_t* __restrict__ fc_init, uint32_t R,
+                                                        QueryState* __restrict__ qstates, int max_passes,
+                                                        float* __restrict__ ftables, int8_t* __restrict__ qtables,
+                                                        int table_dim_all, int quant_mode,
+                                                        float* __restrict__ export_vals,
+                                                        uint32_t* __restrict__ export_flags, uint32_t* __restrict__ front_out) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_k, s_hi, s_cnt;
-    __shared__ float red[1024];
+    __shared__ float red[BT];
     const int q = blockIdx.x, tid = threadIdx.x;
     QueryState* qs = qstates + q;
+    auto publish_front = [&]() {                             // (after quantize_query: thread 0 wrote qmin / flags / qmax itself)
+        if (front_out && tid == 0) {
+            uint32_t* fo = front_out + 4 * (size_t)q;
+            fo[0] = qs->flags & 3u;
+            fo[1] = __float_as_uint(qs->qmin);
+            fo[2] = __float_as_uint(qs->qmax);
+            fo[3] = 0;
+        }
+    };
     const uint32_t n = min(fc_init[2 * q] + qs->fc_n, fc_init[2 * q + 1]);
     if (export_flags && tid == 0) export_flags[q] = qs->flags;
     if (n < R) {                                           // heap never fills: max() stays the FLT_MAX sentinel
         if (export_vals) {                                 // sharded pre-scan: all n values, padded with the sentinel
-            for (uint32_t i = tid; i < R; i += 1024)
+            for (uint32_t i = tid; i < R; i += BT)
                 export_vals[(uint64_t)q * R + i] = i < n ? fc[(uint64_t)q * fc_stride + i] : FLT_MAX;
         }
         if (tid == 0) qs->qmax = FLT_MAX;
-        if (qtables) quantize_query(table_dim_all, ftables + (uint64_t)q * table_dim_all, qtables + (uint64_t)q * table_dim_all,
-                                    qs, FLT_MAX, quant_mode, red);
+        if (qtables) quantize_query<BT>(table_dim_all, ftables + (uint64_t)q * table_dim_all, qtables + (uint64_t)q * table_dim_all,
+                                        qs, FLT_MAX, quant_mode, red);
+        publish_front();
         return;
     }
     const uint32_t kmin = ~qs->sel_nmin, kmax = qs->sel_max;
@@ -1628,16 +1643,16 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         // 8 independent loads per thread and iteration: the loop is latency-bound otherwise (one workgroup)
-        for (uint32_t i0 = tid; i0 < n; i0 += 8 * 1024) {
+        for (uint32_t i0 = tid; i0 < n; i0 += 8 * BT) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const uint32_t i = i0 + u * 1024;
+                const uint32_t i = i0 + u * BT;
                 v[u] = i < n ? src[i] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (i0 + u * 1024 >= n) continue;
+                if (i0 + u * BT >= n) continue;
                 const uint32_t key = fkey(v[u]) - kmin;
                 if (hi >= 32 || ((key ^ prefix) >> hi) == 0) atomicAdd(&hist[(key >> lo) & dmask], 1u);
             }
@@ -1672,15 +1687,16 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
         // qmax, then qmax itself as often as it takes — which of several equal values is dropped does not matter
         if (tid == 0) s_cnt = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += 1024) {
+        for (uint32_t i = tid; i < n; i += BT) {
             const float v = src[i];
             if (v < qmax) export_vals[(uint64_t)q * R + atomicAdd(&s_cnt, 1u)] = v;    // fewer than R such values
         }
         __syncthreads();
-        for (uint32_t i = s_cnt + tid; i < R; i += 1024) export_vals[(uint64_t)q * R + i] = qmax;
+        for (uint32_t i = s_cnt + tid; i < R; i += BT) export_vals[(uint64_t)q * R + i] = qmax;
     }
-    if (qtables) quantize_query(table_dim_all, ftables + (uint64_t)q * table_dim_all, qtables + (uint64_t)q * table_dim_all,
-                                qs, qmax, quant_mode, red);
+    if (qtables) quantize_query<BT>(table_dim_all, ftables + (uint64_t)q * table_dim_all, qtables + (uint64_t)q * table_dim_all,
+                                    qs, qmax, quant_mode, red);
+    publish_front();
 }
 
 // Sharded pre-scan, second half: the gathered smallest values of all ranks stand in for the pre-scan output of
@@ -1715,9 +1731,56 @@ void launch_prescan_minmax(const float* d_vals, uint32_t nvals, int nq, QuerySta
 
 void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_fc_init, int nq, uint32_t R, QueryState* d_qs,
                        int max_passes, float* d_ftables, int8_t* d_qtables, int table_dim_all, int quant_mode,
-                       hipStream_t stream, float* export_vals, uint32_t* export_flags) {
-    hipLaunchKernelGGL(select_kth_kernel, dim3(nq), dim3(1024), 0, stream, d_fc, fc_stride, d_fc_init, R, d_qs, max_passes,
-                       d_ftables, d_qtables, table_dim_all, quant_mode, export_vals, export_flags);
+                       hipStream_t stream, float* export_vals, uint32_t* export_flags, uint32_t* d_front_out, int small_wg) {
+    if (small_wg)
+        hipLaunchKernelGGL((select_kth_kernel<256>), dim3(nq), dim3(256), 0, stream, d_fc, fc_stride, d_fc_init, R, d_qs, max_passes,
+                           d_ftables, d_qtables, table_dim_all, quant_mode, export_vals, export_flags, d_front_out);
+    else
+        hipLaunchKernelGGL((select_kth_kernel<1024>), dim3(nq), dim3(1024), 0, stream, d_fc, fc_stride, d_fc_init, R, d_qs, max_passes,
+                           d_ftables, d_qtables, table_dim_all, quant_mode, export_vals, export_flags, d_front_out);
+}
+
+// Pre-scan items of a queries-in batch built on the device: one per (query, probe), straight from assign[] and the partition
+// table (the level path's planner builds them on the host from a host copy of assign[]).  One wave per query: lane a = probe a
+// (ma <= 64 per round), out_off = the exclusive prefix of the probes' start sizes, fc_init = {all starts, capacity}.
+__global__ __launch_bounds__(256) void ivf_front_items_kernel(const int32_t* __restrict__ assign, const PartDesc* __restrict__ parts, int nq,
+                                                              int ma, uint32_t cap, StartItem* __restrict__ items,
+                                                              uint32_t* __restrict__ fc_init) {
+    const int q = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    if (q >= nq) return;
+    uint32_t base = 0;
+    for (int a0 = 0; a0 < ma; a0 += 64) {
+        const int a = a0 + (int)lane;
+        uint32_t sn = 0;
+        const uint8_t* sc = nullptr;
+        if (a < ma) {
+            const PartDesc& d = parts[assign[(size_t)q * ma + a]];
+            sn = d.global_n ? d.start_n : 0u;
+            sc = d.starts ? d.starts : d.codes;
+        }
+        const uint32_t incl = dpp_wave_incl_sum(sn);
+        if (a < ma) {
+            StartItem it;
+            it.codes = sc;
+            it.n = sn;
+            it.table = (uint32_t)((size_t)q * ma + a);
+            it.query = (uint32_t)q;
+            it.out_off = base + incl - sn;
+            it.filter = 0;
+            items[(size_t)q * ma + a] = it;
+        }
+        base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) {
+        fc_init[2 * q] = min(base, cap);
+        fc_init[2 * q + 1] = cap;
+    }
+}
+
+void launch_ivf_front_items(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, uint32_t cap, StartItem* d_items,
+                            uint32_t* d_fc_init, hipStream_t stream) {
+    hipLaunchKernelGGL(ivf_front_items_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, d_assign, d_parts, nq, ma, cap, d_items, d_fc_init);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1489,6 +1489,52 @@ def test_wgq_grouped_second_phase_matches_oracle(pyqadc, po, M, nq, ma, head, bi
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [16, 32])
+def test_throughput_front_of_partition_major_batches(pyqadc, po, M):
+    """Option front_tp: a partition-major batch runs its front — scan_4 over the starts of every probe, the R-th smallest, qmin /
+    clamp / QuantizerMAX — as three launches of small workgroups (items built on the device from assign[]) and the head starts
+    from int8 tables; same qmin, qmax, int8 tables, clamped float tables, statuses and heaps as the oracle, through the
+    host-table entry point (negative entries, a query whose probes hold fewer than R starts, an empty probed partition) and
+    through qadc_search."""
+    rng = np.random.default_rng(7200 + M)
+    sizes = [int(x) for x in rng.integers(200, 5000, 30)] + [0, 17, 40001, 30000, 300, 400]
+    parts = [rand_codes(rng, n, M) for n in sizes]
+    labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
+    keep, R, ma, K = 0.05, 100, 6, len(sizes)
+    idx = pyqadc.Index(M)
+    idx.add_partitions(parts, labels)
+    idx.finalize(keep)
+    for k, v in dict(wgq=2, wgq_group=2, wgq_group_head=2, device_replay_nq=1, device_replay_alone_nq=0, front_tp=1, profile=1).items():
+        idx.set_option(k, v)
+    nq = 150
+    assign = np.stack([rng.permutation(K - 2)[:ma] for _ in range(nq)]).astype(np.int32)
+    for q in range(nq):
+        b = (32, 33)[q % 2]
+        assign[q] = [b] + [p for p in assign[q] if p != b][:ma - 1]
+    assign[7] = [34, 35, 31, 30, 34, 35]                          # 15 + 20 + 0 + 0 ... starts < R: qmax stays FLT_MAX -> status 1
+    assign[7, 4:] = [31, 30]
+    tables = float_tables(rng, nq, ma, M, negatives=True)
+    tables = np.ascontiguousarray(tables + np.float32(0.6) * np.arange(ma, dtype=np.float32)[None, :, None])
+    t_gpu = tables.copy()
+    got = idx.query_scan(assign, t_gpu, R, want_qtables=True)
+    assert idx.profile()["front_tp_batches"] >= 1 and idx.profile()["group_launches"] >= 1
+    nstat = 0
+    for q in range(nq):
+        t_cpu = tables[q].copy()
+        want = po.query_scan(M, parts, labels, keep, assign[q], t_cpu, R)
+        assert got["status"][q] == want["rc"], q
+        assert got["qmax"][q] == np.float32(want["qmax"]) and got["qmin"][q] == np.float32(want["qmin"]), q
+        if want["rc"]:
+            nstat += 1
+            continue
+        assert np.array_equal(got["qtables"][q], want["qtables"]), q
+        assert np.array_equal(t_gpu[q], t_cpu), q
+        assert heaps_equal(got["heaps"][q], (want["keys"], want["values"])), q
+    assert nstat >= 1
+    idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 32])
 def test_deferred_replay_of_pipelined_partition_major_batches(pyqadc, po, M):
     """Option replay_defer: the device replay of a partition-major batch is not enqueued with the batch but released behind
     the head launch of the NEXT such batch — or by collect when no later batch came.  Five batches through three slots (the
