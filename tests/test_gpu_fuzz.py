@@ -54,7 +54,9 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
                 # grouping of the float pre-scan's adds: the reference binary's (default) or the source's
                 sum_mode=int(rng.choice([1, 1, 0])),
                 # device replay of a partition-major batch released by the next batch's head launch or by collect
-                replay_defer=int(rng.integers(0, 2)))
+                replay_defer=int(rng.integers(0, 2)),
+                # partition-major batches: the front as launches of small workgroups (device-built pre-scan items) or inside the head
+                front_tp=int(rng.integers(0, 2)))
     for k, v in opts.items():
         idx.set_option(k, v)
     tables = float_tables(rng, nq, ma, M, scale=float(rng.choice([0.2, 1.0])))
