@@ -295,6 +295,8 @@ def pmc_leg_main():
     idx.finalize(KEEP)
     idx.set_option("profile", 1)
     set_mode(idx, MODE_ONE_QUERY_PER_PASS)
+    for kv in filter(None, os.environ.get("QADC_BENCH_OPTS", "").split(",")):     # tuning experiments only (as in main)
+        idx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     rng = np.random.default_rng(1234)
     codebooks = rng.normal(size=(M, 16, 128 // M)).astype(np.float32)
     tb = make_tables(rng, codebooks, NQ)
