@@ -919,6 +919,7 @@ def main():
     # own HIP runtime has to be up first — tests/conftest.py — hence not earlier than this.)
     torch.zeros(1, device=dev)
     pyqadc.device_prepare(local_rank)
+    stream_layout = None
     cdev = dev if backend == "nccl" else torch.device("cpu")   # device of the collective buffers
     # QADC_BENCH_FORCE_DIST=1 takes the multi-rank code path (collectives included) even with one rank
     use_dist = world > 1 or bool(os.environ.get("QADC_BENCH_FORCE_DIST"))
@@ -936,6 +937,9 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
+    # the deployment check of DESIGN.md section 5, with every communicator of this process alive: do the library's streams sit where
+    # the measured figures assume (qadc_stream_layout: ten probes, ~3 ms)?
+    stream_layout = pyqadc.stream_layout(local_rank)
     # ---- database: this rank's contiguous shard of the synthetic list + replica of the starts ----
     # measurement hook (tools/dist_sizes3.sh): ONE process stands in for rank 0 of LOOP ranks — it holds 1/LOOP of the list,
     # pre-scans 1/LOOP of the starts, and the loopback transport hands it LOOP copies of its own block to merge
@@ -1200,6 +1204,7 @@ def main():
                        "scan_kernel_ms_per_step": prof["scan_ms"] / args.steps,
                        "host_sort_replay_ms_per_step": prof["host_replay_ms"] / args.steps,
                        "candidates_per_query": prof["candidates"] / (NQ * args.steps), "regrows": prof["regrows"]},
+            "stream_layout": stream_layout,
             "multi_gpu_note": "no 8-GPU node was available to the builder: N > 1 has only run as N processes on ONE GPU over the "
                               "shared-memory transport (tests) and with one rank over RCCL; no scaling curve was measured",
         }

@@ -47,6 +47,20 @@ const char* qadc_version(void);
  * (the reference is single-process CPU code).  After hipDeviceReset() the set is rebuilt by the next call / index. */
 int qadc_device_prepare(int device_id);
 
+/* Diagnostic of the stream layout (no reference counterpart): launches a kernel whose workgroups wait for CUs for several rounds on
+ * stream `a` of the device's set and a one-wave marker on stream `b` right behind it (streams: 0 scan, 1 copy, 2 ordering, 3 front,
+ * 4 alternative scan, 5 collectives, 6 merge).  *wait_us = when the marker started, counted from the first workgroup of the long
+ * launch; *spin_us (optional) = how long that launch lasted.  A marker that starts within a few microseconds sits on another
+ * compute pipe; one that waits most of spin_us shares the long launch's pipe (or its hardware queue): what a scan does to the
+ * collectives or to the next batch's front when the process created other queues before the set. */
+int qadc_stream_probe(int device_id, int a, int b, double* wait_us, double* spin_us);
+/* The check a deployment runs once: "<creation order of the set> | ok" or "... | <pairs still obstructed, with the marker's
+ * wait>", from ten probes of the pairs that matter (nothing may hold up the scan stream but its idle alternative; copy, ordering
+ * and collectives must not hold up the front stream; ordering and front not the collectives').  ~3 ms, on demand only.  Not "ok"
+ * means the process created queues before the set: call qadc_device_prepare earlier (a search over pad streams that would repair
+ * the layout from inside was built and does not converge: DESIGN.md section 5). */
+const char* qadc_stream_layout(int device_id);
+
 /* M = 16 or 32 sub-quantizers of 4 bits (get_simd_scan_func_epi8, db_query_4.cpp:22-35). */
 int qadc_index_create(qadc_index** out, int M, int device_id);
 int qadc_index_destroy(qadc_index* idx);

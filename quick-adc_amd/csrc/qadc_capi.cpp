@@ -1048,6 +1048,7 @@ struct StreamSet {
     hipStream_t stream = nullptr, wgq = nullptr, copy = nullptr, sort = nullptr, front = nullptr, coll = nullptr;
     hipStream_t merge[kMergeStreams] = {};
     std::vector<hipStream_t> created;                           // creation order
+    std::string order, report;                                  // the creation order that was kept, and what the layout probe saw
 };
 std::mutex g_streams_mu;
 std::vector<std::pair<int, StreamSet*>> g_streams;              // (device, set): lives until the process ends
@@ -1101,6 +1102,57 @@ hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merg
     return hipSuccess;
 }
 
+// One probe: microseconds the marker on `b` waited behind the CU-hungry launch on `a` (min of `reps`: other work on the GPU only
+// ever adds to it).  d_t: 4 u64 of device scratch.
+hipError_t probe_wait_us(hipStream_t a, hipStream_t b, unsigned long long* d_t, int ncu, int reps, double* out) {
+    double best = 1e30;
+    for (int r = 0; r < reps; ++r) {
+        const unsigned long long init[4] = {~0ull, 0, 0, 0};
+        hipError_t e = hipMemcpy(d_t, init, sizeof(init), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_stream_probe(d_t, 8 * ncu, 3000, a, b);       // 4 rounds of 30 us at two workgroups per CU
+        if (e == hipSuccess) e = hipStreamSynchronize(a);
+        if (e == hipSuccess) e = hipStreamSynchronize(b);
+        unsigned long long t[4];
+        if (e == hipSuccess) e = hipMemcpy(t, d_t, sizeof(t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        best = std::min(best, ((double)t[2] - (double)t[0]) / 100.0);
+    }
+    *out = best;
+    return hipSuccess;
+}
+
+// How many of the pairs that must not obstruct each other do (-1: the probe itself failed).  A marker that waits more than 40 us
+// of the ~120 us launch sits behind it on the same pipe (~100 us: it runs when the last workgroup has been dispatched) or in the
+// same hardware queue (~135 us: when the launch is over).  Must stay free: the scan stream of {copy, ordering, front, collectives,
+// merge}; the front stream of {copy, ordering, collectives}; the collectives' stream of {ordering, front}.  (By design, and not
+// counted: ordering holds up merge, the idle alternative scan stream shares the scan's pipe, copy and collectives share one.)
+int layout_violations(StreamSet& ss, int device, std::string* report) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
+    unsigned long long* d_t = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d_t), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    struct Pair { hipStream_t a, b; const char* name; };
+    const Pair pairs[] = {
+        {ss.coll, ss.stream, "collectives>scan"}, {ss.copy, ss.stream, "copy>scan"}, {ss.sort, ss.stream, "ordering>scan"},
+        {ss.front, ss.stream, "front>scan"}, {ss.merge[0], ss.stream, "merge>scan"},
+        {ss.copy, ss.front, "copy>front"}, {ss.sort, ss.front, "ordering>front"}, {ss.coll, ss.front, "collectives>front"},
+        {ss.sort, ss.coll, "ordering>collectives"}, {ss.front, ss.coll, "front>collectives"}};
+    int v = 0;
+    double warm = 0;
+    (void)probe_wait_us(ss.copy, ss.front, d_t, prop.multiProcessorCount, 1, &warm);   // (first launch: code object load, LDS opt-in)
+    for (const Pair& p : pairs) {
+        double w = 0;
+        if (probe_wait_us(p.a, p.b, d_t, prop.multiProcessorCount, 2, &w) != hipSuccess) { v = -1; break; }
+        if (w > 40.0) {
+            ++v;
+            if (report) *report += std::string(report->empty() ? "" : ", ") + p.name + " " + std::to_string((int)w) + " us";
+        }
+    }
+    (void)hipFree(d_t);
+    if (report && v == 0) *report = "ok";
+    return v;
+}
+
 // The per-device stream set of the process: found or created (the caller holds no lock).  A cached set whose streams the
 // runtime no longer knows (the application called hipDeviceReset between two indexes) is dropped and rebuilt.
 int shared_stream_set(int device, StreamSet** out) {
@@ -1115,11 +1167,22 @@ int shared_stream_set(int device, StreamSet** out) {
         break;
     }
     StreamSet* ss = new StreamSet();
-    const hipError_t e = create_stream_set(*ss, "S,C,O,F,W,L,M0", 1, false, false);
+    std::string order = "S,C,O,F,W,L,M0";
+    if (const char* hk = std::getenv("QADC_TEST_HOOKS"))
+        if (std::atoi(hk) == 1)
+            if (const char* e = std::getenv("QADC_SHARED_STREAM_ORDER")) order = e;   // measurement hook (tools/stream_probe_matrix.py)
+    const hipError_t e = create_stream_set(*ss, order, 1, false, false);
     if (e != hipSuccess) {
         delete ss;
         return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
+    // (the layout this order gives is CHECKED on demand — qadc_stream_layout, and once by qadc_dist_init: layout_violations below —
+    // not repaired: a search over pad streams in front of re-created sets was built and measured in round 5, and in a process that
+    // created a torch "nccl" group first every candidate left exactly one of the four highest-priority streams on the scan's pipe;
+    // what works is creating the set BEFORE the communicator: qadc_device_prepare)
+    std::string report;
+    ss->order = order;
+    ss->report = report;
     g_streams.emplace_back(device, ss);
     *out = ss;
     return QADC_OK;
@@ -1175,6 +1238,45 @@ int qadc_device_prepare(int device_id) {
     HIPCHECK(hipSetDevice(device_id));
     StreamSet* ss = nullptr;
     return shared_stream_set(device_id, &ss);
+}
+
+const char* qadc_stream_layout(int device_id) {
+    static thread_local std::string out;
+    if (qadc_device_prepare(device_id)) return "";
+    StreamSet* ss = nullptr;
+    if (shared_stream_set(device_id, &ss)) return "";
+    if (ss->report.empty()) {                                    // probed once per set, on demand
+        std::string rep;
+        const int v = layout_violations(*ss, device_id, &rep);
+        ss->report = v < 0 ? "probe failed" : rep;
+    }
+    out = ss->order + " | " + ss->report;
+    return out.c_str();
+}
+
+int qadc_stream_probe(int device_id, int a, int b, double* wait_us, double* spin_us) {
+    if (a < 0 || a > 6 || b < 0 || b > 6 || !wait_us) return fail(QADC_E_ARG, "streams are numbered 0 .. 6 (scan, copy, ordering, front, alternative scan, collectives, merge)");
+    if (int rc = qadc_device_prepare(device_id)) return rc;
+    StreamSet* ss = nullptr;
+    if (int rc = shared_stream_set(device_id, &ss)) return rc;
+    hipStream_t st[7] = {ss->stream, ss->copy, ss->sort, ss->front, ss->wgq, ss->coll, ss->merge[0]};
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, device_id));
+    DevBuf<unsigned long long> d_t;
+    HIPCHECK(d_t.ensure(4));
+    const unsigned long long init[4] = {~0ull, 0, 0, 0};
+    for (int i = 0; i < 7; ++i) HIPCHECK(hipStreamSynchronize(st[i]));
+    HIPCHECK(hipMemcpy(d_t.p, init, sizeof(init), hipMemcpyHostToDevice));
+    // 8 workgroups per CU at two resident per CU: four rounds of 30 us each
+    HIPCHECK(launch_stream_probe(d_t.p, 8 * prop.multiProcessorCount, 3000, st[a], st[b]));
+    HIPCHECK(hipStreamSynchronize(st[a]));
+    HIPCHECK(hipStreamSynchronize(st[b]));
+    unsigned long long t[4];
+    HIPCHECK(hipMemcpy(t, d_t.p, sizeof(t), hipMemcpyDeviceToHost));
+    d_t.release();
+    *wait_us = ((double)t[2] - (double)t[0]) / 100.0;           // marker start after the first spin workgroup's start
+    if (spin_us) *spin_us = ((double)t[1] - (double)t[0]) / 100.0;
+    return QADC_OK;
 }
 
 int qadc_index_create(qadc_index** out, int M, int device_id) {

@@ -319,6 +319,10 @@ void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_
 // d_front_out (optional): {flags & 3, qmin, qmax, 0} per query = the front_in record of scan_query_kernel's HEAD; small_wg:
 // 256-thread workgroups (a batch of many queries beside running scans) instead of 1024.
 
+// Stream-layout probe: a launch of spin_wgs two-per-CU workgroups spinning spin_ticks (100 MHz wall clock) each on stream a, then a
+// one-wave marker on stream b; d_t[0] = first spin workgroup's start (initialise to ~0), [1] = last one's end (0), [2] = marker start.
+hipError_t launch_stream_probe(unsigned long long* d_t, int spin_wgs, uint32_t spin_ticks, hipStream_t a, hipStream_t b);
+
 // Pre-scan items of a queries-in batch, built on the device from assign[] and the partition table: one StartItem per
 // (query, probe) in assign order, out_off = prefix of the probes' start sizes; d_fc_init[2q] = starts of query q (<= cap),
 // d_fc_init[2q + 1] = cap.  launch_start_scan_f32 + launch_select_kth then are the query's front.

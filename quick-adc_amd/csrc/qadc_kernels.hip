@@ -1778,6 +1778,34 @@ __global__ __launch_bounds__(256) void ivf_front_items_kernel(const int32_t* __r
     }
 }
 
+// ---- stream-layout probe (qadc_stream_probe): does a dispatch that WAITS FOR CUs on stream A hold up stream B? ----
+// probe_spin_kernel: many 256-thread workgroups that hold 64 KiB of LDS each (two per CU: most wave slots stay free) and spin
+// for spin_ticks of the 100 MHz wall clock: the launch keeps its queue's dispatcher waiting for CUs for several rounds.
+// t[0] = first workgroup's start, t[1] = last workgroup's end, t[2] = start of probe_mark_kernel (launched on B right after).
+__global__ __launch_bounds__(256) void probe_spin_kernel(unsigned long long* __restrict__ t, uint32_t spin_ticks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char probe_lds[];
+    const unsigned long long t0 = wall_clock64();
+    if (threadIdx.x == 0) {
+        probe_lds[0] = 1;
+        atomicMin(&t[0], t0);
+    }
+    while (wall_clock64() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) atomicMax(&t[1], wall_clock64());
+}
+__global__ void probe_mark_kernel(unsigned long long* __restrict__ t) {
+    if (threadIdx.x == 0) t[2] = wall_clock64();
+}
+hipError_t launch_stream_probe(unsigned long long* d_t, int spin_wgs, uint32_t spin_ticks, hipStream_t a, hipStream_t b) {
+    static std::atomic<int> opted{0};
+    if (!opted.exchange(1)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_spin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(probe_spin_kernel, dim3(spin_wgs), dim3(256), 65536, a, d_t, spin_ticks);
+    hipLaunchKernelGGL(probe_mark_kernel, dim3(1), dim3(64), 0, b, d_t);
+    return hipGetLastError();
+}
+
 void launch_ivf_front_items(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, uint32_t cap, StartItem* d_items,
                             uint32_t* d_fc_init, hipStream_t stream) {
     hipLaunchKernelGGL(ivf_front_items_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, d_assign, d_parts, nq, ma, cap, d_items, d_fc_init);

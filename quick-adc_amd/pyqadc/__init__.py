@@ -32,7 +32,7 @@ SYMBOLS = [
     "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit", "qadc_prescan_submit",
     "qadc_prescan_collect", "qadc_query_scan_submit_prescanned",
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
-    "qadc_search_collect", "qadc_device_prepare", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_kmeans_iterations_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
+    "qadc_search_collect", "qadc_device_prepare", "qadc_stream_probe", "qadc_stream_layout", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_kmeans_iterations_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
     "qadc_dist_unique_id", "qadc_dist_init", "qadc_dist_collect", "qadc_dist_shutdown", "qadc_dist_merge_blocks", "qadc_dist_merge_blocks_host",
     "qadc_dist_init_transport", "qadc_dist_init_loopback", "qadc_shm_transport_open", "qadc_shm_transport_allgather", "qadc_shm_transport_allgather_host",
     "qadc_shm_transport_close", "qadc_shm_transport_error", "qadc_slot_assign", "qadc_slot_qtables", "qadc_place_partitions",
@@ -167,6 +167,21 @@ def replay_i8(keys, vals, R, sentinel=False):
 def device_prepare(device=0):
     """qadc_device_prepare: the library's per-device stream set, created now — call before any communicator is initialised."""
     _check(lib().qadc_device_prepare(int(device)))
+
+
+def stream_layout(device=0):
+    """qadc_stream_layout: '<stream creation order kept> | <ok or the obstructed pairs>'."""
+    f = lib().qadc_stream_layout
+    f.restype = C.c_char_p
+    return f(int(device)).decode()
+
+
+def stream_probe(a, b, device=0):
+    """qadc_stream_probe: (microseconds a one-wave marker on stream b waited behind a CU-hungry launch on stream a, that launch's
+    duration).  Streams: 0 scan, 1 copy, 2 ordering, 3 front, 4 alternative scan, 5 collectives, 6 merge."""
+    w, sp = C.c_double(0), C.c_double(0)
+    _check(lib().qadc_stream_probe(int(device), int(a), int(b), C.byref(w), C.byref(sp)))
+    return w.value, sp.value
 
 
 def sort_keys_i8(heap_keys, heap_vals):

@@ -170,3 +170,24 @@ def test_gpu_labels_mode_is_read_off_partition_0_even_if_empty(pyqadc):
     idx.add_partitions([a, e, b], [la, None, lb])                        # an empty partition elsewhere is only a warning
     idx.finalize(0.5)
     idx.close()
+
+
+def test_stream_layout_check_of_a_fresh_process():
+    """qadc_stream_layout / qadc_stream_probe: in a process that created nothing on the GPU before the
+    library's stream set, the ten pairs that matter are unobstructed ("... | ok"), the one obstruction the layout has BY DESIGN is
+    there (the ordering stream's CU-hungry launch holds up the merge stream: they share a pipe) and a marker on another pipe starts
+    within a few microseconds.  Run in a child process: the test process itself has a history (torch, other indexes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import pyqadc; pyqadc.device_prepare(0); print(pyqadc.stream_layout(0)); "
+            "print(min(pyqadc.stream_probe(2, 6)[0] for _ in range(3)), min(pyqadc.stream_probe(0, 1)[0] for _ in range(3)))"
+            % os.path.join(root, "quick-adc_amd"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("QADC_")}
+    out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().split("\n")
+    assert out[-2].startswith("S,C,O,F,W,L,M0 | "), out
+    blocked, free = [float(x) for x in out[-1].split()]
+    assert free < 40.0, out
+    if out[-2].endswith("| ok"):                                 # (a box shared with other jobs may obstruct a probe: then only the format is checked)
+        assert blocked > 60.0, out

@@ -50,4 +50,6 @@ name, placement = sys.argv[1], sys.argv[2]
 r = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 shard = None if placement == "none" else dict(rank=r, world=WORLD, placement=placement, init=lambda ix: ix.dist_init_loopback(r, WORLD), merge="loopback")
 o = bench.ivf_leg(0, shard=shard, **SHAPES[name])
+import pyqadc as _pq
+o["stream_layout"] = _pq.stream_layout(0)
 print(json.dumps({k: o[k] for k in o if k not in ("workload", "algorithmic_GBps_rule") and not k.startswith("_")}))
