@@ -1066,8 +1066,20 @@ hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merg
         pos = comma + 1;
         hipStream_t* dst = nullptr;
         int prio = prio_greatest;
-        if (tok == "S") { dst = &ss.stream; prio = prio_least; }
-        else if (tok == "W") { dst = &ss.wgq; prio = w_low ? prio_least : prio_normal; }
+        if (tok == "S") {
+            dst = &ss.stream;
+            prio = prio_least;
+            if (const char* hk = std::getenv("QADC_TEST_HOOKS"))            // measurement hook: the scan stream's priority
+                if (std::atoi(hk) == 1)
+                    if (const char* sp = std::getenv("QADC_SCAN_PRIO")) prio = sp[0] == 'h' ? prio_greatest : sp[0] == 'n' ? prio_normal : prio_least;
+        }
+        else if (tok == "W") {
+            dst = &ss.wgq;
+            prio = w_low ? prio_least : prio_normal;
+            if (const char* hk = std::getenv("QADC_TEST_HOOKS"))            // measurement hook: the alternative scan stream's priority
+                if (std::atoi(hk) == 1)
+                    if (const char* sp = std::getenv("QADC_W_PRIO")) prio = sp[0] == 'h' ? prio_greatest : sp[0] == 'n' ? prio_normal : prio_least;
+        }
         else if (tok == "C") dst = &ss.copy;
         else if (tok == "O") dst = &ss.sort;
         else if (tok == "F") dst = &ss.front;
@@ -1076,6 +1088,9 @@ hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merg
             if (tok[1] - '0' >= n_merge) continue;
             dst = &ss.merge[tok[1] - '0'];
             prio = merge_normal ? prio_normal : prio_least;
+            if (const char* hk = std::getenv("QADC_TEST_HOOKS"))
+                if (std::atoi(hk) == 1)
+                    if (const char* sp = std::getenv("QADC_MERGE_PRIO2")) prio = sp[0] == 'h' ? prio_greatest : sp[0] == 'n' ? prio_normal : prio_least;
         } else if (tok == "D" || tok == "N" || tok == "H") {
             hipStream_t dummy = nullptr;
             e = hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, tok == "D" ? prio_least : tok == "N" ? prio_normal : prio_greatest);
