@@ -138,8 +138,8 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * batches run their front — float pre-scan of the starts, R-th smallest, quantizer — as three launches of small workgroups off the
  * scan stream instead of inside the head launch),
  * "plan_early" (pipelined query-kernel batches: float tables, state clear and partition-major plan run on the stream that produces
- * assign[] instead of the scan stream; default 1), "wgq_stream" (query-kernel batches scan on the normal-priority alternative of the
- * scan stream; default 0), "wgq_ramp_shift" (the walk's ramp epochs grow by 2^shift; default doubling), "mq_single" (a lone long
+ * assign[] instead of the scan stream; default 1), "wgq_stream" (query-kernel batches scan on the highest-priority alternative of the
+ * scan stream; default 1 since round 5), "wgq_ramp_shift" (the walk's ramp epochs grow by 2^shift; default doubling), "mq_single" (a lone long
  * run through the multi-query kernel's 4-seat form: 0 never — default —, 1 for lists that fit the Infinity Cache, 2 always),
  * "wgq_order_bucket_max" (the ordering pass sorts by (slot, position) buckets and ranks inside a bucket by counting; a query with
  * a bucket above this many entries takes the bitonic network; default 256, 0 = always the network), "wgq_select_rank" (the front's

@@ -1028,9 +1028,11 @@ namespace {
 //    GPU_MAX_HW_QUEUES), the queues take hardware slots in creation order, and slot i is served by compute pipe i mod 4;
 //  * queues on one pipe are served in turn, whatever their priority: a dispatch that waits for free CUs — anything launched
 //    beside a long scan — holds up the other queues of its pipe.  So what matters is WHICH streams share a pipe:
-//        pipe 0: S scan stream (lowest priority), W its normal-priority alternative (option "wgq_stream"; never busy together)
-//        pipe 1: C copy / coarse assignment, L the merge's collectives         (both highest priority, both short)
-//        pipe 2: O ordering pass + replays of single-GPU batches, M the merge's interleave + replay (O idles under the merge)
+//        pipe 0: S scan stream of the level path (lowest priority), W scan stream of the one-workgroup-per-query batches (option
+//                "wgq_stream"; highest priority since round 5 — see the last item —; a batch uses one or the other)
+//        pipe 1: C copy / coarse assignment, L the merge's collectives         (both short; C normal priority since round 5)
+//        pipe 2: O ordering pass + replays of single-GPU batches (normal priority since round 5), M the merge's interleave +
+//                replay (highest since round 5; O idles under the merge)
 //        pipe 3: F the next batch's front — alone: it decides when the next scan can start
 //    One of 8 ranks' batch (loopback stand-in) with this order against round 3's (the merge's nine streams created at
 //    qadc_dist_init, one merge stream per slot): C3 shape 0.84 -> 0.51-0.53 ms, C5 1.26 -> 0.89-0.90.  With the front on the
@@ -1039,7 +1041,17 @@ namespace {
 //  * the layout a process gets is only the one above for the FIRST set of streams it creates: an index created after another
 //    one was destroyed — in either order of stream destruction — lands elsewhere (same shapes: 0.81 / 1.20 ms; the single-GPU
 //    C3 leg 0.75 -> 1.08 us per query; that was bench.py's IVF leg, the third index of its process).  Round 3's "figures
-//    depend on the process's history" was this.
+//    depend on the process's history" was this;
+//  * (round 5, qadc_stream_probe: profiles/r05_stream_probe.txt) on one pipe only a HIGHER-priority queue's waiting dispatch
+//    holds up a lower-priority queue; queues of equal priority cost each other a few microseconds.  And the runtime's four
+//    queues of the highest priority are all a process has: a fifth highest-priority stream — a communicator's, or a fifth of
+//    ours — shares one of them.  Hence the priorities below (round 4 had C and O at the highest, W normal, M lowest, and every
+//    batch on S): FOUR highest-priority streams — W, the scan stream of the one-workgroup-per-query (IVF) batches, which
+//    nobody can hold up then; F; L; M — C and O at normal priority, S (the level path's long launches) lowest as before.
+//    Same-box A/B, every leg of bench.py and the one-of-8 stand-ins (profiles/r05_stream_priorities.txt, "candidate 4"):
+//    nothing slower, the flat 125 M-code step 1.13 -> 1.08 ms, and one of 8 ranks' IVF batch in a process that created a
+//    torch "nccl" group BEFORE the set 0.73 -> 0.49 ms (C3) / 1.03 -> 0.83 (C5) instead of 0.38 / 0.72 in a fresh one: the
+//    order rule (qadc_device_prepare first) still holds, breaking it costs half as much.
 // Hence: ONE set of streams per process and device, created back to back in the order above by the first index on that
 // device, shared by every later index and never destroyed.  Indexes of one device that are driven at the same time share
 // these streams (stream order is then a superset of what each needs: correct, possibly serialised); the expected use is one
@@ -1075,19 +1087,24 @@ hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merg
         }
         else if (tok == "W") {
             dst = &ss.wgq;
-            prio = w_low ? prio_least : prio_normal;
+            prio = w_low ? prio_least : prio_greatest;
             if (const char* hk = std::getenv("QADC_TEST_HOOKS"))            // measurement hook: the alternative scan stream's priority
                 if (std::atoi(hk) == 1)
                     if (const char* sp = std::getenv("QADC_W_PRIO")) prio = sp[0] == 'h' ? prio_greatest : sp[0] == 'n' ? prio_normal : prio_least;
         }
-        else if (tok == "C") dst = &ss.copy;
-        else if (tok == "O") dst = &ss.sort;
+        else if (tok == "C" || tok == "O") {
+            dst = tok == "C" ? &ss.copy : &ss.sort;
+            prio = prio_normal;
+            if (const char* hk = std::getenv("QADC_TEST_HOOKS"))            // measurement hook: copy / ordering stream priority
+                if (std::atoi(hk) == 1)
+                    if (const char* sp = std::getenv(tok == "C" ? "QADC_C_PRIO" : "QADC_O_PRIO")) prio = sp[0] == 'h' ? prio_greatest : sp[0] == 'n' ? prio_normal : prio_least;
+        }
         else if (tok == "F") dst = &ss.front;
         else if (tok == "L") dst = &ss.coll;
         else if (tok.size() == 2 && tok[0] == 'M' && tok[1] >= '0' && tok[1] < '0' + kMergeStreams) {
             if (tok[1] - '0' >= n_merge) continue;
             dst = &ss.merge[tok[1] - '0'];
-            prio = merge_normal ? prio_normal : prio_least;
+            prio = merge_normal ? prio_normal : prio_greatest;
             if (const char* hk = std::getenv("QADC_TEST_HOOKS"))
                 if (std::atoi(hk) == 1)
                     if (const char* sp = std::getenv("QADC_MERGE_PRIO2")) prio = sp[0] == 'h' ? prio_greatest : sp[0] == 'n' ? prio_normal : prio_least;

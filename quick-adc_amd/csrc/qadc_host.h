@@ -375,7 +375,8 @@ struct qadc_index {
     hipStream_t coll_stream = nullptr;  // the multi-GPU merge's collectives (highest priority; unused until qadc_dist_init)
     hipStream_t merge_streams[kMergeStreams] = {};   // the merges' interleave + replay (lowest priority; unused until qadc_dist_init)
     std::vector<hipStream_t> own_streams;   // only under a measurement hook: streams created for this index alone (destroyed with it)
-    int wgq_stream_on = 0;              // option "wgq_stream": 1 = query-kernel batches scan on wgq_stream instead of `stream`
+    int wgq_stream_on = 1;              // option "wgq_stream": 1 (default since round 5) = query-kernel batches scan on wgq_stream — highest
+                                        // priority: nothing on its pipe can hold it up — instead of `stream` (lowest: the level path's)
     hipStream_t front_stream = nullptr; // a batch's pre-scan/quantize chain, under the previous batch's streaming launches
     hipStream_t copy_stream = nullptr;  // uploads and on-demand copies: issued where they depend on nothing (see plan_and_launch)
     uint32_t replay_seq = 0;            // device replays alternate between two side streams in submission order

@@ -174,15 +174,16 @@ def test_gpu_labels_mode_is_read_off_partition_0_even_if_empty(pyqadc):
 
 def test_stream_layout_check_of_a_fresh_process():
     """qadc_stream_layout / qadc_stream_probe: in a process that created nothing on the GPU before the
-    library's stream set, the ten pairs that matter are unobstructed ("... | ok"), the one obstruction the layout has BY DESIGN is
-    there (the ordering stream's CU-hungry launch holds up the merge stream: they share a pipe) and a marker on another pipe starts
-    within a few microseconds.  Run in a child process: the test process itself has a history (torch, other indexes)."""
+    library's stream set, the ten pairs that matter are unobstructed ("... | ok"), an obstruction the layout has BY DESIGN is
+    there (a CU-hungry launch on the highest-priority scan stream of the query-kernel batches holds up the level path's
+    lowest-priority scan stream: they share a pipe, and a batch uses one or the other) and a marker on another pipe starts within
+    a few microseconds.  Run in a child process: the test process itself has a history (torch, other indexes)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r); import pyqadc; pyqadc.device_prepare(0); print(pyqadc.stream_layout(0)); "
-            "print(min(pyqadc.stream_probe(2, 6)[0] for _ in range(3)), min(pyqadc.stream_probe(0, 1)[0] for _ in range(3)))"
+            "print(min(pyqadc.stream_probe(4, 0)[0] for _ in range(3)), min(pyqadc.stream_probe(0, 1)[0] for _ in range(3)))"
             % os.path.join(root, "quick-adc_amd"))
     env = {k: v for k, v in os.environ.items() if not k.startswith("QADC_")}
     out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().split("\n")
