@@ -41,8 +41,9 @@ const char* qadc_version(void);
  * it otherwise).  The set — scan, copy, ordering, front, collectives, merge — is created once per process and device, back to
  * back, because which hardware queue and compute pipe a stream lands on depends on the streams that exist already (DESIGN.md
  * section 5).  Four of the seven are highest-priority streams and the runtime keeps at most four queues per priority: a process that
- * creates a communicator (RCCL / torch.distributed "nccl": one more highest-priority stream) BEFORE the set measured a 40-60 %
- * slower IVF batch (profiles/r05_queue_map_rccl.txt); created AFTER the set it costs nothing.  So: call this (or create the
+ * creates a communicator (RCCL / torch.distributed "nccl": one more highest-priority stream) BEFORE the set measured a 14-30 %
+ * slower multi-GPU IVF batch (40-60 % with the priorities of rounds 1-4: profiles/r05_queue_map_rccl.txt, r05_stream_priorities.txt);
+ * created AFTER the set it costs nothing.  So: call this (or create the
  * first index) right after the process selected its GPU and before it initialises any communicator.  No reference counterpart
  * (the reference is single-process CPU code).  After hipDeviceReset() the set is rebuilt by the next call / index. */
 int qadc_device_prepare(int device_id);
