@@ -551,6 +551,37 @@ def reff_substract_from_unique(vector, base_vectors, assign):
     return out
 
 
+def reff_parse_data_filename(filename):
+    """parse_data_filename (quantizers.cpp:58-87) in a child process: 0 = .pq.data, 1 = .opq.data, 101 = its exit(1)."""
+    return int(ref_float().qadc_reff_parse_data_filename(str(filename).encode()))
+
+
+def reff_pq_from_data_file(filename):
+    """The reference's pq_from_data_file factory (quantizers.cpp:27-46, 89-103) -> dict(dim, m, b, is_opq, centroids, rotation)."""
+    L = ref_float()
+    L.qadc_reff_pq_from_data_file.restype = C.c_long
+    dim, m, b, o = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    fn = str(filename).encode()
+    need = L.qadc_reff_pq_from_data_file(fn, C.byref(dim), C.byref(m), C.byref(b), C.byref(o), None, C.c_long(0), None, C.c_long(0))
+    cent = np.zeros(need, np.float32)
+    rot = np.zeros(dim.value * dim.value if o.value else 0, np.float32)
+    L.qadc_reff_pq_from_data_file(fn, C.byref(dim), C.byref(m), C.byref(b), C.byref(o), _p(cent, f32p), C.c_long(need),
+                                  _p(rot, f32p) if o.value else None, C.c_long(len(rot)))
+    return dict(dim=dim.value, m=m.value, b=b.value, is_opq=bool(o.value), centroids=cent,
+                rotation=rot.reshape(dim.value, dim.value) if o.value else None)
+
+
+def reff_select_k_neighbors(dists, k):
+    """The selection half of find_k_neighbors (neighbors.cpp:18-28, 47-71: add_candidates_heaps block by block, then
+    kv_binheap::sort) on given distances [count][neighbor_count] -> (assign [count][k] int32, sorted distances)."""
+    d = np.ascontiguousarray(dists, np.float32)
+    count, nn = d.shape
+    a = np.zeros((count, k), np.int32)
+    sd = np.zeros((count, k), np.float32)
+    ref_float().qadc_reff_select_k_neighbors(_p(d, f32p), count, nn, k, _p(a, i32p), _p(sd, f32p))
+    return a, sd
+
+
 class RefScanner4:
     """The reference's scanner_4, whole (db_query_4.cpp:73-310), over row-major partitions held in memory."""
 

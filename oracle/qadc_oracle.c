@@ -25,6 +25,9 @@
  *       binary's and mode 0 the source's.
  *   - NOT pinned (third-party arithmetic absent from this image): the BLAS-expansion table form and find_k_neighbors
  *       (OpenBLAS cblas_sgemm, distances.hpp:151-183, neighbors.cpp:30-76), cv::kmeans — not restated here at all.
+ *       (The SELECTION half of find_k_neighbors — add_candidates_heaps + kv_binheap::sort on given distances — and the
+ *       .pq.data / .opq.data readers are in oracle/_ref/libqadc_ref_float.so as the reference's own text; the tests use
+ *       those directly, there is no restatement of them here.)
  *
  * Build: strict IEEE (no -ffast-math) so every float expression evaluates exactly as
  * written here.

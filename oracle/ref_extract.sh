@@ -11,7 +11,9 @@
 # before this script returns: no reference text is written under the repo (oracle/_ref/
 # travels to the GPU box and must hold binaries only).  No stand-in header, library or macro
 # is involved — the only lines of the cited structs that are left out are base_pq's two
-# cereal `save`/`load` member templates (quantizers.hpp:170-187), which the path never calls.
+# cereal `save`/`load` member templates (quantizers.hpp:170-187), which the path never calls,
+# and, of struct opq, the two cblas rotate_* overrides and its cereal templates (279-323): the
+# .opq.data reader (quantizers.cpp:40-46) only needs the rotation member and setup_rotation.
 #
 # Each range carries the first 16 hex digits of the sha256 of its text: if the reference
 # drifts by a byte the build stops instead of silently compiling something else.
@@ -44,3 +46,9 @@ cut_range distances.hpp       60   92  1f5eb31e1388ec18  x_distances_b.inc    # 
 cut_range distances.hpp      237  275  6c3a81d8301bbef9  x_distances_c.inc    # centroids_getter, base_centroids_getter
 cut_range distances.hpp      294  311  5e1490bd959a644e  x_distances_d.inc    # compute_dists_single_simd_cg<DSQ>
 cut_range databases.cpp       24   48  4ceddaef15d5b5c3  x_substract.inc      # substract_vectors, substract_vectors_from_unique
+# N3 / N1 (round 5): the .pq.data / .opq.data reader and the selection half of find_k_neighbors
+cut_range quantizers.hpp     248  277  ff18229a99e946df  x_opq_a.inc          # struct opq up to set_rotation (the two cblas rotate_* overrides and the cereal templates, 279-323, are left out: the readers never call them)
+cut_range quantizers.hpp     324  324  aa1d1a63390229c7  x_opq_z.inc          # its closing brace
+cut_range quantizers.cpp      16   46  288255bdaacf4e70  x_pq_files_a.inc     # read_from_fstream, read_pq_from_fstream, pq_from_data_file(name, pq&), opq_from_data_file<>
+cut_range quantizers.cpp      48  103  97a3c88ebb41e778  x_pq_files_b.inc     # invalid_data_filename, pq_type, parse_data_filename, pq_from_data_file(name)
+cut_range neighbors.cpp       15   28  9d06318706e284de  x_neighbors_heaps.inc # BLOCK_VECS / BLOCK_NEIGHS, add_candidates_heaps

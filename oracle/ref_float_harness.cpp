@@ -20,6 +20,12 @@
 //                                                       reduceadd, fmanorm, centroids getters,
 //                                                       compute_dists_single_simd_cg<DSQ>
 //   x_substract        databases.cpp:24-48             substract_vectors(_from_unique)
+//   x_opq_a/z          quantizers.hpp:248-277,324      struct opq (rotation member, setup / set_rotation; without
+//                                                       its cblas rotate_* overrides and cereal templates)
+//   x_pq_files_a/b     quantizers.cpp:16-46,48-103     the .pq.data / .opq.data readers, parse_data_filename,
+//                                                       the pq_from_data_file factory (N3)
+//   x_neighbors_heaps  neighbors.cpp:15-28             add_candidates_heaps: the selection half of
+//                                                       find_k_neighbors (its distance half is cblas_sgemm) (N1)
 // binheap.hpp, simd_layout.hpp, simd_scan.hpp, neighbors.hpp and config.h are included whole.
 //
 // What the harness itself adds: `mem_db`, an in-memory base_db (the reference's flat_db /
@@ -66,6 +72,12 @@
 #include "x_scanner_4.inc"
 #include "x_scanner_simple.inc"
 #include "x_substract.inc"
+#include <fstream>
+#include "x_opq_a.inc"
+#include "x_opq_z.inc"
+#include "x_pq_files_a.inc"
+#include "x_pq_files_b.inc"
+#include "x_neighbors_heaps.inc"
 
 namespace {
 
@@ -281,6 +293,53 @@ int qadc_reff_scanner4_try_query(void* hv, const int* assign, int ma, const floa
         query_metrics m;
         h->sc.query_scan(nullptr, const_cast<int*>(assign), ma, tb.data(), h->M * 16, bh, m);
     });
+}
+
+// ---- N3: .pq.data / .opq.data through the reference's own readers (quantizers.cpp:27-46, 58-103) ----
+// parse_data_filename in a child process: 0 = ".pq.data", 1 = ".opq.data", 101 = the reference's "Invalid data filename" exit(1)
+int qadc_reff_parse_data_filename(const char* filename) {
+    const int rc = run_forked([&] { _exit(parse_data_filename(filename) == type_opq ? 11 : 10); });
+    return rc == 10 ? 0 : rc == 11 ? 1 : 101;
+}
+
+// The factory pq_from_data_file(name) (89-103): header fields, codebooks (cap floats; returns the count needed) and, for an
+// .opq.data file, the rotation (rcap floats).  The name must be valid (probe with qadc_reff_parse_data_filename).
+long qadc_reff_pq_from_data_file(const char* filename, int* dim, int* sq_count, int* sq_bits, int* is_opq, float* centroids,
+                                 long cap, float* rotation, long rcap) {
+    std::unique_ptr<base_pq> pq = pq_from_data_file(filename);
+    *dim = pq->dim;
+    *sq_count = pq->sq_count;
+    *sq_bits = pq->sq_bits;
+    opq* o = dynamic_cast<opq*>(pq.get());
+    *is_opq = o != nullptr;
+    const long need = pq->all_centroids_dim();
+    if (centroids && cap >= need) std::memcpy(centroids, pq->centroids_flat.get(), sizeof(float) * need);
+    if (o && rotation && rcap >= static_cast<long>(pq->dim) * pq->dim)
+        std::memcpy(rotation, o->rotation.get(), sizeof(float) * pq->dim * pq->dim);
+    return need;
+}
+
+// ---- N1: the selection half of find_k_neighbors (neighbors.cpp:30-76) — given the distances of `count` vectors to
+// `neighbor_count` neighbours (row-major), the k nearest per vector in the order find_k_neighbors writes them: its own
+// add_candidates_heaps (18-28) fed block by block as its loop does (BLOCK_VECS x BLOCK_NEIGHS, 47-65), then
+// kv_binheap::sort (67-71).  The distance half (dists_func = cblas_sgemm expansion, 42, 58-59) is not here: no cblas.
+void qadc_reff_select_k_neighbors(const float* dists, int count, int neighbor_count, int k, int* assign, float* sorted) {
+    std::unique_ptr<kv_binheap<int, float>[]> heaps(new kv_binheap<int, float>[BLOCK_VECS]);
+    for (int h = 0; h < BLOCK_VECS; ++h) heaps[h].reset_capacity(k);
+    std::vector<float> block(static_cast<size_t>(BLOCK_VECS) * BLOCK_NEIGHS);
+    for (int v0 = 0; v0 < count; v0 += BLOCK_VECS) {
+        const int bv = std::min(BLOCK_VECS, count - v0);
+        for (int v = 0; v < bv; ++v) heaps[v].reset();
+        for (int n0 = 0; n0 < neighbor_count; n0 += BLOCK_NEIGHS) {
+            const int bn = std::min(BLOCK_NEIGHS, neighbor_count - n0);
+            for (int v = 0; v < bv; ++v)
+                std::memcpy(block.data() + static_cast<size_t>(v) * bn, dists + static_cast<size_t>(v0 + v) * neighbor_count + n0,
+                            sizeof(float) * bn);
+            add_candidates_heaps(block.data(), heaps.get(), bv, bn, n0);
+        }
+        for (int v = 0; v < bv; ++v)
+            heaps[v].sort(assign + static_cast<size_t>(v0 + v) * k, sorted + static_cast<size_t>(v0 + v) * k);
+    }
 }
 
 }  // extern "C"

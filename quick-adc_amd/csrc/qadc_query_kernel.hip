@@ -92,13 +92,22 @@ __device__ __forceinline__ void q_lds_barrier() {
 // [dword 2][dword 3], address x*256 + g*64 + (lane & 15)*4 + j — is 64 KiB instead of 128, so TWO workgroups share a CU
 // (32 waves instead of 16 to hide the walk's latencies behind) at the price of a 2-way bank conflict on every lookup
 // (lanes l and l + 16 of a 32-lane group share a replica): the walk is latency / issue bound, the LDS pipe 30 % busy.
+// Round 5 (QADC_Q32_SWIZZLE): the conflict is a property of the ORDER in which a lane takes its code's dwords, not of the image.
+// Lanes with bit 4 set (h = 1) process the dwords as 1, 0, 3, 2: at the lookup (w, k) they read group w ^ 1 — so the 32 lanes of a
+// pass touch banks (w * 16 + l) and ((w ^ 1) * 16 + l), l = 0..15: 32 distinct banks, no conflict, same 64 KiB image.  Price:
+// four v_cndmask per code (the dword swap); the address bytes come from two lane constants, (lane & 15) * 4 + 64 h for even w
+// and (lane & 15) * 4 + 64 (1 - h) for odd w, with the immediate offset (w & ~1) * 64 + k.
 #ifndef QADC_Q32_REPL16
 #define QADC_Q32_REPL16 1
+#endif
+#ifndef QADC_Q32_SWIZZLE
+#define QADC_Q32_SWIZZLE 1
 #endif
 template <int M>
 struct QCfg {
     static constexpr int CS = M / 2, DW = M / 8, CPL = 16 / CS;
     static constexpr bool R16 = M == 32 && QADC_Q32_REPL16 != 0;  // 16 replicas per dword, all four dwords in one 64 KiB region
+    static constexpr bool SWZ = R16 && QADC_Q32_SWIZZLE != 0;    // the two 16-lane halves of a pass read different dword groups
     static constexpr int TABLE_BYTES = R16 ? 65536 : (M / 16) * 65536;
     static constexpr int WTAB_BYTES = kQWaves * M * 16 * 4;      // float[16 waves][M*16] (pre-scan)
     static constexpr int FCAP = (TABLE_BYTES - WTAB_BYTES) / 4;  // pre-scan values kept in LDS: 12288 / 24576
@@ -120,18 +129,34 @@ __device__ __forceinline__ uint32_t q_pair_sum(const uint32_t* d, uint32_t lane_
     // all M/2 addresses first, then all M/2 reads, then the adds: the reads of a code (and, unrolled, of the codes
     // around it) are in flight together instead of waiting out one LDS latency per pair
     uint32_t a[M / 2], v[M / 2];
-    constexpr bool R16 = QCfg<M>::R16;                           // (then lane_lo = (lane & 15) * 4 and every dword lives in region 0)
+    constexpr bool R16 = QCfg<M>::R16;                           // (then every dword lives in region 0)
+    constexpr bool SWZ = QCfg<M>::SWZ;
+    uint32_t e[M / 8];
+#pragma unroll
+    for (int w = 0; w < M / 8; ++w) e[w] = d[w];
+    if constexpr (SWZ) {
+        // lanes 16..31 / 48..63 take their code's dwords in the order 1, 0, 3, 2 (integer adds: any order gives the sum), and
+        // lane_lo / lane_hi carry (lane & 15) * 4 + 64 h / + 64 (1 - h): in every 32-lane pass of a lookup the two halves read
+        // DIFFERENT dword groups of the rows — 32 distinct banks instead of 16 banks twice
+        const bool h = (lane_lo & 64u) != 0;
+#pragma unroll
+        for (int w = 0; w < M / 8; w += 2) {
+            e[w] = h ? d[w + 1] : d[w];
+            e[w + 1] = h ? d[w] : d[w + 1];
+        }
+    }
 #pragma unroll
     for (int w = 0; w < M / 8; ++w) {
-        const uint32_t lo = (!R16 && (w >> 1)) ? lane_hi : lane_lo;
+        const uint32_t lo = SWZ ? ((w & 1) ? lane_hi : lane_lo) : (!R16 && (w >> 1)) ? lane_hi : lane_lo;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[w * 4 + k] = __builtin_amdgcn_perm(d[w], lo, 0x0c020000u | ((4u + k) << 8));
+        for (int k = 0; k < 4; ++k) a[w * 4 + k] = __builtin_amdgcn_perm(e[w], lo, 0x0c020000u | ((4u + k) << 8));
     }
 #pragma unroll
     for (int w = 0; w < M / 8; ++w)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            v[w * 4 + k] = *reinterpret_cast<q_lds_bytes_t>(static_cast<uintptr_t>(a[w * 4 + k] + (R16 ? w * 64 : (w & 1) * 128) + k));
+            v[w * 4 + k] = *reinterpret_cast<q_lds_bytes_t>(
+                static_cast<uintptr_t>(a[w * 4 + k] + (SWZ ? (w & ~1) * 64 : R16 ? w * 64 : (w & 1) * 128) + k));
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < M / 2; ++i) s += v[i];
@@ -988,7 +1013,8 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
             *reinterpret_cast<uint4*>(qsmem + ((size_t)k * kQWG + tid) * 16) = make_uint4(wk, wk, wk, wk);
         }
     };
-    const uint32_t lane_lo = C::R16 ? (tid & 15u) * 4u : (tid & 31u) * 4u, lane_hi = lane_lo | 0x10000u;
+    const uint32_t lane_lo = C::SWZ ? (tid & 15u) * 4u + ((tid >> 4) & 1u) * 64u : C::R16 ? (tid & 15u) * 4u : (tid & 31u) * 4u;
+    const uint32_t lane_hi = C::SWZ ? (tid & 15u) * 4u + (1u - ((tid >> 4) & 1u)) * 64u : lane_lo | 0x10000u;
     if (tid < 256) misc[tid] = 0;                                // both histograms
     if (tid == 0) { s_ccount = 0; s_hreps = 0; }
     // ---- how the query's scan order is shared by the G workgroups of the query (G = 1: everything is "mine") ----

@@ -103,6 +103,55 @@ def _need_ref_io(po):
         pytest.skip("oracle/_ref/libqadc_ref_io.so not built (no /root/reference here and no prebuilt copy)")
 
 
+def test_quantizer_data_files_against_the_reference_readers(po, tmp_path):
+    """N3, .pq.data / .opq.data pinned: files written by the numpy writer (convert-quantizer.py's layout) and written back by
+    host/qadc_io.hpp's pq_to_data_file are read by the REFERENCE's own pq_from_data_file factory (quantizers.cpp:27-46,
+    89-103, compiled from line ranges into oracle/_ref/libqadc_ref_float.so) to the same header, codebooks and rotation bit
+    for bit; and parse_data_filename (58-87) accepts / refuses exactly the names our reader does."""
+    if not po.have_ref_float():
+        pytest.skip("oracle/_ref/libqadc_ref_float.so not built")
+    build_tool()
+    rng = np.random.default_rng(11)
+    n = 0
+    for m, k, sq_dim, opq in ((16, 16, 8, False), (16, 16, 8, True), (32, 16, 3, True), (8, 256, 16, False), (32, 16, 4, False),
+                              (16, 16, 60, True)):
+        cb = rng.normal(size=(m, k, sq_dim)).astype(np.float32)
+        dim = m * sq_dim
+        rot = rng.normal(size=(dim, dim)).astype(np.float32) if opq else None
+        name = "q%d.%s.data" % (n, "opq" if opq else "pq")
+        src, dst = str(tmp_path / name), str(tmp_path / ("out." + name))
+        iof.write_pq_data(src, cb, rot)
+        rc, out, err = run_tool("pq", src, dst)
+        assert rc == 0 and out == "pq dim=%d m=%d b=%d opq=%d" % (dim, m, int(np.log2(k)), opq), err
+        for f in (src, dst):
+            got = po.reff_pq_from_data_file(f)
+            assert (got["dim"], got["m"], got["b"], got["is_opq"]) == (dim, m, int(np.log2(k)), opq), f
+            assert np.array_equal(got["centroids"].view(np.uint32), cb.reshape(-1).view(np.uint32)), f
+            if opq:
+                assert np.array_equal(got["rotation"].view(np.uint32), rot.view(np.uint32)), f
+        n += 1
+    # names: the last extension must be ".data", the one before it ".pq" or ".opq" (case-sensitive; directories are not looked at)
+    cb = rng.normal(size=(16, 16, 2)).astype(np.float32)
+    rot = rng.normal(size=(32, 32)).astype(np.float32)
+    for name, want in (("a.pq.data", 0), ("a.opq.data", 1), ("a.b.c.opq.data", 1), (".pq.data", 0), ("a.data", 101), ("apq.data", 101),
+                       ("a.pq.dat", 101), ("a.pq.data.bak", 101), ("noext", 101), ("a.PQ.data", 101), ("a.opq.pq.data", 0),
+                       ("a.pq.opq.data", 1), ("a..data", 101)):
+        f = str(tmp_path / name)
+        iof.write_pq_data(f, cb, rot if want == 1 else None)
+        assert po.reff_parse_data_filename(f) == want, name
+        rc, out, err = run_tool("pq", f, str(tmp_path / "o.pq.data" if want != 1 else tmp_path / "o.opq.data"))
+        if want == 101:
+            assert rc == 1 and "Invalid data filename: " + f in err and "Filename must end with: .pq.data or .opq.data" in err, name
+        else:
+            assert rc == 0 and out == "pq dim=32 m=16 b=4 opq=%d" % want, (name, err)
+    # (a short file: the reference's fstream reads leave the tail of the codebooks uninitialised without a word,
+    # quantizers.cpp:17-33 checks nothing; ours refuses the file — stricter on purpose, stated in DESIGN.md section 8)
+    short = str(tmp_path / "short.pq.data")
+    open(short, "wb").write(open(str(tmp_path / "a.pq.data"), "rb").read()[:100])
+    rc, _, err = run_tool("pq", short, str(tmp_path / "o2.pq.data"))
+    assert rc == 1 and "Invalid quantizer file: " + short in err
+
+
 def test_vecs_files_against_the_reference_reader_and_writer(po, tmp_path):
     """host/qadc_io.hpp's vecs side pinned to the reference's own vector_io.cpp / vector_io.hpp compiled
     into oracle/_ref (vector_io.cpp:40-91, vector_io.hpp:69-166): files written by the REFERENCE's save_vectors are read by

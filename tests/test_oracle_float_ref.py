@@ -257,6 +257,42 @@ def test_pack4_and_residuals_match_the_reference(po):
     assert np.array_equal(po.reff_substract_from_unique(v, base, a), (v[None, :] - base[a]).astype(np.float32))
 
 
+def test_coarse_selection_rule_against_the_reference_heaps(po):
+    """N1, the selection half of find_k_neighbors (neighbors.cpp:18-28, 47-71: add_candidates_heaps block by block, then
+    kv_binheap::sort — compiled from the reference's text; the distance half is cblas_sgemm and is not).  The product (device
+    coarse_select kernels, host/query_driver.hpp) and every test model select `the ma smallest by (distance, index)`:
+    on distances WITHOUT exact ties among the kept and the boundary values that is what the reference's heaps produce, entry for
+    entry, at the shapes of configs[2] / [4] and at ragged block sizes.  WITH exact float ties the reference's choice depends on
+    its heap's history (which of several equal maxima sits at the root when a smaller value arrives) and on std::sort's order of
+    equal keys: only the multiset of kept DISTANCES is the same — stated as a known difference in DESIGN.md section 8 (N1)."""
+    _need_ref_float(po)
+    rng = np.random.default_rng(77)
+
+    def rule(d, k):
+        return np.stack([np.lexsort((np.arange(d.shape[1]), row))[:k] for row in d]).astype(np.int32)
+
+    for count, K, k in ((40, 4096, 32), (24, 16384, 64), (300, 300, 8), (257, 256, 1), (5, 1000, 16), (3, 513, 64), (2, 70, 64)):
+        base = (np.arange(K) * 0.37 + rng.random(K) * 0.2).astype(np.float32)     # K distinct values ...
+        assert len(np.unique(base)) == K
+        d = np.stack([rng.permutation(base) for _ in range(count)])               # ... in another order for every vector
+        a, sd = po.reff_select_k_neighbors(d, k)
+        want = rule(d, k)
+        assert np.array_equal(a, want), (count, K, k)
+        assert np.array_equal(sd, np.take_along_axis(d, want, 1))
+        # ties only ABOVE the kept values do not matter either
+        d2 = d.copy()
+        kth = np.sort(d2, 1)[:, k - 1:k]
+        d2[d2 > kth] = np.floor(d2[d2 > kth] / 16.0) * 16.0 + 16.0 + kth.max()
+        a2, _ = po.reff_select_k_neighbors(d2, k)
+        assert np.array_equal(a2, want), (count, K, k)
+    # exact ties among the kept values: same distances, not (in general) the same entries
+    d = np.floor(rng.random((50, 4096)) * 300).astype(np.float32)
+    a, sd = po.reff_select_k_neighbors(d, 32)
+    want = rule(d, 32)
+    assert np.array_equal(sd, np.take_along_axis(d, want, 1))
+    assert not np.array_equal(a, want)
+
+
 def test_extraction_refuses_a_drifted_reference(tmp_path):
     """oracle/ref_extract.sh carries the sha256 of every line range it cuts out of the reference: one changed byte inside a
     range stops the build instead of silently compiling something else; the untouched reference passes."""
@@ -270,10 +306,11 @@ def test_extraction_refuses_a_drifted_reference(tmp_path):
     out = tmp_path / "out"
     out.mkdir()
     assert subprocess.run([script, ref, str(out)], stderr=subprocess.PIPE).returncode == 0
-    assert sorted(os.listdir(out))[0].startswith("x_") and len(os.listdir(out)) == 12
+    assert sorted(os.listdir(out))[0].startswith("x_") and len(os.listdir(out)) == 17
     drift = tmp_path / "ref"
     drift.mkdir()
-    for f in ("quantizers.hpp", "databases.hpp", "query_common.hpp", "db_query_4.cpp", "db_query.cpp", "distances.hpp", "databases.cpp"):
+    for f in ("quantizers.hpp", "databases.hpp", "query_common.hpp", "db_query_4.cpp", "db_query.cpp", "distances.hpp", "databases.cpp", "quantizers.cpp",
+              "neighbors.cpp"):
         shutil.copy(os.path.join(ref, f), drift / f)
     lines = open(drift / "query_common.hpp").read().split("\n")
     lines[69] = lines[69] + " "                                    # one blank appended to line 70 (inside scan_4's range, 59-143)
