@@ -67,6 +67,17 @@ int enqueue_merge_now(qadc_index* idx, Slot& s) {
         ds.h_out_mapped = ds.h_out.p;
     }
     if (!ds.ev_done) HIPCHECK(hipEventCreateWithFlags(&ds.ev_done, hipEventDisableTiming));
+    if (!ds.ev_gathered) HIPCHECK(hipEventCreateWithFlags(&ds.ev_gathered, hipEventDisableTiming));
+    const bool sharded = d.shard_replay && world > 1;
+    const int per = (nq + world - 1) / world;
+    const size_t sw = share_words(per, R);
+    if (sharded) {
+        // everything that can fail for lack of memory is done BEFORE the batch's first collective: between the stream gather and
+        // the share gather only launches and event records remain, so a rank cannot drop out between two collectives its peers enter
+        HIPCHECK(ds.d_share.ensure(sw));
+        HIPCHECK(ds.d_shares.ensure(sw * world));
+        if (!ds.ev_replayed) HIPCHECK(hipEventCreateWithFlags(&ds.ev_replayed, hipEventDisableTiming));
+    }
     hipStream_t st = d.stream;
     HIPCHECK(hipStreamWaitEvent(st, ds.ev_ready, 0));
     if (s.wgq) {
@@ -84,17 +95,11 @@ int enqueue_merge_now(qadc_index* idx, Slot& s) {
     if (d.gather(ds.d_block.p, ds.d_gathered.p, bw, st, gerr)) return fail(QADC_E_HIP, gerr);
     // the collectives keep `st` to themselves (the next batch's front gather is issued right behind this one); the merge's
     // compute — a millisecond of replay latency — goes to a stream of its own
-    if (!ds.ev_gathered) HIPCHECK(hipEventCreateWithFlags(&ds.ev_gathered, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(ds.ev_gathered, st));
     hipStream_t ms = d.merge_stream[ds.seq % kMergeStreams] ? d.merge_stream[ds.seq % kMergeStreams] : st;
     if (ms != st) HIPCHECK(hipStreamWaitEvent(ms, ds.ev_gathered, 0));
     uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ds.d_out + sizeof(uint64_t) * (size_t)R * nq);
-    if (d.shard_replay && world > 1) {
-        const int per = (nq + world - 1) / world;
-        const size_t sw = share_words(per, R);
-        HIPCHECK(ds.d_share.ensure(sw));
-        HIPCHECK(ds.d_shares.ensure(sw * world));
-        if (!ds.ev_replayed) HIPCHECK(hipEventCreateWithFlags(&ds.ev_replayed, hipEventDisableTiming));
+    if (sharded) {
         // (a rank past the last query of a ragged batch replays fewer; the unpack never reads those heaps)
         HIPCHECK(launch_dist_merge(ds.d_gathered.p, bw, world, nq, s.ma, (uint32_t)R, ds.d_moff.p, ds.d_mcnt.p, ds.d_mcnt.p + nq,
                                    ds.d_merged.p, ds.d_share.p, reinterpret_cast<uint32_t*>(ds.d_share.p + (size_t)per * R), ms,

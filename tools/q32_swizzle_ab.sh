@@ -32,7 +32,7 @@ lib = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for f in glob.glob('/tmp/swz_%s/**/*counter_collection.csv' % lib, recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0][:60]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void qadc::', '').split('(')[0][:60]
         acc[k][r['Counter_Name']] += float(r['Counter_Value']); 
         if r['Counter_Name'] == 'GRBM_GUI_ACTIVE': n[k] += 1
 for k, c in acc.items():
