@@ -375,12 +375,21 @@ __device__ __forceinline__ uint32_t prefix_bound_wave(const QueryState* qs, int 
     return min((uint32_t)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(reached)), 127u);
 }
 
+#ifndef QADC_BYTE0_PLAIN_AND
+#define QADC_BYTE0_PLAIN_AND 0   // (tried in round 5, same-box A/B: nothing at the IVF shapes, +0.6 % on the flat batched step: profiles/r05_byte0_and_ab.txt)
+#endif
 // (byte K of d) & mask in ONE VALU instruction (sub-dword operand select); the compiler finds this form for only a
 // quarter of the lookups by itself and spends a shift + and on the others
 template <int K>
 __device__ __forceinline__ uint32_t byte_and(uint32_t d, uint32_t mask) {
     uint32_t r;
+#if QADC_BYTE0_PLAIN_AND
+    // byte 0 needs no operand select (the mask is below 0x100): a plain v_and_b32 issues at FULL rate on gfx950, every SDWA form
+    // at half (tools/microbench/valu_rate.hip: 1.2 vs 1.9 ns per wave-instruction per SIMD) — a quarter of the extracts
+    if (K == 0) asm("v_and_b32_e32 %0, %1, %2" : "=v"(r) : "v"(mask), "v"(d));
+#else
     if (K == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(mask), "v"(d));
+#endif
     if (K == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(mask), "v"(d));
     if (K == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(mask), "v"(d));
     if (K == 3) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(mask), "v"(d));
