@@ -235,9 +235,11 @@ int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_
  *   flat_db::assign_compute_residuals   (databases.hpp:93-101)
  *   opq::rotate_multiple_vectors        (quantizers.hpp:289-301)
  *   compute_dists_single_simd_cg        (distances.hpp:294-311)
- * followed by the same chain as qadc_query_scan.  Float parity of these feeders against the reference
- * is unpinned (its versions go through OpenBLAS / AVX kernels); they are bit-exact against
- * quick-adc_amd/host/query_driver.hpp, which evaluates the same loops on the host.
+ * followed by the same chain as qadc_query_scan.  Pinned to the reference's own code: the direct
+ * table form (fmanorm as compiled), the residuals, and the SELECTION of the ma nearest — find_k_neighbors' heaps, exact
+ * distance ties included (what the heap's history and kv_binheap::sort leave, neighbors.cpp:18-28, 47-71).  Restated,
+ * unpinned: the distances under the selection and the BLAS-expansion table form (cblas_sgemm in the reference: sequential
+ * float sums here); bit-exact against quick-adc_amd/host/query_driver.hpp, which evaluates the same loops on the host.
  * ------------------------------------------------------------------------------------------- */
 /* codebooks [M][16][dim/M] (base_pq::centroids_flat order). */
 int qadc_index_set_pq(qadc_index* idx, int dim, const float* codebooks);

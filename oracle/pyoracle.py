@@ -551,6 +551,19 @@ def reff_substract_from_unique(vector, base_vectors, assign):
     return out
 
 
+def select_k_neighbors(dists, k):
+    """The oracle's restatement of find_k_neighbors' selection half (orc_select_k_neighbors; pinned to the reference's own
+    heaps, exact ties included) -> (assign [count][k] int32, sorted distances [count][k])."""
+    d = np.ascontiguousarray(dists, np.float32)
+    if d.ndim == 1:
+        d = d[None, :]
+    count, nn = d.shape
+    a = np.zeros((count, k), np.int32)
+    sd = np.zeros((count, k), np.float32)
+    lib().orc_select_k_neighbors(_p(d, f32p), C.c_long(count), nn, k, _p(a, i32p), _p(sd, f32p))
+    return a, sd
+
+
 def reff_parse_data_filename(filename):
     """parse_data_filename (quantizers.cpp:58-87) in a child process: 0 = .pq.data, 1 = .opq.data, 101 = its exit(1)."""
     return int(ref_float().qadc_reff_parse_data_filename(str(filename).encode()))

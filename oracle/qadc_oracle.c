@@ -25,9 +25,9 @@
  *       binary's and mode 0 the source's.
  *   - NOT pinned (third-party arithmetic absent from this image): the BLAS-expansion table form and find_k_neighbors
  *       (OpenBLAS cblas_sgemm, distances.hpp:151-183, neighbors.cpp:30-76), cv::kmeans — not restated here at all.
- *       (The SELECTION half of find_k_neighbors — add_candidates_heaps + kv_binheap::sort on given distances — and the
- *       .pq.data / .opq.data readers are in oracle/_ref/libqadc_ref_float.so as the reference's own text; the tests use
- *       those directly, there is no restatement of them here.)
+ *       (The SELECTION half of find_k_neighbors — add_candidates_heaps + kv_binheap::sort on given distances — IS pinned:
+ *       orc_select_k_neighbors below against the reference's own text in oracle/_ref/libqadc_ref_float.so, exact ties
+ *       included.  The .pq.data / .opq.data readers are in that library too; the tests use them directly.)
  *
  * Build: strict IEEE (no -ffast-math) so every float expression evaluates exactly as
  * written here.
@@ -102,8 +102,8 @@ void orc_heap_replay_f32(long n, const uint32_t* keys, const float* vals, int R,
  * (heapsort below it), then one final insertion sort.  Restated here step for step; pinned by the
  * reference build's own sort_keys output on every golden case (tests/test_oracle_golden.py).
  * ------------------------------------------------------------------------------------------ */
-typedef struct { const int8_t* v; } orc_sortctx;
-#define ORC_LESS(c, a, b) ((c)->v[(a)] < (c)->v[(b)])
+typedef struct { const int8_t* v; const float* f; } orc_sortctx;      /* int8 heap values, or float ones (f != NULL) */
+#define ORC_LESS(c, a, b) ((c)->f ? (c)->f[(a)] < (c)->f[(b)] : (c)->v[(a)] < (c)->v[(b)])
 
 static void orc_ss_swap(int* a, int* b) { int t = *a; *a = *b; *b = t; }
 
@@ -209,23 +209,80 @@ static void orc_ss_insertion_sort(const orc_sortctx* c, int* first, int* last) {
     }
 }
 
+static void orc_ss_std_sort(const orc_sortctx* c, int* perm, int size) {       /* std::sort(perm, perm + size, comp) */
+    if (size <= 0) return;
+    long lg = 0;
+    for (long n = size; n > 1; n >>= 1) ++lg;                                 /* std::__lg */
+    orc_ss_introsort_loop(c, perm, perm + size, lg * 2);
+    if (size > 16) {                                                          /* __final_insertion_sort */
+        orc_ss_insertion_sort(c, perm, perm + 16);
+        for (int* i = perm + 16; i != perm + size; ++i) orc_ss_linear_insert(c, i);
+    } else {
+        orc_ss_insertion_sort(c, perm, perm + size);
+    }
+}
+
 /* out_keys[i] = heap_keys[perm[i]] for the std::sort-ed permutation of a heap array of `size` entries. */
 void orc_sort_keys_i8(int size, const uint32_t* heap_keys, const int8_t* heap_vals, uint32_t* out_keys) {
     if (size <= 0) return;
     int* perm = (int*)malloc(sizeof(int) * (size_t)size);
     for (int i = 0; i < size; ++i) perm[i] = i;
-    const orc_sortctx c = { heap_vals };
-    long lg = 0;
-    for (long n = size; n > 1; n >>= 1) ++lg;                                 /* std::__lg */
-    orc_ss_introsort_loop(&c, perm, perm + size, lg * 2);
-    if (size > 16) {                                                          /* __final_insertion_sort */
-        orc_ss_insertion_sort(&c, perm, perm + 16);
-        for (int* i = perm + 16; i != perm + size; ++i) orc_ss_linear_insert(&c, i);
-    } else {
-        orc_ss_insertion_sort(&c, perm, perm + size);
-    }
+    const orc_sortctx c = { heap_vals, NULL };
+    orc_ss_std_sort(&c, perm, size);
     for (int i = 0; i < size; ++i) out_keys[i] = heap_keys[perm[i]];
     free(perm);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The SELECTION half of find_k_neighbors — neighbors.cpp:18-28 (add_candidates_heaps), 47-71: per vector a
+ * kv_binheap<int, float> of capacity k takes the neighbour distances in index order (binheap.hpp:75-116, the same push
+ * as the int8 heap's), then kv_binheap::sort (118-127) writes keys and values in std::sort's order of the permutation.
+ * The distances are GIVEN (the reference's come from cblas_sgemm).  Pinned to the reference's own text
+ * (oracle/_ref/libqadc_ref_float.so: qadc_reff_select_k_neighbors) by tests/test_oracle_float_ref.py, exact ties included.
+ * ---------------------------------------------------------------------------------------- */
+void orc_select_k_neighbors(const float* dists, long count, int neighbor_count, int k, int32_t* assign, float* sorted) {
+    float* hv = (float*)malloc(sizeof(float) * (size_t)(k > 0 ? k : 1));
+    int* hk = (int*)malloc(sizeof(int) * (size_t)(k > 0 ? k : 1));
+    int* perm = (int*)malloc(sizeof(int) * (size_t)(k > 0 ? k : 1));
+    for (long v = 0; v < count; ++v) {
+        const float* d = dists + (size_t)v * neighbor_count;
+        int size = 0;
+        for (int n = 0; n < neighbor_count; ++n) {
+            const float value = d[n];
+            if (size != k) {                                                  /* binheap.hpp:78-90 */
+                int index = size++;
+                hv[index] = value; hk[index] = n;
+                int parent = (index - 1) / 2;
+                while (index != 0 && hv[index] > hv[parent]) {
+                    const float tv = hv[index]; hv[index] = hv[parent]; hv[parent] = tv;
+                    const int tk = hk[index]; hk[index] = hk[parent]; hk[parent] = tk;
+                    index = parent;
+                    parent = (index - 1) / 2;
+                }
+            } else if (value < hv[0]) {                                       /* 93-115 */
+                int index = 0;
+                hv[0] = value; hk[0] = n;
+                for (;;) {
+                    const int left = 2 * index + 1, right = 2 * index + 2;
+                    if (left >= size) break;
+                    int largest = left;
+                    if (right < size && hv[right] > hv[left]) largest = right;
+                    if (hv[largest] <= hv[index]) break;
+                    const float tv = hv[index]; hv[index] = hv[largest]; hv[largest] = tv;
+                    const int tk = hk[index]; hk[index] = hk[largest]; hk[largest] = tk;
+                    index = largest;
+                }
+            }
+        }
+        for (int i = 0; i < size; ++i) perm[i] = i;
+        const orc_sortctx c = { NULL, hv };
+        orc_ss_std_sort(&c, perm, size);
+        for (int i = 0; i < size; ++i) {
+            assign[(size_t)v * k + i] = hk[perm[i]];
+            if (sorted) sorted[(size_t)v * k + i] = hv[perm[i]];
+        }
+    }
+    free(hv); free(hk); free(perm);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -1825,6 +1825,195 @@ void launch_ivf_front_items(const int32_t* d_assign, const PartDesc* d_parts, in
 // Plain sequential float arithmetic (no FMA contraction), so a host evaluation of the same loops
 // (host/query_driver.hpp) gives identical bits.
 // ---------------------------------------------------------------------------------------------
+// ---- find_k_neighbors' selection WITH exact float ties (neighbors.cpp:18-28, 47-71; binheap.hpp:75-127) ----
+// The select kernels below pick "the ma smallest by (distance, index)".  That IS what the reference's heaps leave whenever no two
+// of the kept-or-boundary distances are exactly equal (pinned: tests/test_oracle_float_ref.py).  With exact ties the reference's
+// result depends on its heap's history — a kv_binheap<int, float> of capacity ma takes the K distances in index order (push: a
+// full heap accepts only values strictly below its root, the root sinks preferring the LEFT child on equal children) — and on the
+// order std::sort leaves equal keys in (libstdc++ introsort on the permutation 0..ma-1 of the heap array, comparator
+// value[a] < value[b]: median-of-3 quicksort loop down to ranges of 16, depth limit 2 floor(log2 n) with heapsort below it, one
+// final insertion sort — GCC 11.4 bits/stl_algo.h, the same restatement as the oracle's sort_keys).  A select kernel that SEES a
+// tie (two equal values among its ma, or a value equal to the ma-th outside them) calls this for its query: wave 0, the heap and
+// the permutation in LDS, lane 0 doing the sequential part, the other lanes only the loads and the pre-filter (a chunk of 64
+// distances none of which is below the root is skipped with one ballot).  ma <= 256.
+struct ExactSel {
+    float* hv;      // [256] heap values
+    int* hk;        // [256] heap keys
+    int* perm;      // [256] permutation sorted by std::sort's algorithm; then [72]: the quicksort loop's pending ranges
+};
+constexpr int kExactSelInts = 256 + 72;     // (everything lives in LDS: a private array would give the select kernels a scratch segment)
+
+__device__ __forceinline__ bool xs_less(const ExactSel& x, int a, int b) { return x.hv[a] < x.hv[b]; }
+
+__device__ __forceinline__ void xs_push_heap(const ExactSel& x, int* first, int hole, int top, int value) {      // std::__push_heap
+    int parent = (hole - 1) / 2;
+    while (hole > top && xs_less(x, first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+
+__device__ __forceinline__ void xs_adjust_heap(const ExactSel& x, int* first, int hole, int len, int value) {    // std::__adjust_heap
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (xs_less(x, first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    xs_push_heap(x, first, hole, top, value);
+}
+
+__device__ __forceinline__ void xs_heapsort(const ExactSel& x, int* first, int* last) {                          // std::__partial_sort(first, last, last)
+    const int len = (int)(last - first);
+    if (len >= 2)
+        for (int parent = (len - 2) / 2;; --parent) {
+            xs_adjust_heap(x, first, parent, len, first[parent]);
+            if (parent == 0) break;
+        }
+    while (last - first > 1) {
+        --last;
+        const int value = *last;
+        *last = *first;
+        xs_adjust_heap(x, first, 0, (int)(last - first), value);
+    }
+}
+
+__device__ __forceinline__ void xs_linear_insert(const ExactSel& x, int* last) {                                 // std::__unguarded_linear_insert
+    const int val = *last;
+    int* next = last - 1;
+    while (xs_less(x, val, *next)) {
+        *last = *next;
+        last = next;
+        --next;
+    }
+    *last = val;
+}
+
+__device__ __forceinline__ void xs_insertion_sort(const ExactSel& x, int* first, int* last) {                    // std::__insertion_sort
+    if (first == last) return;
+    for (int* i = first + 1; i != last; ++i) {
+        if (xs_less(x, *i, *first)) {
+            const int val = *i;
+            for (int* p = i; p != first; --p) *p = *(p - 1);                                      // std::move_backward
+            *first = val;
+        } else {
+            xs_linear_insert(x, i);
+        }
+    }
+}
+
+__device__ __forceinline__ void xs_std_sort(const ExactSel& x, int n) {
+    int* perm = x.perm;
+    int lg = 0;
+    for (int m = n; m > 1; m >>= 1) ++lg;
+    // std::__introsort_loop, its tail recursion on [cut, last) as an explicit stack (at most 2 lg + 1 ranges deep)
+    int* st_first = x.perm + 256; int* st_last = st_first + 24; int* st_depth = st_last + 24;
+    int sp = 0;
+    st_first[0] = 0; st_last[0] = n; st_depth[0] = 2 * lg; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = st_first[sp], last = st_last[sp], depth = st_depth[sp];
+        // (the recursion handles [cut, last) FIRST and then continues with [first, cut): ranges are disjoint, so the order in which
+        // they are processed does not change the result; here the right part is stacked and the left one continues)
+        while (last - first > 16) {
+            if (depth == 0) {
+                xs_heapsort(x, perm + first, perm + last);
+                break;
+            }
+            --depth;
+            const int mid = first + (last - first) / 2;
+            {                                                                                     // std::__move_median_to_first(first, first + 1, mid, last - 1)
+                int* r = perm + first; int* a = perm + first + 1; int* b = perm + mid; int* c = perm + last - 1;
+                int* pick;
+                if (xs_less(x, *a, *b)) pick = xs_less(x, *b, *c) ? b : (xs_less(x, *a, *c) ? c : a);
+                else pick = xs_less(x, *a, *c) ? a : (xs_less(x, *b, *c) ? c : b);
+                const int t = *r; *r = *pick; *pick = t;
+            }
+            int lo = first + 1, hi = last;                                                       // std::__unguarded_partition(first + 1, last, first)
+            for (;;) {
+                while (xs_less(x, perm[lo], perm[first])) ++lo;
+                --hi;
+                while (xs_less(x, perm[first], perm[hi])) --hi;
+                if (!(lo < hi)) break;
+                const int t = perm[lo]; perm[lo] = perm[hi]; perm[hi] = t;
+                ++lo;
+            }
+            if (sp < 24) { st_first[sp] = lo; st_last[sp] = last; st_depth[sp] = depth; ++sp; }
+            last = lo;
+        }
+    }
+    if (n > 16) {                                                                                 // std::__final_insertion_sort
+        xs_insertion_sort(x, perm, perm + 16);
+        for (int* i = perm + 16; i != perm + n; ++i) xs_linear_insert(x, i);
+    } else {
+        xs_insertion_sort(x, perm, perm + n);
+    }
+}
+
+// called by every lane of wave 0 (lane = 0..63); dq = the query's K distances in global memory
+__device__ __forceinline__ void coarse_exact_select(const float* __restrict__ dq, int K, int ma, int32_t* __restrict__ out,
+                                                 float* hv, int* hk, int* perm, uint32_t lane) {
+    const ExactSel x{hv, hk, perm};
+    int size = 0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + (int)lane;
+        const float v = k < K ? dq[k] : 0.0f;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(k < K && (size < ma || v < hv[0]));
+        while (todo) {
+            const int j = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float vj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), j));
+            if (lane == 0) {                                                                      // kv_binheap::push (binheap.hpp:75-116)
+                if (size != ma) {
+                    int i = size;
+                    hv[i] = vj; hk[i] = k0 + j;
+                    int parent = (i - 1) / 2;
+                    while (i != 0 && hv[i] > hv[parent]) {
+                        const float tv = hv[i]; hv[i] = hv[parent]; hv[parent] = tv;
+                        const int tk = hk[i]; hk[i] = hk[parent]; hk[parent] = tk;
+                        i = parent;
+                        parent = (i - 1) / 2;
+                    }
+                } else if (vj < hv[0]) {
+                    int i = 0;
+                    hv[0] = vj; hk[0] = k0 + j;
+                    for (;;) {
+                        const int l = 2 * i + 1, r = 2 * i + 2;
+                        if (l >= ma) break;
+                        int c = l;
+                        if (r < ma && hv[r] > hv[l]) c = r;
+                        if (hv[c] <= hv[i]) break;
+                        const float tv = hv[i]; hv[i] = hv[c]; hv[c] = tv;
+                        const int tk = hk[i]; hk[i] = hk[c]; hk[c] = tk;
+                        i = c;
+                    }
+                }
+            }
+            if (size != ma) ++size;                                                               // (uniform: every lane counts)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = (int)lane; i < size; i += 64) perm[i] = i;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) xs_std_sort(x, size);                                                          // kv_binheap::sort (binheap.hpp:118-127)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = (int)lane; i < size; i += 64) out[i] = hk[perm[i]];
+}
+
 // KPT = centroids per thread kept in registers (K <= 256 * KPT); KPT == 0: distances live in the global scratch.
 // Every thread accumulates ITS centroid's dimensions in ascending order (bit-exact with the host loop); a
 // thread walks one row sequentially, so each cache line it touches is reused 16 times from L1 and the K x dim
@@ -1871,7 +2060,13 @@ __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int k = j * 256 + tid;
-            if (j < nblk && k < K) row_dist(k, mine[j]);
+            if (j < nblk && k < K) {
+                row_dist(k, mine[j]);
+                if (dist)                                        // (the exact-tie path below reads the row from memory)
+#pragma unroll
+                    for (int b = 0; b < QB; ++b)
+                        if (b < nqb) dist[(size_t)(q0 + b) * K + k] = mine[j][b];
+            }
         }
     } else {
         for (int k = tid; k < K; k += 256) {
@@ -1883,14 +2078,19 @@ __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restr
         }
     }
     __syncthreads();
-    // per query: ma rounds of "smallest (distance, index) strictly after the previous pick"
+    __shared__ float x_hv[256];
+    __shared__ int x_hk[256], x_perm[kExactSelInts];
+    // per query: ma rounds of "smallest (distance, index) strictly after the previous pick" (+ one more round that only looks
+    // for a value equal to the ma-th outside the picks: an exact tie, see coarse_exact_select)
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         if (b >= nqb) break;
         const float* __restrict__ dq = dist + (size_t)(q0 + b) * K;
         float last_v = -1.0f;
         int last_k = -1;
-        for (int a = 0; a < ma; ++a) {
+        bool tie = false;
+        const int rounds = (dist && ma > 1 && ma <= 256 && ma < K) ? ma + 1 : ma;
+        for (int a = 0; a < rounds; ++a) {
             float bv = FLT_MAX;
             int bk = 0x7fffffff;
             if (KPT > 0) {
@@ -1922,9 +2122,15 @@ __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restr
 #pragma unroll
             for (int w = 1; w < 4; ++w)
                 if (rv[w] < bv || (rv[w] == bv && rk[w] < bk)) { bv = rv[w]; bk = rk[w]; }
+            tie = tie || (a > 0 && bv == last_v);
             last_v = bv;
             last_k = bk;
-            if (tid == 0) assign[(size_t)(q0 + b) * ma + a] = last_k;
+            if (tid == 0 && a < ma) assign[(size_t)(q0 + b) * ma + a] = last_k;
+            __syncthreads();
+        }
+        if (tie && dist && ma <= 256) {                          // (uniform: every thread saw the same picks)
+            __threadfence_block();
+            if (tid < 64) coarse_exact_select(dq, K, ma, assign + (size_t)(q0 + b) * ma, x_hv, x_hk, x_perm, (uint32_t)tid);
             __syncthreads();
         }
     }
@@ -2038,9 +2244,13 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
         const int k = j * 256 + tid;
         mine[j] = k < K ? __float_as_uint(dist[(size_t)q * K + k]) : 0xffffffffu;
     }
+    __shared__ float x_hv[256];
+    __shared__ int x_hk[256], x_perm[kExactSelInts];
     uint32_t last_v = 0;
     int last_k = -1, par = 0;
-    for (int a = 0; a < ma; ++a, par ^= 1) {
+    bool tie = false;
+    const int rounds = (ma > 1 && ma <= 256 && ma < K) ? ma + 1 : ma;   // (the extra round looks for a value equal to the ma-th outside the picks)
+    for (int a = 0; a < rounds; ++a, par ^= 1) {
         uint32_t bv = 0xffffffffu, bk = 0xffffffffu;
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
@@ -2058,9 +2268,14 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
 #pragma unroll
         for (int w = 1; w < 4; ++w)
             if (rv[par][w] < bv || (rv[par][w] == bv && rk[par][w] < bk)) { bv = rv[par][w]; bk = rk[par][w]; }
+        tie = tie || (a > 0 && bv == last_v && bk != 0xffffffffu);
         last_v = bv;
         last_k = (int)bk;
-        if (tid == 0) assign[(size_t)q * ma + a] = last_k;
+        if (tid == 0 && a < ma) assign[(size_t)q * ma + a] = last_k;
+    }
+    if (tie && ma <= 256) {                                      // exact float ties: the reference's heap history decides (coarse_exact_select)
+        __syncthreads();
+        if (tid < 64) coarse_exact_select(dist + (size_t)q * K, K, ma, assign + (size_t)q * ma, x_hv, x_hk, x_perm, (uint32_t)tid);
     }
 }
 
@@ -2069,7 +2284,8 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
 // of keys EQUAL to it with the smallest indices, collected into LDS; (3) one bitonic sort of those ma (key, index) pairs.
 // Result identical to the rounds above (ascending distance, lower index first on ties); K = 16384, ma = 64: 330 -> ~25 us
 // for a workgroup on its own, which is what a rank's share of a sharded front waits for.
-// More than 256 keys tied at the threshold (degenerate inputs) -> `slow` is set and the rounds run for that query.
+// An exact float tie — a value equal to the ma-th outside the picks, or two equal values among them — hands the query to
+// coarse_exact_select (the reference's heap history decides); without ties the result is the reference's entry for entry.
 template <int KPT>
 __global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* __restrict__ dist, int K, int ma, int32_t* __restrict__ assign) {
     __shared__ uint32_t hist[256];
@@ -2166,34 +2382,15 @@ __global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* _
     }
     __syncthreads();
     const uint32_t nless = s_nless, nties = s_nties;            // nless == ma - need_ties
-    if (nties > 256u) {                                          // degenerate: the rounds (same result), this workgroup only
-        uint32_t last_v = 0;
-        int last_k = -1;
-        __shared__ uint32_t rv[2][4], rk[2][4];
-        int par = 0;
-        for (int a = 0; a < ma; ++a, par ^= 1) {
-            uint32_t bv = 0xffffffffu, bk = 0xffffffffu;
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                const uint32_t k = (uint32_t)(j * 256 + tid), v = mine[j];
-                const bool after = v > last_v || (v == last_v && (int)k > last_k);
-                if (k < (uint32_t)K && after && (v < bv || (v == bv && k < bk))) { bv = v; bk = k; }
-            }
-            const uint32_t wv = dpp_wave_min_u32(bv);
-            const uint32_t wk = dpp_wave_min_u32(bv == wv ? bk : 0xffffffffu);
-            if ((tid & 63) == 0) { rv[par][tid >> 6] = wv; rk[par][tid >> 6] = wk; }
-            __syncthreads();
-            bv = rv[par][0];
-            bk = rk[par][0];
-#pragma unroll
-            for (int w = 1; w < 4; ++w)
-                if (rv[par][w] < bv || (rv[par][w] == bv && rk[par][w] < bk)) { bv = rv[par][w]; bk = rk[par][w]; }
-            last_v = bv;
-            last_k = (int)bk;
-            if (tid == 0) assign[(size_t)q * ma + a] = last_k;
-        }
+    __shared__ float x_hv[256];
+    __shared__ int x_hk[256], x_perm[kExactSelInts];
+    __shared__ uint32_t s_tie;
+    if (nties > need_ties) {                                     // a value equal to the ma-th outside the picks: an exact tie at the boundary —
+        // the reference's heap history decides which of them stay and in which order (coarse_exact_select); uniform branch
+        if (tid < 64) coarse_exact_select(dist + (size_t)q * K, K, ma, assign + (size_t)q * ma, x_hv, x_hk, x_perm, (uint32_t)tid);
         return;
     }
+    if (tid == 0) s_tie = 0;
     // ties: the need_ties smallest indices among them; then the ma survivors in (distance, index) order.  Both by COUNTING — an
     // entry's place is the number of smaller entries, read as LDS broadcasts (indices and keys are distinct) — instead of two
     // 256-element bitonic networks: 72 barrier steps were most of this kernel (87 us alone on the GPU at the C5 shape for 67 MB of
@@ -2207,15 +2404,23 @@ __global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* _
     __syncthreads();
     if (tid < ma) {
         const uint64_t key = cand[tid];
-        uint32_t rank = 0;
+        const uint32_t kv = (uint32_t)(key >> 32);
+        uint32_t rank = 0, same = 0;
         int j = 0;
         for (; j + 2 <= ma; j += 2) {                            // (two keys per LDS read)
             const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&cand[j]);
             rank += (kk.x < key ? 1u : 0u) + (kk.y < key ? 1u : 0u);
+            same += ((uint32_t)(kk.x >> 32) == kv ? 1u : 0u) + ((uint32_t)(kk.y >> 32) == kv ? 1u : 0u);
         }
-        for (; j < ma; ++j) rank += cand[j] < key ? 1u : 0u;
+        for (; j < ma; ++j) {
+            rank += cand[j] < key ? 1u : 0u;
+            same += (uint32_t)(cand[j] >> 32) == kv ? 1u : 0u;
+        }
         assign[(size_t)q * ma + rank] = (int32_t)(uint32_t)key;
+        if (same > 1u) s_tie = 1u;                               // two picks with the same distance: an exact tie inside
     }
+    __syncthreads();
+    if (s_tie && tid < 64) coarse_exact_select(dist + (size_t)q * K, K, ma, assign + (size_t)q * ma, x_hv, x_hk, x_perm, (uint32_t)tid);
 }
 
 void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,

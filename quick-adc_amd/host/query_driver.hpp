@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "float_sum.hpp"
+#include "qadc_heap.hpp"
 
 namespace qadc {
 
@@ -187,12 +188,14 @@ struct ivf_database {
         }
         return s;
     }
-    // the ma nearest coarse centroids, ascending by distance (find_k_neighbors + heap sort, neighbors.cpp:30-76)
+    // the ma nearest coarse centroids, ascending by distance, as find_k_neighbors selects them (neighbors.cpp:18-28, 47-71): the
+    // distances go through a kv_binheap<int, float> of capacity ma in index order, then kv_binheap::sort — which is "the ma smallest
+    // by (distance, index)" unless distances tie exactly, and then whatever the heap's history and std::sort leave (pinned to the
+    // reference's own heaps: tests/test_oracle_float_ref.py; the device kernels do the same, coarse_exact_select)
     void nearest(const float* x, int ma, int* out) const {
-        std::vector<std::pair<float, int>> d(part_count);
-        for (int k = 0; k < part_count; ++k) d[k] = std::make_pair(dist2(x, k), k);
-        std::partial_sort(d.begin(), d.begin() + ma, d.end());
-        for (int a = 0; a < ma; ++a) out[a] = d[a].second;
+        kv_heap<int, float> h(ma);
+        for (int k = 0; k < part_count; ++k) h.push(k, dist2(x, k));
+        h.sort_keys(out);
     }
     void add_vectors(const float* vecs, unsigned n, unsigned labels_offset) {  // databases.hpp:270-298
         std::vector<float> res(pq->dim);

@@ -141,12 +141,13 @@ def search_inputs(case):
             dot = (dot + (xv * cv).astype(np.float32)).astype(np.float32)
         return ((vn + cn).astype(np.float32) + (np.float32(-2.0) * dot).astype(np.float32)).astype(np.float32)
 
+    import pyoracle                                              # (the checker's side only: the workers never call this function)
     nq = q.shape[0]
     assign = np.zeros((nq, ma), np.int32)
     tables = np.zeros((nq, ma, M * 16), np.float32)
     for i in range(nq):
         dist = sqdist(q[i][None, :], coarse)
-        assign[i] = np.lexsort((np.arange(K), dist))[:ma]
+        assign[i] = pyoracle.select_k_neighbors(dist, ma)[0][0]     # find_k_neighbors' heaps (exact ties: as the reference leaves them)
         resid = (q[i][None, :] - coarse[assign[i]]).astype(np.float32)
         for a in range(ma):
             tables[i, a] = expansion(resid[a].reshape(M, 1, ds), cb).reshape(-1)

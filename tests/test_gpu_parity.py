@@ -398,7 +398,7 @@ def test_search_with_device_side_feeders(pyqadc, po, M, K, ma, opq, form):
     for q in range(nq):
         if K:
             dist = _seq_sqdist(queries[q][None, :], coarse)
-            assign = np.lexsort((np.arange(K), dist))[:ma].astype(np.int32)
+            assign = po.select_k_neighbors(dist, ma)[0][0]       # find_k_neighbors' heaps (centroids 3 and 5 tie exactly)
             resid = (queries[q][None, :] - coarse[assign]).astype(np.float32)
         else:
             assign = np.zeros(ma, np.int32)
@@ -1627,11 +1627,13 @@ def test_ordering_pass_bucket_sort_and_its_bitonic_fallback_agree(pyqadc, po, gr
 @pytest.mark.gpu
 @pytest.mark.parametrize("nq,K,dim,ma", [(300, 700, 16, 9), (257, 4100, 48, 33), (1030, 256, 128, 16), (70, 16384, 96, 64),
                                          (33, 1500, 32, 200), (20, 900, 16, 8)])
-def test_coarse_assignment_of_large_batches_is_the_sequential_one(pyqadc, nq, K, dim, ma):
+def test_coarse_assignment_of_large_batches_is_the_sequential_one(pyqadc, po, nq, K, dim, ma):
     """Batches of >= 256 queries compute the coarse distances as [16 queries] x [256 centroids] tiles and select per
     query in a second kernel; assign[] must be what the sequential host loop gives — squared L2 accumulated in
-    ascending d, the ma nearest in ascending (distance, index) order — including exact ties (duplicated centroids), a
-    ragged last query group, K not a multiple of 256 and dimensions that are not a multiple of the 32-wide tile."""
+    ascending d, the ma nearest as find_k_neighbors' heaps select them (ascending distance; exact ties — duplicated
+    centroids — as the heap's history and kv_binheap::sort leave them: the oracle's orc_select_k_neighbors, pinned to the
+    reference's own heaps) —, a ragged last query group, K not a multiple of 256 and dimensions that are not a multiple of the
+    32-wide tile."""
     rng = np.random.default_rng(nq + K)
     idx = pyqadc.Index(16)
     idx.add_partitions([rand_codes(rng, 40, 16) for _ in range(K)])
@@ -1653,8 +1655,38 @@ def test_coarse_assignment_of_large_batches_is_the_sequential_one(pyqadc, nq, K,
     got = idx.search(queries, ma, 30)["assign"]
     for q in list(range(0, nq, 17)) + [7, nq - 1]:
         d = _seq_sqdist(queries[q][None, :], coarse)
-        want = np.lexsort((np.arange(K), d))[:ma]
+        want = po.select_k_neighbors(d, ma)[0][0]
         assert np.array_equal(got[q], want), q
+    idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,K,dim,ma,levels", [(300, 700, 16, 9, 3), (40, 4100, 48, 33, 2), (530, 256, 32, 16, 4), (24, 16384, 96, 64, 2),
+                                                (33, 1500, 32, 200, 3), (20, 900, 16, 8, 2), (50, 600, 16, 5, 2), (9, 300, 16, 2, 2),
+                                                (12, 16500, 16, 9, 2), (520, 16500, 16, 12, 3), (30, 500, 16, 256, 5), (7, 40, 16, 40, 2)])
+def test_coarse_assignment_with_exact_distance_ties_is_find_k_neighbors(pyqadc, po, nq, K, dim, ma, levels):
+    """Integer-valued centroids and queries: the squared distances are small integers, so most of a query's distances tie
+    exactly — inside its ma nearest and across the ma-th.  The reference's choice then depends on its heap's history and on
+    std::sort's order of equal keys (neighbors.cpp:18-28, 47-71; binheap.hpp:75-127); every selection kernel of the device —
+    the radix form (8 <= ma <= 256), the rounds (ma < 8), the fused form (K > 16384) — must reproduce it entry for entry
+    (coarse_exact_select), against the oracle's restatement that is pinned to the reference's own heaps on the CPU."""
+    rng = np.random.default_rng(nq * 7 + K + ma)
+    idx = pyqadc.Index(16)
+    idx.add_partitions([rand_codes(rng, 40, 16) for _ in range(K)])
+    idx.finalize(1.0)
+    idx.set_pq(rng.normal(size=(16, 16, dim // 16)).astype(np.float32))
+    coarse = rng.integers(0, levels, (K, dim)).astype(np.float32)
+    queries = rng.integers(0, levels, (nq, dim)).astype(np.float32)
+    idx.set_coarse(coarse)
+    got = idx.search(queries, ma, 30)["assign"]
+    nrule = 0
+    checked = list(range(nq)) if nq <= 64 else list(range(0, nq, 13)) + [nq - 1]
+    for q in checked:
+        d = _seq_sqdist(queries[q][None, :], coarse)
+        want = po.select_k_neighbors(d, ma)[0][0]
+        assert np.array_equal(got[q], want), q
+        nrule += int(np.array_equal(want, np.lexsort((np.arange(K), d))[:ma]))
+    assert ma == K or ma <= 2 or nrule * 4 < len(checked)       # (the plain (distance, index) rule is NOT what the heaps leave here)
     idx.close()
 
 

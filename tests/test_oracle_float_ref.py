@@ -257,14 +257,15 @@ def test_pack4_and_residuals_match_the_reference(po):
     assert np.array_equal(po.reff_substract_from_unique(v, base, a), (v[None, :] - base[a]).astype(np.float32))
 
 
-def test_coarse_selection_rule_against_the_reference_heaps(po):
+def test_coarse_selection_against_the_reference_heaps(po):
     """N1, the selection half of find_k_neighbors (neighbors.cpp:18-28, 47-71: add_candidates_heaps block by block, then
-    kv_binheap::sort — compiled from the reference's text; the distance half is cblas_sgemm and is not).  The product (device
-    coarse_select kernels, host/query_driver.hpp) and every test model select `the ma smallest by (distance, index)`:
-    on distances WITHOUT exact ties among the kept and the boundary values that is what the reference's heaps produce, entry for
-    entry, at the shapes of configs[2] / [4] and at ragged block sizes.  WITH exact float ties the reference's choice depends on
-    its heap's history (which of several equal maxima sits at the root when a smaller value arrives) and on std::sort's order of
-    equal keys: only the multiset of kept DISTANCES is the same — stated as a known difference in DESIGN.md section 8 (N1)."""
+    kv_binheap::sort — compiled from the reference's text; the distance half is cblas_sgemm and is not).  (1) The oracle's
+    restatement (orc_select_k_neighbors: the heap's push + libstdc++'s std::sort on the permutation) equals the reference's heaps
+    entry for entry, distances AND indices, on tie-free and on tie-heavy inputs, at the shapes of configs[2] / [4], at ragged
+    block sizes, with k > neighbours.  (2) On distances WITHOUT exact ties among the kept and the boundary values both equal
+    `the k smallest by (distance, index)` — the fast path of the device's selection kernels; WITH exact ties they do not (which
+    of several equal maxima sits at the heap's root when a smaller value arrives, and std::sort's order of equal keys, decide),
+    which is why the device has coarse_exact_select (GPU: test_coarse_assignment_with_exact_distance_ties_is_find_k_neighbors)."""
     _need_ref_float(po)
     rng = np.random.default_rng(77)
 
@@ -279,18 +280,27 @@ def test_coarse_selection_rule_against_the_reference_heaps(po):
         want = rule(d, k)
         assert np.array_equal(a, want), (count, K, k)
         assert np.array_equal(sd, np.take_along_axis(d, want, 1))
+        b, sb = po.select_k_neighbors(d, k)
+        assert np.array_equal(b, a) and np.array_equal(sb, sd)
         # ties only ABOVE the kept values do not matter either
         d2 = d.copy()
         kth = np.sort(d2, 1)[:, k - 1:k]
         d2[d2 > kth] = np.floor(d2[d2 > kth] / 16.0) * 16.0 + 16.0 + kth.max()
         a2, _ = po.reff_select_k_neighbors(d2, k)
         assert np.array_equal(a2, want), (count, K, k)
-    # exact ties among the kept values: same distances, not (in general) the same entries
-    d = np.floor(rng.random((50, 4096)) * 300).astype(np.float32)
-    a, sd = po.reff_select_k_neighbors(d, 32)
-    want = rule(d, 32)
-    assert np.array_equal(sd, np.take_along_axis(d, want, 1))
-    assert not np.array_equal(a, want)
+    # exact ties among the kept values and across the boundary
+    ndiff = 0
+    for count, K, k, levels in ((50, 4096, 32, 300), (20, 16384, 64, 2000), (40, 300, 8, 20), (40, 1000, 16, 5), (10, 513, 64, 3),
+                                (10, 70, 64, 7), (6, 5000, 200, 100), (4, 64, 256, 9), (6, 2000, 256, 50), (30, 700, 2, 3),
+                                (300, 260, 5, 4), (8, 9000, 129, 40)):
+        d = np.floor(rng.random((count, K)) * levels).astype(np.float32)
+        a, sd = po.reff_select_k_neighbors(d, k)
+        b, sb = po.select_k_neighbors(d, k)
+        kk = min(k, K)
+        assert np.array_equal(a[:, :kk], b[:, :kk]) and np.array_equal(sd[:, :kk], sb[:, :kk]), (count, K, k, levels)
+        assert np.array_equal(sd[:, :kk], np.take_along_axis(d, rule(d, kk), 1))    # (the kept DISTANCES are the k smallest either way)
+        ndiff += int(not np.array_equal(a[:, :kk], rule(d, kk)))
+    assert ndiff >= 10
 
 
 def test_extraction_refuses_a_drifted_reference(tmp_path):
