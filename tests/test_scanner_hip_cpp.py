@@ -13,16 +13,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "scanner_hip_demo")
 
 
-def _compile(src, exe):
-    """g++ -std=c++14 against the C-ABI library; written under a per-process name and renamed into place, so that
-    parallel test workers never execute (or overwrite) a half-linked binary."""
+def _compile(src, exe, link=True):
+    """g++ -std=c++14 against the C-ABI library (link=False: a header-only driver); written under a per-process name and
+    renamed into place, so that parallel test workers never execute (or overwrite) a half-linked binary."""
     libdir = os.path.join(ROOT, "quick-adc_amd")
-    if not os.path.exists(os.path.join(libdir, "libqadc_hip.so")):
+    if link and not os.path.exists(os.path.join(libdir, "libqadc_hip.so")):
         import __graft_entry__
         __graft_entry__.build()
     tmp = "%s.%d.tmp" % (exe, os.getpid())
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-pthread", src, "-o", tmp,
-                           "-L" + libdir, "-lqadc_hip", "-Wl,-rpath," + libdir])
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-pthread", src, "-o", tmp] +
+                          (["-L" + libdir, "-lqadc_hip", "-Wl,-rpath," + libdir] if link else []))
     os.replace(tmp, exe)
 
 
@@ -326,3 +326,34 @@ def test_db_query_cpu_front_end_matches_the_oracle(po, tmp_path, M, bits, batch)
             wk, wv = po.heap_replay_f32(np.concatenate([np.zeros(R, np.uint32), np.arange(n, dtype=np.uint32)]),
                                         np.concatenate([sent, cand]), R)
         assert np.array_equal(keys, wk) and np.array_equal(vals, wv), q
+
+
+NEAREST = os.path.join(ROOT, "tests", "cpp", "nearest_demo")
+
+
+@pytest.mark.parametrize("K,dim,ma,levels", [(700, 16, 9, 3), (4100, 48, 33, 2), (300, 16, 2, 2), (900, 32, 64, 3), (40, 16, 40, 2), (513, 16, 256, 4)])
+def test_host_coarse_selection_with_exact_ties_is_find_k_neighbors(po, tmp_path, K, dim, ma, levels):
+    """The host twin of the device's coarse selection (ivf_database::nearest, host/query_driver.hpp) on integer-valued centroids
+    and queries — distances tie exactly, inside the ma nearest and across the ma-th — against the REFERENCE's own heaps
+    (find_k_neighbors' selection half compiled from its text, oracle/_ref) and against the oracle's restatement, fed with the same
+    sequential squared distances.  CPU only."""
+    _compile(os.path.join(ROOT, "tests", "cpp", "nearest_demo.cpp"), NEAREST, link=False)
+    rng = np.random.default_rng(K + ma)
+    nq = 25
+    coarse = rng.integers(0, levels, (K, dim)).astype(np.float32)
+    queries = rng.integers(0, levels, (nq, dim)).astype(np.float32)
+    f = str(tmp_path / "in.bin")
+    with open(f, "wb") as fh:
+        fh.write(np.array([K, dim, ma, nq], np.int32).tobytes() + coarse.tobytes() + queries.tobytes())
+    got = np.array([[int(x) for x in l.split()] for l in subprocess.check_output([NEAREST, f]).decode().strip().split("\n")], np.int32)
+    d = np.zeros((nq, K), np.float32)
+    for j in range(dim):                                         # squared L2 in ascending d, float32 (dist2 of the twin)
+        t = (queries[:, j:j + 1] - coarse[None, :, j]).astype(np.float32)
+        d = (d + (t * t).astype(np.float32)).astype(np.float32)
+    want, _ = po.select_k_neighbors(d, ma)
+    assert np.array_equal(got, want)
+    if po.have_ref_float():
+        ref, _ = po.reff_select_k_neighbors(d, ma)
+        assert np.array_equal(got, ref)
+    rule = np.stack([np.lexsort((np.arange(K), row))[:ma] for row in d])
+    assert ma == K or not np.array_equal(got, rule)              # (the plain (distance, index) rule is not what the heaps leave)
