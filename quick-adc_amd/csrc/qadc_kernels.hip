@@ -375,6 +375,9 @@ __device__ __forceinline__ uint32_t prefix_bound_wave(const QueryState* qs, int 
     return min((uint32_t)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(reached)), 127u);
 }
 
+#ifndef QADC_MQ_SEATS26
+#define QADC_MQ_SEATS26 1
+#endif
 #ifndef QADC_BYTE0_PLAIN_AND
 #define QADC_BYTE0_PLAIN_AND 0   // (tried in round 5, same-box A/B: nothing at the IVF shapes, +0.6 % on the flat batched step: profiles/r05_byte0_and_ab.txt)
 #endif
@@ -604,6 +607,162 @@ __device__ __forceinline__ void scan_mq_body(const ScanItem* __restrict__ its, c
     for (; t0 < ntiles; t0 += G * U) run(t0, part_t());
 }
 
+// Round 5: two more seat counts for the IVF second phase (QADC_MQ_SEATS26).  A group with 1-2 live seats reads 4-byte rows
+// (one LDS cycle per 64 lookups instead of two, v_add_u32 adds at full issue rate), one with 5-6 reads 12 of a 16-byte row
+// (ds_read_b64 + ds_read_b32: three LDS cycles instead of four, three dword adds instead of two 64-bit ones).  Rows are kept
+// as dwords of two u16 fields; everything else — bounds, bias test, rare emit path, software pipeline — as in scan_mq_body.
+template <int M, int U, int NQ>
+__device__ __forceinline__ void scan_mq_body_x(const ScanItem* __restrict__ its, const ScanItem& it, int nq, uint32_t bx, uint32_t G,
+                                               const int8_t* __restrict__ qtables, QueryState* __restrict__ qstates,
+                                               CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap, uint32_t R) {
+    static_assert(NQ == 2 || NQ == 6, "seat counts of this body");
+    constexpr int CS = M / 2, DW = M / 8, CPL = 16 / CS;
+    constexpr int ROWB = NQ == 2 ? 4 : 16, ND = NQ / 2;          // bytes per row, dwords used per row
+    constexpr int TAB = M * 256;
+    typedef const __attribute__((address_space(3))) uint32_t* lds_u32_t;
+    typedef const __attribute__((address_space(3))) uint64_t* lds_u64_t;
+    uint32_t* lbound = reinterpret_cast<uint32_t*>(smem + TAB);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (int e = tid; e < M * 16; e += kMQWG) {
+        uint32_t dwv[ND];
+#pragma unroll
+        for (int w = 0; w < ND; ++w) {
+            uint32_t lo = 0, hi = 0;
+            if (2 * w < nq && its[2 * w].n != 0) lo = (uint8_t)qtables[(uint64_t)its[2 * w].table * (M * 16) + e];
+            if (2 * w + 1 < nq && its[2 * w + 1].n != 0) hi = (uint8_t)qtables[(uint64_t)its[2 * w + 1].table * (M * 16) + e];
+            dwv[w] = lo | (hi << 16);
+        }
+        uint32_t* dst = reinterpret_cast<uint32_t*>(smem + e * ROWB);
+#pragma unroll
+        for (int w = 0; w < ND; ++w) dst[w] = dwv[w];
+    }
+    for (int j = (int)wave; j < NQ; j += kMQWG / 64) {
+        uint32_t b = 0;
+        if (j < nq && its[j].n != 0) b = prefix_bound_wave(qstates + its[j].query, its[j].order >> 16, R, lane);
+        if (lane == 0) lbound[j] = b;
+    }
+    __syncthreads();
+    uint32_t bq[NQ], bias[ND];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) bq[j] = __builtin_amdgcn_readfirstlane(lbound[j]);
+#pragma unroll
+    for (int w = 0; w < ND; ++w) bias[w] = (0x8000u - bq[2 * w]) | ((0x8000u - bq[2 * w + 1]) << 16);
+    constexpr uint32_t kTop = 0x80008000u;
+
+    typedef const __attribute__((address_space(1))) u32x4_t* gvec_t;
+    const gvec_t src = (gvec_t)(uintptr_t)it.codes;
+    const uint32_t n = it.n;
+    const uint32_t nvec = (n + CPL - 1) / CPL;
+    const uint32_t ntiles = (nvec + kMQWG - 1) / kMQWG;
+    constexpr uint32_t nib_mask = NQ == 2 ? 0x3cu : 0xf0u;
+    struct Row { uint32_t d[ND]; };
+    auto code_sums = [&](const uint32_t* d) -> Row {
+        Row a;
+#pragma unroll
+        for (int w = 0; w < ND; ++w) a.d[w] = 0;
+#pragma unroll
+        for (int w = 0; w < DW; ++w) {
+            const uint32_t dl = NQ == 2 ? d[w] << 2 : d[w] << 4;
+            const uint32_t dh = NQ == 2 ? d[w] >> 2 : d[w];
+#define QADC_MQX_READ(addr)                                                                                    \
+            {                                                                                                  \
+                if (NQ == 2) {                                                                                 \
+                    a.d[0] += *reinterpret_cast<lds_u32_t>(static_cast<uintptr_t>(addr));                      \
+                } else {                                                                                       \
+                    const uint64_t r01 = *reinterpret_cast<lds_u64_t>(static_cast<uintptr_t>(addr));           \
+                    const uint32_t r2 = *reinterpret_cast<lds_u32_t>(static_cast<uintptr_t>((addr) + 8));      \
+                    a.d[0] += (uint32_t)r01;                                                                   \
+                    a.d[1] += (uint32_t)(r01 >> 32);                                                           \
+                    a.d[ND - 1] += r2;                                                                         \
+                }                                                                                              \
+            }
+#define QADC_MQX_BYTE(k)                                                                                       \
+            {                                                                                                  \
+                const int t0 = 2 * (4 * w + (k));                                                              \
+                const uint32_t xl = byte_and<(k)>(dl, nib_mask), xh = byte_and<(k)>(dh, nib_mask);             \
+                QADC_MQX_READ(xl + t0 * (16 * ROWB))                                                           \
+                QADC_MQX_READ(xh + (t0 + 1) * (16 * ROWB))                                                     \
+            }
+            QADC_MQX_BYTE(0) QADC_MQX_BYTE(1) QADC_MQX_BYTE(2) QADC_MQX_BYTE(3)
+#undef QADC_MQX_BYTE
+#undef QADC_MQX_READ
+        }
+        return a;
+    };
+    // one iteration over U tiles: v = the tiles' vectors (zeros where not loaded), tt = first tile, FULL = every lane holds CPL codes
+    auto consume = [&](const u32x4_t (&v)[U], uint32_t tt, auto full) {
+        Row sums[U * CPL];
+        uint32_t all = kTop;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            const uint32_t e = (tt + u * G) * kMQWG + tid;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const Row a = code_sums(d + c * DW);
+                sums[u * CPL + c] = a;
+                const bool live = decltype(full)::value || (tt + u * G < ntiles && e < nvec && e * CPL + c < n);
+#pragma unroll
+                for (int w = 0; w < ND; ++w) {
+                    const uint32_t t = a.d[w] + bias[w];         // field top bit: sum >= bound
+                    all &= live ? t : kTop;
+                }
+            }
+        }
+        if (__builtin_expect((all & kTop) != kTop, 0)) {         // rare
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const uint32_t e = (tt + u * G) * kMQWG + tid;
+                    if (!decltype(full)::value && !(tt + u * G < ntiles && e < nvec && e * CPL + c < n)) continue;
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const uint32_t sj = (sums[u * CPL + c].d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                        if (sj < bq[j]) {
+                            const ScanItem* ij = its + j;
+                            emit_candidate(qstates + ij->query, hdr, out + (uint64_t)ij->query * cand_cap, cand_cap,
+                                           it.labels, it.key_base, ij->order, it.dup_pos, it.dup_reps, it.pos0 + e * CPL + c, sj);
+                        }
+                    }
+                }
+        }
+    };
+    using full_t = std::integral_constant<bool, true>;
+    using part_t = std::integral_constant<bool, false>;
+    const uint32_t tiles_full = (n / CPL) / kMQWG;
+    uint32_t t0 = bx;
+    if (t0 + (U - 1) * G < tiles_full) {                         // software pipeline over the full tiles (see scan_mq_body)
+        u32x4_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[(t0 + u * G) * kMQWG + tid];
+        for (;;) {
+            const uint32_t tn = t0 + G * U;
+            const bool more_full = tn + (U - 1) * G < tiles_full;
+            u32x4_t nv[U];
+            if (more_full) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) nv[u] = src[(tn + u * G) * kMQWG + tid];
+            }
+            consume(v, t0, full_t());
+            t0 = tn;
+            if (!more_full) break;
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = nv[u];
+        }
+    }
+    for (; t0 < ntiles; t0 += G * U) {
+        u32x4_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t t = t0 + u * G, e = t * kMQWG + tid;
+            v[u] = u32x4_t{0, 0, 0, 0};
+            if (t < ntiles && e < nvec) v[u] = src[e];
+        }
+        consume(v, t0, part_t());
+    }
+}
+
 // Two builds of the kernel.  NARROW = false: the 8-seat body alone — the flat list's bound levels (every group of a flat
 // batch is full but possibly the last).  NARROW = true: both bodies, a group whose seats 4..7 are empty taking the 4-seat
 // one — the IVF second phase, whose remainder groups are mostly narrow.  They are separate kernels on purpose: with both
@@ -632,13 +791,25 @@ __device__ __forceinline__ void scan_mq_kernel_body(const ScanItem* __restrict__
     if (it.n == 0) return;                                   // (device-planned launches are sized for the worst case: no such group)
     lds_base_is_zero();
     if (NARROW) {
-        // seats 4..7 all empty (a remainder group of the IVF second phase): 4-seat form
-        bool upper = false;
-        for (int j = 4; j < nq; ++j) upper = upper || its[j].n != 0;
-        if (!upper) {
+        // seats are filled from 0 upward: the live ones are 0 .. nlive-1 (a remainder group of the IVF second phase is mostly short)
+        int nlive = 0;
+        for (int j = 0; j < nq; ++j) nlive += its[j].n != 0 ? 1 : 0;
+#if QADC_MQ_SEATS26
+        if (nlive <= 2) {
+            scan_mq_body_x<M, U, 2>(its, it, min(nq, 2), bx, G, qtables, qstates, hdr, out, cand_cap, R);
+            return;
+        }
+#endif
+        if (nlive <= 4) {
             scan_mq_body<M, U, 4, QADC_MQ_PIPE != 0>(its, it, min(nq, 4), bx, G, qtables, qstates, hdr, out, cand_cap, R);
             return;
         }
+#if QADC_MQ_SEATS26
+        if (nlive <= 6) {
+            scan_mq_body_x<M, U, 6>(its, it, min(nq, 6), bx, G, qtables, qstates, hdr, out, cand_cap, R);
+            return;
+        }
+#endif
     }
     scan_mq_body<M, U, 8, NARROW && QADC_MQ_PIPE != 0>(its, it, nq, bx, G, qtables, qstates, hdr, out, cand_cap, R);
 }
