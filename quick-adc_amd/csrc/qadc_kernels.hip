@@ -791,9 +791,10 @@ __device__ __forceinline__ void scan_mq_kernel_body(const ScanItem* __restrict__
     if (it.n == 0) return;                                   // (device-planned launches are sized for the worst case: no such group)
     lds_base_is_zero();
     if (NARROW) {
-        // seats are filled from 0 upward: the live ones are 0 .. nlive-1 (a remainder group of the IVF second phase is mostly short)
+        // seats are filled from 0 upward (a remainder group of the IVF second phase is mostly short); nlive = 1 + the highest
+        // live seat, so that a form never drops a seat whatever the planner did
         int nlive = 0;
-        for (int j = 0; j < nq; ++j) nlive += its[j].n != 0 ? 1 : 0;
+        for (int j = 0; j < nq; ++j) nlive = its[j].n != 0 ? j + 1 : nlive;
 #if QADC_MQ_SEATS26
         if (nlive <= 2) {
             scan_mq_body_x<M, U, 2>(its, it, min(nq, 2), bx, G, qtables, qstates, hdr, out, cand_cap, R);
