@@ -137,7 +137,9 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  * merge this many batches later; default 1), "replay_defer" (the device replay of a pipelined partition-major batch waits for the
  * next batch's head launch; default 0: measured -2 % / +3 % at the two IVF configuration shapes), "front_tp" (partition-major
  * batches run their front — float pre-scan of the starts, R-th smallest, quantizer — as three launches of small workgroups off the
- * scan stream instead of inside the head launch),
+ * scan stream instead of inside the head launch), "group_stream" / "head_lds_pad" (experiment hooks of round 5, default 0: the
+ * partition-major phase of a pipelined batch on the level path's scan stream so that the next batch's head runs beside it; extra
+ * dynamic LDS bytes of the head launch — measured worse),
  * "plan_early" (pipelined query-kernel batches: float tables, state clear and partition-major plan run on the stream that produces
  * assign[] instead of the scan stream; default 1), "wgq_stream" (query-kernel batches scan on the highest-priority alternative of the
  * scan stream; default 1 since round 5), "wgq_ramp_shift" (the walk's ramp epochs grow by 2^shift; default doubling), "mq_single" (a lone long

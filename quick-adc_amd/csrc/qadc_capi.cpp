@@ -1642,6 +1642,8 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "wgq_inline") idx->wgq_inline = value != 0;
     else if (n == "replay_wave") idx->replay_wave = value != 0;
     else if (n == "replay_defer") idx->replay_defer = value != 0;
+    else if (n == "group_stream") idx->group_stream = value != 0;
+    else if (n == "head_lds_pad") idx->head_lds_pad = (int)value;
     else if (n == "front_tp") idx->front_tp = value != 0;
     else if (n == "mq_narrow") idx->group.mq_narrow = value != 0;
     else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);

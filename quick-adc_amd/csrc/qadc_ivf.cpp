@@ -351,10 +351,19 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         H.cand_cap = gcap;
         H.hdr = s.d_hdr;
         H.G = 1;
+        H.lds_pad = (uint32_t)idx->head_lds_pad;
         // (profile: one event before and after each of the three launches — prof_ev[1..4]; ~10 us of stream time each)
         if (idx->profile) HIPCHECK(prof_event(s, st));
         HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
+        if (idx->group_stream && !s.dist_batch && !alone && !s.rerun && idx->wgq_stream_on) {
+            // experiment "group_stream": everything behind the head moves to the level path's scan stream; the query-kernel stream is
+            // free for the next batch's head at once
+            if (!s.ev_head) HIPCHECK(hipEventCreateWithFlags(&s.ev_head, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(s.ev_head, st));
+            st = idx->stream;
+            HIPCHECK(hipStreamWaitEvent(st, s.ev_head, 0));
+        }
         // Option replay_defer (off by default).  At the C3 shape the head suffers from company: 1024-thread workgroups, latency-bound
         // (waves parked ~70 %), two per CU only while all 32 wave slots of the CU are free — and the previous batch's replay, one wave
         // per query spread over every CU for ~0.25 ms, starts exactly when this head does (kernel trace: head 0.285 ms in the

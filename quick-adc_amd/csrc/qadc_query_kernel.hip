@@ -2306,8 +2306,13 @@ uint32_t query_kernel_lds_values(int M) { return M == 16 ? QCfg<16>::FCAP : QCfg
 template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD = false>
 static hipError_t launch_scan_query_nt(int nq, const QueryKernelArgs& args, hipStream_t stream) {
     static std::atomic<uint64_t> done{0};
-    const size_t lds = QCfg<M>::LDS_BYTES;
-    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>), (int)lds, done);
+    const size_t lds = QCfg<M>::LDS_BYTES + args.lds_pad;
+    hipError_t e;
+    if (args.lds_pad)                                            // (experiment: the limit is raised per launch, untracked)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else
+        e = dynamic_lds_optin(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>), (int)lds, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>), dim3(nq * (MULTI ? args.G : 1)), dim3(kQWG), lds, stream, args);
     return hipGetLastError();
