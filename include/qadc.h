@@ -273,13 +273,17 @@ int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vec
  *   codes [n][M/2].  The caller dispatches (assign, code, label = index + offset) to its partitions in vector order
  *   like databases.hpp:291-297 (host/db_build.hpp does).
  * qadc_kmeans_iterations_host = kmeans_fast_iterations_thread (databases.cpp:50-90): `iters` rounds of assign-to-nearest
- *   + centroid = (sum of the members in ascending vector order) / count (an empty cluster becomes NaN like the
- *   reference's 0/0); centroids [K][dim] in and out.  The reference seeds these iterations with two OpenCV
+ *   + centroid = (sum of the members in ascending vector order) * (1.0f / count) — AS THE REFERENCE IS COMPILED: under its
+ *   -ffast-math g++ replaces the source's division (databases.cpp:83-88) by a reciprocal and a multiplication, pinned to those
+ *   loops compiled here with the reference's flags (tests/test_oracle_float_ref.py); an empty cluster becomes NaN either way;
+ *   centroids [K][dim] in and out.  qadc_kmeans_iterations_host_mode: div_mode 1 = that, 0 = the source's division.  The reference seeds these iterations with two OpenCV
  *   k-means++ iterations (databases.cpp:96-113) — third-party, not restated: the caller provides the seed. */
 int qadc_ivf_encode_host(int M, int dim, const float* codebooks, const float* rotation, int K, const float* coarse,
                          const float* vectors, uint64_t n, int32_t* assign_out, uint8_t* codes, int device_id);
 int qadc_kmeans_iterations_host(const float* vectors, uint64_t n, int dim, int K, float* centroids, int iters,
                                 int32_t* assign_out, int device_id);
+int qadc_kmeans_iterations_host_mode(const float* vectors, uint64_t n, int dim, int K, float* centroids, int iters,
+                                     int32_t* assign_out, int div_mode, int device_id);
 
 /* Host-only helper (no GPU involved): push (keys[i], vals[i]), i = 0..n-1, in order into an empty
  * heap of capacity R with kv_binheap<unsigned,int8_t>::push semantics (binheap.hpp:75-116), after

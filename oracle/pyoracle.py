@@ -564,6 +564,16 @@ def select_k_neighbors(dists, k):
     return a, sd
 
 
+def reff_kmeans_update(vectors, assign, K):
+    """kmeans_fast_iterations_thread's centroid-update loops (databases.cpp:70-88) as compiled with the reference's flags ->
+    centroids [K][dim]."""
+    v = np.ascontiguousarray(vectors, np.float32)
+    a = np.ascontiguousarray(assign, np.int32)
+    c = np.zeros((K, v.shape[1]), np.float32)
+    ref_float().qadc_reff_kmeans_update(_p(v, f32p), C.c_long(v.shape[0]), v.shape[1], K, _p(a, i32p), _p(c, f32p))
+    return c
+
+
 def reff_parse_data_filename(filename):
     """parse_data_filename (quantizers.cpp:58-87) in a child process: 0 = .pq.data, 1 = .opq.data, 101 = its exit(1)."""
     return int(ref_float().qadc_reff_parse_data_filename(str(filename).encode()))

@@ -52,3 +52,4 @@ cut_range quantizers.hpp     324  324  aa1d1a63390229c7  x_opq_z.inc          # 
 cut_range quantizers.cpp      16   46  288255bdaacf4e70  x_pq_files_a.inc     # read_from_fstream, read_pq_from_fstream, pq_from_data_file(name, pq&), opq_from_data_file<>
 cut_range quantizers.cpp      48  103  97a3c88ebb41e778  x_pq_files_b.inc     # invalid_data_filename, pq_type, parse_data_filename, pq_from_data_file(name)
 cut_range neighbors.cpp       15   28  9d06318706e284de  x_neighbors_heaps.inc # BLOCK_VECS / BLOCK_NEIGHS, add_candidates_heaps
+cut_range databases.cpp       70   88  32e83d7d4a358e15  x_kmeans_update.inc   # the centroid-update loops of kmeans_fast_iterations_thread (its assignment half is find_k_neighbors: cblas)

@@ -26,6 +26,9 @@
 //                                                       the pq_from_data_file factory (N3)
 //   x_neighbors_heaps  neighbors.cpp:15-28             add_candidates_heaps: the selection half of
 //                                                       find_k_neighbors (its distance half is cblas_sgemm) (N1)
+//   x_kmeans_update    databases.cpp:70-88             the centroid-update loops of kmeans_fast_iterations_thread, included
+//                                                       inside a harness function that declares the variables they use
+//                                                       under the reference's names (its assignment half is find_k_neighbors) (N4)
 // binheap.hpp, simd_layout.hpp, simd_scan.hpp, neighbors.hpp and config.h are included whole.
 //
 // What the harness itself adds: `mem_db`, an in-memory base_db (the reference's flat_db /
@@ -59,6 +62,7 @@
 #include "neighbors.hpp"
 #include "simd_layout.hpp"
 #include "simd_scan.hpp"
+#include "vector_io.hpp"
 #undef _mm256_set_m128i
 #include "x_quantizers_a.inc"
 #include "x_quantizers_b.inc"
@@ -340,6 +344,21 @@ void qadc_reff_select_k_neighbors(const float* dists, int count, int neighbor_co
         for (int v = 0; v < bv; ++v)
             heaps[v].sort(assign + static_cast<size_t>(v0 + v) * k, sorted + static_cast<size_t>(v0 + v) * k);
     }
+}
+
+// ---- N4: kmeans_fast_iterations_thread's centroid update (databases.cpp:70-88) as g++ compiles it with the reference's flags
+// (-ffast-math turns the division by the member count into a multiplication by its reciprocal).  The loops are included as
+// they stand; the function around them declares what they use under the reference's own names (databases.cpp:50-54).
+void qadc_reff_kmeans_update(const float* vectors, long n, int dimension, int centroid_count, const int* assign, float* centroids) {
+    vectors_owner<float> learn_vectors;
+    learn_vectors.data.reset(new float[static_cast<size_t>(n) * dimension]);
+    std::memcpy(learn_vectors.data.get(), vectors, sizeof(float) * static_cast<size_t>(n) * dimension);
+    learn_vectors.dimension = dimension;
+    learn_vectors.count = n;
+    const int* assignements = assign;
+    const int dim = learn_vectors.dimension;
+    std::unique_ptr<int[]> assign_count(new int[centroid_count]);
+#include "x_kmeans_update.inc"
 }
 
 }  // extern "C"

@@ -109,6 +109,11 @@ int qadc_ivf_encode_host(int M, int dim, const float* codebooks, const float* ro
 
 int qadc_kmeans_iterations_host(const float* vectors, uint64_t n, int dim, int K, float* centroids, int iters, int32_t* assign_out,
                                 int device_id) {
+    return qadc_kmeans_iterations_host_mode(vectors, n, dim, K, centroids, iters, assign_out, 1, device_id);
+}
+
+int qadc_kmeans_iterations_host_mode(const float* vectors, uint64_t n, int dim, int K, float* centroids, int iters, int32_t* assign_out,
+                                     int div_mode, int device_id) {
     if (!vectors || !centroids || n == 0 || dim <= 0 || dim > 2048 || K <= 0 || iters < 0) return fail(QADC_E_ARG, "bad arguments");
     HIPCHECK(hipSetDevice(device_id));
     ScratchFree mem;
@@ -123,7 +128,7 @@ int qadc_kmeans_iterations_host(const float* vectors, uint64_t n, int dim, int K
     HIPCHECK(hipMemset(d_assign, 0, sizeof(int32_t) * n));
     for (int it = 0; it < iters; ++it) {                       // databases.cpp:57-89
         if (int rc = assign_nearest(d_v, n, dim, K, d_c, d_dist, d_assign)) return rc;
-        launch_kmeans_update(d_v, n, dim, K, d_assign, d_c, nullptr);
+        launch_kmeans_update(d_v, n, dim, K, d_assign, d_c, div_mode != 0, nullptr);
     }
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipDeviceSynchronize());

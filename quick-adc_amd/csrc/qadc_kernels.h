@@ -292,7 +292,7 @@ void launch_float_top1(int M, int sum_mode, const uint8_t* d_codes, uint32_t n, 
 void launch_residual_rotate(const float* d_vectors, uint64_t n, int dim, const float* d_coarse, const int32_t* d_assign,
                             const float* d_rotation, float* d_out, hipStream_t stream);
 void launch_kmeans_update(const float* d_vectors, uint64_t n, int dim, int K, const int32_t* d_assign, float* d_centroids,
-                          hipStream_t stream);
+                          int div_mode, hipStream_t stream);
 void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
                           int32_t* d_assign, hipStream_t stream);
 // Residual + per-query distance tables (compute_dists_single_simd_cg's result, distances.hpp:294-311):

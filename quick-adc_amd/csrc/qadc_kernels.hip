@@ -2883,8 +2883,12 @@ void launch_residual_rotate(const float* d_vectors, uint64_t n, int dim, const f
 // ascending vector order) / member count; an empty cluster divides 0 by 0 like the reference does.  One workgroup per
 // centroid walks assign[] in order, compacts the members of every 256-vector chunk IN ORDER (ballot + prefix) and
 // lets its lanes (one per component) add them sequentially: the float sums are those of the sequential host loop.
+// div_mode 1 (default) — AS COMPILED: the reference is built with -ffast-math, and g++ turns the loop's division by the member
+// count (databases.cpp:83-88) into one reciprocal 1.0f / (float)count and a multiplication per component (pinned to the
+// reference's own loops compiled here: oracle/_ref, qadc_reff_kmeans_update); 0 — the source's division.
 __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restrict__ vectors, uint64_t n, int dim,
-                                                            const int32_t* __restrict__ assign, float* __restrict__ centroids) {
+                                                            const int32_t* __restrict__ assign, float* __restrict__ centroids,
+                                                            int div_mode) {
     __shared__ uint32_t members[256];
     __shared__ uint32_t wcount[4];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2919,13 +2923,13 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < kMaxPer; ++j) {
         const int d = tid + 256 * j;
-        if (d < dim) centroids[(size_t)c * dim + d] = acc[j] / (float)(int)count;
+        if (d < dim) centroids[(size_t)c * dim + d] = div_mode ? acc[j] * (1.0f / (float)(int)count) : acc[j] / (float)(int)count;
     }
 }
 
 void launch_kmeans_update(const float* d_vectors, uint64_t n, int dim, int K, const int32_t* d_assign, float* d_centroids,
-                          hipStream_t stream) {
-    hipLaunchKernelGGL(kmeans_update_kernel, dim3(K), dim3(256), 0, stream, d_vectors, n, dim, d_assign, d_centroids);
+                          int div_mode, hipStream_t stream) {
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(K), dim3(256), 0, stream, d_vectors, n, dim, d_assign, d_centroids, div_mode);
 }
 
 // ---------------------------------------------------------------------------------------------

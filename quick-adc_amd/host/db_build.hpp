@@ -89,8 +89,11 @@ unsigned db_add_hip(Db& db, const char* base_filename, unsigned chunk_count = 10
 }
 
 // databases.cpp:50-90 on the host: assign every vector to its closest centroid (squared L2 accumulated in ascending d,
-// first minimum), then centroid = (sum of its members in vector order) / count.  An empty cluster divides 0 by 0.
-inline void kmeans_fast_iterations(const float* vecs, size_t n, int dim, int K, float* centroids, int iters, int* assign) {
+// first minimum), then centroid = (sum of its members in vector order) times the reciprocal of the count — what the reference
+// binary does under -ffast-math (div_mode 1, pinned to its loops as compiled: oracle/_ref) — or divided by it as the source
+// reads (div_mode 0).  An empty cluster becomes NaN either way.
+inline void kmeans_fast_iterations(const float* vecs, size_t n, int dim, int K, float* centroids, int iters, int* assign,
+                                   int div_mode = 1) {
     std::vector<int> cnt((size_t)K);
     for (int it = 0; it < iters; ++it) {
         for (size_t i = 0; i < n; ++i) {
@@ -115,8 +118,13 @@ inline void kmeans_fast_iterations(const float* vecs, size_t n, int dim, int K, 
             float* c = centroids + (size_t)assign[i] * dim;
             for (int d = 0; d < dim; ++d) c[d] += vecs[i * dim + d];
         }
-        for (int k = 0; k < K; ++k)
-            for (int d = 0; d < dim; ++d) centroids[(size_t)k * dim + d] /= cnt[k];
+        for (int k = 0; k < K; ++k) {
+            const volatile float r = 1.0f / (float)cnt[k];          // (volatile: the host compiler must not fold the two forms)
+            for (int d = 0; d < dim; ++d) {
+                float& c = centroids[(size_t)k * dim + d];
+                c = div_mode ? c * r : c / (float)cnt[k];
+            }
+        }
     }
 }
 

@@ -32,7 +32,7 @@ SYMBOLS = [
     "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit", "qadc_prescan_submit",
     "qadc_prescan_collect", "qadc_query_scan_submit_prescanned",
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
-    "qadc_search_collect", "qadc_device_prepare", "qadc_stream_probe", "qadc_stream_layout", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_kmeans_iterations_host", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
+    "qadc_search_collect", "qadc_device_prepare", "qadc_stream_probe", "qadc_stream_layout", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_kmeans_iterations_host", "qadc_kmeans_iterations_host_mode", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
     "qadc_dist_unique_id", "qadc_dist_init", "qadc_dist_collect", "qadc_dist_shutdown", "qadc_dist_merge_blocks", "qadc_dist_merge_blocks_host",
     "qadc_dist_init_transport", "qadc_dist_init_loopback", "qadc_shm_transport_open", "qadc_shm_transport_allgather", "qadc_shm_transport_allgather_host",
     "qadc_shm_transport_close", "qadc_shm_transport_error", "qadc_slot_assign", "qadc_slot_qtables", "qadc_place_partitions",
@@ -117,6 +117,7 @@ def lib():
         L.qadc_pq_encode_host.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_uint64, u8p, C.c_int]
         L.qadc_ivf_encode_host.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_int, f32p, f32p, C.c_uint64, i32p, u8p, C.c_int]
         L.qadc_kmeans_iterations_host.argtypes = [f32p, C.c_uint64, C.c_int, C.c_int, f32p, C.c_int, i32p, C.c_int]
+        L.qadc_kmeans_iterations_host_mode.argtypes = [f32p, C.c_uint64, C.c_int, C.c_int, f32p, C.c_int, i32p, C.c_int, C.c_int]
         L.qadc_replay_i8.argtypes = [C.c_uint64, u32p, i8p, C.c_int, C.c_int, u32p, i8p, i32p]
         L.qadc_sort_keys_i8.argtypes = [C.c_int, u32p, i8p, u32p]
         L.qadc_merge_streams_i8.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, i32p, C.c_uint64, C.c_int,
@@ -287,12 +288,14 @@ def ivf_encode(codebooks, vectors, coarse=None, rotation=None, device=0):
     return assign, codes
 
 
-def kmeans_iterations(vectors, centroids, iters, device=0):
-    """kmeans_fast_iterations_thread on the GPU: -> (centroids float32 [K][dim], assign int32 [n] of the last round)."""
+def kmeans_iterations(vectors, centroids, iters, device=0, div_mode=1):
+    """kmeans_fast_iterations_thread on the GPU: -> (centroids float32 [K][dim], assign int32 [n] of the last round).
+    div_mode 1: centroid = sum * (1 / count) as the reference is compiled (-ffast-math); 0: the source's division."""
     v = np.ascontiguousarray(vectors, np.float32)
     c = np.array(centroids, np.float32, order="C", copy=True)
     assign = np.zeros(v.shape[0], np.int32)
-    _check(lib().qadc_kmeans_iterations_host(_p(v, f32p), v.shape[0], v.shape[1], c.shape[0], _p(c, f32p), iters, _p(assign, i32p), device))
+    _check(lib().qadc_kmeans_iterations_host_mode(_p(v, f32p), v.shape[0], v.shape[1], c.shape[0], _p(c, f32p), iters, _p(assign, i32p),
+                                                  div_mode, device))
     return c, assign
 
 

@@ -1719,16 +1719,25 @@ def test_ivf_encode_and_kmeans_iterations_match_numpy(pyqadc):
     # flat database: no assignment, no residual
     _, codes_flat = pyqadc.ivf_encode(cb, v[:100])
     assert np.array_equal(codes_flat, pyqadc.pq_encode(cb, v[:100]))
-    # two k-means rounds from the first K vectors
-    cen, asg = pyqadc.kmeans_iterations(v, v[:K], 2)
-    c = v[:K].copy()
-    for _ in range(2):
-        a = np.array([int(np.lexsort((np.arange(K), _seq_sqdist(v[i][None, :], c)))[0]) for i in range(n)])
-        c = np.zeros_like(c)
-        cnt = np.zeros(K, np.int64)
-        for i in range(n):
-            c[a[i]] = (c[a[i]] + v[i]).astype(np.float32)
-            cnt[a[i]] += 1
-        with np.errstate(invalid="ignore", divide="ignore"):
-            c = (c / cnt[:, None].astype(np.float32)).astype(np.float32)
-    assert np.array_equal(asg, a) and np.array_equal(cen, c, equal_nan=True)
+    # two k-means rounds from the first K vectors: the update as the reference is COMPILED (sum * (1 / count): -ffast-math) by
+    # default — checked against the reference's own loops compiled into oracle/_ref where that library is present — and as its
+    # source reads (sum / count) with div_mode 0
+    import pyoracle as po
+    for mode in (1, 0):
+        cen, asg = pyqadc.kmeans_iterations(v, v[:K], 2, div_mode=mode)
+        c = v[:K].copy()
+        for _ in range(2):
+            a = np.array([int(np.lexsort((np.arange(K), _seq_sqdist(v[i][None, :], c)))[0]) for i in range(n)])
+            c = np.zeros_like(c)
+            cnt = np.zeros(K, np.int64)
+            for i in range(n):
+                c[a[i]] = (c[a[i]] + v[i]).astype(np.float32)
+                cnt[a[i]] += 1
+            with np.errstate(invalid="ignore", divide="ignore"):
+                if mode:
+                    want_ref = po.reff_kmeans_update(v, a, K) if po.have_ref_float() else None
+                    c = (c * (np.float32(1.0) / cnt[:, None].astype(np.float32)).astype(np.float32)).astype(np.float32)
+                    assert want_ref is None or np.array_equal(want_ref, c, equal_nan=True)
+                else:
+                    c = (c / cnt[:, None].astype(np.float32)).astype(np.float32)
+        assert np.array_equal(asg, a) and np.array_equal(cen, c, equal_nan=True), mode

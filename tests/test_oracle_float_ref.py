@@ -303,6 +303,35 @@ def test_coarse_selection_against_the_reference_heaps(po):
     assert ndiff >= 10
 
 
+def test_kmeans_centroid_update_as_compiled(po):
+    """N4: kmeans_fast_iterations_thread's centroid update (databases.cpp:70-88).  The source divides every component by the member
+    count; the reference binary (-ffast-math) multiplies by ONE reciprocal per centroid — a different float in a good part of the
+    entries.  The product's default (div_mode 1: device kernel, host twin) is the binary's; this test pins the formula to the
+    reference's own loops compiled here with its flags, incl. an empty cluster (NaN) and a one-member cluster."""
+    _need_ref_float(po)
+    rng = np.random.default_rng(5)
+    ndiff = ntot = 0
+    for n, dim, K in ((5000, 128, 37), (700, 96, 300), (64, 16, 8), (1200, 33, 7)):
+        v = rng.normal(size=(n, dim)).astype(np.float32) * np.float32(3.7)
+        a = rng.integers(0, K - 1, n).astype(np.int32)               # (cluster K-1 stays empty)
+        a[0] = K - 2 if K > 2 else a[0]
+        got = po.reff_kmeans_update(v, a, K)
+        s = np.zeros((K, dim), np.float32)
+        cnt = np.zeros(K, np.int64)
+        for i in range(n):
+            s[a[i]] = (s[a[i]] + v[i]).astype(np.float32)
+            cnt[a[i]] += 1
+        with np.errstate(invalid="ignore", divide="ignore"):
+            compiled = (s * (np.float32(1.0) / cnt[:, None].astype(np.float32)).astype(np.float32)).astype(np.float32)
+            source = (s / cnt[:, None].astype(np.float32)).astype(np.float32)
+        assert np.array_equal(got, compiled, equal_nan=True), (n, dim, K)
+        assert np.isnan(got[K - 1]).all()
+        live = cnt > 0
+        ndiff += int((compiled[live] != source[live]).sum())
+        ntot += int(live.sum()) * dim
+    assert ndiff > ntot // 50                                        # (the two forms really differ)
+
+
 def test_extraction_refuses_a_drifted_reference(tmp_path):
     """oracle/ref_extract.sh carries the sha256 of every line range it cuts out of the reference: one changed byte inside a
     range stops the build instead of silently compiling something else; the untouched reference passes."""
@@ -316,7 +345,7 @@ def test_extraction_refuses_a_drifted_reference(tmp_path):
     out = tmp_path / "out"
     out.mkdir()
     assert subprocess.run([script, ref, str(out)], stderr=subprocess.PIPE).returncode == 0
-    assert sorted(os.listdir(out))[0].startswith("x_") and len(os.listdir(out)) == 17
+    assert sorted(os.listdir(out))[0].startswith("x_") and len(os.listdir(out)) == 18
     drift = tmp_path / "ref"
     drift.mkdir()
     for f in ("quantizers.hpp", "databases.hpp", "query_common.hpp", "db_query_4.cpp", "db_query.cpp", "distances.hpp", "databases.cpp", "quantizers.cpp",
