@@ -258,19 +258,29 @@ int qadc_search_collect(qadc_index* idx, int slot, uint32_t* keys, int8_t* value
                         int32_t* assign_out);
 
 /* "Next" row N4 (database build): PQ encode on the device — base_pq::encode_multiple_vectors for plain PQ
- * (quantizers.hpp:222-245): nearest centroid per sub-quantizer, packed by multiple_set_bits_4
- * (quantizers.hpp:49-68).  d_vectors [n][dim] float and d_codes [n][M/2] are device pointers of `device_id`
- * (the _host form stages host buffers).  Used by bench.py to build a real-encoded list for its recall figure. */
+ * (quantizers.hpp:222-245): per sub-quantizer find_k_neighbors(count, 16, sq_dim, k = 1, ...) (neighbors.cpp:30-76) — the
+ * BLAS-expansion distances (||v||^2 + ||c||^2) - 2 v.c of compute_cross_dists_blas (distances.hpp:151-215) pushed in
+ * centroid order into a capacity-1 kv_binheap: the first strict minimum — packed by multiple_set_bits_4
+ * (quantizers.hpp:49-68).  The norms add as the reference is compiled (pinned to its own text), the
+ * product is one sequential dot (the reference's is OpenBLAS's sgemm: restated).  d_vectors [n][dim] float and d_codes
+ * [n][M/2] are device pointers of `device_id` (the _host form stages host buffers).
+ * _mode: encode_form 1 = that (what the plain entry points do), 0 = the direct form sum (x - c)^2, first minimum (this
+ * library's encoder before round 6: vectors nearly equidistant from two centroids can get another code than the
+ * reference writes); sum_mode 1 = norms as compiled, 0 = sequential. */
 int qadc_pq_encode(int M, int dim, const float* codebooks, const void* d_vectors, uint64_t n, void* d_codes, int device_id);
 int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vectors, uint64_t n, uint8_t* codes,
                         int device_id);
+int qadc_pq_encode_mode(int M, int dim, const float* codebooks, const void* d_vectors, uint64_t n, void* d_codes,
+                        int encode_form, int sum_mode, int device_id);
+int qadc_pq_encode_host_mode(int M, int dim, const float* codebooks, const float* vectors, uint64_t n, uint8_t* codes,
+                             int encode_form, int sum_mode, int device_id);
 
 /* N4, the rest of the build path (host buffers in and out, any device).
  * qadc_ivf_encode_host = the compute of index_db::add_vectors (databases.hpp:270-298) / flat_db::add_vectors (136-156):
  *   nearest coarse centroid per vector (K > 0; squared L2 in ascending d, lowest index on ties — find_k_neighbors with
  *   k = 1), residual, optional OPQ rotation rotated[r] = sum_c x[c] * rotation[r][c] (quantizers.hpp:289-301; rotation
- *   [dim][dim] or NULL), PQ encode (quantizers.hpp:222-245).  assign_out [n] (nullable; untouched when K == 0),
- *   codes [n][M/2].  The caller dispatches (assign, code, label = index + offset) to its partitions in vector order
+ *   [dim][dim] or NULL), PQ encode (quantizers.hpp:222-245; qadc_pq_encode above, _mode likewise).  assign_out [n]
+ *   (nullable; untouched when K == 0), codes [n][M/2].  The caller dispatches (assign, code, label = index + offset) to its partitions in vector order
  *   like databases.hpp:291-297 (host/db_build.hpp does).
  * qadc_kmeans_iterations_host = kmeans_fast_iterations_thread (databases.cpp:50-90): `iters` rounds of assign-to-nearest
  *   + centroid = (sum of the members in ascending vector order) * (1.0f / count) — AS THE REFERENCE IS COMPILED: under its
@@ -280,6 +290,9 @@ int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vec
  *   k-means++ iterations (databases.cpp:96-113) — third-party, not restated: the caller provides the seed. */
 int qadc_ivf_encode_host(int M, int dim, const float* codebooks, const float* rotation, int K, const float* coarse,
                          const float* vectors, uint64_t n, int32_t* assign_out, uint8_t* codes, int device_id);
+int qadc_ivf_encode_host_mode(int M, int dim, const float* codebooks, const float* rotation, int K, const float* coarse,
+                              const float* vectors, uint64_t n, int32_t* assign_out, uint8_t* codes, int encode_form,
+                              int sum_mode, int device_id);
 int qadc_kmeans_iterations_host(const float* vectors, uint64_t n, int dim, int K, float* centroids, int iters,
                                 int32_t* assign_out, int device_id);
 int qadc_kmeans_iterations_host_mode(const float* vectors, uint64_t n, int dim, int K, float* centroids, int iters,

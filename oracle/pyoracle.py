@@ -248,6 +248,41 @@ def tables_direct(centroids, vector, sum_mode=1):
     return out
 
 
+def cross_dists(centroids, vectors, sum_mode=1, with_product=True):
+    """compute_cross_dists_blas restated (orc_cross_dists): centroids [cent_count][dsq], vectors [count][dsq] ->
+    [count][cent_count] float32 = fma(-2, v.c, ||v||^2 + ||c||^2); with_product=False: the norms matrix sgemm receives."""
+    c = np.ascontiguousarray(centroids, np.float32)
+    v = np.ascontiguousarray(vectors, np.float32)
+    out = np.zeros((v.shape[0], c.shape[0]), np.float32)
+    lib().orc_cross_dists(c.shape[1], _p(c, f32p), c.shape[0], _p(v, f32p), C.c_long(v.shape[0]), C.c_long(c.shape[0]),
+                          sum_mode, 1 if with_product else 0, _p(out, f32p))
+    return out
+
+
+def tables_expansion(centroids, vectors, sum_mode=1):
+    """BLAS-expansion table form (compute_dists_multiple_blas_cg restated): centroids [M][16][dsq], vectors
+    [count][M*dsq] (or one vector) -> [count][M*16] float32."""
+    cf = np.ascontiguousarray(centroids, np.float32)
+    M, _, dsq = cf.shape
+    v = np.ascontiguousarray(vectors, np.float32).reshape(-1, M * dsq)
+    out = np.zeros((v.shape[0], M * 16), np.float32)
+    lib().orc_tables_expansion(dsq, M, _p(cf, f32p), _p(v, f32p), C.c_long(v.shape[0]), sum_mode, _p(out, f32p))
+    return out
+
+
+def pq_encode(codebooks, vectors, rotation=None, form=1, sum_mode=1):
+    """base_pq / opq encode_multiple_vectors restated (orc_pq_encode): codebooks [M][16][dsq], vectors [n][dim] ->
+    codes [n][M/2] uint8.  form 1 = the reference's (expansion distances, find_k_neighbors with k = 1), 0 = direct."""
+    cf = np.ascontiguousarray(codebooks, np.float32)
+    M, _, dsq = cf.shape
+    v = np.ascontiguousarray(vectors, np.float32).reshape(-1, M * dsq)
+    rot = None if rotation is None else np.ascontiguousarray(rotation, np.float32)
+    out = np.zeros((v.shape[0], M // 2), np.uint8)
+    lib().orc_pq_encode(M, M * dsq, _p(cf, f32p), _p(rot, f32p) if rot is not None else None, _p(v, f32p),
+                        C.c_long(v.shape[0]), form, sum_mode, _p(out, u8p))
+    return out
+
+
 def start_size(size, keep):
     return int(lib().orc_start_size(int(size), C.c_float(keep)))
 
@@ -603,6 +638,23 @@ def reff_select_k_neighbors(dists, k):
     sd = np.zeros((count, k), np.float32)
     ref_float().qadc_reff_select_k_neighbors(_p(d, f32p), count, nn, k, _p(a, i32p), _p(sd, f32p))
     return a, sd
+
+
+def reff_cross_norms(centroids, vectors):
+    """compute_cross_dists_blas<DSQ> (distances.hpp:151-215) UP TO its cblas_sgemm call: [count][cent_count] float32 =
+    ||v||^2 + ||c||^2 as the reference's own text computes it with its flags.  None for a DSQ outside its dispatch."""
+    c = np.ascontiguousarray(centroids, np.float32)
+    v = np.ascontiguousarray(vectors, np.float32)
+    out = np.zeros((v.shape[0], c.shape[0]), np.float32)
+    rc = ref_float().qadc_reff_cross_norms(c.shape[1], _p(c, f32p), c.shape[0], _p(v, f32p), v.shape[0], _p(out, f32p))
+    return out if rc == 0 else None
+
+
+def reff_extract_subvectors(vectors, subq_dim, sq_i):
+    v = np.ascontiguousarray(vectors, np.float32)
+    out = np.zeros((v.shape[0], subq_dim), np.float32)
+    ref_float().qadc_reff_extract_subvectors(_p(v, f32p), v.shape[1], v.shape[0], subq_dim, sq_i, _p(out, f32p))
+    return out
 
 
 class RefScanner4:

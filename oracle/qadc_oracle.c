@@ -23,8 +23,12 @@
  *       that build (oracle/gen_golden_float.py).  The reference is built with -ffast-math, so "as the source reads"
  *       and "as the binary computes" differ in the grouping of float sums; where they do, mode 1 (the default) is the
  *       binary's and mode 0 the source's.
- *   - NOT pinned (third-party arithmetic absent from this image): the BLAS-expansion table form and find_k_neighbors
- *       (OpenBLAS cblas_sgemm, distances.hpp:151-183, neighbors.cpp:30-76), cv::kmeans — not restated here at all.
+ *   - the BLAS-expansion distance form (orc_cross_dists, orc_tables_expansion; the encoder orc_pq_encode on top of it):
+ *       its norm half (||v||^2 + ||c||^2 as compute_cross_dists_blas hands it to sgemm) is PINNED to the reference's text
+ *       compiled up to the sgemm call (qadc_reff_cross_norms); the product half is cblas_sgemm of OpenBLAS, absent from
+ *       this image: RESTATED as one sequential dot, unpinned.
+ *   - NOT pinned (third-party arithmetic absent from this image): that sgemm (distances.hpp:178-182, quantizers.hpp:296),
+ *       cv::kmeans — not restated here at all.
  *       (The SELECTION half of find_k_neighbors — add_candidates_heaps + kv_binheap::sort on given distances — IS pinned:
  *       orc_select_k_neighbors below against the reference's own text in oracle/_ref/libqadc_ref_float.so, exact ties
  *       included.  The .pq.data / .opq.data readers are in that library too; the tests use them directly.)
@@ -638,6 +642,131 @@ int orc_tables_direct(int dsq, int M, const float* centroids, const float* vecto
             dists[m * 16 + cent] = compiled ? tables_direct_compiled(dsq, x, c) : tables_direct_seq(dsq, x, c);
         }
     return compiled;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The BLAS-expansion distance form — compute_cross_dists_blas<DSQ>, distances.hpp:151-183 (and its <4> specialisation,
+ * 185-215): dists[v][c] = ||v||^2 + ||c||^2 first (153-176), then cblas_sgemm(alpha = -2, beta = 1) adds -2 v.c (178-182).
+ * It is what find_k_neighbors feeds its heaps with (neighbors.cpp:42, 58-59: the encoder, quantizers.hpp:222-245, and the
+ * coarse assignment) and what compute_dists_multiple_blas_cg builds tables from (277-292: every ma > 1 query, every
+ * batch).
+ *   norms (PINNED to the reference's own text compiled up to the sgemm call: oracle/_ref qadc_reff_cross_norms,
+ *     tests/test_oracle_float_ref.py): sum_mode 1 = fmanorm<DSQ/8, DSQ%8>(vec) / norm_4(vec) AS COMPILED — the grouping of
+ *     tables_direct_compiled above with c = 0 (AVX lanes by fma, reduceadd's tree, remainder pairs
+ *     p_k = fma(x_2k, x_2k, r(x_2k+1^2)); norm_4 = p0 + p1), for the reference's cent_count of 16 (with a centroid
+ *     count that is not a multiple of 8 g++'s vectorised DSQ = 4 norm loop groups its tail centroids differently — the
+ *     quantizers always have 16); sum_mode 0 or a remainder outside {0, 4, 6} = one sequential loop.
+ *   product (RESTATED, unpinned: OpenBLAS is not in this image): one sequential dot in ascending d, then
+ *     fma(-2, dot, norms) — one rounding, as a gemm micro-kernel's C += alpha * acc.
+ * ---------------------------------------------------------------------------------------- */
+float orc_sqnorm(int dsq, const float* x, int sum_mode) {
+    const int blocks = dsq / 8, rem = dsq % 8;
+    if (sum_mode == 0 || !(rem == 0 || rem == 4 || rem == 6)) {
+        float s = 0;
+        for (int d = 0; d < dsq; ++d) {
+            const float sq = x[d] * x[d];
+            s = s + sq;
+        }
+        return s;
+    }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < blocks; ++b)
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(x[b * 8 + j], x[b * 8 + j], acc[j]);
+    const float r0 = acc[0] + acc[4], r1 = acc[1] + acc[5], r2 = acc[2] + acc[6], r3 = acc[3] + acc[7];
+    const float vec = (r0 + r2) + (r1 + r3);
+    if (rem == 0) return vec;
+    float p[3] = {0, 0, 0};
+    for (int k = 0; k < rem / 2; ++k) {
+        const float sq1 = x[blocks * 8 + 2 * k + 1] * x[blocks * 8 + 2 * k + 1];
+        p[k] = fmaf(x[blocks * 8 + 2 * k], x[blocks * 8 + 2 * k], sq1);
+    }
+    if (rem == 4) return (p[0] + p[1]) + vec;
+    return (vec + p[2]) + (p[0] + p[1]);                      /* rem == 6 */
+}
+
+/* dists[v * dists_dim + c], v < vec_count, c < cent_count; with_product 0 = the matrix as sgemm receives it (norms only). */
+void orc_cross_dists(int dsq, const float* centroids, int cent_count, const float* vectors, long vec_count, long dists_dim,
+                     int sum_mode, int with_product, float* dists) {
+    float* cn = (float*)malloc(sizeof(float) * (size_t)(cent_count > 0 ? cent_count : 1));
+    for (int c = 0; c < cent_count; ++c) cn[c] = orc_sqnorm(dsq, centroids + (size_t)c * dsq, sum_mode);
+    for (long v = 0; v < vec_count; ++v) {
+        const float* x = vectors + (size_t)v * dsq;
+        const float vn = orc_sqnorm(dsq, x, sum_mode);
+        for (int c = 0; c < cent_count; ++c) {
+            const float base = vn + cn[c];
+            float out = base;
+            if (with_product) {
+                const float* ce = centroids + (size_t)c * dsq;
+                float dot = 0;
+                for (int d = 0; d < dsq; ++d) {
+                    const float pr = x[d] * ce[d];
+                    dot = dot + pr;
+                }
+                out = fmaf(-2.0f, dot, base);
+            }
+            dists[(size_t)v * dists_dim + c] = out;
+        }
+    }
+    free(cn);
+}
+
+/* compute_dists_multiple_blas_cg (distances.hpp:277-292): tables [count][M*16] of `count` vectors [count][M*dsq]. */
+void orc_tables_expansion(int dsq, int M, const float* centroids, const float* vectors, long count, int sum_mode, float* dists) {
+    float* sub = (float*)malloc(sizeof(float) * (size_t)(count > 0 ? count : 1) * dsq);
+    for (int m = 0; m < M; ++m) {
+        for (long v = 0; v < count; ++v)                                     /* extract_subvectors, quantizers.hpp:86-94 */
+            memcpy(sub + (size_t)v * dsq, vectors + (size_t)v * M * dsq + (size_t)m * dsq, sizeof(float) * dsq);
+        orc_cross_dists(dsq, centroids + (size_t)m * 16 * dsq, 16, sub, count, (long)M * 16, sum_mode, 1, dists + m * 16);
+    }
+    free(sub);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * base_pq::encode_multiple_vectors — quantizers.hpp:222-245 (opq: rotate_multiple_vectors first, 289-301): per
+ * sub-quantizer extract the sub-vectors (86-94), find_k_neighbors(count, 16, sq_dim, k = 1, ...) (neighbors.cpp:30-76:
+ * the expansion distances of orc_cross_dists, pushed in centroid order into a capacity-1 kv_binheap — the first strict
+ * minimum, the first centroid when its distance is NaN), multiple_set_bits_4 (49-68).
+ *   form 1 = that (the reference's); form 0 = the direct form sum (x - c)^2 in one sequential loop, first minimum (this
+ *   repository's encoder before round 6, kept as an option).
+ * rotation (nullable) [dim][dim]: rotated[r] = sum_c x[c] * rotation[r][c], one sequential float sum (the reference's is
+ * a cblas_sgemm: restated, unpinned).  codebooks [M][16][dim/M]; vectors [n][dim]; codes [n][M/2].
+ * ---------------------------------------------------------------------------------------- */
+void orc_pq_encode(int M, int dim, const float* codebooks, const float* rotation, const float* vectors, long n, int form,
+                   int sum_mode, uint8_t* codes) {
+    const int dsq = dim / M;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    float* rot = NULL;
+    if (rotation) {
+        rot = (float*)malloc(sizeof(float) * nn * dim);
+        for (long v = 0; v < n; ++v)
+            for (int r = 0; r < dim; ++r) {
+                float acc = 0;
+                for (int c = 0; c < dim; ++c) {
+                    const float pr = vectors[(size_t)v * dim + c] * rotation[(size_t)r * dim + c];
+                    acc = acc + pr;
+                }
+                rot[(size_t)v * dim + r] = acc;
+            }
+        vectors = rot;
+    }
+    float* sub = (float*)malloc(sizeof(float) * nn * dsq);
+    float* dists = (float*)malloc(sizeof(float) * nn * 16);
+    int32_t* assign = (int32_t*)malloc(sizeof(int32_t) * nn * M);
+    int32_t* a1 = (int32_t*)malloc(sizeof(int32_t) * nn);
+    for (int m = 0; m < M; ++m) {
+        const float* cb = codebooks + (size_t)m * 16 * dsq;
+        for (long v = 0; v < n; ++v) memcpy(sub + (size_t)v * dsq, vectors + (size_t)v * dim + (size_t)m * dsq, sizeof(float) * dsq);
+        if (form == 1) {
+            orc_cross_dists(dsq, cb, 16, sub, n, 16, sum_mode, 1, dists);
+        } else {
+            for (long v = 0; v < n; ++v)
+                for (int c = 0; c < 16; ++c) dists[(size_t)v * 16 + c] = tables_direct_seq(dsq, sub + (size_t)v * dsq, cb + (size_t)c * dsq);
+        }
+        orc_select_k_neighbors(dists, n, 16, 1, a1, NULL);
+        for (long v = 0; v < n; ++v) assign[(size_t)v * M + m] = a1[v];
+    }
+    orc_pack4(assign, n, M, codes);
+    free(sub); free(dists); free(assign); free(a1); free(rot);
 }
 
 /* starts size — db_query_4.cpp:125-126: max(1u, unsigned(size * keep)), product in float. */

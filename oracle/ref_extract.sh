@@ -53,3 +53,8 @@ cut_range quantizers.cpp      16   46  288255bdaacf4e70  x_pq_files_a.inc     # 
 cut_range quantizers.cpp      48  103  97a3c88ebb41e778  x_pq_files_b.inc     # invalid_data_filename, pq_type, parse_data_filename, pq_from_data_file(name)
 cut_range neighbors.cpp       15   28  9d06318706e284de  x_neighbors_heaps.inc # BLOCK_VECS / BLOCK_NEIGHS, add_candidates_heaps
 cut_range databases.cpp       70   88  32e83d7d4a358e15  x_kmeans_update.inc   # the centroid-update loops of kmeans_fast_iterations_thread (its assignment half is find_k_neighbors: cblas)
+# N4 (round 6): the half of compute_cross_dists_blas that is NOT cblas — the norms and the ||v||^2 + ||c||^2 matrix it hands to
+# sgemm as C (beta = 1).  Each range stops right before the "// BLAS Call" block; the harness closes the function body.
+cut_range distances.hpp       51   57  e6e5667a9932e9dc  x_norm_4.inc          # norm_4
+cut_range distances.hpp      151  176  f6a7290f0f54b133  x_cross_norms.inc     # compute_cross_dists_blas<DSQ>: head, centroid norms, distance-matrix loop (without 178-183: alpha/beta + cblas_sgemm + closing brace)
+cut_range distances.hpp      185  208  a7d682be7297aaa0  x_cross_norms_4.inc   # its <4> specialisation, likewise (without 210-215)

@@ -26,6 +26,10 @@
 //                                                       the pq_from_data_file factory (N3)
 //   x_neighbors_heaps  neighbors.cpp:15-28             add_candidates_heaps: the selection half of
 //                                                       find_k_neighbors (its distance half is cblas_sgemm) (N1)
+//   x_norm_4, x_cross_norms(_4)  distances.hpp:51-57,151-176,185-208
+//                                                       norm_4 and compute_cross_dists_blas<DSQ> / <4> UP TO their cblas_sgemm call:
+//                                                       the norms and the ||v||^2 + ||c||^2 matrix sgemm receives as C (N4, round 6);
+//                                                       this file closes the two function bodies
 //   x_kmeans_update    databases.cpp:70-88             the centroid-update loops of kmeans_fast_iterations_thread, included
 //                                                       inside a harness function that declares the variables they use
 //                                                       under the reference's names (its assignment half is find_k_neighbors) (N4)
@@ -82,6 +86,11 @@
 #include "x_pq_files_a.inc"
 #include "x_pq_files_b.inc"
 #include "x_neighbors_heaps.inc"
+#include "x_norm_4.inc"
+#include "x_cross_norms.inc"
+}   // closes compute_cross_dists_blas<DSQ>: the range ends before its "BLAS Call" block (distances.hpp:178-183)
+#include "x_cross_norms_4.inc"
+}   // closes compute_cross_dists_blas<4> likewise (210-215)
 
 namespace {
 
@@ -344,6 +353,26 @@ void qadc_reff_select_k_neighbors(const float* dists, int count, int neighbor_co
         for (int v = 0; v < bv; ++v)
             heaps[v].sort(assign + static_cast<size_t>(v0 + v) * k, sorted + static_cast<size_t>(v0 + v) * k);
     }
+}
+
+// ---- N4: the encoder's distances up to the BLAS call.  find_k_neighbors (neighbors.cpp:30-76), which base_pq::encode_multiple_vectors
+// calls per sub-quantizer with k = 1 (quantizers.hpp:222-245), gets its distances from get_cross_dists_func(dim) =
+// compute_cross_dists_blas<dim> (distances.cpp:87-121): dists[v][c] = ||v||^2 + ||c||^2, then cblas_sgemm(alpha = -2, beta = 1)
+// adds -2 v.c.  This returns the matrix as it stands BEFORE the sgemm, computed by the reference's own text with its flags
+// (dists_dim = cent_count).  Returns 0, or -1 for a dimension outside the reference's dispatch.
+int qadc_reff_cross_norms(int DSQ, const float* centroids, int cent_count, const float* vectors, int vec_count, float* dists) {
+    switch (DSQ) {
+#define QADC_CN(D) case D: compute_cross_dists_blas<D>(dists, centroids, cent_count, vectors, vec_count, cent_count); return 0;
+        QADC_CN(4) QADC_CN(8) QADC_CN(16) QADC_CN(30) QADC_CN(32) QADC_CN(48) QADC_CN(60) QADC_CN(64) QADC_CN(96) QADC_CN(120)
+        QADC_CN(128) QADC_CN(192) QADC_CN(240) QADC_CN(256)
+#undef QADC_CN
+        default: return -1;
+    }
+}
+
+// extract_subvectors (quantizers.hpp:70-77 region): sub-vector sq_i of every vector, contiguous.
+void qadc_reff_extract_subvectors(const float* vectors, int dim, int count, int subq_dim, int sq_i, float* out) {
+    extract_subvectors(vectors, dim, count, subq_dim, sq_i, out);
 }
 
 // ---- N4: kmeans_fast_iterations_thread's centroid update (databases.cpp:70-88) as g++ compiles it with the reference's flags

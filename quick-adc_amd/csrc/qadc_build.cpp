@@ -9,6 +9,11 @@ using namespace qadc::host;
 extern "C" {
 
 int qadc_pq_encode(int M, int dim, const float* codebooks, const void* d_vectors, uint64_t n, void* d_codes, int device_id) {
+    return qadc_pq_encode_mode(M, dim, codebooks, d_vectors, n, d_codes, 1, 1, device_id);
+}
+
+int qadc_pq_encode_mode(int M, int dim, const float* codebooks, const void* d_vectors, uint64_t n, void* d_codes, int encode_form,
+                        int sum_mode, int device_id) {
     if ((M != 16 && M != 32) || dim <= 0 || dim % M != 0 || !codebooks || (n && (!d_vectors || !d_codes)))
         return fail(QADC_E_ARG, "bad arguments");
     HIPCHECK(hipSetDevice(device_id));
@@ -16,7 +21,8 @@ int qadc_pq_encode(int M, int dim, const float* codebooks, const void* d_vectors
     float* d_cb = nullptr;
     HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_cb), ncb * sizeof(float)));
     HIPCHECK(hipMemcpy(d_cb, codebooks, ncb * sizeof(float), hipMemcpyHostToDevice));
-    if (n) launch_pq_encode(static_cast<const float*>(d_vectors), n, M, dim, d_cb, static_cast<uint8_t*>(d_codes), nullptr);
+    if (n) launch_pq_encode(static_cast<const float*>(d_vectors), n, M, dim, d_cb, encode_form != 0, sum_mode != 0,
+                            static_cast<uint8_t*>(d_codes), nullptr);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipFree(d_cb));
@@ -24,6 +30,11 @@ int qadc_pq_encode(int M, int dim, const float* codebooks, const void* d_vectors
 }
 
 int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vectors, uint64_t n, uint8_t* codes, int device_id) {
+    return qadc_pq_encode_host_mode(M, dim, codebooks, vectors, n, codes, 1, 1, device_id);
+}
+
+int qadc_pq_encode_host_mode(int M, int dim, const float* codebooks, const float* vectors, uint64_t n, uint8_t* codes, int encode_form,
+                             int sum_mode, int device_id) {
     if (!vectors || !codes) return fail(QADC_E_ARG, "bad arguments");
     HIPCHECK(hipSetDevice(device_id));
     float* d_v = nullptr;
@@ -31,7 +42,7 @@ int qadc_pq_encode_host(int M, int dim, const float* codebooks, const float* vec
     HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_v), std::max<size_t>(1, n * dim * sizeof(float))));
     HIPCHECK(hipMalloc(reinterpret_cast<void**>(&d_c), std::max<size_t>(1, n * (M / 2))));
     HIPCHECK(hipMemcpy(d_v, vectors, n * dim * sizeof(float), hipMemcpyHostToDevice));
-    const int rc = qadc_pq_encode(M, dim, codebooks, d_v, n, d_c, device_id);
+    const int rc = qadc_pq_encode_mode(M, dim, codebooks, d_v, n, d_c, encode_form, sum_mode, device_id);
     if (rc == QADC_OK) HIPCHECK(hipMemcpy(codes, d_c, n * (M / 2), hipMemcpyDeviceToHost));
     HIPCHECK(hipFree(d_v));
     HIPCHECK(hipFree(d_c));
@@ -67,6 +78,12 @@ int assign_nearest(const float* d_vectors, uint64_t n, int dim, int K, const flo
 
 int qadc_ivf_encode_host(int M, int dim, const float* codebooks, const float* rotation, int K, const float* coarse,
                          const float* vectors, uint64_t n, int32_t* assign_out, uint8_t* codes, int device_id) {
+    return qadc_ivf_encode_host_mode(M, dim, codebooks, rotation, K, coarse, vectors, n, assign_out, codes, 1, 1, device_id);
+}
+
+int qadc_ivf_encode_host_mode(int M, int dim, const float* codebooks, const float* rotation, int K, const float* coarse,
+                              const float* vectors, uint64_t n, int32_t* assign_out, uint8_t* codes, int encode_form, int sum_mode,
+                              int device_id) {
     if ((M != 16 && M != 32) || dim <= 0 || dim % M != 0 || !codebooks || K < 0 || (K > 0 && !coarse) ||
         (n && (!vectors || !codes)))
         return fail(QADC_E_ARG, "bad arguments");
@@ -99,7 +116,7 @@ int qadc_ivf_encode_host(int M, int dim, const float* codebooks, const float* ro
         launch_residual_rotate(d_v, n, dim, d_coarse, d_assign, d_rot, d_x, nullptr);
         d_enc = d_x;
     }
-    if (n) launch_pq_encode(d_enc, n, M, dim, d_cb, d_codes, nullptr);
+    if (n) launch_pq_encode(d_enc, n, M, dim, d_cb, encode_form != 0, sum_mode != 0, d_codes, nullptr);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipMemcpy(codes, d_codes, n * (size_t)(M / 2), hipMemcpyDeviceToHost));

@@ -333,9 +333,10 @@ void launch_ivf_front_items(const int32_t* d_assign, const PartDesc* d_parts, in
 // Key range of d_vals[q][nvals] into QueryState::sel_nmin / sel_max (injected pre-scan values).
 void launch_prescan_minmax(const float* d_vals, uint32_t nvals, int nq, QueryState* d_qs, hipStream_t stream);
 
-// PQ encode of device-resident vectors [n][dim] with codebooks [M][16][dim/M] -> codes [n][M/2].
-void launch_pq_encode(const float* d_vectors, uint64_t n, int M, int dim, const float* d_codebooks, uint8_t* d_codes,
-                      hipStream_t stream);
+// PQ encode of device-resident vectors [n][dim] with codebooks [M][16][dim/M] -> codes [n][M/2].  form 1 = the reference's
+// (find_k_neighbors with k = 1 on the BLAS-expansion distances), 0 = direct sum (x - c)^2; sum_mode: the norms' grouping.
+void launch_pq_encode(const float* d_vectors, uint64_t n, int M, int dim, const float* d_codebooks, int form, int sum_mode,
+                      uint8_t* d_codes, hipStream_t stream);
 
 void launch_fill_codes(uint8_t* d_dst, uint64_t first_word, uint64_t nwords, uint64_t seed, hipStream_t stream);
 

@@ -2669,6 +2669,28 @@ __device__ __forceinline__ float direct_sqdist(const X& x, const C& c, int ds, i
     return (vec + p[2]) + (p[0] + p[1]);
 }
 
+// The BLAS-expansion distance compute_cross_dists_blas<DSQ> (distances.hpp:151-215) leaves in dists[v][c]:
+//   ||v||^2 + ||c||^2 (153-176), then cblas_sgemm(alpha = -2, beta = 1) adds -2 v.c (178-182).
+// expansion_sqnorm = fmanorm<DSQ/8, DSQ%8>(vec) / norm_4(vec) AS COMPILED with the reference's flags (sum_mode 1): the
+// grouping of direct_sqdist with c = 0 — pinned to the reference's own text compiled up to the sgemm call (oracle/_ref
+// qadc_reff_cross_norms, the 14 dimensions of its dispatch, 16 centroids) through the oracle's orc_sqnorm; host twin:
+// host/float_sum.hpp sqnorm.  sum_mode 0, or a remainder the reference has no instance of: one sequential sum.
+// The product is OpenBLAS's in the reference (not in this image: restated, unpinned): one sequential dot in ascending d,
+// then base + (-2 dot) — -2 dot is exact, so this is the single rounding of a gemm kernel's C += alpha * acc.
+struct zero_vec {
+    __device__ __forceinline__ float operator[](int) const { return 0.0f; }
+};
+template <typename X>
+__device__ __forceinline__ float expansion_sqnorm(const X& x, int ds, int sum_mode) {
+    return direct_sqdist(x, zero_vec{}, ds, sum_mode);
+}
+template <typename X, typename C>
+__device__ __forceinline__ float expansion_dist(const X& x, const C& c, int ds, float vn, float cn) {
+    float dot = 0.0f;
+    for (int d = 0; d < ds; ++d) dot += x[d] * c[d];
+    return (vn + cn) + (-2.0f * dot);
+}
+
 __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
                                                            const int32_t* __restrict__ assign,
                                                            const float* __restrict__ codebooks,
@@ -2704,16 +2726,10 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restri
         if (expansion) {
             // compute_cross_dists_blas (distances.hpp:151-183): ||v||^2 + ||c||^2, then sgemm(alpha = -2, beta = 1) adds
             // -2 v.c: the BLAS-expansion form nns_engine uses for ma > 1 and nns_engine_batch always.  It can come out
-            // slightly NEGATIVE when v ~ c — the case query_scan clamps (db_query_4.cpp:258-269).  Sequential sums,
-            // no contraction; host twin: pq4::tables_blas.
-            float vn = 0.0f, cn = 0.0f, dot = 0.0f;
-            for (int d = 0; d < ds; ++d) {
-                const float v = res[m * ds + d], c = ce[d];
-                vn += v * v;
-                cn += c * c;
-                dot += v * c;
-            }
-            s = (vn + cn) + (-2.0f * dot);
+            // slightly NEGATIVE when v ~ c — the case query_scan clamps (db_query_4.cpp:258-269).  Norms as compiled,
+            // sequential dot, no contraction (expansion_dist above); host twin: pq4::tables_blas.
+            const float* __restrict__ v = res + m * ds;
+            s = expansion_dist(v, ce, ds, expansion_sqnorm(v, ds, sum_mode), expansion_sqnorm(ce, ds, sum_mode));
         } else {
             s = direct_sqdist(res + m * ds, ce, ds, sum_mode);
         }
@@ -2750,22 +2766,18 @@ __global__ __launch_bounds__(256) void build_tables_multi_kernel(const float* __
         float ce[8];
 #pragma unroll
         for (int d = 0; d < 8; ++d) ce[d] = d < ds ? codebooks[(size_t)e * ds + d] : 0.0f;
-        float cn = 0.0f;                                         // (expansion form: ||c||^2 does not depend on the probe)
-#pragma unroll
-        for (int d = 0; d < 8; ++d)
-            if (d < ds) cn += ce[d] * ce[d];
+        // (expansion form: ||c||^2 does not depend on the probe; constant ds so that the lane loops unroll over the registers)
+        const float cn = !expansion ? 0.0f : ds == 8 ? expansion_sqnorm(ce, 8, sum_mode) : ds == 4 ? expansion_sqnorm(ce, 4, sum_mode)
+                                                                                          : expansion_sqnorm(ce, ds, 0);
         for (int a = 0; a < na; ++a) {
             const float* __restrict__ r = res + a * dim + m * ds;
             float s = 0.0f;
             if (expansion) {
-                float vn = 0.0f, dot = 0.0f;
+                const float vn = ds == 8 ? expansion_sqnorm(r, 8, sum_mode) : ds == 4 ? expansion_sqnorm(r, 4, sum_mode) : expansion_sqnorm(r, ds, 0);
+                float dot = 0.0f;
 #pragma unroll
                 for (int d = 0; d < 8; ++d)
-                    if (d < ds) {
-                        const float v = r[d];
-                        vn += v * v;
-                        dot += v * ce[d];
-                    }
+                    if (d < ds) dot += r[d] * ce[d];
                 s = (vn + cn) + (-2.0f * dot);
             } else if (ds == 8) {
                 s = direct_sqdist(r, ce, 8, sum_mode);               // (constant ds: the block loop unrolls over the registers)
@@ -2798,17 +2810,25 @@ void launch_build_tables(const float* d_queries, const float* d_coarse, const in
 }
 
 // ---------------------------------------------------------------------------------------------
-// PQ encoder (base_pq::encode_multiple_vectors, quantizers.hpp:222-245, for plain PQ):
-// nearest centroid per sub-quantizer (first minimum of the sequentially accumulated squared distance, as
-// host/query_driver.hpp pq4::encode), two sub-quantizers per byte: even one in the low nibble
-// (multiple_set_bits_4, quantizers.hpp:49-68).  One thread per code byte.
+// PQ encoder (base_pq::encode_multiple_vectors, quantizers.hpp:222-245): per sub-quantizer
+// find_k_neighbors(count, 16, sq_dim, k = 1, ...) (neighbors.cpp:30-76) — the BLAS-expansion distances of
+// compute_cross_dists_blas (expansion_dist above) pushed in centroid order into a kv_binheap of capacity 1
+// (add_candidates_heaps, 18-28; binheap.hpp:75-116): the first centroid is appended whatever its distance, a later one
+// replaces it iff its distance is strictly smaller — the first strict minimum, centroid 0 when its distance is NaN.
+// Two sub-quantizers per byte, the even one in the low nibble (multiple_set_bits_4, quantizers.hpp:49-68).
+// form 1 = that (the reference's form; parity: the oracle's orc_pq_encode, tests/test_gpu_parity.py); form 0 = the direct
+// sum (x - c)^2 in one sequential loop (this repository's encoder before round 6).  One thread per code byte.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pq_encode_kernel(const float* __restrict__ vectors, uint64_t n, int M, int dim,
-                                                        const float* __restrict__ codebooks, uint8_t* __restrict__ codes) {
+                                                        const float* __restrict__ codebooks, int form, int sum_mode,
+                                                        uint8_t* __restrict__ codes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     float* cb = reinterpret_cast<float*>(dyn);                // [M][16][ds]
+    float* cnorm = cb + (size_t)M * 16 * (dim / M);           // [M][16] ||c||^2 (form 1)
     const int ds = dim / M, cs = M / 2;
     for (int i = threadIdx.x; i < M * 16 * ds; i += 256) cb[i] = codebooks[i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < M * 16; e += 256) cnorm[e] = form ? expansion_sqnorm(cb + (size_t)e * ds, ds, sum_mode) : 0.0f;
     __syncthreads();
     const uint64_t total = n * (uint64_t)cs;
     for (uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (uint64_t)gridDim.x * 256) {
@@ -2818,16 +2838,21 @@ __global__ __launch_bounds__(256) void pq_encode_kernel(const float* __restrict_
         for (int h = 0; h < 2; ++h) {
             const int m = 2 * b + h;
             const float* __restrict__ x = vectors + vi * dim + (uint64_t)m * ds;
+            const float vn = form ? expansion_sqnorm(x, ds, sum_mode) : 0.0f;
             int best = 0;
-            float bestd = FLT_MAX;
+            float bestd = 0.0f;
             for (int c = 0; c < 16; ++c) {
                 const float* ce = cb + ((size_t)m * 16 + c) * ds;
                 float s = 0.0f;
-                for (int d = 0; d < ds; ++d) {
-                    const float t = x[d] - ce[d];
-                    s += t * t;
+                if (form) {
+                    s = expansion_dist(x, ce, ds, vn, cnorm[m * 16 + c]);
+                } else {
+                    for (int d = 0; d < ds; ++d) {
+                        const float t = x[d] - ce[d];
+                        s += t * t;
+                    }
                 }
-                if (s < bestd) { bestd = s; best = c; }
+                if (c == 0 || s < bestd) { bestd = s; best = c; }
             }
             packed |= (uint32_t)best << (4 * h);
         }
@@ -2835,12 +2860,12 @@ __global__ __launch_bounds__(256) void pq_encode_kernel(const float* __restrict_
     }
 }
 
-void launch_pq_encode(const float* d_vectors, uint64_t n, int M, int dim, const float* d_codebooks, uint8_t* d_codes,
-                      hipStream_t stream) {
+void launch_pq_encode(const float* d_vectors, uint64_t n, int M, int dim, const float* d_codebooks, int form, int sum_mode,
+                      uint8_t* d_codes, hipStream_t stream) {
     const uint64_t total = n * (uint64_t)(M / 2);
     const int grid = (int)std::min<uint64_t>((total + 255) / 256, 16384);
-    hipLaunchKernelGGL(pq_encode_kernel, dim3(grid), dim3(256), (size_t)M * 16 * (dim / M) * sizeof(float), stream, d_vectors, n,
-                       M, dim, d_codebooks, d_codes);
+    hipLaunchKernelGGL(pq_encode_kernel, dim3(grid), dim3(256), ((size_t)M * 16 * (dim / M) + (size_t)M * 16) * sizeof(float), stream,
+                       d_vectors, n, M, dim, d_codebooks, form, sum_mode, d_codes);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -20,6 +20,11 @@
 //                      (acc[j] + acc[j+4]; (r0+r2) + (r1+r3)); the scalar remainder is paired
 //                      p_k = fma(d_2k, d_2k, r(d_2k+1 * d_2k+1)) (d = c - x): REM 4 -> (p0+p1) + vec, REM 6 -> (vec+p2) + (p0+p1).
 //                      Other remainders (no instance in the reference's dispatch, distances.cpp:50-84): one sequential loop.
+//   sqnorm(x, ds)      fmanorm<ds/8, ds%8>(x) / norm_4(x) as compute_cross_dists_blas calls them (distances.hpp:151-215) for the
+//                      BLAS-expansion distances: the grouping of sqdist with c = 0 (norm_4: fma(x0,x0,r(x1*x1)) + fma(x2,x2,r(x3*x3))),
+//                      pinned to the reference's text compiled up to its sgemm call (oracle/_ref qadc_reff_cross_norms).
+//   expansion_dist(x, c, ds, vn, cn)   (vn + cn) - 2 x.c with ONE sequential dot: the sgemm(alpha = -2, beta = 1) that follows in
+//                      the reference is OpenBLAS's (restated, unpinned); -2 dot is exact, so the sum rounds once like C += alpha*acc.
 //
 // float_sum_mode() = 1 (default) selects these groupings; 0 = the source-order / sequential loops.
 #pragma once
@@ -79,6 +84,42 @@ inline float sqdist(const float* x, const float* c, int ds) {
     }
     if (rem == 4) return (p[0] + p[1]) + vec;
     return (vec + p[2]) + (p[0] + p[1]);
+}
+
+inline float sqnorm(const float* x, int ds) {
+    const int blocks = ds / 8, rem = ds % 8;
+    if (float_sum_mode() == 0 || !(rem == 0 || rem == 4 || rem == 6)) {
+        float s = 0;
+        for (int d = 0; d < ds; ++d) {
+            const float sq = x[d] * x[d];
+            s = s + sq;
+        }
+        return s;
+    }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < blocks; ++b)
+        for (int j = 0; j < 8; ++j) acc[j] = std::fma(x[b * 8 + j], x[b * 8 + j], acc[j]);
+    const float r0 = acc[0] + acc[4], r1 = acc[1] + acc[5], r2 = acc[2] + acc[6], r3 = acc[3] + acc[7];
+    const float vec = (r0 + r2) + (r1 + r3);
+    if (rem == 0) return vec;
+    float p[3] = {0, 0, 0};
+    for (int k = 0; k < rem / 2; ++k) {
+        const float sq1 = x[blocks * 8 + 2 * k + 1] * x[blocks * 8 + 2 * k + 1];
+        p[k] = std::fma(x[blocks * 8 + 2 * k], x[blocks * 8 + 2 * k], sq1);
+    }
+    if (rem == 4) return (p[0] + p[1]) + vec;
+    return (vec + p[2]) + (p[0] + p[1]);
+}
+
+inline float expansion_dist(const float* x, const float* c, int ds, float vn, float cn) {
+    float dot = 0;
+    for (int d = 0; d < ds; ++d) {
+        const float pr = x[d] * c[d];
+        dot = dot + pr;
+    }
+    const float base = vn + cn;
+    const float m2 = -2.0f * dot;
+    return base + m2;
 }
 
 }  // namespace qadc

@@ -13,8 +13,9 @@
 //   process_queries  fresh heap per query, recall = true nearest neighbour among the R returned keys,
 //                  averaged metrics (query_common.hpp:330-368) and the CSV line of db_query_4.cpp:387-390
 // The direct table form (ma == 1: pq4::tables_direct) adds like the reference's AVX/FMA kernel as compiled
-// (host/float_sum.hpp, pinned to the reference build by the oracle's tests).  The BLAS-expansion form, the OPQ
-// rotation and the coarse assignment go through OpenBLAS in the reference and are NOT pinned (sequential sums here).
+// (host/float_sum.hpp, pinned to the reference build by the oracle's tests).  The BLAS-expansion form's norm half is pinned
+// the same way; its product, the OPQ rotation and the coarse distances go through OpenBLAS in the reference and are NOT
+// pinned (sequential sums here).
 #pragma once
 #include <sys/time.h>
 
@@ -66,9 +67,8 @@ struct pq4 {
     int table_dim() const { return sq_count * 16; }
     const float* centroid(int m, int c) const { return centroids.data() + ((size_t)m * 16 + c) * sq_dim(); }
 
-    // tables[m][c] = ||x_m - centroid(m,c)||^2, one sequential sum in ascending d: the encoder's distances (the
-    // reference encodes through find_k_neighbors' BLAS products, neighbors.cpp:30-76 — unpinned; the device encoder adds
-    // in this order)
+    // tables[m][c] = ||x_m - centroid(m,c)||^2, one sequential sum in ascending d: the direct-form encoder's distances
+    // (encode_form 0; this repository's encoder before round 6)
     void tables(const float* x, float* out) const {
         const int ds = sq_dim();
         for (int m = 0; m < sq_count; ++m)
@@ -95,31 +95,31 @@ struct pq4 {
     // distances.hpp:151-183, 277-292): per sub-quantizer ||v||^2 + ||c||^2 first, then sgemm(alpha = -2, beta = 1) adds
     // -2 v.c.  What nns_engine evaluates for ma > 1 and nns_engine_batch always (query_common.hpp:194-213, 292-297).
     // Cancellation makes entries slightly NEGATIVE when v ~ c: the case scanner_4::query_scan clamps in place
-    // (db_query_4.cpp:258-269).  Sequential float sums (the device twin, build_tables_kernel, adds in the same order;
-    // OpenBLAS associates differently, so this form is bit-compatible with the device, not with the reference binary).
+    // (db_query_4.cpp:258-269).  The norms add as the reference is compiled (float_sum.hpp sqnorm, pinned); the product is
+    // one sequential dot (OpenBLAS's sgemm in the reference: restated).  The device twin, build_tables_kernel, adds in
+    // the same order: bit-compatible with the device and the oracle's orc_tables_expansion.
     void tables_blas(const float* vecs, int count, float* out) const {
         const int ds = sq_dim();
+        std::vector<float> cn((size_t)sq_count * 16);
+        for (int e = 0; e < sq_count * 16; ++e) cn[e] = sqnorm(centroids.data() + (size_t)e * ds, ds);
         for (int v = 0; v < count; ++v) {
             const float* x = vecs + (size_t)v * dim;
             float* o = out + (size_t)v * sq_count * 16;
-            for (int m = 0; m < sq_count; ++m)
-                for (int c = 0; c < 16; ++c) {
-                    const float* ce = centroid(m, c);
-                    float vn = 0, cn = 0, dot = 0;
-                    for (int d = 0; d < ds; ++d) {
-                        vn += x[m * ds + d] * x[m * ds + d];
-                        cn += ce[d] * ce[d];
-                        dot += x[m * ds + d] * ce[d];
-                    }
-                    o[m * 16 + c] = (vn + cn) + (-2.0f * dot);
-                }
+            for (int m = 0; m < sq_count; ++m) {
+                const float vn = sqnorm(x + m * ds, ds);
+                for (int c = 0; c < 16; ++c) o[m * 16 + c] = expansion_dist(x + m * ds, centroid(m, c), ds, vn, cn[m * 16 + c]);
+            }
         }
     }
 
-    // nearest centroid per sub-quantizer (first minimum), packed two per byte: even sub-quantizer in the low
-    // nibble, odd one in the high nibble of byte m/2 (multiple_set_bits_4, quantizers.hpp:49-68)
+    // encode_multiple_vectors (quantizers.hpp:222-245): rotate (opq), then per sub-quantizer find_k_neighbors with k = 1
+    // (neighbors.cpp:30-76) on the BLAS-expansion distances — a capacity-1 kv_binheap fed in centroid order keeps the
+    // first strict minimum (centroid 0 when its distance is NaN) — packed two per byte: even sub-quantizer in the low
+    // nibble, odd one in the high nibble of byte m/2 (multiple_set_bits_4, quantizers.hpp:49-68).
+    // encode_form 1 = that; 0 = the direct form of tables().  Device twin: pq_encode_kernel; oracle: orc_pq_encode.
+    int encode_form = 1;
     void encode(const float* vecs, size_t n, std::uint8_t* codes) const {
-        const int ds = sq_dim(), cs = code_size();
+        const int cs = code_size();
         std::vector<float> t((size_t)sq_count * 16), rot;
         for (size_t i = 0; i < n; ++i) {
             const float* x = vecs + i * dim;
@@ -128,7 +128,8 @@ struct pq4 {
                 rotate_multiple_vectors(rot.data(), 1);
                 x = rot.data();
             }
-            tables(x, t.data());
+            if (encode_form) tables_blas(x, 1, t.data());
+            else tables(x, t.data());
             std::uint8_t* code = codes + i * cs;
             for (int m = 0; m < sq_count; ++m) {
                 int best = 0;
@@ -138,7 +139,6 @@ struct pq4 {
                 else code[m / 2] = (std::uint8_t)(code[m / 2] | (best << 4));
             }
         }
-        (void)ds;
     }
 };
 

@@ -97,26 +97,24 @@ struct pq_bytes {
     }
     void tables_direct(const float* x, float* out) const { tables(x, out); }   // the engine's name for the ma == 1 form
     void tables_blas(const float* vecs, int count, float* out) const {   // (||v||^2 + ||c||^2) - 2 v.c, distances.hpp:151-183
-        const int ds = sq_dim(), nc = ncent();
+        const int ds = sq_dim(), nc = ncent();                           // (norms as compiled, one sequential dot: float_sum.hpp)
+        std::vector<float> cn((std::size_t)sq_count * nc);
+        for (int e = 0; e < sq_count * nc; ++e) cn[e] = sqnorm(centroids.data() + (std::size_t)e * ds, ds);
         for (int v = 0; v < count; ++v)
-            for (int m = 0; m < sq_count; ++m)
-                for (int c = 0; c < nc; ++c) {
-                    const float* x = vecs + (std::size_t)v * dim + m * ds;
-                    const float* ce = centroid(m, c);
-                    float vn = 0, cn = 0, dot = 0;
-                    for (int d = 0; d < ds; ++d) {
-                        vn += x[d] * x[d];
-                        cn += ce[d] * ce[d];
-                        dot += x[d] * ce[d];
-                    }
-                    out[((std::size_t)v * sq_count + m) * nc + c] = (vn + cn) + (-2.0f * dot);
-                }
+            for (int m = 0; m < sq_count; ++m) {
+                const float* x = vecs + (std::size_t)v * dim + m * ds;
+                const float vn = sqnorm(x, ds);
+                for (int c = 0; c < nc; ++c)
+                    out[((std::size_t)v * sq_count + m) * nc + c] = expansion_dist(x, centroid(m, c), ds, vn, cn[m * nc + c]);
+            }
     }
-    void encode(const float* vecs, std::size_t n, std::uint8_t* codes) const {   // nearest centroid, first minimum
+    // encode_multiple_vectors (quantizers.hpp:222-245): find_k_neighbors with k = 1 on the expansion distances = their first
+    // strict minimum in centroid order
+    void encode(const float* vecs, std::size_t n, std::uint8_t* codes) const {
         const int nc = ncent(), cs = code_size();
         std::vector<float> t((std::size_t)table_dim());
         for (std::size_t i = 0; i < n; ++i) {
-            tables(vecs + i * dim, t.data());
+            tables_blas(vecs + i * dim, 1, t.data());
             for (int m = 0; m < sq_count; ++m) {
                 int best = 0;
                 for (int c = 1; c < nc; ++c)

@@ -32,7 +32,7 @@ SYMBOLS = [
     "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit", "qadc_prescan_submit",
     "qadc_prescan_collect", "qadc_query_scan_submit_prescanned",
     "qadc_query_scan_collect", "qadc_index_set_pq", "qadc_index_set_rotation", "qadc_index_set_coarse", "qadc_search", "qadc_search_submit",
-    "qadc_search_collect", "qadc_device_prepare", "qadc_stream_probe", "qadc_stream_layout", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_kmeans_iterations_host", "qadc_kmeans_iterations_host_mode", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
+    "qadc_search_collect", "qadc_device_prepare", "qadc_stream_probe", "qadc_stream_layout", "qadc_pq_encode", "qadc_pq_encode_host", "qadc_ivf_encode_host", "qadc_pq_encode_mode", "qadc_pq_encode_host_mode", "qadc_ivf_encode_host_mode", "qadc_kmeans_iterations_host", "qadc_kmeans_iterations_host_mode", "qadc_replay_i8", "qadc_sort_keys_i8", "qadc_merge_streams_i8", "qadc_candidates_i8", "qadc_float_top1", "qadc_profile_read", "qadc_profile_reset",
     "qadc_dist_unique_id", "qadc_dist_init", "qadc_dist_collect", "qadc_dist_shutdown", "qadc_dist_merge_blocks", "qadc_dist_merge_blocks_host",
     "qadc_dist_init_transport", "qadc_dist_init_loopback", "qadc_shm_transport_open", "qadc_shm_transport_allgather", "qadc_shm_transport_allgather_host",
     "qadc_shm_transport_close", "qadc_shm_transport_error", "qadc_slot_assign", "qadc_slot_qtables", "qadc_place_partitions",
@@ -116,6 +116,10 @@ def lib():
         L.qadc_pq_encode.argtypes = [C.c_int, C.c_int, f32p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.qadc_pq_encode_host.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_uint64, u8p, C.c_int]
         L.qadc_ivf_encode_host.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_int, f32p, f32p, C.c_uint64, i32p, u8p, C.c_int]
+        L.qadc_pq_encode_mode.argtypes = [C.c_int, C.c_int, f32p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.qadc_pq_encode_host_mode.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_int]
+        L.qadc_ivf_encode_host_mode.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_int, f32p, f32p, C.c_uint64, i32p, u8p, C.c_int, C.c_int,
+                                                C.c_int]
         L.qadc_kmeans_iterations_host.argtypes = [f32p, C.c_uint64, C.c_int, C.c_int, f32p, C.c_int, i32p, C.c_int]
         L.qadc_kmeans_iterations_host_mode.argtypes = [f32p, C.c_uint64, C.c_int, C.c_int, f32p, C.c_int, i32p, C.c_int, C.c_int]
         L.qadc_replay_i8.argtypes = [C.c_uint64, u32p, i8p, C.c_int, C.c_int, u32p, i8p, i32p]
@@ -271,9 +275,9 @@ def merge_streams_i8(gathered, world, nq, R, cap, ma, q_first, q_step, status, k
                                        _p(keys, u32p), _p(vals, i8p), _p(sizes, i32p)))
 
 
-def ivf_encode(codebooks, vectors, coarse=None, rotation=None, device=0):
+def ivf_encode(codebooks, vectors, coarse=None, rotation=None, device=0, encode_form=1, sum_mode=1):
     """index_db::add_vectors' compute on the GPU: nearest coarse centroid, residual, optional OPQ rotation, PQ encode.
-    -> (assign int32 [n] or None for a flat database, codes uint8 [n][M/2])."""
+    -> (assign int32 [n] or None for a flat database, codes uint8 [n][M/2]).  encode_form / sum_mode: see pq_encode."""
     cb = np.ascontiguousarray(codebooks, np.float32)
     v = np.ascontiguousarray(vectors, np.float32)
     M, dim, n = cb.shape[0], v.shape[1], v.shape[0]
@@ -283,8 +287,8 @@ def ivf_encode(codebooks, vectors, coarse=None, rotation=None, device=0):
     K = 0 if co is None else co.shape[0]
     assign = np.zeros(n, np.int32) if K else None
     codes = np.zeros((n, M // 2), np.uint8)
-    _check(lib().qadc_ivf_encode_host(M, dim, _p(cb, f32p), _p(rot, f32p), K, _p(co, f32p), _p(v, f32p), n, _p(assign, i32p),
-                                      _p(codes, u8p), device))
+    _check(lib().qadc_ivf_encode_host_mode(M, dim, _p(cb, f32p), _p(rot, f32p), K, _p(co, f32p), _p(v, f32p), n, _p(assign, i32p),
+                                           _p(codes, u8p), encode_form, sum_mode, device))
     return assign, codes
 
 
@@ -299,13 +303,14 @@ def kmeans_iterations(vectors, centroids, iters, device=0, div_mode=1):
     return c, assign
 
 
-def pq_encode(codebooks, vectors, device=0):
-    """PQ-encode host vectors [n][dim] on the GPU -> uint8 codes [n][M/2]."""
+def pq_encode(codebooks, vectors, device=0, encode_form=1, sum_mode=1):
+    """PQ-encode host vectors [n][dim] on the GPU -> uint8 codes [n][M/2].  encode_form 1 (default) = the reference's form
+    (find_k_neighbors with k = 1 on the BLAS-expansion distances), 0 = direct sum (x - c)^2; sum_mode 1 = norms as compiled."""
     cb = np.ascontiguousarray(codebooks, np.float32)
     v = np.ascontiguousarray(vectors, np.float32)
     M, dim = cb.shape[0], v.shape[1]
     codes = np.zeros((v.shape[0], M // 2), np.uint8)
-    _check(lib().qadc_pq_encode_host(M, dim, _p(cb, f32p), _p(v, f32p), v.shape[0], _p(codes, u8p), device))
+    _check(lib().qadc_pq_encode_host_mode(M, dim, _p(cb, f32p), _p(v, f32p), v.shape[0], _p(codes, u8p), encode_form, sum_mode, device))
     return codes
 
 

@@ -119,7 +119,8 @@ CASES = ["flat32", "ivf_lanes", "ivf_whole", "ivf_search", "ivf_search_whole", "
 
 def search_inputs(case):
     """assign[] and float tables of a queries-in case, evaluated by the same sequential float loops as the device feeders
-    (and host/query_driver.hpp): squared L2 in ascending d, lowest index on ties; BLAS-expansion tables for ma > 1."""
+    (and host/query_driver.hpp): squared L2 in ascending d, lowest index on ties; BLAS-expansion tables for ma > 1 (the
+    oracle's orc_tables_expansion)."""
     q, coarse, cb, ma, M = case["queries"], case["coarse"], case["codebooks"], case["search_ma"], case["M"]
     K, dim = coarse.shape
     ds = dim // M
@@ -131,16 +132,6 @@ def search_inputs(case):
             s_ = (s_ + (t * t).astype(np.float32)).astype(np.float32)
         return s_
 
-    def expansion(x, c_):
-        vn = np.zeros(np.broadcast_shapes(x.shape[:-1], c_.shape[:-1]), np.float32)
-        cn, dot = np.zeros_like(vn), np.zeros_like(vn)
-        for d in range(c_.shape[-1]):
-            xv, cv = x[..., d].astype(np.float32), c_[..., d].astype(np.float32)
-            vn = (vn + (xv * xv).astype(np.float32)).astype(np.float32)
-            cn = (cn + (cv * cv).astype(np.float32)).astype(np.float32)
-            dot = (dot + (xv * cv).astype(np.float32)).astype(np.float32)
-        return ((vn + cn).astype(np.float32) + (np.float32(-2.0) * dot).astype(np.float32)).astype(np.float32)
-
     import pyoracle                                              # (the checker's side only: the workers never call this function)
     nq = q.shape[0]
     assign = np.zeros((nq, ma), np.int32)
@@ -150,5 +141,5 @@ def search_inputs(case):
         assign[i] = pyoracle.select_k_neighbors(dist, ma)[0][0]     # find_k_neighbors' heaps (exact ties: as the reference leaves them)
         resid = (q[i][None, :] - coarse[assign[i]]).astype(np.float32)
         for a in range(ma):
-            tables[i, a] = expansion(resid[a].reshape(M, 1, ds), cb).reshape(-1)
+            tables[i, a] = pyoracle.tables_expansion(cb, resid[a])[0]
     return assign, tables

@@ -24,14 +24,10 @@ def _seq_sqdist(x, c):
 
 
 def _seq_expansion(x, c):
-    vn = np.zeros(np.broadcast_shapes(x.shape[:-1], c.shape[:-1]), np.float32)
-    cn, dot = np.zeros_like(vn), np.zeros_like(vn)
-    for d in range(c.shape[-1]):
-        xv, cv = x[..., d].astype(np.float32), c[..., d].astype(np.float32)
-        vn = (vn + (xv * xv).astype(np.float32)).astype(np.float32)
-        cn = (cn + (cv * cv).astype(np.float32)).astype(np.float32)
-        dot = (dot + (xv * cv).astype(np.float32)).astype(np.float32)
-    return ((vn + cn).astype(np.float32) + (np.float32(-2.0) * dot).astype(np.float32)).astype(np.float32)
+    """The BLAS-expansion table form of one residual (x [M][1][ds], c = codebooks [M][16][ds]) -> [M][16]: the ORACLE's
+    orc_tables_expansion (norm half pinned to the reference as compiled, the sgemm's product one sequential dot)."""
+    import pyoracle
+    return pyoracle.tables_expansion(c, x.reshape(-1)).reshape(c.shape[0], 16)
 
 
 def _build(pyqadc, rng, M, K, N, dim, keep):

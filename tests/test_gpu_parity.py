@@ -346,17 +346,11 @@ def _seq_sqdist(x, c):
 
 
 def _seq_expansion(x, c):
-    """(||x||^2 + ||c||^2) + (-2 x.c), every sum accumulated in float32 in ascending d: the BLAS-expansion table
-    form (distances.hpp:151-183) as the device feeder and host/query_driver.hpp evaluate it."""
-    vn = np.zeros(np.broadcast_shapes(x.shape[:-1], c.shape[:-1]), np.float32)
-    cn = np.zeros_like(vn)
-    dot = np.zeros_like(vn)
-    for d in range(c.shape[-1]):
-        xv, cv = x[..., d].astype(np.float32), c[..., d].astype(np.float32)
-        vn = (vn + (xv * xv).astype(np.float32)).astype(np.float32)
-        cn = (cn + (cv * cv).astype(np.float32)).astype(np.float32)
-        dot = (dot + (xv * cv).astype(np.float32)).astype(np.float32)
-    return ((vn + cn).astype(np.float32) + (np.float32(-2.0) * dot).astype(np.float32)).astype(np.float32)
+    """The BLAS-expansion table form (distances.hpp:151-183, 277-292) of one vector (x [M][1][ds], c = codebooks
+    [M][16][ds]) -> [M][16], from the ORACLE (orc_tables_expansion: (||x||^2 + ||c||^2) with the norms as the reference
+    compiles them, then -2 x.c as one sequential dot): what the device feeder and host/query_driver.hpp must reproduce."""
+    import pyoracle
+    return pyoracle.tables_expansion(c, x.reshape(-1)).reshape(c.shape[0], 16)
 
 
 @pytest.mark.parametrize("form", [0, 1, 2])
@@ -492,23 +486,56 @@ def test_many_indexes_create_destroy(pyqadc, po):
         idx.close()
 
 
-@pytest.mark.parametrize("M", [16, 32])
-def test_pq_encode_matches_host_loops(pyqadc, M):
-    """N4: device PQ encoder == first-minimum of the sequentially accumulated squared distances, packed
-    low nibble = even sub-quantizer (numpy restatement of the host loop)."""
-    rng = np.random.default_rng(M)
-    dim, n = 128, 20000
-    ds = dim // M
-    cb = rng.normal(size=(M, 16, ds)).astype(np.float32)
-    cb[3, 7] = cb[3, 2]                                       # duplicate centroid: ties must resolve to the first
-    v = rng.normal(size=(n, dim)).astype(np.float32)
-    got = pyqadc.pq_encode(cb, v)
-    best = np.zeros((n, M), np.int64)
-    for m in range(M):
-        d = _seq_sqdist(v[:, None, m * ds:(m + 1) * ds], cb[m][None, :, :])      # [n][16]
-        best[:, m] = np.argmin(d, axis=1)                     # first minimum
-    want = (best[:, 0::2] | (best[:, 1::2] << 4)).astype(np.uint8)
-    assert np.array_equal(got, want)
+def test_pq_encode_writes_the_reference_codes_golden(pyqadc, po):
+    """N4: qadc_pq_encode / qadc_ivf_encode_host (OPQ cases) write the codes of tests/golden/ref_encode_cases.npz — made by the
+    reference's own extract_subvectors, compute_cross_dists_blas (up to its sgemm), add_candidates_heaps and
+    multiple_set_bits_4 (oracle/gen_golden_encode.py) — on normal, grid-valued (exact ties), duplicate-centroid,
+    midpoint and cancellation-dominated inputs, M = 16 / 32, sq_dim 4 ... 60, with and without OPQ; encode_form 0 writes
+    the oracle's direct-form codes, which differ from the reference's on the last two kinds."""
+    import golden_cases
+    ncase = differs = 0
+    for c in golden_cases.encode_cases():
+        cb, v, rot = c["codebooks"], c["vectors"], c["rotation"]
+        if rot is None:
+            got = pyqadc.pq_encode(cb, v)
+            got0 = pyqadc.pq_encode(cb, v, encode_form=0)
+        else:
+            got = pyqadc.ivf_encode(cb, v, rotation=rot)[1]
+            got0 = pyqadc.ivf_encode(cb, v, rotation=rot, encode_form=0)[1]
+        assert np.array_equal(got, c["codes"]), c["cid"]
+        assert np.array_equal(got0, po.pq_encode(cb, v, rot, form=0)), c["cid"]
+        differs += int((got0 != got).any())
+        ncase += 1
+    assert ncase == 15 and differs >= 4
+
+
+@pytest.mark.parametrize("M,dim", [(16, 128), (32, 128), (32, 96), (16, 64), (16, 480)])
+@pytest.mark.parametrize("kind", ["normal", "grid", "offset", "mid"])
+def test_pq_encode_matches_the_oracle_encoder(pyqadc, po, M, dim, kind):
+    """N4 at larger counts: device encoder == the ORACLE's orc_pq_encode (expansion distances, find_k_neighbors' k = 1
+    selection through the pinned heap restatement, packed) — not a numpy copy of the kernel's loop — on tie-heavy
+    grid-valued vectors, vectors exactly between two centroids, and vectors whose expansion is all cancellation; sq_dim 3
+    (BASELINE configs[4]: no instance in the reference, sequential norms) included; sum_mode 0 likewise."""
+    rng = np.random.default_rng(M * 1000 + dim + len(kind))
+    n, ds = 20000, dim // M
+    if kind == "grid":
+        cb, v = rng.integers(0, 3, (M, 16, ds)).astype(np.float32), rng.integers(0, 3, (n, dim)).astype(np.float32)
+        cb[:, 7] = cb[:, 2]
+    elif kind == "offset":
+        cb = (100 + 0.01 * rng.normal(size=(M, 16, ds))).astype(np.float32)
+        v = (100 + 0.01 * rng.normal(size=(n, dim))).astype(np.float32)
+    else:
+        cb, v = rng.normal(size=(M, 16, ds)).astype(np.float32), rng.normal(size=(n, dim)).astype(np.float32)
+        cb[3, 7] = cb[3, 2]                                   # duplicate centroid: ties must resolve to the first
+    if kind == "mid":
+        m = rng.integers(0, M, n)
+        ab = np.stack([rng.choice(16, 2, replace=False) for _ in range(n)])
+        for i in range(n):
+            v[i, m[i] * ds:(m[i] + 1) * ds] = (cb[m[i], ab[i, 0]] + cb[m[i], ab[i, 1]]) * np.float32(0.5)
+    want = po.pq_encode(cb, v)
+    assert np.array_equal(pyqadc.pq_encode(cb, v), want)
+    assert np.array_equal(pyqadc.pq_encode(cb, v, sum_mode=0), po.pq_encode(cb, v, sum_mode=0))
+    assert np.array_equal(pyqadc.pq_encode(cb, v, encode_form=0), po.pq_encode(cb, v, form=0))
 
 
 @pytest.mark.parametrize("M", [16, 32])
@@ -1693,7 +1720,9 @@ def test_coarse_assignment_with_exact_distance_ties_is_find_k_neighbors(pyqadc, 
 @pytest.mark.gpu
 def test_ivf_encode_and_kmeans_iterations_match_numpy(pyqadc):
     """N4 through ctypes: qadc_ivf_encode_host (nearest centroid, residual, OPQ rotation, PQ encode) and
-    qadc_kmeans_iterations_host against numpy evaluations of the same sequential loops."""
+    qadc_kmeans_iterations_host: assignment and residual against numpy evaluations of the same sequential loops, the codes
+    against the ORACLE's encoder (orc_pq_encode with the rotation) fed with those residuals."""
+    import pyoracle as po
     rng = np.random.default_rng(99)
     M, dim, K, n = 16, 32, 50, 3000
     cb = rng.normal(size=(M, 16, dim // M)).astype(np.float32)
@@ -1701,28 +1730,17 @@ def test_ivf_encode_and_kmeans_iterations_match_numpy(pyqadc):
     rot = (rng.normal(size=(dim, dim)) * 0.3).astype(np.float32)
     v = rng.normal(size=(n, dim)).astype(np.float32)
     assign, codes = pyqadc.ivf_encode(cb, v, coarse=coarse, rotation=rot)
-    for i in list(range(0, n, 97)) + [n - 1]:
-        d = _seq_sqdist(v[i][None, :], coarse)
-        a = int(np.lexsort((np.arange(K), d))[0])
-        assert assign[i] == a
-        res = (v[i] - coarse[a]).astype(np.float32)
-        x = np.zeros(dim, np.float32)
-        for r in range(dim):
-            acc = np.float32(0)
-            for c in range(dim):
-                acc = np.float32(acc + np.float32(res[c] * rot[r, c]))
-            x[r] = acc
-        t = _seq_sqdist(x.reshape(M, 1, dim // M), cb)          # [M][16]
-        best = np.array([int(np.lexsort((np.arange(16), t[m]))[0]) for m in range(M)])
-        want = (best[0::2] | (best[1::2] << 4)).astype(np.uint8)
-        assert np.array_equal(codes[i], want), i
+    want_assign = np.array([int(np.lexsort((np.arange(K), _seq_sqdist(v[i][None, :], coarse)))[0]) for i in range(n)])
+    assert np.array_equal(assign, want_assign)
+    res = (v - coarse[want_assign]).astype(np.float32)
+    assert np.array_equal(codes, po.pq_encode(cb, res, rot))
+    assert np.array_equal(pyqadc.ivf_encode(cb, v, coarse=coarse, rotation=rot, encode_form=0)[1], po.pq_encode(cb, res, rot, form=0))
     # flat database: no assignment, no residual
     _, codes_flat = pyqadc.ivf_encode(cb, v[:100])
     assert np.array_equal(codes_flat, pyqadc.pq_encode(cb, v[:100]))
     # two k-means rounds from the first K vectors: the update as the reference is COMPILED (sum * (1 / count): -ffast-math) by
     # default — checked against the reference's own loops compiled into oracle/_ref where that library is present — and as its
     # source reads (sum / count) with div_mode 0
-    import pyoracle as po
     for mode in (1, 0):
         cen, asg = pyqadc.kmeans_iterations(v, v[:K], 2, div_mode=mode)
         c = v[:K].copy()

@@ -303,6 +303,65 @@ def test_coarse_selection_against_the_reference_heaps(po):
     assert ndiff >= 10
 
 
+# ------------------------------------------------------------------------------------------------ N4: the encoder
+def _seq_rotate(po, v, rot):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("gen_golden_encode", os.path.join(os.path.dirname(po.__file__), "gen_golden_encode.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.seq_rotate(v, rot)
+
+
+def test_oracle_encoder_matches_reference_golden(po):
+    """orc_pq_encode (find_k_neighbors with k = 1 on the BLAS-expansion distances) writes the codes of
+    tests/golden/ref_encode_cases.npz — the chain of the reference's own extract_subvectors, compute_cross_dists_blas up to
+    its sgemm, add_candidates_heaps and multiple_set_bits_4 — and orc_cross_dists' norm half is that matrix bit for bit.
+    Runs everywhere.  The direct form (what this repository encoded with before round 6) writes OTHER codes on the
+    cancellation-dominated and the midpoint cases: the fixtures can tell the forms apart."""
+    ncase = direct_differs = 0
+    for c in golden_cases.encode_cases():
+        M, ds = c["M"], c["dim"] // c["M"]
+        assert np.array_equal(po.pq_encode(c["codebooks"], c["vectors"], c["rotation"]), c["codes"]), c["cid"]
+        x = c["vectors"] if c["rotation"] is None else _seq_rotate(po, c["vectors"], c["rotation"])
+        for m in range(M):
+            sub = x[:c["norms"].shape[1], m * ds:(m + 1) * ds]
+            assert np.array_equal(po.cross_dists(c["codebooks"][m], sub, with_product=False), c["norms"][m]), (c["cid"], m)
+        direct_differs += int((po.pq_encode(c["codebooks"], c["vectors"], c["rotation"], form=0) != c["codes"]).any())
+        ncase += 1
+    assert ncase == 15 and direct_differs >= 4
+
+
+def test_cross_norms_match_the_reference_as_compiled(po):
+    """||v||^2 + ||c||^2 as compute_cross_dists_blas<DSQ> hands it to sgemm, for every DSQ of get_cross_dists_func
+    (distances.cpp:87-121) and 16 centroids: the reference's text compiled up to the sgemm call vs orc_cross_dists.  The
+    source-order sum (sum_mode 0) is NOT what the binary computes."""
+    _need_ref_float(po)
+    rng = np.random.default_rng(151)
+    for ds in (4, 8, 16, 30, 32, 48, 60, 64, 96, 120, 128, 192, 240, 256):
+        c = (rng.normal(size=(16, ds)) * rng.choice([0.01, 1.0, 30.0])).astype(np.float32)
+        v = (rng.normal(size=(2000, ds)) * rng.choice([0.01, 1.0, 30.0])).astype(np.float32)
+        want = po.reff_cross_norms(c, v)
+        assert np.array_equal(po.cross_dists(c, v, with_product=False), want), ds
+        assert not np.array_equal(po.cross_dists(c, v, sum_mode=0, with_product=False), want), ds
+    assert po.reff_cross_norms(np.zeros((16, 3), np.float32), np.zeros((1, 3), np.float32)) is None   # (no instance: sequential here)
+
+
+def test_expansion_tables_are_the_cross_dists_per_sub_quantizer(po):
+    """orc_tables_expansion (compute_dists_multiple_blas_cg, distances.hpp:277-292) = orc_cross_dists of every
+    sub-quantizer's 16 centroids, laid out [count][M*16]; its norm half equals the reference's."""
+    rng = np.random.default_rng(9)
+    for M, ds in ((16, 8), (32, 4), (32, 3), (16, 30)):
+        cb = rng.normal(size=(M, 16, ds)).astype(np.float32)
+        v = rng.normal(size=(50, M * ds)).astype(np.float32)
+        t = po.tables_expansion(cb, v).reshape(50, M, 16)
+        for m in range(M):
+            assert np.array_equal(t[:, m], po.cross_dists(cb[m], v[:, m * ds:(m + 1) * ds])), (M, m)
+            if po.have_ref_float() and ds != 3:
+                assert np.array_equal(po.cross_dists(cb[m], v[:, m * ds:(m + 1) * ds], with_product=False),
+                                      po.reff_cross_norms(cb[m], v[:, m * ds:(m + 1) * ds]))
+
+
 def test_kmeans_centroid_update_as_compiled(po):
     """N4: kmeans_fast_iterations_thread's centroid update (databases.cpp:70-88).  The source divides every component by the member
     count; the reference binary (-ffast-math) multiplies by ONE reciprocal per centroid — a different float in a good part of the
@@ -360,7 +419,8 @@ def test_extraction_refuses_a_drifted_reference(tmp_path):
     assert r.returncode != 0 and b"the reference changed" in r.stderr
 
 
-@pytest.mark.parametrize("script,committed", [("gen_golden_float.py", "ref_query_scan_cases.npz"), ("gen_golden.py", "ref_scan_cases.npz")])
+@pytest.mark.parametrize("script,committed", [("gen_golden_float.py", "ref_query_scan_cases.npz"), ("gen_golden.py", "ref_scan_cases.npz"),
+                                              ("gen_golden_encode.py", "ref_encode_cases.npz")])
 def test_golden_fixtures_regenerate_from_the_reference_build(po, tmp_path, script, committed):
     """The committed fixtures ARE what the generators produce from the reference build today: every array, bit for bit."""
     import os

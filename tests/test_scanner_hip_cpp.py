@@ -328,6 +328,51 @@ def test_db_query_cpu_front_end_matches_the_oracle(po, tmp_path, M, bits, batch)
         assert np.array_equal(keys, wk) and np.array_equal(vals, wv), q
 
 
+ENCODE_DEMO = os.path.join(ROOT, "tests", "cpp", "encode_demo")
+
+
+def _run_encode_demo(tmp_path, cb, v, rot=None, bits=4, form=1):
+    M, nc, ds = cb.shape
+    n, dim = v.shape
+    fin, fout = str(tmp_path / "enc_in.bin"), str(tmp_path / "enc_out.bin")
+    with open(fin, "wb") as fh:
+        fh.write(np.array([M, bits, dim, n, form, 0 if rot is None else 1], np.int32).tobytes() + cb.tobytes() +
+                 (b"" if rot is None else rot.tobytes()) + v.tobytes())
+    subprocess.check_call([ENCODE_DEMO, fin, fout])
+    raw = np.fromfile(fout, np.uint8)
+    cs = M * bits // 8
+    return raw[:n * cs].reshape(n, cs), raw[n * cs:].view(np.float32).reshape(n, M * nc)
+
+
+def test_host_encoder_and_expansion_tables_match_the_oracle(po, tmp_path):
+    """N4 / A10 on the CPU: pq4::encode and pq4::tables_blas (host/query_driver.hpp), the host twins of pq_encode_kernel and
+    build_tables_kernel, against the golden codes made from the reference's own text (tests/golden/ref_encode_cases.npz) and
+    the oracle's orc_tables_expansion; encode_form 0 = the oracle's direct form; pq_bytes::encode (BASELINE configs[0]'s
+    quantizers, 256 centroids) = find_k_neighbors' selection on the oracle's expansion distances."""
+    import golden_cases
+    _compile(os.path.join(ROOT, "tests", "cpp", "encode_demo.cpp"), ENCODE_DEMO, link=False)
+    for c in golden_cases.encode_cases():
+        codes, tables = _run_encode_demo(tmp_path, c["codebooks"], c["vectors"], c["rotation"])
+        assert np.array_equal(codes, c["codes"]), c["cid"]
+        if c["rotation"] is None:
+            assert np.array_equal(tables, po.tables_expansion(c["codebooks"], c["vectors"])), c["cid"]
+        codes0, _ = _run_encode_demo(tmp_path, c["codebooks"], c["vectors"], c["rotation"], form=0)
+        assert np.array_equal(codes0, po.pq_encode(c["codebooks"], c["vectors"], c["rotation"], form=0)), c["cid"]
+    rng = np.random.default_rng(8)
+    for M, dim, kind in ((8, 64, "n"), (4, 32, "grid"), (16, 64, "offset")):
+        ds = dim // M
+        if kind == "grid":
+            cb, v = rng.integers(0, 3, (M, 256, ds)).astype(np.float32), rng.integers(0, 3, (300, dim)).astype(np.float32)
+        elif kind == "offset":
+            cb = (50 + 0.01 * rng.normal(size=(M, 256, ds))).astype(np.float32)
+            v = (50 + 0.01 * rng.normal(size=(300, dim))).astype(np.float32)
+        else:
+            cb, v = rng.normal(size=(M, 256, ds)).astype(np.float32), rng.normal(size=(300, dim)).astype(np.float32)
+        codes, _ = _run_encode_demo(tmp_path, cb, v, bits=8)
+        want = np.stack([po.select_k_neighbors(po.cross_dists(cb[m], v[:, m * ds:(m + 1) * ds]), 1)[0][:, 0] for m in range(M)], 1)
+        assert np.array_equal(codes, want.astype(np.uint8)), (M, kind)
+
+
 NEAREST = os.path.join(ROOT, "tests", "cpp", "nearest_demo")
 
 
