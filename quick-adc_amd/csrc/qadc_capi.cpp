@@ -1323,6 +1323,10 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     qadc_index* idx = new qadc_index();
     idx->M = M;
     idx->cs = M / 2;
+    if (M == 16) {                                             // the partition-major batches' head at 16x4: 8 waves per query, 2 probes
+        idx->head_wg = 512;                                    // (same-box A/B, profiles/r06_head_wg_ab.txt: C3 0.656 -> 0.607 us per query;
+        idx->group.head = 2;                                   //  32x4 keeps 16 waves and 3 probes: 3.99 against 4.02-4.05)
+    }
     idx->device = device_id;
     // Test hooks (tests/conftest.py runs every parity test through every scan path this way).  They only apply when
     // QADC_TEST_HOOKS=1 is set as well, so that a stray QADC_* variable in a deployment cannot change the scan path.
@@ -1643,7 +1647,7 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "replay_wave") idx->replay_wave = value != 0;
     else if (n == "replay_defer") idx->replay_defer = value != 0;
     else if (n == "group_stream") idx->group_stream = value != 0;
-    else if (n == "head_lds_pad") idx->head_lds_pad = (int)value;
+    else if (n == "head_wg") idx->head_wg = value == 512 ? 512 : 0;
     else if (n == "front_tp") idx->front_tp = value != 0;
     else if (n == "mq_narrow") idx->group.mq_narrow = value != 0;
     else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);

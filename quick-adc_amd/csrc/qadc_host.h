@@ -416,7 +416,7 @@ struct qadc_index {
                            // scan stream instead of inside the head (option "front_tp"; launch_wgq_batch)
     int group_stream = 0;  // experiment (round 5): 1 = the partition-major phase and the ordering pass of a pipelined batch go to the LEVEL path's
                            // scan stream (lowest priority, same pipe as the query-kernel stream), so that the NEXT batch's head runs beside them
-    int head_lds_pad = 0;  // experiment: extra dynamic LDS bytes of the head launch (> 14 KiB: one head workgroup per CU, 16 wave slots left)
+    int head_wg = 0;       // 512: the IVF head launch runs in 512-thread workgroups (8 waves per query); 0 / 1024: 16 waves
     int replay_defer = 0;  // 1: the device replay of a partition-major batch waits for the NEXT batch's head launch.  Measured, round 5
                            // (profiles/r05_replay_defer_ab.txt): C3 head 0.27 -> 0.215 ms but partition-major phase 0.31 -> 0.36 (batch
                            // 0.666 -> 0.651 ms); C5 — whose head is HBM-bound and did not mind the replay — 4.13 -> 4.25.  Off.

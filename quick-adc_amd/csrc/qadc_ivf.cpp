@@ -351,7 +351,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         H.cand_cap = gcap;
         H.hdr = s.d_hdr;
         H.G = 1;
-        H.lds_pad = (uint32_t)idx->head_lds_pad;
+        H.head_wg = (uint32_t)idx->head_wg;
         // (profile: one event before and after each of the three launches — prof_ev[1..4]; ~10 us of stream time each)
         if (idx->profile) HIPCHECK(prof_event(s, st));
         HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));

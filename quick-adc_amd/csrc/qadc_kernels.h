@@ -145,7 +145,7 @@ struct QueryKernelArgs {
     // gathered int8 tables with front_in seeding every query's flags / qmin / qmax.
     uint32_t front_only;
     uint32_t pos_bits;       // the ordering pass's bucket sort: bits of the longest partition's length << 16 | largest bucket it ranks
-    uint32_t lds_pad;        // host side only: extra dynamic LDS of the launch (experiment "head_lds_pad": fewer workgroups per CU)
+    uint32_t head_wg;        // host side only: 512 = the head launch in 512-thread workgroups (8 waves per query; option "head_wg")
     uint32_t select_rank;    // 0 = auto; else the front's select takes the m-th smallest of its 64 samples as threshold (tests)
     uint32_t ramp_shift;     // the ramp epochs of the walk grow by 2^ramp_shift (0 = the default: 1, i.e. doubling)
     uint32_t* front_out;

@@ -103,13 +103,14 @@ __device__ __forceinline__ void q_lds_barrier() {
 #ifndef QADC_Q32_SWIZZLE
 #define QADC_Q32_SWIZZLE 1
 #endif
-template <int M>
+template <int M, int WG = 1024>
 struct QCfg {
     static constexpr int CS = M / 2, DW = M / 8, CPL = 16 / CS;
+    static constexpr int WAVES = WG / 64;                        // waves of the query workgroup (kQWaves, or 8: the IVF head's 512-thread form)
     static constexpr bool R16 = M == 32 && QADC_Q32_REPL16 != 0;  // 16 replicas per dword, all four dwords in one 64 KiB region
     static constexpr bool SWZ = R16 && QADC_Q32_SWIZZLE != 0;    // the two 16-lane halves of a pass read different dword groups
     static constexpr int TABLE_BYTES = R16 ? 65536 : (M / 16) * 65536;
-    static constexpr int WTAB_BYTES = kQWaves * M * 16 * 4;      // float[16 waves][M*16] (pre-scan)
+    static constexpr int WTAB_BYTES = WAVES * M * 16 * 4;        // float[waves][M*16] (pre-scan)
     static constexpr int FCAP = (TABLE_BYTES - WTAB_BYTES) / 4;  // pre-scan values kept in LDS: 12288 / 24576
     static constexpr int VALS_OFF = 0;                           // float[FCAP]        } pre-scan phase
     static constexpr int WTAB_OFF = FCAP * 4;                    // float[16][M*16]    }
@@ -269,12 +270,13 @@ __device__ __forceinline__ uint32_t q_bound_from_hist(const uint32_t* hist, uint
 // written — L2 — and keys alone let two workgroups share a CU at 8192 candidates, where keys + payloads left room for one).
 // scr / scr_slots / nslots / pos_bits: 2 x scr_slots + 1 words of LDS scratch, the number of assign slots and the bits of
 // the longest partition's length — for the BUCKET sort below (scr == nullptr: bitonic only).
-template <int LOGCAP, bool PAYLDS, typename Load>
+template <int LOGCAP, bool PAYLDS, int WGS = 1024, typename Load>
 __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand, uint64_t* __restrict__ stream, uint32_t cap,
                                                       uint32_t* wcnt, uint32_t tid, uint32_t lane, uint32_t wave,
                                                       uint32_t* scr = nullptr, uint32_t scr_slots = 0, uint32_t nslots = 0,
                                                       uint32_t pos_bits = 0, uint32_t bucket_max = 256) {
     uint32_t out_count = 0;
+    constexpr uint32_t kQWG = WGS, kQWaves = WGS / 64;               // (the caller's workgroup: shadows the 1024-thread default)
     constexpr uint32_t kCap = 1u << LOGCAP, kPer = kCap / kQWG;      // entries per thread in the write-out
     uint64_t* skey = reinterpret_cast<uint64_t*>(qsmem);             // [n2] (slot << (32 + LOGCAP) | pos << LOGCAP | index)
     uint64_t* spay = reinterpret_cast<uint64_t*>(qsmem + kCap * 8);  // [ncand] key | val << 32 | reps << 40 | slot << 48
@@ -445,9 +447,10 @@ __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand,
 //         int8 tables, and emits straight into that path's structures — unordered Cand records in the query's region,
 //         counts in QueryState::hist[level 0] — so that ONE launch replaces a dependent chain of k0 short level
 //         launches; the later levels derive their bounds from it and sort_cands_kernel orders everything.
-template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD>
+template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD, int WG = 1024>
 __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
-    using C = QCfg<M>;
+    using C = QCfg<M, WG>;
+    constexpr int kQWG = WG, kQWaves = WG / 64;                  // this instantiation's workgroup (shadows the 1024-thread default)
     if (reinterpret_cast<uintptr_t>((q_lds_bytes_t)qsmem) != 0) __builtin_trap();   // the lookups use absolute LDS addresses
     constexpr int DW = C::DW, CPL = C::CPL;
     float* vals = reinterpret_cast<float*>(qsmem + C::VALS_OFF);
@@ -989,27 +992,34 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         constexpr int kIter = C::TABLE_BYTES / 16 / kQWG;        // 16x4: 4, 32x4: 8 (4 with 16 replicas) units per thread
         constexpr int kLPP = C::R16 ? 4 : 8;                     // lanes (16-byte units) per pair's row piece
         constexpr int kPPI = 64 / kLPP;                          // pairs per wave and iteration
-        uint32_t w = 0;
-        {
-            const uint32_t pi = lane & (uint32_t)(kPPI * kIter - 1);   // (16x4: lanes 32..63 repeat 0..31)
+        constexpr int kPairs = kPPI * kIter;                     // (g, x) pairs a wave needs: 32 or 64 — or 128 (32x4 in 8 waves)
+        constexpr int kNW = (kPairs + 63) / 64;                  // pair dwords a lane computes
+        uint32_t w[kNW];
+#pragma unroll
+        for (int hf = 0; hf < kNW; ++hf) {
+            const uint32_t pi = (uint32_t)hf * 64u + (lane & (uint32_t)(min(kPairs, 64) - 1));   // (16x4 in 16 waves: lanes 32..63 repeat 0..31)
             const uint32_t k = pi / kPPI, within = pi % kPPI;
             uint32_t x, g;
+            constexpr uint32_t kRows = kQWG / 16;                // 256-byte rows one iteration of the workgroup covers
+            constexpr uint32_t kKPR = 256u / kRows;              // iterations per 64 KiB region
             if (C::R16) {                                        // a wave-iteration = 1 KiB = rows x .. x+3, each [g0][g1][g2][g3]
-                x = k * 64u + wave * 4u + (within >> 2);
+                x = k * kRows + wave * 4u + (within >> 2);
                 g = within & 3u;
             } else {
-                x = (k & 3u) * 64u + wave * 4u + (within >> 1);
-                g = (k >> 2) * 2u + (within & 1u);
+                x = (k % kKPR) * kRows + wave * 4u + (within >> 1);
+                g = (k / kKPR) * 2u + (within & 1u);
             }
+            w[hf] = 0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const uint32_t b = 4u * g + jj;
-                w |= ((uint32_t)tq[(2 * b) * 16 + (x & 15u)] + (uint32_t)tq[(2 * b + 1) * 16 + (x >> 4)]) << (8 * jj);
+                w[hf] |= ((uint32_t)tq[(2 * b) * 16 + (x & 15u)] + (uint32_t)tq[(2 * b + 1) * 16 + (x >> 4)]) << (8 * jj);
             }
         }
 #pragma unroll
         for (int k = 0; k < kIter; ++k) {
-            const uint32_t wk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((k * kPPI + (lane / kLPP)) * 4u), (int)w);
+            const uint32_t wk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)(k * kPPI) & 63u) + (lane / kLPP)) * 4u),
+                                                                       (int)w[(k * kPPI) / 64]);
             *reinterpret_cast<uint4*>(qsmem + ((size_t)k * kQWG + tid) * 16) = make_uint4(wk, wk, wk, wk);
         }
     };
@@ -1410,7 +1420,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         flags |= 32u;                                            // more candidates than the in-workgroup sort takes: host falls back
     } else if (ncand) {
         // (bucket-sort scratch: the value histograms — misc[0..255] — are dead by now)
-        out_count = q_order_and_write<12, true>([&](uint32_t i) { return cands[i]; }, ncand, stream, A.cap, wcnt, tid, lane, wave,
+        out_count = q_order_and_write<12, true, WG>([&](uint32_t i) { return cands[i]; }, ncand, stream, A.cap, wcnt, tid, lane, wave,
                                                 misc, 127u, (uint32_t)ma, A.pos_bits >> 16, A.pos_bits & 0xffffu);
     }
     STAMP(14);
@@ -1444,9 +1454,9 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     }
 }
 
-template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD>
-__global__ __launch_bounds__(kQWG, OCC) void scan_query_kernel(QueryKernelArgs A) {
-    scan_query_body<M, U, OCC, NT, MULTI, HEAD>(A);
+template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD, int WG = 1024>
+__global__ __launch_bounds__(WG, OCC) void scan_query_kernel(QueryKernelArgs A) {
+    scan_query_body<M, U, OCC, NT, MULTI, HEAD, WG>(A);
 }
 
 // Small batches (G > 1): the same kernel with room for inline input behind its arguments (QueryKernelArgs::inline_input).
@@ -2303,18 +2313,13 @@ static hipError_t dynamic_lds_optin(const void* fn, int bytes, std::atomic<uint6
 size_t query_kernel_lds_bytes(int M) { return M == 16 ? QCfg<16>::LDS_BYTES : QCfg<32>::LDS_BYTES; }
 uint32_t query_kernel_lds_values(int M) { return M == 16 ? QCfg<16>::FCAP : QCfg<32>::FCAP; }
 
-template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD = false>
+template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD = false, int WG = 1024>
 static hipError_t launch_scan_query_nt(int nq, const QueryKernelArgs& args, hipStream_t stream) {
     static std::atomic<uint64_t> done{0};
-    const size_t lds = QCfg<M>::LDS_BYTES + args.lds_pad;
-    hipError_t e;
-    if (args.lds_pad)                                            // (experiment: the limit is raised per launch, untracked)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    else
-        e = dynamic_lds_optin(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>), (int)lds, done);
+    const size_t lds = QCfg<M, WG>::LDS_BYTES;
+    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&scan_query_kernel<M, U, OCC, NT, MULTI, HEAD, WG>), (int)lds, done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((scan_query_kernel<M, U, OCC, NT, MULTI, HEAD>), dim3(nq * (MULTI ? args.G : 1)), dim3(kQWG), lds, stream, args);
+    hipLaunchKernelGGL((scan_query_kernel<M, U, OCC, NT, MULTI, HEAD, WG>), dim3(nq * (MULTI ? args.G : 1)), dim3(WG), lds, stream, args);
     return hipGetLastError();
 }
 
@@ -2335,6 +2340,16 @@ static hipError_t launch_scan_query_inline(int nq, const QueryKernelArgs& args, 
 template <int M, int U, int OCC>
 static hipError_t launch_scan_query_v(int nq, const QueryKernelArgs& args, hipStream_t stream, const void* payload, size_t bytes) {
     if (payload && (args.head_codes || args.G <= 1 || bytes > kInlineBytes)) return hipErrorInvalidValue;
+    // The IVF head in 512-thread workgroups (option "head_wg"; default at 16x4).  Same image, same walk, 8 waves per query: two
+    // such workgroups fill a CU's LDS (2 x 64 KiB) with 16 of its 32 wave slots, so the other launches of the pipeline — the
+    // next batches' coarse distances / tables / select, the previous batch's replay — find wave slots on every CU while the
+    // head runs.  Alone on the GPU the head is SLOWER this way (C3: 0.172 -> 0.205 ms per 1024 queries, half the waves to hide
+    // its round trips behind); in the pipelined batches it is faster (0.281 -> 0.235) and the batch with it: 0.656 -> 0.612 us
+    // per query at C3, same box, profiles/r06_head_wg_ab.txt.  32x4 (C5) keeps 16 waves: 3.99 -> 4.02-4.05 us per query with 8.
+    // 4 waves per query and 8 waves at 128 VGPRs with 4 tiles in flight were measured too (C3 0.70 / 0.63): not kept.
+    if (args.head_codes && args.head_wg == 512 && U == 2)
+        return args.nontemporal ? launch_scan_query_nt<M, 2, OCC, true, true, true, 512>(nq, args, stream)
+                                : launch_scan_query_nt<M, 2, OCC, false, true, true, 512>(nq, args, stream);
     if (args.head_codes)
         return args.nontemporal ? launch_scan_query_nt<M, U, OCC, true, true, true>(nq, args, stream)
                                 : launch_scan_query_nt<M, U, OCC, false, true, true>(nq, args, stream);

@@ -56,7 +56,9 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
                 # device replay of a partition-major batch released by the next batch's head launch or by collect
                 replay_defer=int(rng.integers(0, 2)),
                 # partition-major batches: the front as launches of small workgroups (device-built pre-scan items) or inside the head
-                front_tp=int(rng.integers(0, 2)))
+                front_tp=int(rng.integers(0, 2)),
+                # the partition-major batches' head launch in 512- or 1024-thread workgroups
+                head_wg=int(rng.choice([0, 512])))
     for k, v in opts.items():
         idx.set_option(k, v)
     tables = float_tables(rng, nq, ma, M, scale=float(rng.choice([0.2, 1.0])))
