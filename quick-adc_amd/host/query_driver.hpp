@@ -100,8 +100,12 @@ struct pq4 {
     // the same order: bit-compatible with the device and the oracle's orc_tables_expansion.
     void tables_blas(const float* vecs, int count, float* out) const {
         const int ds = sq_dim();
-        std::vector<float> cn((size_t)sq_count * 16);
+        std::vector<float> cn((size_t)sq_count * 16);                        // (||c||^2: per call — the codebooks are a public member)
         for (int e = 0; e < sq_count * 16; ++e) cn[e] = sqnorm(centroids.data() + (size_t)e * ds, ds);
+        tables_blas(vecs, count, cn.data(), out);
+    }
+    void tables_blas(const float* vecs, int count, const float* cn, float* out) const {
+        const int ds = sq_dim();
         for (int v = 0; v < count; ++v) {
             const float* x = vecs + (size_t)v * dim;
             float* o = out + (size_t)v * sq_count * 16;
@@ -119,8 +123,9 @@ struct pq4 {
     // encode_form 1 = that; 0 = the direct form of tables().  Device twin: pq_encode_kernel; oracle: orc_pq_encode.
     int encode_form = 1;
     void encode(const float* vecs, size_t n, std::uint8_t* codes) const {
-        const int cs = code_size();
-        std::vector<float> t((size_t)sq_count * 16), rot;
+        const int cs = code_size(), ds = sq_dim();
+        std::vector<float> t((size_t)sq_count * 16), rot, cn((size_t)sq_count * 16);
+        for (int e = 0; e < sq_count * 16; ++e) cn[e] = sqnorm(centroids.data() + (size_t)e * ds, ds);
         for (size_t i = 0; i < n; ++i) {
             const float* x = vecs + i * dim;
             if (!rotation.empty()) {                       // encode_multiple_vectors rotates first (quantizers.hpp:224)
@@ -128,7 +133,7 @@ struct pq4 {
                 rotate_multiple_vectors(rot.data(), 1);
                 x = rot.data();
             }
-            if (encode_form) tables_blas(x, 1, t.data());
+            if (encode_form) tables_blas(x, 1, cn.data(), t.data());
             else tables(x, t.data());
             std::uint8_t* code = codes + i * cs;
             for (int m = 0; m < sq_count; ++m) {

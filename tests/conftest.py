@@ -44,6 +44,8 @@ def pytest_generate_tests(metafunc):
     itself overrides it."""
     if metafunc.module.__name__.endswith("test_bench_launch"):
         return                                             # bench.py picks its own paths (and clears QADC_WGQ)
+    if getattr(metafunc.function, "_path_independent", False):
+        return                                             # (stateless build entry points: no query path involved)
     if metafunc.definition.get_closest_marker("gpu") and "scan_path" in metafunc.fixturenames:
         metafunc.parametrize("scan_path", ["levels", "levels_head", "wgq", "wgq_lanes"], indirect=True)
 

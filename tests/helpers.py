@@ -33,3 +33,10 @@ def splitmix64(x):
         x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         return x ^ (x >> np.uint64(31))
+
+
+def path_independent(fn):
+    """Marks a GPU test that involves no query path (the stateless database-build entry points): tests/conftest.py then runs it
+    once instead of once per scan path."""
+    fn._path_independent = True
+    return fn

@@ -53,12 +53,42 @@ def test_self_launch_builds_one_rank_per_gpu(monkeypatch):
     assert cmd[cmd.index("--gpus") + 1] == "4" and cmd[cmd.index("--steps") + 1] == "3"
 
 
+def test_bench_prepares_the_stream_set_before_any_communicator():
+    """A process that creates a communicator BEFORE the library's stream set runs a rank's IVF batch 14-60 % slower (DESIGN.md
+    section 5): in bench.py's main() the qadc_device_prepare call must come before init_process_group and before any rank-side
+    index is created — checked on the source, no GPU needed."""
+    import ast
+    src = open(BENCH).read()
+    main = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    calls = {}
+    for node in ast.walk(main):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute):
+            calls.setdefault(node.func.attr, []).append(node.lineno)
+    assert "device_prepare" in calls and "init_process_group" in calls and "Index" in calls
+    assert min(calls["device_prepare"]) < min(calls["init_process_group"])
+    assert min(calls["device_prepare"]) < min(calls["Index"])
+
+
+@pytest.mark.gpu
+def test_a_hung_multi_rank_leg_is_abandoned_with_a_nonzero_exit():
+    """The N-rank IVF legs sit under a watchdog on every rank: when they do not finish in time (here: 0.2 s for legs that take
+    seconds) rank 0 prints the headline with the error in `ivf` and every rank leaves with exit code 3 — the launcher returns
+    non-zero instead of hanging."""
+    env = _env(QADC_BENCH_BACKEND="gloo", QADC_BENCH_ONE_GPU=1, QADC_BENCH_IVF_TIMEOUT=0.2,
+               **dict(SMALL, QADC_BENCH_IVF_CODES=int(4e6), QADC_BENCH_CODES=int(1e7)))
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "abandoned" in line["ivf"]["error"]
+
+
 SMALL = dict(QADC_BENCH_CODES=int(4e7), QADC_BENCH_CPU_SECONDS=0, QADC_BENCH_REAL_CODES=0, QADC_BENCH_IVF_CODES=0,
              QADC_BENCH_32X4=0, QADC_BENCH_LATENCY=0, QADC_BENCH_PMC=0)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,native", [(2, 1), (4, 1), (2, 0)])
+@pytest.mark.parametrize("ranks,native", [(2, 1), (4, 1), (8, 1), (2, 0)])
 def test_gpus_n_self_launch_runs_the_multi_rank_loop_on_one_gpu(ranks, native):
     """bench.py --gpus N end to end with N ranks on ONE GPU (gloo for the script's own barriers): the flat multi-rank loop —
     sliced pre-scan, one gather per step carrying streams + the next pre-scan values, host-share replay, second gather —

@@ -3,7 +3,7 @@ seeded inputs.  Bit-exact bar: heap arrays (keys, values, size), int8 tables, qm
 import numpy as np
 import pytest
 
-from helpers import rand_codes, rand_qtables, float_tables, heaps_equal
+from helpers import rand_codes, rand_qtables, float_tables, heaps_equal, path_independent
 
 pytestmark = pytest.mark.gpu
 
@@ -486,6 +486,7 @@ def test_many_indexes_create_destroy(pyqadc, po):
         idx.close()
 
 
+@path_independent
 def test_pq_encode_writes_the_reference_codes_golden(pyqadc, po):
     """N4: qadc_pq_encode / qadc_ivf_encode_host (OPQ cases) write the codes of tests/golden/ref_encode_cases.npz — made by the
     reference's own extract_subvectors, compute_cross_dists_blas (up to its sgemm), add_candidates_heaps and
@@ -509,6 +510,7 @@ def test_pq_encode_writes_the_reference_codes_golden(pyqadc, po):
     assert ncase == 15 and differs >= 4
 
 
+@path_independent
 @pytest.mark.parametrize("M,dim", [(16, 128), (32, 128), (32, 96), (16, 64), (16, 480)])
 @pytest.mark.parametrize("kind", ["normal", "grid", "offset", "mid"])
 def test_pq_encode_matches_the_oracle_encoder(pyqadc, po, M, dim, kind):
@@ -517,7 +519,7 @@ def test_pq_encode_matches_the_oracle_encoder(pyqadc, po, M, dim, kind):
     grid-valued vectors, vectors exactly between two centroids, and vectors whose expansion is all cancellation; sq_dim 3
     (BASELINE configs[4]: no instance in the reference, sequential norms) included; sum_mode 0 likewise."""
     rng = np.random.default_rng(M * 1000 + dim + len(kind))
-    n, ds = 20000, dim // M
+    n, ds = 8000, dim // M
     if kind == "grid":
         cb, v = rng.integers(0, 3, (M, 16, ds)).astype(np.float32), rng.integers(0, 3, (n, dim)).astype(np.float32)
         cb[:, 7] = cb[:, 2]
@@ -1718,6 +1720,7 @@ def test_coarse_assignment_with_exact_distance_ties_is_find_k_neighbors(pyqadc, 
 
 
 @pytest.mark.gpu
+@path_independent
 def test_ivf_encode_and_kmeans_iterations_match_numpy(pyqadc):
     """N4 through ctypes: qadc_ivf_encode_host (nearest centroid, residual, OPQ rotation, PQ encode) and
     qadc_kmeans_iterations_host: assignment and residual against numpy evaluations of the same sequential loops, the codes
