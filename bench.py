@@ -872,9 +872,10 @@ def self_launch(args):
         else:
             sys.stderr.write(txt)
     rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)                                # (also from a launch that ended non-zero: rank 0's line says what was abandoned)
     if rc != 0 or line is None:
         raise SystemExit("bench.py: the %d-rank launch failed (exit code %d)" % (args.gpus, rc))
-    print(line, flush=True)
 
 
 def main():

@@ -112,43 +112,39 @@ int qadc_index_partition_count(const qadc_index* idx);
 uint32_t qadc_index_partition_size(const qadc_index* idx, int part);
 uint32_t qadc_index_start_size(const qadc_index* idx, int part);
 
-/* Tunables: "quant_mode" (1 = as compiled by the reference's flags, 0 = source level), "sum_mode" (grouping of the float
- * sums of the pre-scan [scan_4, query_common.hpp:72-80] and of the direct table form [fmanorm, distances.hpp:60-76]:
- * 1 = as the reference binary adds them — it is built with -ffast-math, CMakeLists.txt:7 —, 0 = source order), "profile" (0/1),
- * "cand_capacity" (candidate region entries per query), "level_base", "level_growth" (bound levels),
- * "prescan_sample", "small_run", "small_vec_per_wg", "wgs_per_item", "variant", "share_variant" (0 = never
- * launch the queries of a batch as L2-sharing siblings), "share_codes_per_wg", "mq" (8 queries per pass),
- * "mq_codes_per_wg", "mq_min_wgs", "mq_min_tiles", "mq_narrow" (IVF second phase: groups of at most 4 queries take the 4-seat form of that kernel), "prescan_mq", "overlap_front", "head_early", "front_run_max",
- * "front_min_batch", "front_dist" (kernel and launch tuning), "device_replay_nq" (batches of at least this many
- * queries replay their candidate streams through the heap on the device; 0 = always on the host),
- * "device_replay_alone_nq" (... from this many when nothing else is in flight: a synchronous call), "replay_threads",
- * "replay_wave" (device replay of the query kernel's streams: 1 one wave per query with the heap in registers — default — 0 one lane per query, heaps in LDS);
- * the one-workgroup-per-query path: "wgq" (0 never, 1 auto, 2 always), "wgq_min_nq", "wgq_max_codes",
- * "wgq_small_codes", "wgq_capacity", "wgq_cand_cap", "wgq_group_cand_cap", "wgq_variant", "wgq_split" / "wgq_split_codes" (workgroups a
- * small batch spreads one query over / codes each keeps at least), "wgq_inline" (a lone small query's input rides
- * in the kernel arguments), "wgq_poll" (... and its completion is read from the mapped result block),
- * "wgq_group" (large IVF batches: partition-major second phase; 0 never, 1 auto, 2 whenever possible),
- * "wgq_group_codes_per_wg" (... whose groups take one workgroup per this many codes of the longest partition; default 16384),
- * "wgq_group_head" (probes per query the one-workgroup-per-query head walks before it), "wgq_group_head_dist" (the same under the
- * multi-GPU merge, counted in probes with codes on the rank),
- * "head_level", "table_form", "dist_cap_entries", "dist_device_nq", "dist_async", "dist_shard_front", "dist_inject_failure" (test hook),
- * "dist_shard_replay" (an enqueued multi-GPU merge replays only this rank's share of the queries — q = rank (mod world) — and a
- * second, small all-gather shares the heaps; default 1), "dist_share_lag" (that gather is issued behind the first gather of the
- * merge this many batches later; default 1), "replay_defer" (the device replay of a pipelined partition-major batch waits for the
- * next batch's head launch; default 0: measured -2 % / +3 % at the two IVF configuration shapes), "front_tp" (partition-major
- * batches run their front — float pre-scan of the starts, R-th smallest, quantizer — as three launches of small workgroups off the
- * scan stream instead of inside the head launch), "group_stream" / "head_lds_pad" (experiment hooks of round 5, default 0: the
- * partition-major phase of a pipelined batch on the level path's scan stream so that the next batch's head runs beside it; extra
- * dynamic LDS bytes of the head launch — measured worse),
- * "plan_early" (pipelined query-kernel batches: float tables, state clear and partition-major plan run on the stream that produces
- * assign[] instead of the scan stream; default 1), "wgq_stream" (query-kernel batches scan on the highest-priority alternative of the
- * scan stream; default 1 since round 5), "wgq_ramp_shift" (the walk's ramp epochs grow by 2^shift; default doubling), "mq_single" (a lone long
- * run through the multi-query kernel's 4-seat form: 0 never — default —, 1 for lists that fit the Infinity Cache, 2 always),
- * "wgq_order_bucket_max" (the ordering pass sorts by (slot, position) buckets and ranks inside a bucket by counting; a query with
- * a bucket above this many entries takes the bitonic network; default 256, 0 = always the network), "wgq_select_rank" (the front's
- * select draws its threshold from 64 sampled pre-scan values: 0 = the rank it computes itself, 1..64 = this rank — test hook).
+/* Options (30; qadc_option_names() returns the list, comma separated).  None changes WHAT is computed except the three parity
+ * switches of the float half; the rest choose paths and sizes, and tests/test_gpu_fuzz.py draws them at random against the oracle.
+ *  parity      "quant_mode"  1 = QuantizerMAX as the reference is compiled (one reciprocal, multiply), 0 = its source's division
+ *              "sum_mode"    grouping of the float sums of the pre-scan (scan_4, query_common.hpp:72-80), of the direct table form
+ *                            (fmanorm, distances.hpp:60-76) and of the expansion form's norms: 1 = as the reference binary adds them —
+ *                            it is built with -ffast-math, CMakeLists.txt:7 —, 0 = source order
+ *              "table_form"  float tables of qadc_search: 0 direct, 1 BLAS expansion, 2 (default) nns_engine's rule: expansion iff ma > 1
+ *  diagnostics "profile"     0/1: HIP-event timing of the scan launches (qadc_profile_read)
+ *  path        "wgq"         the one-workgroup-per-query path: 0 never, 1 auto (default), 2 whenever structurally possible
+ *              "wgq_group"   large IVF batches take a partition-major second phase: 0 never, 1 auto, 2 whenever possible
+ *              "wgq_group_head"  probes per query the head walks before it (default 2 at 16x4, 3 at 32x4; 4 under the multi-GPU merge)
+ *              "head_level"  level path: bound levels 0 .. head_level-1 are scanned by ONE head launch (default 5; 0 = off)
+ *              "head_wg"     512 = the IVF head in 512-thread workgroups (8 waves per query; default at 16x4), 0 = 1024
+ *  level path  "mq"          queries that share a run are scanned 8 per pass (default 1)
+ *              "share_variant"  kernel form of such shared launches (bit 6 = sibling-major, bit 3 = chunked; 0 = never share)
+ *              "variant"     kernel form of the other launches: bit 2 non-temporal loads, bit 3 chunked tiles, bit 4 the PROBE
+ *                            diagnostic (lookups replaced by an XOR: bench.py's measured streaming ceiling; results meaningless)
+ *              "front_run_max"  leading levels whose runs are at most this long join the front stream (0 = none)
+ *              "wgs_per_item"   workgroups per (query, level) run (0 = auto)
+ *              "cand_capacity", "level_base", "level_growth", "small_run", "prescan_sample"   sizes of the candidate regions, the
+ *                            bound levels, the small-run kernel's limit, the unfiltered part of the pre-scan
+ *  replay      "device_replay_nq" / "device_replay_alone_nq"  batches of at least this many queries replay their streams on the
+ *                            device (0 = never) / the same for a batch with nothing else in flight (a synchronous call)
+ *  query path  "wgq_split" / "wgq_split_codes"  workgroups a small batch spreads one query over / codes each keeps at least
+ *              "wgq_capacity" / "wgq_cand_cap"  stream entries per query to start with / candidates per query before a batch falls
+ *                            back to the level path
+ *  multi-GPU   "dist_cap_entries", "dist_device_nq", "dist_shard_replay" (an enqueued merge replays only this rank's share of the
+ *              queries and a second, small all-gather shares the heaps; default 1), "dist_shard_front" (feeders + pre-scan +
+ *              quantizer of a qadc_search batch are split over the ranks; default 1), "dist_inject_failure" (tests: this rank's
+ *              next collect fails before the gather) — after qadc_dist_init only.
  * Streams: the library keeps ONE set of HIP streams per process and device, created by the first index on the device and shared
  * by every later one. */
+const char* qadc_option_names(void);
 int qadc_set_option(qadc_index* idx, const char* name, double value);
 
 /* Copy codes back (tests / checksums): partition `part`, codes [first, first+count). */
@@ -454,7 +450,6 @@ typedef struct qadc_profile {
     uint64_t group_batches;    /* batches the above figures cover */
     uint64_t front_sharded_batches; /* multi-GPU: qadc_search batches whose front ran on 1/world of the queries per rank */
     uint64_t dist_async_collects;   /* multi-GPU: qadc_dist_collect calls served by a merge enqueued with the batch (one event wait) */
-    uint64_t front_tp_batches;      /* partition-major batches whose front ran as launches of its own (option "front_tp") */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

@@ -162,9 +162,6 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
     }
     size_t nitems = 0;
     for (auto& v : per_level) nitems += v.size();
-    uint64_t db_bytes_plan = 0;
-    for (auto& p : idx->parts) db_bytes_plan += (uint64_t)p.n * cs;
-    const bool db_small = db_bytes_plan <= (200ull << 20);
     std::vector<ScanItem>& all_items = plan.all_items;
     all_items.assign(nitems, ScanItem());
     s.launches.clear();
@@ -198,19 +195,15 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
             ll.early = false;
             ll.shared = !ll.small && same && cnt >= 2 && idx->share_variant != 0;
             ll.mq = ll.shared && idx->mq;
-            // (option "mq_single": a lone long run — one query over a list — through the multi-query kernel's 4-seat form with one
-            // seat taken instead of scan_i8_kernel: 256-thread workgroups with 4 KiB of tables instead of 1024-thread ones that each
-            // build a 64 KiB image; 1 = only for lists that fit the Infinity Cache, 2 = always)
-            if (!ll.small && cnt == 1 && idx->mq && idx->mq_single && (idx->mq_single >= 2 || db_small)) ll.mq = true;
             if (ll.mq) {
                 // 8 queries per pass (scan_i8_mq_kernel): 256-thread workgroups, ~64 Ki codes each, groups of 8
                 // queries as L2-sharing siblings
                 const uint64_t tiles = std::max<uint64_t>((nvec + 255) / 256, 1);
                 uint64_t w = idx->wgs_per_item > 0 ? (uint64_t)idx->wgs_per_item
-                                                   : (maxn + idx->mq_codes_per_wg - 1) / idx->mq_codes_per_wg;
+                                                   : (maxn + kMqCodesPerWg - 1) / kMqCodesPerWg;
                 const uint64_t ngroups = (cnt + 7) / 8;
-                w = std::max<uint64_t>(w, (idx->mq_min_wgs + ngroups - 1) / ngroups);   // >= 2 rounds of the 2048 resident workgroups
-                w = std::min<uint64_t>(std::min<uint64_t>(w, 65536), std::max<uint64_t>(tiles / idx->mq_min_tiles, 1));
+                w = std::max<uint64_t>(w, (kMqMinWgs + ngroups - 1) / ngroups);   // >= 2 rounds of the 2048 resident workgroups
+                w = std::min<uint64_t>(std::min<uint64_t>(w, 65536), std::max<uint64_t>(tiles / kMqMinTiles, 1));
                 if (w >= 8) w &= ~7ull;
                 ll.wgs = (int)w;
             } else if (ll.shared) {
@@ -220,7 +213,7 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
                 // lookup rate instead.  Workgroups per run: ~2M codes each (amortises the table build, leaves the
                 // dispatcher room to balance), a multiple of 8 so that the XCD decode applies.
                 uint64_t w = idx->wgs_per_item > 0 ? (uint64_t)idx->wgs_per_item
-                                                   : (maxn + idx->share_codes_per_wg - 1) / idx->share_codes_per_wg;
+                                                   : (maxn + kShareCodesPerWg - 1) / kShareCodesPerWg;
                 w = std::min<uint64_t>(std::max<uint64_t>(w, 64), 512);
                 w = std::min<uint64_t>(w, std::max<uint64_t>((nvec + 4095) / 4096, 1));
                 if (w >= 8) w &= ~7ull;
@@ -228,7 +221,7 @@ int plan_batch(qadc_index* idx, Slot& s, BatchPlan& plan) {
             } else if (ll.small) {
                 // enough workgroups to fill the chip, but no more: each one pays a table build + bound fetch
                 const uint64_t want = std::max<uint64_t>(1, 4096 / cnt);
-                ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + idx->small_vec_per_wg - 1) / idx->small_vec_per_wg, 1), want);
+                ll.wgs = (int)std::min<uint64_t>(std::max<uint64_t>((nvec + kSmallVecPerWg - 1) / kSmallVecPerWg, 1), want);
             }
             else {
                 // each streaming workgroup builds a 64-128 KiB table: with many runs in the launch, give every
@@ -355,7 +348,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     for (int i = 0; i < kSlots; ++i) alone = alone && (&idx->slot[i] == &s || !idx->slot[i].busy);
     alone = alone && !idx->pre_slot[0].busy && !idx->pre_slot[1].busy;
     hipStream_t main_stream = st;
-    if ((idx->overlap_front && !alone) || s.mode == 1) st = idx->front_stream;
+    if (!alone || s.mode == 1) st = idx->front_stream;
     HIPCHECK(hipMemsetAsync(s.d_state.p, 0, state_bytes, st));
     // The upload goes on the copy stream, where it depends on nothing (the slot's previous batch was collected),
     // and the main stream waits for it.  Issued on the main stream it would sit in the DMA engine's queue until the
@@ -394,7 +387,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         // The LAST select of the chain also quantizes the query's tables (QuantizerMAX) in the same workgroup.
         // every query pre-scans the same starts (flat database, or one shared probe): 8 queries per pass
         auto shared_items = [&](const std::vector<StartItem>& v) {
-            if (!idx->prescan_mq || v.size() < 2) return false;
+            if (v.size() < 2) return false;
             for (auto& si : v)
                 if (si.codes != v[0].codes || si.n != v[0].n || si.out_off != v[0].out_off || si.filter != v[0].filter) return false;
             return true;
@@ -453,7 +446,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
                                  s.cap_q, (uint32_t)s.R, str);
         else if (ll.mq)
             launch_scan_i8_mq(M, s.d_items + ll.first, ll.nitems, ll.wgs, s.d_qt, s.d_qs, s.d_hdr, s.d_cands.p, s.cap_q,
-                              (uint32_t)s.R, str, /*narrow=*/ll.nitems <= 4 ? idx->group.mq_narrow : 0);   // (8 queries per pass: the 8-seat
+                              (uint32_t)s.R, str, /*narrow=*/ll.nitems <= 4 ? 1 : 0);   // (8 queries per pass: the 8-seat
                                                                    // build, see scan_i8_mq_kernel; <= 4 runs: the build with the 4-seat body)
         else
             launch_scan_i8(M, ll.shared ? idx->share_variant : (variant & ~64), s.d_items + ll.first, ll.nitems, ll.wgs,
@@ -484,19 +477,19 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         int G = std::min<int>(idx->wgq_split, std::max(1, 256 / nq));
         G = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)G, s.head_codes / 16384));
         H.G = G;
-        HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, str));
+        HIPCHECK(launch_scan_query(M, nq, H, str));
         idx->prof.head_launches++;
         return QADC_OK;
     };
     size_t n_early = 0;
     uint64_t batch_codes = 0;
     for (auto& ll : s.launches) batch_codes += ll.codes;
-    if (st != main_stream && (s.mode == 0 || (s.mode == 2 && idx->front_dist)) && batch_codes >= idx->front_min_batch)
+    if (st != main_stream && (s.mode == 0 || s.mode == 2) && batch_codes >= kFrontMinBatch)
         while (n_early < s.launches.size() && s.launches[n_early].maxn <= idx->front_run_max) ++n_early;
     if (n_early == s.launches.size() && n_early) --n_early;        // the last level closes the batch on the main stream
     // the head precedes every level: with the early levels (or on request) it joins the front as well
     bool head_pending = s.head_codes != 0;
-    if (head_pending && st != main_stream && (n_early || idx->head_early)) {
+    if (head_pending && st != main_stream) {
         if (int rc = launch_head(st)) return rc;
         head_pending = false;
     }
@@ -542,7 +535,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
     if (s.heaps_ready) {
         uint64_t* d_heaps = reinterpret_cast<uint64_t*>(d_result + off_heaps);
         uint32_t* d_sizes = reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
-        if (idx->replay_wave && (uint32_t)s.R <= replay_wave_max_R())     // one wave per query, all lanes at work (heap in registers)
+        if ((uint32_t)s.R <= replay_wave_max_R())     // one wave per query, all lanes at work (heap in registers)
             HIPCHECK(launch_replay_heap_wave_states(s.d_qs, s.d_stream.p, s.out_cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
         else                                                              // one wave per query, lane 0 pushing into an LDS heap (any R)
             launch_replay_heap(s.d_qs, s.d_stream.p, s.out_cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st);
@@ -640,8 +633,6 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
     Slot& s = idx->slot[slot_i];
     if (!s.busy) return fail(QADC_E_STATE, "slot holds no batch");
     if (int rc = use_device(idx)) return rc;
-    if (s.replay_pending)                                     // (no later batch launched its head meanwhile: the replay goes out now)
-        if (int rc = issue_replay(idx, s, nullptr)) return rc;
     if (s.dist_batch && !from_dist) {
         need_stream = true;
         if (idx->dist && idx->dist->slot[slot_i].pending)
@@ -792,7 +783,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
                 idx->prof.group_pass_codes8 += full * n;
                 idx->prof.group_seats += full * 8;
                 if (rem) {
-                    const bool narrow = idx->group.mq_narrow && rem <= 4;
+                    const bool narrow = rem <= 4;
                     (narrow ? idx->prof.group_pass_codes4 : idx->prof.group_pass_codes8) += n;
                     idx->prof.group_seats += narrow ? 4 : 8;
                 }
@@ -894,7 +885,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
                     }
                 }
             };
-            int nt = idx->replay_threads > 0 ? idx->replay_threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 8);
+            int nt = (int)std::min<unsigned>(std::thread::hardware_concurrency(), 8);
             nt = std::max(1, std::min(nt, s.nq / 2));
             if (total < 16384) nt = 1;
             const int per = std::max(1, s.nq / (nt * 4));
@@ -1004,7 +995,7 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
     // queries are independent: large batches (IVF) are replayed by a few host threads, the caller still
     // drives the library from one thread
     const uint64_t pushes = s.out_off[s.nq];
-    int nt = idx->replay_threads > 0 ? idx->replay_threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 16);   // (10M-code list, 32 queries per step: 8 -> 16 threads 0.260 -> 0.231 ms per step)
+    int nt = (int)std::min<unsigned>(std::thread::hardware_concurrency(), 16);   // (10M-code list, 32 queries per step: 8 -> 16 threads 0.260 -> 0.231 ms per step)
     nt = std::max(1, std::min(nt, s.nq / 2));
     if (pushes < 4000) nt = 1;                                 // (waking the workers costs about as much as 4 K pushes)
     // tasks of a few queries each, handed out dynamically: candidate counts differ from query to query
@@ -1065,72 +1056,28 @@ struct StreamSet {
 std::mutex g_streams_mu;
 std::vector<std::pair<int, StreamSet*>> g_streams;              // (device, set): lives until the process ends
 
-// Creates the streams of `order` (tokens S W C O F L M0..; D / N / H = an idle dummy of the lowest / normal / highest
-// priority — measurement hook) back to back.  A token left out is not created and falls back on another stream.
-hipError_t create_stream_set(StreamSet& ss, const std::string& order, int n_merge, bool merge_normal, bool w_low) {
+// Creates the set's streams back to back, in the order and with the priorities the comment above derives:
+// S (level-path scan, lowest), C (copy, normal), O (ordering, normal), F (front), W (query-kernel scan), L (collectives), M (merge) —
+// the last four at the highest priority: the four highest-priority hardware queues a process has.
+hipError_t create_stream_set(StreamSet& ss) {
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     const int prio_normal = (prio_least + prio_greatest) / 2;
+    struct Want { hipStream_t* dst; int prio; };
+    const Want wants[] = {{&ss.stream, prio_least}, {&ss.copy, prio_normal}, {&ss.sort, prio_normal}, {&ss.front, prio_greatest},
+                          {&ss.wgq, prio_greatest}, {&ss.coll, prio_greatest}, {&ss.merge[0], prio_greatest}};
     hipError_t e = hipSuccess;
-    for (size_t pos = 0; pos <= order.size() && e == hipSuccess;) {
-        const size_t comma = std::min(order.find(',', pos), order.size());
-        const std::string tok = order.substr(pos, comma - pos);
-        pos = comma + 1;
-        hipStream_t* dst = nullptr;
-        int prio = prio_greatest;
-        if (tok == "S") {
-            dst = &ss.stream;
-            prio = prio_least;
-            if (const char* hk = std::getenv("QADC_TEST_HOOKS"))            // measurement hook: the scan stream's priority
-                if (std::atoi(hk) == 1)
-                    if (const char* sp = std::getenv("QADC_SCAN_PRIO")) prio = sp[0] == 'h' ? prio_greatest : sp[0] == 'n' ? prio_normal : prio_least;
-        }
-        else if (tok == "W") {
-            dst = &ss.wgq;
-            prio = w_low ? prio_least : prio_greatest;
-            if (const char* hk = std::getenv("QADC_TEST_HOOKS"))            // measurement hook: the alternative scan stream's priority
-                if (std::atoi(hk) == 1)
-                    if (const char* sp = std::getenv("QADC_W_PRIO")) prio = sp[0] == 'h' ? prio_greatest : sp[0] == 'n' ? prio_normal : prio_least;
-        }
-        else if (tok == "C" || tok == "O") {
-            dst = tok == "C" ? &ss.copy : &ss.sort;
-            prio = prio_normal;
-            if (const char* hk = std::getenv("QADC_TEST_HOOKS"))            // measurement hook: copy / ordering stream priority
-                if (std::atoi(hk) == 1)
-                    if (const char* sp = std::getenv(tok == "C" ? "QADC_C_PRIO" : "QADC_O_PRIO")) prio = sp[0] == 'h' ? prio_greatest : sp[0] == 'n' ? prio_normal : prio_least;
-        }
-        else if (tok == "F") dst = &ss.front;
-        else if (tok == "L") dst = &ss.coll;
-        else if (tok.size() == 2 && tok[0] == 'M' && tok[1] >= '0' && tok[1] < '0' + kMergeStreams) {
-            if (tok[1] - '0' >= n_merge) continue;
-            dst = &ss.merge[tok[1] - '0'];
-            prio = merge_normal ? prio_normal : prio_greatest;
-            if (const char* hk = std::getenv("QADC_TEST_HOOKS"))
-                if (std::atoi(hk) == 1)
-                    if (const char* sp = std::getenv("QADC_MERGE_PRIO2")) prio = sp[0] == 'h' ? prio_greatest : sp[0] == 'n' ? prio_normal : prio_least;
-        } else if (tok == "D" || tok == "N" || tok == "H") {
-            hipStream_t dummy = nullptr;
-            e = hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, tok == "D" ? prio_least : tok == "N" ? prio_normal : prio_greatest);
-            if (e == hipSuccess) ss.created.push_back(dummy);
-            continue;
-        } else continue;
-        if (*dst) continue;
-        e = hipStreamCreateWithPriority(dst, hipStreamNonBlocking, prio);
-        if (e == hipSuccess) ss.created.push_back(*dst);
-    }
-    if (e == hipSuccess && !ss.stream) {
-        e = hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, prio_least);
-        if (e == hipSuccess) ss.created.push_back(ss.stream);
+    for (const Want& w : wants) {
+        e = hipStreamCreateWithPriority(w.dst, hipStreamNonBlocking, w.prio);
+        if (e != hipSuccess) break;
+        ss.created.push_back(*w.dst);
     }
     if (e != hipSuccess) {
         for (size_t i = ss.created.size(); i-- > 0;) (void)hipStreamDestroy(ss.created[i]);
         ss = StreamSet();
         return e;
     }
-    for (hipStream_t* p : {&ss.wgq, &ss.copy, &ss.sort, &ss.front, &ss.coll})   // (left out by the hook: fall back on the scan stream)
-        if (!*p) *p = ss.stream;
-    for (int i = 0; i < kMergeStreams; ++i)
-        if (!ss.merge[i]) ss.merge[i] = ss.merge[0] ? ss.merge[0] : ss.stream;
+    for (int i = 1; i < kMergeStreams; ++i) ss.merge[i] = ss.merge[0];
     return hipSuccess;
 }
 
@@ -1199,51 +1146,24 @@ int shared_stream_set(int device, StreamSet** out) {
         break;
     }
     StreamSet* ss = new StreamSet();
-    std::string order = "S,C,O,F,W,L,M0";
-    if (const char* hk = std::getenv("QADC_TEST_HOOKS"))
-        if (std::atoi(hk) == 1)
-            if (const char* e = std::getenv("QADC_SHARED_STREAM_ORDER")) order = e;   // measurement hook (tools/stream_probe_matrix.py)
-    const hipError_t e = create_stream_set(*ss, order, 1, false, false);
+    const hipError_t e = create_stream_set(*ss);
     if (e != hipSuccess) {
         delete ss;
         return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
-    // (the layout this order gives is CHECKED on demand — qadc_stream_layout, and once by qadc_dist_init: layout_violations below —
-    // not repaired: a search over pad streams in front of re-created sets was built and measured in round 5, and in a process that
-    // created a torch "nccl" group first every candidate left exactly one of the four highest-priority streams on the scan's pipe;
-    // what works is creating the set BEFORE the communicator: qadc_device_prepare)
-    std::string report;
-    ss->order = order;
-    ss->report = report;
+    // (the layout this order gives is CHECKED on demand — qadc_stream_layout: layout_violations above — not repaired: a search
+    // over pad streams in front of re-created sets was built and measured in round 5, and in a process that created a torch "nccl"
+    // group first every candidate left exactly one of the four highest-priority streams on the scan's pipe; what works is creating
+    // the set BEFORE the communicator: qadc_device_prepare)
+    ss->order = "S,C,O,F,W,L,M0";
     g_streams.emplace_back(device, ss);
     *out = ss;
     return QADC_OK;
 }
 
-int attach_streams(qadc_index* idx, bool hooks) {
-    std::string order = "S,C,O,F,W,L,M0";
-    int n_merge = 1;
-    bool merge_normal = false, own = false, w_low = false;
-    if (hooks) {
-        if (const char* e = std::getenv("QADC_W_LOW")) { w_low = std::atoi(e) != 0; own = true; }                                                // measurement hooks (tools/stream_order_ab*.sh): a set of the index's own
-        if (const char* e = std::getenv("QADC_STREAM_ORDER")) { order = e; own = true; n_merge = kMergeStreams; }
-        if (const char* e = std::getenv("QADC_MERGE_STREAMS")) { n_merge = std::max(1, std::min(std::atoi(e), kMergeStreams)); own = true; }
-        if (const char* e = std::getenv("QADC_MERGE_PRIO")) { merge_normal = std::atoi(e) != 0; own = true; }
-        if (const char* e = std::getenv("QADC_OWN_STREAMS")) own = own || std::atoi(e) != 0;
-        if (const char* e = std::getenv("QADC_WGQ_STREAM")) idx->wgq_stream_on = std::atoi(e) != 0;
-    }
+int attach_streams(qadc_index* idx) {
     StreamSet* ss = nullptr;
-    if (own) {
-        ss = new StreamSet();
-        const hipError_t e = create_stream_set(*ss, order, n_merge, merge_normal, w_low);
-        if (e != hipSuccess) {
-            delete ss;
-            return fail(QADC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
-        }
-        idx->own_streams = ss->created;                          // destroyed with the index
-    } else {
-        if (int rc = shared_stream_set(idx->device, &ss)) return rc;
-    }
+    if (int rc = shared_stream_set(idx->device, &ss)) return rc;
     idx->stream = ss->stream;
     idx->wgq_stream = ss->wgq;
     idx->copy_stream = ss->copy;
@@ -1251,7 +1171,6 @@ int attach_streams(qadc_index* idx, bool hooks) {
     idx->front_stream = ss->front;
     idx->coll_stream = ss->coll;
     for (int i = 0; i < kMergeStreams; ++i) idx->merge_streams[i] = ss->merge[i];
-    if (own) delete ss;
     return QADC_OK;
 }
 
@@ -1277,7 +1196,8 @@ const char* qadc_stream_layout(int device_id) {
     if (qadc_device_prepare(device_id)) return "";
     StreamSet* ss = nullptr;
     if (shared_stream_set(device_id, &ss)) return "";
-    if (ss->report.empty()) {                                    // probed once per set, on demand
+    std::lock_guard<std::mutex> lock(g_streams_mu);              // (the report cache is shared by every index of the device)
+    if (ss->report.empty()) {                                    // probed once per set, on demand — by THIS entry point only
         std::string rep;
         const int v = layout_violations(*ss, device_id, &rep);
         ss->report = v < 0 ? "probe failed" : rep;
@@ -1333,14 +1253,9 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     const char* hooks = std::getenv("QADC_TEST_HOOKS");
     if (hooks && std::atoi(hooks) == 1) {
         if (const char* e = std::getenv("QADC_WGQ")) idx->wgq = std::atoi(e);   // force (2) / forbid (0) the one-workgroup-per-query path
-        if (const char* e = std::getenv("QADC_WGQ_POLL")) idx->wgq_poll = std::atoi(e);     // the lone-small-batch shortcuts
-        if (const char* e = std::getenv("QADC_WGQ_INLINE")) idx->wgq_inline = std::atoi(e);
-        if (const char* e = std::getenv("QADC_WGQ_GROUP")) idx->group.mode = std::max(0, std::min(std::atoi(e), 2));
-        if (const char* e = std::getenv("QADC_REPLAY_WAVE")) idx->replay_wave = std::atoi(e) != 0;
-        if (const char* e = std::getenv("QADC_FRONT_TP")) idx->front_tp = std::atoi(e) != 0;
         if (const char* e = std::getenv("QADC_HEAD_LEVEL")) idx->head_level = std::max(0, std::min(std::atoi(e), kMaxLevels - 1));
     }
-    if (int rc = attach_streams(idx, hooks && std::atoi(hooks) == 1)) {
+    if (int rc = attach_streams(idx)) {
         delete idx;
         return rc;
     }
@@ -1376,7 +1291,7 @@ int qadc_index_destroy(qadc_index* idx) {
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
         s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
         s.h_cands.release(); s.d_stream.release(); s.d_qflags.release(); s.d_fvals.release(); s.d_qcands.release(); s.h_fetch.release();
-        s.d_fblock.release(); s.d_fgathered.release(); s.d_front_all.release(); s.h_fmap.release(); s.d_front_tp.release();
+        s.d_fblock.release(); s.d_fgathered.release(); s.d_front_all.release(); s.h_fmap.release();
         if (s.ev_fa) (void)hipEventDestroy(s.ev_fa);
         if (s.ev_fb) (void)hipEventDestroy(s.ev_fb);
         if (s.ev_assign) (void)hipEventDestroy(s.ev_assign);
@@ -1387,11 +1302,9 @@ int qadc_index_destroy(qadc_index* idx) {
         if (s.ev_up) (void)hipEventDestroy(s.ev_up);
         if (s.ev_front) (void)hipEventDestroy(s.ev_front);
         if (s.ev_scanned) (void)hipEventDestroy(s.ev_scanned);
-        if (s.ev_head) (void)hipEventDestroy(s.ev_head);
         for (auto e : s.prof_ev) (void)hipEventDestroy(e);
     }
-    // (the streams belong to the process — see attach_streams — unless a measurement hook gave this index a set of its own)
-    for (size_t i = idx->own_streams.size(); i-- > 0;) (void)hipStreamDestroy(idx->own_streams[i]);
+    // (the streams belong to the process: attach_streams)
     delete idx;
     return QADC_OK;
 }
@@ -1632,96 +1545,61 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part) {
     return (idx && part >= 0 && part < (int)idx->parts.size()) ? idx->parts[part].start_n : 0;
 }
 
+// The 30 options (include/qadc.h documents each; tests/test_capi_host.py pins this list, tests/test_gpu_fuzz.py draws them)
+const char* qadc_option_names(void) {
+    return "quant_mode,sum_mode,table_form,profile,"                                       // parity (float half), diagnostics
+           "wgq,wgq_group,wgq_group_head,head_level,head_wg,"                              // which path scans a batch, and its head
+           "mq,share_variant,variant,front_run_max,wgs_per_item,"                          // level path: launch forms
+           "cand_capacity,level_base,level_growth,small_run,prescan_sample,"               // level path: sizes
+           "device_replay_nq,device_replay_alone_nq,"                                      // where the heap replay runs
+           "wgq_split,wgq_split_codes,wgq_capacity,wgq_cand_cap,"                          // query-kernel path: sizes
+           "dist_cap_entries,dist_device_nq,dist_shard_replay,dist_shard_front,dist_inject_failure";   // multi-GPU merge
+}
+
 int qadc_set_option(qadc_index* idx, const char* name, double value) {
     if (!idx || !name) return fail(QADC_E_ARG, "bad arguments");
     const std::string n(name);
+    if (n.compare(0, 5, "dist_") == 0 && !idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
     if (n == "quant_mode") idx->quant_mode = value != 0 ? 1 : 0;
     else if (n == "sum_mode") idx->sum_mode = value != 0 ? 1 : 0;
-    else if (n == "cand_capacity") idx->cand_capacity = (uint32_t)std::max(16.0, std::min(value, 2147483648.0 - 1));
-    else if (n == "level_base") idx->level_base = (uint64_t)std::max(16.0, value);
-    else if (n == "level_growth") idx->level_growth = (uint64_t)std::max(2.0, value);
-    else if (n == "wgs_per_item") idx->wgs_per_item = (int)value;
-    else if (n == "overlap_front") idx->overlap_front = value != 0;
-    else if (n == "head_early") idx->head_early = value != 0;
-    else if (n == "wgq_inline") idx->wgq_inline = value != 0;
-    else if (n == "replay_wave") idx->replay_wave = value != 0;
-    else if (n == "replay_defer") idx->replay_defer = value != 0;
-    else if (n == "group_stream") idx->group_stream = value != 0;
-    else if (n == "head_wg") idx->head_wg = value == 512 ? 512 : 0;
-    else if (n == "front_tp") idx->front_tp = value != 0;
-    else if (n == "mq_narrow") idx->group.mq_narrow = value != 0;
-    else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);
+    else if (n == "table_form") idx->feed.table_form = std::max(0, std::min((int)value, 2));
+    else if (n == "profile") idx->profile = value != 0;
+    else if (n == "wgq") idx->wgq = (int)value;
     else if (n == "wgq_group") { idx->group.mode = (int)std::max(0.0, std::min(value, 2.0)); idx->group.strikes = 0; }
     else if (n == "wgq_group_head") idx->group.head = idx->group.head_dist = (int)std::max(1.0, std::min(value, 4096.0));
-    else if (n == "wgq_group_head_dist") idx->group.head_dist = (int)std::max(1.0, std::min(value, 4096.0));
-    else if (n == "wgq_poll") idx->wgq_poll = value != 0;
-    else if (n == "wgq_split_codes") idx->wgq_split_codes = (uint32_t)std::max(value, 1024.0);
-    else if (n == "front_dist") idx->front_dist = value != 0;
-    else if (n == "share_variant") idx->share_variant = (int)value;
-    else if (n == "mq") idx->mq = value != 0;
-    else if (n == "mq_single") idx->mq_single = (int)std::max(0.0, std::min(value, 2.0));
-    else if (n == "prescan_mq") idx->prescan_mq = value != 0;
-    else if (n == "front_run_max") idx->front_run_max = (uint64_t)std::max(value, 0.0);
-    else if (n == "device_replay_nq") idx->device_replay_nq = (int)std::max(value, 0.0);
-    else if (n == "front_min_batch") idx->front_min_batch = (uint64_t)std::max(value, 0.0);
-    else if (n == "mq_codes_per_wg") idx->mq_codes_per_wg = (uint32_t)std::max(value, 4096.0);
-    else if (n == "mq_min_wgs") idx->mq_min_wgs = (uint32_t)std::max(value, 1.0);
-    else if (n == "mq_min_tiles") idx->mq_min_tiles = (uint32_t)std::max(value, 1.0);
-    else if (n == "share_codes_per_wg") idx->share_codes_per_wg = (uint32_t)std::max(value, 4096.0);
-    else if (n == "variant") idx->variant = (int)value;
-    else if (n == "prescan_sample") idx->prescan_sample = (uint32_t)std::max(256.0, value);
-    else if (n == "replay_threads") idx->replay_threads = (int)value;
-    else if (n == "small_vec_per_wg") idx->small_vec_per_wg = (uint32_t)std::max(256.0, value);
-    else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
-    else if (n == "wgq") idx->wgq = (int)value;
-    else if (n == "wgq_variant") idx->wgq_variant = (int)value;
-    else if (n == "plan_early") idx->plan_early = value != 0;
-    else if (n == "wgq_order_bucket_max") idx->order_bucket_max = (int)std::max(0.0, std::min(value, 4096.0));
-    else if (n == "wgq_group_codes_per_wg") idx->group.codes_per_wg = value <= 0 ? 0u : (uint32_t)std::max(value, 4096.0);
-    else if (n == "wgq_select_rank") idx->select_rank = (int)std::max(0.0, std::min(value, 64.0));
-    else if (n == "wgq_ramp_shift") idx->wgq_ramp_shift = (int)std::max(0.0, std::min(value, 4.0));
-    else if (n == "wgq_stream") idx->wgq_stream_on = value != 0;
-    else if (n == "dist_cap_entries") {                       // entries per rank block of the native gather (test knob)
-        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
-        idx->dist->cap_entries = (uint32_t)std::max(16.0, std::min(value, 1073741824.0));
-    }
-    else if (n == "dist_device_nq") {                         // batches of at least this many queries replay on the device
-        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
-        idx->dist->device_nq = (int)std::max(1.0, value);
-    }
-    else if (n == "dist_async") {                             // 1: enqueue the merge with the batch where possible; 0: always at collect time
-        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
-        idx->dist->async_merge = value != 0;
-    }
-    else if (n == "dist_shard_replay") {                      // 1: an enqueued merge replays this rank's share of the queries only (+ a heap gather)
-        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
-        idx->dist->shard_replay = value != 0;
-    }
-    else if (n == "dist_share_lag") {                         // the heap gather of merge s is issued behind the first gather of merge s + lag
-        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
-        idx->dist->share_lag = (int)std::max(0.0, std::min(value, 6.0));
-    }
-    else if (n == "dist_shard_front") {                       // 1: feeders + pre-scan + quantizer of a qadc_search batch are split over the ranks
-        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
-        idx->dist->shard_front = value == 2 ? 2 : value != 0;      // (2: also with a world of one — measurement hook: the front as a launch of its own)
-    }
-    else if (n == "dist_inject_failure") {                    // test hook: this rank's next qadc_dist_collect fails before the gather
-        if (!idx->dist) return fail(QADC_E_STATE, "qadc_dist_init has not been called");
-        idx->dist->inject_failure = value != 0;
-    }
-    else if (n == "table_form") idx->feed.table_form = std::max(0, std::min((int)value, 2));
-    else if (n == "wgq_group_cand_cap") idx->group.cand_cap = (uint32_t)std::max(64.0, std::min(value, (double)kOrderCandCap));
-    else if (n == "wgq_cand_cap") idx->wgq_cand_cap = (uint32_t)std::max(1.0, std::min(value, (double)kQueryCandCap));
-    else if (n == "wgq_min_nq") idx->wgq_min_nq = (int)std::max(value, 1.0);
-    else if (n == "wgq_max_codes") idx->wgq_max_codes = (uint64_t)std::max(value, 0.0);
-    else if (n == "wgq_small_codes") idx->wgq_small_codes = (uint64_t)std::max(value, 0.0);
     else if (n == "head_level") idx->head_level = (int)std::max(0.0, std::min(value, (double)(kMaxLevels - 1)));
+    else if (n == "head_wg") idx->head_wg = value == 512 ? 512 : 0;
+    else if (n == "mq") idx->mq = value != 0;
+    else if (n == "share_variant") idx->share_variant = (int)value;
+    else if (n == "variant") idx->variant = (int)value;
+    else if (n == "front_run_max") idx->front_run_max = (uint64_t)std::max(value, 0.0);
+    else if (n == "wgs_per_item") idx->wgs_per_item = (int)value;
+    else if (n == "cand_capacity") {
+        idx->cand_capacity = (uint32_t)std::max(16.0, std::min(value, 2147483648.0 - 1));
+        for (auto& sl : idx->slot) sl.cap_q = 0;
+    }
+    else if (n == "level_base") idx->level_base = (uint64_t)std::max(16.0, value);
+    else if (n == "level_growth") idx->level_growth = (uint64_t)std::max(2.0, value);
+    else if (n == "small_run") idx->small_run = (uint32_t)std::max(0.0, value);
+    else if (n == "prescan_sample") idx->prescan_sample = (uint32_t)std::max(256.0, value);
+    else if (n == "device_replay_nq") idx->device_replay_nq = (int)std::max(value, 0.0);
+    else if (n == "device_replay_alone_nq") idx->device_replay_alone_nq = (int)std::max(0.0, value);
     else if (n == "wgq_split") idx->wgq_split = (int)std::max(1.0, std::min(value, 64.0));
-    else if (n == "wgq_capacity") idx->wgq_capacity = (uint32_t)std::max(16.0, std::min(value, 1048576.0));
-    else if (n == "profile") idx->profile = value != 0;
+    else if (n == "wgq_split_codes") idx->wgq_split_codes = (uint32_t)std::max(value, 1024.0);
+    else if (n == "wgq_capacity") {
+        idx->wgq_capacity = (uint32_t)std::max(16.0, std::min(value, 1048576.0));
+        for (auto& sl : idx->slot) sl.wgq_cap = 0;
+    }
+    else if (n == "wgq_cand_cap") {                            // both candidate capacities of the query-kernel path
+        idx->wgq_cand_cap = (uint32_t)std::max(1.0, std::min(value, (double)kQueryCandCap));          // in-workgroup sort
+        idx->group.cand_cap = (uint32_t)std::max(64.0, std::min(value, (double)kOrderCandCap));       // partition-major batches
+    }
+    else if (n == "dist_cap_entries") idx->dist->cap_entries = (uint32_t)std::max(16.0, std::min(value, 1073741824.0));
+    else if (n == "dist_device_nq") idx->dist->device_nq = (int)std::max(1.0, value);
+    else if (n == "dist_shard_replay") idx->dist->shard_replay = value != 0;
+    else if (n == "dist_shard_front") idx->dist->shard_front = value == 2 ? 2 : value != 0;   // (2: also with a world of one: tests)
+    else if (n == "dist_inject_failure") idx->dist->inject_failure = value != 0;              // (tests: this rank's next collect fails before the gather)
     else return fail(QADC_E_ARG, "unknown option: " + n);
-    if (n == "cand_capacity") for (auto& sl : idx->slot) sl.cap_q = 0;
-    if (n == "wgq_capacity") for (auto& sl : idx->slot) sl.wgq_cap = 0;
     return QADC_OK;
 }
 

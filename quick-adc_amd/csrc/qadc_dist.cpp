@@ -38,7 +38,7 @@ int load_rccl(DistState& d, std::string& err) {
 // per query) + dist_heaps_unpack_kernel put every rank's d_out in the state the unsharded replay leaves.  The replay is a
 // latency chain of ~0.4 ms; its share gather is therefore NOT issued right behind it on the collectives' stream (everything
 // later on that stream — the next batches' front and merge gathers — would wait for it) but behind the first gather of a
-// LATER merge (share_lag = 1 batch later; or at collect), when the chain is long over.  All of it in host program order, which
+// LATER merge (one batch later; or at collect), when the chain is long over.  All of it in host program order, which
 // is the same on every rank, from rank-invariant state (sequence numbers, option values): the ranks issue the same collectives
 // in the same order.
 // Two steps.  enqueue_merge (at the end of the batch's launch) records where the scan ends and marks the merge PENDING;
@@ -158,9 +158,9 @@ int flush_merges(qadc_index* idx, uint64_t upto) {
         if (best < 0) return QADC_OK;
         const uint64_t seq = d.slot[best].seq;
         if (int rc = enqueue_merge_now(idx, idx->slot[best])) return rc;
-        // the heap shares of the merges `share_lag` back: their replays are over by now, the gather does not hold up this stream
-        if (seq >= (uint64_t)d.share_lag)
-            if (int rc = flush_shares(idx, seq - (uint64_t)d.share_lag)) return rc;
+        // the heap shares of the merges kShareLag (1) back: their replays are over by now, the gather does not hold up this stream
+        if (seq >= (uint64_t)kShareLag)
+            if (int rc = flush_shares(idx, seq - (uint64_t)kShareLag)) return rc;
     }
 }
 
@@ -177,7 +177,7 @@ int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream) {
     // such a batch's device merge — or just its pack, gather and copy-out — behind the scan was measured on bench.py's
     // 32-query flat steps, one of 8 ranks: 1.61-1.65 ms per step against 1.22; interleave + replay kernels under the long
     // scan launches take 1.5-1.9 ms per batch, the host 0.07)
-    if (!d.async_merge || nq < d.device_nq || (uint32_t)R > replay_wave_max_R() || (size_t)s.ma * world > dist_interleave_max_cells())
+    if (nq < d.device_nq || (uint32_t)R > replay_wave_max_R() || (size_t)s.ma * world > dist_interleave_max_cells())
         return QADC_OK;
     if (!ds.ev_ready) HIPCHECK(hipEventCreateWithFlags(&ds.ev_ready, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(ds.ev_ready, scan_stream));

@@ -222,16 +222,7 @@ struct Slot {
     hipEvent_t ev_done = nullptr;
     hipEvent_t ev_front = nullptr;      // pre-scan + quantizer finished (front stream)
     hipEvent_t ev_up = nullptr;         // this batch's upload finished (copy stream)
-    DevBuf<unsigned char> d_front_tp;   // throughput front of a partition-major batch: [StartItem nq*ma][fc_init 2nq][front records 4nq]
     hipEvent_t ev_scanned = nullptr;    // last scan level finished (main stream)
-    // device replay of a partition-major batch deferred until the NEXT batch's head launch is through (option "replay_defer"):
-    // issued by that batch's launch, or by collect
-    bool replay_pending = false;
-    hipStream_t replay_stream = nullptr;
-    hipEvent_t ev_head = nullptr;       // this batch's head launch finished (scan stream)
-    uint64_t* rp_heaps = nullptr;
-    uint32_t* rp_sizes = nullptr;
-    uint32_t rp_cap = 0;
     std::vector<hipEvent_t> prof_ev;    // pairs: [2i] before, [2i+1] after; pair 0 = pre-scan chain
     size_t prof_used = 0;
 
@@ -316,10 +307,8 @@ struct DistState {
     PinBuf<uint64_t> h_allheaps;
     int device_nq = 256;                                     // batches of at least this many queries replay on the device
     int inject_failure = 0;                                  // test hook: the next qadc_dist_collect of this rank fails locally
-    int async_merge = 1;                                     // enqueue the merge with the batch where possible (option "dist_async")
     int shard_replay = 1;                                    // an enqueued merge replays only this rank's share of the queries; a second,
                                                              // small all-gather shares the heaps (option "dist_shard_replay")
-    int share_lag = 1;                                       // ... issued behind the first gather of the merge `share_lag` batches later
     uint64_t next_seq = 1;
     int shard_front = 1;                                     // qadc_search batches: every rank runs the front of 1/world of the queries (option "dist_shard_front")
     DistSlot slot[kSlots];
@@ -348,14 +337,26 @@ struct FeederState {
     int table_form = 2;          // float tables of qadc_search: 0 direct, 1 BLAS expansion, 2 the reference's nns_engine rule
 };
 
+// Fixed tuning constants (each was an option while it was being measured; the sweeps are in profiles/, see profiles/README.md)
+constexpr uint32_t kShareCodesPerWg = 1u << 20;    // codes per workgroup of a sibling-major shared launch
+constexpr uint32_t kMqCodesPerWg = 1u << 16;       // ... of a multi-query launch (8 queries per pass)
+constexpr uint32_t kMqMinWgs = 4096;               // workgroups a multi-query launch should have at least (2 rounds of the chip)
+constexpr uint32_t kMqMinTiles = 4;                // ... but never fewer than this many 4 KiB tiles per workgroup
+constexpr uint32_t kSmallVecPerWg = 512;           // 16-byte vectors one small-run workgroup covers
+constexpr uint64_t kFrontMinBatch = 3000000000ull; // leading levels join the front stream only in batches of at least this many (code, query)
+                                                   // pairs: under a shorter last level they only make the front stream the step's longest chain
+constexpr int kWgqMinNq = 128;                     // query-kernel path, auto: batches of at least this many queries ...
+constexpr uint64_t kWgqMaxCodes = 1ull << 24;      //   ... probing at most this many codes per query, or
+constexpr uint64_t kWgqSmallCodes = 1ull << 18;    //   any batch probing at most this many codes per query
+constexpr uint32_t kGroupCodesPerWg = 16384;       // partition-major phase: codes of the longest partition per workgroup of a group
+constexpr int kShareLag = 1;                       // multi-GPU: a merge's heap-share gather is issued behind the first gather of the next merge
+
 // Partition-major second phase of large IVF batches (launch_wgq_batch, qadc_ivf.cpp)
 struct GroupState {
     int strikes = 0;       // grouped batches whose candidate regions overflowed (data whose later probes fall below the head's bound)
     int mode = 1;          // option "wgq_group": 0 never, 1 auto, 2 whenever possible
     int head = 3;          // ... after a head of this many probes per query (one workgroup per query; 4 until the ordering pass took 8192 candidates)
     int head_dist = 4;     // ... under the multi-GPU merge (probes with codes on this rank; option "wgq_group_head_dist")
-    int mq_narrow = 1;     // groups whose upper four seats are empty run the 4-seat form (the two-body build of the kernel)
-    uint32_t codes_per_wg = 16384;   // codes of the longest partition per workgroup of a group (option "wgq_group_codes_per_wg"; 0 = mq_codes_per_wg)
     uint32_t cand_cap = kOrderCandCap;   // candidates per query of such a batch before it falls back (option "wgq_group_cand_cap")
 };
 
@@ -374,9 +375,6 @@ struct qadc_index {
     hipStream_t wgq_stream = nullptr;   // scan stream of the one-workgroup-per-query batches when option "wgq_stream" says so (normal priority)
     hipStream_t coll_stream = nullptr;  // the multi-GPU merge's collectives (highest priority; unused until qadc_dist_init)
     hipStream_t merge_streams[kMergeStreams] = {};   // the merges' interleave + replay (lowest priority; unused until qadc_dist_init)
-    std::vector<hipStream_t> own_streams;   // only under a measurement hook: streams created for this index alone (destroyed with it)
-    int wgq_stream_on = 1;              // option "wgq_stream": 1 (default since round 5) = query-kernel batches scan on wgq_stream — highest
-                                        // priority: nothing on its pipe can hold it up — instead of `stream` (lowest: the level path's)
     hipStream_t front_stream = nullptr; // a batch's pre-scan/quantize chain, under the previous batch's streaming launches
     hipStream_t copy_stream = nullptr;  // uploads and on-demand copies: issued where they depend on nothing (see plan_and_launch)
     uint32_t replay_seq = 0;            // device replays alternate between two side streams in submission order
@@ -393,60 +391,24 @@ struct qadc_index {
     uint64_t level_growth = 4;
     int wgs_per_item = 0;  // 0 = auto
     int share_variant = 0x41;            // streaming-kernel variant for shared launches: sibling-major, U=2, cached loads
-    uint32_t share_codes_per_wg = 1u << 20;
     int mq = 1;                          // shared launches use the 8-queries-per-pass kernel
-    int mq_single = 0;                   // a lone long run takes that kernel's 4-seat form too (option "mq_single": 1 cached lists, 2 always)
     int device_replay_nq = 64;           // batches of at least this many queries replay their streams on the device (0 = never)
     int device_replay_alone_nq = 512;    // ... a batch with nothing else in flight (a synchronous call): from this many
     uint64_t front_run_max = 2u << 20;   // leading levels whose runs are at most this long join the front (0 = none); they are
                                          // counted with the small launches, not event-timed.  125M x 32: 2 Mi -4 %, 8 Mi +1 %
-    uint64_t front_min_batch = 3000000000ull;   // ... in batches of at least this many (code, query) pairs: under a last level
-                                         // of a few hundred microseconds the early levels hide; under a shorter one they only make the front
-                                         // stream the longest chain of the step (32 queries per step: 3e7 codes 0.42 -> 0.37 ms with
-                                         // everything on the main stream, 6e7 0.64 -> 0.62, 1.25e8 1.12 -> 1.14: tools/front_run_ab.sh)
-    int prescan_mq = 1;                  // ... and so does the float pre-scan when every query pre-scans the same starts
-    uint32_t mq_codes_per_wg = 1u << 16;
-    uint32_t mq_min_wgs = 4096;          // workgroups a multi-query launch should have at least (2 rounds of the chip)
-    uint32_t mq_min_tiles = 4;           // ... but never fewer than this many 4 KiB tiles per workgroup
-    int front_dist = 1;    // early levels also for the multi-GPU loop's batches (pre-scan injected)
     uint32_t wgq_split_codes = 8192;    // a query is split over several workgroups only down to this many codes each
-    int wgq_poll = 1;      // ... and its completion is read from the result block, not from the event
-    int wgq_inline = 1;    // a lone small query's input rides in the kernel arguments (no upload)
-    int front_tp = 0;      // partition-major batches: the front (pre-scan, select, quantizer) as three launches of small workgroups off the
-                           // scan stream instead of inside the head (option "front_tp"; launch_wgq_batch)
-    int group_stream = 0;  // experiment (round 5): 1 = the partition-major phase and the ordering pass of a pipelined batch go to the LEVEL path's
-                           // scan stream (lowest priority, same pipe as the query-kernel stream), so that the NEXT batch's head runs beside them
     int head_wg = 0;       // 512: the IVF head launch runs in 512-thread workgroups (8 waves per query); 0 / 1024: 16 waves
-    int replay_defer = 0;  // 1: the device replay of a partition-major batch waits for the NEXT batch's head launch.  Measured, round 5
-                           // (profiles/r05_replay_defer_ab.txt): C3 head 0.27 -> 0.215 ms but partition-major phase 0.31 -> 0.36 (batch
-                           // 0.666 -> 0.651 ms); C5 — whose head is HBM-bound and did not mind the replay — 4.13 -> 4.25.  Off.
-    int replay_wave = 1;   // device replay of the query kernel's streams: 1 = one wave per query (heap in registers), 0 = one lane per query
-                           // (C3 shape, 1024-query batches: lanes 0.78 us per query, waves 0.75; C5 shape: 4.83 vs 4.67 — since
-                           // the wave heap sifts all levels at once; with its element-by-element sift the waves lost,
-                           // 0.93 vs 0.80.  The multi-GPU merge replays by waves.)
-    int head_early = 1;    // the head launch joins the front stream (under the previous batch's long levels)
-    int overlap_front = 1; // pre-scan chain of batch s+1 on its own stream, under batch s's scan
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
-    int replay_threads = 0;            // 0 = auto
     WorkerPool pool;                   // host replay workers (started on first use)
-    uint32_t small_vec_per_wg = 512;  // 16-byte vectors one small-run workgroup covers
     uint32_t small_run = 1u << 17;  // runs shorter than this use the small-run kernel
     int variant = 0x0d;    // kernel tuning variant (see launch_scan_i8): U=2, non-temporal loads, chunked tiles
     // one workgroup per query (IVF batches, small lists): 0 = never, 1 = auto, 2 = whenever structurally possible
     int wgq = 1;
-    int wgq_min_nq = 128;                // auto: batches of at least this many queries ...
-    uint64_t wgq_max_codes = 1ull << 24; //   ... probing at most this many codes per query (estimate), or
-    uint64_t wgq_small_codes = 1ull << 18;   // any batch probing at most this many codes per query
     uint32_t wgq_capacity = 4096;        // stream entries per query to start with
     int wgq_split = 12;                 // workgroups a small batch may spread one query's scan order over
     int head_level = 5;                  // level path: bound levels 0..head_level-1 (the first 512 Ki codes of every query) are
                                          // scanned by ONE launch of the query kernel in head mode instead of head_level dependent
                                          // level launches (0 = off): -5 % per step on a 125M-code shard, neutral at 1B
-    int plan_early = 1;                  // pipelined query-kernel batches: tables, state clear and plan off the scan stream (option "plan_early")
-    int wgq_variant = 0;                 // kernel tuning variant (launch_scan_query)
-    int order_bucket_max = 256;          // largest bucket the ordering pass's bucket sort ranks by counting (option "wgq_order_bucket_max"; beyond: bitonic)
-    int select_rank = 0;                 // option "wgq_select_rank": 0 = auto (QueryKernelArgs::select_rank)
-    int wgq_ramp_shift = 0;              // ramp epochs of the query kernel's walk grow by 2^shift (0 = default, doubling)
     uint32_t wgq_cand_cap = kQueryCandCap;   // candidates per query before the batch falls back to the level path (test knob)
     DevBuf<PartDesc> d_partdesc;         // device partition table (qadc_index_finalize)
     std::vector<PartDesc> h_partdesc;    // its host copy (a lone small query carries the descriptors it needs in its launch)
@@ -487,7 +449,6 @@ int table_expansion(const qadc_index* idx, int ma);
 bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64_t codes_per_query);
 bool will_group(const qadc_index* idx, int nq, int ma, bool dev_replay);
 int launch_wgq_batch(qadc_index* idx, Slot& s);
-int issue_replay(qadc_index* idx, Slot& s, hipEvent_t after);   // a deferred device replay (launch_wgq_batch / collect_common)
 int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int ma, int R);
 // qadc_dist.cpp
 int load_rccl(DistState& d, std::string& err);

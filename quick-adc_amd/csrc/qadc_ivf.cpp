@@ -22,11 +22,11 @@ int table_expansion(const qadc_index* idx, int ma) {
 bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64_t codes_per_query) {
     if (idx->wgq == 0 || mode != 0 || ma > 4096 || R <= 0) return false;
     if (idx->wgq >= 2) return true;
-    if (codes_per_query <= idx->wgq_small_codes) return true;
+    if (codes_per_query <= kWgqSmallCodes) return true;
     // an IVF batch (several partitions, several probes per query: the queries walk different codes) — the query kernel is
     // ahead of the level path at every batch size (C3 shape, synchronous: 1 query 217 -> 175 us, 64 queries 0.85 -> 0.73 ms)
-    if (ma > 1 && idx->parts.size() > 1 && codes_per_query <= idx->wgq_max_codes) return true;
-    return nq >= idx->wgq_min_nq && codes_per_query <= idx->wgq_max_codes;
+    if (ma > 1 && idx->parts.size() > 1 && codes_per_query <= kWgqMaxCodes) return true;
+    return nq >= kWgqMinNq && codes_per_query <= kWgqMaxCodes;
 }
 
 // One launch per batch: scan_query_kernel (one workgroup per query), then — for batches large enough to replay on
@@ -61,7 +61,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     // flight — a synchronous call — is answered sooner by the host's threads up to a few hundred queries (C3 shape,
     // synchronous: 64 queries 1.41 -> 0.87 ms, 256: 1.89 -> 1.44, 512: 2.26 vs 2.41)
     const int replay_from = alone ? std::max(idx->device_replay_nq, idx->device_replay_alone_nq) : idx->device_replay_nq;
-    s.dev_replay = idx->device_replay_nq > 0 && nq >= replay_from && (uint32_t)s.R <= (idx->replay_wave ? replay_wave_max_R() : replay_lanes_max_R());
+    s.dev_replay = idx->device_replay_nq > 0 && nq >= replay_from && (uint32_t)s.R <= replay_wave_max_R();
     s.dist_batch = idx->dist != nullptr;
     s.heaps_ready = s.dev_replay && !s.dist_batch;
     if (s.dist_batch) s.dev_replay = true;                   // streams stay on the device for the gather (qadc_dist_collect)
@@ -119,12 +119,12 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     const uint32_t ccap = std::min<uint32_t>(idx->wgq_cand_cap, kQueryCandCap);
     HIPCHECK(s.d_qcands.ensure((size_t)nsub * ccap));
 
-    hipStream_t st = idx->wgq_stream_on ? idx->wgq_stream : idx->stream;
+    hipStream_t st = idx->wgq_stream;
     // A lone small query (the synchronous single-query call): its input — which partitions, their descriptors, the
     // float tables — fits the kernel-argument segment and rides in the dispatch packet; no copy precedes the launch.
     alignas(16) unsigned char inl[kInlineBytes];
     size_t inl_bytes = 0, inl_off_parts = 0, inl_off_tables = 0;
-    if (alone && G > 1 && idx->wgq_inline && s.float_path && !s.device_tables && !s.assign_on_device) {
+    if (alone && G > 1 && s.float_path && !s.device_tables && !s.assign_on_device) {
         const size_t na = (size_t)nq * ma;
         inl_off_parts = align16(sizeof(int32_t) * na);
         inl_off_tables = align16(inl_off_parts + sizeof(PartDesc) * na);
@@ -155,8 +155,8 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     // collectives' stream behind the unpack of a sharded front.  On the scan stream those ~6 short launches cost it ~0.1 ms
     // per batch (C3 shape: a seventh of the batch) between the previous batch's ordering pass and this batch's head.
     // (Round 3 tried the front stream for this and lost: it shared a pipe with the scan stream then, and carries every other
-    // replay — DESIGN.md section 5.)  option "plan_early"; a lone batch and a re-run keep everything on one stream.
-    const bool pre = idx->plan_early && !alone && !s.rerun;
+    // replay — DESIGN.md section 5.)  A lone batch and a re-run keep everything on one stream.
+    const bool pre = !alone && !s.rerun;
     hipStream_t pre_st = pre ? idx->copy_stream : st;
     bool pre_used = false, flush_later = false;
     QueryKernelArgs A{};
@@ -216,7 +216,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
                 F.G = 1;
                 F.front_only = 1;
                 F.front_out = d_front_share;
-                HIPCHECK(launch_scan_query(M, idx->wgq_variant, s.front_n, F, fs));
+                HIPCHECK(launch_scan_query(M, s.front_n, F, fs));
             }
             // the collectives of the merge live on ONE stream, in the order the host issues them (the same on every rank)
             if (!s.ev_fa) HIPCHECK(hipEventCreateWithFlags(&s.ev_fa, hipEventDisableTiming));
@@ -252,12 +252,10 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     A.sum_mode = idx->sum_mode;
     A.nontemporal = idx->total_codes * (uint64_t)idx->cs > (200ull << 20);   // (same rule as the level path)
     A.G = G;
-    A.ramp_shift = (uint32_t)idx->wgq_ramp_shift;
-    A.select_rank = (uint32_t)idx->select_rank;
     A.pos_bits = (idx->max_part_n ? 64u - (uint32_t)__builtin_clzll((unsigned long long)idx->max_part_n) : 0u) << 16 |
-                 (uint32_t)idx->order_bucket_max;
+                 256u;
     if (idx->profile) HIPCHECK(prof_event(s, st));
-    s.poll = alone && G > 1 && !s.dev_replay && !idx->profile && idx->wgq_poll;
+    s.poll = alone && G > 1 && !s.dev_replay && !idx->profile;
     if (s.poll)
         for (int i = 0; i < nsub; ++i) s.h_qout[i].flags = 0;
     A.inline_off_parts = (uint32_t)inl_off_parts;
@@ -302,32 +300,6 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         launch_ivf_plan(A.assign, idx->d_partdesc.p, nq, ma, head_slots, (int)nparts, d_gplan, d_gplan + 2 * nparts,
                         d_gplan + nparts, d_gitems, pre_st);
         pre_used = pre_used || pre_st != st;
-        // ---- throughput front (option "front_tp"): the batch's pre-scan, select and quantizer as THREE launches of small
-        // workgroups off the scan stream — one 256-thread workgroup per (query, probe) pair for scan_4 over the pair's starts
-        // (start_scan_f32_kernel, items built on the device from assign[]), one per query for the R-th smallest and the quantizer
-        // (select_kth_kernel<256>) — instead of inside the head, where the front is a third of a 1024-thread workgroup's life spent
-        // in dependent round trips (50 K of 170 K cycles at the C3 shape, 236 K of 656 K at C5) with a CU's wave slots held.
-        // The head then starts from int8 tables + {flags, qmin, qmax} like the head of a sharded front.
-        uint32_t* d_front_tp = nullptr;
-        if (idx->front_tp && A.ftables && !s.front_sharded) {
-            const uint64_t fstride = ((uint64_t)ma * idx->max_start_n + 3) & ~3ull;
-            if ((uint64_t)nq * fstride < (1ull << 31) && fstride < (1ull << 31)) {
-                auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-                const size_t off_init = up16(sizeof(StartItem) * (size_t)nq * ma);
-                const size_t off_front = up16(off_init + sizeof(uint32_t) * 2 * (size_t)nq);
-                HIPCHECK(s.d_front_tp.ensure(off_front + sizeof(uint32_t) * 4 * (size_t)nq));
-                HIPCHECK(s.d_fc.ensure((size_t)nq * fstride));
-                StartItem* d_sit = reinterpret_cast<StartItem*>(s.d_front_tp.p);
-                uint32_t* d_finit = reinterpret_cast<uint32_t*>(s.d_front_tp.p + off_init);
-                d_front_tp = reinterpret_cast<uint32_t*>(s.d_front_tp.p + off_front);
-                launch_ivf_front_items(A.assign, idx->d_partdesc.p, nq, ma, (uint32_t)fstride, d_sit, d_finit, pre_st);
-                launch_start_scan_f32(M, idx->sum_mode, d_sit, nq * ma, 1, A.ftables, s.d_fc.p, fstride, d_finit, s.d_qs, pre_st);
-                launch_select_kth(s.d_fc.p, fstride, d_finit, nq, (uint32_t)s.R, s.d_qs, 4, A.ftables, s.d_qtables.p, (int)(table_dim * ma),
-                                  idx->quant_mode, pre_st, nullptr, nullptr, d_front_tp, 1);
-                HIPCHECK(hipGetLastError());
-                idx->prof.front_tp_batches++;
-            }
-        }
         if (pre_used) {
             if (!s.ev_pre) HIPCHECK(hipEventCreateWithFlags(&s.ev_pre, hipEventDisableTiming));
             HIPCHECK(hipEventRecord(s.ev_pre, pre_st));
@@ -339,11 +311,6 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             flush_later = false;
         }
         QueryKernelArgs H = A;
-        if (d_front_tp) {                                        // the front ran as launches of its own (above): an int8 batch for the head
-            H.ftables = nullptr;
-            H.qtables = s.d_qtables.p;
-            H.front_in = d_front_tp;
-        }
         H.head_codes = ~0ull;
         H.head_slots = (uint32_t)head_slots;
         H.qstates = s.d_qs;
@@ -354,38 +321,15 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         H.head_wg = (uint32_t)idx->head_wg;
         // (profile: one event before and after each of the three launches — prof_ev[1..4]; ~10 us of stream time each)
         if (idx->profile) HIPCHECK(prof_event(s, st));
-        HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, H, st));
+        HIPCHECK(launch_scan_query(M, nq, H, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
-        if (idx->group_stream && !s.dist_batch && !alone && !s.rerun && idx->wgq_stream_on) {
-            // experiment "group_stream": everything behind the head moves to the level path's scan stream; the query-kernel stream is
-            // free for the next batch's head at once
-            if (!s.ev_head) HIPCHECK(hipEventCreateWithFlags(&s.ev_head, hipEventDisableTiming));
-            HIPCHECK(hipEventRecord(s.ev_head, st));
-            st = idx->stream;
-            HIPCHECK(hipStreamWaitEvent(st, s.ev_head, 0));
-        }
-        // Option replay_defer (off by default).  At the C3 shape the head suffers from company: 1024-thread workgroups, latency-bound
-        // (waves parked ~70 %), two per CU only while all 32 wave slots of the CU are free — and the previous batch's replay, one wave
-        // per query spread over every CU for ~0.25 ms, starts exactly when this head does (kernel trace: head 0.285 ms in the
-        // pipeline against 0.173 alone, with the scan queue 98 % busy).  With the option the replays that wait are released here,
-        // behind the head, and run under the partition-major phase instead — which then pays for them (VALU issue 74-87 % busy):
-        // C3 -2 % per batch, C5 +3 % (profiles/r05_replay_defer_ab.txt).  The replay's ~0.05 ms of VALU work per batch lands somewhere.
-        bool waiting = false;
-        for (int i = 0; i < kSlots; ++i) waiting = waiting || (&idx->slot[i] != &s && idx->slot[i].replay_pending);
-        if (waiting) {
-            if (!s.ev_head) HIPCHECK(hipEventCreateWithFlags(&s.ev_head, hipEventDisableTiming));
-            HIPCHECK(hipEventRecord(s.ev_head, st));
-            for (int i = 0; i < kSlots; ++i)
-                if (&idx->slot[i] != &s && idx->slot[i].replay_pending)
-                    if (int rc = issue_replay(idx, idx->slot[i], s.ev_head)) return rc;
-        }
         // (workgroups per group: 16 K codes each.  One workgroup per partition — the multi-query scans' own 64 K — leaves the C3 shape's
         //  4.4 K groups 2.5 rounds of the GPU's 1792 resident workgroups, and the last round mostly empty: 0.335 -> 0.315 ms per
         //  batch at C3, 3.29 -> 3.18 at C5 with 16 K; 8 K the same, 4 K slower: a table build per 4 tile iterations)
-        const uint64_t per_wg = idx->group.codes_per_wg ? idx->group.codes_per_wg : idx->mq_codes_per_wg;
+        const uint64_t per_wg = kGroupCodesPerWg;
         const int wgs = (int)std::max<uint64_t>(1, ((uint64_t)idx->max_part_n + per_wg - 1) / per_wg);
         launch_scan_i8_mq(M, d_gitems, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, gcap, (uint32_t)s.R, st,
-                          idx->group.mq_narrow);
+                          /*narrow=*/1);
         if (idx->profile) HIPCHECK(prof_event(s, st));
         HIPCHECK(launch_order_cands(s.d_qs, s.d_cands.p, gcap, gcap, nq, s.d_stream.p, cap, s.d_qout, s.d_qflags.p, ma, A.pos_bits, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
@@ -399,7 +343,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         }
         if (flush_later)
             if (int rc = flush_merges(idx, ~0ull)) return rc;
-        HIPCHECK(launch_scan_query(M, idx->wgq_variant, nq, A, st, inl_bytes ? inl : nullptr, inl_bytes));
+        HIPCHECK(launch_scan_query(M, nq, A, st, inl_bytes ? inl : nullptr, inl_bytes));
     }
     if (idx->profile) HIPCHECK(prof_event(s, st));
     if (s.dist_batch && !s.rerun)
@@ -417,38 +361,13 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             st = (idx->replay_seq++ & 1) ? idx->front_stream : idx->sort_stream;
             HIPCHECK(hipStreamWaitEvent(st, s.ev_scanned, 0));
         }
-        if (s.heaps_ready && !alone && s.wgq_grouped && !s.dist_batch && idx->replay_defer) {
-            // deferred: released by the next partition-major batch's head launch (above), or by collect
-            s.replay_pending = true;
-            s.replay_stream = st;
-            s.rp_heaps = reinterpret_cast<uint64_t*>(d_result + off_heaps);
-            s.rp_sizes = reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
-            s.rp_cap = cap;
-            return QADC_OK;                                      // (ev_done is recorded behind the replay, by issue_replay)
-        }
         if (s.heaps_ready) {
             uint64_t* d_heaps = reinterpret_cast<uint64_t*>(d_result + off_heaps);
             uint32_t* d_sizes = reinterpret_cast<uint32_t*>(d_result + off_heaps + sizeof(uint64_t) * (size_t)s.R * nq);
-            if (idx->replay_wave)                               // one wave per query, heap in registers
-                HIPCHECK(launch_replay_heap_wave_qflags(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
-            else                                                // one lane per query, heaps in LDS
-                HIPCHECK(launch_replay_heap_lanes(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
+            // one wave per query, heap in registers (replay_heap_wave_kernel)
+            HIPCHECK(launch_replay_heap_wave_qflags(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
         }
     }
-    if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(s.ev_done, st));
-    return QADC_OK;
-}
-
-// A deferred device replay: on the side stream the batch was given, behind the batch's own scan and (if given) behind `after`.
-int issue_replay(qadc_index* idx, Slot& s, hipEvent_t after) {
-    s.replay_pending = false;
-    hipStream_t st = s.replay_stream;
-    if (after) HIPCHECK(hipStreamWaitEvent(st, after, 0));
-    if (idx->replay_wave)
-        HIPCHECK(launch_replay_heap_wave_qflags(s.d_qflags.p, s.d_stream.p, s.rp_cap, s.nq, (uint32_t)s.R, s.rp_heaps, s.rp_sizes, st));
-    else
-        HIPCHECK(launch_replay_heap_lanes(s.d_qflags.p, s.d_stream.p, s.rp_cap, s.nq, (uint32_t)s.R, s.rp_heaps, s.rp_sizes, st));
     if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     HIPCHECK(hipEventRecord(s.ev_done, st));
     return QADC_OK;

@@ -146,8 +146,6 @@ struct QueryKernelArgs {
     uint32_t front_only;
     uint32_t pos_bits;       // the ordering pass's bucket sort: bits of the longest partition's length << 16 | largest bucket it ranks
     uint32_t head_wg;        // host side only: 512 = the head launch in 512-thread workgroups (8 waves per query; option "head_wg")
-    uint32_t select_rank;    // 0 = auto; else the front's select takes the m-th smallest of its 64 samples as threshold (tests)
-    uint32_t ramp_shift;     // the ramp epochs of the walk grow by 2^ramp_shift (0 = the default: 1, i.e. doubling)
     uint32_t* front_out;
     const uint32_t* front_in;
 };
@@ -158,9 +156,8 @@ struct QueryKernelInline {
     alignas(16) unsigned char payload[kInlineBytes];
 };
 
-size_t query_kernel_lds_bytes(int M);
 uint32_t query_kernel_lds_values(int M);       // pre-scan values a query may have before fvals is needed
-hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& args, hipStream_t stream,
+hipError_t launch_scan_query(int M, int nq, const QueryKernelArgs& args, hipStream_t stream,
                              const void* inline_payload = nullptr, size_t inline_bytes = 0);
 // Large IVF batches, partition-major second phase (qadc_query_kernel.hip): regroup the (query, probe) pairs of the
 // probes s0 .. ma-1 by partition into ScanItem groups of 8 for scan_i8_mq_kernel (d_cnt, d_fill: K zeroed counters;
@@ -176,10 +173,6 @@ hipError_t launch_front_unpack(const unsigned char* d_gathered, size_t block_byt
                                int8_t* d_qt, int32_t* d_assign, uint32_t* d_front, int32_t* h_assign, uint32_t* h_front,
                                hipStream_t stream);
 // kv_binheap push replay of the ordered streams, 64 queries per wave (one lane each); R <= replay_lanes_max_R().
-uint32_t replay_lanes_max_R();
-hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
-                                    uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);
-
 // ---- multi-GPU merge around one ncclAllGather (qadc_dist_collect) ----
 // Per-rank block (u64 words): [nq x {offset, count, flags, 0} as u32][cap_entries entries][extra floats, padded to u64].
 inline size_t dist_block_words(int nq, uint32_t cap_entries, uint32_t extra_n) {
@@ -323,12 +316,6 @@ void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_
 // Stream-layout probe: a launch of spin_wgs two-per-CU workgroups spinning spin_ticks (100 MHz wall clock) each on stream a, then a
 // one-wave marker on stream b; d_t[0] = first spin workgroup's start (initialise to ~0), [1] = last one's end (0), [2] = marker start.
 hipError_t launch_stream_probe(unsigned long long* d_t, int spin_wgs, uint32_t spin_ticks, hipStream_t a, hipStream_t b);
-
-// Pre-scan items of a queries-in batch, built on the device from assign[] and the partition table: one StartItem per
-// (query, probe) in assign order, out_off = prefix of the probes' start sizes; d_fc_init[2q] = starts of query q (<= cap),
-// d_fc_init[2q + 1] = cap.  launch_start_scan_f32 + launch_select_kth then are the query's front.
-void launch_ivf_front_items(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, uint32_t cap, StartItem* d_items,
-                            uint32_t* d_fc_init, hipStream_t stream);
 
 // Key range of d_vals[q][nvals] into QueryState::sel_nmin / sel_max (injected pre-scan values).
 void launch_prescan_minmax(const float* d_vals, uint32_t nvals, int nq, QueryState* d_qs, hipStream_t stream);

@@ -186,14 +186,15 @@ __device__ __forceinline__ uint32_t pair_sum(const uint32_t* d, uint32_t lane_lo
     return s;
 }
 
-// Tuning knobs (compile-time): U = 16-KiB tiles in flight per lane, NT = non-temporal loads,
-// CHUNK = each workgroup owns a contiguous run of tiles instead of a grid-stride, PROBE = replace the
-// LDS lookups by a trivial reduction (streaming-ceiling diagnostic; results meaningless).
-template <int M, int U, bool NT, bool CHUNK, bool PROBE, bool PF>
+// Compile-time forms: NT = non-temporal loads, CHUNK = each workgroup owns a contiguous run of tiles instead of a grid-stride,
+// PROBE = replace the LDS lookups by a trivial reduction (the streaming-ceiling diagnostic of bench.py; results meaningless).
+// U = 2 16-KiB tiles in flight per lane (1 and 4, and a software-prefetch form, were measured in rounds 1-2: profiles/README.md).
+template <int M, bool NT, bool CHUNK, bool PROBE>
 __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
     const ScanItem* __restrict__ items, const int8_t* __restrict__ qtables, QueryState* __restrict__ qstates,
     CandHeader* __restrict__ hdr, Cand* __restrict__ out, uint32_t cand_cap, uint32_t R, uint32_t sib_items) {
     using C = ScanCfg<M>;
+    constexpr int U = 2;
     // Workgroup -> (run, position in the run).  2-D launch: blockIdx.y = run.  Sibling-major 1-D launch
     // (sib_items = runs in the launch, all over the SAME code range, one per query): the hardware deals consecutive
     // workgroup ids round-robin to the 8 XCDs, so ids that are equal mod 8 share an L2; the decode below puts the
@@ -299,30 +300,17 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
     const uint32_t full_last = min(last, tiles_full);
 
     uint32_t t0 = first;
-    if (PF) {
-        // software prefetch: the next U tiles are requested before the current ones are consumed
-        u32x4 cur[U], nxt[U];
-        uint32_t ecur[U], enxt[U];
-        load_tiles(t0, cur, ecur, part_t());
-        for (; t0 < last; t0 += step * U) {
-            load_tiles(t0 + step * U, nxt, enxt, part_t());
-            process(cur, ecur, part_t());
-#pragma unroll
-            for (int u = 0; u < U; ++u) { cur[u] = nxt[u]; ecur[u] = enxt[u]; }
-        }
-    } else {
-        for (; t0 + (U - 1) * step < full_last; t0 += step * U) {   // steady state: unpredicated
-            u32x4 v[U];
-            uint32_t e[U];
-            load_tiles(t0, v, e, full_t());
-            process(v, e, full_t());
-        }
-        for (; t0 < last; t0 += step * U) {                          // ragged end of the run
-            u32x4 v[U];
-            uint32_t e[U];
-            load_tiles(t0, v, e, part_t());
-            process(v, e, part_t());
-        }
+    for (; t0 + (U - 1) * step < full_last; t0 += step * U) {       // steady state: unpredicated
+        u32x4 v[U];
+        uint32_t e[U];
+        load_tiles(t0, v, e, full_t());
+        process(v, e, full_t());
+    }
+    for (; t0 < last; t0 += step * U) {                              // ragged end of the run
+        u32x4 v[U];
+        uint32_t e[U];
+        load_tiles(t0, v, e, part_t());
+        process(v, e, part_t());
     }
 }
 
@@ -348,9 +336,6 @@ __global__ __launch_bounds__(kWG, (M == 16 ? 8 : 4)) void scan_i8_kernel(
 //
 // Exactness is untouched: the same integer sums, the same prefix bound per query, the same candidates.
 // ---------------------------------------------------------------------------------------------
-#ifndef QADC_MQ_PIPE
-#define QADC_MQ_PIPE 1             // (build-time A/B: software-pipelined loads in the IVF second phase's build of the kernel)
-#endif
 constexpr int kMQ = 8;          // queries per pass
 constexpr int kMQWG = 256;      // threads per workgroup
 
@@ -375,24 +360,14 @@ __device__ __forceinline__ uint32_t prefix_bound_wave(const QueryState* qs, int 
     return min((uint32_t)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(reached)), 127u);
 }
 
-#ifndef QADC_MQ_SEATS26
-#define QADC_MQ_SEATS26 1
-#endif
-#ifndef QADC_BYTE0_PLAIN_AND
-#define QADC_BYTE0_PLAIN_AND 0   // (tried in round 5, same-box A/B: nothing at the IVF shapes, +0.6 % on the flat batched step: profiles/r05_byte0_and_ab.txt)
-#endif
 // (byte K of d) & mask in ONE VALU instruction (sub-dword operand select); the compiler finds this form for only a
 // quarter of the lookups by itself and spends a shift + and on the others
 template <int K>
 __device__ __forceinline__ uint32_t byte_and(uint32_t d, uint32_t mask) {
     uint32_t r;
-#if QADC_BYTE0_PLAIN_AND
-    // byte 0 needs no operand select (the mask is below 0x100): a plain v_and_b32 issues at FULL rate on gfx950, every SDWA form
-    // at half (tools/microbench/valu_rate.hip: 1.2 vs 1.9 ns per wave-instruction per SIMD) — a quarter of the extracts
-    if (K == 0) asm("v_and_b32_e32 %0, %1, %2" : "=v"(r) : "v"(mask), "v"(d));
-#else
+    // (a plain v_and_b32 for byte 0 — full issue rate on gfx950, every SDWA form half — was tried in round 5: nothing at the IVF
+    //  shapes, +0.6 % on the flat batched step, profiles/r05_byte0_and_ab.txt)
     if (K == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(mask), "v"(d));
-#endif
     if (K == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(mask), "v"(d));
     if (K == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(mask), "v"(d));
     if (K == 3) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(mask), "v"(d));
@@ -607,7 +582,7 @@ __device__ __forceinline__ void scan_mq_body(const ScanItem* __restrict__ its, c
     for (; t0 < ntiles; t0 += G * U) run(t0, part_t());
 }
 
-// Round 5: two more seat counts for the IVF second phase (QADC_MQ_SEATS26).  A group with 1-2 live seats reads 4-byte rows
+// Round 5: two more seat counts for the IVF second phase (scan_mq_body_x).  A group with 1-2 live seats reads 4-byte rows
 // (one LDS cycle per 64 lookups instead of two, v_add_u32 adds at full issue rate), one with 5-6 reads 12 of a 16-byte row
 // (ds_read_b64 + ds_read_b32: three LDS cycles instead of four, three dword adds instead of two 64-bit ones).  Rows are kept
 // as dwords of two u16 fields; everything else — bounds, bias test, rare emit path, software pipeline — as in scan_mq_body.
@@ -795,24 +770,20 @@ __device__ __forceinline__ void scan_mq_kernel_body(const ScanItem* __restrict__
         // live seat, so that a form never drops a seat whatever the planner did
         int nlive = 0;
         for (int j = 0; j < nq; ++j) nlive = its[j].n != 0 ? j + 1 : nlive;
-#if QADC_MQ_SEATS26
         if (nlive <= 2) {
             scan_mq_body_x<M, U, 2>(its, it, min(nq, 2), bx, G, qtables, qstates, hdr, out, cand_cap, R);
             return;
         }
-#endif
         if (nlive <= 4) {
-            scan_mq_body<M, U, 4, QADC_MQ_PIPE != 0>(its, it, min(nq, 4), bx, G, qtables, qstates, hdr, out, cand_cap, R);
+            scan_mq_body<M, U, 4, true>(its, it, min(nq, 4), bx, G, qtables, qstates, hdr, out, cand_cap, R);
             return;
         }
-#if QADC_MQ_SEATS26
         if (nlive <= 6) {
             scan_mq_body_x<M, U, 6>(its, it, min(nq, 6), bx, G, qtables, qstates, hdr, out, cand_cap, R);
             return;
         }
-#endif
     }
-    scan_mq_body<M, U, 8, NARROW && QADC_MQ_PIPE != 0>(its, it, nq, bx, G, qtables, qstates, hdr, out, cand_cap, R);
+    scan_mq_body<M, U, 8, NARROW && true>(its, it, nq, bx, G, qtables, qstates, hdr, out, cand_cap, R);
 }
 
 template <int M, int U>
@@ -940,18 +911,18 @@ void launch_scan_i8_small(int M, const ScanItem* d_items, int nitems, int wgs_pe
     else         hipLaunchKernelGGL((scan_i8_small_kernel<32, 4>), grid, block, 0, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cap_per_query, R);
 }
 
-template <int M, int U, bool NT, bool CHUNK, bool PROBE, bool PF>
+template <int M, bool NT, bool CHUNK, bool PROBE>
 static void launch_scan_variant(dim3 grid, hipStream_t stream, const ScanItem* d_items, const int8_t* d_qtables,
                                 QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap, uint32_t R,
                                 uint32_t sib_items) {
-    auto k = &scan_i8_kernel<M, U, NT, CHUNK, PROBE, PF>;
+    auto k = &scan_i8_kernel<M, NT, CHUNK, PROBE>;
     static std::atomic<uint64_t> done{0};
     ensure_dynamic_lds(reinterpret_cast<const void*>(k), ScanCfg<M>::LDS_BYTES, done);
     hipLaunchKernelGGL(k, grid, dim3(kWG), ScanCfg<M>::LDS_BYTES, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, sib_items);
 }
 
-// variant bits: [1:0] U = 1,2,4 (index 0,1,2)  [2] NT  [3] CHUNK  [4] PROBE  [5] PF (software prefetch)
-// [6] sibling-major 1-D launch (every run of the launch covers the same codes; see the kernel's decode).
+// variant bits: [2] NT (non-temporal loads)  [3] CHUNK  [4] PROBE (ceiling diagnostic)
+// [6] sibling-major 1-D launch (every run of the launch covers the same codes; see the kernel's decode).  Other bits: ignored.
 void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int wgs_per_item,
                     const int8_t* d_qtables, QueryState* d_qs, CandHeader* d_hdr, Cand* d_cands, uint32_t cand_cap,
                     uint32_t R, hipStream_t stream) {
@@ -959,29 +930,18 @@ void launch_scan_i8(int M, int variant, const ScanItem* d_items, int nitems, int
     const dim3 grid = sib ? dim3((unsigned)wgs_per_item * (unsigned)nitems) : dim3(wgs_per_item, nitems);
     const uint32_t sib_items = sib ? (uint32_t)nitems : 0u;
 #define QADC_ARGS grid, stream, d_items, d_qtables, d_qs, d_hdr, d_cands, cand_cap, R, sib_items
-#define QADC_V(MM, UU, NTT, CH, PR) \
-    do { if (variant & 32) launch_scan_variant<MM, UU, NTT, CH, PR, true>(QADC_ARGS); \
-         else launch_scan_variant<MM, UU, NTT, CH, PR, false>(QADC_ARGS); } while (0)
-#define QADC_DISPATCH_U(MM, NTT, CH, PR)                                    \
-    switch (variant & 3) {                                                  \
-        case 0: QADC_V(MM, 1, NTT, CH, PR); break;                          \
-        case 2: QADC_V(MM, 4, NTT, CH, PR); break;                          \
-        default: QADC_V(MM, 2, NTT, CH, PR); break;                         \
-    }
 #define QADC_DISPATCH_P(MM, PR)                                             \
     switch ((variant >> 2) & 3) {                                           \
-        case 0: QADC_DISPATCH_U(MM, false, false, PR) break;                \
-        case 1: QADC_DISPATCH_U(MM, true, false, PR) break;                 \
-        case 2: QADC_DISPATCH_U(MM, false, true, PR) break;                 \
-        default: QADC_DISPATCH_U(MM, true, true, PR) break;                 \
+        case 0: launch_scan_variant<MM, false, false, PR>(QADC_ARGS); break; \
+        case 1: launch_scan_variant<MM, true, false, PR>(QADC_ARGS); break;  \
+        case 2: launch_scan_variant<MM, false, true, PR>(QADC_ARGS); break;  \
+        default: launch_scan_variant<MM, true, true, PR>(QADC_ARGS); break;  \
     }
 #define QADC_DISPATCH(MM)                                                   \
     if (variant & 16) { QADC_DISPATCH_P(MM, true) } else { QADC_DISPATCH_P(MM, false) }
     if (M == 16) { QADC_DISPATCH(16) } else { QADC_DISPATCH(32) }
 #undef QADC_DISPATCH
 #undef QADC_DISPATCH_P
-#undef QADC_DISPATCH_U
-#undef QADC_V
 #undef QADC_ARGS
 }
 
@@ -1921,44 +1881,6 @@ void launch_select_kth(const float* d_fc, uint64_t fc_stride, const uint32_t* d_
                            d_ftables, d_qtables, table_dim_all, quant_mode, export_vals, export_flags, d_front_out);
 }
 
-// Pre-scan items of a queries-in batch built on the device: one per (query, probe), straight from assign[] and the partition
-// table (the level path's planner builds them on the host from a host copy of assign[]).  One wave per query: lane a = probe a
-// (ma <= 64 per round), out_off = the exclusive prefix of the probes' start sizes, fc_init = {all starts, capacity}.
-__global__ __launch_bounds__(256) void ivf_front_items_kernel(const int32_t* __restrict__ assign, const PartDesc* __restrict__ parts, int nq,
-                                                              int ma, uint32_t cap, StartItem* __restrict__ items,
-                                                              uint32_t* __restrict__ fc_init) {
-    const int q = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
-    const uint32_t lane = threadIdx.x & 63u;
-    if (q >= nq) return;
-    uint32_t base = 0;
-    for (int a0 = 0; a0 < ma; a0 += 64) {
-        const int a = a0 + (int)lane;
-        uint32_t sn = 0;
-        const uint8_t* sc = nullptr;
-        if (a < ma) {
-            const PartDesc& d = parts[assign[(size_t)q * ma + a]];
-            sn = d.global_n ? d.start_n : 0u;
-            sc = d.starts ? d.starts : d.codes;
-        }
-        const uint32_t incl = dpp_wave_incl_sum(sn);
-        if (a < ma) {
-            StartItem it;
-            it.codes = sc;
-            it.n = sn;
-            it.table = (uint32_t)((size_t)q * ma + a);
-            it.query = (uint32_t)q;
-            it.out_off = base + incl - sn;
-            it.filter = 0;
-            items[(size_t)q * ma + a] = it;
-        }
-        base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    }
-    if (lane == 0) {
-        fc_init[2 * q] = min(base, cap);
-        fc_init[2 * q + 1] = cap;
-    }
-}
-
 // ---- stream-layout probe (qadc_stream_probe): does a dispatch that WAITS FOR CUs on stream A hold up stream B? ----
 // probe_spin_kernel: many 256-thread workgroups that hold 64 KiB of LDS each (two per CU: most wave slots stay free) and spin
 // for spin_ticks of the 100 MHz wall clock: the launch keeps its queue's dispatcher waiting for CUs for several rounds.
@@ -1985,11 +1907,6 @@ hipError_t launch_stream_probe(unsigned long long* d_t, int spin_wgs, uint32_t s
     hipLaunchKernelGGL(probe_spin_kernel, dim3(spin_wgs), dim3(256), 65536, a, d_t, spin_ticks);
     hipLaunchKernelGGL(probe_mark_kernel, dim3(1), dim3(64), 0, b, d_t);
     return hipGetLastError();
-}
-
-void launch_ivf_front_items(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, uint32_t cap, StartItem* d_items,
-                            uint32_t* d_fc_init, hipStream_t stream) {
-    hipLaunchKernelGGL(ivf_front_items_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, d_assign, d_parts, nq, ma, cap, d_items, d_fc_init);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2742,10 +2659,7 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restri
 // (query, probe) is 65 K workgroups of 512 results each at the C5 shape — the launch was bound by workgroup dispatch and by
 // re-reading the codebook row per result (92 us alone on the GPU for 134 MB of tables; round 4: -> 8 K workgroups).
 // Entry for entry the arithmetic of build_tables_kernel: the same residual, the same sums in the same grouping.
-#ifndef QADC_BT_PROBES
-#define QADC_BT_PROBES 16
-#endif
-constexpr int kBTProbes = QADC_BT_PROBES;
+constexpr int kBTProbes = 16;
 __global__ __launch_bounds__(256) void build_tables_multi_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
                                                                  const int32_t* __restrict__ assign,
                                                                  const float* __restrict__ codebooks, int ma, int M, int dim,

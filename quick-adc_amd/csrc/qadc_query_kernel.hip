@@ -43,15 +43,6 @@ constexpr uint32_t kOrderBuckets = 1024;   // order_cands_kernel's bucket-sort s
 // else is dispatched there.  Round 4, same-box A/B on one of 8 ranks' IVF batch: replay 16 -> 4 waves per workgroup and the
 // one-workgroup totals kernel 1024 -> 256 threads: C3 0.52 -> 0.45 ms per batch, C5 0.81 -> 0.78 (profiles/r04_side_wg_ab.txt).
 constexpr int kSideWG = 256;
-#ifndef QADC_SELECT_THRESHOLD
-#define QADC_SELECT_THRESHOLD 1   // 0: the front's select runs its radix passes only (A/B builds)
-#endif
-#ifndef QADC_BUCKET_SORT
-#define QADC_BUCKET_SORT 1   // 0: the ordering passes always run the bitonic network (A/B builds)
-#endif
-#ifndef QADC_WALK_PIPE
-#define QADC_WALK_PIPE 1
-#endif
 
 namespace qadc {
 
@@ -88,27 +79,21 @@ __device__ __forceinline__ void q_lds_barrier() {
 // one dword = the four tables of a code dword, replicated over the 32 banks of a ds_read lane group; a lane reads
 // with bank = lane & 31.  64 KiB (16x4: two workgroups per CU) / 128 KiB (32x4: one).  The tables start at LDS
 // address 0 (absolute addressing spares an add per lookup) and OVERLAY the pre-scan's buffers, which are dead by then.
-// 32x4 (QADC_Q32_REPL16, round 4): the same image with SIXTEEN replicas — row x (256 B) = [dword 0: 16 replicas][dword 1]
+// 32x4 (round 4): the same image with SIXTEEN replicas — row x (256 B) = [dword 0: 16 replicas][dword 1]
 // [dword 2][dword 3], address x*256 + g*64 + (lane & 15)*4 + j — is 64 KiB instead of 128, so TWO workgroups share a CU
 // (32 waves instead of 16 to hide the walk's latencies behind) at the price of a 2-way bank conflict on every lookup
 // (lanes l and l + 16 of a 32-lane group share a replica): the walk is latency / issue bound, the LDS pipe 30 % busy.
-// Round 5 (QADC_Q32_SWIZZLE): the conflict is a property of the ORDER in which a lane takes its code's dwords, not of the image.
+// Round 5: the conflict is a property of the ORDER in which a lane takes its code's dwords, not of the image.
 // Lanes with bit 4 set (h = 1) process the dwords as 1, 0, 3, 2: at the lookup (w, k) they read group w ^ 1 — so the 32 lanes of a
 // pass touch banks (w * 16 + l) and ((w ^ 1) * 16 + l), l = 0..15: 32 distinct banks, no conflict, same 64 KiB image.  Price:
 // four v_cndmask per code (the dword swap); the address bytes come from two lane constants, (lane & 15) * 4 + 64 h for even w
 // and (lane & 15) * 4 + 64 (1 - h) for odd w, with the immediate offset (w & ~1) * 64 + k.
-#ifndef QADC_Q32_REPL16
-#define QADC_Q32_REPL16 1
-#endif
-#ifndef QADC_Q32_SWIZZLE
-#define QADC_Q32_SWIZZLE 1
-#endif
 template <int M, int WG = 1024>
 struct QCfg {
     static constexpr int CS = M / 2, DW = M / 8, CPL = 16 / CS;
     static constexpr int WAVES = WG / 64;                        // waves of the query workgroup (kQWaves, or 8: the IVF head's 512-thread form)
-    static constexpr bool R16 = M == 32 && QADC_Q32_REPL16 != 0;  // 16 replicas per dword, all four dwords in one 64 KiB region
-    static constexpr bool SWZ = R16 && QADC_Q32_SWIZZLE != 0;    // the two 16-lane halves of a pass read different dword groups
+    static constexpr bool R16 = M == 32;                           // 16 replicas per dword, all four dwords in one 64 KiB region
+    static constexpr bool SWZ = R16;                                 // the two 16-lane halves of a pass read different dword groups
     static constexpr int TABLE_BYTES = R16 ? 65536 : (M / 16) * 65536;
     static constexpr int WTAB_BYTES = WAVES * M * 16 * 4;        // float[waves][M*16] (pre-scan)
     static constexpr int FCAP = (TABLE_BYTES - WTAB_BYTES) / 4;  // pre-scan values kept in LDS: 12288 / 24576
@@ -318,9 +303,9 @@ __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand,
     // array, then an entry's place inside its bucket is the number of smaller keys there (the lanes that share a bucket
     // read them as broadcasts).  The keys are distinct (they end in the entry's index), so the order is the network's.
     // Not taken — the network runs — when the candidates exceed half the key array or one bucket holds more than
-    // bucket_max entries (256; option "wgq_order_bucket_max" — the tests lower it to reach the fallback).
+    // bucket_max entries (256).
     bool sorted_by_buckets = false;
-    if (QADC_BUCKET_SORT && scr && nslots != 0 && nslots * 2 <= scr_slots && ncand <= kCap / 2) {
+    if (scr && nslots != 0 && nslots * 2 <= scr_slots && ncand <= kCap / 2) {
         uint32_t s_log = 5;                                      // sub-buckets per slot: 32, fewer when the scratch is short
         while ((nslots << s_log) > scr_slots) --s_log;
         const uint32_t nb = nslots << s_log;
@@ -712,7 +697,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         //    threshold T some percent up the distribution.  ONE pass over the values keeps every key <= T (all of them:
         //    ranks below T stay exact) in the dead per-wave table area, and the radix passes run over those few hundred
         //    keys.  Fewer than R kept (an unlucky sample) or more than the area holds: the passes run over all values
-        //    (option "wgq_select_rank" = m, for the tests to reach both).
+        //    (tests/test_gpu_parity.py builds a list whose sample is unlucky on purpose.)
         //  * once the chosen digit's bin holds <= 256 keys they are collected and ranked by counting.
         // Either way the result is the exact R-th smallest key.
         const uint32_t n = s_nvals;
@@ -745,11 +730,11 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                     }
                 }
             };
-            if (QADC_SELECT_THRESHOLD && n > 2048u) {
+            if (n > 2048u) {
                 if (wave == 0) {
                     const uint32_t i = (uint32_t)((uint64_t)lane * n / 64u);   // (evenly spaced: the values lie probe by probe, nearest centroid first)
                     const uint32_t skey = q_fkey(in_lds ? vals[i] : gvals[i]);
-                    const uint32_t m = A.select_rank ? min(64u, A.select_rank) : min(64u, (uint32_t)((96ull * R + n - 1u) / n) + 3u);
+                    const uint32_t m = min(64u, (uint32_t)((96ull * R + n - 1u) / n) + 3u);
                     uint32_t less = 0, le = 0;
 #pragma unroll 8
                     for (int j = 0; j < 64; ++j) {
@@ -966,7 +951,6 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     // replays and writes the ordered stream.  Exactness does not depend on how the waves interleave: the bound of an
     // epoch is fixed before its first code is tested, and the order is restored by the sort.
     constexpr int kRounds = U;                                   // loads per lane in flight
-    constexpr bool PIPE = QADC_WALK_PIPE;                        // (build-time A/B of the pipelined walk)
     constexpr uint32_t kEpochVec = 32768;                        // longest epoch (vectors): bounds how stale a bound gets
     uint32_t* hist_done = misc;                                  // [128] candidates of the finished epochs, by value
     uint32_t* hist_cur = misc + 128;                             // [128] candidates of the running epoch
@@ -1308,7 +1292,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 uint32_t width;
                 if (ramp < kEpochVec) {
                     width = min(ramp, rest);
-                    ramp <<= (A.ramp_shift ? A.ramp_shift : 1u);
+                    ramp <<= 1u;
                 } else {
                     width = min(rest, kEpochVec);
                 }
@@ -1332,7 +1316,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                     }
                 };
                 uint32_t tl = wave;
-                if constexpr (PIPE) {
+                {
                     // software pipeline over the full tiles: the NEXT iteration's loads are issued before the current tiles are
                     // summed, so a wave has loads in flight while it works the LDS pipe — without it the 16 (x 2 workgroups) waves of
                     // a CU, which issued their loads together, get them back together, and the memory system idles while they all
@@ -1364,8 +1348,6 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                             for (int i = 0; i < kRounds; ++i) v[i] = nv[i];
                         }
                     }
-                } else {
-                    for (; tl + (kRounds - 1) * kQWaves < full_tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, true>());
                 }
                 for (; tl < tiles; tl += kQWaves * kRounds) step(tl, std::integral_constant<bool, false>());
                 t0 += width;
@@ -1639,118 +1621,6 @@ __global__ __launch_bounds__(kQWG) void order_cands_kernel(const QueryState* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// kv_binheap<unsigned,int8_t>::push (binheap.hpp:75-116) for 64 queries per wave: lane l replays the ordered
-// stream of query q0 + l through its own max-heap of capacity R in LDS, sentinel (0,127) first
-// (db_query_4.cpp:276).  Heap slot i of lane l lives at (i*64 + l) * 8 bytes: the bank of an access depends on
-// the lane only, so the 64 lanes never conflict, whatever slots they are at.  One query's pushes are inherently
-// sequential (each is a dependent chain of LDS round trips); 64 of them per wave, and a few waves per batch,
-// replay a 1024-query IVF batch in the shadow of the next batch's scan, on a handful of CUs.
-// ---------------------------------------------------------------------------------------------
-// One lane's max-heap of capacity R in LDS, slot i at (i*64 + lane) * 8 bytes.  push() = kv_binheap::push
-// (binheap.hpp:75-116): appended and bubbled up past strictly smaller parents while there is room; afterwards accepted
-// only if strictly below the root, sinking with the left child preferred on ties, stopping at a child <= the value.
-struct LaneHeap {
-    uint64_t* hv;
-    uint32_t lane, R, size;
-    uint32_t depth;                                           // levels of a full heap: floor(log2(R)) + 1 (wave-uniform)
-    __device__ __forceinline__ static int32_t val_of(uint64_t e) { return (int32_t)((e >> 32) & 0xffu); }
-    __device__ __forceinline__ uint64_t& at(uint32_t i) { return hv[i * 64u + lane]; }
-    __device__ __forceinline__ void push(uint64_t e) {
-        const int32_t value = val_of(e);
-        if (size != R) {
-            uint32_t i = size++;
-            while (i != 0) {
-                const uint32_t parent = (i - 1) / 2;
-                const uint64_t pe = at(parent);
-                if (!(value > val_of(pe))) break;
-                at(i) = pe;
-                i = parent;
-            }
-            at(i) = e;
-            return;
-        }
-        // Full heap: replace the root if strictly smaller, then sink.  The 64 lanes of a wave sift 64 different heaps
-        // in lockstep, so the loop runs a wave-uniform number of levels with the per-lane state in a predicate (a
-        // data-dependent `break` per lane costs an exec-mask round trip per level and buys nothing: some lane almost
-        // always sinks to the bottom).
-        const bool accept = value < val_of(at(0));
-        if (__builtin_amdgcn_ballot_w64(accept) == 0) return;
-        // Branch-free levels: both children are read from clamped slots whether they exist or not and the shifted child
-        // is stored either to the hole or to a scratch row (slot R) — a predicated read or store costs an exec-mask round
-        // trip with its scalar bookkeeping, which doubled the length of this dependent chain.
-        bool sinking = accept;
-        uint32_t i = 0;
-        for (uint32_t lvl = 0; lvl < depth; ++lvl) {
-            const uint32_t l = 2 * i + 1;
-            const uint64_t le = at(min(l, R - 1)), re = at(min(l + 1, R - 1));
-            const bool has_l = sinking && l < size, has_r = sinking && l + 1 < size;
-            const bool right = has_r && val_of(re) > val_of(le); // the right child only if strictly greater
-            const uint64_t ce = right ? re : le;
-            const uint32_t c = right ? l + 1 : l;
-            const bool down = has_l && val_of(ce) > value;       // stop at a child <= the value
-            at(down ? i : R) = ce;
-            i = down ? c : i;
-            sinking = down;
-        }
-        at(accept ? i : R) = e;
-    }
-};
-
-// heaps of the 64 queries of a wave -> global, query by query, coalesced; 0xffffffff marks "replay on the host"
-__device__ __forceinline__ void lane_heaps_out(const uint64_t* hv, uint32_t lane, uint32_t size, bool host_replay, int q0, int nq,
-                                               uint32_t R, uint64_t* __restrict__ heaps, uint32_t* __restrict__ heap_sizes) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int l = 0; l < 64; ++l) {
-        const int qq = q0 + l;
-        if (qq >= nq) break;
-        const uint32_t sz = __shfl(size, l, 64);
-        const uint32_t hr = __shfl((uint32_t)host_replay, l, 64);
-        if (hr) {
-            if (lane == 0) heap_sizes[qq] = 0xffffffffu;
-            continue;
-        }
-        for (uint32_t i = lane; i < sz; i += 64) heaps[(size_t)qq * R + i] = hv[i * 64u + (uint32_t)l];
-        if (lane == 0) heap_sizes[qq] = sz;
-    }
-}
-
-__global__ __launch_bounds__(64) void replay_heap_lanes_kernel(const uint32_t* __restrict__ qflags,
-                                                               const uint64_t* __restrict__ stream, uint32_t cap, int nq,
-                                                               uint32_t R, uint64_t* __restrict__ heaps,
-                                                               uint32_t* __restrict__ heap_sizes) {
-    LaneHeap h{reinterpret_cast<uint64_t*>(qsmem), threadIdx.x, R, 0, 32u - (uint32_t)__builtin_clz(R)};
-    const uint32_t lane = threadIdx.x;
-    const int q = blockIdx.x * 64 + (int)lane;
-    const bool have = q < nq;
-    uint32_t flags = 0, n = 0;
-    if (have) { flags = qflags[4 * q]; n = qflags[4 * q + 1]; }
-    bool host_replay = false;                                   // overflowed stream: the batch is re-run / replayed on the host
-    if (have && n > cap) { host_replay = true; n = 0; }
-    if (flags & (1u | 32u)) n = 0;                              // qmax too high: the reference exits, no result / fallback pending
-    const uint64_t* __restrict__ src = stream + (size_t)(have ? q : 0) * cap;
-    if (have && !host_replay && !(flags & 1u)) h.push((uint64_t)127 << 32);   // the sentinel: key 0, value 127
-    // The stream of a lane is sequential in memory, 8 bytes at a time, a different cache line per lane: the next eight
-    // entries are requested BEFORE the current eight are pushed, so that their latency (a microsecond or two for 64
-    // scattered lines) passes under ~8 us of heap work instead of in front of it.
-    constexpr int kPF = 8;
-    uint64_t nxt[kPF];
-#pragma unroll
-    for (int u = 0; u < kPF; ++u) nxt[u] = (uint32_t)u < n ? src[u] : 0;
-    for (uint32_t j = 0; j < n; j += kPF) {
-        uint64_t cur[kPF];
-#pragma unroll
-        for (int u = 0; u < kPF; ++u) cur[u] = nxt[u] & 0xffffffffffull;
-#pragma unroll
-        for (int u = 0; u < kPF; ++u) nxt[u] = j + kPF + u < n ? src[j + kPF + u] : 0;
-#pragma unroll
-        for (int u = 0; u < kPF; ++u)
-            if (j + u < n) h.push(cur[u]);
-    }
-    lane_heaps_out(h.hv, lane, h.size, host_replay, blockIdx.x * 64, nq, R, heaps, heap_sizes);
-}
-
-// ---------------------------------------------------------------------------------------------
 // Multi-GPU: the code list is range-sharded over the ranks; every rank's ordered push stream is a
 // superset of the pushes the sequential scan's heap accepts from that range, so replaying the streams in GLOBAL scan
 // order (assign slot, rank, position) reproduces the reference heap array for array.  Two kernels around ONE
@@ -1969,10 +1839,7 @@ struct WaveHeap {
 // chain) beside the scan kernels.  Round 3 packed 16 to a workgroup so that they tie up few CUs; but a 16-wave workgroup must
 // first FIND half a CU free, and beside the partition-major scan (28 of 32 wave slots taken, in 4-wave workgroups) it waits
 // for that at the head of its queue.  Four to a workgroup start at once in the slots that scan leaves free (see kSideWG).
-#ifndef QADC_REPLAY_WAVES
-#define QADC_REPLAY_WAVES 4
-#endif
-constexpr int kReplayWaves = QADC_REPLAY_WAVES;                  // (round 3 packed 16 to a workgroup; see kSideWG)
+constexpr int kReplayWaves = 4;                  // (round 3 packed 16 to a workgroup; see kSideWG)
 template <int NREG, int QF>
 __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(const uint64_t* __restrict__ stream, const uint64_t* __restrict__ off,
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ info,
@@ -2092,10 +1959,7 @@ __global__ __launch_bounds__(256) void front_unpack_kernel(const unsigned char* 
 
 // ---- the world's gathered blocks -> ONE stream per query in global scan order (assign slot, rank, position) ----
 // Per query: totals and flags over the ranks, exclusive prefix over the queries (one workgroup).
-#ifndef QADC_TOTALS_THREADS
-#define QADC_TOTALS_THREADS 256
-#endif
-constexpr int kTotalsThreads = QADC_TOTALS_THREADS;
+constexpr int kTotalsThreads = 256;
 __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world, int nq,
                                                            uint64_t* __restrict__ moff, uint32_t* __restrict__ mcnt,
                                                            uint32_t* __restrict__ info, uint32_t* __restrict__ status) {
@@ -2310,7 +2174,6 @@ static hipError_t dynamic_lds_optin(const void* fn, int bytes, std::atomic<uint6
     return hipSuccess;
 }
 
-size_t query_kernel_lds_bytes(int M) { return M == 16 ? QCfg<16>::LDS_BYTES : QCfg<32>::LDS_BYTES; }
 uint32_t query_kernel_lds_values(int M) { return M == 16 ? QCfg<16>::FCAP : QCfg<32>::FCAP; }
 
 template <int M, int U, int OCC, bool NT, bool MULTI, bool HEAD = false, int WG = 1024>
@@ -2361,19 +2224,11 @@ static hipError_t launch_scan_query_v(int nq, const QueryKernelArgs& args, hipSt
                             : launch_scan_query_nt<M, U, OCC, false, false>(nq, args, stream);
 }
 
-// variant = 64-vector tiles (16-byte loads per lane in flight) per wave and iteration: 0 -> 2 (default), 1 -> 3, 2 -> 4, 3 -> 6.
-// 16x4: two workgroups per CU (64 KiB of tables each); 32x4: one (128 KiB).
-hipError_t launch_scan_query(int M, int variant, int nq, const QueryKernelArgs& args, hipStream_t stream,
-                             const void* inline_payload, size_t inline_bytes) {
-    if (M == 16) {
-        if (variant == 1) return launch_scan_query_v<16, 3, QCfg<16>::OCC>(nq, args, stream, inline_payload, inline_bytes);
-        if (variant == 2) return launch_scan_query_v<16, 4, QCfg<16>::OCC>(nq, args, stream, inline_payload, inline_bytes);
-        if (variant == 3) return launch_scan_query_v<16, 6, 4>(nq, args, stream, inline_payload, inline_bytes);   // one workgroup per CU, 128 VGPRs
-        return launch_scan_query_v<16, 2, QCfg<16>::OCC>(nq, args, stream, inline_payload, inline_bytes);
-    }
-    if (variant == 1) return launch_scan_query_v<32, 3, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
-    if (variant == 2) return launch_scan_query_v<32, 4, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
-    if (variant == 3) return launch_scan_query_v<32, 6, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
+// Two 64-vector tiles (16-byte loads per lane) in flight per wave and iteration (3, 4 and 6 were measured in round 4: no faster).
+// 16x4: two workgroups per CU (64 KiB of tables each); 32x4: two as well (16 replicas).
+hipError_t launch_scan_query(int M, int nq, const QueryKernelArgs& args, hipStream_t stream, const void* inline_payload,
+                             size_t inline_bytes) {
+    if (M == 16) return launch_scan_query_v<16, 2, QCfg<16>::OCC>(nq, args, stream, inline_payload, inline_bytes);
     return launch_scan_query_v<32, 2, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
 }
 
@@ -2394,12 +2249,6 @@ hipError_t launch_order_cands(const QueryState* d_qs, const Cand* d_regions, uin
     hipLaunchKernelGGL(order_cands_kernel, dim3(nq), dim3(kQWG), kOrderCandCap * 8, stream, d_qs, d_regions, cand_cap, ccap, d_stream, cap,
                        d_qout, d_qflags, (uint32_t)ma, pos_bits);
     return hipGetLastError();
-}
-
-uint32_t replay_lanes_max_R() { return 288; }                    // (R + 1) * 512 B of LDS per wave (<= 144.5 KiB): R slots + a scratch row
-
-static hipError_t lane_heap_lds_optin(const void* fn, std::atomic<uint64_t>& done) {
-    return dynamic_lds_optin(fn, (int)((replay_lanes_max_R() + 1) * 512), done);
 }
 
 hipError_t launch_dist_pack(const uint32_t* d_src_off, const uint32_t* d_src_cnt, const uint32_t* d_src_flags, int nq,
@@ -2501,16 +2350,6 @@ hipError_t launch_dist_merge(const uint64_t* d_gathered, size_t block_words, int
 hipError_t launch_dist_heaps_unpack(const uint64_t* d_all, size_t share_words, int world, int per, int nq, uint32_t R, uint64_t* d_heaps,
                                     uint32_t* d_sizes, hipStream_t stream) {
     hipLaunchKernelGGL(dist_heaps_unpack_kernel, dim3(nq), dim3(256), 0, stream, d_all, share_words, world, per, nq, R, d_heaps, d_sizes);
-    return hipGetLastError();
-}
-
-hipError_t launch_replay_heap_lanes(const uint32_t* d_qflags, const uint64_t* d_stream, uint32_t cap, int nq, uint32_t R,
-                                    uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream) {
-    static std::atomic<uint64_t> done{0};
-    const hipError_t e = lane_heap_lds_optin(reinterpret_cast<const void*>(&replay_heap_lanes_kernel), done);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(replay_heap_lanes_kernel, dim3((nq + 63) / 64), dim3(64), ((size_t)R + 1) * 512, stream, d_qflags, d_stream,
-                       cap, nq, R, d_heaps, d_heap_sizes);
     return hipGetLastError();
 }
 

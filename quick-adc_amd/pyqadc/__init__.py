@@ -27,7 +27,7 @@ SYMBOLS = [
     "qadc_index_add_partition_device", "qadc_index_add_partition_synthetic",
     "qadc_index_add_partition_shard", "qadc_index_add_partition_synthetic_shard", "qadc_query_scan_collect_candidates",
     "qadc_index_set_key_base", "qadc_index_finalize", "qadc_index_partition_count",
-    "qadc_index_partition_size", "qadc_index_start_size", "qadc_set_option",
+    "qadc_index_partition_size", "qadc_index_start_size", "qadc_set_option", "qadc_option_names",
     "qadc_index_read_codes", "qadc_query_scan", "qadc_query_scan_candidates", "qadc_scan_i8",
     "qadc_scan_i8_candidates", "qadc_scan_start", "qadc_query_scan_submit", "qadc_prescan_submit",
     "qadc_prescan_collect", "qadc_query_scan_submit_prescanned",
@@ -52,8 +52,7 @@ class Profile(C.Structure):
                 ("group_head_ms", C.c_double), ("group_scan_ms", C.c_double), ("group_order_ms", C.c_double),
                 ("group_head_codes", C.c_uint64), ("group_pairs", C.c_uint64), ("group_seats", C.c_uint64),
                 ("group_pass_codes8", C.c_uint64), ("group_pass_codes4", C.c_uint64), ("group_batches", C.c_uint64),
-                ("front_sharded_batches", C.c_uint64), ("dist_async_collects", C.c_uint64),
-                ("front_tp_batches", C.c_uint64)]
+                ("front_sharded_batches", C.c_uint64), ("dist_async_collects", C.c_uint64)]
 
 
 class QadcError(RuntimeError):
@@ -172,6 +171,13 @@ def replay_i8(keys, vals, R, sentinel=False):
 def device_prepare(device=0):
     """qadc_device_prepare: the library's per-device stream set, created now — call before any communicator is initialised."""
     _check(lib().qadc_device_prepare(int(device)))
+
+
+def option_names():
+    """The names qadc_set_option accepts (qadc_option_names)."""
+    f = lib().qadc_option_names
+    f.restype = C.c_char_p
+    return f().decode().split(",")
 
 
 def stream_layout(device=0):

@@ -38,16 +38,14 @@ def po():
 def pytest_generate_tests(metafunc):
     """Every GPU parity test runs through the scan paths of the library: the level-structured one (QADC_WGQ=0:
     bound levels, many workgroups per run, candidate sort), the same with its first levels replaced by a head launch
-    (QADC_HEAD_LEVEL=2), and the one-workgroup-per-query one (QADC_WGQ=2, wherever it is structurally possible) — that
-    one twice: with its device-side heap replay as one wave per query (the default) and as one lane per query
-    (QADC_REPLAY_WAVE=0).  The environment variables are read by qadc_index_create; a test that sets the `wgq` option
-    itself overrides it."""
+    (QADC_HEAD_LEVEL=2), and the one-workgroup-per-query one (QADC_WGQ=2, wherever it is structurally possible).  The
+    environment variables are read by qadc_index_create; a test that sets the `wgq` option itself overrides it."""
     if metafunc.module.__name__.endswith("test_bench_launch"):
         return                                             # bench.py picks its own paths (and clears QADC_WGQ)
     if getattr(metafunc.function, "_path_independent", False):
         return                                             # (stateless build entry points: no query path involved)
     if metafunc.definition.get_closest_marker("gpu") and "scan_path" in metafunc.fixturenames:
-        metafunc.parametrize("scan_path", ["levels", "levels_head", "wgq", "wgq_lanes"], indirect=True)
+        metafunc.parametrize("scan_path", ["levels", "levels_head", "wgq"], indirect=True)
 
 
 @pytest.fixture(autouse=True)
@@ -56,7 +54,6 @@ def scan_path(request, monkeypatch):
     if mode is not None:
         monkeypatch.setenv("QADC_TEST_HOOKS", "1")         # (the library ignores the QADC_* hooks without it)
         monkeypatch.setenv("QADC_WGQ", "2" if mode.startswith("wgq") else "0")
-        monkeypatch.setenv("QADC_REPLAY_WAVE", "0" if mode == "wgq_lanes" else "1")
         # "levels_head": the first two bound levels of every query are scanned by one head launch of the query kernel
         monkeypatch.setenv("QADC_HEAD_LEVEL", "2" if mode == "levels_head" else "0")
     return mode

@@ -31,6 +31,27 @@ def test_exports_every_declared_symbol(pyqadc):
     assert b"gfx950" in lib.qadc_version()
 
 
+def test_the_option_list_is_thirty_names_and_the_tests_draw_them(pyqadc):
+    """qadc_option_names() = the options qadc_set_option accepts: at most 30, each documented in include/qadc.h, and each drawn
+    by the randomised parity sweep (tests/test_gpu_fuzz.py) — except `profile` (diagnostics), `wgq` / `head_level` (the scan_path
+    parametrisation of tests/conftest.py), `table_form` (test_search_with_device_side_feeders) and the dist_* ones
+    (tests/dist_worker.py, tests/dist_cases.py)."""
+    names = pyqadc.option_names()
+    assert len(names) == len(set(names)) <= 30
+    hdr = open(os.path.join(ROOT, "include", "qadc.h")).read()
+    fuzz = open(os.path.join(ROOT, "tests", "test_gpu_fuzz.py")).read()
+    dist = open(os.path.join(ROOT, "tests", "dist_worker.py")).read() + open(os.path.join(ROOT, "tests", "dist_cases.py")).read()
+    src = open(os.path.join(ROOT, "quick-adc_amd", "csrc", "qadc_capi.cpp")).read()
+    assert sorted(set(re.findall(r'n == "([a-z_0-9]+)"', src))) == sorted(names)          # the setter's chain and the list agree
+    elsewhere = {"profile", "wgq", "head_level", "table_form"}
+    for n in names:
+        assert '"%s"' % n in hdr, n
+        if n.startswith("dist_"):
+            assert n in dist, n
+        elif n not in elsewhere:
+            assert re.search(r"\b%s=" % n, fuzz), n
+
+
 def test_host_replay_matches_reference_golden(pyqadc):
     g = golden_cases.load()
     for i in range(int(g["n_heap_cases"])):

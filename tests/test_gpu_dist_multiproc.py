@@ -57,8 +57,6 @@ def oracle_heaps(po, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_native_merge_with_several_processes_on_one_gpu(po, world, tmp_path, scan_path):
-    if scan_path == "wgq_lanes":
-        pytest.skip("the merge replays by waves whatever `replay_wave` says: same run as 'wgq'")
     names = CASES
     res = run_world(world, names, tmp_path)
     for name in names:

@@ -78,8 +78,7 @@ def test_gpu_per_code_values_match_reference_golden(pyqadc, po, g):
         assert np.array_equal(idx.candidates_i8(p0, c["qt"][0]), c["cand"]), c["cid"]
         want = np.sort(c["fcand"])
         for path in ("one", "mq"):
-            idx.set_option("prescan_mq", 1 if path == "mq" else 0)
-            nq = 8 if path == "mq" else 1                    # (the multi-query pre-scan kernel takes groups of queries)
+            nq = 8 if path == "mq" else 1                    # (the multi-query pre-scan kernel takes groups of queries that share their starts)
             tb = np.repeat(c["tables"][None, :1, :], nq, 0).copy()
             got = np.array([idx.scan_start(np.full((nq, 1), p0, np.int32), tb, k)[nq - 1] for k in range(1, len(want) + 1)])
             assert np.array_equal(got, want), (c["cid"], path)

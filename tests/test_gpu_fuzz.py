@@ -40,25 +40,22 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
     idx = pyqadc.Index(M)
     idx.add_partitions(parts, labels=labels)
     idx.finalize(keep)
+    # every option of qadc_set_option that changes HOW a batch is computed (never what): tests/test_capi_host.py checks that this
+    # list and the library's agree ("profile" and the qadc_dist_* ones apart: test_gpu_dist_multiproc.py draws those)
     opts = dict(small_run=int(rng.choice([1024, 8192, 131072])), mq=int(rng.integers(0, 2)),
-                share_variant=int(rng.choice([0, 0x41, 0x49])), cand_capacity=int(rng.choice([64, 1024, 16384])),
+                share_variant=int(rng.choice([0, 0x40, 0x48])), variant=int(rng.choice([0x00, 0x04, 0x08, 0x0c])),
+                wgs_per_item=int(rng.choice([0, 0, 3])), cand_capacity=int(rng.choice([64, 1024, 16384])),
                 prescan_sample=int(rng.choice([64, 4096, 65536])), level_base=int(rng.choice([64, 512, 4096])),
-                level_growth=int(rng.choice([2, 4, 8])), overlap_front=int(rng.integers(0, 2)),
-                prescan_mq=int(rng.integers(0, 2)),
+                level_growth=int(rng.choice([2, 4, 8])),
                 front_run_max=int(rng.choice([0, 4096, 8 << 20])), device_replay_nq=int(rng.choice([0, 1, 1])), device_replay_alone_nq=int(rng.choice([0, 0, 512])),
-                # one-workgroup-per-query path: workgroups per query, kernel variant, tiny stream / candidate capacities
-                wgq_split=int(rng.choice([1, 3, 8])), wgq_variant=int(rng.choice([0, 1, 2, 3])),
+                # one-workgroup-per-query path (`wgq` and `head_level` come from the scan_path parametrisation of tests/conftest.py):
+                # workgroups per query, tiny stream / candidate capacities
+                wgq_split=int(rng.choice([1, 3, 8])), wgq_split_codes=int(rng.choice([1024, 8192])),
                 wgq_capacity=int(rng.choice([64, 4096])), wgq_cand_cap=int(rng.choice([64, 4096, 4096])),
-                # partition-major second phase of device-replayed batches (with its overflow fallback), head length
-                wgq_group=int(rng.choice([0, 2, 2])), wgq_group_head=int(rng.choice([1, 2, 4])),
-                # grouping of the float pre-scan's adds: the reference binary's (default) or the source's
-                sum_mode=int(rng.choice([1, 1, 0])),
-                # device replay of a partition-major batch released by the next batch's head launch or by collect
-                replay_defer=int(rng.integers(0, 2)),
-                # partition-major batches: the front as launches of small workgroups (device-built pre-scan items) or inside the head
-                front_tp=int(rng.integers(0, 2)),
-                # the partition-major batches' head launch in 512- or 1024-thread workgroups
-                head_wg=int(rng.choice([0, 512])))
+                # partition-major second phase of device-replayed batches (with its overflow fallback), head length and form
+                wgq_group=int(rng.choice([0, 2, 2])), wgq_group_head=int(rng.choice([1, 2, 4])), head_wg=int(rng.choice([0, 512])),
+                # the float half: grouping of the pre-scan's adds and the quantizer as the reference binary has them, or as its source reads
+                sum_mode=int(rng.choice([1, 1, 0])), quant_mode=int(rng.choice([1, 1, 0])))
     for k, v in opts.items():
         idx.set_option(k, v)
     tables = float_tables(rng, nq, ma, M, scale=float(rng.choice([0.2, 1.0])))
@@ -68,7 +65,7 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
         tables = np.where(rng.random(tables.shape) < 0.01, -np.float32(0.02) * tables, tables).astype(np.float32)
     res = idx.query_scan(assign, tables.copy(), R)
     for q in range(nq):
-        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R, sum_mode=opts["sum_mode"])
+        want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R, quant_mode=opts["quant_mode"], sum_mode=opts["sum_mode"])
         if want["rc"] != 0:                                # the reference would exit: reported as status
             assert res["status"][q] == 1, (seed, q, opts)
             continue

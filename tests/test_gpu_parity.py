@@ -212,11 +212,10 @@ def test_negative_int8_tables_rejected(pyqadc):
     idx.close()
 
 
-@pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x05, 0x09, 0x0d, 0x0e, 0x21, 0x2c, 0x2d, 0x2e, 0x26])
+@pytest.mark.parametrize("variant", [0x00, 0x04, 0x08, 0x0c])
 @pytest.mark.parametrize("M", [16, 32])
 def test_kernel_tuning_variants_are_exact(pyqadc, po, M, variant):
-    """Every tuning variant of the scan kernel (tiles in flight, non-temporal loads, chunked tile order,
-    software prefetch) must give the same heap arrays."""
+    """Every form of the scan kernel (non-temporal loads, chunked tile order, both, neither) must give the same heap arrays."""
     rng = np.random.default_rng(variant * 7 + M)
     sizes = [70001, 4097, 1]
     parts = [rand_codes(rng, s, M) for s in sizes]
@@ -901,7 +900,7 @@ def test_grouped_second_phase_orders_more_than_4096_candidates_per_query(pyqadc,
                                                         for a in range(1, ma)))
     assert max(estimate) > 5000 and sum(e > 4096 for e in estimate) >= 2, sorted(estimate)[-5:]   # (what the case is for)
     # ... and with the ordering pass held to the query kernel's 4096 the same batch does fall back (and still ends right)
-    idx.set_option("wgq_group_cand_cap", 4096)
+    idx.set_option("wgq_cand_cap", 4096)
     idx.profile_reset()
     res2 = idx.query_scan(assign, tables.copy(), R)
     assert idx.profile()["group_fallbacks"] >= 1
@@ -959,14 +958,11 @@ def test_wgq_prescan_values_beyond_the_lds_budget(pyqadc, po, M, n, keep):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rank", [0, 1, 2, 40, 64])
 @pytest.mark.parametrize("M,sizes,keep,R", [(16, (60001, 90001, 8000, 70001), 0.02, 100), (32, (1200001,), 0.02, 100),
                                            (16, (60001, 90001, 70001), 0.02, 1000), (16, (150001,), 0.02, 1)])
-def test_front_select_threshold_and_its_fallbacks_give_the_same_qmax(pyqadc, po, M, sizes, keep, R, rank):
+def test_front_select_threshold_gives_the_oracles_qmax(pyqadc, po, M, sizes, keep, R):
     """The front's select (R-th smallest pre-scan value = qmax) first keeps the keys below a threshold drawn from 64
-    sampled values and runs its radix passes over those.  rank 0 = the sample rank it computes itself; 1 / 2 = a threshold so
-    low that fewer than R keys are kept, 40 / 64 = so high that the kept keys exceed their LDS area (24 K values of the
-    32x4 case): both make the passes run over all values.  3 K .. 24 K values (LDS and global scratch), R = 1, 100 and 1000:
+    sampled values and runs its radix passes over those.  3 K .. 24 K values (LDS and global scratch), R = 1, 100 and 1000:
     qmin, qmax, int8 tables and heaps equal the oracle's every time."""
     rng = np.random.default_rng(77 + M + len(sizes) + R)
     parts = [rand_codes(rng, n, M) for n in sizes]
@@ -974,7 +970,6 @@ def test_front_select_threshold_and_its_fallbacks_give_the_same_qmax(pyqadc, po,
     idx.add_partitions(parts)
     idx.finalize(keep)
     idx.set_option("wgq", 2)
-    idx.set_option("wgq_select_rank", rank)
     nq, ma = 3, len(sizes)
     assign = np.stack([rng.permutation(len(sizes))[:ma] for _ in range(nq)]).astype(np.int32)
     tables = float_tables(rng, nq, ma, M)
@@ -990,10 +985,43 @@ def test_front_select_threshold_and_its_fallbacks_give_the_same_qmax(pyqadc, po,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R", [1, 7, 100, 288, 289, 1000])
-def test_wgq_device_replay_lanes_and_host_replay_agree(pyqadc, po, R):
-    """Batches of >= 64 queries replay on the device, one lane per query (replay_heap_lanes_kernel, R <= 288);
-    larger heaps and small batches replay on the host.  Ragged labelled partitions, tie-heavy tables, ma = 5."""
+@pytest.mark.parametrize("M", [16, 32])
+@pytest.mark.parametrize("sample", ["low", "high"])
+def test_front_select_with_an_unlucky_sample_falls_back_exactly(pyqadc, po, M, sample):
+    """The select's two fallbacks, reached by DATA: the 64 sampled pre-scan values (evenly spaced over the 8000 starts of a flat
+    list: positions lane * 8000 / 64) are made all-smallest ("low": the threshold keeps fewer than R keys) or all-largest ("high":
+    it keeps nearly everything — more than the kept-key area holds); either way the passes then run over all values and qmax,
+    the int8 tables and the heaps are the oracle's."""
+    rng = np.random.default_rng(4100 + M + len(sample))
+    n, keep, R = 400000, 0.02, 100
+    codes = rand_codes(rng, n, M)
+    nstart = po.start_size(n, keep)
+    assert nstart == 8000
+    pos = (np.arange(64, dtype=np.int64) * nstart) // 64
+    codes[:nstart] |= 0x11                                      # no start code has a zero nibble ...
+    codes[pos] = 0x00 if sample == "low" else 0xff              # ... or an all-ones one, except the sampled ones
+    codes[:nstart][np.all(codes[:nstart] == 0xff, axis=1) & ~np.isin(np.arange(nstart), pos)] ^= 0x22
+    tables = float_tables(rng, 1, 1, M)
+    t = tables.reshape(M, 16)
+    t[:, 0] = 0.0                                               # nibble 0: distance 0 — the sampled codes of "low" sum to exactly 0
+    t[:, 15] = t.max() * 4 + 1                                  # nibble 15: far — the sampled codes of "high" are the largest sums
+    idx = pyqadc.Index(M)
+    idx.add_partitions([codes])
+    idx.finalize(keep)
+    idx.set_option("wgq", 2)
+    got = idx.query_scan(np.zeros((1, 1), np.int32), tables.copy(), R, want_qtables=True)
+    want = po.query_scan(M, [codes], None, keep, [0], tables[0].copy(), R)
+    assert want["rc"] == got["status"][0] == 0
+    assert got["qmax"][0] == np.float32(want["qmax"]) and np.array_equal(got["qtables"][0], want["qtables"])
+    assert heaps_equal(got["heaps"][0], (want["keys"], want["values"]))
+    idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [1, 7, 100, 320, 321, 1000])
+def test_wgq_device_replay_and_host_replay_agree(pyqadc, po, R):
+    """Batches of >= 64 queries replay on the device, one wave per query with the heap in registers (replay_heap_wave_kernel,
+    R <= 320); larger heaps and small batches replay on the host.  Ragged labelled partitions, tie-heavy tables, ma = 5."""
     rng = np.random.default_rng(R)
     M, K, ma, nq = 16, 12, 5, 130
     sizes = [int(x) for x in rng.integers(1, 9000, K)]
@@ -1408,15 +1436,15 @@ def test_wgq_small_batches_split_a_query_over_several_workgroups(pyqadc, po, M, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [16, 32])
-@pytest.mark.parametrize("inline,poll", [(1, 1), (0, 1), (1, 0), (0, 0)])
-def test_wgq_lone_small_query_shortcuts_change_nothing(pyqadc, po, M, inline, poll):
-    """A lone small query takes three shortcuts: its input rides in the kernel arguments (wgq_inline), its first block
-    and the head of every workgroup's chunk are walked from registers loaded under the front, and the host reads its
-    completion from the mapped result block (wgq_poll).  Every combination, repeated with different tables on the same
+@pytest.mark.parametrize("profiled", [0, 1])
+def test_wgq_lone_small_query_shortcuts_change_nothing(pyqadc, po, M, profiled):
+    """A lone small query takes three shortcuts: its input rides in the kernel arguments, its first block and the head of every
+    workgroup's chunk are walked from registers loaded under the front, and the host reads its completion from the mapped result
+    block (not with the profile on: then the completion event is waited for).  Repeated with different tables on the same
     slot (stale records / stale stream entries would show): heaps == oracle.  Shapes: a flat list whose first block and
     chunks are fully register-resident, one whose chunks are longer than the resident part, one shorter than the
     first block (plain walk), a sharded tail (padding-lane replays at the very end) and labels."""
-    rng = np.random.default_rng(900 + M + 2 * inline + poll)
+    rng = np.random.default_rng(900 + M + profiled)
     keep, R = 0.05, 100                                        # (the shortest list still pre-scans more than R codes)
     for n, labelled, split, split_codes in [(100000, False, 12, 8192), (400003, True, 6, 16384), (5000, False, 12, 1024),
                                             (65536 + 7, True, 16, 4096)]:
@@ -1425,7 +1453,7 @@ def test_wgq_lone_small_query_shortcuts_change_nothing(pyqadc, po, M, inline, po
         idx = pyqadc.Index(M)
         idx.add_partitions([codes], [labels] if labelled else None)
         idx.finalize(keep)
-        for k, v in (("wgq", 2), ("wgq_split", split), ("wgq_split_codes", split_codes), ("wgq_inline", inline), ("wgq_poll", poll)):
+        for k, v in (("wgq", 2), ("wgq_split", split), ("wgq_split_codes", split_codes), ("profile", profiled)):
             idx.set_option(k, v)
         for rep in range(4):
             t = float_tables(rng, 1, 1, M)
@@ -1517,125 +1545,27 @@ def test_wgq_grouped_second_phase_matches_oracle(pyqadc, po, M, nq, ma, head, bi
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M", [16, 32])
-def test_throughput_front_of_partition_major_batches(pyqadc, po, M):
-    """Option front_tp: a partition-major batch runs its front — scan_4 over the starts of every probe, the R-th smallest, qmin /
-    clamp / QuantizerMAX — as three launches of small workgroups (items built on the device from assign[]) and the head starts
-    from int8 tables; same qmin, qmax, int8 tables, clamped float tables, statuses and heaps as the oracle, through the
-    host-table entry point (negative entries, a query whose probes hold fewer than R starts, an empty probed partition) and
-    through qadc_search."""
-    rng = np.random.default_rng(7200 + M)
-    sizes = [int(x) for x in rng.integers(200, 5000, 30)] + [0, 17, 40001, 30000, 300, 400]
-    parts = [rand_codes(rng, n, M) for n in sizes]
-    labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
-    keep, R, ma, K = 0.05, 100, 6, len(sizes)
-    idx = pyqadc.Index(M)
-    idx.add_partitions(parts, labels)
-    idx.finalize(keep)
-    for k, v in dict(wgq=2, wgq_group=2, wgq_group_head=2, device_replay_nq=1, device_replay_alone_nq=0, front_tp=1, profile=1).items():
-        idx.set_option(k, v)
-    nq = 150
-    assign = np.stack([rng.permutation(K - 2)[:ma] for _ in range(nq)]).astype(np.int32)
-    for q in range(nq):
-        b = (32, 33)[q % 2]
-        assign[q] = [b] + [p for p in assign[q] if p != b][:ma - 1]
-    assign[7] = [34, 35, 31, 30, 34, 35]                          # 15 + 20 + 0 + 0 ... starts < R: qmax stays FLT_MAX -> status 1
-    assign[7, 4:] = [31, 30]
-    tables = float_tables(rng, nq, ma, M, negatives=True)
-    tables = np.ascontiguousarray(tables + np.float32(0.6) * np.arange(ma, dtype=np.float32)[None, :, None])
-    t_gpu = tables.copy()
-    got = idx.query_scan(assign, t_gpu, R, want_qtables=True)
-    assert idx.profile()["front_tp_batches"] >= 1 and idx.profile()["group_launches"] >= 1
-    nstat = 0
-    for q in range(nq):
-        t_cpu = tables[q].copy()
-        want = po.query_scan(M, parts, labels, keep, assign[q], t_cpu, R)
-        assert got["status"][q] == want["rc"], q
-        assert got["qmax"][q] == np.float32(want["qmax"]) and got["qmin"][q] == np.float32(want["qmin"]), q
-        if want["rc"]:
-            nstat += 1
-            continue
-        assert np.array_equal(got["qtables"][q], want["qtables"]), q
-        assert np.array_equal(t_gpu[q], t_cpu), q
-        assert heaps_equal(got["heaps"][q], (want["keys"], want["values"])), q
-    assert nstat >= 1
-    idx.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M", [16, 32])
-def test_deferred_replay_of_pipelined_partition_major_batches(pyqadc, po, M):
-    """Option replay_defer: the device replay of a partition-major batch is not enqueued with the batch but released behind
-    the head launch of the NEXT such batch — or by collect when no later batch came.  Five batches through three slots (the
-    first is alone on the GPU: replayed at once; the last has no successor: released by its collect; one is collected while its
-    successor is already in flight), changing batch sizes; heaps == oracle for every query, and the same with the option off."""
-    rng = np.random.default_rng(7100 + M)
-    sizes = [int(x) for x in rng.integers(200, 5000, 30)] + [0, 17, 40001, 30000]
-    parts = [rand_codes(rng, n, M) for n in sizes]
-    labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
-    keep, R, ma, K = 0.05, 100, 6, len(sizes)
-    idx = pyqadc.Index(M)
-    idx.add_partitions(parts, labels)
-    idx.finalize(keep)
-    for k, v in dict(wgq=2, wgq_group=2, wgq_group_head=2, device_replay_nq=1, device_replay_alone_nq=0).items():
-        idx.set_option(k, v)
-    batches = []
-    for nq in (70, 131, 64, 200, 97):
-        assign = np.stack([rng.permutation(K)[:ma] for _ in range(nq)]).astype(np.int32)
-        for q in range(nq):                                       # a long first probe, later probes farther away: the head's bound holds
-            b = (32, 33)[q % 2]
-            assign[q] = [b] + [p for p in assign[q] if p != b][:ma - 1]
-        tables = float_tables(rng, nq, ma, M)
-        tables = np.ascontiguousarray(tables + np.float32(0.6) * np.arange(ma, dtype=np.float32)[None, :, None])
-        batches.append((assign, tables))
-    for defer in (1, 0):
-        idx.set_option("replay_defer", defer)
-        idx.set_option("profile", 1)
-        idx.profile_reset()
-        res = [None] * len(batches)
-        idx.submit(0, batches[0][0], batches[0][1].copy(), R)
-        idx.submit(1, batches[1][0], batches[1][1].copy(), R)       # deferred: released by batch 2's head
-        idx.submit(2, batches[2][0], batches[2][1].copy(), R)       # deferred: released by batch 3's head
-        res[0] = idx.collect(0)
-        idx.submit(0, batches[3][0], batches[3][1].copy(), R)
-        res[1] = idx.collect(1)
-        res[2] = idx.collect(2)
-        idx.submit(1, batches[4][0], batches[4][1].copy(), R)       # deferred, no successor: released by its collect
-        res[3] = idx.collect(0)
-        res[4] = idx.collect(1)
-        assert idx.profile()["group_launches"] == len(batches) and idx.profile()["group_fallbacks"] == 0
-        for b, (assign, tables) in enumerate(batches):
-            for q in range(assign.shape[0]):
-                want = po.query_scan(M, parts, labels, keep, assign[q], tables[q].copy(), R)
-                assert want["rc"] == res[b]["status"][q] == 0
-                sz = res[b]["sizes"][q]
-                assert heaps_equal((res[b]["keys"][q, :sz], res[b]["values"][q, :sz]), (want["keys"], want["values"])), (defer, b, q)
-    idx.close()
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("grouped", [True, False])
-@pytest.mark.parametrize("bucket_max", [256, 24, 3, 0])
-def test_ordering_pass_bucket_sort_and_its_bitonic_fallback_agree(pyqadc, po, grouped, bucket_max):
+@pytest.mark.parametrize("ma", [12, 70])
+def test_ordering_pass_bucket_sort_and_its_bitonic_fallback_agree(pyqadc, po, grouped, ma):
     """The ordering pass (candidates back into scan order: assign slot, then position) sorts by (slot, position
-    quarter-octave) buckets and ranks inside a bucket by counting; a query with a bucket above `wgq_order_bucket_max`
-    takes the bitonic network instead.  256 = the default; 24 and 3 = some / nearly all queries fall back; 0 = every query
-    with a candidate does.  Same heaps as the oracle in every form — on the partition-major path's order_cands_kernel
-    (grouped) and in the query kernel's own tail — with partitions from empty to 40001 codes (positions from one bucket
-    to all 29 quarter-octaves) and ma = 12 slots."""
-    rng = np.random.default_rng(515)
-    M, nq, ma, R, keep = 16, 130, 12, 100, 0.05
-    sizes = [int(x) for x in rng.integers(1, 3000, 30)] + [0, 15, 17, 40001, 129, 30000, 25013, 36000]
+    quarter-octave) buckets and ranks inside a bucket by counting; when the slots do not fit its scratch it takes the bitonic
+    network instead: ma = 12 is the bucket sort everywhere; with ma = 70 the query kernel's own tail (scratch for 127 buckets, two
+    sub-buckets per slot needed) runs the network while order_cands_kernel (1024 buckets) still sorts by buckets.  Same heaps as the
+    oracle in every form, with partitions from empty to 40001 codes (positions from one bucket to all 29 quarter-octaves)."""
+    rng = np.random.default_rng(515 + ma)
+    M, nq, R, keep = 16, 130, 100, 0.05
+    sizes = [int(x) for x in rng.integers(1, 3000, 80)] + [0, 15, 17, 40001, 129, 30000, 25013, 36000]
     parts = [rand_codes(rng, n, M) for n in sizes]
     labels = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in sizes]
     idx = pyqadc.Index(M)
     idx.add_partitions(parts, labels)
     idx.finalize(keep)
     for k, v in (("wgq", 2), ("wgq_group", 2 if grouped else 0), ("wgq_group_head", 3), ("device_replay_alone_nq", 0),
-                 ("profile", 1), ("wgq_order_bucket_max", bucket_max)):
+                 ("profile", 1)):
         idx.set_option(k, v)
     K = len(sizes)
-    big = [33, 35, 36, 37]
+    big = [83, 85, 86, 87]
     assign = np.stack([rng.permutation(K)[:ma] for _ in range(nq)]).astype(np.int32)
     for q in range(nq):
         b = big[q % 4]

@@ -404,7 +404,7 @@ def test_extraction_refuses_a_drifted_reference(tmp_path):
     out = tmp_path / "out"
     out.mkdir()
     assert subprocess.run([script, ref, str(out)], stderr=subprocess.PIPE).returncode == 0
-    assert sorted(os.listdir(out))[0].startswith("x_") and len(os.listdir(out)) == 18
+    assert sorted(os.listdir(out))[0].startswith("x_") and len(os.listdir(out)) == 21
     drift = tmp_path / "ref"
     drift.mkdir()
     for f in ("quantizers.hpp", "databases.hpp", "query_common.hpp", "db_query_4.cpp", "db_query.cpp", "distances.hpp", "databases.cpp", "quantizers.cpp",

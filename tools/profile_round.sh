@@ -1,13 +1,14 @@
 #!/bin/bash
-# Round-5 evidence (GPU box, via gpurun).  The headline of bench.py is now the metric's mode (32-query steps, ONE QUERY PER PASS), so:
+# Per-round evidence (GPU box, via gpurun; written in round 5, tag = first argument).  The headline of bench.py is the metric's mode
+# (32-query steps, ONE QUERY PER PASS), so:
 #   (1) `rocprofv3 --kernel-trace --stats` of the headline + batched regions only (side legs off): the average duration of
-#       scan_i8_kernel<16,2,true,true,..> there is what `roofline.avg_launch_ms` of that run's line must agree with
+#       scan_i8_kernel<16,true,true,false> there is what `roofline.avg_launch_ms` of that run's line must agree with
 #   (2) PMC passes of `bench.py --pmc-leg` (two steps of the headline's mode): FETCH_SIZE, WRITE_SIZE (separate passes), SQ / GRBM set
 #   (3) the same for the batched mode (QADC_BENCH_BATCHED loop only; as tools/profile_r02.sh did)
 #   (4) the default command under the kernel trace (every leg), the plain bench line
 #   (5) the IVF legs alone: kernel trace + PMC passes (as tools/profile_r04.sh), the one-of-8 stand-ins of both modes
-# Then: python3 tools/summarize_profile_r05.py   (writes profiles/r05_*)
-TAG=${1:-r05}
+# Then: python3 tools/summarize_profile_round.py <tag>   (writes profiles/<tag>_*)
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 # raw traces are hundreds of MB: they stay under /tmp on the box; only the summaries (gpurun_out/profiles_<tag>/) and the small logs travel back
@@ -38,7 +39,7 @@ for SH in c3 c5; do
 done
 cd $R
 python3 bench.py > $RAW/${TAG}_bench_plain.json 2> $RAW/${TAG}_bench_plain.err
-bash tools/dist_sizes_r05.sh > $RAW/${TAG}_shard_sizes.txt 2>&1
-QADC_TEST_HOOKS=1 bash tools/stream_order_ab3.sh > /dev/null 2>&1; cp gpurun_out/stream_order3.txt $RAW/${TAG}_ivf_shard_sizes.txt
-QADC_PROF_RAW=$RAW QADC_PROFILES_OUT=$R/gpurun_out/profiles_${TAG} python3 tools/summarize_profile_r05.py $TAG > gpurun_out/${TAG}_summary.log 2>&1
+bash tools/dist_sizes.sh > $RAW/${TAG}_shard_sizes.txt 2>&1
+RANKS_EMU=0 python3 tools/ivf_shard_sizes.py > $RAW/${TAG}_ivf_shard_sizes.txt 2>/dev/null
+QADC_PROF_RAW=$RAW QADC_PROFILES_OUT=$R/gpurun_out/profiles_${TAG} python3 tools/summarize_profile_round.py $TAG > gpurun_out/${TAG}_summary.log 2>&1
 tail -n 40 gpurun_out/${TAG}_summary.log

@@ -1,7 +1,7 @@
-"""gpurun_out/prof_r05_* (tools/profile_r05.sh) -> profiles/r05_*:
+"""gpurun_out/prof_<tag>_* (tools/profile_round.sh) -> profiles/<tag>_*  (file names below with tag r05):
 
   r05_headline_kernel_stats.csv     `rocprofv3 --kernel-trace --stats` kernel summary of `python3 bench.py --steps 20 --warmup 2` with
-                                    the side legs off: the headline region (scan_i8_kernel<16,2,true,true,..>: 32 queries per launch,
+                                    the side legs off: the headline region (scan_i8_kernel<16,true,true,false>: 32 queries per launch,
                                     ONE QUERY PER PASS) and the batched region (scan_i8_mq_kernel).  The AverageNs of scan_i8_kernel
                                     is what `roofline.avg_launch_ms` of r05_headline_bench.json (the line of that same run) must match.
   r05_headline_bench.json           the JSON line of that run
@@ -21,7 +21,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, TAG = os.environ.get("QADC_PROF_RAW", os.path.join(ROOT, "gpurun_out")), (sys.argv[1] if len(sys.argv) > 1 else "r05")
+G, TAG = os.environ.get("QADC_PROF_RAW", os.path.join(ROOT, "gpurun_out")), (sys.argv[1] if len(sys.argv) > 1 else "r06")
 P = os.environ.get("QADC_PROFILES_OUT", os.path.join(ROOT, "profiles"))
 os.makedirs(P, exist_ok=True)
 
