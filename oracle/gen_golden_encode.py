@@ -101,7 +101,10 @@ CASES = [  # cid, M, dim, n, kind, opq
 def main():
     assert po.have_ref_float(), "build oracle/_ref first (make -C oracle)"
     rng = np.random.default_rng(60406)
-    d = {"cases": np.array([c[0] for c in CASES]), "case_meta": np.array([[c[1], c[2], c[3], int(c[5])] for c in CASES], np.int32)}
+    import subprocess
+    gxx = subprocess.run(["g++", "-dumpfullversion"], stdout=subprocess.PIPE).stdout.decode().strip()
+    d = {"compiler": np.array("g++ %s -std=c++14 -O3 -m64 -mavx2 -mfma -mpopcnt -mbmi2 -ffast-math (oracle/Makefile REF_FLAGS)" % gxx),
+         "cases": np.array([c[0] for c in CASES]), "case_meta": np.array([[c[1], c[2], c[3], int(c[5])] for c in CASES], np.int32)}
     for cid, M, dim, n, kind, opq in CASES:
         cb, v = make_inputs(rng, M, dim, n, kind)
         rot = None

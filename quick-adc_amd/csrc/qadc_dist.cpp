@@ -46,7 +46,7 @@ int load_rccl(DistState& d, std::string& err) {
 // after issuing its own front gather: on the collectives' stream that gather then lies in front of the previous batch's
 // merge gather (which waits for that batch's scan), so a front that runs under the previous scan is not held up by it.
 // heap share of a rank: heaps u64[per][R], then sizes u32[per]
-static size_t share_words(int per, int R) { return (size_t)per * R + ((size_t)per + 1) / 2; }
+static size_t share_words(int per, int R) { return (size_t)per * R + ((size_t)per + 1) / 2 + 1; }   // heaps, sizes, the "broken stream" word
 
 int enqueue_merge_now(qadc_index* idx, Slot& s) {
     DistState& d = *idx->dist;
@@ -171,6 +171,7 @@ int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream) {
     DistSlot& ds = d.slot[slot_i];
     ds.enqueued = false;
     ds.pending = false;
+    ds.pending_share = false;                                 // (a resubmitted slot: nothing of an earlier, failed enqueue may survive)
     const int nq = s.nq, R = s.R, world = d.world;
     // (level-path batches as well: the ordering pass leaves what the pack needs in the query states.  Below dist_device_nq
     // queries the merge stays at collect time, where the ranks replay shares on the host's otherwise idle cores: enqueuing

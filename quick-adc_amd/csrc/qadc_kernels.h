@@ -201,7 +201,8 @@ size_t dist_interleave_max_cells();
 hipError_t launch_dist_merge(const uint64_t* d_gathered, size_t block_words, int world, int nq, int ma, uint32_t R,
                              uint64_t* d_moff, uint32_t* d_mcnt, uint32_t* d_info, uint64_t* d_merged, uint64_t* d_heaps,
                              uint32_t* d_heap_sizes, hipStream_t stream, uint32_t* d_status = nullptr, int q0 = 0, int qstep = 1);
-// d_all = the gathered shares, `share_words` u64 each: heaps u64[per][R] then sizes u32[per]; rank r's j-th heap is query j * world + r.
+// d_all = the gathered shares, `share_words` u64 each: heaps u64[per][R], sizes u32[per] (padded to u64), one "broken stream" word;
+// rank r's j-th heap is query j * world + r.  A set word in ANY share raises d_sizes[nq + 2] (the batch's status word 2) on this rank.
 hipError_t launch_dist_heaps_unpack(const uint64_t* d_all, size_t share_words, int world, int per, int nq, uint32_t R, uint64_t* d_heaps,
                                     uint32_t* d_sizes, hipStream_t stream);
 // The loopback stand-in for an all-gather (qadc_dist_init_loopback): the block into all `world` slots, one kernel.
@@ -219,7 +220,7 @@ hipError_t launch_dist_pack_qflags(const uint32_t* d_qflags, int nq, const uint6
 // (q0 / qstep: wave w replays query q0 + w * qstep and writes heap w — see launch_dist_merge)
 hipError_t launch_replay_heap_wave(const uint64_t* d_stream, const uint64_t* d_off, const uint32_t* d_cnt, const uint32_t* d_info,
                                    int nq, uint32_t R, uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream, int q0 = 0, int qstep = 1);
-// ... on the single-GPU layout of launch_replay_heap_lanes: query q's stream at q * cap, {flags, entries} in d_qflags[4q..].
+// ... on the single-GPU layout of the query kernel's streams: query q's stream at q * cap, {flags, entries} in d_qflags[4q..].
 // ... on the level path's layout: the compact ordered output of sort_cands_kernel, described by the query states.
 hipError_t launch_replay_heap_wave_states(const QueryState* d_qs, const uint64_t* d_stream, uint32_t out_cap, int nq, uint32_t R,
                                           uint64_t* d_heaps, uint32_t* d_heap_sizes, hipStream_t stream);

@@ -1921,7 +1921,9 @@ __global__ __launch_bounds__(kReplayWaves * 64) void replay_heap_wave_kernel(con
 }
 
 // ---- sharded replay of the multi-GPU merge: the ranks' heap shares -> the batch's heaps in query order ----
-// Rank r replayed queries r, r + world, ...: share block = heaps u64[per][R], then sizes u32[per] (per = ceil(nq / world)).
+// Rank r replayed queries r, r + world, ...: share block = heaps u64[per][R], then sizes u32[per] (per = ceil(nq / world)) padded
+// to whole u64 words, then ONE more word: != 0 if one of the rank's queries had a push stream that was not grouped by assign slot
+// (dist_interleave_kernel) — every rank then fails the batch (status word 2 = sizes[nq + 2]), not only the owner of the query.
 __global__ __launch_bounds__(256) void dist_heaps_unpack_kernel(const uint64_t* __restrict__ all, size_t share_words, int world, int per, int nq,
                                                                 uint32_t R, uint64_t* __restrict__ heaps, uint32_t* __restrict__ sizes) {
     const int q = blockIdx.x;                                    // one workgroup per query
@@ -1930,7 +1932,10 @@ __global__ __launch_bounds__(256) void dist_heaps_unpack_kernel(const uint64_t* 
     const uint32_t sz = reinterpret_cast<const uint32_t*>(blk + (size_t)per * R)[j];
     const uint32_t n = sz == 0xffffffffu ? 0u : min(sz, R);
     for (uint32_t i = threadIdx.x; i < n; i += 256) heaps[(size_t)q * R + i] = blk[(size_t)j * R + i];
-    if (threadIdx.x == 0) sizes[q] = sz;
+    if (threadIdx.x == 0) {
+        sizes[q] = sz;
+        if (reinterpret_cast<const uint32_t*>(blk + (size_t)per * R)[((per + 1) / 2) * 2]) sizes[nq + 2] = 1u;
+    }
 }
 
 // ---- sharded front: the ranks' shares -> the batch's arrays in query order ----
@@ -1962,7 +1967,8 @@ __global__ __launch_bounds__(256) void front_unpack_kernel(const unsigned char* 
 constexpr int kTotalsThreads = 256;
 __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world, int nq,
                                                            uint64_t* __restrict__ moff, uint32_t* __restrict__ mcnt,
-                                                           uint32_t* __restrict__ info, uint32_t* __restrict__ status) {
+                                                           uint32_t* __restrict__ info, uint32_t* __restrict__ status,
+                                                           uint32_t* __restrict__ share_flag) {
     __shared__ uint64_t wsum[16];
     __shared__ unsigned long long rank_tot[16];
     __shared__ uint32_t bad;
@@ -2030,6 +2036,7 @@ __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __res
         moff[q] = base;
         base += mcnt[q];
     }
+    if (share_flag && threadIdx.x == 0) *share_flag = 0;         // (sharded replay: this rank's "a stream of mine was broken" word, see below)
     if (status) {                                                // (host-mapped: the caller reads it after the batch's event)
         if (my_bad) atomicOr(&bad, my_bad);
         __syncthreads();
@@ -2050,7 +2057,7 @@ __global__ __launch_bounds__(1024) void dist_totals_kernel(const uint64_t* __res
 __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __restrict__ gathered, size_t block_words, int world,
                                                               int nq, int ma, const uint64_t* __restrict__ moff,
                                                               const uint32_t* __restrict__ info, uint64_t* __restrict__ merged, int q0, int qstep,
-                                                              uint32_t* __restrict__ status) {
+                                                              uint32_t* __restrict__ status, uint32_t* __restrict__ share_flag) {
     uint32_t* cnt_sg = reinterpret_cast<uint32_t*>(qsmem);        // [ma][world] -> exclusive prefix in (s, g) order
     uint32_t* cnt_gs = cnt_sg + (size_t)ma * world;               // [world][ma] -> exclusive prefix in (g, s) order
     __shared__ uint32_t wtot[4];
@@ -2094,6 +2101,9 @@ __global__ __launch_bounds__(256) void dist_interleave_kernel(const uint64_t* __
                     const bool live = i < n;
                     const bool broken = live && (sl >= (uint32_t)ma || (prev != 0xffffffffu && prev > sl));
                     if (broken && status) status[2] = 1u;
+                    // (sharded replay: only the rank that owns the query interleaves it — the word travels in its heap share, and
+                    //  dist_heaps_unpack_kernel raises status[2] on EVERY rank: the ranks must agree on the batch's error)
+                    if (broken && share_flag) *share_flag = 1u;
                     if (live && sl >= (uint32_t)ma) continue;
                     if (live && prev != sl) cnt_gs[g * ma + sl] = i;             // the run's first entry
                     if (live && next != sl) cnt_sg[sl * world + g] = i + 1;      // one past its last
@@ -2339,11 +2349,13 @@ hipError_t launch_dist_merge(const uint64_t* d_gathered, size_t block_words, int
     static std::atomic<uint64_t> done{0};
     const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&dist_interleave_kernel), 65536, done);
     if (e != hipSuccess) return e;
+    // (sharded replay, qstep = world > 1: d_heap_sizes points into this rank's heap share; the share's flag word follows its sizes)
+    uint32_t* d_share_flag = qstep > 1 ? d_heap_sizes + (((nq + qstep - 1) / qstep + 1) / 2) * 2 : nullptr;
     hipLaunchKernelGGL(dist_totals_kernel, dim3(1), dim3(kTotalsThreads), 0, stream, d_gathered, block_words, world, nq, d_moff, d_mcnt, d_info,
-                       d_status);
+                       d_status, d_share_flag);
     if (nmine == 0) return hipGetLastError();
     hipLaunchKernelGGL(dist_interleave_kernel, dim3(nmine), dim3(256), (size_t)ma * world * 8, stream, d_gathered, block_words, world, nq, ma,
-                       d_moff, d_info, d_merged, q0, qstep, d_status);
+                       d_moff, d_info, d_merged, q0, qstep, d_status, d_share_flag);
     return launch_replay_heap_wave(d_merged, d_moff, d_mcnt, d_info, nmine, R, d_heaps, d_heap_sizes, stream, q0, qstep);
 }
 

@@ -14,7 +14,8 @@
 //                      N 8:  ((t1+t2)+(t3+t4)) + ((t5+t6)+(t7+t0))
 //                      N 16: ((A+B)+C)+D   A=(t5+t6)+(t7+t8)  B=(t1+t2)+(t3+t4)  C=(t11+t12)+(t9+t10)  D=(t13+t14)+(t15+t0)
 //                      N 32: the 16-term grouping of t[0..16), then s = s + ((t[j+2]+t[j+3]) + (t[j]+t[j+1])), j = 16, 20, 24, 28
-//                      other N (no 2-term / 16-bit instance was read): source order
+//                      other N, and every 16-bit instance (scan_standard<uint16_t, N>: no such instance of the reference was read or
+//                      pinned — adc_sum<N, false>): source order
 //   sqdist(x, c, ds)   fmanorm<ds/8, ds%8>(x, c) (distances.hpp:60-76) as compute_dists_single_simd_cg calls it (294-311):
 //                      per AVX lane j acc[j] = fma(d, d, acc[j]) over the blocks (d = x - c), reduceadd's tree
 //                      (acc[j] + acc[j+4]; (r0+r2) + (r1+r3)); the scalar remainder is paired
@@ -37,9 +38,9 @@ inline int& float_sum_mode() {
     return mode;
 }
 
-template <int N>
+template <int N, bool PINNED = true>
 inline float adc_sum(const float* t) {
-    if (float_sum_mode() == 0 || !(N == 4 || N == 8 || N == 16 || N == 32)) {
+    if (!PINNED || float_sum_mode() == 0 || !(N == 4 || N == 8 || N == 16 || N == 32)) {
         float s = 0;
         for (int i = 0; i < N; ++i) s += t[i];
         return s;

@@ -35,7 +35,7 @@ void scan_standard(const std::uint8_t* pqcodes_, const unsigned* labels, const u
         const T* const code = pqcodes + (std::size_t)i * NSQ;
         float t[NSQ];
         for (int sq = 0; sq < NSQ; ++sq) t[sq] = dists[sq * NCENT + code[sq]];
-        const float candidate = adc_sum<NSQ>(t);
+        const float candidate = adc_sum<NSQ, sizeof(T) == 1>(t);   // (the as-compiled grouping was read off the uint8_t instances only)
         if (candidate < min) {
             bh.push(labels != nullptr ? labels[i] : i, candidate);
             min = bh.max();

@@ -22,9 +22,19 @@ def g():
     return golden_cases.load_query_scan()
 
 
+PINNED_GXX = "11.4.0"      # the groupings of the float sums were read off THIS compiler's build of the reference (-O3 -ffast-math -mavx2 -mfma)
+
+
 def _need_ref_float(po):
     if not po.have_ref_float():
         pytest.skip("oracle/_ref/libqadc_ref_float.so not built (no /root/reference here)")
+    import os
+    import subprocess
+    if os.path.isdir("/root/reference"):                        # (a live build: made by the local g++; the GPU box runs the prebuilt file)
+        v = subprocess.run(["g++", "-dumpfullversion"], stdout=subprocess.PIPE).stdout.decode().strip()
+        if v != PINNED_GXX:
+            pytest.skip("oracle/_ref was built by g++ %s; the as-compiled groupings (sum_mode / quant_mode / div_mode 1) are pinned to g++ %s: "
+                        "another compiler may group the reference's -ffast-math sums differently — not a failure of this repository" % (v, PINNED_GXX))
 
 
 def rand_tables(rng, ma, M, negatives=False):
