@@ -122,7 +122,7 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  *  diagnostics "profile"     0/1: HIP-event timing of the scan launches (qadc_profile_read)
  *  path        "wgq"         the one-workgroup-per-query path: 0 never, 1 auto (default), 2 whenever structurally possible
  *              "wgq_group"   large IVF batches take a partition-major second phase: 0 never, 1 auto, 2 whenever possible
- *              "wgq_group_head"  probes per query the head walks before it (default 2 at 16x4, 3 at 32x4; 4 under the multi-GPU merge)
+ *              "wgq_group_head"  probes per query the head walks before it (default 2; 4 under the multi-GPU merge)
  *              "head_level"  level path: bound levels 0 .. head_level-1 are scanned by ONE head launch (default 5; 0 = off)
  *              "head_wg"     512 = the IVF head in 512-thread workgroups (8 waves per query; default at 16x4), 0 = 1024
  *  level path  "mq"          queries that share a run are scanned 8 per pass (default 1)

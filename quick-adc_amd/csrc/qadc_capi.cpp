@@ -1243,10 +1243,8 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
     qadc_index* idx = new qadc_index();
     idx->M = M;
     idx->cs = M / 2;
-    if (M == 16) {                                             // the partition-major batches' head at 16x4: 8 waves per query, 2 probes
-        idx->head_wg = 512;                                    // (same-box A/B, profiles/r06_head_wg_ab.txt: C3 0.656 -> 0.607 us per query;
-        idx->group.head = 2;                                   //  32x4 keeps 16 waves and 3 probes: 3.99 against 4.02-4.05)
-    }
+    if (M == 16) idx->head_wg = 512;                           // the partition-major batches' head at 16x4: 8 waves per query (same-box A/B,
+                                                               // profiles/r06_head_wg_ab.txt: C3 0.656 -> 0.612 us per query; 32x4 keeps 16 waves)
     idx->device = device_id;
     // Test hooks (tests/conftest.py runs every parity test through every scan path this way).  They only apply when
     // QADC_TEST_HOOKS=1 is set as well, so that a stray QADC_* variable in a deployment cannot change the scan path.

@@ -355,7 +355,8 @@ constexpr int kShareLag = 1;                       // multi-GPU: a merge's heap-
 struct GroupState {
     int strikes = 0;       // grouped batches whose candidate regions overflowed (data whose later probes fall below the head's bound)
     int mode = 1;          // option "wgq_group": 0 never, 1 auto, 2 whenever possible
-    int head = 3;          // ... after a head of this many probes per query (one workgroup per query; 4 until the ordering pass took 8192 candidates)
+    int head = 2;          // ... after a head of this many probes per query (one workgroup per query).  Round 6, same-box A/B: 2 instead of 3
+                           // -1 % at C3 with the 8-wave head, -1.7 % at C5 (-2.8 % at 2048-query batches); 1 leaves the bound too loose
     int head_dist = 4;     // ... under the multi-GPU merge (probes with codes on this rank; option "wgq_group_head_dist")
     uint32_t cand_cap = kOrderCandCap;   // candidates per query of such a batch before it falls back (option "wgq_group_cand_cap")
 };
