@@ -190,7 +190,7 @@ struct Slot {
     uint64_t wgq_codes = 0;             // codes a query probes (exact maximum, or an estimate) — sizes wgq_G
     uint64_t head_codes = 0;            // level path: codes of every query's scan order covered by the head launch (0 = none)
     uint64_t wgq_fcap = 0;              // pre-scan values per query in the global scratch (0 = they fit LDS)
-    DevBuf<uint32_t> d_qflags;          // [nq][4]: {flags, entries} for replay_heap_lanes_kernel
+    DevBuf<uint32_t> d_qflags;          // [nq][4]: {flags, entries} for replay_heap_wave_kernel
     DevBuf<float> d_fvals;
     DevBuf<QCand> d_qcands;             // unordered candidates of the query workgroups (scratch)
     PinBuf<uint64_t> h_fetch;           // streams fetched on demand when they were left in device memory

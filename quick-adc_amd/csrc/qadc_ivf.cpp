@@ -30,7 +30,7 @@ bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64
 }
 
 // One launch per batch: scan_query_kernel (one workgroup per query), then — for batches large enough to replay on
-// the device — replay_heap_lanes_kernel on the side stream.  No host planning: the kernel walks assign[] and the
+// the device — replay_heap_wave_kernel on the side stream.  No host planning: the kernel walks assign[] and the
 // device partition table itself.
 int launch_wgq_batch(qadc_index* idx, Slot& s) {
     ScopedMs timer(idx->prof.host_plan_ms);

@@ -119,7 +119,7 @@ struct QueryKernelArgs {
     QCand* cands;            // [nq][ccap] unordered candidates (scratch)
     uint32_t ccap;           // <= kQueryCandCap
     QueryOut* qout;          // [nq]
-    uint32_t* qstate_flags;  // optional [nq][4]: {flags, entries} for replay_heap_lanes_kernel, or nullptr
+    uint32_t* qstate_flags;  // optional [nq][4]: {flags, entries} for replay_heap_wave_kernel, or nullptr
     uint32_t R;
     int quant_mode;
     int sum_mode;            // grouping of the float pre-scan's adds: 1 = as the reference is compiled, 0 = source order (qadc_float_sum.h)

@@ -21,7 +21,7 @@
 //
 // Output per query: the ordered push stream (entry = key | value << 32 | assign slot << 40, the format of the
 // sorted output of sort_cands_kernel) and a QueryOut record; the heap replay follows (host for small batches,
-// replay_heap_lanes_kernel — one LANE per query — for large ones).  Exactness argument: every dropped code has
+// replay_heap_wave_kernel — one WAVE per query, the heap in registers — for large ones).  Exactness argument: every dropped code has
 // cand >= the R-th smallest (<127) value of a set of codes that all PRECEDE it in this query's scan order
 // (the finished epochs), DESIGN.md section 4.
 //
@@ -1429,7 +1429,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         o.pad[0] = (uint32_t)min((clk1 - clk0) >> 6, (uint64_t)0xffff) | ((uint32_t)min((clk3 - clk2) >> 6, (uint64_t)0xffff) << 16);
         o.pad[1] = (uint32_t)((clk2 - clk1) >> 4);
         publish(o);
-        if (A.qstate_flags) {                                    // what replay_heap_lanes_kernel reads
+        if (A.qstate_flags) {                                    // what replay_heap_wave_kernel reads
             A.qstate_flags[4 * wgi + 0] = flags | 4u;
             A.qstate_flags[4 * wgi + 1] = s_count;
         }
@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_inline_kernel(QueryKerne
 // small kernels, no host round trip — into groups of up to 8 pairs that share one pass of scan_i8_mq_kernel over the
 // partition (one LDS lookup serves 8 queries).  Every pair is bound level 1: its bound derives from the head's
 // candidates only, i.e. from codes that precede it in its query's scan order, whatever order the groups run in.
-// order_cands_kernel then restores scan order per query and hands the streams to replay_heap_lanes_kernel.
+// order_cands_kernel then restores scan order per query and hands the streams to replay_heap_wave_kernel.
 // ---------------------------------------------------------------------------------------------
 // One wave per query, lanes = assign slots.  A (query, probe) pair belongs to the second phase iff its partition has codes
 // here and at least `h` such probes precede it in the query's assign[] (those are the head's: scan_query_kernel, HEAD).
@@ -1574,7 +1574,7 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int32_t* __restr
 }
 
 // One workgroup per query: the query's unordered Cand records (head + grouped pairs) -> ordered push stream in the
-// layout scan_query_kernel writes ([nq][cap] entries, QueryOut, {flags, entries} for the lane replay).
+// layout scan_query_kernel writes ([nq][cap] entries, QueryOut, {flags, entries} for the device replay).
 __global__ __launch_bounds__(kQWG) void order_cands_kernel(const QueryState* __restrict__ qstates, const Cand* __restrict__ regions,
                                                            uint32_t cand_cap, uint32_t ccap, uint64_t* __restrict__ stream,
                                                            uint32_t cap, QueryOut* __restrict__ qout, uint32_t* __restrict__ qflags,
