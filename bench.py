@@ -69,6 +69,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "quick-adc_amd"))
+# Kernel arguments in device memory (a HIP runtime setting, read when the runtime starts): a query kernel's first dependent reads —
+# its partition descriptors, and a lone small query's whole input, which rides in the kernel-argument segment — then come from HBM
+# instead of host memory over PCIe.  Synchronous single query: 54.9 -> 51.5 us on the same box (profiles/r06_latency_sweep.txt);
+# nothing else moves.  A serving process sets the same variable.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 LDS_PEAK_GCYC = 256 * 2.4  # LDS-array cycles per second: 256 CUs x 2.4 GHz nominal (same guide)
