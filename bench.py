@@ -1317,6 +1317,8 @@ def main():
                     out["ivf"] = {"error": "the multi-rank IVF legs did not finish within %s s; abandoned, exit code 3" % limit}
                     print(json.dumps(out), flush=True)
                     line_printed.append(1)
+                if rank != 0:
+                    time.sleep(1.0)                            # (rank 0's line first: a launcher tears the other ranks down at the first exit)
                 os._exit(3)
 
         limit = float(os.environ.get("QADC_BENCH_IVF_TIMEOUT", 420))
