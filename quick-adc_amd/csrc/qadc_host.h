@@ -348,7 +348,7 @@ constexpr uint64_t kFrontMinBatch = 3000000000ull; // leading levels join the fr
 constexpr int kWgqMinNq = 128;                     // query-kernel path, auto: batches of at least this many queries ...
 constexpr uint64_t kWgqMaxCodes = 1ull << 24;      //   ... probing at most this many codes per query, or
 constexpr uint64_t kWgqSmallCodes = 1ull << 18;    //   any batch probing at most this many codes per query
-constexpr uint32_t kGroupCodesPerWg = 16384;       // partition-major phase: codes of the longest partition per workgroup of a group
+constexpr uint32_t kGroupBytesPerWg = 131072;      // partition-major phase: bytes of the longest partition's codes per workgroup of a group
 constexpr int kShareLag = 1;                       // multi-GPU: a merge's heap-share gather is issued behind the first gather of the next merge
 
 // Partition-major second phase of large IVF batches (launch_wgq_batch, qadc_ivf.cpp)

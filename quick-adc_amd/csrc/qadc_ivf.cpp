@@ -323,10 +323,11 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         if (idx->profile) HIPCHECK(prof_event(s, st));
         HIPCHECK(launch_scan_query(M, nq, H, st));
         if (idx->profile) HIPCHECK(prof_event(s, st));
-        // (workgroups per group: 16 K codes each.  One workgroup per partition — the multi-query scans' own 64 K — leaves the C3 shape's
-        //  4.4 K groups 2.5 rounds of the GPU's 1792 resident workgroups, and the last round mostly empty: 0.335 -> 0.315 ms per
-        //  batch at C3, 3.29 -> 3.18 at C5 with 16 K; 8 K the same, 4 K slower: a table build per 4 tile iterations)
-        const uint64_t per_wg = kGroupCodesPerWg;
+        // (workgroups per group: 128 KiB of codes each — 16 K codes at 16x4, 8 K at 32x4.  One workgroup per partition — the multi-query
+        //  scans' own 64 K codes — leaves the C3 shape's 4.4 K groups 2.5 rounds of the GPU's 1792 resident workgroups, and the last
+        //  round mostly empty: 0.335 -> 0.315 ms per batch at C3 with 16 K; 8 K / 12 K / 24 K / 32 K measured again in round 6:
+        //  0.350 / 0.342 / 0.340 / 0.364 against 0.337.  C5: 16 K 3.06 ms, 8 K 2.97 (round 6, same box, profiles/r06_head_wg_ab.txt))
+        const uint64_t per_wg = kGroupBytesPerWg / (uint64_t)idx->cs;
         const int wgs = (int)std::max<uint64_t>(1, ((uint64_t)idx->max_part_n + per_wg - 1) / per_wg);
         launch_scan_i8_mq(M, d_gitems, (int)(ngroups * 8), wgs, A.qtables, s.d_qs, s.d_hdr, s.d_cands.p, gcap, (uint32_t)s.R, st,
                           /*narrow=*/1);
