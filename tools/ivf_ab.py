@@ -16,6 +16,8 @@ def main():
     import pyqadc
     torch.zeros(1, device="cuda:0")
     pyqadc.device_prepare(0)
+    import gc                                                  # as bench.py's main(): with torch loaded a full collection takes ~50 ms and
+    gc.collect(); gc.freeze(); gc.disable()                    # lands in some arm's timed loop (the "second arm" stall of the round-6 runs)
     shapes = ["c3", "c5"] if sys.argv[1] == "both" else [sys.argv[1]]
     arms = [a.split(":", 1) for a in sys.argv[2:]]
     reps = int(os.environ.get("AB_REPS", 2))
