@@ -1185,7 +1185,7 @@ def main():
         run_steps(1)
         idx.profile_reset()
         sync()
-        run_steps(max(3, args.steps // 4))
+        run_steps(max(3, args.steps // 2))
         sync()
         cprof = idx.profile()
         idx.set_option("variant", 0x0d)
