@@ -66,6 +66,28 @@ def ivf_queries(rng):
             "queries_whose_key_SET_differs": differ_sets}
 
 
+def coarse_assignment(rng):
+    """assign[] of 2000 queries over K = 4096 centroids (128-d, clustered), nprobe 32: this library's coarse distances (direct form,
+    one sequential sum) against the reference's FORM with a real BLAS in it (||q||^2 + ||c||^2 as compiled, then numpy's sgemm), both
+    through find_k_neighbors' selection (the oracle's pinned restatement)."""
+    K, dim, nq, ma = 4096, 128, 2000, 32
+    centres = 3 * rng.normal(size=(1000, dim)).astype(np.float32)
+    coarse = (centres[rng.integers(0, 1000, K)] + rng.normal(size=(K, dim))).astype(np.float32)
+    queries = (centres[rng.integers(0, 1000, nq)] + rng.normal(size=(nq, dim))).astype(np.float32)
+    direct = np.zeros((nq, K), np.float32)
+    for d in range(dim):
+        t = (queries[:, d:d + 1] - coarse[None, :, d]).astype(np.float32)
+        direct = (direct + (t * t).astype(np.float32)).astype(np.float32)
+    norms = np.concatenate([po.cross_dists(coarse[k0:k0 + 256], queries, with_product=False) for k0 in range(0, K, 256)], 1)   # BLOCK_NEIGHS = 256
+    blas = (norms + np.float32(-2.0) * (queries @ coarse.T)).astype(np.float32)
+    a_dir = po.select_k_neighbors(direct, ma)[0]
+    a_blas = po.select_k_neighbors(blas, ma)[0]
+    same_order = int((a_dir == a_blas).all(1).sum())
+    same_set = int(sum(set(x.tolist()) == set(y.tolist()) for x, y in zip(a_dir, a_blas)))
+    return {"what": coarse_assignment.__doc__.split("\n")[0], "queries": nq, "K": K, "nprobe": ma,
+            "queries_with_the_same_assign_array": same_order, "queries_with_the_same_probed_SET": same_set}
+
+
 def main():
     rng = np.random.default_rng(606)
     out = {"what": __doc__.split("\n\n")[0], "numpy": np.__version__, "cases": []}
@@ -100,6 +122,7 @@ def main():
         out["cases"].append(case)
         print(case, flush=True)
     out["ivf_queries"] = ivf_queries(rng)
+    out["coarse_assignment"] = coarse_assignment(rng)
     json.dump(out, open(os.path.join(ROOT, "profiles", "r06_sgemm_order_sensitivity.json"), "w"), indent=1)
 
 
