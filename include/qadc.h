@@ -234,10 +234,12 @@ int qadc_query_scan_collect_candidates(qadc_index* idx, int slot, uint64_t cand_
  *   opq::rotate_multiple_vectors        (quantizers.hpp:289-301)
  *   compute_dists_single_simd_cg        (distances.hpp:294-311)
  * followed by the same chain as qadc_query_scan.  Pinned to the reference's own code: the direct
- * table form (fmanorm as compiled), the residuals, and the SELECTION of the ma nearest — find_k_neighbors' heaps, exact
- * distance ties included (what the heap's history and kv_binheap::sort leave, neighbors.cpp:18-28, 47-71).  Restated,
- * unpinned: the distances under the selection and the BLAS-expansion table form (cblas_sgemm in the reference: sequential
- * float sums here); bit-exact against quick-adc_amd/host/query_driver.hpp, which evaluates the same loops on the host.
+ * table form (fmanorm as compiled), the residuals, the SELECTION of the ma nearest — find_k_neighbors' heaps, exact
+ * distance ties included (what the heap's history and kv_binheap::sort leave, neighbors.cpp:18-28, 47-71) — and the NORM half
+ * of the BLAS-expansion form (||v||^2 + ||c||^2 as compute_cross_dists_blas hands it to sgemm, distances.hpp:151-215): the
+ * coarse distances under the selection and the ma > 1 tables are in that form.  Restated, unpinned: the products of cblas_sgemm
+ * (OpenBLAS is not in the image: one sequential dot each); bit-exact against quick-adc_amd/host/query_driver.hpp and the
+ * oracle, which evaluate the same sums on the host.
  * ------------------------------------------------------------------------------------------- */
 /* codebooks [M][16][dim/M] (base_pq::centroids_flat order). */
 int qadc_index_set_pq(qadc_index* idx, int dim, const float* codebooks);
@@ -273,8 +275,8 @@ int qadc_pq_encode_host_mode(int M, int dim, const float* codebooks, const float
 
 /* N4, the rest of the build path (host buffers in and out, any device).
  * qadc_ivf_encode_host = the compute of index_db::add_vectors (databases.hpp:270-298) / flat_db::add_vectors (136-156):
- *   nearest coarse centroid per vector (K > 0; squared L2 in ascending d, lowest index on ties — find_k_neighbors with
- *   k = 1), residual, optional OPQ rotation rotated[r] = sum_c x[c] * rotation[r][c] (quantizers.hpp:289-301; rotation
+ *   nearest coarse centroid per vector (K > 0; find_k_neighbors with k = 1 on the expansion distances: first strict
+ *   minimum), residual, optional OPQ rotation rotated[r] = sum_c x[c] * rotation[r][c] (quantizers.hpp:289-301; rotation
  *   [dim][dim] or NULL), PQ encode (quantizers.hpp:222-245; qadc_pq_encode above, _mode likewise).  assign_out [n]
  *   (nullable; untouched when K == 0), codes [n][M/2].  The caller dispatches (assign, code, label = index + offset) to its partitions in vector order
  *   like databases.hpp:291-297 (host/db_build.hpp does).

@@ -64,11 +64,16 @@ struct ScratchFree {                                           // hipFree on eve
 };
 constexpr uint64_t kBuildChunk = 32768;                        // vectors per pass (the distance scratch is chunk x K floats)
 
-// nearest centroid of every vector, chunk by chunk: the coarse kernels of qadc_search with ma = 1
-int assign_nearest(const float* d_vectors, uint64_t n, int dim, int K, const float* d_coarse, float* d_dist, int32_t* d_assign) {
+// nearest centroid of every vector, chunk by chunk: the coarse kernels of qadc_search with ma = 1 (find_k_neighbors with k = 1 on the
+// expansion distances).  d_dist: chunk x K distances + chunk query norms + K centroid norms (the centroids may have moved: each call).
+int assign_nearest(const float* d_vectors, uint64_t n, int dim, int K, const float* d_coarse, float* d_dist, int32_t* d_assign, int sum_mode) {
+    const uint64_t chunk = std::min<uint64_t>(kBuildChunk, std::max<uint64_t>(n, 1));
+    float* d_qnorm = d_dist + chunk * (uint64_t)K;
+    float* d_cnorm = d_qnorm + chunk;
+    launch_row_sqnorm(d_coarse, K, dim, sum_mode, d_cnorm, nullptr);
     for (uint64_t o = 0; o < n; o += kBuildChunk) {
         const int cnt = (int)std::min<uint64_t>(kBuildChunk, n - o);
-        launch_coarse_assign(d_vectors + o * dim, d_coarse, cnt, K, dim, 1, d_dist, d_assign + o, nullptr);
+        launch_coarse_assign(d_vectors + o * dim, d_coarse, cnt, K, dim, 1, d_qnorm, d_cnorm, sum_mode, d_dist, d_assign + o, nullptr);
     }
     HIPCHECK(hipGetLastError());
     return QADC_OK;
@@ -102,7 +107,7 @@ int qadc_ivf_encode_host_mode(int M, int dim, const float* codebooks, const floa
     if (K > 0) {
         HIPCHECK(mem.alloc(&d_coarse, sizeof(float) * (size_t)K * dim));
         HIPCHECK(hipMemcpy(d_coarse, coarse, sizeof(float) * (size_t)K * dim, hipMemcpyHostToDevice));
-        HIPCHECK(mem.alloc(&d_dist, sizeof(float) * (size_t)std::min<uint64_t>(kBuildChunk, std::max<uint64_t>(n, 1)) * K));
+        HIPCHECK(mem.alloc(&d_dist, sizeof(float) * ((size_t)std::min<uint64_t>(kBuildChunk, std::max<uint64_t>(n, 1)) * (K + 1) + K)));
         HIPCHECK(mem.alloc(&d_assign, sizeof(int32_t) * n));
     }
     HIPCHECK(mem.alloc(&d_v, sizeof(float) * n * dim));
@@ -110,7 +115,7 @@ int qadc_ivf_encode_host_mode(int M, int dim, const float* codebooks, const floa
     HIPCHECK(hipMemcpy(d_v, vectors, sizeof(float) * n * dim, hipMemcpyHostToDevice));
     const float* d_enc = d_v;
     if (n && K > 0)
-        if (int rc = assign_nearest(d_v, n, dim, K, d_coarse, d_dist, d_assign)) return rc;
+        if (int rc = assign_nearest(d_v, n, dim, K, d_coarse, d_dist, d_assign, sum_mode != 0)) return rc;
     if (n && (K > 0 || rotation)) {
         HIPCHECK(mem.alloc(&d_x, sizeof(float) * n * dim));
         launch_residual_rotate(d_v, n, dim, d_coarse, d_assign, d_rot, d_x, nullptr);
@@ -138,13 +143,13 @@ int qadc_kmeans_iterations_host_mode(const float* vectors, uint64_t n, int dim, 
     int32_t* d_assign = nullptr;
     HIPCHECK(mem.alloc(&d_v, sizeof(float) * n * dim));
     HIPCHECK(mem.alloc(&d_c, sizeof(float) * (size_t)K * dim));
-    HIPCHECK(mem.alloc(&d_dist, sizeof(float) * (size_t)std::min<uint64_t>(kBuildChunk, n) * K));
+    HIPCHECK(mem.alloc(&d_dist, sizeof(float) * ((size_t)std::min<uint64_t>(kBuildChunk, n) * (K + 1) + K)));
     HIPCHECK(mem.alloc(&d_assign, sizeof(int32_t) * n));
     HIPCHECK(hipMemcpy(d_v, vectors, sizeof(float) * n * dim, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(d_c, centroids, sizeof(float) * (size_t)K * dim, hipMemcpyHostToDevice));
     HIPCHECK(hipMemset(d_assign, 0, sizeof(int32_t) * n));
     for (int it = 0; it < iters; ++it) {                       // databases.cpp:57-89
-        if (int rc = assign_nearest(d_v, n, dim, K, d_c, d_dist, d_assign)) return rc;
+        if (int rc = assign_nearest(d_v, n, dim, K, d_c, d_dist, d_assign, 1)) return rc;
         launch_kmeans_update(d_v, n, dim, K, d_assign, d_c, div_mode != 0, nullptr);
     }
     HIPCHECK(hipGetLastError());

@@ -334,6 +334,8 @@ struct FeederState {
     bool has_rotation = false;
     int K = 0;                   // coarse centroids (0 = flat)
     DevBuf<float> d_coarse;      // [K][dim]
+    DevBuf<float> d_cnorm;       // [K] ||centroid||^2 as compute_cross_dists_blas adds it (launch_row_sqnorm), for sum_mode cnorm_mode
+    int cnorm_mode = -1;         // (-1: not computed yet / the centroids changed)
     int table_form = 2;          // float tables of qadc_search: 0 direct, 1 BLAS expansion, 2 the reference's nns_engine rule
 };
 

@@ -382,6 +382,17 @@ bool will_group(const qadc_index* idx, int nq, int ma, bool dev_replay) {
            (idx->group.mode == 2 || (idx->group.mode == 1 && idx->group.strikes < 2 && nq >= 256 && pairs >= 2 * nparts));
 }
 
+// ||c||^2 of the coarse centroids, once per centroid set and sum_mode, on the stream the coarse kernels run on
+static int ensure_cnorm(qadc_index* idx, hipStream_t cs) {
+    FeederState& f = idx->feed;
+    if (f.cnorm_mode == idx->sum_mode) return QADC_OK;
+    HIPCHECK(f.d_cnorm.ensure((size_t)f.K));
+    launch_row_sqnorm(f.d_coarse.p, f.K, f.dim, idx->sum_mode, f.d_cnorm.p, cs);
+    HIPCHECK(hipGetLastError());
+    f.cnorm_mode = idx->sum_mode;
+    return QADC_OK;
+}
+
 // N1: queries in.  Coarse assignment runs on the copy stream (so it does not queue behind the previous
 // batch's scan), the host reads assign[] back to plan the work items, residuals and float tables are built
 // on the GPU by the main stream.
@@ -445,9 +456,11 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
         if (s.front_n) {
             HIPCHECK(hipMemcpyAsync(s.d_queries.p, s.h_queries.p + (size_t)s.front_q0 * dim, sizeof(float) * (size_t)s.front_n * dim,
                                     hipMemcpyHostToDevice, cs));
-            HIPCHECK(s.d_cdist.ensure((size_t)s.front_n * idx->feed.K));
+            HIPCHECK(s.d_cdist.ensure((size_t)s.front_n * idx->feed.K + (size_t)s.front_n));   // (+ the queries' norms behind the distances)
+            if (int rc = ensure_cnorm(idx, cs)) return rc;
             int32_t* d_assign_share = reinterpret_cast<int32_t*>(s.d_fblock.p + (size_t)s.front_per * tab);
-            launch_coarse_assign(s.d_queries.p, idx->feed.d_coarse.p, s.front_n, idx->feed.K, dim, ma, s.d_cdist.p, d_assign_share, cs);
+            launch_coarse_assign(s.d_queries.p, idx->feed.d_coarse.p, s.front_n, idx->feed.K, dim, ma, s.d_cdist.p + (size_t)s.front_n * idx->feed.K,
+                                 idx->feed.d_cnorm.p, idx->sum_mode, s.d_cdist.p, d_assign_share, cs);
             HIPCHECK(hipGetLastError());
         }
         if (!s.ev_feed) HIPCHECK(hipEventCreateWithFlags(&s.ev_feed, hipEventDisableTiming));
@@ -465,8 +478,10 @@ int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int
     }
     HIPCHECK(hipMemcpyAsync(s.d_queries.p, s.h_queries.p, sizeof(float) * (size_t)nq * dim, hipMemcpyHostToDevice, cs));
     if (idx->feed.K) {
-        HIPCHECK(s.d_cdist.ensure((size_t)nq * idx->feed.K));
-        launch_coarse_assign(s.d_queries.p, idx->feed.d_coarse.p, nq, idx->feed.K, dim, ma, s.d_cdist.p, s.d_assign.p, cs);
+        HIPCHECK(s.d_cdist.ensure((size_t)nq * idx->feed.K + (size_t)nq));                     // (+ the queries' norms behind the distances)
+        if (int rc = ensure_cnorm(idx, cs)) return rc;
+        launch_coarse_assign(s.d_queries.p, idx->feed.d_coarse.p, nq, idx->feed.K, dim, ma, s.d_cdist.p + (size_t)nq * idx->feed.K,
+                             idx->feed.d_cnorm.p, idx->sum_mode, s.d_cdist.p, s.d_assign.p, cs);
         HIPCHECK(hipGetLastError());
         if (!s.ev_feed) HIPCHECK(hipEventCreateWithFlags(&s.ev_feed, hipEventDisableTiming));
         HIPCHECK(hipEventRecord(s.ev_feed, cs));             // the tables need assign[] on the device, not the copy below
@@ -538,6 +553,7 @@ int qadc_index_set_coarse(qadc_index* idx, int K, const float* centroids) {
     HIPCHECK(idx->feed.d_coarse.ensure((size_t)K * idx->feed.dim));
     HIPCHECK(hipMemcpy(idx->feed.d_coarse.p, centroids, (size_t)K * idx->feed.dim * sizeof(float), hipMemcpyHostToDevice));
     idx->feed.K = K;
+    idx->feed.cnorm_mode = -1;
     return QADC_OK;
 }
 

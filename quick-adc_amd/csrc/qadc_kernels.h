@@ -287,8 +287,13 @@ void launch_residual_rotate(const float* d_vectors, uint64_t n, int dim, const f
                             const float* d_rotation, float* d_out, hipStream_t stream);
 void launch_kmeans_update(const float* d_vectors, uint64_t n, int dim, int K, const int32_t* d_assign, float* d_centroids,
                           int div_mode, hipStream_t stream);
-void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
-                          int32_t* d_assign, hipStream_t stream);
+// Coarse assignment of nq queries: the reference's find_k_neighbors (neighbors.cpp:30-76) — expansion distances
+// (||q||^2 + ||c||^2) - 2 q.c (compute_cross_dists_blas, distances.hpp:151-183: norms as compiled under sum_mode 1, the product one
+// sequential dot) into d_dist [nq][K], then the ma nearest per query as its heaps select them (exact ties included) into
+// d_assign [nq][ma].  d_cnorm [K] = launch_row_sqnorm of the centroids (the caller's, once per centroid set); d_qnorm [nq] scratch.
+void launch_row_sqnorm(const float* d_rows, int n, int dim, int sum_mode, float* d_out, hipStream_t stream);
+void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_qnorm,
+                          const float* d_cnorm, int sum_mode, float* d_dist, int32_t* d_assign, hipStream_t stream);
 // Residual + per-query distance tables (compute_dists_single_simd_cg's result, distances.hpp:294-311):
 // tables[q][a][m][c] = sum_d ((x - centroid[assign])[m*ds+d] - codebook[m][c][d])^2; sum_mode 1: added like the
 // reference's fmanorm as compiled (AVX lanes + fused multiply-add + reduceadd tree: direct_sqdist in qadc_kernels.hip),

@@ -2048,6 +2048,71 @@ __device__ __forceinline__ void xs_std_sort(const ExactSel& x, int n) {
     }
 }
 
+// ||x - c||^2 over ds components as the reference's direct table form adds it: fmanorm<ds/8, ds%8> called by
+// compute_dists_single_simd_cg (distances.hpp:60-76, 294-311) AS COMPILED with the reference's flags (pinned to that
+// build through the oracle's orc_tables_direct; host twin: host/float_sum.hpp sqdist):
+//   per AVX lane j: acc[j] = fma(d, d, acc[j]) over the ds/8 blocks, d = x - c;  reduceadd's tree acc[j] + acc[j+4],
+//   then (r0 + r2) + (r1 + r3);  the scalar remainder is paired p_k = fma(d_2k, d_2k, r(d_2k+1^2)), d = c - x:
+//   REM 4 -> (p0 + p1) + vec,  REM 6 -> (vec + p2) + (p0 + p1).
+// sum_mode 0, or a remainder the reference has no instance of (sq_dim 3 of BASELINE configs[4]; its dispatch is
+// distances.cpp:50-84): one sequential sum in ascending d.  X / C: anything indexable by int (pointer or register array).
+template <typename X, typename C>
+__device__ __forceinline__ float direct_sqdist(const X& x, const C& c, int ds, int sum_mode) {
+    const int blocks = ds >> 3, rem = ds & 7;
+    if (sum_mode == 0 || !(rem == 0 || rem == 4 || rem == 6)) {
+        float s = 0.0f;
+        for (int d = 0; d < ds; ++d) {
+            const float t = x[d] - c[d];
+            s += t * t;
+        }
+        return s;
+    }
+    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int b = 0; b < blocks; ++b) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = x[b * 8 + j] - c[b * 8 + j];
+            acc[j] = __fmaf_rn(d, d, acc[j]);
+        }
+    }
+    const float r0 = acc[0] + acc[4], r1 = acc[1] + acc[5], r2 = acc[2] + acc[6], r3 = acc[3] + acc[7];
+    const float vec = (r0 + r2) + (r1 + r3);
+    if (rem == 0) return vec;
+    float p[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (2 * k < rem) {
+            const float d0 = c[blocks * 8 + 2 * k] - x[blocks * 8 + 2 * k];
+            const float d1 = c[blocks * 8 + 2 * k + 1] - x[blocks * 8 + 2 * k + 1];
+            p[k] = __fmaf_rn(d0, d0, d1 * d1);
+        }
+    }
+    if (rem == 4) return (p[0] + p[1]) + vec;
+    return (vec + p[2]) + (p[0] + p[1]);
+}
+
+// The BLAS-expansion distance compute_cross_dists_blas<DSQ> (distances.hpp:151-215) leaves in dists[v][c]:
+//   ||v||^2 + ||c||^2 (153-176), then cblas_sgemm(alpha = -2, beta = 1) adds -2 v.c (178-182).
+// expansion_sqnorm = fmanorm<DSQ/8, DSQ%8>(vec) / norm_4(vec) AS COMPILED with the reference's flags (sum_mode 1): the
+// grouping of direct_sqdist with c = 0 — pinned to the reference's own text compiled up to the sgemm call (oracle/_ref
+// qadc_reff_cross_norms, the 14 dimensions of its dispatch, 16 centroids) through the oracle's orc_sqnorm; host twin:
+// host/float_sum.hpp sqnorm.  sum_mode 0, or a remainder the reference has no instance of: one sequential sum.
+// The product is OpenBLAS's in the reference (not in this image: restated, unpinned): one sequential dot in ascending d,
+// then base + (-2 dot) — -2 dot is exact, so this is the single rounding of a gemm kernel's C += alpha * acc.
+struct zero_vec {
+    __device__ __forceinline__ float operator[](int) const { return 0.0f; }
+};
+template <typename X>
+__device__ __forceinline__ float expansion_sqnorm(const X& x, int ds, int sum_mode) {
+    return direct_sqdist(x, zero_vec{}, ds, sum_mode);
+}
+template <typename X, typename C>
+__device__ __forceinline__ float expansion_dist(const X& x, const C& c, int ds, float vn, float cn) {
+    float dot = 0.0f;
+    for (int d = 0; d < ds; ++d) dot += x[d] * c[d];
+    return (vn + cn) + (-2.0f * dot);
+}
+
 // called by every lane of wave 0 (lane = 0..63); dq = the query's K distances in global memory
 __device__ __forceinline__ void coarse_exact_select(const float* __restrict__ dq, int K, int ma, int32_t* __restrict__ out,
                                                  float* hv, int* hk, int* perm, uint32_t lane) {
@@ -2110,9 +2175,21 @@ __device__ __forceinline__ void coarse_exact_select(const float* __restrict__ dq
 // QB = queries per workgroup: a thread walks ITS centroid rows once and accumulates the QB queries' distances side by
 // side (each in its own ascending-d order, so every sum is bit-exact with the host loop) — the K x dim matrix is read
 // nq/QB times instead of nq times, which is what this kernel is bound by.
+// ||row||^2 of n rows of `dim` floats, one thread per row, in the grouping the reference's compute_cross_dists_blas adds it
+// (fmanorm<dim/8, dim%8> as compiled; expansion_sqnorm): the ||q||^2 and ||c||^2 of the coarse distances below.
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ rows, int n, int dim, int sum_mode, float* __restrict__ out) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i < n) out[i] = expansion_sqnorm(rows + (size_t)i * dim, dim, sum_mode);
+}
+
+// The coarse distances are the reference's: find_k_neighbors (neighbors.cpp:30-76) takes them from compute_cross_dists_blas<dim>
+// (distances.hpp:151-183): (||q||^2 + ||c||^2) — qnorm / cnorm, as compiled — then sgemm(alpha = -2, beta = 1) adds -2 q.c; the
+// product is restated as ONE sequential dot in ascending d (OpenBLAS is not in this image), the sum rounds once.  They can come
+// out slightly negative for q ~ c: the selections below order floats of either sign.
 template <int KPT, int QB>
 __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restrict__ queries,
                                                             const float* __restrict__ coarse, int nq, int K, int dim, int ma,
+                                                            const float* __restrict__ qnorm, const float* __restrict__ cnorm,
                                                             float* __restrict__ dist, int32_t* __restrict__ assign) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     float* q = reinterpret_cast<float*>(dyn);                 // [QB][dim]
@@ -2139,11 +2216,11 @@ __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restr
         for (int d = 0; d < dim; ++d) {
             const float cv = c[d];
 #pragma unroll
-            for (int b = 0; b < QB; ++b) {
-                const float t = q[b * dim + d] - cv;
-                s[b] += t * t;
-            }
+            for (int b = 0; b < QB; ++b) s[b] += q[b * dim + d] * cv;
         }
+        const float cn = cnorm[k];
+#pragma unroll
+        for (int b = 0; b < QB; ++b) s[b] = (qnorm[min(q0 + b, nq - 1)] + cn) + (-2.0f * s[b]);
     };
     if (KPT > 0) {
 #pragma unroll
@@ -2175,7 +2252,7 @@ __global__ __launch_bounds__(256) void coarse_assign_kernel(const float* __restr
     for (int b = 0; b < QB; ++b) {
         if (b >= nqb) break;
         const float* __restrict__ dq = dist + (size_t)(q0 + b) * K;
-        float last_v = -1.0f;
+        float last_v = -FLT_MAX;
         int last_k = -1;
         bool tie = false;
         const int rounds = (dist && ma > 1 && ma <= 256 && ma < K) ? ma + 1 : ma;
@@ -2249,7 +2326,8 @@ __device__ __forceinline__ uint32_t dpp_wave_min_u32(uint32_t x) {
 }
 
 __global__ __launch_bounds__(256) void coarse_dist_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,
-                                                          int nq, int K, int dim, float* __restrict__ dist) {
+                                                          int nq, int K, int dim, const float* __restrict__ qnorm,
+                                                          const float* __restrict__ cnorm, float* __restrict__ dist) {
     __shared__ float tile[kCDC * kCDStride];                     // [d][centroid]
     __shared__ __attribute__((aligned(16))) float qt[kCDC * kCDQ];   // [d][query]
     const int tid = threadIdx.x;
@@ -2295,34 +2373,37 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float* __restric
         if (d0 + kCDC < dim) fetch(d0 + kCDC);                   // in flight while this tile is consumed
         for (int dd = 0; dd < dcn; ++dd) {
             const float cv = tile[dd * kCDStride + tid];
-            // two queries per instruction: v_pk_add_f32 (with the negated centroid component in both halves), v_pk_mul_f32,
-            // v_pk_add_f32 — each component is the IEEE result of the scalar operation, the sums stay sequential in d, so
-            // assign[] is unchanged bit for bit; 24 VALU instructions per step instead of 32 (the compiler packed the multiply
-            // and the add by itself, not the subtraction)
+            // two queries per instruction: v_pk_mul_f32 + v_pk_add_f32 — each component is the IEEE result of the scalar operation
+            // (no contraction: -ffp-contract=off), the dots stay sequential in d
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const f32x2 cv2 = {cv, cv};
 #pragma unroll
             for (int b4 = 0; b4 < kCDQ / 4; ++b4) {
                 const float4 t4 = *reinterpret_cast<const float4*>(&qt[dd * kCDQ + 4 * b4]);   // same address in every lane: broadcast
                 const f32x2 q01 = {t4.x, t4.y}, q23 = {t4.z, t4.w};
-                f32x2 t01, t23;                                  // q - cv as q + (-cv): the same IEEE result; (written out: the compiler
-                                                                 // scalarises a packed subtraction of a splat)
-                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t01) : "v"(q01), "v"(cv2));
-                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t23) : "v"(q23), "v"(cv2));
-                const f32x2 s01 = t01 * t01, s23 = t23 * t23;
+                const f32x2 s01 = q01 * cv2, s23 = q23 * cv2;
                 acc[4 * b4] += s01.x; acc[4 * b4 + 1] += s01.y; acc[4 * b4 + 2] += s23.x; acc[4 * b4 + 3] += s23.y;
             }
         }
     }
     const int k = k0 + tid;
-    if (k < K)
+    if (k < K) {
+        const float cn = cnorm[k];
 #pragma unroll
         for (int b = 0; b < kCDQ; ++b)
-            if (q0 + b < nq) dist[(size_t)(q0 + b) * K + k] = acc[b];
+            if (q0 + b < nq) dist[(size_t)(q0 + b) * K + k] = (qnorm[q0 + b] + cn) + (-2.0f * acc[b]);
+    }
 }
 
-// ma rounds of "smallest (distance, index) strictly after the previous pick" over a query's K distances (>= 0: their bit
-// patterns order like the values); one workgroup per query, KPT distances per lane in registers
+// Distances of either sign as unsigned keys that order like the values (positive: sign bit set; negative: all bits flipped; -0 does
+// not occur: a sum of a non-negative and a product rounds to +0); 0xffffffff stays above every finite key: the padding past K.
+__device__ __forceinline__ uint32_t coarse_key(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+// ma rounds of "smallest (distance, index) strictly after the previous pick" over a query's K distances (as coarse_key);
+// one workgroup per query, KPT distances per lane in registers
 template <int KPT>
 __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restrict__ dist, int K, int ma, int32_t* __restrict__ assign) {
     __shared__ uint32_t rv[2][4], rk[2][4];
@@ -2331,7 +2412,7 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const int k = j * 256 + tid;
-        mine[j] = k < K ? __float_as_uint(dist[(size_t)q * K + k]) : 0xffffffffu;
+        mine[j] = k < K ? coarse_key(dist[(size_t)q * K + k]) : 0xffffffffu;
     }
     __shared__ float x_hv[256];
     __shared__ int x_hk[256], x_perm[kExactSelInts];
@@ -2386,7 +2467,7 @@ __global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* _
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const int k = j * 256 + tid;
-        mine[j] = k < K ? __float_as_uint(dist[(size_t)q * K + k]) : 0xffffffffu;
+        mine[j] = k < K ? coarse_key(dist[(size_t)q * K + k]) : 0xffffffffu;
     }
     if (tid == 0) { s_prefix = 0; s_rank = (uint32_t)ma; s_nless = 0; s_nties = 0; s_kept = 0; s_T0 = 0xffffffffu; }
     __syncthreads();
@@ -2512,15 +2593,21 @@ __global__ __launch_bounds__(256) void coarse_select_radix_kernel(const float* _
     if (s_tie && tid < 64) coarse_exact_select(dist + (size_t)q * K, K, ma, assign + (size_t)q * ma, x_hv, x_hk, x_perm, (uint32_t)tid);
 }
 
-void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_dist,
-                          int32_t* d_assign, hipStream_t stream) {
+void launch_row_sqnorm(const float* d_rows, int n, int dim, int sum_mode, float* d_out, hipStream_t stream) {
+    if (n > 0) hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_rows, n, dim, sum_mode, d_out);
+}
+
+void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq, int K, int dim, int ma, float* d_qnorm,
+                          const float* d_cnorm, int sum_mode, float* d_dist, int32_t* d_assign, hipStream_t stream) {
     const int kpt = (K + 255) / 256;
+    launch_row_sqnorm(d_queries, nq, dim, sum_mode, d_qnorm, stream);                       // ||q||^2 (the centroids': the caller's, once)
     // large batches share every centroid row between 4 queries (registers: KPT x 4 distances per thread)
 #define QADC_CA(N, QB) hipLaunchKernelGGL((coarse_assign_kernel<N, QB>), dim3((nq + QB - 1) / QB), dim3(256), (size_t)QB * dim * sizeof(float), \
-                                          stream, d_queries, d_coarse, nq, K, dim, ma, d_dist, d_assign)
+                                          stream, d_queries, d_coarse, nq, K, dim, ma, d_qnorm, d_cnorm, d_dist, d_assign)
     // (any batch size: even one query — 15 of its group's 16 rows idle — is through sooner than with a row per lane)
     if (kpt <= 64 && ma <= K && dim % 4 == 0 && (reinterpret_cast<uintptr_t>(d_coarse) & 15) == 0 && d_dist) {
-        hipLaunchKernelGGL(coarse_dist_kernel, dim3(kpt, (nq + kCDQ - 1) / kCDQ), dim3(256), 0, stream, d_queries, d_coarse, nq, K, dim, d_dist);
+        hipLaunchKernelGGL(coarse_dist_kernel, dim3(kpt, (nq + kCDQ - 1) / kCDQ), dim3(256), 0, stream, d_queries, d_coarse, nq, K, dim, d_qnorm,
+                           d_cnorm, d_dist);
         if (ma <= 256 && ma >= 8) {                              // radix select + one sort (few probes: the rounds are as quick)
             if (kpt <= 4) hipLaunchKernelGGL(coarse_select_radix_kernel<4>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
             else if (kpt <= 16) hipLaunchKernelGGL(coarse_select_radix_kernel<16>, dim3(nq), dim3(256), 0, stream, d_dist, K, ma, d_assign);
@@ -2541,71 +2628,6 @@ void launch_coarse_assign(const float* d_queries, const float* d_coarse, int nq,
         else QADC_CA(0, 1);
     }
 #undef QADC_CA
-}
-
-// ||x - c||^2 over ds components as the reference's direct table form adds it: fmanorm<ds/8, ds%8> called by
-// compute_dists_single_simd_cg (distances.hpp:60-76, 294-311) AS COMPILED with the reference's flags (pinned to that
-// build through the oracle's orc_tables_direct; host twin: host/float_sum.hpp sqdist):
-//   per AVX lane j: acc[j] = fma(d, d, acc[j]) over the ds/8 blocks, d = x - c;  reduceadd's tree acc[j] + acc[j+4],
-//   then (r0 + r2) + (r1 + r3);  the scalar remainder is paired p_k = fma(d_2k, d_2k, r(d_2k+1^2)), d = c - x:
-//   REM 4 -> (p0 + p1) + vec,  REM 6 -> (vec + p2) + (p0 + p1).
-// sum_mode 0, or a remainder the reference has no instance of (sq_dim 3 of BASELINE configs[4]; its dispatch is
-// distances.cpp:50-84): one sequential sum in ascending d.  X / C: anything indexable by int (pointer or register array).
-template <typename X, typename C>
-__device__ __forceinline__ float direct_sqdist(const X& x, const C& c, int ds, int sum_mode) {
-    const int blocks = ds >> 3, rem = ds & 7;
-    if (sum_mode == 0 || !(rem == 0 || rem == 4 || rem == 6)) {
-        float s = 0.0f;
-        for (int d = 0; d < ds; ++d) {
-            const float t = x[d] - c[d];
-            s += t * t;
-        }
-        return s;
-    }
-    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (int b = 0; b < blocks; ++b) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float d = x[b * 8 + j] - c[b * 8 + j];
-            acc[j] = __fmaf_rn(d, d, acc[j]);
-        }
-    }
-    const float r0 = acc[0] + acc[4], r1 = acc[1] + acc[5], r2 = acc[2] + acc[6], r3 = acc[3] + acc[7];
-    const float vec = (r0 + r2) + (r1 + r3);
-    if (rem == 0) return vec;
-    float p[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (2 * k < rem) {
-            const float d0 = c[blocks * 8 + 2 * k] - x[blocks * 8 + 2 * k];
-            const float d1 = c[blocks * 8 + 2 * k + 1] - x[blocks * 8 + 2 * k + 1];
-            p[k] = __fmaf_rn(d0, d0, d1 * d1);
-        }
-    }
-    if (rem == 4) return (p[0] + p[1]) + vec;
-    return (vec + p[2]) + (p[0] + p[1]);
-}
-
-// The BLAS-expansion distance compute_cross_dists_blas<DSQ> (distances.hpp:151-215) leaves in dists[v][c]:
-//   ||v||^2 + ||c||^2 (153-176), then cblas_sgemm(alpha = -2, beta = 1) adds -2 v.c (178-182).
-// expansion_sqnorm = fmanorm<DSQ/8, DSQ%8>(vec) / norm_4(vec) AS COMPILED with the reference's flags (sum_mode 1): the
-// grouping of direct_sqdist with c = 0 — pinned to the reference's own text compiled up to the sgemm call (oracle/_ref
-// qadc_reff_cross_norms, the 14 dimensions of its dispatch, 16 centroids) through the oracle's orc_sqnorm; host twin:
-// host/float_sum.hpp sqnorm.  sum_mode 0, or a remainder the reference has no instance of: one sequential sum.
-// The product is OpenBLAS's in the reference (not in this image: restated, unpinned): one sequential dot in ascending d,
-// then base + (-2 dot) — -2 dot is exact, so this is the single rounding of a gemm kernel's C += alpha * acc.
-struct zero_vec {
-    __device__ __forceinline__ float operator[](int) const { return 0.0f; }
-};
-template <typename X>
-__device__ __forceinline__ float expansion_sqnorm(const X& x, int ds, int sum_mode) {
-    return direct_sqdist(x, zero_vec{}, ds, sum_mode);
-}
-template <typename X, typename C>
-__device__ __forceinline__ float expansion_dist(const X& x, const C& c, int ds, float vn, float cn) {
-    float dot = 0.0f;
-    for (int d = 0; d < ds; ++d) dot += x[d] * c[d];
-    return (vn + cn) + (-2.0f * dot);
 }
 
 __global__ __launch_bounds__(256) void build_tables_kernel(const float* __restrict__ queries, const float* __restrict__ coarse,

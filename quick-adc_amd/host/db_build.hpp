@@ -88,25 +88,25 @@ unsigned db_add_hip(Db& db, const char* base_filename, unsigned chunk_count = 10
     return added;
 }
 
-// databases.cpp:50-90 on the host: assign every vector to its closest centroid (squared L2 accumulated in ascending d,
-// first minimum), then centroid = (sum of its members in vector order) times the reciprocal of the count — what the reference
+// databases.cpp:50-90 on the host: assign every vector to its closest centroid (find_k_neighbors with k = 1: the expansion
+// distances, first strict minimum), then centroid = (sum of its members in vector order) times the reciprocal of the count — what the reference
 // binary does under -ffast-math (div_mode 1, pinned to its loops as compiled: oracle/_ref) — or divided by it as the source
 // reads (div_mode 0).  An empty cluster becomes NaN either way.
 inline void kmeans_fast_iterations(const float* vecs, size_t n, int dim, int K, float* centroids, int iters, int* assign,
                                    int div_mode = 1) {
     std::vector<int> cnt((size_t)K);
+    std::vector<float> cn((size_t)K);
     for (int it = 0; it < iters; ++it) {
+        // find_k_neighbors with k = 1 (databases.cpp:60-66 -> neighbors.cpp:30-76): expansion distances (float_sum.hpp), the first
+        // strict minimum in centroid order (a capacity-1 kv_binheap: centroid 0 stays when its distance is NaN)
+        for (int k = 0; k < K; ++k) cn[k] = sqnorm(centroids + (size_t)k * dim, dim);
         for (size_t i = 0; i < n; ++i) {
             const float* x = vecs + i * dim;
+            const float xn = sqnorm(x, dim);
             int best = 0;
-            float bestd = std::numeric_limits<float>::max();
-            for (int k = 0; k < K; ++k) {
-                const float* c = centroids + (size_t)k * dim;
-                float s = 0;
-                for (int d = 0; d < dim; ++d) {
-                    const float t = x[d] - c[d];
-                    s += t * t;
-                }
+            float bestd = expansion_dist(x, centroids, dim, xn, cn[0]);
+            for (int k = 1; k < K; ++k) {
+                const float s = expansion_dist(x, centroids + (size_t)k * dim, dim, xn, cn[k]);
                 if (s < bestd) { bestd = s; best = k; }
             }
             assign[i] = best;

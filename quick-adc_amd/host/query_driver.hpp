@@ -184,14 +184,11 @@ struct ivf_database {
     ivf_database(std::unique_ptr<pq4> p, int k, std::vector<float> c)
         : pq(std::move(p)), part_count(k), coarse(std::move(c)), partitions(k), labels(k) {}
 
-    float dist2(const float* x, int k) const {
+    // the coarse distance as find_k_neighbors gets it from compute_cross_dists_blas (distances.hpp:151-183): (||x||^2 + ||c||^2) with the
+    // norms as compiled (float_sum.hpp sqnorm), then -2 x.c — the sgemm, restated as one sequential dot (device twin: coarse_dist_kernel)
+    float dist2(const float* x, float xn, int k) const {
         const float* c = coarse.data() + (size_t)k * pq->dim;
-        float s = 0;
-        for (int d = 0; d < pq->dim; ++d) {
-            const float t = x[d] - c[d];
-            s += t * t;
-        }
-        return s;
+        return expansion_dist(x, c, pq->dim, xn, sqnorm(c, pq->dim));
     }
     // the ma nearest coarse centroids, ascending by distance, as find_k_neighbors selects them (neighbors.cpp:18-28, 47-71): the
     // distances go through a kv_binheap<int, float> of capacity ma in index order, then kv_binheap::sort — which is "the ma smallest
@@ -199,7 +196,8 @@ struct ivf_database {
     // reference's own heaps: tests/test_oracle_float_ref.py; the device kernels do the same, coarse_exact_select)
     void nearest(const float* x, int ma, int* out) const {
         kv_heap<int, float> h(ma);
-        for (int k = 0; k < part_count; ++k) h.push(k, dist2(x, k));
+        const float xn = sqnorm(x, pq->dim);
+        for (int k = 0; k < part_count; ++k) h.push(k, dist2(x, xn, k));
         h.sort_keys(out);
     }
     void add_vectors(const float* vecs, unsigned n, unsigned labels_offset) {  // databases.hpp:270-298

@@ -119,25 +119,18 @@ CASES = ["flat32", "ivf_lanes", "ivf_whole", "ivf_search", "ivf_search_whole", "
 
 def search_inputs(case):
     """assign[] and float tables of a queries-in case, evaluated by the same sequential float loops as the device feeders
-    (and host/query_driver.hpp): squared L2 in ascending d, lowest index on ties; BLAS-expansion tables for ma > 1 (the
+    (and host/query_driver.hpp): expansion-form coarse distances through find_k_neighbors' selection; BLAS-expansion tables for ma > 1 (the
     oracle's orc_tables_expansion)."""
     q, coarse, cb, ma, M = case["queries"], case["coarse"], case["codebooks"], case["search_ma"], case["M"]
     K, dim = coarse.shape
     ds = dim // M
-
-    def sqdist(x, c_):
-        s_ = np.zeros(c_.shape[:-1], np.float32)
-        for d in range(c_.shape[-1]):
-            t = (x[..., d] - c_[..., d]).astype(np.float32)
-            s_ = (s_ + (t * t).astype(np.float32)).astype(np.float32)
-        return s_
 
     import pyoracle                                              # (the checker's side only: the workers never call this function)
     nq = q.shape[0]
     assign = np.zeros((nq, ma), np.int32)
     tables = np.zeros((nq, ma, M * 16), np.float32)
     for i in range(nq):
-        dist = sqdist(q[i][None, :], coarse)
+        dist = pyoracle.cross_dists(coarse, q[i][None, :])[0]         # the reference's coarse distances (expansion form)
         assign[i] = pyoracle.select_k_neighbors(dist, ma)[0][0]     # find_k_neighbors' heaps (exact ties: as the reference leaves them)
         resid = (q[i][None, :] - coarse[assign[i]]).astype(np.float32)
         for a in range(ma):

@@ -15,12 +15,13 @@ def pyqadc():
     return pyqadc
 
 
-def _seq_sqdist(x, c):
-    s = np.zeros(np.broadcast_shapes(x.shape[:-1], c.shape[:-1]), np.float32)
-    for d in range(c.shape[-1]):
-        t = (x[..., d] - c[..., d]).astype(np.float32)
-        s = (s + (t * t).astype(np.float32)).astype(np.float32)
-    return s
+def _coarse_dists(x, c):
+    """The coarse distances of the query row(s) x [1 or n][dim] to the centroids c [K][dim] as find_k_neighbors gets them
+    (compute_cross_dists_blas, distances.hpp:151-183): the ORACLE's orc_cross_dists — (||x||^2 + ||c||^2) with the norms as the
+    reference compiles them, then -2 x.c as one sequential dot.  Returns [K] for one row, [n][K] for several."""
+    import pyoracle
+    d = pyoracle.cross_dists(c, np.ascontiguousarray(x, np.float32).reshape(-1, c.shape[1]))
+    return d[0] if d.shape[0] == 1 else d
 
 
 def _seq_expansion(x, c):
@@ -51,7 +52,7 @@ def _check(po, res, sample, queries, parts, labels, cb, coarse, M, ma, keep, R):
     K, dim = coarse.shape
     ds = dim // M
     for q in sample:
-        dist = _seq_sqdist(queries[q][None, :], coarse)
+        dist = _coarse_dists(queries[q][None, :], coarse)
         assign = np.lexsort((np.arange(K), dist))[:ma].astype(np.int32)
         assert np.array_equal(res["assign"][q], assign), q
         resid = (queries[q][None, :] - coarse[assign]).astype(np.float32)
@@ -118,7 +119,7 @@ def test_c3_full_size_the_bench_list_against_oracle(pyqadc, po):
     assert int(res["status"].sum()) == 0
     ds = dim // M
     for q in rng.choice(nq, 12, replace=False):
-        dist = _seq_sqdist(queries[q][None, :], coarse)
+        dist = _coarse_dists(queries[q][None, :], coarse)
         assign = np.lexsort((np.arange(K), dist))[:MA].astype(np.int32)
         assert np.array_equal(res["assign"][q], assign), q
         resid = (queries[q][None, :] - coarse[assign]).astype(np.float32)
@@ -170,7 +171,7 @@ def test_c5_full_size_1e9_codes_32x4_nprobe64_on_one_gpu(pyqadc, po):
     assert int(res["status"].sum()) == 0
     ds = dim // M
     for q in rng.choice(nq, 6, replace=False):
-        dist = _seq_sqdist(queries[q][None, :], coarse)
+        dist = _coarse_dists(queries[q][None, :], coarse)
         assign = np.lexsort((np.arange(K), dist))[:MA].astype(np.int32)
         assert np.array_equal(res["assign"][q], assign), q
         resid = (queries[q][None, :] - coarse[assign]).astype(np.float32)

@@ -335,13 +335,13 @@ def test_edge_cases_small_r_large_r_repeated_and_empty_partitions(pyqadc, po, M)
     idx.close()
 
 
-def _seq_sqdist(x, c):
-    """sum_d (x[d] - c[..., d])^2 accumulated in float32 in ascending d, as the device loops do."""
-    s = np.zeros(c.shape[:-1], np.float32)
-    for d in range(c.shape[-1]):
-        t = (x[..., d] - c[..., d]).astype(np.float32)
-        s = (s + (t * t).astype(np.float32)).astype(np.float32)
-    return s
+def _coarse_dists(x, c):
+    """The coarse distances of the query row(s) x [1 or n][dim] to the centroids c [K][dim] as find_k_neighbors gets them
+    (compute_cross_dists_blas, distances.hpp:151-183): the ORACLE's orc_cross_dists — (||x||^2 + ||c||^2) with the norms as the
+    reference compiles them, then -2 x.c as one sequential dot.  Returns [K] for one row, [n][K] for several."""
+    import pyoracle
+    d = pyoracle.cross_dists(c, np.ascontiguousarray(x, np.float32).reshape(-1, c.shape[1]))
+    return d[0] if d.shape[0] == 1 else d
 
 
 def _seq_expansion(x, c):
@@ -390,7 +390,7 @@ def test_search_with_device_side_feeders(pyqadc, po, M, K, ma, opq, form):
     res = idx.search(queries, ma, R)
     for q in range(nq):
         if K:
-            dist = _seq_sqdist(queries[q][None, :], coarse)
+            dist = _coarse_dists(queries[q][None, :], coarse)
             assign = po.select_k_neighbors(dist, ma)[0][0]       # find_k_neighbors' heaps (centroids 3 and 5 tie exactly)
             resid = (queries[q][None, :] - coarse[assign]).astype(np.float32)
         else:
@@ -1613,7 +1613,7 @@ def test_coarse_assignment_of_large_batches_is_the_sequential_one(pyqadc, po, nq
     idx.set_coarse(coarse)
     got = idx.search(queries, ma, 30)["assign"]
     for q in list(range(0, nq, 17)) + [7, nq - 1]:
-        d = _seq_sqdist(queries[q][None, :], coarse)
+        d = _coarse_dists(queries[q][None, :], coarse)
         want = po.select_k_neighbors(d, ma)[0][0]
         assert np.array_equal(got[q], want), q
     idx.close()
@@ -1641,7 +1641,7 @@ def test_coarse_assignment_with_exact_distance_ties_is_find_k_neighbors(pyqadc, 
     nrule = 0
     checked = list(range(nq)) if nq <= 64 else list(range(0, nq, 13)) + [nq - 1]
     for q in checked:
-        d = _seq_sqdist(queries[q][None, :], coarse)
+        d = _coarse_dists(queries[q][None, :], coarse)
         want = po.select_k_neighbors(d, ma)[0][0]
         assert np.array_equal(got[q], want), q
         nrule += int(np.array_equal(want, np.lexsort((np.arange(K), d))[:ma]))
@@ -1653,8 +1653,8 @@ def test_coarse_assignment_with_exact_distance_ties_is_find_k_neighbors(pyqadc, 
 @path_independent
 def test_ivf_encode_and_kmeans_iterations_match_numpy(pyqadc):
     """N4 through ctypes: qadc_ivf_encode_host (nearest centroid, residual, OPQ rotation, PQ encode) and
-    qadc_kmeans_iterations_host: assignment and residual against numpy evaluations of the same sequential loops, the codes
-    against the ORACLE's encoder (orc_pq_encode with the rotation) fed with those residuals."""
+    qadc_kmeans_iterations_host: the assignment against the oracle's expansion-form coarse distances (find_k_neighbors with k = 1),
+    the codes against the ORACLE's encoder (orc_pq_encode with the rotation) fed with those residuals."""
     import pyoracle as po
     rng = np.random.default_rng(99)
     M, dim, K, n = 16, 32, 50, 3000
@@ -1663,7 +1663,7 @@ def test_ivf_encode_and_kmeans_iterations_match_numpy(pyqadc):
     rot = (rng.normal(size=(dim, dim)) * 0.3).astype(np.float32)
     v = rng.normal(size=(n, dim)).astype(np.float32)
     assign, codes = pyqadc.ivf_encode(cb, v, coarse=coarse, rotation=rot)
-    want_assign = np.array([int(np.lexsort((np.arange(K), _seq_sqdist(v[i][None, :], coarse)))[0]) for i in range(n)])
+    want_assign = np.argmin(_coarse_dists(v, coarse), axis=1)   # (k = 1: the first strict minimum of the expansion distances)
     assert np.array_equal(assign, want_assign)
     res = (v - coarse[want_assign]).astype(np.float32)
     assert np.array_equal(codes, po.pq_encode(cb, res, rot))
@@ -1678,7 +1678,7 @@ def test_ivf_encode_and_kmeans_iterations_match_numpy(pyqadc):
         cen, asg = pyqadc.kmeans_iterations(v, v[:K], 2, div_mode=mode)
         c = v[:K].copy()
         for _ in range(2):
-            a = np.array([int(np.lexsort((np.arange(K), _seq_sqdist(v[i][None, :], c)))[0]) for i in range(n)])
+            a = np.argmin(_coarse_dists(v, c), axis=1)
             c = np.zeros_like(c)
             cnt = np.zeros(K, np.int64)
             for i in range(n):

@@ -391,10 +391,7 @@ def test_host_coarse_selection_with_exact_ties_is_find_k_neighbors(po, tmp_path,
     with open(f, "wb") as fh:
         fh.write(np.array([K, dim, ma, nq], np.int32).tobytes() + coarse.tobytes() + queries.tobytes())
     got = np.array([[int(x) for x in l.split()] for l in subprocess.check_output([NEAREST, f]).decode().strip().split("\n")], np.int32)
-    d = np.zeros((nq, K), np.float32)
-    for j in range(dim):                                         # squared L2 in ascending d, float32 (dist2 of the twin)
-        t = (queries[:, j:j + 1] - coarse[None, :, j]).astype(np.float32)
-        d = (d + (t * t).astype(np.float32)).astype(np.float32)
+    d = po.cross_dists(coarse, queries)                          # the reference's coarse distances (expansion form: dist2 of the twin)
     want, _ = po.select_k_neighbors(d, ma)
     assert np.array_equal(got, want)
     if po.have_ref_float():

@@ -67,9 +67,9 @@ def ivf_queries(rng):
 
 
 def coarse_assignment(rng):
-    """assign[] of 2000 queries over K = 4096 centroids (128-d, clustered), nprobe 32: this library's coarse distances (direct form,
-    one sequential sum) against the reference's FORM with a real BLAS in it (||q||^2 + ||c||^2 as compiled, then numpy's sgemm), both
-    through find_k_neighbors' selection (the oracle's pinned restatement)."""
+    """assign[] of 2000 queries over K = 4096 centroids (128-d, clustered), nprobe 32, through find_k_neighbors' selection (the oracle's
+    pinned restatement): the reference's FORM with a real BLAS in it (||q||^2 + ||c||^2 as compiled, then numpy's sgemm) against (a) this
+    library's coarse distances — the same form with one sequential dot — and (b) the direct form sum (q - c)^2 it used until round 6."""
     K, dim, nq, ma = 4096, 128, 2000, 32
     centres = 3 * rng.normal(size=(1000, dim)).astype(np.float32)
     coarse = (centres[rng.integers(0, 1000, K)] + rng.normal(size=(K, dim))).astype(np.float32)
@@ -80,12 +80,14 @@ def coarse_assignment(rng):
         direct = (direct + (t * t).astype(np.float32)).astype(np.float32)
     norms = np.concatenate([po.cross_dists(coarse[k0:k0 + 256], queries, with_product=False) for k0 in range(0, K, 256)], 1)   # BLOCK_NEIGHS = 256
     blas = (norms + np.float32(-2.0) * (queries @ coarse.T)).astype(np.float32)
-    a_dir = po.select_k_neighbors(direct, ma)[0]
+    seq = np.concatenate([po.cross_dists(coarse[k0:k0 + 256], queries) for k0 in range(0, K, 256)], 1)
     a_blas = po.select_k_neighbors(blas, ma)[0]
-    same_order = int((a_dir == a_blas).all(1).sum())
-    same_set = int(sum(set(x.tolist()) == set(y.tolist()) for x, y in zip(a_dir, a_blas)))
-    return {"what": coarse_assignment.__doc__.split("\n")[0], "queries": nq, "K": K, "nprobe": ma,
-            "queries_with_the_same_assign_array": same_order, "queries_with_the_same_probed_SET": same_set}
+    res = {"what": coarse_assignment.__doc__.split("\n")[0], "queries": nq, "K": K, "nprobe": ma}
+    for name, dmat in (("expansion_form_sequential_dot(the library)", seq), ("direct_form(until round 6)", direct)):
+        a = po.select_k_neighbors(dmat, ma)[0]
+        res[name] = {"queries_with_the_same_assign_array": int((a == a_blas).all(1).sum()),
+                     "queries_with_the_same_probed_SET": int(sum(set(x.tolist()) == set(y.tolist()) for x, y in zip(a, a_blas)))}
+    return res
 
 
 def main():
