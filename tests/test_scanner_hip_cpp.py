@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import splitmix64
+from helpers import path_independent, splitmix64
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "scanner_hip_demo")
@@ -272,6 +272,7 @@ def test_db_build_demo_builds_as_cxx14():
 
 
 @pytest.mark.gpu
+@path_independent
 @pytest.mark.parametrize("M,dim,K,n,opq", [(16, 32, 37, 5000, 0), (32, 64, 300, 40000, 1), (16, 128, 1000, 70000, 0)])
 def test_gpu_database_build_equals_the_host_build(M, dim, K, n, opq, tmp_path):
     """N4: host/db_build.hpp (index_db::add_vectors / flat_db::add_vectors compute and the k-means fast iterations on
