@@ -364,14 +364,14 @@ def pmc_traffic_in_run(M, N, nq_step):
 
 def pmc_traffic_from_profiles(M, N, alg_bytes_per_launch):
     """Fallback: the committed one-query-per-pass PMC profile, only if it was taken on exactly this mode/config."""
-    f = os.path.join(ROOT, "profiles", "r05_headline_hbm_traffic.json")
+    f = os.path.join(ROOT, "profiles", "r06_headline_hbm_traffic.json")
     if not os.path.exists(f):
         return None, "no in-run PMC pass and no committed profile"
     pj = json.load(open(f))
     if pj.get("mode") != "one_query_per_pass_batch32" or pj.get("codes") != N or pj.get("M") != M:
         return None, "committed PMC profile is for another mode/config (%s, %s codes, M=%s)" % (
             pj.get("mode"), pj.get("codes"), pj.get("M"))
-    return pj["traffic_over_algorithmic"] * alg_bytes_per_launch, "profiles/r05_headline_hbm_traffic.json (ratio x this run's bytes)"
+    return pj["traffic_over_algorithmic"] * alg_bytes_per_launch, "profiles/r06_headline_hbm_traffic.json (ratio x this run's bytes)"
 
 
 # --------------------------------------------------------------------------------------------- GPU side legs
