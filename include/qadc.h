@@ -112,7 +112,7 @@ int qadc_index_partition_count(const qadc_index* idx);
 uint32_t qadc_index_partition_size(const qadc_index* idx, int part);
 uint32_t qadc_index_start_size(const qadc_index* idx, int part);
 
-/* Options (32; qadc_option_names() returns the list, comma separated).  None changes WHAT is computed except the three parity
+/* Options (30; qadc_option_names() returns the list, comma separated).  None changes WHAT is computed except the three parity
  * switches of the float half; the rest choose paths and sizes, and tests/test_gpu_fuzz.py draws them at random against the oracle.
  *  parity      "quant_mode"  1 = QuantizerMAX as the reference is compiled (one reciprocal, multiply), 0 = its source's division
  *              "sum_mode"    grouping of the float sums of the pre-scan (scan_4, query_common.hpp:72-80), of the direct table form
@@ -138,12 +138,6 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  *  query path  "wgq_split" / "wgq_split_codes"  workgroups a small batch spreads one query over / codes each keeps at least
  *              "wgq_capacity" / "wgq_cand_cap"  stream entries per query to start with / candidates per query before a batch falls
  *                            back to the level path
- *  resident    "resident" (default 0) / "resident_idle_us" (2000)  1 = a lone synchronous query with caller-built float tables
- *                            (what nns_engine issues, query_common.hpp:278-307) is answered by workgroups that STAY on the GPU between
- *                            calls: the input goes through mapped host memory and a bell word instead of a launch.  The workgroups
- *                            leave by themselves after resident_idle_us without a query (a caller that went quiet, or died), when
- *                            any other batch is submitted to the index, when the option is cleared and when the index is destroyed;
- *                            a query that finds them gone is served by an ordinary launch.  Nothing is ever killed
  *  multi-GPU   "dist_cap_entries", "dist_device_nq", "dist_shard_replay" (an enqueued merge replays only this rank's share of the
  *              queries and a second, small all-gather shares the heaps; default 1), "dist_shard_front" (feeders + pre-scan +
  *              quantizer of a qadc_search batch are split over the ranks; default 1), "dist_inject_failure" (tests: this rank's
@@ -458,9 +452,6 @@ typedef struct qadc_profile {
     uint64_t group_batches;    /* batches the above figures cover */
     uint64_t front_sharded_batches; /* multi-GPU: qadc_search batches whose front ran on 1/world of the queries per rank */
     uint64_t dist_async_collects;   /* multi-GPU: qadc_dist_collect calls served by a merge enqueued with the batch (one event wait) */
-    uint64_t resident_launches;     /* option "resident": launches of the resident query kernel (counted with or without "profile") */
-    uint64_t resident_queries;      /* ... queries handed to it through the bell */
-    uint64_t resident_fallbacks;    /* ... queries it could not take or that found its workgroups gone: served by an ordinary launch */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

@@ -261,7 +261,6 @@ hipError_t prof_event(Slot& s, hipStream_t st) {
 // Plans the batch in slot s and enqueues all of its GPU work (front, levels, ordering, optional device replay).
 int plan_and_launch(qadc_index* idx, Slot& s) {
     if (s.wgq) return launch_wgq_batch(idx, s);
-    if (int rc = resident_stop(idx)) return rc;                  // (no other launch of the index while the resident kernel runs)
     ScopedMs timer(idx->prof.host_plan_ms);
     const int M = idx->M, cs = idx->cs, nq = s.nq, ma = s.ma;
     // (tried, round 4: consecutive level-path batches alternating between two scan streams on the scan pipe, so that the first
@@ -592,7 +591,6 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
     }
     s.full_prescan = false;
     s.rerun = false;
-    s.no_resident = false;
     s.group_fell_back = false;
     s.front_sharded = false;
     s.assign_on_device = false;
@@ -671,23 +669,11 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
                 seen = true;
                 for (int i = 0; i < nsub && seen; ++i)
                     seen = (reinterpret_cast<const volatile uint32_t*>(&s.h_qout[i].flags)[0] & 4u) != 0;
-                if (!seen && (spins & 63u) == 63u) {
-                    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count();
-                    // (the resident kernel has no completion event to fall back on: its workgroups either finish or announce
-                    // that they have left; the second bound only guards against a GPU that stopped answering)
-                    if (s.resident ? (resident_lost(idx, s.wgq_G) || waited > 2.0) : waited > 300e-6) break;
-                }
+                if (!seen && (spins & 63u) == 63u &&
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count() > 300e-6)
+                    break;
             }
             std::atomic_thread_fence(std::memory_order_acquire);
-        }
-        if (!seen && s.resident) {
-            // a resident workgroup left (idle limit) before it saw this query: serve it by an ordinary launch
-            idx->prof.resident_fallbacks++;
-            if (int rc = resident_stop(idx)) { s.busy = false; return rc; }
-            s.resident = false;
-            s.no_resident = true;
-            if (int rc = plan_and_launch(idx, s)) { s.busy = false; return rc; }
-            continue;
         }
         if (!seen) HIPCHECK(hipEventSynchronize(s.ev_done));
         uint64_t max_count = 0;
@@ -1278,7 +1264,6 @@ int qadc_index_create(qadc_index** out, int M, int device_id) {
 int qadc_index_destroy(qadc_index* idx) {
     if (!idx) return QADC_OK;
     (void)hipSetDevice(idx->device);
-    (void)resident_stop(idx);
     // a pre-scan (front stream) or an on-demand copy may still be in flight: drain all four streams before freeing
     for (hipStream_t st : {idx->stream, idx->wgq_stream, idx->front_stream, idx->copy_stream, idx->sort_stream})
         if (st) (void)hipStreamSynchronize(st);
@@ -1295,7 +1280,6 @@ int qadc_index_destroy(qadc_index* idx) {
     idx->feed.d_rotation.release();
     idx->feed.d_coarse.release();
     idx->d_partdesc.release();
-    idx->resident.release();
     Slot* all_slots[kSlots + 2];
     for (int i = 0; i < kSlots; ++i) all_slots[i] = &idx->slot[i];
     all_slots[kSlots] = &idx->pre_slot[0];
@@ -1559,7 +1543,7 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part) {
     return (idx && part >= 0 && part < (int)idx->parts.size()) ? idx->parts[part].start_n : 0;
 }
 
-// The 32 options (include/qadc.h documents each; tests/test_capi_host.py pins this list, tests/test_gpu_fuzz.py draws them)
+// The 30 options (include/qadc.h documents each; tests/test_capi_host.py pins this list, tests/test_gpu_fuzz.py draws them)
 const char* qadc_option_names(void) {
     return "quant_mode,sum_mode,table_form,profile,"                                       // parity (float half), diagnostics
            "wgq,wgq_group,wgq_group_head,head_level,head_wg,"                              // which path scans a batch, and its head
@@ -1567,7 +1551,6 @@ const char* qadc_option_names(void) {
            "cand_capacity,level_base,level_growth,small_run,prescan_sample,"               // level path: sizes
            "device_replay_nq,device_replay_alone_nq,"                                      // where the heap replay runs
            "wgq_split,wgq_split_codes,wgq_capacity,wgq_cand_cap,"                          // query-kernel path: sizes
-           "resident,resident_idle_us,"                                                    // the lone query without a launch
            "dist_cap_entries,dist_device_nq,dist_shard_replay,dist_shard_front,dist_inject_failure";   // multi-GPU merge
 }
 
@@ -1608,15 +1591,6 @@ int qadc_set_option(qadc_index* idx, const char* name, double value) {
     else if (n == "wgq_cand_cap") {                            // both candidate capacities of the query-kernel path
         idx->wgq_cand_cap = (uint32_t)std::max(1.0, std::min(value, (double)kQueryCandCap));          // in-workgroup sort
         idx->group.cand_cap = (uint32_t)std::max(64.0, std::min(value, (double)kOrderCandCap));       // partition-major batches
-    }
-    else if (n == "resident") {
-        idx->resident.enabled = value != 0 ? 1 : 0;
-        if (!idx->resident.enabled)
-            if (int rc = resident_stop(idx)) return rc;
-    }
-    else if (n == "resident_idle_us") {
-        if (int rc = resident_stop(idx)) return rc;              // (the limit is a launch argument)
-        idx->resident.idle_us = (uint32_t)std::max(50.0, std::min(value, 1e6));
     }
     else if (n == "dist_cap_entries") idx->dist->cap_entries = (uint32_t)std::max(16.0, std::min(value, 1073741824.0));
     else if (n == "dist_device_nq") idx->dist->device_nq = (int)std::max(1.0, value);

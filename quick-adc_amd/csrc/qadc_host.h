@@ -186,8 +186,6 @@ struct Slot {
     bool dist_batch = false;            // launched with the native multi-GPU merge active: streams kept in device memory
     uint32_t wgq_cap = 0;               // stream entries per query workgroup (regrown on overflow)
     bool poll = false;                  // collect watches the workgroups' done bits instead of the completion event
-    bool resident = false;              // ... of the RESIDENT kernel: there is no completion event behind them (ResidentState)
-    bool no_resident = false;           // this batch already fell back from the resident kernel: ordinary launches only
     int wgq_G = 1;                      // workgroups per query (small batches: the scan order of a query is split)
     uint64_t wgq_codes = 0;             // codes a query probes (exact maximum, or an estimate) — sizes wgq_G
     uint64_t head_codes = 0;            // level path: codes of every query's scan order covered by the head launch (0 = none)
@@ -365,25 +363,6 @@ struct GroupState {
     uint32_t cand_cap = kOrderCandCap;   // candidates per query of such a batch before it falls back (option "wgq_group_cand_cap")
 };
 
-// The resident query kernel of an index (option "resident"; device side and protocol: qadc_kernels.h, ResidentCtl).
-struct ResidentState {
-    int enabled = 0;                    // option "resident": lone small float-table queries go through the bell, not a launch
-    uint32_t idle_us = 2000;            // option "resident_idle_us": a workgroup leaves after this long without a bell
-    bool running = false;               // a launch is (as far as the host knows) on the GPU
-    int wgs = 0;                        // ... with this many workgroups
-    bool nontemporal = false;           // ... compiled for this load policy
-    uint32_t cap = 0, ccap = 0;         // ... writing streams / candidates of this capacity per workgroup
-    uint32_t seq = 0;                   // last sequence number rung
-    std::chrono::steady_clock::time_point last_bell;
-    PinBuf<unsigned char> h_ctl;        // ResidentCtl, mapped
-    ResidentCtl* d_ctl = nullptr;
-    PinBuf<unsigned char> h_result;     // [QueryOut[wgs]][u64 entries[wgs][cap]], mapped
-    unsigned char* d_result = nullptr;
-    DevBuf<int8_t> d_qtables;
-    DevBuf<QCand> d_qcands;
-    void release() { h_ctl.release(); h_result.release(); d_qtables.release(); d_qcands.release(); }
-};
-
 }  // namespace host
 }  // namespace qadc
 
@@ -449,7 +428,6 @@ struct qadc_index {
     FeederState feed;                   // qadc_ivf.cpp: N1, the feeders on the device
     GroupState group;                   // qadc_ivf.cpp: partition-major second phase of large IVF batches
     DistState* dist = nullptr;          // qadc_dist.cpp: qadc_dist_init
-    ResidentState resident;             // qadc_ivf.cpp: the resident query kernel (option "resident")
 };
 
 namespace qadc {
@@ -475,8 +453,6 @@ bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64
 bool will_group(const qadc_index* idx, int nq, int ma, bool dev_replay);
 int launch_wgq_batch(qadc_index* idx, Slot& s);
 int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int ma, int R);
-int resident_stop(qadc_index* idx);                          // tells the resident kernel to leave and waits for it (no-op when none runs)
-bool resident_lost(qadc_index* idx, int wgs);                // one of the first `wgs` resident workgroups has left
 // qadc_dist.cpp
 int load_rccl(DistState& d, std::string& err);
 int enqueue_merge(qadc_index* idx, Slot& s, hipStream_t scan_stream);

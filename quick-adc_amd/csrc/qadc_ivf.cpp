@@ -29,104 +29,6 @@ bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64
     return nq >= kWgqMinNq && codes_per_query <= kWgqMaxCodes;
 }
 
-// ---- the resident query kernel (option "resident"; protocol: qadc_kernels.h, ResidentCtl) -------------------------------
-// Replaces, for the lone synchronous query, the launch by a bell in mapped memory.  What keeps it safe: the workgroups never
-// wait for one another or for the host beyond the idle limit; the host never waits for a workgroup that has announced its
-// exit (resident_lost); and every other launch of the index first tells the kernel to leave (resident_stop).
-bool resident_lost(qadc_index* idx, int wgs) {
-    ResidentState& r = idx->resident;
-    if (!r.running) return true;
-    const volatile uint32_t* ex = reinterpret_cast<const ResidentCtl*>(r.h_ctl.p)->exited;
-    for (int g = 0; g < wgs; ++g)
-        if (ex[g]) return true;
-    return false;
-}
-
-int resident_stop(qadc_index* idx) {
-    ResidentState& r = idx->resident;
-    if (!r.running) return QADC_OK;
-    ResidentCtl* c = reinterpret_cast<ResidentCtl*>(r.h_ctl.p);
-    __atomic_store_n(&c->bell, (uint64_t)kResidentLeave << 32, __ATOMIC_RELEASE);
-    r.running = false;
-    HIPCHECK(hipStreamSynchronize(idx->wgq_stream));             // every workgroup sees the word within one poll
-    return QADC_OK;
-}
-
-// Hands the lone query in slot s (inline payload `inl`) to the resident kernel, launching it first if none runs or the
-// running one does not fit (workgroups, capacities, load policy) or may have gone idle.  QADC_OK: s.h_qout / s.h_entries
-// point into the resident result block and the collect call polls them.
-static int resident_submit(qadc_index* idx, Slot& s, const unsigned char* inl, size_t inl_bytes, size_t off_parts,
-                           size_t off_tables, int G, uint32_t cap, uint32_t ccap, bool nontemporal, uint32_t pos_bits) {
-    ResidentState& r = idx->resident;
-    const int M = idx->M;
-    const int wgs = std::max(2, std::min<int>(idx->wgq_split, kResidentMaxWgs));
-    const auto now = std::chrono::steady_clock::now();
-    if (r.running) {
-        const double idle = std::chrono::duration<double, std::micro>(now - r.last_bell).count();
-        // (the kernel's own clock starts at ITS last bell: well before half the limit the host stops trusting it to be there)
-        if (G > r.wgs || cap != r.cap || ccap != r.ccap || nontemporal != r.nontemporal || idle > 0.5 * r.idle_us ||
-            resident_lost(idx, r.wgs) || r.seq >= 0xfffffff0u)
-            if (int rc = resident_stop(idx)) return rc;
-    }
-    if (!r.running) {
-        if (G > wgs) return QADC_E_STATE;                        // (caller falls back to the launch)
-        HIPCHECK(r.h_ctl.ensure(sizeof(ResidentCtl), hipHostMallocMapped | hipHostMallocCoherent));
-        HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.d_ctl), r.h_ctl.p, 0));
-        const size_t res_bytes = (sizeof(QueryOut) + sizeof(uint64_t) * (size_t)cap) * (size_t)wgs + 16;
-        HIPCHECK(r.h_result.ensure(res_bytes, hipHostMallocMapped | hipHostMallocCoherent));
-        HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.d_result), r.h_result.p, 0));
-        HIPCHECK(r.d_qtables.ensure((size_t)kInlineBytes));      // (more int8 entries than an inline payload has floats)
-        HIPCHECK(r.d_qcands.ensure((size_t)wgs * ccap));
-        ResidentCtl* c = reinterpret_cast<ResidentCtl*>(r.h_ctl.p);
-        if (r.seq >= 0xfffffff0u) r.seq = 0;
-        std::memset(c, 0, sizeof(ResidentCtl));
-        __atomic_store_n(&c->bell, (uint64_t)r.seq << 32, __ATOMIC_RELEASE);
-        ResidentArgs RA{};
-        RA.a.qtables = r.d_qtables.p;
-        RA.a.stream = reinterpret_cast<uint64_t*>(r.d_result + sizeof(QueryOut) * (size_t)wgs);
-        RA.a.cap = cap;
-        RA.a.cands = r.d_qcands.p;
-        RA.a.ccap = ccap;
-        RA.a.qout = reinterpret_cast<QueryOut*>(r.d_result);
-        RA.a.nontemporal = nontemporal;
-        RA.ctl = r.d_ctl;
-        RA.first_seq = r.seq + 1;
-        int khz = 0;
-        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, idx->device) != hipSuccess || khz <= 0) khz = 100000;
-        RA.idle_ticks = (uint64_t)r.idle_us * (uint64_t)khz / 1000u;
-        RA.max_polls = (uint32_t)std::min<uint64_t>((uint64_t)r.idle_us * 16u + 1024u, 0x7fffffffu);
-        HIPCHECK(launch_scan_query_resident(M, wgs, RA, idx->wgq_stream));
-        r.running = true;
-        r.wgs = wgs;
-        r.cap = cap;
-        r.ccap = ccap;
-        r.nontemporal = nontemporal;
-        idx->prof.resident_launches++;
-    }
-    ResidentCtl* c = reinterpret_cast<ResidentCtl*>(r.h_ctl.p);
-    ResidentParams P{};
-    P.seq = r.seq + 1;
-    P.ma = (uint32_t)s.ma;
-    P.R = (uint32_t)s.R;
-    P.G = (uint32_t)G;
-    P.off_parts = (uint32_t)off_parts;
-    P.off_tables = (uint32_t)off_tables;
-    P.pos_bits = pos_bits;
-    P.quant_mode = idx->quant_mode;
-    P.sum_mode = idx->sum_mode;
-    static_assert(sizeof(ResidentParams) == 64, "ResidentParams is one 64-byte record");
-    std::memcpy(c->payload, &P, sizeof(P));
-    std::memcpy(c->payload + 64, inl, inl_bytes);
-    s.h_qout = reinterpret_cast<QueryOut*>(r.h_result.p);
-    s.h_entries = reinterpret_cast<uint64_t*>(r.h_result.p + sizeof(QueryOut) * (size_t)r.wgs);
-    for (int g = 0; g < G; ++g) s.h_qout[g].flags = 0;
-    r.seq++;
-    __atomic_store_n(&c->bell, ((uint64_t)r.seq << 32) | (uint64_t)inl_bytes, __ATOMIC_RELEASE);
-    r.last_bell = std::chrono::steady_clock::now();
-    idx->prof.resident_queries++;
-    return QADC_OK;
-}
-
 // One launch per batch: scan_query_kernel (one workgroup per query), then — for batches large enough to replay on
 // the device — replay_heap_wave_kernel on the side stream.  No host planning: the kernel walks assign[] and the
 // device partition table itself.
@@ -236,19 +138,6 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             inl_bytes = total;
         }
     }
-    s.resident = false;
-    if (inl_bytes && idx->resident.enabled && !s.no_resident && !s.rerun && !idx->profile && !s.dev_replay && fcap == 0) {
-        const uint32_t pos_bits = (idx->max_part_n ? 64u - (uint32_t)__builtin_clzll((unsigned long long)idx->max_part_n) : 0u) << 16 | 256u;
-        const bool nt_loads = idx->total_codes * (uint64_t)idx->cs > (200ull << 20);
-        if (resident_submit(idx, s, inl, inl_bytes, inl_off_parts, inl_off_tables, G, cap, ccap, nt_loads, pos_bits) == QADC_OK) {
-            s.resident = true;
-            s.poll = true;
-            s.prof_used = 0;
-            return QADC_OK;
-        }
-        idx->prof.resident_fallbacks++;
-    }
-    if (int rc = resident_stop(idx)) return rc;                  // (any other launch of this index: the resident kernel leaves first)
     if (in_bytes && !inl_bytes) {
         if (alone) {
             HIPCHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, st));

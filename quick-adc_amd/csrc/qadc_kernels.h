@@ -156,41 +156,6 @@ struct QueryKernelInline {
     alignas(16) unsigned char payload[kInlineBytes];
 };
 
-// ---- the RESIDENT query kernel (option "resident"): the lone synchronous query without a launch ----
-// nns_engine calls query_scan once per query (query_common.hpp:278-307); one launch per call costs ~9 us of submit and ~10 us of
-// dispatch / completion latency around ~27 us of kernel.  With the option on, the workgroups a lone small query is spread over
-// STAY on the GPU between calls: the host writes the query's input (the inline payload above, behind a ResidentParams record)
-// into a block of pinned, device-mapped memory and then rings a bell word in it; one lane per workgroup watches the bell, the
-// workgroup stages the payload into LDS (one PCIe round trip) and runs the unchanged scan_query_body on it; results return through
-// the mapped result block as before.  The workgroups are independent of one another (each publishes its own record), so a
-// workgroup that leaves — bell = kResidentLeave, or no bell for idle_ticks of the 100 MHz wall clock (a host that died, or went
-// quiet) — cannot strand another: it sets its `exited` word, the host sees it and serves the query by an ordinary launch.
-// Nothing is ever killed, and no kernel outlives its index by more than the idle limit.
-struct ResidentParams {                         // first 64 bytes of ResidentCtl::payload
-    uint32_t seq;                               // the bell's sequence number (diagnostic)
-    uint32_t ma, R, G;                          // G: workgroups that take part in this query (the others idle through it)
-    uint32_t off_parts, off_tables;             // QueryKernelArgs::inline_off_* (relative to payload + 64)
-    uint32_t pos_bits;
-    int32_t quant_mode, sum_mode;
-    uint32_t pad[7];
-};
-constexpr uint32_t kResidentLeave = 0xffffffffu;
-constexpr int kResidentMaxWgs = 64;
-struct ResidentCtl {                            // pinned, device-mapped, coherent host memory
-    uint64_t bell;                              // sequence << 32 | payload bytes behind the params record; written LAST by the host
-    uint32_t pad0[14];
-    uint32_t exited[kResidentMaxWgs];           // [workgroup]: it left (written once, by the workgroup, system scope)
-    alignas(64) unsigned char payload[64 + kInlineBytes];
-};
-struct ResidentArgs {
-    QueryKernelArgs a;                          // the per-index constants: output regions, scratch, nontemporal
-    ResidentCtl* ctl;                           // device address of the mapped block
-    uint32_t first_seq;                         // the first sequence number this launch answers
-    uint32_t max_polls;                         // second bound on an idle wait (should the wall clock misbehave)
-    uint64_t idle_ticks;                        // wall-clock ticks without a bell after which a workgroup leaves
-};
-hipError_t launch_scan_query_resident(int M, int wgs, const ResidentArgs& args, hipStream_t stream);
-
 uint32_t query_kernel_lds_values(int M);       // pre-scan values a query may have before fvals is needed
 hipError_t launch_scan_query(int M, int nq, const QueryKernelArgs& args, hipStream_t stream,
                              const void* inline_payload = nullptr, size_t inline_bytes = 0);

@@ -1455,70 +1455,6 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_inline_kernel(QueryKerne
     scan_query_body<M, U, OCC, NT, true, false>(A);
 }
 
-// The resident form of the same kernel (qadc_kernels.h: ResidentCtl): the workgroups stay between the calls of a synchronous
-// query loop, the query's input arrives through mapped host memory instead of the kernel-argument segment, and a bell word
-// replaces the launch.  One lane per workgroup watches the bell (a system-scope load = one PCIe read per poll); the payload is
-// staged into LDS behind the body's own image (one more round trip, all lanes), and the body reads assign[] / descriptors /
-// float tables from there.  A workgroup leaves on kResidentLeave or after idle_ticks of the wall clock without a bell.
-constexpr int kResidentStage = 64 + (int)kInlineBytes;
-template <int M, int U, int OCC, bool NT>
-__global__ __launch_bounds__(kQWG, OCC) void scan_query_resident_kernel(ResidentArgs RA) {
-    using C = QCfg<M>;
-    unsigned char* stage = qsmem + C::LDS_BYTES;                 // [kResidentStage] params + payload
-    uint32_t* s_bell = reinterpret_cast<uint32_t*>(stage + kResidentStage);
-    const uint32_t tid = threadIdx.x;
-    ResidentCtl* ctl = RA.ctl;
-    uint32_t last = RA.first_seq - 1u;
-    for (;;) {
-        if (tid == 0) {
-            const uint64_t t0 = wall_clock64();
-            uint64_t b;
-            for (uint32_t polls = 0;; ++polls) {
-                b = __hip_atomic_load(&ctl->bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((uint32_t)(b >> 32) != last) break;
-                if (wall_clock64() - t0 > RA.idle_ticks || polls > RA.max_polls) {
-                    b = (uint64_t)kResidentLeave << 32;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            s_bell[0] = (uint32_t)(b >> 32);
-            s_bell[1] = (uint32_t)b;
-        }
-        __syncthreads();
-        const uint32_t seq = q_uni(s_bell[0]), bytes = min(q_uni(s_bell[1]), (uint32_t)kInlineBytes);
-        if (seq == kResidentLeave) {
-            if (tid == 0) __hip_atomic_store(&ctl->exited[blockIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;
-        }
-        last = seq;
-        // the payload the host stored before it rang: system-scope loads (no cache of this GPU may answer them)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(ctl->payload);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(stage);
-            const uint32_t nw = (64u + bytes + 3u) / 4u;
-            for (uint32_t i = tid; i < nw; i += kQWG)
-                dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        __syncthreads();
-        const ResidentParams* P = reinterpret_cast<const ResidentParams*>(stage);
-        QueryKernelArgs A = RA.a;
-        A.ma = (int)q_uni(P->ma);                                // (workgroup-uniform: keep them in scalar registers)
-        A.R = q_uni(P->R);
-        A.G = (int)q_uni(P->G);
-        A.pos_bits = q_uni(P->pos_bits);
-        A.quant_mode = (int)q_uni((uint32_t)P->quant_mode);
-        A.sum_mode = (int)q_uni((uint32_t)P->sum_mode);
-        A.inline_input = 1u;
-        A.assign = reinterpret_cast<const int32_t*>(stage + 64);
-        A.parts = reinterpret_cast<const PartDesc*>(stage + 64 + q_uni(P->off_parts));
-        A.ftables = reinterpret_cast<float*>(stage + 64 + q_uni(P->off_tables));
-        if ((int)blockIdx.x < A.G) scan_query_body<M, U, OCC, NT, true, false>(A);
-        __syncthreads();                                         // the stage and the body's LDS are rewritten by the next query
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Large IVF batches, partition-major second phase.  A batch of 1024 queries x 32 probes lands ~8 times on each of
 // 4096 partitions: walking query by query reads (and looks up) every partition 8 times.  After the head launch
@@ -2304,25 +2240,6 @@ hipError_t launch_scan_query(int M, int nq, const QueryKernelArgs& args, hipStre
                              size_t inline_bytes) {
     if (M == 16) return launch_scan_query_v<16, 2, QCfg<16>::OCC>(nq, args, stream, inline_payload, inline_bytes);
     return launch_scan_query_v<32, 2, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
-}
-
-template <int M, bool NT>
-static hipError_t launch_scan_query_resident_v(int wgs, const ResidentArgs& args, hipStream_t stream) {
-    static std::atomic<uint64_t> done{0};
-    const size_t lds = QCfg<M>::LDS_BYTES + kResidentStage + 16;
-    const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&scan_query_resident_kernel<M, 2, 4, NT>), (int)lds, done);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((scan_query_resident_kernel<M, 2, 4, NT>), dim3(wgs), dim3(kQWG), lds, stream, args);
-    return hipGetLastError();
-}
-
-// wgs <= kResidentMaxWgs workgroups that answer lone queries until told to leave (same register budget as the inline launch)
-hipError_t launch_scan_query_resident(int M, int wgs, const ResidentArgs& args, hipStream_t stream) {
-    if (wgs < 2 || wgs > kResidentMaxWgs) return hipErrorInvalidValue;
-    if (M == 16) return args.a.nontemporal ? launch_scan_query_resident_v<16, true>(wgs, args, stream)
-                                            : launch_scan_query_resident_v<16, false>(wgs, args, stream);
-    return args.a.nontemporal ? launch_scan_query_resident_v<32, true>(wgs, args, stream)
-                              : launch_scan_query_resident_v<32, false>(wgs, args, stream);
 }
 
 void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, int s0, int K, uint32_t* d_cnt,

@@ -52,8 +52,7 @@ class Profile(C.Structure):
                 ("group_head_ms", C.c_double), ("group_scan_ms", C.c_double), ("group_order_ms", C.c_double),
                 ("group_head_codes", C.c_uint64), ("group_pairs", C.c_uint64), ("group_seats", C.c_uint64),
                 ("group_pass_codes8", C.c_uint64), ("group_pass_codes4", C.c_uint64), ("group_batches", C.c_uint64),
-                ("front_sharded_batches", C.c_uint64), ("dist_async_collects", C.c_uint64),
-                ("resident_launches", C.c_uint64), ("resident_queries", C.c_uint64), ("resident_fallbacks", C.c_uint64)]
+                ("front_sharded_batches", C.c_uint64), ("dist_async_collects", C.c_uint64)]
 
 
 class QadcError(RuntimeError):

@@ -52,9 +52,6 @@ def test_random_configuration_matches_oracle(pyqadc, po, seed):
                 # workgroups per query, tiny stream / candidate capacities
                 wgq_split=int(rng.choice([1, 3, 8])), wgq_split_codes=int(rng.choice([1024, 8192])),
                 wgq_capacity=int(rng.choice([64, 4096])), wgq_cand_cap=int(rng.choice([64, 4096, 4096])),
-                # a lone query through the resident kernel (tests/test_gpu_resident.py has the protocol's corners)
-                # (drawn from a generator of their own: the configurations of the earlier soaks stay what they were)
-                resident=int(np.random.default_rng(5000 + seed).choice([0, 1])), resident_idle_us=int(np.random.default_rng(6000 + seed).choice([50, 2000])),
                 # partition-major second phase of device-replayed batches (with its overflow fallback), head length and form
                 wgq_group=int(rng.choice([0, 2, 2])), wgq_group_head=int(rng.choice([1, 2, 4])), head_wg=int(rng.choice([0, 512])),
                 # the float half: grouping of the pre-scan's adds and the quantizer as the reference binary has them, or as its source reads
