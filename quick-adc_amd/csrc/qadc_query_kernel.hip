@@ -103,6 +103,9 @@ struct QCfg {
     static constexpr int MISC_OFF = TABLE_BYTES + 512;
     // misc (u32 words): [0..255] radix histogram / [0..127] value histogram, then scalars
     static constexpr int LDS_BYTES = MISC_OFF + (256 + 64 + 64) * 4;
+    // small batches (several workgroups per query): the first block's per-epoch value counters, behind everything else
+    static constexpr int FB_EPOCHS = M == 16 ? 25 : 21;          // epoch 0 = codes [0, 128), then quarter octaves up to 4096 vectors
+    static constexpr int FBH_BYTES = FB_EPOCHS * 128 * 4;
     static constexpr int OCC = (M == 16 || R16) ? 8 : 4;         // waves per SIMD the register budget is sized for
 };
 
@@ -513,7 +516,8 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
             const uint64_t chunk_ = ((V_top - B_ + G - 1) / G + 63) / 64 * 64;
             const uint64_t lo_ = min(V_top, B_ + (uint64_t)g * chunk_), hi_ = min(V_top, lo_ + chunk_);
             const uint32_t nfull0 = d_res.n / CPL;
-            resident = B_ == kFirstBlock && nfull0 >= kFirstBlock;
+            resident = B_ == kFirstBlock && nfull0 >= kFirstBlock && d_res.n > kFirstBlock * CPL;   // (the partition's last code — the one
+                                                                 //  with padding-lane replays — never lies in the first block)
             if (resident) {
                 res_lo = res_hi = (uint32_t)min(lo_, (uint64_t)nfull0);
                 if (lo_ < nfull0) res_hi = (uint32_t)min(min(hi_, (uint64_t)nfull0), lo_ + kResident);
@@ -1055,22 +1059,134 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     q_lds_barrier();
     STAMP(7);
     uint64_t lo1 = my_lo;                                        // where pass 1 of the plain walk starts
+    uint32_t nfb = 0;                                            // entries workgroup 0 wrote straight into its stream (the first block's)
+    const uint32_t dup_pos_res = RES && d_res.first_pos + d_res.n == d_res.global_n ? d_res.n - 1u : 0xffffffffu;
+    const uint32_t dup_reps_res = RES ? (16u - d_res.global_n % 16u) % 16u : 0u;
     if constexpr (RES) {
         if (resident) {
-            // the walk's first epochs, from the registers loaded at kernel entry: same epoch rule (a code is tested
-            // against the bound of the FINISHED epochs), tile t of the partition belongs to wave t mod 16
-            if (!A.ftables) {                                    // (float path: the quantizer staged this table already)
+            // ---- the first block in ONE step (round 6) ----
+            // Until round 6 the block's 4096 vectors (in registers since the front) were walked in five ramp epochs — lookups,
+            // emission, two barriers and a bound each: 13-15 K cycles — and workgroup 0, which emits the block's ~850 candidates,
+            // then SORTED them (37 K cycles of its 88 K; the other workgroups order ~70): workgroup 0 was the critical path of
+            // the lone query, by 14 us (phase stamps, profiles/r06_lone_query_stamps.txt).  Now every lane looks its codes up
+            // once; the values below 127 are counted per EPOCH of the block (epoch 0 = codes [0, 128), then quarter octaves:
+            // 25 epochs at 8192 codes) in LDS; after one barrier the waves derive every epoch's bound in parallel — the R-th
+            // smallest value of ALL codes of the earlier epochs, which all precede the epoch's codes in scan order (the
+            // prefix-bound rule) — and after a second one workgroup 0 writes the qualifying codes STRAIGHT
+            // into its stream at their scan-order index (prefix sums over (vector row, wave, lane): no candidate buffer, no
+            // sort).  The finer epochs also emit fewer candidates than the ramp did.
+            // the float path staged this partition's int8 table in the quantizer; the int8 path stages it here
+            if (!A.ftables) {
                 if (tid < M * 4) reinterpret_cast<uint32_t*>(tq)[tid] = table_word(a_res);
                 q_lds_barrier();
             }
             write_tables();
-            q_lds_barrier();
+            uint32_t* fbh = reinterpret_cast<uint32_t*>(qsmem + C::LDS_BYTES);    // [kFbEpochs][128] (the launch adds FBH_BYTES)
+            uint32_t* s_fbound = misc + 352;                                     // [kFbEpochs + 1]
+            constexpr int kFbCodes = (int)kFirstBlock * CPL;
+            constexpr int kFbEpochs = C::FB_EPOCHS;                              // epochs of the block; bound index kFbEpochs = behind it
+            static_assert((1 << (kFbEpochs + 27) / 4) == kFbCodes, "epochs of the first block");
+            if (g == 0)
+                for (uint32_t i = tid; i < (uint32_t)kFbEpochs * 128u; i += kQWG) fbh[i] = 0;
+            q_lds_barrier();                                     // image and counters ready
             tables_of = a_res;
             STAMP(8);
-            const uint32_t dup_pos = d_res.first_pos + d_res.n == d_res.global_n ? d_res.n - 1u : 0xffffffffu;
-            const uint32_t dup_reps = (16u - d_res.global_n % 16u) % 16u;
-            const uint32_t key_base = d_res.key_base + d_res.first_pos;
-            auto proc = [&](const u32x4& v, uint32_t vec, bool do_emit) {
+            auto epoch_of = [](uint32_t p) -> uint32_t {
+                if (p < 128u) return 0u;
+                const uint32_t lg = 31u - (uint32_t)__builtin_clz(p);
+                return 1u + 4u * (lg - 7u) + ((p >> (lg - 2u)) & 3u);
+            };
+            constexpr int kRows = (int)(kFirstBlock / kQWG);
+            uint32_t cvs[kRows];                                 // the lane's values, a byte per code
+#pragma unroll
+            for (int j = 0; j < kRows; ++j) {
+                uint32_t dd[4] = {fb[j].x, fb[j].y, fb[j].z, fb[j].w};
+                asm volatile("" : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]), "+v"(dd[3]));   // (keeps the lookup addresses of all rows from being formed at once)
+                cvs[j] = 0;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const uint32_t cv = min(q_pair_sum<M>(dd + c * DW, lane_lo, lane_hi), 127u);
+                    cvs[j] |= cv << (8 * c);
+                    if (cv < 127u) {
+                        const uint32_t p = ((uint32_t)j * kQWG + tid) * CPL + c;
+                        atomicAdd(g == 0 ? &fbh[epoch_of(p) * 128u + cv] : &hist_done[cv], 1u);   // (the others need the block's total only)
+                    }
+                }
+            }
+            q_lds_barrier();
+            if (g == 0) {
+                // wave w: bounds of the epochs w + 1 and w + 17 — counts of the epochs before them, bins 2 lane and 2 lane + 1
+                uint32_t c0 = 0, c1 = 0;
+                int e_done = 0;
+                for (int e = (int)wave + 1; e <= kFbEpochs; e += kQWaves) {
+                    for (; e_done < e; ++e_done) {
+                        const uint2 h2 = *reinterpret_cast<const uint2*>(&fbh[e_done * 128 + 2 * (int)lane]);
+                        c0 += h2.x;
+                        c1 += h2.y;
+                    }
+                    const uint32_t incl = q_wave_incl_sum(c0 + c1);
+                    const uint32_t excl = incl - (c0 + c1);
+                    const uint64_t reached = __builtin_amdgcn_ballot_w64(incl >= R);
+                    uint32_t b_ = 127u;
+                    if (reached != 0) {
+                        const uint32_t bl = excl + c0 >= R ? 2 * lane : 2 * lane + 1;
+                        b_ = min((uint32_t)__builtin_amdgcn_readlane((int)bl, (int)__builtin_ctzll(reached)), 127u);
+                    }
+                    if (lane == 0) s_fbound[e] = b_;
+                    if (e == kFbEpochs) {                        // the block's totals: what the rest of the walk counts on
+                        hist_done[2 * lane] = c0;
+                        hist_done[2 * lane + 1] = c1;
+                    }
+                }
+                if (tid == 0) s_fbound[0] = 127u;
+                q_lds_barrier();
+                bound = q_uni(s_fbound[kFbEpochs]);
+                // emission in scan order: row j, then wave, then lane, then the code inside the vector
+                const uint32_t key_base = d_res.key_base + d_res.first_pos;
+                uint32_t passm = 0, incl_j[kRows];               // passm: bit (j * CPL + c) = that code qualifies
+#pragma unroll
+                for (int j = 0; j < kRows; ++j) {
+                    uint32_t k_ = 0;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        const uint32_t p = ((uint32_t)j * kQWG + tid) * CPL + c;
+                        const uint32_t cv = (cvs[j] >> (8 * c)) & 0xffu;
+                        if (cv < s_fbound[epoch_of(p)]) {
+                            passm |= 1u << (j * CPL + c);
+                            ++k_;
+                        }
+                    }
+                    incl_j[j] = q_wave_incl_sum(k_);
+                    if (lane == 63) fbh[j * kQWaves + (int)wave] = incl_j[j];   // (the counters are dead: every bound is out)
+                }
+                q_lds_barrier();
+                if (wave == 0) {                                 // exclusive scan over the (row, wave) totals, in that order
+                    const uint32_t t_ = lane < (uint32_t)(kRows * kQWaves) ? fbh[lane] : 0u;
+                    const uint32_t in_ = q_wave_incl_sum(t_);
+                    fbh[64 + lane] = in_ - t_;
+                    if (lane == 63) fbh[128] = in_;
+                }
+                q_lds_barrier();
+                nfb = fbh[128];
+#pragma unroll
+                for (int j = 0; j < kRows; ++j) {
+                    uint32_t wp = fbh[64 + j * kQWaves + (int)wave] + incl_j[j];
+#pragma unroll
+                    for (int c = CPL - 1; c >= 0; --c) {         // (wp counts down from behind the lane's last entry of the row)
+                        if (passm & (1u << (j * CPL + c))) {
+                            --wp;
+                            const uint32_t p = ((uint32_t)j * kQWG + tid) * CPL + c;
+                            const uint32_t key = d_res.labels ? d_res.labels[p] : key_base + p;
+                            const uint64_t en = (uint64_t)key | ((uint64_t)((cvs[j] >> (8 * c)) & 0xffu) << 32) | ((uint64_t)a_res << 40);
+                            if (wp < A.cap) stream[wp] = en;
+                        }
+                    }
+                }
+            } else {
+                bound = q_uni(q_bound_from_hist(hist_done, R, lane));
+            }
+            STAMP(9);
+            auto proc = [&](const u32x4& v, uint32_t vec) {
                 uint32_t dd[4] = {v.x, v.y, v.z, v.w};
                 // (opaque copy: keeps the compiler from hoisting the 16 lookup addresses of every resident vector
                 // out of the epoch loop, which would spill)
@@ -1080,23 +1196,14 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                     const uint32_t cv = min(q_pair_sum<M>(dd + c * DW, lane_lo, lane_hi), 127u);
                     if (__builtin_expect(cv < bound, 0)) {
                         const uint32_t p = vec * CPL + c;
-                        // one LDS atomic per wave, not per lane: while the bound is loose every code qualifies
-                        const uint64_t act = __builtin_amdgcn_ballot_w64(true);
-                        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-                        if (do_emit) {
-                            uint32_t base = 0;
-                            if (before == 0) base = atomicAdd(&s_ccount, (uint32_t)__popcll(act));
-                            const uint32_t slot = q_uni(base) + before;
-                            if (slot < A.ccap) {
-                                QCand qc;
-                                qc.key = d_res.labels ? d_res.labels[p] : key_base + p;
-                                qc.val_reps = cv | ((p == dup_pos ? dup_reps : 0u) << 8);
-                                qc.pos = p;
-                                qc.slot = (uint32_t)a_res;
-                                cands[slot] = qc;
-                            }
-                        } else if (before == 0) {
-                            atomicAdd(&s_dirty, 1u);
+                        const uint32_t slot = atomicAdd(&s_ccount, 1u);
+                        if (slot < A.ccap) {
+                            QCand qc;
+                            qc.key = d_res.labels ? d_res.labels[p] : d_res.key_base + d_res.first_pos + p;
+                            qc.val_reps = cv | ((p == dup_pos_res ? dup_reps_res : 0u) << 8);
+                            qc.pos = p;
+                            qc.slot = (uint32_t)a_res;
+                            cands[slot] = qc;
                         }
                         atomicAdd(&hist_cur[cv], 1u);
                     }
@@ -1115,25 +1222,13 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                     last_cnt = cnt;
                 }
             };
-            for (uint32_t e_lo = 0; e_lo < kFirstBlock;) {       // the first block: bound only, unless this is workgroup 0
-                const uint32_t e_hi = e_lo + min(ramp, kFirstBlock - e_lo);
-                ramp *= 2u;
-#pragma unroll
-                for (int j = 0; j < (int)(kFirstBlock / kQWG); ++j) {
-                    const uint32_t vec = j * kQWG + tid;
-                    if (vec >= e_lo && vec < e_hi) proc(fb[j], vec, g == 0);
-                }
-                end_epoch_r();
-                e_lo = e_hi;
-            }
-            STAMP(9);
 #pragma unroll
             for (int jj = 0; jj < (int)(kResident / kQWG); jj += 4) {    // this workgroup's chunk: epochs of 4096 vectors
                 if (res_lo + jj * kQWG < res_hi) {
 #pragma unroll
                     for (int j = jj; j < jj + 4; ++j) {
                         const uint32_t vec = res_lo + j * kQWG + tid;
-                        if (vec < res_hi) proc(cf[j], vec, true);
+                        if (vec < res_hi) proc(cf[j], vec);
                     }
                     end_epoch_r();
                 }
@@ -1402,9 +1497,12 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         flags |= 32u;                                            // more candidates than the in-workgroup sort takes: host falls back
     } else if (ncand) {
         // (bucket-sort scratch: the value histograms — misc[0..255] — are dead by now)
-        out_count = q_order_and_write<12, true, WG>([&](uint32_t i) { return cands[i]; }, ncand, stream, A.cap, wcnt, tid, lane, wave,
+        // (behind the first block's entries, which workgroup 0 wrote in order as it found them)
+        out_count = q_order_and_write<12, true, WG>([&](uint32_t i) { return cands[i]; }, ncand, stream + min(nfb, A.cap),
+                                                A.cap - min(nfb, A.cap), wcnt, tid, lane, wave,
                                                 misc, 127u, (uint32_t)ma, A.pos_bits >> 16, A.pos_bits & 0xffffu);
     }
+    out_count += nfb;
     STAMP(14);
     s_count = out_count;
     if constexpr (RES) __syncthreads();                          // every lane's stream entries happen-before lane 0's release in publish()
@@ -1418,9 +1516,10 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         o.qmax = qmax;
         const uint64_t clk3 = __builtin_readcyclecounter();
 #ifdef QADC_STAMPS
-        if (blockIdx.x == 1) {
+        if (blockIdx.x <= 1) {                                   // (workgroup 0 emits the first block: it used to be the long one)
             stamps[6] = clk1; stamps[11] = clk2; stamps[15] = clk3;
-            printf("STAMPS ncand=%u:", ncand);
+            for (int i_ = 12; i_ < 14; ++i_) stamps[i_] = stamps[11];
+            printf("STAMPS wg=%u ncand=%u out=%u:", (unsigned)blockIdx.x, ncand, out_count);
             for (int i_ = 1; i_ < 16; ++i_) printf(" %d:%llu", i_, (unsigned long long)(stamps[i_] - stamps[i_ - 1]));
             printf("\n");
         }
@@ -2199,7 +2298,7 @@ static hipError_t launch_scan_query_nt(int nq, const QueryKernelArgs& args, hipS
 template <int M, int U, int OCC, bool NT>
 static hipError_t launch_scan_query_inline(int nq, const QueryKernelArgs& args, hipStream_t stream, const void* payload, size_t bytes) {
     static std::atomic<uint64_t> done{0};
-    const size_t lds = QCfg<M>::LDS_BYTES;
+    const size_t lds = QCfg<M>::LDS_BYTES + QCfg<M>::FBH_BYTES;
     const hipError_t e = dynamic_lds_optin(reinterpret_cast<const void*>(&scan_query_inline_kernel<M, U, OCC, NT>), (int)lds, done);
     if (e != hipSuccess) return e;
     QueryKernelInline ia;
