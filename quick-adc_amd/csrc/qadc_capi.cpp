@@ -675,7 +675,10 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         }
-        if (!seen) HIPCHECK(hipEventSynchronize(s.ev_done));
+        if (!seen) {
+            if (s.ev_valid) HIPCHECK(hipEventSynchronize(s.ev_done));
+            else HIPCHECK(hipStreamSynchronize(idx->wgq_stream));    // (a polled batch records no event: launch_wgq_batch)
+        }
         uint64_t max_count = 0;
         bool cand_overflow = false;
         for (int q = 0; q < s.nq * s.wgq_G; ++q) {
@@ -868,9 +871,9 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
         if (simple) {
             s.out_off[s.nq] = total;
             s.skipped_streams = skipped;
-            if (s.out_entries.size() < total) s.out_entries.resize(total);
             for (int q = 0; q < s.nq * (split ? s.wgq_G : 1); ++q) ncand += s.h_qout[q].count;
             idx->prof.candidates += ncand;
+            if (s.out_entries.size() < total) s.out_entries.resize(total);
             auto copy = [&](int q0, int q1) {
                 for (int q = q0; q < q1; ++q) {
                     uint64_t* dst = s.out_entries.data() + s.out_off[q];

@@ -186,6 +186,7 @@ struct Slot {
     bool dist_batch = false;            // launched with the native multi-GPU merge active: streams kept in device memory
     uint32_t wgq_cap = 0;               // stream entries per query workgroup (regrown on overflow)
     bool poll = false;                  // collect watches the workgroups' done bits instead of the completion event
+    bool ev_valid = false;              // ev_done was recorded behind this batch's launches (not for a polled batch)
     int wgq_G = 1;                      // workgroups per query (small batches: the scan order of a query is split)
     uint64_t wgq_codes = 0;             // codes a query probes (exact maximum, or an estimate) — sizes wgq_G
     uint64_t head_codes = 0;            // level path: codes of every query's scan order covered by the head launch (0 = none)
@@ -399,7 +400,8 @@ struct qadc_index {
     int device_replay_alone_nq = 512;    // ... a batch with nothing else in flight (a synchronous call): from this many
     uint64_t front_run_max = 2u << 20;   // leading levels whose runs are at most this long join the front (0 = none); they are
                                          // counted with the small launches, not event-timed.  125M x 32: 2 Mi -4 %, 8 Mi +1 %
-    uint32_t wgq_split_codes = 8192;    // a query is split over several workgroups only down to this many codes each
+    uint32_t wgq_split_codes = 2048;    // a query is split over several workgroups only down to this many codes each (round 6, with the
+                                        // one-step first block: lone query, 10^5 codes, same box: 12 workgroups 36.1 us, 16: 33.3, 32: 32.6, 48: 32.6)
     int head_wg = 0;       // 512: the IVF head launch runs in 512-thread workgroups (8 waves per query); 0 / 1024: 16 waves
     uint32_t prescan_sample = 1u << 16;  // starts pre-scanned unfiltered before the survivor filter kicks in
     WorkerPool pool;                   // host replay workers (started on first use)
@@ -408,7 +410,7 @@ struct qadc_index {
     // one workgroup per query (IVF batches, small lists): 0 = never, 1 = auto, 2 = whenever structurally possible
     int wgq = 1;
     uint32_t wgq_capacity = 4096;        // stream entries per query to start with
-    int wgq_split = 12;                 // workgroups a small batch may spread one query's scan order over
+    int wgq_split = 32;                 // workgroups a small batch may spread one query's scan order over
     int head_level = 5;                  // level path: bound levels 0..head_level-1 (the first 512 Ki codes of every query) are
                                          // scanned by ONE launch of the query kernel in head mode instead of head_level dependent
                                          // level launches (0 = off): -5 % per step on a 125M-code shard, neutral at 1B

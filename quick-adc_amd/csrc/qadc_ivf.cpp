@@ -46,9 +46,11 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     const size_t in_bytes = align16(off_tables + tables_bytes);
     HIPCHECK(s.h_in.ensure(std::max<size_t>(in_bytes, 16)));
     HIPCHECK(s.d_in.ensure(std::max<size_t>(in_bytes, 16)));
-    if (assign_bytes) std::memcpy(s.h_in.p, s.assign.data(), assign_bytes);
-    if (s.float_path && !s.device_tables) std::memcpy(s.h_in.p + off_tables, s.tables, nt * sizeof(float));
-    if (!s.float_path) std::memcpy(s.h_in.p + off_tables, s.qtables_in.data(), nt);
+    auto fill_upload = [&]() {
+        if (assign_bytes) std::memcpy(s.h_in.p, s.assign.data(), assign_bytes);
+        if (s.float_path && !s.device_tables) std::memcpy(s.h_in.p + off_tables, s.tables, nt * sizeof(float));
+        if (!s.float_path) std::memcpy(s.h_in.p + off_tables, s.qtables_in.data(), nt);
+    };
 
     // ---- result block in pinned, device-mapped host memory: [QueryOut[nq]][streams u64[nq][cap] unless they stay
     // on the device][heaps u64[nq][R]][sizes u32[nq]] ----
@@ -138,6 +140,7 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             inl_bytes = total;
         }
     }
+    if (!inl_bytes) fill_upload();                               // (an inline query's input rides in the dispatch packet instead)
     if (in_bytes && !inl_bytes) {
         if (alone) {
             HIPCHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, st));
@@ -369,8 +372,13 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             HIPCHECK(launch_replay_heap_wave_qflags(s.d_qflags.p, s.d_stream.p, cap, nq, (uint32_t)s.R, d_heaps, d_sizes, st));
         }
     }
-    if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(s.ev_done, st));
+    // (a polled batch — the lone synchronous query — is read from its records' done bits; should they not show up in time the collect
+    // call waits for the scan stream itself, so the ~1 us of an event record stays off the call)
+    s.ev_valid = !s.poll;
+    if (s.ev_valid) {
+        if (!s.ev_done) HIPCHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(s.ev_done, st));
+    }
     return QADC_OK;
 }
 

@@ -426,6 +426,45 @@ __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand,
     return out_count;
 }
 
+// How the scan order (V vectors) of a query is shared by its G workgroups: everybody walks the first block [0, B) for the bound,
+// workgroup g then takes [lo, hi) of the rest.  `handicap` (vectors, a multiple of 64; 0 = even split): what workgroup 0's extra
+// work in the first block — it alone derives the per-epoch bounds and writes the block's candidates out — is worth in chunk
+// vectors; its chunk is shorter by that much (possibly empty) and the others share the difference.  Lone query, 10^5 codes in 12
+// workgroups: workgroup 0's first block 11.4 K cycles against 4.8 K, a chunk of 3.8 K vectors 5.5 K cycles (phase stamps).
+// 32-bit arithmetic whenever the order fits (the 64-bit divisions are ~0.4 K cycles of scalar-free VALU each at kernel entry).
+struct QRange { uint64_t lo, hi; };
+__device__ __forceinline__ QRange q_chunk_range(uint64_t V, uint64_t B, int G, int g, uint32_t handicap) {
+    QRange r;
+    const uint64_t rest = V - B;
+    if (G < 2 || handicap == 0) {
+        const uint64_t chunk = rest < 0xffffff00ull ? (uint64_t)((((uint32_t)rest + (uint32_t)G - 1u) / (uint32_t)G + 63u) / 64u * 64u)
+                                                    : ((rest + G - 1) / G + 63) / 64 * 64;
+        r.lo = min(V, B + (uint64_t)g * chunk);
+        r.hi = min(V, r.lo + chunk);
+        return r;
+    }
+    uint64_t c0, per1;
+    if (rest < 0xff000000ull) {
+        const uint32_t per = (((uint32_t)rest + handicap + (uint32_t)G - 1u) / (uint32_t)G + 63u) / 64u * 64u;
+        const uint32_t c0_ = min(per > handicap ? per - handicap : 0u, (uint32_t)rest);
+        c0 = c0_;
+        per1 = (((uint32_t)rest - c0_ + (uint32_t)G - 2u) / (uint32_t)(G - 1) + 63u) / 64u * 64u;
+    } else {
+        const uint64_t per = ((rest + handicap + G - 1) / G + 63) / 64 * 64;
+        c0 = min(per > handicap ? per - handicap : (uint64_t)0, rest);
+        per1 = ((rest - c0 + G - 2) / (G - 1) + 63) / 64 * 64;
+    }
+    if (g == 0) {
+        r.lo = B;
+        r.hi = B + c0;
+    } else {
+        r.lo = min(V, B + c0 + (uint64_t)(g - 1) * per1);
+        r.hi = min(V, r.lo + per1);
+    }
+    return r;
+}
+constexpr uint32_t kWg0Handicap = 6144;
+
 // OCC = waves per SIMD the register budget is sized for: 8 = two workgroups per CU (64 VGPRs), 4 = one (128 VGPRs).
 // NT = non-temporal code loads (lists that stream from HBM anyway); a database that fits the 256 MiB Infinity Cache
 // keeps the default policy and is re-read from the cache by every query.
@@ -487,7 +526,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     // complete codes (a flat list, or a first partition of >= 4096 vectors); anything else takes the plain walk. ----
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) u32x4* gvec_t;
-    constexpr uint32_t kFirstBlock = 4096, kResident = M == 16 ? 4096 : 8192;   // (16x4: more would spill)
+    constexpr uint32_t kFirstBlock = 4096, kResident = M == 16 ? 6144 : 8192;   // (vectors; 16x4: 90 -> 98 VGPRs of 128 with 6144)
     constexpr bool RES = MULTI && !HEAD;
     u32x4 fb[RES ? kFirstBlock / kQWG : 1], cf[RES ? kResident / kQWG : 1];
     uint64_t V_top = 0;
@@ -513,11 +552,11 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         if (a_res < ma) {
             d_res = q_load_desc(parts, (int)q_uni((uint32_t)part_of(a_res)));
             const uint64_t B_ = min(V_top, (uint64_t)kFirstBlock);
-            const uint64_t chunk_ = ((V_top - B_ + G - 1) / G + 63) / 64 * 64;
-            const uint64_t lo_ = min(V_top, B_ + (uint64_t)g * chunk_), hi_ = min(V_top, lo_ + chunk_);
             const uint32_t nfull0 = d_res.n / CPL;
             resident = B_ == kFirstBlock && nfull0 >= kFirstBlock && d_res.n > kFirstBlock * CPL;   // (the partition's last code — the one
                                                                  //  with padding-lane replays — never lies in the first block)
+            const QRange mine_ = q_chunk_range(V_top, B_, G, g, resident ? kWg0Handicap : 0u);
+            const uint64_t lo_ = mine_.lo, hi_ = mine_.hi;
             if (resident) {
                 res_lo = res_hi = (uint32_t)min(lo_, (uint64_t)nfull0);
                 if (lo_ < nfull0) res_hi = (uint32_t)min(min(hi_, (uint64_t)nfull0), lo_ + kResident);
@@ -607,15 +646,15 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
 #pragma unroll
             for (int k = 0; k < kTV; ++k) r.tv[k] = 0.0f;
             if (r.active) {
-                const float* __restrict__ ft = ft_all + (size_t)a * (M * 16);
-#pragma unroll
-                for (int k = 0; k < kTV; ++k) r.tv[k] = ft[k * 64 + (int)lane];
-                const PartDesc& d = parts[assign[a]];
+                const PartDesc& d = parts[assign[a]];            // (before the table: the code loads wait for these words only)
                 const uint32_t gn = d.global_n, st_n = d.start_n;
                 const uint8_t* st_p = d.starts;
                 const uint8_t* co_p = d.codes;
                 r.sn = gn ? st_n : 0u;
                 r.sc = st_p ? st_p : co_p;
+                const float* __restrict__ ft = ft_all + (size_t)a * (M * 16);
+#pragma unroll
+                for (int k = 0; k < kTV; ++k) r.tv[k] = ft[k * 64 + (int)lane];
             }
             return r;
         };
@@ -626,29 +665,10 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
             const bool active = cur.active;
             uint32_t sn = 0, base = 0;
             const uint8_t* sc = nullptr;
-            if (active) {
-                q_wave_lds_sync();
-#pragma unroll
-                for (int k = 0; k < kTV; ++k) {
-                    mytab[k * 64 + (int)lane] = cur.tv[k];
-                    if (sub == 0) lmin = fminf(lmin, cur.tv[k]);
-                }
-                q_wave_lds_sync();
-                sn = q_uni(cur.sn);
-                sc = reinterpret_cast<const uint8_t*>(q_uni64(reinterpret_cast<uint64_t>(cur.sc)));
-                if (sub == 0 && sn) {
-                    if (lane == 0) base = atomicAdd(&s_nvals, sn);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (lane == 0) wcnt[16 + pslot] = base;      // hand the base to the probe's other waves
-                }
-            }
-            if (wpp > 1) {
-                __syncthreads();
-                if (active && sn) base = wcnt[16 + pslot];
-            }
             const uint32_t step = 64u * (uint32_t)wpp;
-            for (uint32_t i0 = (uint32_t)sub * 64u + lane; i0 < sn; i0 += step * kPB) {
-                uint32_t dwv[kPB][DW];
+            const uint32_t i_first = (uint32_t)sub * 64u + lane;
+            uint32_t dwv[kPB][DW];
+            auto load_batch = [&](uint32_t i0) {
 #pragma unroll
                 for (int u = 0; u < kPB; ++u) {
                     const uint32_t i = i0 + (uint32_t)u * step;
@@ -666,10 +686,38 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                         }
                     }
                 }
+            };
+            if (active) {
+                // (round 6: the descriptor is fetched before the table in round_in, and the first start vectors are requested
+                // here, BEFORE the wave waits for its table's floats: the lone query's pre-scan was two memory round trips in a
+                // row — table, then codes — 7.2 K cycles for one code per lane)
+                sn = q_uni(cur.sn);
+                sc = reinterpret_cast<const uint8_t*>(q_uni64(reinterpret_cast<uint64_t>(cur.sc)));
+                if constexpr (RES) load_batch(i_first);          // (small batches only: the 64-register head kernels would spill)
+                q_wave_lds_sync();
+#pragma unroll
+                for (int k = 0; k < kTV; ++k) {
+                    mytab[k * 64 + (int)lane] = cur.tv[k];
+                    if (sub == 0) lmin = fminf(lmin, cur.tv[k]);
+                }
+                q_wave_lds_sync();
+                if (sub == 0 && sn) {
+                    if (lane == 0) base = atomicAdd(&s_nvals, sn);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (lane == 0) wcnt[16 + pslot] = base;      // hand the base to the probe's other waves
+                }
+            }
+            if (wpp > 1) {
+                q_lds_barrier();
+                if (active && sn) base = wcnt[16 + pslot];
+            }
+            for (uint32_t i0 = i_first; i0 < sn; i0 += step * kPB) {
+                if (!RES || i0 != i_first) load_batch(i0);
                 const uint32_t tb = (uint32_t)C::WTAB_OFF + wave * (uint32_t)(M * 16 * 4);   // mytab, as an absolute LDS address
 #pragma unroll
                 for (int u = 0; u < kPB; ++u) {
                     const uint32_t i = i0 + (uint32_t)u * step;
+                    if (RES && i - lane >= sn) continue;         // (wave-uniform: none of the wave's lanes has a start here)
                     const float cand = q_prescan_sum<M>(dwv[u], tb, sum_mode);   // (lanes past the starts sum code 0: not stored)
                     if (i < sn) {
                         if (in_lds) vals[base + i] = cand;
@@ -677,10 +725,23 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                     }
                 }
             }
-            if (wpp > 1) __syncthreads();                        // the hand-over slot is reused by the next round
+            if (wpp > 1) q_lds_barrier();                        // the hand-over slot is reused by the next round
             cur = nxt;
         }
         STAMP(3);
+        // the quantizer's first kQB table entries per lane (all of them for up to 32 probes at 16x4): requested here, they
+        // arrive under the select (they used to be waited for between the select and the quantizer: 2.4 K cycles for 256 floats)
+        constexpr int kQB = 8;                                   // table entries in flight per lane (the clamp's store to the same
+                                                                 // array keeps the compiler from overlapping the loads by itself)
+        const int all = ma * M * 16;
+        float qtv0[RES ? kQB : 1];                               // (small batches only: the 64-register head kernels would spill them)
+        if constexpr (RES) {
+#pragma unroll
+            for (int u = 0; u < kQB; ++u) {
+                const int i = (int)tid + u * kQWG;
+                qtv0[u] = i < all ? ft_all[i] : 0.0f;
+            }
+        }
         prefetch();                                              // in flight under the select and the quantizer
         // qmin = min over ALL ma tables (db_query_4.cpp:258)
         lmin = q_wave_min(lmin);
@@ -764,9 +825,103 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 __syncthreads();
                 const uint32_t c = s_sel;
                 if (c >= R && c <= kListCap) nlist = c;          // (workgroup-uniform)
+            } else if (in_lds && n <= 256u) {                     // a handful of values: they ARE the list
+                for (uint32_t i = tid; i < n; i += kQWG) list[i] = q_fkey(vals[i]);
+                __syncthreads();
+                nlist = n;
             }
-            if (tid == 0) { s_prefix = 0; s_k = R; }
-            for (int pass = 0; pass < 4; ++pass) {
+            // Round 6.  Up to 256 keys (kept by the threshold, or all there are) are ranked at once.  More: ONE histogram pass
+            // over a digit fitted to the keys — bucket = (key - smallest key) >> sh, sh such that the keys' range fills 256
+            // buckets — which puts a dozen keys into the bucket of rank R where the fixed top byte of a float key (sign and
+            // seven exponent bits) puts nearly all of them into two or three; that bucket's keys are collected and ranked.
+            // The lone query's 10^3 pre-scan values went through four histogram passes of three barriers each before:
+            // 6.9 K cycles.  A bucket of more than 256 keys (tie-heavy tables) leaves it to the four fixed passes below.
+            uint32_t& s_kmin = misc[329];
+            uint32_t& s_kmax = misc[330];
+            bool direct = nlist != 0 && nlist <= 256u;
+            if (direct) {
+                if (tid < nlist) {
+                    const uint32_t key = list[tid];
+                    const uint4* l4 = reinterpret_cast<const uint4*>(list);
+                    uint32_t less = 0, le = 0, j = 0;
+                    for (; j + 4 <= nlist; j += 4) {
+                        const uint4 kk = l4[j >> 2];
+                        less += (kk.x < key ? 1u : 0u) + (kk.y < key ? 1u : 0u) + (kk.z < key ? 1u : 0u) + (kk.w < key ? 1u : 0u);
+                        le += (kk.x <= key ? 1u : 0u) + (kk.y <= key ? 1u : 0u) + (kk.z <= key ? 1u : 0u) + (kk.w <= key ? 1u : 0u);
+                    }
+                    for (; j < nlist; ++j) {
+                        const uint32_t kj = list[j];
+                        less += kj < key ? 1u : 0u;
+                        le += kj <= key ? 1u : 0u;
+                    }
+                    if (less < R && R <= le) s_prefix = key;
+                }
+                __syncthreads();
+            } else {
+                if (tid == 0) { s_kmin = 0xffffffffu; s_kmax = 0; s_sel = 0; }
+                if (tid < 256) hist[tid] = 0;
+                __syncthreads();
+                uint32_t mn = 0xffffffffu, mx = 0;
+                for_each_key([&](uint32_t key) { mn = min(mn, key); mx = max(mx, key); });
+                mn = q_wave_scan_bits(mn, 0xffffffffu, [](uint32_t a, uint32_t b) { return min(a, b); });
+                mx = q_wave_scan_bits(mx, 0u, [](uint32_t a, uint32_t b) { return max(a, b); });
+                if (lane == 63) {
+                    atomicMin(&s_kmin, mn);
+                    atomicMax(&s_kmax, mx);
+                }
+                __syncthreads();
+                const uint32_t kmin = s_kmin, range = s_kmax - kmin;
+                const uint32_t sh = range >= 256u ? 24u - (uint32_t)__builtin_clz(range) : 0u;
+                for_each_key([&](uint32_t key) { atomicAdd(&hist[(key - kmin) >> sh], 1u); });
+                __syncthreads();
+                if (tid < 64) {                                  // wave 0: 4 buckets per lane, pick the one holding rank R
+                    const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+                    const uint32_t sum4 = c0 + c1 + c2 + c3;
+                    const uint32_t incl = q_wave_incl_sum(sum4);
+                    const uint32_t excl = incl - sum4;
+                    if (incl >= R && excl < R) {                 // exactly one lane
+                        uint32_t run = excl, digit = 4 * tid;
+                        const uint32_t cs4[4] = {c0, c1, c2, c3};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (run + cs4[j] >= R) { digit = 4 * tid + j; break; }
+                            run += cs4[j];
+                        }
+                        s_prefix = digit;
+                        s_k = R - run;
+                        s_binc = hist[digit];
+                    }
+                }
+                __syncthreads();
+                if (s_binc <= 256u) {                            // (workgroup-uniform)
+                    const uint32_t b_ = s_prefix, k2 = s_k;
+                    for_each_key([&](uint32_t key) {
+                        if (((key - kmin) >> sh) == b_) hist[atomicAdd(&s_sel, 1u)] = key;
+                    });
+                    __syncthreads();
+                    const uint32_t c = s_sel;
+                    if (tid < c) {
+                        const uint32_t key = hist[tid];
+                        const uint4* h4 = reinterpret_cast<const uint4*>(hist);
+                        uint32_t less = 0, le = 0, j = 0;
+                        for (; j + 4 <= c; j += 4) {
+                            const uint4 kk = h4[j >> 2];
+                            less += (kk.x < key ? 1u : 0u) + (kk.y < key ? 1u : 0u) + (kk.z < key ? 1u : 0u) + (kk.w < key ? 1u : 0u);
+                            le += (kk.x <= key ? 1u : 0u) + (kk.y <= key ? 1u : 0u) + (kk.z <= key ? 1u : 0u) + (kk.w <= key ? 1u : 0u);
+                        }
+                        for (; j < c; ++j) {
+                            const uint32_t kj = hist[j];
+                            less += kj < key ? 1u : 0u;
+                            le += kj <= key ? 1u : 0u;
+                        }
+                        if (less < k2 && k2 <= le) s_prefix = key;
+                    }
+                    __syncthreads();
+                    direct = true;
+                }
+            }
+            if (!direct && tid == 0) { s_prefix = 0; s_k = R; }
+            for (int pass = 0; pass < 4 && !direct; ++pass) {
                 const int lo = 24 - 8 * pass;
                 if (tid < 256) hist[tid] = 0;
                 __syncthreads();
@@ -851,15 +1006,13 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         if ((double)qmax > 1e30) flags |= 1u;                   // (a double compare, as db_query_4.cpp:271: 1e30f itself is above 1e30)
         const float delta = (qmax - qmin) / 127;
         const float scale = 127.0f / (qmax - qmin);
-        const int all = ma * M * 16;
-        constexpr int kQB = 8;                                   // table entries in flight per lane (the clamp's store to the same
-                                                                 // array keeps the compiler from overlapping the loads by itself)
         for (int i0 = tid; i0 < all; i0 += kQWG * kQB) {
             float tv[kQB];
 #pragma unroll
             for (int u = 0; u < kQB; ++u) {
                 const int i = i0 + u * kQWG;
-                tv[u] = i < all ? ft_all[i] : 0.0f;
+                if constexpr (RES) tv[u] = i0 == (int)tid ? qtv0[u] : (i < all ? ft_all[i] : 0.0f);
+                else tv[u] = i < all ? ft_all[i] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < kQB; ++u) {
@@ -961,6 +1114,14 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     uint32_t& s_ccount = misc[326];                              // candidates appended so far
     uint32_t& s_hreps = misc[324];                               // (HEAD, one workgroup per query) padding-lane replays among them
     QCand* __restrict__ cands = A.cands + (size_t)wgi * A.ccap;
+    // small batches: the first kLdsCands candidates of a workgroup wait in LDS (where the first block's epoch counters lay) —
+    // a workgroup has ~10^2 of them, and through global memory the ordering pass began with a store drain and an L2 round trip
+    constexpr uint32_t kLdsCands = RES ? (uint32_t)C::FBH_BYTES / 16u : 0u;
+    QCand* lcands = reinterpret_cast<QCand*>(qsmem + C::LDS_BYTES);
+    auto put_cand = [&](uint32_t slot, const QCand& qc) {
+        if (RES && slot < kLdsCands) lcands[slot] = qc;
+        else cands[slot] = qc;
+    };
     auto next_part = [&](int a_) {
         ++a_;
         while (a_ < mas && q_uni(parts[assign[a_]].n) == 0) ++a_; // empty partition (db_query_4.cpp:291-293) / no local codes
@@ -1049,8 +1210,8 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     // chunk of the rest.  The bound a workgroup uses for a code is the R-th smallest value of candidates from the
     // first block and from its own chunk before that code: a subset of the code's scan-order prefix, hence valid.
     const uint64_t B = MULTI ? min(V, (uint64_t)kFirstBlock) : 0;
-    const uint64_t chunk = MULTI ? ((V - B + G - 1) / G + 63) / 64 * 64 : V;
-    const uint64_t my_lo = min(V, B + (uint64_t)g * chunk), my_hi = min(V, my_lo + chunk);
+    const QRange mine = MULTI ? q_chunk_range(V, B, G, g, (RES && resident) ? kWg0Handicap : 0u) : QRange{0, V};
+    const uint64_t my_lo = mine.lo, my_hi = mine.hi;
 
     uint32_t bound = 127, ramp = MULTI ? 256 : 64, last_cnt = 0;   // (several workgroups per query: fewer, larger ramp epochs)
     uint32_t& s_dirty = misc[327];                               // bumped by a histogram-only walk that found a candidate
@@ -1182,6 +1343,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                         }
                     }
                 }
+                q_lds_barrier();                                 // (the counters' words hold candidates from here on)
             } else {
                 bound = q_uni(q_bound_from_hist(hist_done, R, lane));
             }
@@ -1203,7 +1365,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                             qc.val_reps = cv | ((p == dup_pos_res ? dup_reps_res : 0u) << 8);
                             qc.pos = p;
                             qc.slot = (uint32_t)a_res;
-                            cands[slot] = qc;
+                            put_cand(slot, qc);
                         }
                         atomicAdd(&hist_cur[cv], 1u);
                     }
@@ -1222,16 +1384,15 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                     last_cnt = cnt;
                 }
             };
+            if (res_lo < res_hi) {                               // this workgroup's chunk, as far as it lies in registers: one epoch
 #pragma unroll
-            for (int jj = 0; jj < (int)(kResident / kQWG); jj += 4) {    // this workgroup's chunk: epochs of 4096 vectors
-                if (res_lo + jj * kQWG < res_hi) {
-#pragma unroll
-                    for (int j = jj; j < jj + 4; ++j) {
+                for (int j = 0; j < (int)(kResident / kQWG); ++j) {
+                    if (res_lo + j * kQWG < res_hi) {            // (workgroup-uniform)
                         const uint32_t vec = res_lo + j * kQWG + tid;
                         if (vec < res_hi) proc(cf[j], vec);
                     }
-                    end_epoch_r();
                 }
+                end_epoch_r();
             }
             STAMP(10);
             ramp = max(ramp, 2u * kFirstBlock);
@@ -1324,7 +1485,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                         qc.val_reps = cv | ((p == dup_pos ? dup_reps : 0u) << 8);
                         qc.pos = p;
                         qc.slot = (uint32_t)a;
-                        cands[slot] = qc;
+                        put_cand(slot, qc);
                     }
                 } else {
                     atomicAdd(&s_dirty, 1u);                     // (histogram-only walk: still makes the epoch "dirty")
@@ -1498,7 +1659,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     } else if (ncand) {
         // (bucket-sort scratch: the value histograms — misc[0..255] — are dead by now)
         // (behind the first block's entries, which workgroup 0 wrote in order as it found them)
-        out_count = q_order_and_write<12, true, WG>([&](uint32_t i) { return cands[i]; }, ncand, stream + min(nfb, A.cap),
+        out_count = q_order_and_write<12, true, WG>([&](uint32_t i) { return (RES && i < kLdsCands) ? lcands[i] : cands[i]; }, ncand, stream + min(nfb, A.cap),
                                                 A.cap - min(nfb, A.cap), wcnt, tid, lane, wave,
                                                 misc, 127u, (uint32_t)ma, A.pos_bits >> 16, A.pos_bits & 0xffffu);
     }
