@@ -858,7 +858,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 }
                 __syncthreads();
             } else {
-                if (tid == 0) { s_kmin = 0xffffffffu; s_kmax = 0; s_sel = 0; }
+                if (tid == 0) { s_kmin = 0xffffffffu; s_kmax = 0; }      // (s_sel — the threshold's count — may still be being read)
                 if (tid < 256) hist[tid] = 0;
                 __syncthreads();
                 uint32_t mn = 0xffffffffu, mx = 0;
@@ -891,6 +891,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                         s_k = R - run;
                         s_binc = hist[digit];
                     }
+                    if (tid == 0) s_sel = 0;
                 }
                 __syncthreads();
                 if (s_binc <= 256u) {                            // (workgroup-uniform)
