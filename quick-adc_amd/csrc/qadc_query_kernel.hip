@@ -1407,6 +1407,29 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         const bool do_emit = pass == 1 || g == 0;
         uint64_t pbase = 0, cbase = 0;                           // vectors / codes of the scan order before partition a
         int a = HEAD ? 0 : next_part(-1);                        // (HEAD walks every slot: cbase counts empty-here partitions too)
+        if (MULTI && !HEAD && V < 0xffffffffull) {
+            // the partition `lo` lies in, found by the lanes together (lanes = assign slots, 64 per step: two loads deep).  The
+            // loop below takes one slot per iteration, two DEPENDENT loads each: workgroup g of a lone query over 32 probes
+            // spent up to ~1.4 us per skipped slot there — the launch lasted 74 us where its first workgroups needed 31
+            // (rocprofv3 against the phase stamps of workgroups 0 and 1, round 6)
+            uint32_t run = 0;
+            a = mas;
+            for (int a0 = 0; a0 < mas; a0 += 64) {
+                const int a_ = a0 + (int)lane;
+                const uint32_t nv_ = a_ < mas ? (parts[assign[a_]].n + CPL - 1) / CPL : 0u;
+                const uint32_t incl = q_wave_incl_sum(nv_);
+                const uint32_t before = run + incl - nv_;
+                const uint64_t hit = __builtin_amdgcn_ballot_w64(nv_ != 0 && (uint64_t)before + nv_ > lo);
+                if (hit) {
+                    const int l_ = (int)__builtin_ctzll(hit);
+                    a = a0 + l_;
+                    pbase = (uint32_t)__builtin_amdgcn_readlane((int)before, l_);
+                    break;
+                }
+                run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                pbase = run;
+            }
+        }
         while (MULTI && a < mas) {                                // skip the partitions that end before lo
             const uint32_t n_ = q_uni(parts[assign[a]].n);
             const uint32_t nv = (eff_n(n_, cbase) + CPL - 1) / CPL;
@@ -1678,7 +1701,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         o.qmax = qmax;
         const uint64_t clk3 = __builtin_readcyclecounter();
 #ifdef QADC_STAMPS
-        if (blockIdx.x <= 1) {                                   // (workgroup 0 emits the first block: it used to be the long one)
+        if (blockIdx.x <= 1 || blockIdx.x + 1 == gridDim.x) {   // (workgroup 0 emits the first block; the last one skips the most partitions)
             stamps[6] = clk1; stamps[11] = clk2; stamps[15] = clk3;
             for (int i_ = 12; i_ < 14; ++i_) stamps[i_] = stamps[11];
             printf("STAMPS wg=%u ncand=%u out=%u:", (unsigned)blockIdx.x, ncand, out_count);

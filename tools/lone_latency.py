@@ -10,17 +10,22 @@ import numpy as np
 import bench, pyqadc
 import ctypes as C
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-opts = dict(kv.split("=") for kv in sys.argv[2:])                # e.g. wgq_split=24 wgq_split_codes=4096
-M, R, reps = 16, 100, 420
+opts = dict(kv.split("=") for kv in sys.argv[2:])                # e.g. wgq_split=24 wgq_split_codes=4096; K=64 ma=32: an IVF shape
+if "lib" in opts:                                                # lib=r06base: a library built from another commit, next to the shipped one
+    pyqadc.LIB_PATH = os.path.join(ROOT, "quick-adc_amd", "libqadc_hip_%s.so" % opts.pop("lib"))
+K, ma = int(opts.pop("K", 1)), int(opts.pop("ma", 1))
+reps = int(opts.pop("reps", 420))                                # (lib=stamps reps=23: the phase stamps of three timed calls)            # n codes in K equal partitions, ma of them probed
+M, R = 16, 100
 idx = pyqadc.Index(M, 0)
-idx.add_partition_synthetic(n, 1)
+for p_ in range(K):
+    idx.add_partition_synthetic(n // K, 1 + p_)
 idx.finalize(bench.KEEP)
 for k_, v_ in opts.items():
     idx.set_option(k_, float(v_))
 rng = np.random.default_rng(0)
 cb = rng.normal(size=(M, 16, 8)).astype(np.float32)
-tb = bench.make_tables(rng, cb, 1)
-a = np.zeros((1, 1), np.int32)
+tb = bench.make_tables(rng, cb, ma)
+a = rng.permutation(K)[:ma].astype(np.int32).reshape(1, ma)
 keys, vals = np.zeros((1, R), np.uint32), np.zeros((1, R), np.int8)
 sizes, status = np.zeros(1, np.int32), np.zeros(1, np.int32)
 qmin, qmax = np.zeros(1, np.float32), np.zeros(1, np.float32)
@@ -36,7 +41,7 @@ for i in range(reps):
     if i == 20:
         idx.profile_reset()
     t0 = time.perf_counter()
-    rc = fn(h, 1, 1, pa, ptrs[i], R, *fixed)
+    rc = fn(h, 1, ma, pa, ptrs[i], R, *fixed)
     t1 = time.perf_counter()
     assert rc == 0 and status[0] == 0 and sizes[0] == R
     if i >= 20:
@@ -45,6 +50,6 @@ pr = idx.profile()
 idx.close()
 ts = np.sort(np.array(ts)) * 1e6
 k = reps - 20
-print(opts, "codes %d: median %.1f us  p10 %.1f  p90 %.1f;  host timers per call: submit (plan + launch) %.2f us, stream assembly %.2f us, "
+print(opts, "K=%d ma=%d" % (K, ma), "codes %d: median %.1f us  p10 %.1f  p90 %.1f;  host timers per call: submit (plan + launch) %.2f us, stream assembly %.2f us, "
       "heap replay %.2f us; stream entries per query %.0f" % (n, np.median(ts), ts[len(ts) // 10], ts[len(ts) * 9 // 10],
       pr["host_plan_ms"] * 1e3 / k, pr["host_replay_ms"] * 1e3 / k, pr["host_heap_ms"] * 1e3 / k, pr["candidates"] / k))
