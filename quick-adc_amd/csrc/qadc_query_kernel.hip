@@ -515,7 +515,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
 #define STAMP(k) do {} while (0)
 #endif
     if (tid < 256) hist[tid] = 0;
-    if (tid == 0) { s_nvals = 0; s_count = 0; }
+    if (tid == 0) { s_nvals = 0; s_count = 0; misc[329] = 0xffffffffu; misc[330] = 0; }   // (329 / 330: smallest / largest pre-scan key)
     __syncthreads();
 
     // ---- small batches (MULTI): a query's time is LATENCY — every ramp epoch of the walk below would wait out one
@@ -564,12 +564,19 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         }
     }
     STAMP(1);
-    auto prefetch = [&]() {
+    auto prefetch_fb = [&]() {                                   // the first block ...
         if constexpr (RES) {
             if (resident) {
                 const gvec_t src0 = (gvec_t)(uintptr_t)d_res.codes;
 #pragma unroll
                 for (int j = 0; j < (int)(kFirstBlock / kQWG); ++j) fb[j] = src0[j * kQWG + tid];
+            }
+        }
+    };
+    auto prefetch_cf = [&]() {                                   // ... and the first vectors of the workgroup's own chunk
+        if constexpr (RES) {
+            if (resident) {
+                const gvec_t src0 = (gvec_t)(uintptr_t)d_res.codes;
 #pragma unroll
                 for (int j = 0; j < (int)(kResident / kQWG); ++j) {
                     cf[j] = u32x4{0, 0, 0, 0};
@@ -623,6 +630,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         float* mytab = wtab + wave * (M * 16);
         const int sum_mode = A.sum_mode;                         // grouping of the float adds (qadc_float_sum.h)
         float lmin = FLT_MAX;
+        uint32_t kmn = 0xffffffffu, kmx = 0;                     // (small batches) smallest / largest key among this lane's pre-scan values
         const int pslot = (int)wave / wpp, sub = (int)wave % wpp;
         // The pre-scan is LATENCY, not work: a wave's round used to be a chain of dependent memory round trips — assign[a],
         // the partition descriptor, the probe's float table, then one 16-byte code load per 64 starts, each waited for before the
@@ -694,6 +702,12 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 sn = q_uni(cur.sn);
                 sc = reinterpret_cast<const uint8_t*>(q_uni64(reinterpret_cast<uint64_t>(cur.sc)));
                 if constexpr (RES) load_batch(i_first);          // (small batches only: the 64-register head kernels would spill)
+            }
+            // the first block's vectors (small batches): requested behind the first start vectors, so that these 64 KiB — ~1 K
+            // cycles of the CU's vector-memory issue — go out under the pre-scan's lookups, not after them (the own chunk's
+            // vectors follow after the pre-scan: all of them in registers across it would spill)
+            if (RES && a0 == 0) prefetch_fb();
+            if (active) {
                 q_wave_lds_sync();
 #pragma unroll
                 for (int k = 0; k < kTV; ++k) {
@@ -722,6 +736,11 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                     if (i < sn) {
                         if (in_lds) vals[base + i] = cand;
                         else gvals[base + i] = cand;
+                        if constexpr (RES) {
+                            const uint32_t k_ = q_fkey(cand);
+                            kmn = min(kmn, k_);
+                            kmx = max(kmx, k_);
+                        }
                     }
                 }
             }
@@ -742,10 +761,18 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 qtv0[u] = i < all ? ft_all[i] : 0.0f;
             }
         }
-        prefetch();                                              // in flight under the select and the quantizer
+        prefetch_cf();                                           // in flight under the select and the quantizer
         // qmin = min over ALL ma tables (db_query_4.cpp:258)
         lmin = q_wave_min(lmin);
         if (lane == 0) redf[wave] = lmin;
+        if constexpr (RES) {                                     // the keys' range, for the select's fitted digit (same barrier)
+            kmn = q_wave_scan_bits(kmn, 0xffffffffu, [](uint32_t a, uint32_t b) { return min(a, b); });
+            kmx = q_wave_scan_bits(kmx, 0u, [](uint32_t a, uint32_t b) { return max(a, b); });
+            if (lane == 63) {
+                atomicMin(&misc[329], kmn);
+                atomicMax(&misc[330], kmx);
+            }
+        }
         __threadfence_block();
         __syncthreads();
         qmin = redf[0];
@@ -858,18 +885,22 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
                 }
                 __syncthreads();
             } else {
-                if (tid == 0) { s_kmin = 0xffffffffu; s_kmax = 0; }      // (s_sel — the threshold's count — may still be being read)
-                if (tid < 256) hist[tid] = 0;
-                __syncthreads();
-                uint32_t mn = 0xffffffffu, mx = 0;
-                for_each_key([&](uint32_t key) { mn = min(mn, key); mx = max(mx, key); });
-                mn = q_wave_scan_bits(mn, 0xffffffffu, [](uint32_t a, uint32_t b) { return min(a, b); });
-                mx = q_wave_scan_bits(mx, 0u, [](uint32_t a, uint32_t b) { return max(a, b); });
-                if (lane == 63) {
-                    atomicMin(&s_kmin, mn);
-                    atomicMax(&s_kmax, mx);
+                // (small batches without a threshold cut: the pre-scan left the range of ALL keys in s_kmin / s_kmax, and the
+                // histogram's words are still clear from the kernel's entry: two barriers less)
+                if (!(RES && nlist == 0)) {
+                    if (tid == 0) { s_kmin = 0xffffffffu; s_kmax = 0; }      // (s_sel — the threshold's count — may still be being read)
+                    if (tid < 256) hist[tid] = 0;
+                    __syncthreads();
+                    uint32_t mn = 0xffffffffu, mx = 0;
+                    for_each_key([&](uint32_t key) { mn = min(mn, key); mx = max(mx, key); });
+                    mn = q_wave_scan_bits(mn, 0xffffffffu, [](uint32_t a, uint32_t b) { return min(a, b); });
+                    mx = q_wave_scan_bits(mx, 0u, [](uint32_t a, uint32_t b) { return max(a, b); });
+                    if (lane == 63) {
+                        atomicMin(&s_kmin, mn);
+                        atomicMax(&s_kmax, mx);
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
                 const uint32_t kmin = s_kmin, range = s_kmax - kmin;
                 const uint32_t sh = range >= 256u ? 24u - (uint32_t)__builtin_clz(range) : 0u;
                 for_each_key([&](uint32_t key) { atomicAdd(&hist[(key - kmin) >> sh], 1u); });
@@ -1046,7 +1077,8 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         if (tid < 256) hist[tid] = 0;                            // becomes the value histogram of the scan
         __syncthreads();
     } else {
-        prefetch();
+        prefetch_fb();
+        prefetch_cf();
         if (HEAD && A.front_in) {                                // the front ran on another rank: its verdict travels with the tables
             flags = A.front_in[4 * (size_t)q] & 3u;
             qmin = __uint_as_float(A.front_in[4 * (size_t)q + 1]);
