@@ -292,7 +292,17 @@ __device__ __forceinline__ uint32_t q_order_and_write(Load load, uint32_t ncand,
         if (tid < ncand) {
             const uint64_t mine = skey[tid];
             uint32_t rank = 0;
-            for (uint32_t j = 0; j < ncand; ++j) rank += skey[j] < mine ? 1u : 0u;   // same address in every lane: a broadcast read
+            // same address in every lane: broadcast reads.  Two keys per read, eight reads in flight (one key per iteration was one
+            // LDS round trip per key: ~100 cycles each, 3.5 K for a lone query's 35 candidates); the keys behind ncand are ~0: never smaller
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            const u64x2* s2 = reinterpret_cast<const u64x2*>(skey);
+            for (uint32_t j = 0; j < n2 / 2; j += 8) {
+                u64x2 kk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kk[u] = s2[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank += (kk[u].x < mine ? 1u : 0u) + (kk[u].y < mine ? 1u : 0u);
+            }
             sorted[rank] = mine;
         }
         q_lds_barrier();
