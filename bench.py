@@ -71,7 +71,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "quick-adc_amd"))
 # Kernel arguments in device memory (a HIP runtime setting, read when the runtime starts): a query kernel's first dependent reads —
 # its partition descriptors, and a lone small query's whole input, which rides in the kernel-argument segment — then come from HBM
-# instead of host memory over PCIe.  Synchronous single query: 54.9 -> 51.5 us on the same box (profiles/r06_latency_sweep.txt);
+# instead of host memory over PCIe.  Synchronous single query: 54.9 -> 51.5 us on the same box (profiles/r06_latency_sweep.txt;
+# the kernel-side work of round 6 took it on to 32 us: profiles/r06_lone_query_latency_ab.txt);
 # nothing else moves.  A serving process sets the same variable.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
