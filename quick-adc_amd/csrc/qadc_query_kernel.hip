@@ -516,6 +516,16 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     uint64_t* __restrict__ stream = A.stream + (size_t)wgi * A.cap;
     const uint32_t R = A.R;
 
+    // A lone query's input lies in the kernel-argument segment, which the host has just written: every first touch of one of its
+    // ~25 lines is a miss to memory (~2 K cycles), and the front touches them one dependent step at a time.  One load per lane
+    // over the whole payload, issued here and not waited for before the pre-scan is through, brings the lines in together.
+    uint32_t warm = 0;
+    if constexpr (MULTI && !HEAD) {
+        if (A.inline_input) {
+            const uint32_t words = (A.inline_off_tables + (uint32_t)ma * (uint32_t)(M * 16) * 4u) / 4u;
+            warm = reinterpret_cast<const uint32_t*>(A.assign)[min(tid * 8u, words - 1u)];   // (every 32 bytes: each 128-byte line four times)
+        }
+    }
     const uint64_t clk0 = __builtin_readcyclecounter();          // phase clocks (QueryOut::pad): 1/16 shader cycles
 #ifdef QADC_STAMPS
     uint64_t stamps[16];
@@ -758,6 +768,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
             cur = nxt;
         }
         STAMP(3);
+        if constexpr (RES) asm volatile("" ::"v"(warm));         // (the warm-up load's destination is live until here)
         // the quantizer's first kQB table entries per lane (all of them for up to 32 probes at 16x4): requested here, they
         // arrive under the select (they used to be waited for between the select and the quantizer: 2.4 K cycles for 256 floats)
         constexpr int kQB = 8;                                   // table entries in flight per lane (the clamp's store to the same
