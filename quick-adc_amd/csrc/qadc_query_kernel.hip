@@ -629,20 +629,25 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
         float* __restrict__ ft_all = A.ftables + tbase;
         // ---- 1. float pre-scan of the starts.  waves_per_probe waves share a probe when ma < 16. ----
         // total starts of the query decide where the values live (LDS, or the global scratch when there are many)
-        uint32_t mine = 0;
-        for (int a = tid; a < ma; a += kQWG) {
-            const PartDesc& d = parts[assign[a]];
-            mine += d.global_n ? d.start_n : 0u;
-        }
-        mine = q_wave_sum(mine);
-        if (lane == 0) wcnt[wave] = mine;
-        __syncthreads();
         uint32_t total_starts = 0;
+        if (RES && ma == 1) {                                    // a flat list: one descriptor, nothing to add up (two barriers less)
+            const PartDesc& d = parts[A.inline_input ? q : assign[0]];
+            total_starts = q_uni(d.global_n) ? q_uni(d.start_n) : 0u;
+        } else {
+            uint32_t mine = 0;
+            for (int a = tid; a < ma; a += kQWG) {
+                const PartDesc& d = parts[assign[a]];
+                mine += d.global_n ? d.start_n : 0u;
+            }
+            mine = q_wave_sum(mine);
+            if (lane == 0) wcnt[wave] = mine;
+            __syncthreads();
 #pragma unroll
-        for (int w = 0; w < kQWaves; ++w) total_starts += wcnt[w];
+            for (int w = 0; w < kQWaves; ++w) total_starts += wcnt[w];
+            __syncthreads();
+        }
         const bool in_lds = total_starts <= (uint32_t)C::FCAP;
         float* __restrict__ gvals = A.fvals + (size_t)wgi * A.fcap;
-        __syncthreads();
 
         STAMP(2);
         const int wpp = ma >= kQWaves ? 1 : kQWaves / ma;        // waves per probe
@@ -1095,8 +1100,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
             }
             return;
         }
-        if (tid < 256) hist[tid] = 0;                            // becomes the value histogram of the scan
-        __syncthreads();
+        // (the select's histogram words become the scan's value histograms: cleared with the rest of them below)
     } else {
         prefetch_fb();
         prefetch_cf();
