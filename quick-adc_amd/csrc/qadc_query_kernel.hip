@@ -7,7 +7,9 @@
 // than the scan.  Here a query belongs to one 1024-thread workgroup that walks the query's scan order itself:
 //
 //   1. float pre-scan of the probed partitions' starts (scan_4<M>, query_common.hpp:59-90; same add order) into
-//      LDS, R-th smallest by a 4-pass radix select in LDS  -> qmax            (db_query_4.cpp:230-242, 259)
+//      LDS, R-th smallest by one histogram pass over a digit fitted to the keys + a ranking of the chosen bucket (a
+//      threshold cut first when there are thousands of values; four fixed-digit passes when a bucket overflows)
+//      -> qmax                                                                (db_query_4.cpp:230-242, 259)
 //   2. qmin over all ma tables, negative clamp, QuantizerMAX<int8_t>           (db_query_4.cpp:37-71, 258-284)
 //   3. int8 scan of every probed partition in assign[] order                   (simd_scan.hpp:125-187):
 //      pair-fused 256-entry byte tables in LDS, bank-replicated so that any code data reads conflict-free,
@@ -26,7 +28,9 @@
 // (the finished epochs), DESIGN.md section 4.
 //
 // Variants of the same kernel: MULTI (a small batch spreads each query over G workgroups, which share the first
-// block of the scan order for their bound) and HEAD (the first launch of the level-structured path).  gfx950 only.
+// block of the scan order for their bound — walked in ONE step from registers, workgroup 0 writing its candidates
+// straight into the stream: see "the first block in ONE step" below) and HEAD (the first launch of the
+// level-structured path, and the head of a partition-major IVF batch).  gfx950 only.
 #include "qadc_kernels.h"
 #include "qadc_float_sum.h"
 
