@@ -135,8 +135,8 @@ uint32_t qadc_index_start_size(const qadc_index* idx, int part);
  *                            bound levels, the small-run kernel's limit, the unfiltered part of the pre-scan
  *  replay      "device_replay_nq" / "device_replay_alone_nq"  batches of at least this many queries replay their streams on the
  *                            device (0 = never) / the same for a batch with nothing else in flight (a synchronous call)
- *  query path  "wgq_split" / "wgq_split_codes"  workgroups a small batch spreads one query over (default 32) / codes each keeps at
- *                            least (2048)
+ *  query path  "wgq_split" / "wgq_split_codes"  workgroups a call of one or two queries spreads each over (default 32) / codes each
+ *                            keeps at least (2048); small batches of three or more queries: at most 12, four times the codes
  *              "wgq_capacity" / "wgq_cand_cap"  stream entries per query to start with / candidates per query before a batch falls
  *                            back to the level path
  *  multi-GPU   "dist_cap_entries", "dist_device_nq", "dist_shard_replay" (an enqueued merge replays only this rank's share of the

@@ -474,7 +474,7 @@ int plan_and_launch(qadc_index* idx, Slot& s) {
         H.cand_cap = s.cap_q;
         H.hdr = s.d_hdr;
         H.nontemporal = 0;                                   // the queries of a batch share the head of a flat list through L2
-        int G = std::min<int>(idx->wgq_split, std::max(1, 256 / nq));
+        int G = std::min<int>(nq <= 2 ? idx->wgq_split : std::min(idx->wgq_split, kSplitBatch), std::max(1, 256 / nq));   // (as launch_wgq_batch)
         G = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)G, s.head_codes / 16384));
         H.G = G;
         HIPCHECK(launch_scan_query(M, nq, H, str));

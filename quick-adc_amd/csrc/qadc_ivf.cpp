@@ -71,8 +71,14 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     // the query's first block, then scans its own chunk); the sub-streams are concatenated in workgroup order.
     int G = 1;
     if (!s.dev_replay && nq * 2 <= 256) {
-        G = std::min<int>(idx->wgq_split, 256 / nq);
-        G = (int)std::min<uint64_t>((uint64_t)G, s.wgq_codes / idx->wgq_split_codes);   // at least wgq_split_codes codes per workgroup
+        // A query or two have the GPU to themselves and latency decides: up to wgq_split (32) workgroups each, down to
+        // wgq_split_codes (2048) codes per workgroup — 10^5 codes, one query: 12 workgroups 36.1 us, 32: 32.6.  From three queries
+        // on every further workgroup repeats a front for a shorter chunk while the host's replay of the queries, one after the
+        // other, sets the call's time: at most kSplitBatch workgroups per query, four times the codes each (same box, 10^5 codes,
+        // 32 against 12 workgroups: 2 queries 35.8 / 37.0 us, 4: 52.9 / 50.0, 8: 71 / 67, 16: 122 / 97)
+        const bool few = nq <= 2;
+        G = std::min<int>(few ? idx->wgq_split : std::min(idx->wgq_split, kSplitBatch), 256 / nq);
+        G = (int)std::min<uint64_t>((uint64_t)G, s.wgq_codes / ((uint64_t)idx->wgq_split_codes * (few ? 1u : 4u)));
         G = std::max(G, 1);
     }
     s.wgq_G = G;

@@ -14,6 +14,7 @@ opts = dict(kv.split("=") for kv in sys.argv[2:])                # e.g. wgq_spli
 if "lib" in opts:                                                # lib=r06base: a library built from another commit, next to the shipped one
     pyqadc.LIB_PATH = os.path.join(ROOT, "quick-adc_amd", "libqadc_hip_%s.so" % opts.pop("lib"))
 K, ma = int(opts.pop("K", 1)), int(opts.pop("ma", 1))
+nq = int(opts.pop("nq", 1))                                     # a small synchronous batch instead of the lone query
 reps = int(opts.pop("reps", 420))                                # (lib=stamps reps=23: the phase stamps of three timed calls)            # n codes in K equal partitions, ma of them probed
 M, R = 16, 100
 idx = pyqadc.Index(M, 0)
@@ -24,11 +25,11 @@ for k_, v_ in opts.items():
     idx.set_option(k_, float(v_))
 rng = np.random.default_rng(0)
 cb = rng.normal(size=(M, 16, 8)).astype(np.float32)
-tb = bench.make_tables(rng, cb, ma)
-a = rng.permutation(K)[:ma].astype(np.int32).reshape(1, ma)
-keys, vals = np.zeros((1, R), np.uint32), np.zeros((1, R), np.int8)
-sizes, status = np.zeros(1, np.int32), np.zeros(1, np.int32)
-qmin, qmax = np.zeros(1, np.float32), np.zeros(1, np.float32)
+tb = bench.make_tables(rng, cb, ma * nq)
+a = np.stack([rng.permutation(K)[:ma] for _ in range(nq)]).astype(np.int32).reshape(nq, ma)
+keys, vals = np.zeros((nq, R), np.uint32), np.zeros((nq, R), np.int8)
+sizes, status = np.zeros(nq, np.int32), np.zeros(nq, np.int32)
+qmin, qmax = np.zeros(nq, np.float32), np.zeros(nq, np.float32)
 P = pyqadc._p
 fixed = (P(keys, pyqadc.u32p), P(vals, pyqadc.i8p), P(sizes, pyqadc.i32p), P(status, pyqadc.i32p),
          P(qmin, pyqadc.f32p), P(qmax, pyqadc.f32p), None)
@@ -41,7 +42,7 @@ for i in range(reps):
     if i == 20:
         idx.profile_reset()
     t0 = time.perf_counter()
-    rc = fn(h, 1, ma, pa, ptrs[i], R, *fixed)
+    rc = fn(h, nq, ma, pa, ptrs[i], R, *fixed)
     t1 = time.perf_counter()
     assert rc == 0 and status[0] == 0 and sizes[0] == R
     if i >= 20:
@@ -50,6 +51,6 @@ pr = idx.profile()
 idx.close()
 ts = np.sort(np.array(ts)) * 1e6
 k = reps - 20
-print(opts, "K=%d ma=%d" % (K, ma), "codes %d: median %.1f us  p10 %.1f  p90 %.1f;  host timers per call: submit (plan + launch) %.2f us, stream assembly %.2f us, "
+print(opts, "K=%d ma=%d nq=%d" % (K, ma, nq), "codes %d: median %.1f us  p10 %.1f  p90 %.1f;  host timers per call: submit (plan + launch) %.2f us, stream assembly %.2f us, "
       "heap replay %.2f us; stream entries per query %.0f" % (n, np.median(ts), ts[len(ts) // 10], ts[len(ts) * 9 // 10],
       pr["host_plan_ms"] * 1e3 / k, pr["host_replay_ms"] * 1e3 / k, pr["host_heap_ms"] * 1e3 / k, pr["candidates"] / k))
