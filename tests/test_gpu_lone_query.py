@@ -116,3 +116,22 @@ def test_workgroups_per_query(pyqadc, po):
         idx.set_option("wgq_split_codes", codes)
         check(idx, po, M, parts, labels, 0.01, a, tb, 100)
     idx.close()
+
+
+@path_independent
+@pytest.mark.parametrize("M", [16, 32])
+def test_int8_tables_in(pyqadc, po, M):
+    """The caller's int8 tables (qadc_scan_i8: no front in the kernel; the one-step first block stages the table itself), one
+    and two queries per call, list lengths around the first block, small and saturating table entries."""
+    from helpers import rand_qtables
+    nc = 4096 * (32 // M)
+    for n in (nc, nc + 1, 3 * nc + 5, 120001):
+        rng, parts, labels, idx = make(pyqadc, M, [n], 0.01, n % 2 == 1, 3 + n, wgq_split_codes=1024)
+        for nq in (1, 2):
+            for tmax, R in ((3, 10), (12, 100), (127, 100), (40, 1)):
+                qt = rand_qtables(rng, (nq, 1), M, tmax)
+                got = idx.scan_i8(np.zeros((nq, 1), np.int32), qt, R)
+                for q in range(nq):
+                    want = po.scan_i8(M, parts, labels, qt[q], R)
+                    assert heaps_equal(got[q], want), (M, n, nq, tmax, R, q)
+        idx.close()
