@@ -186,6 +186,7 @@ struct Slot {
     bool dist_batch = false;            // launched with the native multi-GPU merge active: streams kept in device memory
     uint32_t wgq_cap = 0;               // stream entries per query workgroup (regrown on overflow)
     bool poll = false;                  // collect watches the workgroups' done bits instead of the completion event
+    bool appended = false;              // ... and appended the sub-streams to out_entries as they finished (no copy left to do)
     bool ev_valid = false;              // ev_done was recorded behind this batch's launches (not for a polled batch)
     int wgq_G = 1;                      // workgroups per query (small batches: the scan order of a query is split)
     uint64_t wgq_codes = 0;             // codes a query probes (exact maximum, or an estimate) — sizes wgq_G
