@@ -659,7 +659,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
     }
     for (int attempt = 0; s.wgq; ++attempt) {                  // one workgroup per query: per-query stream capacity only
         bool seen = false;
-        s.appended = false;
+        s.appended = s.replayed = false;
         if (s.poll) {
             // a lone small batch: the kernel's workgroups set the done bit of their records in the mapped result block as
             // they finish; watching those spares the completion-signal path (end-of-kernel release, signal, wake-up).
@@ -672,8 +672,17 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
             const int nsub = s.nq * s.wgq_G;
             if (s.out_entries.size() < (size_t)nsub * s.wgq_cap) s.out_entries.resize((size_t)nsub * s.wgq_cap);
             int next = 0;
-            size_t filled = 0;
+            size_t filled = 0, pushed = 0;
             bool appended = true;                                // (false: some sub-stream overflowed — sorted out below, nothing appended counts)
+            // ... and a lone query whose caller wants the heap only (the synchronous query_scan) is replayed as it arrives: the
+            // reference's pushes of the first workgroups' entries — kv_binheap::push, binheap.hpp:75-116, after the (0,127)
+            // sentinel of db_query_4.cpp:276 — run while the last workgroups finish
+            const bool replay_now = s.nq == 1 && !need_stream;
+            if (replay_now) {
+                if (s.early_heap.capacity() != s.R) s.early_heap.reset_capacity(s.R);
+                s.early_heap.reset();
+                s.early_heap.push(0, 127);
+            }
             for (uint32_t spins = 0; !seen; ++spins) {
                 while (next < nsub && (reinterpret_cast<const volatile uint32_t*>(&s.h_qout[next].flags)[0] & 4u) != 0) {
                     std::atomic_thread_fence(std::memory_order_acquire);
@@ -685,6 +694,13 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
                     }
                     ++next;
                 }
+                // (pushes only while nothing waits to be appended: the copies are the misses and go first — with the pushes in
+                // front of them the call was 3-7 us SLOWER than without any early replay, same box)
+                if (replay_now && appended && next < nsub) {
+                    const uint64_t* e_ = s.out_entries.data();
+                    for (const size_t stop = std::min(filled, pushed + 32); pushed < stop; ++pushed)
+                        s.early_heap.push((uint32_t)e_[pushed], (int8_t)(e_[pushed] >> 32));
+                }
                 seen = next == nsub;
                 if (!seen && (spins & 63u) == 63u &&
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count() > 300e-6)
@@ -692,6 +708,11 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
             }
             std::atomic_thread_fence(std::memory_order_acquire);
             s.appended = seen && appended;
+            s.replayed = s.appended && replay_now;
+            if (s.replayed) {
+                const uint64_t* e_ = s.out_entries.data();
+                for (; pushed < filled; ++pushed) s.early_heap.push((uint32_t)e_[pushed], (int8_t)(e_[pushed] >> 32));
+            }
         }
         if (!seen) {
             if (s.ev_valid) HIPCHECK(hipEventSynchronize(s.ev_done));
@@ -910,7 +931,7 @@ int collect_common(qadc_index* idx, int slot_i, bool need_stream, bool from_dist
                     }
                 }
             };
-            int nt = (int)std::min<unsigned>(std::thread::hardware_concurrency(), 8);
+            int nt = (int)std::min<unsigned>(host_threads(), 8);
             nt = std::max(1, std::min(nt, s.nq / 2));
             if (total < 16384) nt = 1;
             const int per = std::max(1, s.nq / (nt * 4));
@@ -1009,6 +1030,12 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
                 }
                 continue;
             }
+            if (s.replayed && s.wgq && s.wgq_G > 1) {            // a lone polled query: replayed while it arrived (collect_common)
+                if (sizes) sizes[q] = s.early_heap.size();
+                if (keys) std::memcpy(keys + (size_t)q * s.R, s.early_heap.keys(), sizeof(uint32_t) * s.early_heap.size());
+                if (values) std::memcpy(values + (size_t)q * s.R, s.early_heap.values(), s.early_heap.size());
+                continue;
+            }
             bh.push(0, 127);  // db_query_4.cpp:276
             for (uint64_t i = s.out_off[q]; i < s.out_off[q + 1]; ++i)
                 bh.push((uint32_t)s.out_entries[i], (int8_t)(s.out_entries[i] >> 32));
@@ -1020,7 +1047,7 @@ int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int
     // queries are independent: large batches (IVF) are replayed by a few host threads, the caller still
     // drives the library from one thread
     const uint64_t pushes = s.out_off[s.nq];
-    int nt = (int)std::min<unsigned>(std::thread::hardware_concurrency(), 16);   // (10M-code list, 32 queries per step: 8 -> 16 threads 0.260 -> 0.231 ms per step)
+    int nt = (int)std::min<unsigned>(host_threads(), 16);   // (10M-code list, 32 queries per step: 8 -> 16 threads 0.260 -> 0.231 ms per step)
     nt = std::max(1, std::min(nt, s.nq / 2));
     if (pushes < 4000) nt = 1;                                 // (waking the workers costs about as much as 4 K pushes)
     // tasks of a few queries each, handed out dynamically: candidate counts differ from query to query

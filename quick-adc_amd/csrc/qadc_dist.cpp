@@ -241,7 +241,7 @@ int qadc_merge_streams_i8(int world, int nq, int R, uint64_t cap, int ma, const 
             std::memcpy(vals + (size_t)q * R, bh.values(), bh.size());
         }
     };
-    const size_t nt = std::min<size_t>(std::min<size_t>(mine.size(), 4), std::max<unsigned>(std::thread::hardware_concurrency(), 1));
+    const size_t nt = std::min<size_t>(std::min<size_t>(mine.size(), 4), std::max<unsigned>(host_threads(), 1));
     if (nt <= 1) {
         work(0, mine.size());
     } else {
@@ -290,7 +290,7 @@ void replay_my_share(const uint64_t* gathered, size_t bw, int world, int rank, i
             o[R] = (uint64_t)bh.size();
         }
     };
-    const int nt = std::max(1, std::min<int>(std::min(per, 8), (int)std::thread::hardware_concurrency()));
+    const int nt = std::max(1, std::min<int>(std::min(per, 8), (int)host_threads()));
     if (nt == 1 || !pool) {
         work(0, per);
     } else {

@@ -187,6 +187,8 @@ struct Slot {
     uint32_t wgq_cap = 0;               // stream entries per query workgroup (regrown on overflow)
     bool poll = false;                  // collect watches the workgroups' done bits instead of the completion event
     bool appended = false;              // ... and appended the sub-streams to out_entries as they finished (no copy left to do)
+    bool replayed = false;              // ... and pushed a lone query's entries through early_heap as they arrived (replay_outputs takes it)
+    kv_heap<uint32_t, int8_t> early_heap;
     bool ev_valid = false;              // ev_done was recorded behind this batch's launches (not for a polled batch)
     int wgq_G = 1;                      // workgroups per query (small batches: the scan order of a query is split)
     uint64_t wgq_codes = 0;             // codes a query probes (exact maximum, or an estimate) — sizes wgq_G
@@ -436,6 +438,13 @@ struct qadc_index {
 
 namespace qadc {
 namespace host {
+
+// std::thread::hardware_concurrency() asks the kernel on every call (sched_getaffinity: ~1 us — a thirtieth of a lone query's call,
+// twice per call); the host's thread count does not change under the library
+inline unsigned host_threads() {
+    static const unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    return n;
+}
 
 struct ScopedMs {
     double& acc;
