@@ -353,7 +353,8 @@ constexpr uint64_t kFrontMinBatch = 3000000000ull; // leading levels join the fr
                                                    // pairs: under a shorter last level they only make the front stream the step's longest chain
 constexpr int kWgqMinNq = 128;                     // query-kernel path, auto: batches of at least this many queries ...
 constexpr uint64_t kWgqMaxCodes = 1ull << 24;      //   ... probing at most this many codes per query, or
-constexpr uint64_t kWgqSmallCodes = 1ull << 18;    //   any batch probing at most this many codes per query
+constexpr uint64_t kWgqSmallCodes = 1ull << 18;    //   any batch probing at most this many codes per query, or
+constexpr uint64_t kWgqLoneCodes = 6ull << 20;     //   a call of one or two queries probing at most this many each
 constexpr uint32_t kGroupBytesPerWg = 131072;      // partition-major phase: bytes of the longest partition's codes per workgroup of a group
 constexpr int kSplitBatch = 12;                    // workgroups per query of a small batch of three or more queries (one or two: option "wgq_split")
 constexpr int kShareLag = 1;                       // multi-GPU: a merge's heap-share gather is issued behind the first gather of the next merge

@@ -23,6 +23,11 @@ bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64
     if (idx->wgq == 0 || mode != 0 || ma > 4096 || R <= 0) return false;
     if (idx->wgq >= 2) return true;
     if (codes_per_query <= kWgqSmallCodes) return true;
+    // a synchronous query or two on a longer list: the level path answers with a dependent chain of ~10 launches (front, head, two
+    // or three levels, sort), the query kernel with ONE launch of 32 workgroups per query whose chunks refresh their bounds as they
+    // go.  Same box, one query, flat list (profiles/r06_lone_query_latency_ab.txt): 3 x 10^5 codes 105 -> 38 us, 10^6 138 -> 63,
+    // 2 x 10^6 148 -> 82, 4 x 10^6 163 -> 122, 6 x 10^6 177 -> 151; at 10^7 the level path is ahead again (203 against 224)
+    if (nq <= 2 && codes_per_query <= kWgqLoneCodes) return true;
     // an IVF batch (several partitions, several probes per query: the queries walk different codes) — the query kernel is
     // ahead of the level path at every batch size (C3 shape, synchronous: 1 query 217 -> 175 us, 64 queries 0.85 -> 0.73 ms)
     if (ma > 1 && idx->parts.size() > 1 && codes_per_query <= kWgqMaxCodes) return true;

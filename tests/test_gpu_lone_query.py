@@ -135,3 +135,15 @@ def test_int8_tables_in(pyqadc, po, M):
                     want = po.scan_i8(M, parts, labels, qt[q], R)
                     assert heaps_equal(got[q], want), (M, n, nq, tmax, R, q)
         idx.close()
+
+
+@path_independent
+def test_lone_query_on_a_long_flat_list(pyqadc, po):
+    """One or two queries on 1.5 M codes: by default the query kernel's 32 workgroups per query (chunks of ~47 K codes that refresh
+    their bounds epoch by epoch), not the level path's chain of launches; three queries take the level path.  Same answers."""
+    M, n = 16, 1500003
+    rng, parts, labels, idx = make(pyqadc, M, [n], 0.01, True, 123)
+    for nq in (1, 2, 3):
+        tb = float_tables(rng, nq, 1, M)
+        check(idx, po, M, parts, labels, 0.01, np.zeros((nq, 1), np.int32), tb, 100)
+    idx.close()
