@@ -453,6 +453,8 @@ typedef struct qadc_profile {
     uint64_t group_batches;    /* batches the above figures cover */
     uint64_t front_sharded_batches; /* multi-GPU: qadc_search batches whose front ran on 1/world of the queries per rank */
     uint64_t dist_async_collects;   /* multi-GPU: qadc_dist_collect calls served by a merge enqueued with the batch (one event wait) */
+    uint64_t lone_front_launches;   /* lone queries on one long partition whose front ran sliced over workgroups, in a launch of its own
+                                       in front of the walk (counted with or without "profile") */
 } qadc_profile;
 
 int qadc_profile_read(qadc_index* idx, qadc_profile* out);

@@ -605,7 +605,12 @@ int submit_common(qadc_index* idx, int slot_i, int nq, int ma, const int32_t* as
             }
             max_codes = std::max(max_codes, c);
         }
-        s.wgq = wgq_eligible(idx, nq, ma, R, mode, max_codes);
+        // (the rules for a LONE call of one or two queries hold when nothing else is in flight: a caller that pipelines single
+        // queries over the slots gets them overlapped by the level path, not serialised on the query kernel's one stream)
+        bool alone = mode == 0;
+        for (int i = 0; i < kSlots; ++i) alone = alone && (&idx->slot[i] == &s || !idx->slot[i].busy);
+        alone = alone && !idx->pre_slot[0].busy && !idx->pre_slot[1].busy;
+        s.wgq = wgq_eligible(idx, nq, ma, R, mode, max_codes, tables != nullptr, alone);
         s.wgq_codes = max_codes;
     }
     if (s.wgq) s.wgq_cap = std::max<uint32_t>(s.wgq_cap, idx->wgq_capacity);
@@ -1339,7 +1344,7 @@ int qadc_index_destroy(qadc_index* idx) {
     for (Slot* sp : all_slots) {
         Slot& s = *sp;
         s.d_in.release(); s.h_in.release(); s.d_state.release(); s.h_result.release();
-        s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release();
+        s.d_ftables.release(); s.d_qtables.release(); s.d_cands.release(); s.d_fc.release(); s.d_lfstate.release();
         s.h_cands.release(); s.d_stream.release(); s.d_qflags.release(); s.d_fvals.release(); s.d_qcands.release(); s.h_fetch.release();
         s.d_fblock.release(); s.d_fgathered.release(); s.d_front_all.release(); s.h_fmap.release();
         if (s.ev_fa) (void)hipEventDestroy(s.ev_fa);

@@ -197,6 +197,7 @@ struct Slot {
     DevBuf<uint32_t> d_qflags;          // [nq][4]: {flags, entries} for replay_heap_wave_kernel
     DevBuf<float> d_fvals;
     DevBuf<QCand> d_qcands;             // unordered candidates of the query workgroups (scratch)
+    DevBuf<uint32_t> d_lfstate;         // sliced front of a lone query (lone_front_kernel): counter + the slices' smallest keys
     PinBuf<uint64_t> h_fetch;           // streams fetched on demand when they were left in device memory
     bool assign_on_device = false;      // qadc_search: assign[] was produced on the GPU and copied back asynchronously
     hipEvent_t ev_assign = nullptr;
@@ -354,8 +355,10 @@ constexpr uint64_t kFrontMinBatch = 3000000000ull; // leading levels join the fr
 constexpr int kWgqMinNq = 128;                     // query-kernel path, auto: batches of at least this many queries ...
 constexpr uint64_t kWgqMaxCodes = 1ull << 24;      //   ... probing at most this many codes per query, or
 constexpr uint64_t kWgqSmallCodes = 1ull << 18;    //   any batch probing at most this many codes per query, or
-constexpr uint64_t kWgqLoneCodes = 6ull << 20;     //   a call of one or two queries probing at most this many each
+constexpr uint64_t kWgqLoneCodes = 6ull << 20;     //   a call of one or two queries probing at most this many each, or
+constexpr uint64_t kWgqLoneSlicedCodes = 24ull << 20;   //   ONE query on one partition of at most this many codes whose front can be sliced
 constexpr uint32_t kGroupBytesPerWg = 131072;      // partition-major phase: bytes of the longest partition's codes per workgroup of a group
+constexpr int kMaxSplit = 64;                      // most workgroups a query is spread over (option "wgq_split" is clamped to it)
 constexpr int kSplitBatch = 12;                    // workgroups per query of a small batch of three or more queries (one or two: option "wgq_split")
 constexpr int kShareLag = 1;                       // multi-GPU: a merge's heap-share gather is issued behind the first gather of the next merge
 
@@ -463,7 +466,9 @@ void finish_float_outputs(qadc_index* idx, Slot& s, int32_t* status, float* qmin
 int replay_outputs(qadc_index* idx, Slot& s, uint32_t* keys, int8_t* values, int32_t* sizes, const int32_t* status);
 // qadc_ivf.cpp
 int table_expansion(const qadc_index* idx, int ma);
-bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64_t codes_per_query);
+bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64_t codes_per_query, bool host_float_tables = false,
+                  bool alone = false);
+uint32_t lone_front_slices(uint32_t starts, int R);
 bool will_group(const qadc_index* idx, int nq, int ma, bool dev_replay);
 int launch_wgq_batch(qadc_index* idx, Slot& s);
 int search_submit(qadc_index* idx, int slot_i, int nq, const float* queries, int ma, int R);

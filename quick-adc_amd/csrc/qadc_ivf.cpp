@@ -19,7 +19,14 @@ int table_expansion(const qadc_index* idx, int ma) {
 
 // Decides whether a batch takes the one-workgroup-per-query path.  codes_per_query: exact maximum when the host
 // knows assign[], an estimate (ma x mean partition size) when assign[] is produced on the GPU.
-bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64_t codes_per_query) {
+// Slices of the sliced front (lone_front_kernel) for a lone query whose one probed partition has `starts` start codes; 0 = it does
+// not apply (a single slice: the walk's own front does as well; more than 64 slices or S x R keys beyond what the last workgroup ranks)
+uint32_t lone_front_slices(uint32_t starts, int R) {
+    const uint32_t S = (starts + kLoneFrontSlice - 1) / kLoneFrontSlice;
+    return S >= 2 && S <= 64 && (uint64_t)S * (uint64_t)R <= (uint64_t)kLoneFrontMaxKeys && R <= kLoneFrontSlice ? S : 0u;
+}
+
+bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64_t codes_per_query, bool host_float_tables, bool alone) {
     if (idx->wgq == 0 || mode != 0 || ma > 4096 || R <= 0) return false;
     if (idx->wgq >= 2) return true;
     if (codes_per_query <= kWgqSmallCodes) return true;
@@ -27,7 +34,13 @@ bool wgq_eligible(const qadc_index* idx, int nq, int ma, int R, int mode, uint64
     // or three levels, sort), the query kernel with ONE launch of 32 workgroups per query whose chunks refresh their bounds as they
     // go.  Same box, one query, flat list (profiles/r06_lone_query_latency_ab.txt): 3 x 10^5 codes 105 -> 38 us, 10^6 138 -> 63,
     // 2 x 10^6 148 -> 82, 4 x 10^6 163 -> 122, 6 x 10^6 177 -> 151; at 10^7 the level path is ahead again (203 against 224)
-    if (nq <= 2 && codes_per_query <= kWgqLoneCodes) return true;
+    if (alone && nq <= 2 && codes_per_query <= kWgqLoneCodes) return true;
+    // ... and ONE query on one long partition, float tables from the caller: with the front sliced over workgroups of its own in a
+    // launch in front of the walk (lone_front_kernel) the query kernel stays ahead of the level path far beyond that — same box:
+    // 10^7 codes 203 -> 136 us (BASELINE configs[1], a synchronous query_scan), 2 x 10^7 229 -> 198
+    if (alone && nq == 1 && ma == 1 && host_float_tables && !idx->dist && !idx->profile && codes_per_query <= kWgqLoneSlicedCodes &&
+        lone_front_slices((uint32_t)std::max(1.0f, (float)codes_per_query * idx->keep), R))
+        return true;
     // an IVF batch (several partitions, several probes per query: the queries walk different codes) — the query kernel is
     // ahead of the level path at every batch size (C3 shape, synchronous: 1 query 217 -> 175 us, 64 queries 0.85 -> 0.73 ms)
     if (ma > 1 && idx->parts.size() > 1 && codes_per_query <= kWgqMaxCodes) return true;
@@ -82,7 +95,10 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         // other, sets the call's time: at most kSplitBatch workgroups per query, four times the codes each (same box, 10^5 codes,
         // 32 against 12 workgroups: 2 queries 35.8 / 37.0 us, 4: 52.9 / 50.0, 8: 71 / 67, 16: 122 / 97)
         const bool few = nq <= 2;
-        G = std::min<int>(few ? idx->wgq_split : std::min(idx->wgq_split, kSplitBatch), 256 / nq);
+        // (from 16 Mi codes on the walk outweighs what further workgroups repeat — with the front sliced off: 2 x 10^7 codes 194 -> 163 us
+        //  at 64 workgroups, 2.5 x 10^7 220 -> 179; below, 32 and 64 are within 5 % of each other either way)
+        const int split = few && s.wgq_codes >= (16ull << 20) ? std::min(2 * idx->wgq_split, kMaxSplit) : idx->wgq_split;
+        G = std::min<int>(few ? split : std::min(idx->wgq_split, kSplitBatch), 256 / nq);
         G = (int)std::min<uint64_t>((uint64_t)G, s.wgq_codes / ((uint64_t)idx->wgq_split_codes * (few ? 1u : 4u)));
         G = std::max(G, 1);
     }
@@ -137,20 +153,27 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
     // float tables — fits the kernel-argument segment and rides in the dispatch packet; no copy precedes the launch.
     alignas(16) unsigned char inl[kInlineBytes];
     size_t inl_bytes = 0, inl_off_parts = 0, inl_off_tables = 0;
+    // The sliced front (lone_front_kernel): a lone query on ONE long partition whose starts fill at least two slices.  Its walk
+    // launch then carries no float tables (the int8 table and {flags, qmin, qmax} come from the front launch in front of it).
+    uint32_t lf_slices = 0;
+    if (alone && G > 1 && nq == 1 && ma == 1 && s.float_path && !s.device_tables && !s.assign_on_device && !idx->profile && !s.dev_replay) {
+        lf_slices = lone_front_slices(idx->parts[s.assign[0]].start_n, s.R);
+    }
     if (alone && G > 1 && s.float_path && !s.device_tables && !s.assign_on_device) {
         const size_t na = (size_t)nq * ma;
         inl_off_parts = align16(sizeof(int32_t) * na);
-        inl_off_tables = align16(inl_off_parts + sizeof(PartDesc) * na);
-        const size_t total = inl_off_tables + nt * sizeof(float);
+        inl_off_tables = lf_slices ? 0 : align16(inl_off_parts + sizeof(PartDesc) * na);
+        const size_t total = lf_slices ? inl_off_parts + sizeof(PartDesc) * na : inl_off_tables + nt * sizeof(float);
         if (total <= kInlineBytes) {
             for (size_t i = 0; i < na; ++i) {
                 reinterpret_cast<int32_t*>(inl)[i] = (int32_t)i;
                 std::memcpy(inl + inl_off_parts + sizeof(PartDesc) * i, &idx->h_partdesc[s.assign[i]], sizeof(PartDesc));
             }
-            std::memcpy(inl + inl_off_tables, s.tables, nt * sizeof(float));
+            if (!lf_slices) std::memcpy(inl + inl_off_tables, s.tables, nt * sizeof(float));
             inl_bytes = total;
         }
     }
+    if (lf_slices && !inl_bytes) lf_slices = 0;
     if (!inl_bytes) fill_upload();                               // (an inline query's input rides in the dispatch packet instead)
     if (in_bytes && !inl_bytes) {
         if (alone) {
@@ -358,6 +381,30 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
         }
         if (flush_later)
             if (int rc = flush_merges(idx, ~0ull)) return rc;
+        if (lf_slices) {
+            const size_t words = 4 + (size_t)kLoneFrontMaxKeys;
+            if (words > s.d_lfstate.cap) {
+                HIPCHECK(s.d_lfstate.ensure(words));
+                HIPCHECK(hipMemset(s.d_lfstate.p, 0, words * sizeof(uint32_t)));   // (the counter: every front leaves it at zero again)
+            }
+            HIPCHECK(s.d_front_all.ensure(4));
+            LoneFrontArgs F{};
+            F.part = idx->d_partdesc.p + s.assign[0];
+            F.R = (uint32_t)s.R;
+            F.S = lf_slices;
+            F.quant_mode = idx->quant_mode;
+            F.sum_mode = idx->sum_mode;
+            F.state = s.d_lfstate.p;
+            F.qtables = s.d_qtables.p;
+            F.front_out = s.d_front_all.p;
+            std::memcpy(F.table, s.tables, (size_t)M * 16 * sizeof(float));
+            HIPCHECK(launch_lone_front(M, F, st));
+            idx->prof.lone_front_launches++;
+            A.ftables = nullptr;                                 // the walk: an int8 query whose verdict comes from the front launch
+            A.qtables = s.d_qtables.p;
+            A.front_in = s.d_front_all.p;
+            s.d_qt = s.d_qtables.p;
+        }
         HIPCHECK(launch_scan_query(M, nq, A, st, inl_bytes ? inl : nullptr, inl_bytes));
     }
     if (idx->profile) HIPCHECK(prof_event(s, st));

@@ -156,6 +156,27 @@ struct QueryKernelInline {
     alignas(16) unsigned char payload[kInlineBytes];
 };
 
+// ---- the sliced front of a lone query on a LONG flat list (lone_front_kernel, qadc_query_kernel.hip) ----
+// Every workgroup of a split query repeats the front, and the front grows with the list (keep x codes starts: 40 K on 4 x 10^6
+// codes at 1 %): on long lists it, not the walk and not the host's replay, sets the call's time (profiles/
+// r06_lone_query_latency_ab.txt).  Here S workgroups pre-scan one slice of the starts each (scan_4<M>, query_common.hpp:59-90,
+// same grouping of the adds) and leave the slice's R smallest values behind; the workgroup that finishes LAST (a counter —
+// nobody waits) takes the R-th smallest of their union — which IS the R-th smallest of all starts, db_query_4.cpp:259 —,
+// qmin, the clamp and QuantizerMAX (db_query_4.cpp:258-284, 37-71) and writes the int8 table and {flags, qmin, qmax} for the walk
+// launch behind it (QueryKernelArgs::front_in).  One probed partition (a flat list).
+constexpr int kLoneFrontSlice = 4096;           // start values per slice (one bitonic sort in LDS)
+constexpr int kLoneFrontMaxKeys = 8192;         // S x R keys the last workgroup sorts
+struct LoneFrontArgs {
+    const PartDesc* part;                       // the probed partition (device partition table entry)
+    uint32_t R, S;                              // top-R; slices = workgroups
+    int quant_mode, sum_mode;
+    uint32_t* state;                            // [0] counter (left at 0), [4 ...] keys[S][R]
+    int8_t* qtables;                            // out: [M*16]
+    uint32_t* front_out;                        // out: {flags & 3, qmin, qmax, 0}
+    alignas(16) float table[32 * 16];           // the query's float table, in the kernel-argument segment
+};
+hipError_t launch_lone_front(int M, const LoneFrontArgs& args, hipStream_t stream);
+
 uint32_t query_kernel_lds_values(int M);       // pre-scan values a query may have before fvals is needed
 hipError_t launch_scan_query(int M, int nq, const QueryKernelArgs& args, hipStream_t stream,
                              const void* inline_payload = nullptr, size_t inline_bytes = 0);

@@ -1108,7 +1108,7 @@ __device__ __forceinline__ void scan_query_body(const QueryKernelArgs& A) {
     } else {
         prefetch_fb();
         prefetch_cf();
-        if (HEAD && A.front_in) {                                // the front ran on another rank: its verdict travels with the tables
+        if (A.front_in) {                                        // the front ran elsewhere (another rank; lone_front_kernel): its verdict travels with the tables
             flags = A.front_in[4 * (size_t)q] & 3u;
             qmin = __uint_as_float(A.front_in[4 * (size_t)q + 1]);
             qmax = __uint_as_float(A.front_in[4 * (size_t)q + 2]);
@@ -1795,9 +1795,206 @@ __global__ __launch_bounds__(kQWG, OCC) void scan_query_inline_kernel(QueryKerne
         const unsigned char* ka = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(QueryKernelInline, payload);
         A.assign = reinterpret_cast<const int32_t*>(ka);
         A.parts = reinterpret_cast<const PartDesc*>(ka + A.inline_off_parts);
-        A.ftables = reinterpret_cast<float*>(const_cast<unsigned char*>(ka) + A.inline_off_tables);
+        A.ftables = A.inline_off_tables ? reinterpret_cast<float*>(const_cast<unsigned char*>(ka) + A.inline_off_tables)
+                                        : nullptr;               // (no tables in the payload: the front ran in lone_front_kernel)
     }
     scan_query_body<M, U, OCC, NT, true, false>(A);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The sliced front of a lone query on a long flat list (qadc_kernels.h: LoneFrontArgs).
+// The k-th smallest (k >= 1) of the n >= k u32 keys in LDS, exactly, by the 1024 threads of the workgroup: histogram passes over a
+// digit fitted to the range the answer still lies in ((key - lo) >> sh, 256 buckets) until the bucket holding rank k has at most 256
+// keys, which are then ranked by counting (a 63 us first version sorted the keys: ~130 barrier steps of a bitonic network).
+// w: 256 + 16 words of LDS scratch.
+__device__ __forceinline__ uint32_t lf_select(const uint32_t* keys, uint32_t n, uint32_t k, uint32_t* w, uint32_t tid) {
+    uint32_t* hist = w;                                          // [256]
+    uint32_t& s_lo = w[256];
+    uint32_t& s_hi = w[257];
+    uint32_t& s_k = w[258];
+    uint32_t& s_cnt = w[259];
+    uint32_t& s_sel = w[260];
+    const uint32_t lane = tid & 63u;
+    if (tid == 0) { s_lo = 0xffffffffu; s_hi = 0; s_k = k; }
+    q_lds_barrier();
+    {
+        uint32_t mn = 0xffffffffu, mx = 0;
+        for (uint32_t i = tid; i < n; i += kQWG) { mn = min(mn, keys[i]); mx = max(mx, keys[i]); }
+        mn = q_wave_scan_bits(mn, 0xffffffffu, [](uint32_t a, uint32_t b) { return min(a, b); });
+        mx = q_wave_scan_bits(mx, 0u, [](uint32_t a, uint32_t b) { return max(a, b); });
+        if (lane == 63) { atomicMin(&s_lo, mn); atomicMax(&s_hi, mx); }
+    }
+    for (;;) {
+        if (tid < 256) hist[tid] = 0;
+        q_lds_barrier();
+        const uint32_t lo = s_lo, hi = s_hi, kk = s_k;
+        if (lo == hi) return lo;                                 // (every key left is the same)
+        const uint32_t range = hi - lo;
+        const uint32_t sh = range >= 256u ? 24u - (uint32_t)__builtin_clz(range) : 0u;
+        for (uint32_t i = tid; i < n; i += kQWG) {
+            const uint32_t key = keys[i];
+            if (key >= lo && key <= hi) atomicAdd(&hist[(key - lo) >> sh], 1u);
+        }
+        q_lds_barrier();
+        if (tid < 64) {                                          // wave 0: 4 buckets per lane, the one holding rank kk
+            const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const uint32_t sum4 = c0 + c1 + c2 + c3;
+            const uint32_t incl = q_wave_incl_sum(sum4);
+            const uint32_t excl = incl - sum4;
+            if (incl >= kk && excl < kk) {
+                uint32_t run = excl, digit = 4 * tid;
+                const uint32_t cs4[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (run + cs4[j] >= kk) { digit = 4 * tid + j; break; }
+                    run += cs4[j];
+                }
+                const uint32_t top = (digit << sh) + ((1u << sh) - 1u);   // (offset of the bucket's last key; compared before it is added: no wrap)
+                s_lo = lo + (digit << sh);
+                s_hi = top >= range ? hi : lo + top;
+                s_k = kk - run;
+                s_cnt = hist[digit];
+            }
+            if (tid == 0) s_sel = 0;
+        }
+        q_lds_barrier();
+        if (s_cnt <= 256u) break;
+    }
+    const uint32_t lo = s_lo, hi = s_hi, kk = s_k;
+    q_lds_barrier();
+    for (uint32_t i = tid; i < n; i += kQWG) {
+        const uint32_t key = keys[i];
+        if (key >= lo && key <= hi) hist[atomicAdd(&s_sel, 1u)] = key;
+    }
+    q_lds_barrier();
+    const uint32_t c = s_sel;
+    if (tid < c) {
+        const uint32_t key = hist[tid];
+        const uint4* h4 = reinterpret_cast<const uint4*>(hist);
+        uint32_t less = 0, le = 0, j = 0;
+        for (; j + 4 <= c; j += 4) {                             // (four keys per LDS read)
+            const uint4 kq = h4[j >> 2];
+            less += (kq.x < key ? 1u : 0u) + (kq.y < key ? 1u : 0u) + (kq.z < key ? 1u : 0u) + (kq.w < key ? 1u : 0u);
+            le += (kq.x <= key ? 1u : 0u) + (kq.y <= key ? 1u : 0u) + (kq.z <= key ? 1u : 0u) + (kq.w <= key ? 1u : 0u);
+        }
+        for (; j < c; ++j) {
+            const uint32_t kj = hist[j];
+            less += kj < key ? 1u : 0u;
+            le += kj <= key ? 1u : 0u;
+        }
+        if (less < kk && kk <= le) s_lo = key;
+    }
+    q_lds_barrier();
+    return s_lo;
+}
+
+template <int M>
+__global__ __launch_bounds__(kQWG, 2) void lone_front_kernel(LoneFrontArgs A) {
+    constexpr int CS = M / 2, DW = M / 8;
+    float* tab = reinterpret_cast<float*>(qsmem);                       // [M*16] at LDS address 0 (q_prescan_sum wants it absolute)
+    uint32_t* keys = reinterpret_cast<uint32_t*>(qsmem + M * 16 * 4);   // [kLoneFrontMaxKeys]
+    uint32_t& s_last = keys[kLoneFrontMaxKeys];                         // (no static LDS in this file: the tables start at address 0)
+    float* s_red = reinterpret_cast<float*>(keys + kLoneFrontMaxKeys + 16);   // [16]
+    uint32_t* scr = keys + kLoneFrontMaxKeys + 32;                      // [272] lf_select's scratch
+    if (reinterpret_cast<uintptr_t>((q_lds_bytes_t)qsmem) != 0) __builtin_trap();
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, s = blockIdx.x;
+    const float* kt = reinterpret_cast<const float*>((const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LoneFrontArgs, table));
+    if (tid < M * 16) tab[tid] = kt[tid];
+    const PartDesc d = *A.part;
+    const uint32_t sn = q_uni(d.global_n) ? q_uni(d.start_n) : 0u;
+    const uint8_t* sc = reinterpret_cast<const uint8_t*>(q_uni64(reinterpret_cast<uint64_t>(d.starts ? d.starts : d.codes)));
+    const uint32_t lo = min(sn, s * (uint32_t)kLoneFrontSlice), hi = min(sn, lo + (uint32_t)kLoneFrontSlice);
+    for (uint32_t i = tid; i < (uint32_t)kLoneFrontSlice; i += kQWG) keys[i] = 0xffffffffu;
+    q_lds_barrier();
+    {   // the slice's float ADC: kLoneFrontSlice / 1024 = 4 codes per lane, all loads first
+        constexpr int kPer = kLoneFrontSlice / kQWG;
+        uint32_t dw[kPer][DW];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t i = lo + tid + (uint32_t)u * kQWG;
+#pragma unroll
+            for (int w = 0; w < DW; ++w) dw[u][w] = 0;
+            if (i < hi) {
+                if constexpr (M == 16) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 v = ((const __attribute__((address_space(1))) u32x2*)(uintptr_t)sc)[i];
+                    dw[u][0] = v.x; dw[u][1] = v.y;
+                } else {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v = ((const __attribute__((address_space(1))) u32x4*)(uintptr_t)sc)[i];
+                    dw[u][0] = v.x; dw[u][1] = v.y; dw[u][2] = v.z; dw[u][3] = v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t i = lo + tid + (uint32_t)u * kQWG;
+            const float cand = q_prescan_sum<M>(dw[u], 0u, A.sum_mode);
+            if (i < hi) keys[i - lo] = q_fkey(cand);
+        }
+        (void)CS;
+    }
+    q_lds_barrier();
+    // the slice's R smallest keys (any R of them under ties; padded with ~0 when the slice has fewer values): everything below the
+    // slice's R-th smallest, then copies of it
+    uint32_t* out = A.state + 4 + (size_t)s * A.R;
+    const uint32_t nsl = hi - lo;
+    if (nsl <= A.R) {
+        for (uint32_t i = tid; i < A.R; i += kQWG) out[i] = i < nsl ? keys[i] : 0xffffffffu;
+    } else {
+        const uint32_t T = lf_select(keys, nsl, A.R, scr, tid);
+        uint32_t& s_below = scr[261];
+        if (tid == 0) s_below = 0;
+        q_lds_barrier();
+        for (uint32_t i = tid; i < nsl; i += kQWG)
+            if (keys[i] < T) out[atomicAdd(&s_below, 1u)] = keys[i];
+        q_lds_barrier();
+        for (uint32_t i = s_below + tid; i < A.R; i += kQWG) out[i] = T;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        s_last = atomicAdd(A.state, 1u) == A.S - 1u ? 1u : 0u;
+        if (s_last) __threadfence();
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last workgroup: R-th smallest of the union, qmin / clamp / QuantizerMAX ----
+    const uint32_t nk = A.S * A.R;
+    for (uint32_t i = tid; i < nk; i += kQWG) keys[i] = A.state[4 + i];
+    q_lds_barrier();
+    float qmax = FLT_MAX;                                        // (fewer starts than R: the reference's exit path)
+    if (sn >= A.R) qmax = q_funkey(lf_select(keys, nk, A.R, scr, tid));
+    float lmin = FLT_MAX;
+    for (uint32_t i = tid; i < (uint32_t)(M * 16); i += kQWG) lmin = fminf(lmin, tab[i]);
+    lmin = q_wave_min(lmin);
+    if (lane == 0) s_red[wave] = lmin;
+    __syncthreads();
+    float qmin = s_red[0];
+#pragma unroll
+    for (int w = 1; w < kQWaves; ++w) qmin = fminf(qmin, s_red[w]);
+    uint32_t flags = 0;
+    if (qmin < 0) { qmin = 0; flags |= 2u; }
+    if ((double)qmax > 1e30) flags |= 1u;
+    const float delta = (qmax - qmin) / 127;
+    const float scale = 127.0f / (qmax - qmin);
+    for (uint32_t i = tid; i < (uint32_t)(M * 16); i += kQWG) {
+        float v = tab[i];
+        if (v < 0) v = 0;
+        int8_t o;
+        if (flags & 1u) o = 127;
+        else if (v >= qmax) o = 127;
+        else o = (int8_t)(int)(A.quant_mode == 0 ? (v - qmin) / delta : (v - qmin) * scale);
+        A.qtables[i] = o;
+    }
+    if (tid == 0) {
+        A.front_out[0] = flags;
+        A.front_out[1] = __float_as_uint(qmin);
+        A.front_out[2] = __float_as_uint(qmax);
+        A.front_out[3] = 0;
+        __hip_atomic_store(A.state, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2585,6 +2782,14 @@ hipError_t launch_scan_query(int M, int nq, const QueryKernelArgs& args, hipStre
                              size_t inline_bytes) {
     if (M == 16) return launch_scan_query_v<16, 2, QCfg<16>::OCC>(nq, args, stream, inline_payload, inline_bytes);
     return launch_scan_query_v<32, 2, QCfg<32>::OCC>(nq, args, stream, inline_payload, inline_bytes);
+}
+
+hipError_t launch_lone_front(int M, const LoneFrontArgs& args, hipStream_t stream) {
+    if (args.S < 1 || args.S * args.R > (uint32_t)kLoneFrontMaxKeys || args.R > (uint32_t)kLoneFrontSlice) return hipErrorInvalidValue;
+    const size_t lds = (size_t)M * 16 * 4 + (size_t)kLoneFrontMaxKeys * 4 + 128 + 272 * 4;
+    if (M == 16) hipLaunchKernelGGL(lone_front_kernel<16>, dim3(args.S), dim3(kQWG), lds, stream, args);
+    else hipLaunchKernelGGL(lone_front_kernel<32>, dim3(args.S), dim3(kQWG), lds, stream, args);
+    return hipGetLastError();
 }
 
 void launch_ivf_plan(const int32_t* d_assign, const PartDesc* d_parts, int nq, int ma, int s0, int K, uint32_t* d_cnt,

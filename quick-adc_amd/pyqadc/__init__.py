@@ -52,7 +52,8 @@ class Profile(C.Structure):
                 ("group_head_ms", C.c_double), ("group_scan_ms", C.c_double), ("group_order_ms", C.c_double),
                 ("group_head_codes", C.c_uint64), ("group_pairs", C.c_uint64), ("group_seats", C.c_uint64),
                 ("group_pass_codes8", C.c_uint64), ("group_pass_codes4", C.c_uint64), ("group_batches", C.c_uint64),
-                ("front_sharded_batches", C.c_uint64), ("dist_async_collects", C.c_uint64)]
+                ("front_sharded_batches", C.c_uint64), ("dist_async_collects", C.c_uint64),
+                ("lone_front_launches", C.c_uint64)]
 
 
 class QadcError(RuntimeError):

@@ -147,3 +147,41 @@ def test_lone_query_on_a_long_flat_list(pyqadc, po):
         tb = float_tables(rng, nq, 1, M)
         check(idx, po, M, parts, labels, 0.01, np.zeros((nq, 1), np.int32), tb, 100)
     idx.close()
+
+
+@path_independent
+@pytest.mark.parametrize("M", [16, 32])
+def test_sliced_front_of_a_lone_query(pyqadc, po, M):
+    """One query, one long partition: the front runs in a launch of its own, sliced over workgroups (lone_front_kernel: every slice's
+    R smallest pre-scan values, the last workgroup takes the R-th smallest of their union, qmin / clamp / QuantizerMAX), and the walk
+    launch behind it takes the int8 table and {flags, qmin, qmax} from it.  qmax, qmin, the int8 table, the clamp of the caller's
+    tables and the heap against the oracle; R from 1 up to where S x R outgrows the last workgroup's budget (the walk's own front
+    then); slices that end ragged; tie-heavy and partly negative tables; fewer starts than R is the reference's exit path."""
+    rng = np.random.default_rng(900 + M)
+    for n, keep in ((1000003, 0.01), (300000, 0.05), (2500000, 0.0041), (900000, 0.3)):
+        parts = [rand_codes(rng, n, M)]
+        idx = pyqadc.Index(M)
+        idx.add_partitions(parts, labels=None)
+        idx.finalize(keep)
+        idx.set_option("wgq", 1)
+        a = np.zeros((1, 1), np.int32)
+        for R, kind in ((100, "plain"), (1, "plain"), (100, "ties"), (257, "negative"), (1000, "plain"), (4000, "plain")):
+            tb = float_tables(rng, 1, 1, M, scale=0.5)
+            if kind == "ties":
+                tb = np.round(tb * 2) / 2
+            if kind == "negative":
+                tb = np.where(rng.random(tb.shape) < 0.02, -np.float32(0.05) * tb, tb).astype(np.float32)
+            t_in = tb.copy()
+            res = idx.query_scan(a, t_in, R, want_qtables=True)
+            want = po.query_scan(M, parts, None, keep, a[0], tb[0].copy(), R)
+            if want["rc"] != 0:
+                assert res["status"][0] == 1, (n, keep, R, kind)
+                continue
+            assert res["status"][0] == 0, (n, keep, R, kind)
+            assert res["qmax"][0] == want["qmax"] and res["qmin"][0] == want["qmin"], (n, keep, R, kind)
+            assert np.array_equal(res["qtables"][0].reshape(-1), want["qtables"].reshape(-1)), (n, keep, R, kind)
+            assert np.array_equal(t_in, np.where(tb < 0, np.float32(0), tb)), (n, keep, R, kind)      # clamped in place like the reference
+            assert heaps_equal(res["heaps"][0], (want["keys"], want["values"])), (n, keep, R, kind)
+        sliced = idx.profile()["lone_front_launches"]
+        idx.close()
+        assert (sliced >= 3) == (keep < 0.3), (n, keep, sliced)      # (keep = 0.3 on 9 x 10^5 codes: 66 slices, one too many — the walk's own front)
