@@ -28,7 +28,8 @@ ONE JSON line, several legs (SURVEY.md §8d keeps the two scan modes apart):
   1024-query pipelined batches through the device-side feeders).
 * `ivf_c5_one_gpu`: the same leg at BASELINE configs[4]'s shape on one GPU (1B x 32x4 codes, K=16384, 96-d, nprobe 64).
 * `c2` / `roofline_c2`: BASELINE configs[1] (flat 10M x 16x4), both modes: 32-query steps and one query per pass.
-* `latency_us_single_query`: synchronous single query on a 10^5-code list (README.md:327-330: 86 us).
+* `latency_us_single_query`: synchronous single query on a 10^5-code list (README.md:327-330: 86 us);
+  `c2.one_query_synchronous`: the same on BASELINE configs[1]'s 10^7-code list.
 * `recall_at_100_real_encode` (flat, 10M) / `recall_at_100_real_encode_ivf` (K = 4096, nprobe 32): recall on REAL encodings against the
   exact float L2 nearest neighbour, with `reference_heaps_equal` (the reference's scan_avx_4 on the same codes and int8 tables).
 * `cpu_baseline`: the reference's own scan_avx_4<16> (oracle/_ref), 1 thread; `cpu_baseline_all_cores`:
@@ -673,6 +674,9 @@ def c2_leg(local_rank):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     cs = M // 2
+    # ---- ONE synchronous query per call, nothing else in flight: what nns_engine issues on this configuration (query_common.hpp:
+    # 278-307) — call to return: the front sliced over workgroups in a launch of its own, then one walk launch of 32 workgroups ----
+    sync_ts, _, _ = sync_query_us(idx, np.zeros((1, 1), np.int32), pool[0][:1].copy(), 150)
     idx.set_option("profile", 1)
     # ---- the metric's mode in the headline's FORM: 32-query steps, every query walks the 80 MB list by itself (one C call per
     # step, 32 independent runs per bound-level launch, no sibling launch, no multi-query pass), three steps in flight ----
@@ -714,7 +718,12 @@ def c2_leg(local_rank):
             "one_query_per_call": {"codes_per_sec": float(N) * nsingle / sdt, "ms_per_query": sdt * 1e3 / nsingle, "queries": nsingle,
                                    "in_flight": depth1,
                                    "mode": "sequential single-query calls (a dependent chain of ~10 short launches each: launch latency bound)",
-                                   "streaming_launch_avg_ms": sprof["scan_ms"] / max(sprof["scan_launches"], 1)}}, roof
+                                   "streaming_launch_avg_ms": sprof["scan_ms"] / max(sprof["scan_launches"], 1)},
+            "one_query_synchronous": {"us_per_call": float(np.median(sync_ts)), "p10": float(sync_ts[len(sync_ts) // 10]),
+                                      "p90": float(sync_ts[len(sync_ts) * 9 // 10]), "calls": int(len(sync_ts)),
+                                      "mode": "ONE synchronous qadc_query_scan per call, call to return, nothing else in flight (the "
+                                              "reference's per-query loop on this configuration); one thread of the reference's scan_avx_4 "
+                                              "needs codes / cpu_baseline.value for the scan alone"}}, roof
 
 
 def real_encode_recall_ivf(local_rank):
@@ -802,6 +811,32 @@ def real_encode_recall_ivf(local_rank):
     return out
 
 
+def sync_query_us(idx, a, tb, reps, warm=20):
+    """Sorted call-to-return times (us) of `reps` synchronous qadc_query_scan calls of ONE query (assign a [1][ma], float tables
+    tb), the C-ABI call as a C/C++ caller makes it: caller-owned output buffers, no per-call allocation on the Python side, a fresh
+    copy of the float tables per call (the call may clamp them in place).  Also returns the last call's (keys, values)."""
+    import pyqadc
+    keys, vals = np.zeros((1, R), np.uint32), np.zeros((1, R), np.int8)
+    sizes, status = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    qmin, qmax = np.zeros(1, np.float32), np.zeros(1, np.float32)
+    P = pyqadc._p
+    fixed = (P(keys, pyqadc.u32p), P(vals, pyqadc.i8p), P(sizes, pyqadc.i32p), P(status, pyqadc.i32p),
+             P(qmin, pyqadc.f32p), P(qmax, pyqadc.f32p), None)
+    pa = P(a, pyqadc.i32p)
+    fn, h = pyqadc.lib().qadc_query_scan, idx._h
+    copies = [tb.copy() for _ in range(reps + warm)]
+    ptrs = [P(t, pyqadc.f32p) for t in copies]
+    ts = []
+    for i in range(reps + warm):
+        t0 = time.perf_counter()
+        rc = fn(h, 1, a.shape[1], pa, ptrs[i], R, *fixed)
+        t1 = time.perf_counter()
+        assert rc == 0 and status[0] == 0 and sizes[0] == R
+        if i >= warm:
+            ts.append(t1 - t0)
+    return np.sort(np.array(ts)) * 1e6, keys, vals
+
+
 def latency_leg(local_rank):
     """Synchronous single query (nq = 1) on a 10^5-code flat list: the reference's only published Quick-ADC point is
     86 us of scan time on ~93 750 probed codes, one CPU thread (README.md:327-330)."""
@@ -816,28 +851,10 @@ def latency_leg(local_rank):
     a = np.zeros((1, 1), np.int32)
     for _ in range(20):
         idx.query_scan(a, tb.copy(), R)
-    # the C-ABI call as a C/C++ caller makes it: caller-owned output buffers, no per-call allocation on the Python
-    # side (pyqadc.Index.query_scan allocates six arrays and builds Python tuples per call: ~7 us of interpreter time
-    # that is not the library's); the float tables are a fresh copy per call (the call may clamp them in place)
-    import ctypes as C
-    keys, vals = np.zeros((1, R), np.uint32), np.zeros((1, R), np.int8)
-    sizes, status = np.zeros(1, np.int32), np.zeros(1, np.int32)
-    qmin, qmax = np.zeros(1, np.float32), np.zeros(1, np.float32)
-    P = pyqadc._p
-    fixed = (P(keys, pyqadc.u32p), P(vals, pyqadc.i8p), P(sizes, pyqadc.i32p), P(status, pyqadc.i32p),
-             P(qmin, pyqadc.f32p), P(qmax, pyqadc.f32p), None)
-    pa = P(a, pyqadc.i32p)
-    fn, h = pyqadc.lib().qadc_query_scan, idx._h
-    copies = [tb.copy() for _ in range(220)]
-    ptrs = [P(t, pyqadc.f32p) for t in copies]
-    ts, ts_py = [], []
-    for i in range(220):
-        t0 = time.perf_counter()
-        rc = fn(h, 1, 1, pa, ptrs[i], R, *fixed)
-        t1 = time.perf_counter()
-        assert rc == 0 and status[0] == 0 and sizes[0] == R
-        if i >= 20:
-            ts.append(t1 - t0)
+    # the C-ABI call as a C/C++ caller makes it (sync_query_us; pyqadc.Index.query_scan allocates six arrays and builds Python
+    # tuples per call: ~7 us of interpreter time that is not the library's)
+    ts, keys, vals = sync_query_us(idx, a, tb, 200)
+    ts_py = []
     want = idx.query_scan(a, tb.copy(), R)                      # same answer as the allocating wrapper
     assert np.array_equal(want["keys"], keys) and np.array_equal(want["values"], vals)
     for _ in range(100):
@@ -846,7 +863,6 @@ def latency_leg(local_rank):
         idx.query_scan(a, t, R)
         ts_py.append(time.perf_counter() - t0)
     idx.close()
-    ts = np.sort(np.array(ts)) * 1e6
     return {"value": float(np.median(ts)), "p10": float(ts[len(ts) // 10]), "p90": float(ts[len(ts) * 9 // 10]),
             "unit": "us", "codes": n, "through_allocating_python_wrapper": float(np.median(ts_py) * 1e6),
             "note": "synchronous qadc_query_scan (C-ABI, caller-owned buffers, called through ctypes), nq=1, R=100, "
