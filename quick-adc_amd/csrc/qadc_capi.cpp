@@ -1541,6 +1541,7 @@ int qadc_index_set_key_base(qadc_index* idx, int part, uint32_t key_base) {
         if (int rc = use_device(idx)) return rc;
         HIPCHECK(hipMemcpy(reinterpret_cast<unsigned char*>(idx->d_partdesc.p + part) + offsetof(PartDesc, key_base), &key_base,
                            sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHECK(hipDeviceSynchronize());                        // (as in qadc_index_finalize)
     }
     return QADC_OK;
 }
@@ -1588,6 +1589,9 @@ int qadc_index_finalize(qadc_index* idx, float keep) {
     }
     HIPCHECK(idx->d_partdesc.ensure(pd.size()));
     HIPCHECK(hipMemcpy(idx->d_partdesc.p, pd.data(), pd.size() * sizeof(PartDesc), hipMemcpyHostToDevice));
+    // (the query kernels run on non-blocking streams, which do not wait for the null stream this copy from pageable memory is issued
+    // on; whatever the runtime's staging does, nothing of the table is in flight when the first query is launched)
+    HIPCHECK(hipDeviceSynchronize());
     idx->finalized = true;
     return QADC_OK;
 }

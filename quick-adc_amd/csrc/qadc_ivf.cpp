@@ -385,7 +385,10 @@ int launch_wgq_batch(qadc_index* idx, Slot& s) {
             const size_t words = 4 + (size_t)kLoneFrontMaxKeys;
             if (words > s.d_lfstate.cap) {
                 HIPCHECK(s.d_lfstate.ensure(words));
-                HIPCHECK(hipMemset(s.d_lfstate.p, 0, words * sizeof(uint32_t)));   // (the counter: every front leaves it at zero again)
+                // (the counter: every front leaves it at zero again.  On the launches' own stream: a plain hipMemset runs on the null
+                // stream, which these non-blocking streams do not wait for — the first front of an index then raced it about once in
+                // 5000 fresh indexes: no workgroup counted itself last, and the walk read whatever lay in front_out)
+                HIPCHECK(hipMemsetAsync(s.d_lfstate.p, 0, words * sizeof(uint32_t), st));
             }
             HIPCHECK(s.d_front_all.ensure(4));
             LoneFrontArgs F{};
@@ -593,6 +596,7 @@ int qadc_index_set_pq(qadc_index* idx, int dim, const float* codebooks) {
     const size_t n = (size_t)idx->M * 16 * (dim / idx->M);
     HIPCHECK(idx->feed.d_codebooks.ensure(n));
     HIPCHECK(hipMemcpy(idx->feed.d_codebooks.p, codebooks, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(hipDeviceSynchronize());                            // (setup copy from pageable memory: nothing in flight when the first batch's kernels start on their non-blocking streams)
     idx->feed.dim = dim;
     return QADC_OK;
 }
@@ -608,6 +612,7 @@ int qadc_index_set_rotation(qadc_index* idx, const float* rotation) {
     const size_t n = (size_t)idx->feed.dim * idx->feed.dim;
     HIPCHECK(idx->feed.d_rotation.ensure(n));
     HIPCHECK(hipMemcpy(idx->feed.d_rotation.p, rotation, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(hipDeviceSynchronize());                            // (setup copy from pageable memory: nothing in flight when the first batch's kernels start on their non-blocking streams)
     idx->feed.has_rotation = true;
     return QADC_OK;
 }
@@ -618,6 +623,7 @@ int qadc_index_set_coarse(qadc_index* idx, int K, const float* centroids) {
     if (int rc = use_device(idx)) return rc;
     HIPCHECK(idx->feed.d_coarse.ensure((size_t)K * idx->feed.dim));
     HIPCHECK(hipMemcpy(idx->feed.d_coarse.p, centroids, (size_t)K * idx->feed.dim * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(hipDeviceSynchronize());                            // (setup copy from pageable memory: nothing in flight when the first batch's kernels start on their non-blocking streams)
     idx->feed.K = K;
     idx->feed.cnorm_mode = -1;
     return QADC_OK;

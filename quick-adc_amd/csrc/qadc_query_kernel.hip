@@ -1937,19 +1937,23 @@ __global__ __launch_bounds__(kQWG, 2) void lone_front_kernel(LoneFrontArgs A) {
     q_lds_barrier();
     // the slice's R smallest keys (any R of them under ties; padded with ~0 when the slice has fewer values): everything below the
     // slice's R-th smallest, then copies of it
+    // (device-scope stores, and device-scope loads in the last workgroup: the slices' key ranges share cache lines at their seams,
+    // their workgroups sit on different XCDs, and with plain accesses behind the fences the last workgroup read stale words about once
+    // in 6000 queries — a NaN qmax in the soak of tools/soak_lone_long.py)
     uint32_t* out = A.state + 4 + (size_t)s * A.R;
+    auto put = [&](uint32_t i, uint32_t v) { __hip_atomic_store(&out[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const uint32_t nsl = hi - lo;
     if (nsl <= A.R) {
-        for (uint32_t i = tid; i < A.R; i += kQWG) out[i] = i < nsl ? keys[i] : 0xffffffffu;
+        for (uint32_t i = tid; i < A.R; i += kQWG) put(i, i < nsl ? keys[i] : 0xffffffffu);
     } else {
         const uint32_t T = lf_select(keys, nsl, A.R, scr, tid);
         uint32_t& s_below = scr[261];
         if (tid == 0) s_below = 0;
         q_lds_barrier();
         for (uint32_t i = tid; i < nsl; i += kQWG)
-            if (keys[i] < T) out[atomicAdd(&s_below, 1u)] = keys[i];
+            if (keys[i] < T) put(atomicAdd(&s_below, 1u), keys[i]);
         q_lds_barrier();
-        for (uint32_t i = s_below + tid; i < A.R; i += kQWG) out[i] = T;
+        for (uint32_t i = s_below + tid; i < A.R; i += kQWG) put(i, T);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1962,7 +1966,7 @@ __global__ __launch_bounds__(kQWG, 2) void lone_front_kernel(LoneFrontArgs A) {
     if (!s_last) return;
     // ---- the last workgroup: R-th smallest of the union, qmin / clamp / QuantizerMAX ----
     const uint32_t nk = A.S * A.R;
-    for (uint32_t i = tid; i < nk; i += kQWG) keys[i] = A.state[4 + i];
+    for (uint32_t i = tid; i < nk; i += kQWG) keys[i] = __hip_atomic_load(&A.state[4 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     q_lds_barrier();
     float qmax = FLT_MAX;                                        // (fewer starts than R: the reference's exit path)
     if (sn >= A.R) qmax = q_funkey(lf_select(keys, nk, A.R, scr, tid));
